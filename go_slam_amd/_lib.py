@@ -1,0 +1,80 @@
+"""ctypes binding of the C-ABI hot-path library (include/goslam_hip.h).
+
+The library is built in-tree (`go_slam_amd/csrc/libgoslam_hip.so`, see csrc/Makefile and
+`__graft_entry__.build`).  There is NO fallback: if the shared object is missing or a call
+fails, a RuntimeError is raised -- a CPU/PyTorch substitute would silently void every parity
+and performance claim made for this package.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libgoslam_hip.so")
+
+_lib = None
+
+c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/goslam_hip.h one-to-one
+_P = c_void_p
+SIGNATURES = {
+    "gs_version": (ctypes.c_char_p, []),
+    "gs_last_error": (ctypes.c_char_p, []),
+    "gs_corr_index_forward": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
+    "gs_corr_index_backward": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
+    "gs_corr_lookup_pyramid": (c_int, [_P] * 6 + [c_int] * 7 + [_P]),
+    "gs_reproject": (c_int, [_P] * 7 + [c_int] * 3 + [_P]),
+    "gs_projmap": (c_int, [_P] * 7 + [c_int] * 3 + [_P]),
+    "gs_frame_distance": (c_int, [_P] * 6 + [c_int] * 3 + [c_float, _P]),
+    "gs_iproj": (c_int, [_P] * 4 + [c_int] * 3 + [_P]),
+    "gs_depth_filter": (c_int, [_P] * 6 + [c_int] * 4 + [_P]),
+    "gs_ba_workspace_bytes": (c_size_t, [c_int] * 5),
+    "gs_ba": (c_int, [_P] * 9 + [c_int] * 3 + [c_float, c_float] + [c_int] * 6 + [_P, _P, _P, _P, c_size_t, _P]),
+}
+
+
+def build(verbose=False):
+    """Compile libgoslam_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("building libgoslam_hip.so failed:\n" + res.stdout[-4000:])
+    return LIB_PATH
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(go_slam_amd has no CPU fallback)")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError => header/library mismatch, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().gs_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (status {rc}): {msg}")
+
+
+def stream_ptr(device=None):
+    """Raw hipStream_t of torch's current stream on `device` (kernels are enqueued there)."""
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())

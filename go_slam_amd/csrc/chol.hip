@@ -1,0 +1,226 @@
+// Dense fp64 Cholesky solve of the reduced camera system, on the device.
+// Stands in for Eigen::SimplicialLLT on the host (reference: src/lib/droid_kernels.cu:1192-1213):
+//   L = A;  diag(L) += ep + lm * diag(L);  LLT;  x = solve(b);  failure (pivot <= 0) => x = 0.
+//
+// The (6P x 6P) matrix lives in HBM/L2 as a dense row-major fp64 array whose LOWER triangle is
+// valid.  Right-looking blocked factorisation, NB = 32:
+//   chol_panel_kernel   : every workgroup (one wave) re-factors the 32x32 diagonal block in LDS
+//                         (cheaper than a dependent launch) and solves 64 rows of the panel
+//   chol_trail_kernel   : 64x64 tiles of the trailing matrix, A22 -= L21 L21^T, operands in LDS
+//   chol_solve_kernel   : one workgroup, blocked forward + backward substitution, writes fp32 dx
+// 2 launches per panel; 6P = 150 (frontend window) is 5 panels, 6P = 1200 (global BA) 38.
+#include "common.h"
+
+namespace {
+
+constexpr int NB = 32;     // panel width
+constexpr int PR = 64;     // panel rows per workgroup (one wave)
+constexpr int TT = 64;     // trailing tile edge
+constexpr int SB = 64;     // substitution block
+
+__global__ void chol_damp_kernel(double* __restrict__ A, int n, double lm, double ep, int32_t* fail_flag) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) *fail_flag = 0;
+  if (i < n) {
+    const double d = A[(size_t)i * n + i];
+    A[(size_t)i * n + i] = d + (ep + lm * d);
+  }
+}
+
+// Factor the diagonal block [k0,k0+nb) in LDS (all workgroups redundantly) and compute
+// L21 = A21 * L11^-T for this workgroup's PR rows.
+__global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ A, int n, int k0,
+                                                        int32_t* fail_flag) {
+  __shared__ double D[NB][NB + 1];
+  __shared__ int bad;
+  const int lane = threadIdx.x;
+  const int nb = min(NB, n - k0);
+  if (lane == 0) bad = 0;
+  for (int idx = lane; idx < NB * NB; idx += 64) {
+    const int r = idx / NB, c = idx % NB;
+    D[r][c] = (r < nb && c <= r) ? A[(size_t)(k0 + r) * n + (k0 + c)] : 0.0;
+  }
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {
+    const double piv = D[j][j];
+    if (!(piv > 0.0) && piv == piv) {   // pivot <= 0 -> numerical issue (NaN falls through like Eigen)
+      if (lane == 0) bad = 1;
+    }
+    const double dj = sqrt(piv);
+    __syncthreads();
+    if (lane == 0) D[j][j] = dj;
+    for (int i = j + 1 + lane; i < nb; i += 64) D[i][j] = D[i][j] / dj;
+    __syncthreads();
+    // rank-1 update of the remaining lower triangle
+    const int rem = nb - (j + 1);
+    for (int idx = lane; idx < rem * rem; idx += 64) {
+      const int i = j + 1 + idx / rem, c = j + 1 + idx % rem;
+      if (c <= i) D[i][c] -= D[i][j] * D[c][j];
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {
+    for (int idx = lane; idx < NB * NB; idx += 64) {
+      const int r = idx / NB, c = idx % NB;
+      if (r < nb && c <= r) A[(size_t)(k0 + r) * n + (k0 + c)] = D[r][c];
+    }
+    if (lane == 0 && bad) *fail_flag = 1;
+  }
+  // panel rows
+  const int row = k0 + nb + blockIdx.x * PR + lane;
+  if (row < n) {
+    double x[NB];
+    double* Ar = A + (size_t)row * n + k0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) x[c] = (c < nb) ? Ar[c] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      if (c < nb) {
+        double s = x[c];
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+          if (t < c) s -= x[t] * D[c][t];
+        x[c] = s / D[c][c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      if (c < nb) Ar[c] = x[c];
+  }
+}
+
+// A22[r][c] -= sum_k L21[r][k] L21[c][k] over lower tiles of the trailing matrix.
+__global__ __launch_bounds__(256) void chol_trail_kernel(double* __restrict__ A, int n, int k0, int nb) {
+  __shared__ double Lr[TT][NB + 1];
+  __shared__ double Lc[TT][NB + 1];
+  // decode (ti,tj), tj <= ti, from the flat lower-triangular tile index
+  const int t = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+  while (ti * (ti + 1) / 2 > t) --ti;
+  const int tj = t - ti * (ti + 1) / 2;
+  const int s0 = k0 + nb;
+  const int r0 = s0 + ti * TT, c0 = s0 + tj * TT;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < TT * NB; idx += 256) {
+    const int r = idx / NB, k = idx % NB;
+    Lr[r][k] = (r0 + r < n && k < nb) ? A[(size_t)(r0 + r) * n + (k0 + k)] : 0.0;
+    Lc[r][k] = (c0 + r < n && k < nb) ? A[(size_t)(c0 + r) * n + (k0 + k)] : 0.0;
+  }
+  __syncthreads();
+  const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+#pragma unroll 4
+  for (int k = 0; k < NB; ++k) {
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = Lr[tr + i][k]; b[i] = Lc[tc + i][k]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + tr + i;
+    if (r >= n) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + tc + j;
+      if (c <= r) A[(size_t)r * n + c] -= acc[i][j];
+    }
+  }
+}
+
+// Blocked forward (L y = b) and backward (L^T x = y) substitution by one workgroup.
+__global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restrict__ L, double* __restrict__ b,
+                                                         int n, float* __restrict__ dx,
+                                                         int32_t* fail_flag, int32_t* fail_count) {
+  __shared__ double Ld[SB][SB + 1];
+  __shared__ double y[SB];
+  const int tid = threadIdx.x;
+  if (*fail_flag) {   // reference: zero update on failure (droid_kernels.cu:1207-1210)
+    for (int i = tid; i < n; i += 256) dx[i] = 0.0f;
+    if (tid == 0) *fail_count += 1;
+    return;
+  }
+  const int nblk = (n + SB - 1) / SB;
+  // ---- forward
+  for (int kb = 0; kb < nblk; ++kb) {
+    const int k0 = kb * SB, nb = min(SB, n - k0);
+    for (int idx = tid; idx < SB * SB; idx += 256) {
+      const int r = idx / SB, c = idx % SB;
+      Ld[r][c] = (r < nb && c <= r) ? L[(size_t)(k0 + r) * n + (k0 + c)] : 0.0;
+    }
+    if (tid < SB) y[tid] = (tid < nb) ? b[k0 + tid] : 0.0;
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {   // column-oriented, nb <= 64 sequential steps
+      const double yj = y[j] / Ld[j][j];
+      __syncthreads();
+      if (tid == j) y[j] = yj;
+      if (tid > j && tid < nb) y[tid] -= Ld[tid][j] * yj;
+      __syncthreads();
+    }
+    if (tid < nb) b[k0 + tid] = y[tid];
+    // b[r] -= L[r][k0:k0+nb] . y  for rows below the block
+    for (int r = k0 + nb + tid; r < n; r += 256) {
+      const double* Lr = L + (size_t)r * n + k0;
+      double s = 0.0;
+      for (int c = 0; c < nb; ++c) s = fma(Lr[c], y[c], s);
+      b[r] -= s;
+    }
+    __syncthreads();
+  }
+  // ---- backward
+  for (int kb = nblk - 1; kb >= 0; --kb) {
+    const int k0 = kb * SB, nb = min(SB, n - k0);
+    for (int idx = tid; idx < SB * SB; idx += 256) {
+      const int r = idx / SB, c = idx % SB;
+      Ld[r][c] = (r < nb && c <= r) ? L[(size_t)(k0 + r) * n + (k0 + c)] : 0.0;
+    }
+    if (tid < SB) y[tid] = (tid < nb) ? b[k0 + tid] : 0.0;
+    __syncthreads();
+    for (int j = nb - 1; j >= 0; --j) {
+      const double xj = y[j] / Ld[j][j];
+      __syncthreads();
+      if (tid == j) y[j] = xj;
+      if (tid < j) y[tid] -= Ld[j][tid] * xj;
+      __syncthreads();
+    }
+    if (tid < nb) { b[k0 + tid] = y[tid]; dx[k0 + tid] = (float)y[tid]; }
+    // b[c] -= sum_r L[k0+r][c] * x[r]  for columns left of the block
+    for (int c = tid; c < k0; c += 256) {
+      double s = 0.0;
+      for (int r = 0; r < nb; ++r) s = fma(L[(size_t)(k0 + r) * n + c], y[r], s);
+      b[c] -= s;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float* dx_out, int32_t* fail_flag,
+                         int32_t* fail_count, hipStream_t st) {
+  chol_damp_kernel<<<gs_cdiv(n, 256), 256, 0, st>>>(H, n, (double)lm, (double)ep, fail_flag);
+  GS_CHECK_LAUNCH("chol_damp");
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int nb = (n - k0 < NB) ? (n - k0) : NB;
+    const int rem = n - k0 - nb;
+    const int pgrid = rem > 0 ? gs_cdiv(rem, PR) : 1;
+    chol_panel_kernel<<<pgrid, 64, 0, st>>>(H, n, k0, fail_flag);
+    GS_CHECK_LAUNCH("chol_panel");
+    if (rem > 0) {
+      const int T = gs_cdiv(rem, TT);
+      chol_trail_kernel<<<T * (T + 1) / 2, 256, 0, st>>>(H, n, k0, nb);
+      GS_CHECK_LAUNCH("chol_trail");
+    }
+  }
+  chol_solve_kernel<<<1, 256, 0, st>>>(H, b, n, dx_out, fail_flag, fail_count);
+  GS_CHECK_LAUNCH("chol_solve");
+  return GS_OK;
+}

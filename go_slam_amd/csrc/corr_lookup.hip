@@ -1,0 +1,250 @@
+// Correlation-volume window lookup (reference: src/lib/correlation_kernels.cu:19-124 and the
+// 4-level loop of src/modules/corr.py:43-53).
+//
+// One lane owns one source pixel p=(y,x) of one edge: its correlation slice
+// volume[n][y][x][:][:] is private to the lane, so nothing is shared through LDS; the lane
+// streams the 8 rows of its 8x8 window (16 B of fp16 each, one unaligned 128-bit load per
+// row on the interior fast path) and emits the 49 bilinear taps.  Lanes are laid out along
+// the flattened pixel index so every output channel plane is written 128 B per wave.
+// The bilinear blend is carried in the volume's dtype in the reference's order
+// (i outer, j inner, `corr += s * T(w)`), which makes fp16 results bit-identical to the
+// reference's fp16-accumulated values; the file is compiled with -ffp-contract=off.
+#include "common.h"
+
+namespace {
+
+// float -> int with the huge/NaN cases pinned far outside any map (the reference's
+// static_cast<int> saturates; a plain cast could wrap `xs + 8` back into range).
+__device__ __forceinline__ int safe_int(float f) { return (int)fminf(fmaxf(f, -1.0e6f), 1.0e6f); }
+
+template <typename T> struct VecRow;   // 8 consecutive taps of a window row
+template <> struct VecRow<_Float16> { typedef struct __attribute__((packed, aligned(2))) { _Float16 v[8]; } type; };
+template <> struct VecRow<float>    { typedef struct __attribute__((packed, aligned(4))) { float v[8]; } type; };
+template <> struct VecRow<double>   { typedef struct __attribute__((packed, aligned(8))) { double v[8]; } type; };
+
+// Sample one level for one pixel; writes 49 taps to out[(i*7+j)*plane].
+template <typename T>
+__device__ __forceinline__ void lookup_r3(const T* __restrict__ slice, int h2, int w2,
+                                          float x0, float y0, T* __restrict__ out, size_t plane) {
+  const float fx0 = floorf(x0), fy0 = floorf(y0);
+  const float dx = x0 - fx0, dy = y0 - fy0;
+  const int xs = safe_int(fx0) - 3, ys = safe_int(fy0) - 3;
+  const T w_nw = (T)(dx * dy);
+  const T w_ne = (T)(dx * (1.0f - dy));
+  const T w_sw = (T)((1.0f - dx) * dy);
+  const T w_se = (T)((1.0f - dx) * (1.0f - dy));
+
+  T s[8][8];   // s[i][j]: i = x offset, j = y offset
+  const bool xin = (xs >= 0) && (xs + 8 <= w2);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int y1 = ys + j;
+    const bool yin = (y1 >= 0) && (y1 < h2);
+    if (yin && xin) {
+      typename VecRow<T>::type row = *reinterpret_cast<const typename VecRow<T>::type*>(slice + (size_t)y1 * w2 + xs);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i][j] = row.v[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int x1 = xs + i;
+        const bool in = yin && (x1 >= 0) && (x1 < w2);
+        s[i][j] = in ? slice[(size_t)(in ? y1 : 0) * w2 + (in ? x1 : 0)] : (T)0;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      // contributions arrive in loop order (i,j), (i,j+1), (i+1,j), (i+1,j+1)
+      T c = s[i][j] * w_se;
+      c = c + s[i][j + 1] * w_sw;
+      c = c + s[i + 1][j] * w_ne;
+      c = c + s[i + 1][j + 1] * w_nw;
+      out[(size_t)(i * 7 + j) * plane] = c;
+    }
+  }
+}
+
+// ---- fused 4-level pyramid lookup: coords [n,h1,w1,2] -> corr [n,4*49,h1,w1] ------------
+template <typename T>
+__global__ __launch_bounds__(256) void corr_pyramid_kernel(
+    const T* __restrict__ v0, const T* __restrict__ v1, const T* __restrict__ v2, const T* __restrict__ v3,
+    const float* __restrict__ coords, T* __restrict__ corr, int hw1, int h2, int w2) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (p >= hw1) return;
+  const size_t pix = (size_t)n * hw1 + p;
+  const float2 c = reinterpret_cast<const float2*>(coords)[pix];
+  T* out = corr + (size_t)n * 196 * hw1 + p;
+  const T* vols[4] = {v0, v1, v2, v3};
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const int h2l = h2 >> l, w2l = w2 >> l;
+    const float sc = 1.0f / (float)(1 << l);   // coords / 2**l (exact)
+    lookup_r3<T>(vols[l] + pix * (size_t)(h2l * w2l), h2l, w2l, c.x * sc, c.y * sc,
+                 out + (size_t)l * 49 * hw1, (size_t)hw1);
+  }
+}
+
+// ---- single level, reference ABI: coords [n,2,h1,w1] -> corr [n,7,7,h1,w1] ---------------
+template <typename T>
+__global__ __launch_bounds__(256) void corr_index_r3_kernel(
+    const T* __restrict__ vol, const float* __restrict__ coords, T* __restrict__ corr,
+    int hw1, int h2, int w2) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (p >= hw1) return;
+  const float x0 = coords[((size_t)n * 2 + 0) * hw1 + p];
+  const float y0 = coords[((size_t)n * 2 + 1) * hw1 + p];
+  lookup_r3<T>(vol + ((size_t)n * hw1 + p) * (size_t)(h2 * w2), h2, w2, x0, y0,
+               corr + (size_t)n * 49 * hw1 + p, (size_t)hw1);
+}
+
+// ---- generic radius (not used by GO-SLAM, kept for ABI completeness) ---------------------
+template <typename T>
+__global__ __launch_bounds__(256) void corr_index_generic_kernel(
+    const T* __restrict__ vol, const float* __restrict__ coords, T* __restrict__ corr,
+    int hw1, int h2, int w2, int r) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (p >= hw1) return;
+  const int rd = 2 * r + 1;
+  const float x0 = coords[((size_t)n * 2 + 0) * hw1 + p];
+  const float y0 = coords[((size_t)n * 2 + 1) * hw1 + p];
+  const float fx0 = floorf(x0), fy0 = floorf(y0);
+  const float dx = x0 - fx0, dy = y0 - fy0;
+  const T* slice = vol + ((size_t)n * hw1 + p) * (size_t)(h2 * w2);
+  T* out = corr + (size_t)n * rd * rd * hw1 + p;
+  for (int c = 0; c < rd * rd; ++c) out[(size_t)c * hw1] = (T)0;
+  for (int i = 0; i < rd + 1; ++i) {
+    for (int j = 0; j < rd + 1; ++j) {
+      const int x1 = safe_int(fx0) - r + i, y1 = safe_int(fy0) - r + j;
+      if (y1 >= 0 && y1 < h2 && x1 >= 0 && x1 < w2) {
+        const T s = slice[(size_t)y1 * w2 + x1];
+        if (i > 0 && j > 0) { T* o = out + (size_t)((i - 1) * rd + (j - 1)) * hw1; *o = *o + s * (T)(dx * dy); }
+        if (i > 0 && j < rd) { T* o = out + (size_t)((i - 1) * rd + j) * hw1; *o = *o + s * (T)(dx * (1.0f - dy)); }
+        if (i < rd && j > 0) { T* o = out + (size_t)(i * rd + (j - 1)) * hw1; *o = *o + s * (T)((1.0f - dx) * dy); }
+        if (i < rd && j < rd) { T* o = out + (size_t)(i * rd + j) * hw1; *o = *o + s * (T)((1.0f - dx) * (1.0f - dy)); }
+      }
+    }
+  }
+}
+
+// ---- backward wrt the volume (training only in the reference) ----------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void corr_index_backward_kernel(
+    const float* __restrict__ coords, const T* __restrict__ corr_grad, T* __restrict__ vol_grad,
+    int hw1, int h2, int w2, int r) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (p >= hw1) return;
+  const int rd = 2 * r + 1;
+  const float x0 = coords[((size_t)n * 2 + 0) * hw1 + p];
+  const float y0 = coords[((size_t)n * 2 + 1) * hw1 + p];
+  const float fx0 = floorf(x0), fy0 = floorf(y0);
+  const float dx = x0 - fx0, dy = y0 - fy0;
+  T* slice = vol_grad + ((size_t)n * hw1 + p) * (size_t)(h2 * w2);
+  const T* g = corr_grad + (size_t)n * rd * rd * hw1 + p;
+  for (int i = 0; i < rd + 1; ++i) {
+    for (int j = 0; j < rd + 1; ++j) {
+      const int x1 = safe_int(fx0) - r + i, y1 = safe_int(fy0) - r + j;
+      if (y1 >= 0 && y1 < h2 && x1 >= 0 && x1 < w2) {
+        T acc = (T)0;
+        if (i > 0 && j > 0) acc = acc + g[(size_t)((i - 1) * rd + (j - 1)) * hw1] * (T)(dx * dy);
+        if (i > 0 && j < rd) acc = acc + g[(size_t)((i - 1) * rd + j) * hw1] * (T)(dx * (1.0f - dy));
+        if (i < rd && j > 0) acc = acc + g[(size_t)(i * rd + (j - 1)) * hw1] * (T)((1.0f - dx) * dy);
+        if (i < rd && j < rd) acc = acc + g[(size_t)(i * rd + j) * hw1] * (T)((1.0f - dx) * (1.0f - dy));
+        T* o = slice + (size_t)y1 * w2 + x1;
+        *o = *o + acc;
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_index_forward(const void* volume, const float* coords, void* corr, int n, int h1, int w1,
+                         int h2, int w2, int r, hipStream_t st) {
+  const int hw1 = h1 * w1;
+  dim3 grid(gs_cdiv(hw1, 256), n), block(256);
+  if (r == 3)
+    corr_index_r3_kernel<T><<<grid, block, 0, st>>>((const T*)volume, coords, (T*)corr, hw1, h2, w2);
+  else
+    corr_index_generic_kernel<T><<<grid, block, 0, st>>>((const T*)volume, coords, (T*)corr, hw1, h2, w2, r);
+  GS_CHECK_LAUNCH("corr_index_forward");
+  return GS_OK;
+}
+
+template <typename T>
+int launch_index_backward(const float* coords, const void* g, void* vg, int n, int h1, int w1, int h2,
+                          int w2, int r, hipStream_t st) {
+  const int hw1 = h1 * w1;
+  dim3 grid(gs_cdiv(hw1, 256), n), block(256);
+  corr_index_backward_kernel<T><<<grid, block, 0, st>>>(coords, (const T*)g, (T*)vg, hw1, h2, w2, r);
+  GS_CHECK_LAUNCH("corr_index_backward");
+  return GS_OK;
+}
+
+template <typename T>
+int launch_pyramid(const void* v0, const void* v1, const void* v2, const void* v3, const float* coords,
+                   void* corr, int n, int h1, int w1, int h2, int w2, hipStream_t st) {
+  const int hw1 = h1 * w1;
+  dim3 grid(gs_cdiv(hw1, 256), n), block(256);
+  corr_pyramid_kernel<T><<<grid, block, 0, st>>>((const T*)v0, (const T*)v1, (const T*)v2, (const T*)v3,
+                                                 coords, (T*)corr, hw1, h2, w2);
+  GS_CHECK_LAUNCH("corr_lookup_pyramid");
+  return GS_OK;
+}
+
+}  // namespace
+
+extern "C" int gs_corr_index_forward(const void* volume, const float* coords, void* corr, int n, int h1,
+                                     int w1, int h2, int w2, int radius, int dtype, gs_stream_t stream) {
+  GS_REQUIRE(volume && coords && corr, "corr_index_forward: null pointer");
+  GS_REQUIRE(n >= 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0 && radius >= 0, "corr_index_forward: bad shape");
+  if (n == 0) return GS_OK;
+  GS_REQUIRE(n <= 65535, "corr_index_forward: n=%d exceeds grid.y limit", n);
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case GS_F16: return launch_index_forward<_Float16>(volume, coords, corr, n, h1, w1, h2, w2, radius, st);
+    case GS_F32: return launch_index_forward<float>(volume, coords, corr, n, h1, w1, h2, w2, radius, st);
+    case GS_F64: return launch_index_forward<double>(volume, coords, corr, n, h1, w1, h2, w2, radius, st);
+  }
+  gs_set_error("corr_index_forward: unsupported dtype %d", dtype);
+  return GS_ERR_UNSUPPORTED;
+}
+
+extern "C" int gs_corr_index_backward(const float* coords, const void* corr_grad, void* volume_grad, int n,
+                                      int h1, int w1, int h2, int w2, int radius, int dtype,
+                                      gs_stream_t stream) {
+  GS_REQUIRE(coords && corr_grad && volume_grad, "corr_index_backward: null pointer");
+  GS_REQUIRE(n >= 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0 && radius >= 0, "corr_index_backward: bad shape");
+  if (n == 0) return GS_OK;
+  GS_REQUIRE(n <= 65535, "corr_index_backward: n=%d exceeds grid.y limit", n);
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case GS_F16: return launch_index_backward<_Float16>(coords, corr_grad, volume_grad, n, h1, w1, h2, w2, radius, st);
+    case GS_F32: return launch_index_backward<float>(coords, corr_grad, volume_grad, n, h1, w1, h2, w2, radius, st);
+    case GS_F64: return launch_index_backward<double>(coords, corr_grad, volume_grad, n, h1, w1, h2, w2, radius, st);
+  }
+  gs_set_error("corr_index_backward: unsupported dtype %d", dtype);
+  return GS_ERR_UNSUPPORTED;
+}
+
+extern "C" int gs_corr_lookup_pyramid(const void* vol0, const void* vol1, const void* vol2, const void* vol3,
+                                      const float* coords, void* corr, int n, int h1, int w1, int h2, int w2,
+                                      int radius, int dtype, gs_stream_t stream) {
+  GS_REQUIRE(vol0 && vol1 && vol2 && vol3 && coords && corr, "corr_lookup_pyramid: null pointer");
+  GS_REQUIRE(radius == 3, "corr_lookup_pyramid: only radius 3 (the reference's value) is supported");
+  GS_REQUIRE(n >= 0 && h1 > 0 && w1 > 0 && (h2 >> 3) > 0 && (w2 >> 3) > 0, "corr_lookup_pyramid: bad shape");
+  if (n == 0) return GS_OK;
+  GS_REQUIRE(n <= 65535, "corr_lookup_pyramid: n=%d exceeds grid.y limit", n);
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case GS_F16: return launch_pyramid<_Float16>(vol0, vol1, vol2, vol3, coords, corr, n, h1, w1, h2, w2, st);
+    case GS_F32: return launch_pyramid<float>(vol0, vol1, vol2, vol3, coords, corr, n, h1, w1, h2, w2, st);
+  }
+  gs_set_error("corr_lookup_pyramid: unsupported dtype %d", dtype);
+  return GS_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,226 @@
+"""Drop-in for the reference's `droid_backends` extension module
+(reference: src/lib/droid.cpp:237-250 -- same nine names, argument order, dtypes, return
+structure and in-place behaviour), implemented on the C-ABI HIP library.
+
+    ba, frame_distance, projmap, depth_filter, iproj,
+    corr_index_forward, corr_index_backward, altcorr_forward, altcorr_backward
+
+Error behaviour mirrors `CHECK_CONTIGUOUS` (droid.cpp:84-85): a non-contiguous tensor raises
+RuntimeError("<name> must be contiguous").  Unlike the reference (legacy default stream) the
+kernels are enqueued on torch's *current* stream of the tensors' device.
+"""
+import torch
+
+from . import _lib
+
+_DT = {torch.float16: 0, torch.float32: 1, torch.float64: 2}
+
+_ws_cache = {}
+
+
+def _chk(name, t, dtype=None):
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor (go_slam_amd has no CPU path)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    return t
+
+
+def _workspace(device, nbytes):
+    """Per-(device, stream) grow-only scratch buffer; gs_* calls never allocate."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
+       t0, t1, iterations, lm, ep, motion_only):
+    """droid.cpp:88-117.  Mutates `poses`/`disps`; returns [dx, dz] (dz None if motion_only)."""
+    _chk("targets", targets, torch.float32)
+    _chk("weights", weights, torch.float32)
+    _chk("poses", poses, torch.float32)
+    _chk("disps", disps, torch.float32)
+    _chk("intrinsics", intrinsics, torch.float32)
+    _chk("disps_sens", disps_sens, torch.float32)
+    _chk("ii", ii, torch.int64)
+    _chk("jj", jj, torch.int64)
+    if not eta.is_contiguous():       # the reference does not check eta; it views it (-1, ht*wd)
+        eta = eta.contiguous()
+    dev = poses.device
+    nbuf, ht, wd = disps.shape
+    E = ii.shape[0]
+    P = int(t1) - int(t0)
+    hw = ht * wd
+    M = eta.reshape(-1, hw).shape[0]
+    L = _lib.lib()
+    need = L.gs_ba_workspace_bytes(E, P, M, nbuf, hw)
+    ws = _workspace(dev, need + 256)
+    dx = torch.empty(P, 6, dtype=torch.float32, device=dev)
+    dz = None if motion_only else torch.empty(M, hw, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.gs_ba(_lib.ptr(poses), _lib.ptr(disps), _lib.ptr(intrinsics), _lib.ptr(disps_sens),
+                     _lib.ptr(targets), _lib.ptr(weights), _lib.ptr(eta), _lib.ptr(ii), _lib.ptr(jj),
+                     int(t0), int(t1), int(iterations), float(lm), float(ep), int(bool(motion_only)),
+                     E, M, nbuf, ht, wd, _lib.ptr(dx), _lib.ptr(dz), None,
+                     _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "droid_backends.ba")
+    return [dx, dz]
+
+
+def frame_distance(poses, disps, intrinsics, ii, jj, beta):
+    """droid.cpp:120-131."""
+    _chk("poses", poses, torch.float32)
+    _chk("disps", disps, torch.float32)
+    _chk("intrinsics", intrinsics, torch.float32)
+    _chk("ii", ii, torch.int64)
+    _chk("jj", jj, torch.int64)
+    n = ii.shape[0]
+    _, ht, wd = disps.shape
+    dist = torch.empty(n, dtype=torch.float32, device=poses.device)
+    with torch.cuda.device(poses.device):
+        rc = _lib.lib().gs_frame_distance(_lib.ptr(poses), _lib.ptr(disps), _lib.ptr(intrinsics), _lib.ptr(ii),
+                                          _lib.ptr(jj), _lib.ptr(dist), n, ht, wd, float(beta),
+                                          _lib.stream_ptr(poses.device))
+    _lib.check(rc, "droid_backends.frame_distance")
+    return dist
+
+
+def projmap(poses, disps, intrinsics, ii, jj):
+    """droid.cpp:133-140 -> [coords [n,h,w,3], valid [n,h,w,1]]."""
+    _chk("poses", poses, torch.float32)
+    _chk("disps", disps, torch.float32)
+    _chk("intrinsics", intrinsics, torch.float32)
+    _chk("ii", ii, torch.int64)
+    _chk("jj", jj, torch.int64)
+    n = ii.shape[0]
+    _, ht, wd = disps.shape
+    coords = torch.empty(n, ht, wd, 3, dtype=torch.float32, device=poses.device)
+    valid = torch.empty(n, ht, wd, 1, dtype=torch.float32, device=poses.device)
+    with torch.cuda.device(poses.device):
+        rc = _lib.lib().gs_projmap(_lib.ptr(poses), _lib.ptr(disps), _lib.ptr(intrinsics), _lib.ptr(ii),
+                                   _lib.ptr(jj), _lib.ptr(coords), _lib.ptr(valid), n, ht, wd,
+                                   _lib.stream_ptr(poses.device))
+    _lib.check(rc, "droid_backends.projmap")
+    return [coords, valid]
+
+
+def depth_filter(poses, disps, intrinsics, ix, thresh):
+    """droid.cpp (depth_filter) -> count [n,h,w]."""
+    _chk("poses", poses, torch.float32)
+    _chk("disps", disps, torch.float32)
+    _chk("intrinsics", intrinsics, torch.float32)
+    _chk("ix", ix, torch.int64)
+    _chk("thresh", thresh, torch.float32)
+    num, ht, wd = disps.shape
+    n = ix.shape[0]
+    counter = torch.empty(n, ht, wd, dtype=torch.float32, device=disps.device)
+    with torch.cuda.device(disps.device):
+        rc = _lib.lib().gs_depth_filter(_lib.ptr(poses), _lib.ptr(disps), _lib.ptr(intrinsics), _lib.ptr(ix),
+                                        _lib.ptr(thresh), _lib.ptr(counter), n, num, ht, wd,
+                                        _lib.stream_ptr(disps.device))
+    _lib.check(rc, "droid_backends.depth_filter")
+    return counter
+
+
+def iproj(poses, disps, intrinsics):
+    """droid.cpp:141-147 -> points [n,h,w,3]."""
+    _chk("poses", poses, torch.float32)
+    _chk("disps", disps, torch.float32)
+    _chk("intrinsics", intrinsics, torch.float32)
+    n, ht, wd = disps.shape
+    points = torch.empty(n, ht, wd, 3, dtype=torch.float32, device=disps.device)
+    with torch.cuda.device(disps.device):
+        rc = _lib.lib().gs_iproj(_lib.ptr(poses), _lib.ptr(disps), _lib.ptr(intrinsics), _lib.ptr(points),
+                                 n, ht, wd, _lib.stream_ptr(disps.device))
+    _lib.check(rc, "droid_backends.iproj")
+    return points
+
+
+def corr_index_forward(volume, coords, radius):
+    """droid.cpp:149-158 -> [corr [n,2r+1,2r+1,h1,w1]] in volume's dtype."""
+    _chk("volume", volume)
+    _chk("coords", coords, torch.float32)
+    if volume.dtype not in _DT:
+        raise RuntimeError(f"corr_index_forward: unsupported dtype {volume.dtype}")
+    n, h1, w1, h2, w2 = volume.shape
+    rd = 2 * radius + 1
+    corr = torch.empty(n, rd, rd, h1, w1, dtype=volume.dtype, device=volume.device)
+    with torch.cuda.device(volume.device):
+        rc = _lib.lib().gs_corr_index_forward(_lib.ptr(volume), _lib.ptr(coords), _lib.ptr(corr), n, h1, w1, h2,
+                                              w2, int(radius), _DT[volume.dtype],
+                                              _lib.stream_ptr(volume.device))
+    _lib.check(rc, "droid_backends.corr_index_forward")
+    return [corr]
+
+
+def corr_index_backward(volume, coords, corr_grad, radius):
+    """droid.cpp:160-171 -> [volume_grad]."""
+    _chk("volume", volume)
+    _chk("coords", coords, torch.float32)
+    _chk("corr_grad", corr_grad, volume.dtype)
+    n, h1, w1, h2, w2 = volume.shape
+    grad = torch.zeros_like(volume)
+    with torch.cuda.device(volume.device):
+        rc = _lib.lib().gs_corr_index_backward(_lib.ptr(coords), _lib.ptr(corr_grad), _lib.ptr(grad), n, h1, w1,
+                                               h2, w2, int(radius), _DT[volume.dtype],
+                                               _lib.stream_ptr(volume.device))
+    _lib.check(rc, "droid_backends.corr_index_backward")
+    return [grad]
+
+
+def corr_lookup_pyramid(pyramid, coords, radius=3):
+    """Fused 4-level form of CorrBlock.__call__ (src/modules/corr.py:43-53): one launch.
+    pyramid: 4 tensors [n,h1,w1,h2>>l,w2>>l]; coords f32 [n,h1,w1,2] -> [n,196,h1,w1]."""
+    assert len(pyramid) == 4
+    for i, v in enumerate(pyramid):
+        _chk(f"pyramid[{i}]", v, pyramid[0].dtype)
+    _chk("coords", coords, torch.float32)
+    n, h1, w1, h2, w2 = pyramid[0].shape
+    for l in range(4):
+        if tuple(pyramid[l].shape) != (n, h1, w1, h2 >> l, w2 >> l):
+            raise RuntimeError(f"pyramid level {l} has shape {tuple(pyramid[l].shape)}")
+    rd = 2 * radius + 1
+    corr = torch.empty(n, 4 * rd * rd, h1, w1, dtype=pyramid[0].dtype, device=coords.device)
+    with torch.cuda.device(coords.device):
+        rc = _lib.lib().gs_corr_lookup_pyramid(_lib.ptr(pyramid[0]), _lib.ptr(pyramid[1]), _lib.ptr(pyramid[2]),
+                                               _lib.ptr(pyramid[3]), _lib.ptr(coords), _lib.ptr(corr), n, h1, w1,
+                                               h2, w2, int(radius), _DT[pyramid[0].dtype],
+                                               _lib.stream_ptr(coords.device))
+    _lib.check(rc, "corr_lookup_pyramid")
+    return corr
+
+
+def reproject(poses, disps, intrinsics, ii, jj):
+    """Fused DepthVideo.reproject (src/depth_video.py:207-217): coords [1,n,h,w,2], valid [1,n,h,w,1]."""
+    _chk("poses", poses, torch.float32)
+    _chk("disps", disps, torch.float32)
+    _chk("intrinsics", intrinsics, torch.float32)
+    _chk("ii", ii, torch.int64)
+    _chk("jj", jj, torch.int64)
+    n = ii.shape[0]
+    _, ht, wd = disps.shape
+    coords = torch.empty(1, n, ht, wd, 2, dtype=torch.float32, device=poses.device)
+    valid = torch.empty(1, n, ht, wd, 1, dtype=torch.float32, device=poses.device)
+    with torch.cuda.device(poses.device):
+        rc = _lib.lib().gs_reproject(_lib.ptr(poses), _lib.ptr(disps), _lib.ptr(intrinsics), _lib.ptr(ii),
+                                     _lib.ptr(jj), _lib.ptr(coords), _lib.ptr(valid), n, ht, wd,
+                                     _lib.stream_ptr(poses.device))
+    _lib.check(rc, "reproject")
+    return coords, valid
+
+
+def altcorr_forward(fmap1, fmap2, coords, radius):
+    """droid.cpp:173-184 -> [corr [B,S,(2r+1)^2,H,W]]."""
+    raise NotImplementedError("altcorr_forward: HIP kernel lands with the global-BA row (SURVEY 8 a3)")
+
+
+def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
+    """droid.cpp (altcorr_backward): training-only in the reference."""
+    raise NotImplementedError("altcorr_backward: training-only path, not built yet")

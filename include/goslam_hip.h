@@ -1,0 +1,124 @@
+/*
+ * goslam_hip.h -- C ABI of the MI355X (gfx950) hot-path library `libgoslam_hip.so`.
+ *
+ * Every entry point replaces one export of the reference's `droid_backends` pybind module
+ * (reference: src/lib/droid.cpp:237-250) or one tiny-cuda-nn call made by
+ * src/InstantNeuS.py; the reference file:line each one stands in for is cited per function.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in `_host`;
+ *   - tensors are dense row-major ("contiguous") with the shapes given in the comments;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); no entry point
+ *     synchronises the device, allocates device memory, or throws;
+ *   - return value: GS_OK (0) or a negative gs_status; gs_last_error() gives a message for
+ *     the calling thread;
+ *   - index tensors are int64 (torch.long) exactly as the reference passes them.
+ */
+#ifndef GOSLAM_HIP_H
+#define GOSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gs_stream_t;
+
+typedef enum {
+  GS_OK = 0,
+  GS_ERR_INVALID_ARG = -1,
+  GS_ERR_WORKSPACE = -2,
+  GS_ERR_LAUNCH = -3,
+  GS_ERR_UNSUPPORTED = -4
+} gs_status;
+
+typedef enum { GS_F16 = 0, GS_F32 = 1, GS_F64 = 2 } gs_dtype;
+
+const char* gs_version(void);
+const char* gs_last_error(void);
+
+/* ------------------------------------------------------------------ correlation ---- */
+
+/* droid_backends.corr_index_forward (src/lib/droid.cpp:149-158, correlation_kernels.cu:19-70,
+ * 126-155).  volume [n,h1,w1,h2,w2] (dtype), coords f32 [n,2,h1,w1] -> corr [n,2r+1,2r+1,h1,w1]
+ * (dtype).  Arithmetic is carried in `dtype` in the reference's accumulation order.        */
+int gs_corr_index_forward(const void* volume, const float* coords, void* corr,
+                          int n, int h1, int w1, int h2, int w2, int radius, int dtype,
+                          gs_stream_t stream);
+
+/* droid_backends.corr_index_backward (droid.cpp:160-171, correlation_kernels.cu:73-124,157-185).
+ * volume_grad [n,h1,w1,h2,w2] must be zero-initialised by the caller.                        */
+int gs_corr_index_backward(const float* coords, const void* corr_grad, void* volume_grad,
+                           int n, int h1, int w1, int h2, int w2, int radius, int dtype,
+                           gs_stream_t stream);
+
+/* CorrBlock.__call__ (src/modules/corr.py:43-53) in ONE launch: the 4 pyramid levels
+ * vol[l] [n,h1,w1,h2>>l,w2>>l] are sampled at coords/2^l (coords f32 [n,h1,w1,2], the layout
+ * FactorGraph hands over) and written as corr [n, 4*(2r+1)^2, h1, w1] (level-major channels). */
+int gs_corr_lookup_pyramid(const void* vol0, const void* vol1, const void* vol2, const void* vol3,
+                           const float* coords, void* corr,
+                           int n, int h1, int w1, int h2, int w2, int radius, int dtype,
+                           gs_stream_t stream);
+
+/* ------------------------------------------------------------------- geometry ------ */
+
+/* DepthVideo.reproject -> pops.projective_transform(jacobian=False)
+ * (src/depth_video.py:207-217, src/geom/projective_ops.py:114-144).
+ * poses f32 [nbuf,7], disps f32 [nbuf,h,w], intrinsics f32 [nbuf,4], ii/jj i64 [n]
+ * -> coords f32 [n,h,w,2], valid f32 [n,h,w,1].                                              */
+int gs_reproject(const float* poses, const float* disps, const float* intrinsics,
+                 const int64_t* ii, const int64_t* jj, float* coords, float* valid,
+                 int n, int h, int w, gs_stream_t stream);
+
+/* droid_backends.projmap (droid.cpp:133-140, droid_kernels.cu:427-516,1463-1488).
+ * intrinsics f32 [4]; coords f32 [n,h,w,3] (channel 2 left 0), valid f32 [n,h,w,1].          */
+int gs_projmap(const float* poses, const float* disps, const float* intrinsics,
+               const int64_t* ii, const int64_t* jj, float* coords, float* valid,
+               int n, int h, int w, gs_stream_t stream);
+
+/* droid_backends.frame_distance (droid.cpp:120-131, droid_kernels.cu:518-657,1438-1460).    */
+int gs_frame_distance(const float* poses, const float* disps, const float* intrinsics,
+                      const int64_t* ii, const int64_t* jj, float* dist,
+                      int n, int h, int w, float beta, gs_stream_t stream);
+
+/* droid_backends.iproj (droid.cpp:141-147, droid_kernels.cu:779-850,1518-1541).
+ * poses f32 [n,7], disps f32 [n,h,w] -> points f32 [n,h,w,3].                                */
+int gs_iproj(const float* poses, const float* disps, const float* intrinsics, float* points,
+             int n, int h, int w, gs_stream_t stream);
+
+/* droid_backends.depth_filter (droid.cpp:186-196 region, droid_kernels.cu:661-775,1491-1515).
+ * disps f32 [num,h,w], ix i64 [n], thresh f32 [n] -> counter f32 [n,h,w] (zeroed here).      */
+int gs_depth_filter(const float* poses, const float* disps, const float* intrinsics,
+                    const int64_t* ix, const float* thresh, float* counter,
+                    int n, int num, int h, int w, gs_stream_t stream);
+
+/* ------------------------------------------------------ dense bundle adjustment ---- */
+
+/* Workspace size for gs_ba (bytes).  n_edges = len(ii), n_poses = t1-t0, n_depth = rows of
+ * eta (= |unique(cat(arange(t0,t1), ii))|; pass an upper bound when unknown), nbuf = poses
+ * rows, hw = h*w.                                                                           */
+size_t gs_ba_workspace_bytes(int n_edges, int n_poses, int n_depth, int nbuf, int hw);
+
+/* droid_backends.ba (droid.cpp:88-117, droid_kernels.cu:1314-1434 incl. the host-side
+ * SparseBlock / schur_block / Eigen LLT of :1117-1311, all on the device here).
+ *   poses f32 [nbuf,7] (in/out), disps f32 [nbuf,h,w] (in/out), intrinsics f32 [4],
+ *   disps_sens f32 [nbuf,h,w], targets/weights f32 [n_edges,2,h,w], eta f32 [n_depth,h,w]
+ *   (ignored when motion_only), ii/jj i64 [n_edges];
+ *   dx f32 [t1-t0,6] and dz f32 [n_depth,h*w] receive the last iteration's update.
+ * A Cholesky failure leaves dx = 0 for that iteration as the reference does (:1202-1210).
+ * status_out (optional, device int32[4]): [0] = #depth keyframes found, [1] = 1 if it
+ * differs from n_depth, [2] = #Cholesky failures, [3] reserved.                             */
+int gs_ba(float* poses, float* disps, const float* intrinsics, const float* disps_sens,
+          const float* targets, const float* weights, const float* eta,
+          const int64_t* ii, const int64_t* jj,
+          int t0, int t1, int iterations, float lm, float ep, int motion_only,
+          int n_edges, int n_depth, int nbuf, int h, int w,
+          float* dx, float* dz, int32_t* status_out,
+          void* workspace, size_t workspace_bytes, gs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOSLAM_HIP_H */

@@ -1,0 +1,280 @@
+"""GPU parity: HIP tracking path (through the C-ABI) vs the CPU oracle on seeded inputs.
+
+Tolerances: lookup fp16 bit-exact (the oracle carries the reference's fp16
+accumulation order), fp32 lookups rtol 1e-5; geometry kernels compiled op-by-op
+(-ffp-contract=off) => masks / counts bit-exact and coords to ~1 ulp; BA dx rtol 1e-4 /
+atol 1e-6, poses/disps after 2 iterations atol 1e-5.
+"""
+import pytest
+import torch
+
+from go_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def db(built_lib):
+    from go_slam_amd import droid_backends
+    return droid_backends
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import droid_oracle
+    return droid_oracle
+
+
+def _rand_volume(n, h1, w1, h2, w2, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, h1, w1, h2, w2, generator=g).to(dtype)
+
+
+def _rand_coords(n, h1, w1, h2, w2, seed=1, spread=6.0):
+    """Coordinates around the identity grid with a few far-out / border / integer cases."""
+    g = torch.Generator().manual_seed(seed)
+    ys, xs = torch.meshgrid(torch.arange(h1, dtype=torch.float32), torch.arange(w1, dtype=torch.float32),
+                            indexing="ij")
+    sx, sy = w2 / w1, h2 / h1
+    c = torch.stack([xs * sx, ys * sy], 0)[None].repeat(n, 1, 1, 1)
+    c = c + spread * torch.randn(n, 2, h1, w1, generator=g)
+    c[:, :, 0, 0] = torch.tensor([-20.0, 3.0])[None]          # fully outside
+    c[:, :, 0, 1] = torch.tensor([2.0, 2.0])[None]            # exact integer (weights 0/1)
+    c[:, :, 1, 0] = torch.tensor([w2 - 1.5, h2 - 0.5])[None]  # straddles the far border
+    c[:, :, 1, 1] = torch.tensor([-0.25, -0.75])[None]        # straddles the near border
+    return c.contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.float64])
+def test_corr_index_forward_matches_oracle(db, O, dev, dtype):
+    n, h1, w1, h2, w2 = 3, 12, 16, 12, 16
+    vol = _rand_volume(n, h1, w1, h2, w2, dtype)
+    coords = _rand_coords(n, h1, w1, h2, w2)
+    ref, = O.corr_index_forward(vol, coords, 3)
+    out, = db.corr_index_forward(vol.to(dev), coords.to(dev), 3)
+    assert out.shape == ref.shape and out.dtype == dtype
+    if dtype == torch.float16:
+        assert torch.equal(out.cpu(), ref), "fp16 lookup must be bit-identical to the fp16-order oracle"
+    else:
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_corr_index_forward_odd_sizes_and_small_levels(db, O, dev):
+    """ScanNet-like floor sizes (30->15->7->3) put most windows across the border."""
+    for (h2, w2) in [(7, 10), (3, 5), (15, 20)]:
+        vol = _rand_volume(2, 6, 9, h2, w2, torch.float16, seed=h2)
+        coords = _rand_coords(2, 6, 9, h2, w2, seed=w2, spread=2.0)
+        ref, = O.corr_index_forward(vol, coords, 3)
+        out, = db.corr_index_forward(vol.to(dev), coords.to(dev), 3)
+        assert torch.equal(out.cpu(), ref)
+
+
+def test_corr_index_integer_coords_return_the_window(db, dev):
+    """KAT: integer coordinates => the 7x7 taps are the volume entries themselves (x-major)."""
+    h, w = 12, 16
+    vol = torch.arange(h * w, dtype=torch.float32).view(1, 1, 1, h, w).repeat(1, 2, 2, 1, 1).contiguous()
+    coords = torch.zeros(1, 2, 2, 2)
+    coords[0, 0] = 8.0
+    coords[0, 1] = 6.0
+    out, = db.corr_index_forward(vol.to(dev), coords.to(dev), 3)
+    out = out.cpu()
+    for i in range(7):
+        for j in range(7):
+            assert out[0, i, j, 0, 0] == vol[0, 0, 0, 6 - 3 + j, 8 - 3 + i]
+
+
+def test_corr_index_generic_radius(db, O, dev):
+    vol = _rand_volume(2, 5, 6, 9, 11, torch.float32)
+    coords = _rand_coords(2, 5, 6, 9, 11, spread=1.5)
+    for r in (1, 2, 4):
+        ref, = O.corr_index_forward(vol, coords, r)
+        out, = db.corr_index_forward(vol.to(dev), coords.to(dev), r)
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_corr_index_backward_matches_oracle(db, O, dev):
+    vol = _rand_volume(2, 5, 6, 9, 11, torch.float32)
+    coords = _rand_coords(2, 5, 6, 9, 11, spread=1.5)
+    g = torch.randn(2, 7, 7, 5, 6)
+    ref, = O.corr_index_backward(vol, coords, g, 3)
+    out, = db.corr_index_backward(vol.to(dev), coords.to(dev), g.to(dev), 3)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", ["tiny", "Scan"])
+def test_corr_lookup_pyramid_matches_four_level_loop(db, O, dev, shape):
+    ht, wd, _ = synth.SHAPES[shape]
+    n = 3
+    f1 = synth.make_features(n, shape, seed=5)[None]
+    f2 = synth.make_features(n, shape, seed=6)[None]
+    pyr = O.corr_pyramid(f1, f2)
+    coords = _rand_coords(n, ht, wd, ht, wd, spread=4.0).permute(0, 2, 3, 1).contiguous()
+    ref = O.corr_lookup(pyr, coords[None], 3)[0]
+    out = db.corr_lookup_pyramid([p.to(dev) for p in pyr], coords.to(dev), 3)
+    assert out.dtype == torch.float16 and tuple(out.shape) == (n, 196, ht, wd)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_reproject_matches_oracle_and_identity_kat(db, O, dev):
+    vid = synth.make_video(8, "tiny", seed=7)
+    ii, jj = synth.make_graph(8, 24, seed=7)
+    ii = torch.cat([ii, torch.tensor([2, 5])])       # two stereo (i == j) edges
+    jj = torch.cat([jj, torch.tensor([2, 5])])
+    ref_c, ref_v = O.reproject(vid["poses"], vid["disps"], vid["intrinsics"], ii, jj)
+    c, v = db.reproject(vid["poses"].to(dev), vid["disps"].to(dev), vid["intrinsics"].to(dev), ii.to(dev), jj.to(dev))
+    assert torch.equal(v.cpu(), ref_v)
+    torch.testing.assert_close(c.cpu(), ref_c, rtol=1e-6, atol=1e-4)
+    # identical poses => coordinates are the pixel grid
+    vid["poses"][:] = vid["poses"][0]
+    c, v = db.reproject(vid["poses"].to(dev), vid["disps"].to(dev), vid["intrinsics"].to(dev),
+                        ii[:24].to(dev), jj[:24].to(dev))
+    ys, xs = torch.meshgrid(torch.arange(12.0), torch.arange(16.0), indexing="ij")
+    torch.testing.assert_close(c.cpu()[0], torch.stack([xs, ys], -1)[None].expand(24, -1, -1, -1), atol=2e-4, rtol=0)
+
+
+def test_projmap_frame_distance_iproj_depth_filter(db, O, dev):
+    vid = synth.make_video(10, "tiny", seed=9)
+    ii, jj = synth.make_graph(10, 30, seed=9)
+    P, D, K = vid["poses"], vid["disps"], vid["intrinsics"][0].contiguous()
+    Pd, Dd, Kd = P.to(dev), D.to(dev), K.to(dev)
+    # projmap
+    rc, rv = O.projmap(P, D, K, ii, jj)
+    c, v = db.projmap(Pd, Dd, Kd, ii.to(dev), jj.to(dev))
+    assert torch.equal(v.cpu(), rv)
+    torch.testing.assert_close(c.cpu(), rc, rtol=1e-6, atol=1e-4)
+    # frame_distance (reduction order differs: rtol 1e-4)
+    for beta in (0.3, 0.7):
+        ref = O.frame_distance(P, D, K, ii, jj, beta)
+        out = db.frame_distance(Pd, Dd, Kd, ii.to(dev), jj.to(dev), beta)
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+    # a pair that looks away => < 75 % valid => 1000
+    P2 = P.clone()
+    P2[1, 3:] = torch.tensor([0.0, 1.0, 0.0, 0.0])       # 180 deg about y
+    out = db.frame_distance(P2.to(dev), Dd, Kd, torch.tensor([0]).to(dev), torch.tensor([1]).to(dev), 0.3)
+    ref = O.frame_distance(P2, D, K, torch.tensor([0]), torch.tensor([1]), 0.3)
+    assert float(out) == float(ref)
+    # iproj
+    ref = O.iproj(P, D, K)
+    out = db.iproj(Pd, Dd, Kd)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-5)
+    # depth_filter: integer counts, bit-exact; includes frames whose neighbours fall off both ends
+    ix = torch.tensor([0, 1, 4, 8, 9])
+    th = torch.tensor([0.05, 0.1, 0.2, 0.05, 0.3])
+    ref = O.depth_filter(P, D, K, ix, th)
+    out = db.depth_filter(Pd, Dd, Kd, ix.to(dev), th.to(dev))
+    assert torch.equal(out.cpu(), ref)
+    assert ref.max() >= 1
+
+
+def _run_ba_pair(db, O, dev, prob, iters, lm, ep, motion_only):
+    K = prob["intrinsics"][0].contiguous()
+    po, do = prob["poses"].clone(), prob["disps"].clone()
+    ref = O.ba(po, do, K, prob["disps_sens"], prob["target"], prob["weight"], prob["eta"], prob["ii"], prob["jj"],
+               prob["t0"], prob["t1"], iters, lm, ep, motion_only)
+    pg, dg = prob["poses"].clone().to(dev), prob["disps"].clone().to(dev)
+    out = db.ba(pg, dg, K.to(dev), prob["disps_sens"].to(dev), prob["target"].to(dev), prob["weight"].to(dev),
+                prob["eta"].to(dev), prob["ii"].to(dev), prob["jj"].to(dev), prob["t0"], prob["t1"], iters, lm, ep,
+                motion_only)
+    torch.cuda.synchronize()
+    return ref, (po, do), out, (pg.cpu(), dg.cpu())
+
+
+def _ba_problem(O, num_kf, num_edges, shape, seed, rgbd=True, noise=0.5):
+    p = synth.make_ba_problem(num_kf, num_edges, shape, seed, rgbd)
+    c, _ = O.reproject(p["poses"], p["disps"], p["intrinsics"], p["ii"], p["jj"])
+    return synth.make_ba_problem(num_kf, num_edges, shape, seed, rgbd, noise_px=noise, coords=c[0])
+
+
+@pytest.mark.parametrize("rgbd", [True, False])
+def test_ba_one_iteration_matches_oracle(db, O, dev, rgbd):
+    prob = _ba_problem(O, 8, 22, "tiny", seed=11, rgbd=rgbd)
+    ref, (po, do), out, (pg, dg) = _run_ba_pair(db, O, dev, prob, 1, 1e-4, 0.1, False)
+    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out[1].cpu(), ref[1], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(pg, po, rtol=0, atol=1e-5)
+    torch.testing.assert_close(dg, do, rtol=0, atol=1e-5)
+
+
+def test_ba_two_iterations_frontend_like(db, O, dev):
+    prob = _ba_problem(O, 12, 40, "Scan", seed=13)
+    ref, (po, do), out, (pg, dg) = _run_ba_pair(db, O, dev, prob, 2, 1e-4, 0.1, False)
+    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=1e-3, atol=2e-6)
+    torch.testing.assert_close(pg, po, rtol=0, atol=1e-5)
+    torch.testing.assert_close(dg, do, rtol=0, atol=1e-5)
+
+
+def test_ba_motion_only(db, O, dev):
+    prob = _ba_problem(O, 8, 22, "tiny", seed=17)
+    ref, (po, do), out, (pg, dg) = _run_ba_pair(db, O, dev, prob, 2, 1e-4, 0.1, True)
+    assert out[1] is None
+    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(pg, po, rtol=0, atol=1e-5)
+    assert torch.equal(dg, prob["disps"]), "motion_only must not touch disparities"
+
+
+def test_ba_window_and_stereo_edges(db, O, dev):
+    """t0 > 1 (fixed early frames stay in the graph) plus i==j stereo edges (Q4) and the
+    EvT `<= 0` skip (Q1) are all exercised by this graph."""
+    prob = _ba_problem(O, 10, 30, "tiny", seed=19)
+    prob["ii"] = torch.cat([prob["ii"], torch.tensor([3, 6])])
+    prob["jj"] = torch.cat([prob["jj"], torch.tensor([3, 6])])
+    g = torch.Generator().manual_seed(3)
+    ht, wd, _ = synth.SHAPES["tiny"]
+    prob["target"] = torch.cat([prob["target"], prob["target"][:2] + 0.1], 0).contiguous()
+    prob["weight"] = torch.cat([prob["weight"], torch.rand(2, 2, ht, wd, generator=g)], 0).contiguous()
+    prob["t0"], prob["t1"] = 3, 10
+    kx = torch.unique(torch.cat([torch.arange(3, 10), prob["ii"]]))
+    prob["eta"] = (1e-2 * torch.rand(len(kx), ht, wd, generator=g) + 1e-4)
+    ref, (po, do), out, (pg, dg) = _run_ba_pair(db, O, dev, prob, 2, 1e-4, 0.1, False)
+    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=1e-3, atol=2e-6)
+    torch.testing.assert_close(pg, po, rtol=0, atol=1e-5)
+    torch.testing.assert_close(dg, do, rtol=0, atol=1e-5)
+    assert torch.equal(pg[:3], prob["poses"][:3]), "poses before t0 are fixed"
+
+
+def test_ba_zero_residual_is_a_fixed_point(db, O, dev):
+    prob = _ba_problem(O, 6, 14, "tiny", seed=23, rgbd=False, noise=0.0)
+    K = prob["intrinsics"][0].contiguous()
+    pg, dg = prob["poses"].clone().to(dev), prob["disps"].clone().to(dev)
+    dx, dz = db.ba(pg, dg, K.to(dev), prob["disps_sens"].to(dev), prob["target"].to(dev), prob["weight"].to(dev),
+                   prob["eta"].to(dev), prob["ii"].to(dev), prob["jj"].to(dev), 1, 6, 2, 1e-4, 0.1, False)
+    assert dx.abs().max() < 1e-4 and dz.abs().max() < 1e-3
+
+
+def test_ba_cholesky_failure_gives_zero_update(db, dev):
+    """Negative damping makes the system indefinite => LLT fails => dx = 0 (reference
+    droid_kernels.cu:1202-1210), poses untouched."""
+    from oracle import droid_oracle as O
+    prob = _ba_problem(O, 6, 14, "tiny", seed=29)
+    K = prob["intrinsics"][0].contiguous()
+    pg, dg = prob["poses"].clone().to(dev), prob["disps"].clone().to(dev)
+    dx, _ = db.ba(pg, dg, K.to(dev), prob["disps_sens"].to(dev), prob["target"].to(dev), prob["weight"].to(dev),
+                  prob["eta"].to(dev), prob["ii"].to(dev), prob["jj"].to(dev), 1, 6, 1, -2.0, -1.0, True)
+    assert torch.count_nonzero(dx) == 0
+    assert torch.equal(pg.cpu(), prob["poses"])
+
+
+def test_ba_rejects_non_contiguous(db, dev):
+    from oracle import droid_oracle as O
+    prob = _ba_problem(O, 6, 14, "tiny", seed=31)
+    K = prob["intrinsics"][0].contiguous().to(dev)
+    tgt = prob["target"].to(dev).permute(0, 1, 3, 2)
+    with pytest.raises(RuntimeError, match="targets must be contiguous"):
+        db.ba(prob["poses"].to(dev), prob["disps"].to(dev), K, prob["disps_sens"].to(dev), tgt,
+              prob["weight"].to(dev), prob["eta"].to(dev), prob["ii"].to(dev), prob["jj"].to(dev), 1, 6, 1, 1e-4, 0.1,
+              False)
+
+
+def test_ba_large_window_blocked_cholesky(db, O, dev):
+    """6P = 282 unknowns: several Cholesky panels + trailing tiles, and degree-8 keyframes."""
+    prob = _ba_problem(O, 48, 260, "tiny", seed=37)
+    ref, (po, do), out, (pg, dg) = _run_ba_pair(db, O, dev, prob, 2, 1e-5, 1e-2, False)
+    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=2e-3, atol=5e-6)
+    torch.testing.assert_close(pg, po, rtol=0, atol=2e-5)
+    torch.testing.assert_close(dg, do, rtol=0, atol=2e-5)
