@@ -7,8 +7,9 @@
 // row on the interior fast path) and emits the 49 bilinear taps.  Lanes are laid out along
 // the flattened pixel index so every output channel plane is written 128 B per wave.
 // The bilinear blend is carried in the volume's dtype in the reference's order
-// (i outer, j inner, `corr += s * T(w)`), which makes fp16 results bit-identical to the
-// reference's fp16-accumulated values; the file is compiled with -ffp-contract=off.
+// (i outer, j inner, `corr += s * T(w)`) with at::Half's compute-in-fp32-round-to-fp16
+// operator semantics, which makes fp16 results bit-identical to the reference's
+// fp16-accumulated values; the file is compiled with -ffp-contract=off.
 #include "common.h"
 
 namespace {
@@ -16,6 +17,19 @@ namespace {
 // float -> int with the huge/NaN cases pinned far outside any map (the reference's
 // static_cast<int> saturates; a plain cast could wrap `xs + 8` back into range).
 __device__ __forceinline__ int safe_int(float f) { return (int)fminf(fmaxf(f, -1.0e6f), 1.0e6f); }
+
+// The reference instantiates its kernels with at::Half, whose operators compute in fp32 and
+// round the result back to fp16 (c10/util/Half-inl.h) -- i.e. `a + b` is half(float(a)+float(b)),
+// a double rounding that a native v_add_f16 does not reproduce in rare tie cases.  Emulate it.
+// `pin` keeps hipcc from folding an fp32 op and the following fp32->fp16 conversion into one
+// single-rounding v_fma_mixlo_f16 (it does so even under -ffp-contract=off).
+__device__ __forceinline__ float pin(float v) { asm volatile("" : "+v"(v)); return v; }
+template <typename T> __device__ __forceinline__ T mul_r(T a, T b) { return a * b; }
+template <typename T> __device__ __forceinline__ T add_r(T a, T b) { return a + b; }
+template <> __device__ __forceinline__ _Float16 mul_r(_Float16 a, _Float16 b) { return (_Float16)pin((float)a * (float)b); }
+template <> __device__ __forceinline__ _Float16 add_r(_Float16 a, _Float16 b) { return (_Float16)pin((float)a + (float)b); }
+// scalar_t(w): the fp32 weight product is rounded to fp32 first, then converted
+template <typename T> __device__ __forceinline__ T wcast(float w) { return (T)pin(w); }
 
 template <typename T> struct VecRow;   // 8 consecutive taps of a window row
 template <> struct VecRow<_Float16> { typedef struct __attribute__((packed, aligned(2))) { _Float16 v[8]; } type; };
@@ -29,10 +43,10 @@ __device__ __forceinline__ void lookup_r3(const T* __restrict__ slice, int h2, i
   const float fx0 = floorf(x0), fy0 = floorf(y0);
   const float dx = x0 - fx0, dy = y0 - fy0;
   const int xs = safe_int(fx0) - 3, ys = safe_int(fy0) - 3;
-  const T w_nw = (T)(dx * dy);
-  const T w_ne = (T)(dx * (1.0f - dy));
-  const T w_sw = (T)((1.0f - dx) * dy);
-  const T w_se = (T)((1.0f - dx) * (1.0f - dy));
+  const T w_nw = wcast<T>(dx * dy);
+  const T w_ne = wcast<T>(dx * (1.0f - dy));
+  const T w_sw = wcast<T>((1.0f - dx) * dy);
+  const T w_se = wcast<T>((1.0f - dx) * (1.0f - dy));
 
   T s[8][8];   // s[i][j]: i = x offset, j = y offset
   const bool xin = (xs >= 0) && (xs + 8 <= w2);
@@ -58,10 +72,10 @@ __device__ __forceinline__ void lookup_r3(const T* __restrict__ slice, int h2, i
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       // contributions arrive in loop order (i,j), (i,j+1), (i+1,j), (i+1,j+1)
-      T c = s[i][j] * w_se;
-      c = c + s[i][j + 1] * w_sw;
-      c = c + s[i + 1][j] * w_ne;
-      c = c + s[i + 1][j + 1] * w_nw;
+      T c = mul_r(s[i][j], w_se);
+      c = add_r(c, mul_r(s[i][j + 1], w_sw));
+      c = add_r(c, mul_r(s[i + 1][j], w_ne));
+      c = add_r(c, mul_r(s[i + 1][j + 1], w_nw));
       out[(size_t)(i * 7 + j) * plane] = c;
     }
   }
@@ -123,10 +137,10 @@ __global__ __launch_bounds__(256) void corr_index_generic_kernel(
       const int x1 = safe_int(fx0) - r + i, y1 = safe_int(fy0) - r + j;
       if (y1 >= 0 && y1 < h2 && x1 >= 0 && x1 < w2) {
         const T s = slice[(size_t)y1 * w2 + x1];
-        if (i > 0 && j > 0) { T* o = out + (size_t)((i - 1) * rd + (j - 1)) * hw1; *o = *o + s * (T)(dx * dy); }
-        if (i > 0 && j < rd) { T* o = out + (size_t)((i - 1) * rd + j) * hw1; *o = *o + s * (T)(dx * (1.0f - dy)); }
-        if (i < rd && j > 0) { T* o = out + (size_t)(i * rd + (j - 1)) * hw1; *o = *o + s * (T)((1.0f - dx) * dy); }
-        if (i < rd && j < rd) { T* o = out + (size_t)(i * rd + j) * hw1; *o = *o + s * (T)((1.0f - dx) * (1.0f - dy)); }
+        if (i > 0 && j > 0) { T* o = out + (size_t)((i - 1) * rd + (j - 1)) * hw1; *o = add_r(*o, mul_r(s, wcast<T>(dx * dy))); }
+        if (i > 0 && j < rd) { T* o = out + (size_t)((i - 1) * rd + j) * hw1; *o = add_r(*o, mul_r(s, wcast<T>(dx * (1.0f - dy)))); }
+        if (i < rd && j > 0) { T* o = out + (size_t)(i * rd + (j - 1)) * hw1; *o = add_r(*o, mul_r(s, wcast<T>((1.0f - dx) * dy))); }
+        if (i < rd && j < rd) { T* o = out + (size_t)(i * rd + j) * hw1; *o = add_r(*o, mul_r(s, wcast<T>((1.0f - dx) * (1.0f - dy)))); }
       }
     }
   }
@@ -152,12 +166,12 @@ __global__ __launch_bounds__(256) void corr_index_backward_kernel(
       const int x1 = safe_int(fx0) - r + i, y1 = safe_int(fy0) - r + j;
       if (y1 >= 0 && y1 < h2 && x1 >= 0 && x1 < w2) {
         T acc = (T)0;
-        if (i > 0 && j > 0) acc = acc + g[(size_t)((i - 1) * rd + (j - 1)) * hw1] * (T)(dx * dy);
-        if (i > 0 && j < rd) acc = acc + g[(size_t)((i - 1) * rd + j) * hw1] * (T)(dx * (1.0f - dy));
-        if (i < rd && j > 0) acc = acc + g[(size_t)(i * rd + (j - 1)) * hw1] * (T)((1.0f - dx) * dy);
-        if (i < rd && j < rd) acc = acc + g[(size_t)(i * rd + j) * hw1] * (T)((1.0f - dx) * (1.0f - dy));
+        if (i > 0 && j > 0) acc = add_r(acc, mul_r(g[(size_t)((i - 1) * rd + (j - 1)) * hw1], wcast<T>(dx * dy)));
+        if (i > 0 && j < rd) acc = add_r(acc, mul_r(g[(size_t)((i - 1) * rd + j) * hw1], wcast<T>(dx * (1.0f - dy))));
+        if (i < rd && j > 0) acc = add_r(acc, mul_r(g[(size_t)(i * rd + (j - 1)) * hw1], wcast<T>((1.0f - dx) * dy)));
+        if (i < rd && j < rd) acc = add_r(acc, mul_r(g[(size_t)(i * rd + j) * hw1], wcast<T>((1.0f - dx) * (1.0f - dy))));
         T* o = slice + (size_t)y1 * w2 + x1;
-        *o = *o + acc;
+        *o = add_r(*o, acc);
       }
     }
   }

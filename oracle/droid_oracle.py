@@ -54,7 +54,8 @@ def corr_pyramid(fmap1, fmap2, num_levels=4):
     pyr = []
     for i in range(num_levels):
         pyr.append(corr.view(batch * num, h1, w1, h2 // 2 ** i, w2 // 2 ** i))
-        corr = F.avg_pool2d(corr.float(), kernel_size=2, stride=2).to(dt)
+        if i + 1 < num_levels:   # (the reference pools once more and drops the result)
+            corr = F.avg_pool2d(corr.float(), kernel_size=2, stride=2).to(dt)
     return pyr
 
 
@@ -195,7 +196,8 @@ def altcorr_pyramid(fmaps, num_levels=4):
     pyr = []
     for i in range(num_levels):
         pyr.append(f.permute(0, 2, 3, 1).contiguous().view(B, N, H // 2 ** i, W // 2 ** i, C))
-        f = F.avg_pool2d(f.float(), kernel_size=2, stride=2).to(dt)
+        if i + 1 < num_levels:
+            f = F.avg_pool2d(f.float(), kernel_size=2, stride=2).to(dt)
     return pyr
 
 
