@@ -1,0 +1,255 @@
+#!/usr/bin/env python
+"""Hot-path benchmark (contract: python bench.py --gpus N --steps K --warmup W -> ONE JSON line).
+
+Metric (BASELINE.json): BA keyframes/s on synthetic 640x480 RGB-D.  One *step* = the
+frontend's per-keyframe work unit = 6 x FactorGraph.update(iters=2, use_inactive=True)
+(reference src/frontend.py:66-67,90-91) on a window graph of P=25 keyframes / E=75 edges at
+the 1/8-resolution map size 60x80: reproject + 4-level corr lookup + UpdateModule (MIOpen) +
+2 Gauss-Newton dense-BA iterations + convex upsampling.  Inputs are resident in HBM before the
+timed region.  Tracking does not shard ("replicas only"), so --gpus N runs N
+independent replicas, one process per GPU, and `value` is their aggregate.
+
+Extra objects on the line: `roofline` for the dominant hand-written kernel (the fused
+correlation-pyramid lookup: 912*HW algorithmic bytes per edge, measured with events on the
+launch stream) and `cpu_baseline` (the CPU oracle + the same UpdateModule on the host cores,
+on a bounded 1-update sample, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+SHAPE = "S480"
+NUM_KF = 25
+NUM_EDGES = 75
+UPDATES_PER_KF = 6
+
+
+def bench_graph(num_kf, num_edges, seed=43):
+    """Frontend-like window graph: |i-j|==1 both directions, then random proximity pairs |i-j|<=6."""
+    g = torch.Generator().manual_seed(seed)
+    pairs = [(i, i + 1) for i in range(num_kf - 1)] + [(i + 1, i) for i in range(num_kf - 1)]
+    have = set(pairs)
+    while len(pairs) < num_edges:
+        i = int(torch.randint(0, num_kf, (1,), generator=g))
+        d = int(torch.randint(2, 7, (1,), generator=g)) * (1 if int(torch.randint(0, 2, (1,), generator=g)) else -1)
+        j = i + d
+        if 0 <= j < num_kf and (i, j) not in have:
+            have.add((i, j))
+            pairs.append((i, j))
+    return (torch.tensor([p[0] for p in pairs], dtype=torch.long),
+            torch.tensor([p[1] for p in pairs], dtype=torch.long))
+
+
+def build_state(device, seed=43):
+    from go_slam_amd import synth
+    from go_slam_amd.depth_video import DepthVideo
+    from go_slam_amd.droid_net import UpdateModule
+    from go_slam_amd.factor_graph import FactorGraph
+
+    ht, wd, _ = synth.SHAPES[SHAPE]
+    torch.manual_seed(seed)
+    # let MIOpen search its NHWC fp16 solvers once per conv shape (the default immediate-mode
+    # pick is ~1.7x slower on the update operator's shapes)
+    torch.backends.cudnn.benchmark = True
+    vid = synth.make_video(NUM_KF, SHAPE, seed=seed, rgbd=True, buffer=NUM_KF + 7)
+    video = DepthVideo(ht, wd, buffer=NUM_KF + 7, device=device)
+    video.poses.copy_(vid["poses"])
+    video.disps.copy_(vid["disps"])
+    video.disps_sens.copy_(vid["disps_sens"])
+    video.intrinsics.copy_(vid["intrinsics"])
+    video.counter = NUM_KF
+    g = torch.Generator().manual_seed(seed + 5)
+    video.fmaps[:NUM_KF, 0] = torch.randn(NUM_KF, 128, ht, wd, generator=g).half().to(device)
+    video.nets[:NUM_KF] = torch.tanh(torch.randn(NUM_KF, 128, ht, wd, generator=g)).half().to(device)
+    video.inps[:NUM_KF] = torch.relu(torch.randn(NUM_KF, 128, ht, wd, generator=g)).half().to(device)
+    update_op = UpdateModule().to(device).eval().to(memory_format=torch.channels_last)
+    # small output heads so that the synthetic GRU state stays in a sane flow range
+    with torch.no_grad():
+        update_op.delta[2].weight.mul_(0.05)
+        update_op.delta[2].bias.zero_()
+    graph = FactorGraph(video, update_op, device=device, corr_impl="volume", max_factors=NUM_EDGES, upsample=True)
+    ii, jj = bench_graph(NUM_KF, NUM_EDGES, seed)
+    graph.add_factors(ii.to(device), jj.to(device))
+    return video, update_op, graph, (vid, ii, jj)
+
+
+def keyframe_step(graph):
+    for _ in range(UPDATES_PER_KF):
+        graph.update(None, None, use_inactive=True)
+
+
+def time_op(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters   # ms
+
+
+def op_breakdown(video, update_op, graph):
+    """Per-op milliseconds (events on the launch stream) for one update's components."""
+    from go_slam_amd import droid_backends as db
+    ii, jj = graph.ii, graph.jj
+    E = ii.numel()
+    ht, wd = graph.ht, graph.wd
+    coords1, _ = video.reproject(ii, jj)
+    corr = graph.corr(coords1)
+    motion = torch.cat([coords1 - graph.coords0, graph.target - coords1], dim=-1).permute(0, 1, 4, 2, 3).clamp(-64, 64)
+    out = {}
+    out["reproject_ms"] = time_op(lambda: video.reproject(ii, jj))
+    out["corr_lookup_ms"] = time_op(lambda: graph.corr(coords1))
+
+    def gru():
+        with torch.autocast("cuda", dtype=torch.float16):
+            update_op(graph.net, graph.inp, corr, motion, ii, jj)
+    out["update_module_ms"] = time_op(gru, iters=5)
+    t0, t1 = 1, NUM_KF
+    target = graph.target.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
+    weight = torch.rand_like(target)
+    kx = torch.unique(torch.cat([torch.arange(t0, t1, device=ii.device), ii]))
+    eta = 0.2 * graph.damping[kx].contiguous() + 1e-7
+    poses0, disps0 = video.poses.clone(), video.disps.clone()
+
+    def ba():
+        video.poses.copy_(poses0)
+        video.disps.copy_(disps0)
+        db.ba(video.poses, video.disps, video.intrinsics[0].contiguous(), video.disps_sens, target, weight, eta,
+              ii, jj, t0, t1, 2, 1e-4, 0.1, False)
+    out["ba_2iter_ms"] = time_op(ba)
+    video.poses.copy_(poses0)
+    video.disps.copy_(disps0)
+    out["edges"] = E
+    return out
+
+
+def cpu_baseline(sample_updates=1):
+    """The CPU oracle (+ the same UpdateModule on the host, fp32) on a bounded sample of the same
+    workload: `sample_updates` update calls = sample_updates/6 keyframe."""
+    from go_slam_amd import synth
+    from go_slam_amd.droid_net import UpdateModule
+    from oracle import droid_oracle as O
+
+    torch.manual_seed(43)
+    ht, wd, _ = synth.SHAPES[SHAPE]
+    vid = synth.make_video(NUM_KF, SHAPE, seed=43, rgbd=True, buffer=NUM_KF + 7)
+    ii, jj = bench_graph(NUM_KF, NUM_EDGES, 43)
+    g = torch.Generator().manual_seed(48)
+    fmaps = torch.randn(NUM_KF, 128, ht, wd, generator=g).half()
+    net = torch.tanh(torch.randn(NUM_KF, 128, ht, wd, generator=g))[ii][None]
+    inp = torch.relu(torch.randn(NUM_KF, 128, ht, wd, generator=g))[ii][None]
+    op = UpdateModule().eval()
+    coords0 = torch.stack(torch.meshgrid(torch.arange(wd).float(), torch.arange(ht).float(), indexing="xy"), -1)
+    # the pyramid build is setup (not part of an update), done once outside the timed region
+    pyr = O.corr_pyramid(fmaps[ii][None], fmaps[jj][None])
+    poses, disps = vid["poses"].clone(), vid["disps"].clone()
+    target, _ = O.reproject(poses, disps, vid["intrinsics"], ii, jj)
+    K = vid["intrinsics"][0].contiguous()
+    t0, t1 = 1, NUM_KF
+    tic = time.perf_counter()
+    with torch.no_grad():
+        for _ in range(sample_updates):
+            coords1, _ = O.reproject(poses, disps, vid["intrinsics"], ii, jj)
+            motion = torch.cat([coords1 - coords0, target - coords1], -1).permute(0, 1, 4, 2, 3).clamp(-64, 64)
+            corr = O.corr_lookup(pyr, coords1, 3).float()
+            net, delta, weight, damping, upmask = op(net, inp, corr, motion, ii, jj)
+            target = coords1 + delta
+            kx = torch.unique(torch.cat([torch.arange(t0, t1), ii]))
+            assert damping.shape[1] == len(kx)     # every keyframe of the window is an edge source
+            eta = 0.2 * damping[0].contiguous() + 1e-7
+            tg = target.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
+            wg = weight.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
+            O.ba(poses, disps, K, vid["disps_sens"], tg, wg, eta, ii, jj, t0, t1, 2, 1e-4, 0.1, False)
+            disps.clamp_(min=0.001)
+    dt = time.perf_counter() - tic
+    kf_per_s = (sample_updates / UPDATES_PER_KF) / dt
+    return {"value": kf_per_s, "unit": "keyframes/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{sample_updates} update(s) = {sample_updates}/{UPDATES_PER_KF} keyframe, {dt:.1f} s of CPU work "
+                      f"(oracle reproject+lookup+BA, UpdateModule fp32 on CPU torch {torch.__version__})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    video, update_op, graph, _ = build_state(device)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        keyframe_step(graph)
+    barrier()
+    tic = time.perf_counter()
+    for _ in range(args.steps):
+        keyframe_step(graph)
+    barrier()
+    elapsed = time.perf_counter() - tic
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    finite = bool(torch.isfinite(video.poses).all()) and bool(torch.isfinite(video.disps).all())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.steps / elapsed          # aggregate keyframes/s over all replicas
+    line = {
+        "metric": "BA keyframes/s (6 x FactorGraph.update: reproject + corr lookup + GRU + 2 GN BA iters) on synthetic 640x480 RGB-D",
+        "value": value, "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (BA/geometry; fp64 solve), f16 (corr volume, GRU convs)", "data": "synthetic",
+        "config": {"workload": "configs[1]-shaped frontend window: 60x80 maps (480x640 RGB-D), P=25 keyframes, "
+                               "E=75 edges, 6 updates/keyframe, iters=2, RGB-D depth prior, upsample on",
+                   "parallelism": f"replicas x{world} (tracking does not shard)"},
+        "updates_per_s": value * UPDATES_PER_KF, "state_finite": finite,
+    }
+    if rank == 0:
+        br = op_breakdown(video, update_op, graph)
+        line["breakdown_ms"] = {k: round(v, 4) for k, v in br.items() if k.endswith("_ms")}
+        ht, wd = graph.ht, graph.wd
+        algo_bytes = 912.0 * ht * wd * br["edges"]            # 912*HW B per edge per lookup
+        t_s = br["corr_lookup_ms"] * 1e-3
+        achieved = algo_bytes / t_s / 1e9
+        line["roofline"] = {"kernel": "corr_pyramid_kernel<f16> (fused 4-level lookup)", "bound": "hbm",
+                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                            "algorithmic_bytes_per_launch": algo_bytes}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(3)
+        print(json.dumps(line))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,7 +82,9 @@ __device__ __forceinline__ void lookup_r3(const T* __restrict__ slice, int h2, i
 }
 
 // ---- fused 4-level pyramid lookup: coords [n,h1,w1,2] -> corr [n,4*49,h1,w1] ------------
-template <typename T>
+// NHWC=true writes the same logical tensor with channels-last strides ([n,h1,w1,196] in
+// memory), the layout MIOpen's NHWC convolutions of the update operator consume directly.
+template <typename T, bool NHWC>
 __global__ __launch_bounds__(256) void corr_pyramid_kernel(
     const T* __restrict__ v0, const T* __restrict__ v1, const T* __restrict__ v2, const T* __restrict__ v3,
     const float* __restrict__ coords, T* __restrict__ corr, int hw1, int h2, int w2) {
@@ -91,14 +93,15 @@ __global__ __launch_bounds__(256) void corr_pyramid_kernel(
   if (p >= hw1) return;
   const size_t pix = (size_t)n * hw1 + p;
   const float2 c = reinterpret_cast<const float2*>(coords)[pix];
-  T* out = corr + (size_t)n * 196 * hw1 + p;
+  T* out = NHWC ? corr + pix * 196 : corr + (size_t)n * 196 * hw1 + p;
+  const size_t plane = NHWC ? (size_t)1 : (size_t)hw1;
   const T* vols[4] = {v0, v1, v2, v3};
 #pragma unroll
   for (int l = 0; l < 4; ++l) {
     const int h2l = h2 >> l, w2l = w2 >> l;
     const float sc = 1.0f / (float)(1 << l);   // coords / 2**l (exact)
     lookup_r3<T>(vols[l] + pix * (size_t)(h2l * w2l), h2l, w2l, c.x * sc, c.y * sc,
-                 out + (size_t)l * 49 * hw1, (size_t)hw1);
+                 out + (size_t)l * 49 * plane, plane);
   }
 }
 
@@ -202,11 +205,15 @@ int launch_index_backward(const float* coords, const void* g, void* vg, int n, i
 
 template <typename T>
 int launch_pyramid(const void* v0, const void* v1, const void* v2, const void* v3, const float* coords,
-                   void* corr, int n, int h1, int w1, int h2, int w2, hipStream_t st) {
+                   void* corr, int n, int h1, int w1, int h2, int w2, int nhwc, hipStream_t st) {
   const int hw1 = h1 * w1;
   dim3 grid(gs_cdiv(hw1, 256), n), block(256);
-  corr_pyramid_kernel<T><<<grid, block, 0, st>>>((const T*)v0, (const T*)v1, (const T*)v2, (const T*)v3,
-                                                 coords, (T*)corr, hw1, h2, w2);
+  if (nhwc)
+    corr_pyramid_kernel<T, true><<<grid, block, 0, st>>>((const T*)v0, (const T*)v1, (const T*)v2, (const T*)v3,
+                                                         coords, (T*)corr, hw1, h2, w2);
+  else
+    corr_pyramid_kernel<T, false><<<grid, block, 0, st>>>((const T*)v0, (const T*)v1, (const T*)v2, (const T*)v3,
+                                                          coords, (T*)corr, hw1, h2, w2);
   GS_CHECK_LAUNCH("corr_lookup_pyramid");
   return GS_OK;
 }
@@ -248,7 +255,7 @@ extern "C" int gs_corr_index_backward(const float* coords, const void* corr_grad
 
 extern "C" int gs_corr_lookup_pyramid(const void* vol0, const void* vol1, const void* vol2, const void* vol3,
                                       const float* coords, void* corr, int n, int h1, int w1, int h2, int w2,
-                                      int radius, int dtype, gs_stream_t stream) {
+                                      int radius, int dtype, int channels_last, gs_stream_t stream) {
   GS_REQUIRE(vol0 && vol1 && vol2 && vol3 && coords && corr, "corr_lookup_pyramid: null pointer");
   GS_REQUIRE(radius == 3, "corr_lookup_pyramid: only radius 3 (the reference's value) is supported");
   GS_REQUIRE(n >= 0 && h1 > 0 && w1 > 0 && (h2 >> 3) > 0 && (w2 >> 3) > 0, "corr_lookup_pyramid: bad shape");
@@ -256,8 +263,8 @@ extern "C" int gs_corr_lookup_pyramid(const void* vol0, const void* vol1, const 
   GS_REQUIRE(n <= 65535, "corr_lookup_pyramid: n=%d exceeds grid.y limit", n);
   hipStream_t st = (hipStream_t)stream;
   switch (dtype) {
-    case GS_F16: return launch_pyramid<_Float16>(vol0, vol1, vol2, vol3, coords, corr, n, h1, w1, h2, w2, st);
-    case GS_F32: return launch_pyramid<float>(vol0, vol1, vol2, vol3, coords, corr, n, h1, w1, h2, w2, st);
+    case GS_F16: return launch_pyramid<_Float16>(vol0, vol1, vol2, vol3, coords, corr, n, h1, w1, h2, w2, channels_last, st);
+    case GS_F32: return launch_pyramid<float>(vol0, vol1, vol2, vol3, coords, corr, n, h1, w1, h2, w2, channels_last, st);
   }
   gs_set_error("corr_lookup_pyramid: unsupported dtype %d", dtype);
   return GS_ERR_UNSUPPORTED;

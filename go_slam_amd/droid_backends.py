@@ -175,9 +175,10 @@ def corr_index_backward(volume, coords, corr_grad, radius):
     return [grad]
 
 
-def corr_lookup_pyramid(pyramid, coords, radius=3):
+def corr_lookup_pyramid(pyramid, coords, radius=3, channels_last=False):
     """Fused 4-level form of CorrBlock.__call__ (src/modules/corr.py:43-53): one launch.
-    pyramid: 4 tensors [n,h1,w1,h2>>l,w2>>l]; coords f32 [n,h1,w1,2] -> [n,196,h1,w1]."""
+    pyramid: 4 tensors [n,h1,w1,h2>>l,w2>>l]; coords f32 [n,h1,w1,2] -> [n,196,h1,w1]
+    (memory format torch.channels_last when `channels_last`)."""
     assert len(pyramid) == 4
     for i, v in enumerate(pyramid):
         _chk(f"pyramid[{i}]", v, pyramid[0].dtype)
@@ -187,11 +188,12 @@ def corr_lookup_pyramid(pyramid, coords, radius=3):
         if tuple(pyramid[l].shape) != (n, h1, w1, h2 >> l, w2 >> l):
             raise RuntimeError(f"pyramid level {l} has shape {tuple(pyramid[l].shape)}")
     rd = 2 * radius + 1
-    corr = torch.empty(n, 4 * rd * rd, h1, w1, dtype=pyramid[0].dtype, device=coords.device)
+    corr = torch.empty((n, 4 * rd * rd, h1, w1), dtype=pyramid[0].dtype, device=coords.device,
+                       memory_format=torch.channels_last if channels_last else torch.contiguous_format)
     with torch.cuda.device(coords.device):
         rc = _lib.lib().gs_corr_lookup_pyramid(_lib.ptr(pyramid[0]), _lib.ptr(pyramid[1]), _lib.ptr(pyramid[2]),
                                                _lib.ptr(pyramid[3]), _lib.ptr(coords), _lib.ptr(corr), n, h1, w1,
-                                               h2, w2, int(radius), _DT[pyramid[0].dtype],
+                                               h2, w2, int(radius), _DT[pyramid[0].dtype], int(bool(channels_last)),
                                                _lib.stream_ptr(coords.device))
     _lib.check(rc, "corr_lookup_pyramid")
     return corr

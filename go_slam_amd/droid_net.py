@@ -1,0 +1,135 @@
+"""Update operator of the tracker (host side, PyTorch-ROCm / MIOpen convolutions).
+
+Mirrors the module tree of the reference's `DroidNet.update` (src/droid_net.py:70-140,
+src/modules/gru.py:5-33, src/droid_net.py:34-67) so that a `droid.pth` state dict loads with
+the same keys: update.{corr_encoder,flow_encoder,weight,delta,gru,agg}.  SURVEY.md 8(a5): these
+convolutions stay ATen/MIOpen; the hand-written HIP kernels are the ops around them.
+
+`torch_scatter.scatter_mean` (absent in this image) is replaced by an index_add segment mean.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class GradientClip(nn.Module):
+    """Forward identity (the reference clips gradients in backward only, modules/clipping.py)."""
+
+    def forward(self, x):
+        return x
+
+
+def segment_mean(x, index, num_segments):
+    """scatter_mean(x, index, dim=0) for x [n,c,h,w] (src/droid_net.py:59 with the batch dim
+    folded away), as one [segments x n] @ [n x c*h*w] GEMM with fp32 accumulation.  An
+    index_add_ formulation costs 2.2 ms of fp16 atomics at E=75, 60x80 on MI355X; the GEMM reads
+    x once (~30 us).  Keeps x's memory format (channels_last stays channels_last)."""
+    n = x.shape[0]
+    onehot = torch.zeros(num_segments, n, dtype=x.dtype, device=x.device)
+    onehot[index, torch.arange(n, device=x.device)] = 1
+    cnt = onehot.sum(dim=1, keepdim=True).clamp(min=1)
+    avg = (onehot / cnt)
+    if x.is_contiguous(memory_format=torch.channels_last):
+        flat = x.permute(0, 2, 3, 1).reshape(n, -1)                     # free view of NHWC memory
+        out = (avg @ flat).view(num_segments, x.shape[2], x.shape[3], x.shape[1])
+        return out.permute(0, 3, 1, 2)                                  # logical NCHW, NHWC strides
+    return (avg @ x.reshape(n, -1)).view((num_segments,) + tuple(x.shape[1:]))
+
+
+def cvx_upsample(data, mask):
+    """Convex 8x upsampling (src/droid_net.py:9-23): data [b,h,w,d], mask [b,576,h,w]."""
+    b, h, w, d = data.shape
+    data = data.permute(0, 3, 1, 2)
+    wts = torch.softmax(mask.view(b, 1, 9, 8, 8, h, w), dim=2)
+    nb = F.unfold(data, kernel_size=3, padding=1).view(b, d, 9, 1, 1, h, w)
+    up = (wts * nb).sum(dim=2)                       # [b,d,8,8,h,w]
+    return up.permute(0, 4, 2, 5, 3, 1).reshape(b, 8 * h, 8 * w, d)
+
+
+class ConvGRU(nn.Module):
+    """src/modules/gru.py:5-33: ConvGRU with a global-context gate."""
+
+    def __init__(self, h_planes=128, i_planes=128):
+        super().__init__()
+        self.do_checkpoint = False
+        c = h_planes + i_planes
+        self.convz = nn.Conv2d(c, h_planes, 3, padding=1)
+        self.convr = nn.Conv2d(c, h_planes, 3, padding=1)
+        self.convq = nn.Conv2d(c, h_planes, 3, padding=1)
+        self.w = nn.Conv2d(h_planes, h_planes, 1)
+        self.convz_glo = nn.Conv2d(h_planes, h_planes, 1)
+        self.convr_glo = nn.Conv2d(h_planes, h_planes, 1)
+        self.convq_glo = nn.Conv2d(h_planes, h_planes, 1)
+
+    def forward(self, net, *inputs):
+        inp = torch.cat(inputs, dim=1)
+        hx = torch.cat([net, inp], dim=1)
+        b, c, h, w = net.shape
+        glo = (torch.sigmoid(self.w(net)) * net).view(b, c, h * w).mean(-1).view(b, c, 1, 1)
+        z = torch.sigmoid(self.convz(hx) + self.convz_glo(glo))
+        r = torch.sigmoid(self.convr(hx) + self.convr_glo(glo))
+        q = torch.tanh(self.convq(torch.cat([r * net, inp], dim=1)) + self.convq_glo(glo))
+        return (1 - z) * net + z * q
+
+
+class GraphAgg(nn.Module):
+    """src/droid_net.py:34-67: per-source-keyframe aggregation -> damping eta + upsampling mask."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(128, 128, 3, padding=1)
+        self.conv2 = nn.Conv2d(128, 128, 3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        self.eta = nn.Sequential(nn.Conv2d(128, 1, 3, padding=1), GradientClip(), nn.Softplus())
+        self.upmask = nn.Sequential(nn.Conv2d(128, 8 * 8 * 9, 1, padding=0))
+
+    def forward(self, net, ii):
+        batch, num, ch, ht, wd = net.shape
+        x = self.relu(self.conv1(net.view(batch * num, ch, ht, wd)))
+        uniq, ix = torch.unique(ii, sorted=True, return_inverse=True)
+        assert batch == 1
+        x = segment_mean(x, ix, uniq.numel())
+        x = self.relu(self.conv2(x))
+        eta = self.eta(x).view(batch, -1, ht, wd)
+        upmask = self.upmask(x).view(batch, -1, 8 * 8 * 9, ht, wd)
+        return 0.01 * eta, upmask
+
+
+class UpdateModule(nn.Module):
+    """src/droid_net.py:70-140."""
+
+    def __init__(self):
+        super().__init__()
+        cor_planes = 4 * (2 * 3 + 1) ** 2
+        self.corr_encoder = nn.Sequential(
+            nn.Conv2d(cor_planes, 128, 1), nn.ReLU(inplace=True),
+            nn.Conv2d(128, 128, 3, padding=1), nn.ReLU(inplace=True))
+        self.flow_encoder = nn.Sequential(
+            nn.Conv2d(4, 128, 7, padding=3), nn.ReLU(inplace=True),
+            nn.Conv2d(128, 64, 3, padding=1), nn.ReLU(inplace=True))
+        self.weight = nn.Sequential(
+            nn.Conv2d(128, 128, 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(128, 2, 3, padding=1), GradientClip(), nn.Sigmoid())
+        self.delta = nn.Sequential(
+            nn.Conv2d(128, 128, 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(128, 2, 3, padding=1), GradientClip())
+        self.gru = ConvGRU(128, 128 + 128 + 64)
+        self.agg = GraphAgg()
+
+    def forward(self, net, inp, corr, flow=None, ii=None, jj=None):
+        batch, num, ch, ht, wd = net.shape
+        if flow is None:
+            flow = torch.zeros(batch, num, 4, ht, wd, device=net.device)
+        out_dim = (batch, num, -1, ht, wd)
+        net = net.view(batch * num, -1, ht, wd)
+        inp = inp.view(batch * num, -1, ht, wd)
+        corr = self.corr_encoder(corr.view(batch * num, -1, ht, wd))
+        flow = self.flow_encoder(flow.view(batch * num, -1, ht, wd))
+        net = self.gru(net, inp, corr, flow)
+        delta = self.delta(net).view(*out_dim).permute(0, 1, 3, 4, 2)[..., :2].contiguous()
+        weight = self.weight(net).view(*out_dim).permute(0, 1, 3, 4, 2)[..., :2].contiguous()
+        net = net.view(*out_dim)
+        if ii is not None:
+            eta, upmask = self.agg(net, ii.to(net.device))
+            return net, delta, weight, eta, upmask
+        return net, delta, weight

@@ -1,0 +1,137 @@
+"""Factor graph over keyframes: edge lists, per-edge GRU state and the `update` hot loop
+(mirrors src/factor_graph.py:24-252 for the volume-correlation frontend path).
+
+update() = reproject (HIP) -> motion features -> 4-level corr lookup (HIP, one launch) ->
+UpdateModule (MIOpen convs) -> dense BA (HIP, no host round trips) -> convex upsampling.
+"""
+import torch
+
+from .corr import CorrBlock
+
+
+def coords_grid(ht, wd, device):
+    y, x = torch.meshgrid(torch.arange(ht, device=device).float(), torch.arange(wd, device=device).float(),
+                          indexing="ij")
+    return torch.stack([x, y], dim=-1)
+
+
+class FactorGraph:
+    def __init__(self, video, update_op, device="cuda:0", corr_impl="volume", max_factors=-1, upsample=False,
+                 channels_last=True):
+        """`channels_last`: keep the per-edge GRU state (net, inp) and the looked-up correlation
+        features in NHWC memory so MIOpen runs its NHWC fp16 kernels (1.4x on the update operator
+        on MI355X); shapes and values are unchanged."""
+        assert corr_impl == "volume", "the low-memory (alt-corr) path lives in update_lowmem"
+        self.channels_last = channels_last
+        self.video = video
+        self.update_op = update_op
+        self.device = torch.device(device)
+        self.max_factors = max_factors
+        self.corr_impl = corr_impl
+        self.upsample = upsample
+        self.ht, self.wd = video.ht, video.wd
+        self.coords0 = coords_grid(self.ht, self.wd, self.device)
+        z = lambda *s: torch.zeros(*s, device=self.device)
+        self.ii = torch.zeros(0, dtype=torch.long, device=self.device)
+        self.jj = torch.zeros(0, dtype=torch.long, device=self.device)
+        self.age = torch.zeros(0, dtype=torch.long, device=self.device)
+        self.corr, self.net, self.inp = None, None, None
+        self.damping = 1e-6 * torch.ones_like(video.disps)
+        self.target = z(1, 0, self.ht, self.wd, 2)
+        self.weight = z(1, 0, self.ht, self.wd, 2)
+        self.ii_inac = torch.zeros(0, dtype=torch.long, device=self.device)
+        self.jj_inac = torch.zeros(0, dtype=torch.long, device=self.device)
+        self.target_inac = z(1, 0, self.ht, self.wd, 2)
+        self.weight_inac = z(1, 0, self.ht, self.wd, 2)
+
+    @torch.no_grad()
+    def add_factors(self, ii, jj, remove=False):
+        """add edges ii->jj (src/factor_graph.py:80-130): builds their correlation pyramids."""
+        ii = torch.as_tensor(ii, dtype=torch.long, device=self.device).reshape(-1)
+        jj = torch.as_tensor(jj, dtype=torch.long, device=self.device).reshape(-1)
+        if ii.numel() == 0:
+            return
+        net = self._fmt(self.video.nets[ii]).unsqueeze(0)
+        c = (ii == jj).long()                       # stereo edges read the right-view feature map
+        fmap1 = self.video.fmaps[ii, 0].unsqueeze(0)
+        fmap2 = self.video.fmaps[jj, c].unsqueeze(0)
+        corr = CorrBlock(fmap1, fmap2, channels_last=self.channels_last)
+        self.corr = corr if self.corr is None else self.corr.cat(corr)
+        inp = self._fmt(self.video.inps[ii]).unsqueeze(0)
+        self.inp = inp if self.inp is None else self._cat_edges(self.inp, inp)
+        with torch.autocast("cuda", enabled=False):
+            target, _ = self.video.reproject(ii, jj)
+            weight = torch.zeros_like(target)
+        self.ii = torch.cat([self.ii, ii])
+        self.jj = torch.cat([self.jj, jj])
+        self.age = torch.cat([self.age, torch.zeros_like(ii)])
+        self.net = net if self.net is None else self._cat_edges(self.net, net)
+        self.target = torch.cat([self.target, target], 1)
+        self.weight = torch.cat([self.weight, weight], 1)
+
+    def _fmt(self, x4):
+        """[E,C,h,w] in the graph's memory format."""
+        return x4.contiguous(memory_format=torch.channels_last) if self.channels_last else x4.contiguous()
+
+    def _cat_edges(self, a5, b5):
+        """cat two [1,E,C,h,w] state tensors over edges, keeping the 4-D memory format."""
+        return self._fmt(torch.cat([a5[0], b5[0]], 0)).unsqueeze(0)
+
+    @torch.no_grad()
+    def rm_factors(self, mask, store=False):
+        """drop edges (src/factor_graph.py:132-158), optionally keeping them as inactive."""
+        if store:
+            self.ii_inac = torch.cat([self.ii_inac, self.ii[mask]])
+            self.jj_inac = torch.cat([self.jj_inac, self.jj[mask]])
+            self.target_inac = torch.cat([self.target_inac, self.target[:, mask]], 1)
+            self.weight_inac = torch.cat([self.weight_inac, self.weight[:, mask]], 1)
+        keep = ~mask
+        self.ii, self.jj, self.age = self.ii[keep], self.jj[keep], self.age[keep]
+        self.corr = self.corr[keep]
+        self.net = self._fmt(self.net[0][keep]).unsqueeze(0)
+        self.inp = self._fmt(self.inp[0][keep]).unsqueeze(0)
+        self.target = self.target[:, keep]
+        self.weight = self.weight[:, keep]
+
+    @torch.no_grad()
+    def update(self, t0=None, t1=None, iters=2, use_inactive=False, EPS=1e-7, motion_only=False):
+        """run the update operator on the factor graph (src/factor_graph.py:199-252)."""
+        coords1, mask = self.video.reproject(self.ii, self.jj)
+        motion = torch.cat([coords1 - self.coords0, self.target - coords1], dim=-1)
+        motion = motion.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
+
+        corr = self.corr(coords1)
+        with torch.autocast("cuda", dtype=torch.float16):
+            self.net, delta, weight, damping, upmask = self.update_op(
+                self.net, self.inp, corr, motion, self.ii, self.jj)
+
+        if t0 is None:
+            t0 = max(1, int(self.ii.min()) + 1)
+        t0 = max(1, t0)
+        if t1 is None:
+            t1 = max(int(self.ii.max()), int(self.jj.max())) + 1
+
+        self.target = coords1 + delta.float()
+        self.weight = weight.float()
+        ht, wd = self.ht, self.wd
+        self.damping[torch.unique(self.ii, sorted=True)] = damping.float()
+
+        if use_inactive:
+            m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
+            ii = torch.cat([self.ii_inac[m], self.ii])
+            jj = torch.cat([self.jj_inac[m], self.jj])
+            target = torch.cat([self.target_inac[:, m], self.target], 1)
+            weight = torch.cat([self.weight_inac[:, m], self.weight], 1)
+        else:
+            ii, jj, target, weight = self.ii, self.jj, self.target, self.weight
+
+        damping_index = torch.unique(torch.cat([torch.arange(t0, t1, device=ii.device), ii]), sorted=True)
+        damping = 0.2 * self.damping[damping_index].contiguous() + EPS
+        target = target.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
+        weight = weight.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
+
+        self.video.ba(target, weight, damping, ii.contiguous(), jj.contiguous(), t0=t0, t1=t1, iters=iters,
+                      lm=1e-4, ep=0.1, motion_only=motion_only)
+        if self.upsample:
+            self.video.upsample(torch.unique(self.ii, sorted=True), upmask[0])
+        self.age += 1

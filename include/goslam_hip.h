@@ -56,11 +56,12 @@ int gs_corr_index_backward(const float* coords, const void* corr_grad, void* vol
 
 /* CorrBlock.__call__ (src/modules/corr.py:43-53) in ONE launch: the 4 pyramid levels
  * vol[l] [n,h1,w1,h2>>l,w2>>l] are sampled at coords/2^l (coords f32 [n,h1,w1,2], the layout
- * FactorGraph hands over) and written as corr [n, 4*(2r+1)^2, h1, w1] (level-major channels). */
+ * FactorGraph hands over) and written as corr [n, 4*(2r+1)^2, h1, w1] (level-major channels);
+ * channels_last != 0 stores the same logical tensor with NHWC strides ([n,h1,w1,196] in memory). */
 int gs_corr_lookup_pyramid(const void* vol0, const void* vol1, const void* vol2, const void* vol3,
                            const float* coords, void* corr,
                            int n, int h1, int w1, int h2, int w2, int radius, int dtype,
-                           gs_stream_t stream);
+                           int channels_last, gs_stream_t stream);
 
 /* ------------------------------------------------------------------- geometry ------ */
 

@@ -119,6 +119,10 @@ def test_corr_lookup_pyramid_matches_four_level_loop(db, O, dev, shape):
     out = db.corr_lookup_pyramid([p.to(dev) for p in pyr], coords.to(dev), 3)
     assert out.dtype == torch.float16 and tuple(out.shape) == (n, 196, ht, wd)
     assert torch.equal(out.cpu(), ref)
+    # same logical tensor, NHWC strides (what the update operator consumes)
+    out_cl = db.corr_lookup_pyramid([p.to(dev) for p in pyr], coords.to(dev), 3, channels_last=True)
+    assert out_cl.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out_cl.cpu(), ref)
 
 
 def test_reproject_matches_oracle_and_identity_kat(db, O, dev):
