@@ -36,7 +36,8 @@ template <> struct VecRow<_Float16> { typedef struct __attribute__((packed, alig
 template <> struct VecRow<float>    { typedef struct __attribute__((packed, aligned(4))) { float v[8]; } type; };
 template <> struct VecRow<double>   { typedef struct __attribute__((packed, aligned(8))) { double v[8]; } type; };
 
-// Sample one level for one pixel; writes 49 taps to out[(i*7+j)*plane].
+// Sample one level for one pixel; writes 49 taps to out[(i*7+j)*plane] (plane == 0: `out` is a
+// 49-entry register array).
 template <typename T>
 __device__ __forceinline__ void lookup_r3(const T* __restrict__ slice, int h2, int w2,
                                           float x0, float y0, T* __restrict__ out, size_t plane) {
@@ -76,9 +77,44 @@ __device__ __forceinline__ void lookup_r3(const T* __restrict__ slice, int h2, i
       c = add_r(c, mul_r(s[i][j + 1], w_sw));
       c = add_r(c, mul_r(s[i + 1][j], w_ne));
       c = add_r(c, mul_r(s[i + 1][j + 1], w_nw));
-      out[(size_t)(i * 7 + j) * plane] = c;
+      out[plane ? (size_t)(i * 7 + j) * plane : (size_t)(i * 7 + j)] = c;
     }
   }
+}
+
+// NHWC emission of one level: the pixel's 196 channels are contiguous (392 B, 8-byte aligned),
+// so taps are packed four at a time into 8-byte stores (49 stores per pixel instead of 196
+// two-byte ones, i.e. 4x fewer write requests at the L2); up to 3 taps carry over to the next level.
+template <typename T, int L>
+__device__ __forceinline__ void emit_nhwc(const T (&lv)[49], T (&carry)[4], T* __restrict__ out) {
+  constexpr int pend = (49 * L) % 4;
+  constexpr int total = pend + 49;
+  constexpr int npk = total / 4;
+  T tmp[52];
+#pragma unroll
+  for (int k = 0; k < pend; ++k) tmp[k] = carry[k];
+#pragma unroll
+  for (int k = 0; k < 49; ++k) tmp[pend + k] = lv[k];
+  T* base = out + 49 * L - pend;
+#pragma unroll
+  for (int q = 0; q < npk; ++q) {
+    struct alignas(4 * sizeof(T)) Pack { T v[4]; } pk;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pk.v[k] = tmp[4 * q + k];
+    *reinterpret_cast<Pack*>(base + 4 * q) = pk;
+  }
+#pragma unroll
+  for (int k = 0; k < total % 4; ++k) carry[k] = tmp[4 * npk + k];
+}
+
+template <typename T, int L>
+__device__ __forceinline__ void level_nhwc(const T* __restrict__ vol, size_t pix, int h2, int w2, float2 c,
+                                           T (&carry)[4], T* __restrict__ out) {
+  const int h2l = h2 >> L, w2l = w2 >> L;
+  const float sc = 1.0f / (float)(1 << L);
+  T lv[49];
+  lookup_r3<T>(vol + pix * (size_t)(h2l * w2l), h2l, w2l, c.x * sc, c.y * sc, lv, 0);
+  emit_nhwc<T, L>(lv, carry, out);
 }
 
 // ---- fused 4-level pyramid lookup: coords [n,h1,w1,2] -> corr [n,4*49,h1,w1] ------------
@@ -93,15 +129,23 @@ __global__ __launch_bounds__(256) void corr_pyramid_kernel(
   if (p >= hw1) return;
   const size_t pix = (size_t)n * hw1 + p;
   const float2 c = reinterpret_cast<const float2*>(coords)[pix];
-  T* out = NHWC ? corr + pix * 196 : corr + (size_t)n * 196 * hw1 + p;
-  const size_t plane = NHWC ? (size_t)1 : (size_t)hw1;
-  const T* vols[4] = {v0, v1, v2, v3};
+  if constexpr (NHWC) {
+    T* out = corr + pix * 196;
+    T carry[4];
+    level_nhwc<T, 0>(v0, pix, h2, w2, c, carry, out);
+    level_nhwc<T, 1>(v1, pix, h2, w2, c, carry, out);
+    level_nhwc<T, 2>(v2, pix, h2, w2, c, carry, out);
+    level_nhwc<T, 3>(v3, pix, h2, w2, c, carry, out);   // (3*49) % 4 + 49 = 52: no remainder
+  } else {
+    T* out = corr + (size_t)n * 196 * hw1 + p;
+    const T* vols[4] = {v0, v1, v2, v3};
 #pragma unroll
-  for (int l = 0; l < 4; ++l) {
-    const int h2l = h2 >> l, w2l = w2 >> l;
-    const float sc = 1.0f / (float)(1 << l);   // coords / 2**l (exact)
-    lookup_r3<T>(vols[l] + pix * (size_t)(h2l * w2l), h2l, w2l, c.x * sc, c.y * sc,
-                 out + (size_t)l * 49 * plane, plane);
+    for (int l = 0; l < 4; ++l) {
+      const int h2l = h2 >> l, w2l = w2 >> l;
+      const float sc = 1.0f / (float)(1 << l);   // coords / 2**l (exact)
+      lookup_r3<T>(vols[l] + pix * (size_t)(h2l * w2l), h2l, w2l, c.x * sc, c.y * sc,
+                   out + (size_t)l * 49 * hw1, (size_t)hw1);
+    }
   }
 }
 
