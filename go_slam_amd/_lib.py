@@ -32,7 +32,27 @@ SIGNATURES = {
     "gs_depth_filter": (c_int, [_P] * 6 + [c_int] * 4 + [_P]),
     "gs_ba_workspace_bytes": (c_size_t, [c_int] * 5),
     "gs_ba": (c_int, [_P] * 9 + [c_int] * 3 + [c_float, c_float] + [c_int] * 6 + [_P, _P, _P, _P, c_size_t, _P]),
+    # include/goslam_neus.h
+    "gs_grid_meta_default": (c_int, [_P]),
+    "gs_render_sample": (c_int, [_P] * 7 + [c_float, _P, _P] + [c_int] * 3 + [_P]),
+    "gs_grid_encode": (c_int, [_P] * 4 + [c_int, _P]),
+    "gs_mlp_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "gs_mlp_forward": (c_int, [_P] * 3 + [c_int] * 3 + [_P, c_size_t, _P]),
+    "gs_neus_forward_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "gs_neus_forward": (c_int, [_P] * 9 + [c_float] + [_P] * 13 + [c_int, c_int, _P, c_size_t, _P]),
 }
+
+
+class GridMeta(ctypes.Structure):
+    """gs_grid_meta of include/goslam_neus.h."""
+    _fields_ = [("scale", c_float * 16), ("resolution", ctypes.c_uint32 * 16), ("size", ctypes.c_uint32 * 16),
+                ("offset", ctypes.c_uint32 * 16), ("hashed", ctypes.c_uint32 * 16), ("total", ctypes.c_uint32)]
+
+
+def grid_meta():
+    m = GridMeta()
+    check(lib().gs_grid_meta_default(ctypes.byref(m)), "gs_grid_meta_default")
+    return m
 
 
 def build(verbose=False):

@@ -1,0 +1,670 @@
+// Mapping hot path: hash-grid NeuS renderer (reference: src/render.py:73-175,
+// src/InstantNeuS.py:12-370; tiny-cuda-nn HashGrid + FullyFusedMLP restated per SURVEY App. B).
+//
+//   render_sample_kernel   one lane per ray: ray/AABB far bound, stratified + near-surface
+//                          samples, merge of the two sorted runs (= the reference's torch.sort)
+//   neus_count_kernel      in-bound count (the reference forces the first 100 points valid when
+//                          no point is in bound, InstantNeuS.py:311-312)
+//   neus_point_kernel      one lane per sample point: 16-level hash-grid gathers (8 corners x
+//                          2 fp16 features = one 4-byte load each; the table is L2/MALL resident),
+//                          the SDF linear row streamed level by level, the ANALYTIC d sdf/d x
+//                          from the same 8 corner values (no autograd graph, no second gather),
+//                          NeuS alpha, and the 80-wide fp16 colour-MLP input row
+//   neus_mlp_kernel        FullyFusedMLP 80->64->64->16 on MFMA (v_mfma_f32_32x32x16_f16):
+//                          H^T = W X^T so that weights are the A operand (kept in VGPRs for the
+//                          whole launch) and the point rows are read as B fragments straight
+//                          from their [point][k] rows; activations between layers go through a
+//                          wave-private LDS tile; sigmoid; fp16 rgb
+//   neus_ray_kernel        one lane per ray: alpha compositing (exclusive cumprod), colour,
+//                          depth, variance, normal, weight sum, per-ray eikonal partial sum
+#include "common.h"
+#include "neus_common.h"
+#include <math.h>
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------
+// sample placement
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void render_sample_kernel(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
+    const float* __restrict__ bound, const float* __restrict__ t_samples, const float* __restrict__ t_surface,
+    const float* __restrict__ perturb, float gt_max, float* __restrict__ z_vals, float* __restrict__ dists,
+    int n, int ns, int nsurf) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const float o[3] = {rays_o[r * 3 + 0], rays_o[r * 3 + 1], rays_o[r * 3 + 2]};
+  const float d[3] = {rays_d[r * 3 + 0], rays_d[r * 3 + 1], rays_d[r * 3 + 2]};
+  // far_bb = min_dim max((b0-o)/d, (b1-o)/d) + 0.01        (render.py:112-118)
+  float far_bb = INFINITY;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float t0 = (bound[2 * k + 0] - o[k]) / d[k];
+    const float t1 = (bound[2 * k + 1] - o[k]) / d[k];
+    // torch.max / torch.min propagate NaN
+    const float tm = (t0 != t0 || t1 != t1) ? NAN : fmaxf(t0, t1);
+    far_bb = (tm != tm || far_bb != far_bb) ? NAN : fminf(far_bb, tm);
+  }
+  far_bb = far_bb + 0.01f;
+  const bool has_depth = gt_depth != nullptr;
+  const float gd = has_depth ? gt_depth[r] : 0.0f;
+  float nearv, farv;
+  if (has_depth) {
+    nearv = gd * 0.01f;
+    farv = fminf(fmaxf(far_bb, 0.0f), gt_max * 1.2f);     // torch.clamp(far_bb, 0, max)
+    if (far_bb != far_bb) farv = far_bb;
+  } else {
+    nearv = 0.01f;
+    farv = far_bb;
+    nsurf = 0;
+  }
+  const int total = ns + nsurf;
+  float* zo = z_vals + (size_t)r * total;
+  float* dd = dists + (size_t)r * total;
+  const float span = farv - nearv;
+  auto zu = [&](int j) { return nearv + span * t_samples[j]; };           // :147
+  auto zs = [&](int j) -> float {                                         // :150-166
+    float z = zu(j);
+    if (perturb) {
+      const float lo = (j == 0) ? z : 0.5f * (zu(j - 1) + z);
+      const float hi = (j == ns - 1) ? z : 0.5f * (z + zu(j + 1));
+      z = lo + (hi - lo) * perturb[j];
+    }
+    return z;
+  };
+  auto zf = [&](int j) -> float {                                         // :126-141
+    const float t = t_surface[j];
+    if (gd > 0.0f) {
+      const float snr = (1.0f - 0.1f) * gd, sfar = (1.0f + 0.1f) * gd;
+      return (snr + (sfar - snr) * t) * 1.0f + (0.001f + (gt_max - 0.001f) * t) * (1.0f - 1.0f);
+    }
+    const float vd = gd * 0.0f;                                           // gt_depth * valid_mask
+    const float snr = (1.0f - 0.1f) * vd, sfar = (1.0f + 0.1f) * vd;
+    return (snr + (sfar - snr) * t) * 0.0f + (0.001f + (gt_max - 0.001f) * t) * (1.0f - 0.0f);
+  };
+  // merge the two ascending runs
+  int a = 0, b = 0;
+  float prev = 0.f;
+  for (int k = 0; k < total; ++k) {
+    float z;
+    if (b >= nsurf) z = zs(a++);
+    else if (a >= ns) z = zf(b++);
+    else {
+      const float za = zs(a), zb = zf(b);
+      if (za <= zb) { z = za; ++a; } else { z = zb; ++b; }
+    }
+    zo[k] = z;
+    if (k > 0) dd[k - 1] = z - prev;
+    prev = z;
+  }
+  dd[total - 1] = span / (float)ns;    // mean over identical columns of (far-near)/N_samples (:149)
+}
+
+// ---------------------------------------------------------------------------------------
+// hash grid
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t grid_index(const gs_grid_meta& m, int l, uint32_t cx, uint32_t cy, uint32_t cz) {
+  const uint32_t size = m.size[l];
+  uint32_t idx;
+  if (m.hashed[l]) {
+    idx = (cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u);
+  } else {
+    const uint32_t res = m.resolution[l];
+    idx = cx + cy * res + cz * res * res;
+  }
+  return idx % size;
+}
+
+// One level: value (2 features) and d value / d x (3 x 2), tcnn accumulation order.
+__device__ __forceinline__ void grid_level(const gs_grid_meta& m, int l, const _Float16* __restrict__ grid,
+                                           const float x[3], float val[2], float dv[3][2], bool want_grad) {
+  const float scale = m.scale[l];
+  float f[3];
+  uint32_t g[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float pos = fmaf(scale, x[d], 0.5f);
+    const float fl = floorf(pos);
+    g[d] = (uint32_t)(int)fl;
+    f[d] = pos - fl;
+  }
+  const _Float16* tab = grid + (size_t)m.offset[l] * 2;
+  float v[8][2];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const uint32_t idx = grid_index(m, l, g[0] + (c & 1), g[1] + ((c >> 1) & 1), g[2] + ((c >> 2) & 1));
+    const uint32_t raw = *reinterpret_cast<const uint32_t*>(tab + (size_t)idx * 2);
+    v[c][0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw & 0xffffu));
+    v[c][1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw >> 16));
+  }
+  val[0] = 0.f; val[1] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float w = 1.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) w = w * (((c >> d) & 1) ? f[d] : (1.0f - f[d]));
+    val[0] = fmaf(w, v[c][0], val[0]);
+    val[1] = fmaf(w, v[c][1], val[1]);
+  }
+  if (want_grad) {
+#pragma unroll
+    for (int gd = 0; gd < 3; ++gd) {
+      const int o0 = (gd == 0) ? 1 : 0, o1 = (gd == 2) ? 1 : 2;   // the two other dims, ascending
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float w = scale;
+        w = w * ((k & 1) ? f[o0] : (1.0f - f[o0]));
+        w = w * ((k & 2) ? f[o1] : (1.0f - f[o1]));
+        const int cl = ((k & 1) << o0) | (((k >> 1) & 1) << o1);
+        const int cr = cl | (1 << gd);
+        a0 = fmaf(w, v[cr][0] - v[cl][0], a0);
+        a1 = fmaf(w, v[cr][1] - v[cl][1], a1);
+      }
+      dv[gd][0] = a0;
+      dv[gd][1] = a1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void grid_encode_kernel(const float* __restrict__ x,
+                                                          const _Float16* __restrict__ grid,
+                                                          _Float16* __restrict__ out, float* __restrict__ dy_dx,
+                                                          int n, gs_grid_meta m) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float xi[3] = {x[i * 3 + 0], x[i * 3 + 1], x[i * 3 + 2]};
+#pragma unroll 1
+  for (int l = 0; l < GS_GRID_LEVELS; ++l) {
+    float val[2], dv[3][2];
+    grid_level(m, l, grid, xi, val, dv, dy_dx != nullptr);
+    out[(size_t)i * 32 + 2 * l + 0] = (_Float16)val[0];
+    out[(size_t)i * 32 + 2 * l + 1] = (_Float16)val[1];
+    if (dy_dx) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) dy_dx[((size_t)i * 32 + 2 * l + f) * 3 + d] = dv[d][f];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// per-point stage
+// ---------------------------------------------------------------------------------------
+struct NeusArgs {
+  const float* rays_o; const float* rays_d; const float* z_vals; const float* dists;
+  const _Float16* grid; const float* sdf_w; const float* sdf_b; const float* color_B;
+  float inv_s;
+  float bound[6]; float rt_bound[6];
+  int n, s;
+};
+
+__device__ __forceinline__ bool point_of(const NeusArgs& A, int idx, float pt[3], float dir[3], float& zm, float& dist) {
+  const int ray = idx / A.s;
+  const float z = A.z_vals[idx];
+  dist = A.dists[idx];
+  zm = z + dist / 2.0f;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    dir[d] = A.rays_d[ray * 3 + d];
+    pt[d] = A.rays_o[ray * 3 + d] + dir[d] * zm;
+  }
+  return (pt[0] < A.rt_bound[1]) && (pt[0] > A.rt_bound[0]) && (pt[1] < A.rt_bound[3]) && (pt[1] > A.rt_bound[2]) &&
+         (pt[2] < A.rt_bound[5]) && (pt[2] > A.rt_bound[4]);
+}
+
+__global__ __launch_bounds__(256) void neus_count_kernel(NeusArgs A, int32_t* __restrict__ count) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  float pt[3], dir[3], zm, dist;
+  const bool in = (idx < A.n * A.s) && point_of(A, idx, pt, dir, zm, dist);
+  const unsigned long long b = __ballot(in);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (int)__popcll(b));
+}
+
+__global__ __launch_bounds__(256) void neus_point_kernel(NeusArgs A, gs_grid_meta m, const int32_t* __restrict__ count,
+                                                         float* __restrict__ sdf_out, float* __restrict__ zmid_out,
+                                                         float* __restrict__ alpha_out, float* __restrict__ grad_out,
+                                                         uint8_t* __restrict__ mask_out, _Float16* __restrict__ mlp_in) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= A.n * A.s) return;
+  float pt[3], dir[3], zm, dist;
+  bool in = point_of(A, idx, pt, dir, zm, dist);
+  if (*count < 1 && idx < 100) in = true;          // InstantNeuS.py:311-312
+  zmid_out[idx] = zm;
+  mask_out[idx] = in ? 1 : 0;
+  if (!in) {                                        // sdf = 100, grad = feat = rgb = 0, alpha * mask = 0
+    sdf_out[idx] = 100.0f;
+    alpha_out[idx] = 0.0f;
+    grad_out[idx * 3 + 0] = 0.f; grad_out[idx * 3 + 1] = 0.f; grad_out[idx * 3 + 2] = 0.f;
+    return;
+  }
+  // normalized_3d_coordinate (InstantNeuS.py:12-32) with the STATIC bound, clamped to [-1,1]
+  float p[3], view[3], inside[3], span[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    span[d] = A.bound[2 * d + 1] - A.bound[2 * d];
+    float q = (pt[d] - A.bound[2 * d]) / span[d] * 2.0f - 1.0f;
+    inside[d] = (q >= -1.0f && q <= 1.0f) ? 1.0f : 0.0f;
+    q = fminf(fmaxf(q, -1.0f), 1.0f);
+    p[d] = q;
+    view[d] = (q + 1.0f) / 2.0f;
+  }
+  // Linear(35 -> 32): xyz part first, then one level (2 inputs) at a time
+  float out[32];
+#pragma unroll
+  for (int o = 0; o < 32; ++o) {
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) acc = fmaf(A.sdf_w[o * 35 + d], p[d], acc);
+    out[o] = acc;
+  }
+  float gview[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int l = 0; l < GS_GRID_LEVELS; ++l) {
+    float val[2], dv[3][2];
+    grid_level(m, l, A.grid, view, val, dv, true);
+    const float e0 = (float)(_Float16)val[0], e1 = (float)(_Float16)val[1];   // encoding output is fp16
+    const float* wl = A.sdf_w + 3 + 2 * l;
+#pragma unroll
+    for (int o = 0; o < 32; ++o) out[o] = fmaf(wl[o * 35 + 1], e1, fmaf(wl[o * 35], e0, out[o]));
+    const float g0 = (float)(_Float16)wl[0], g1 = (float)(_Float16)wl[1];     // dL/d enc arrives as fp16
+#pragma unroll
+    for (int d = 0; d < 3; ++d) gview[d] = fmaf(g1, dv[d][1], fmaf(g0, dv[d][0], gview[d]));
+  }
+#pragma unroll
+  for (int o = 0; o < 32; ++o) out[o] = out[o] + A.sdf_b[o];
+  const float sdf = out[0];
+  float grad[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) grad[d] = (A.sdf_w[d] + gview[d] / 2.0f) * inside[d] * 2.0f / span[d];
+  // NeuS alpha (InstantNeuS.py:276-293), cos_anneal_ratio = 1
+  const float true_cos = (dir[0] * grad[0] + dir[1] * grad[1]) + dir[2] * grad[2];
+  const float iter_cos = -(fmaxf(-true_cos * 0.5f + 0.5f, 0.0f) * 0.0f + fmaxf(-true_cos, 0.0f) * 1.0f);
+  const float est_next = sdf + iter_cos * dist / 2.0f;
+  const float est_prev = sdf - iter_cos * dist / 2.0f;
+  const float prev_cdf = 1.0f / (1.0f + expf(-(est_prev * A.inv_s)));
+  const float next_cdf = 1.0f / (1.0f + expf(-(est_next * A.inv_s)));
+  float alpha = (prev_cdf - next_cdf + 1e-5f) / (prev_cdf + 1e-5f);
+  alpha = fminf(fmaxf(alpha, 0.0f), 1.0f);
+  sdf_out[idx] = sdf;
+  alpha_out[idx] = alpha;
+  grad_out[idx * 3 + 0] = grad[0]; grad_out[idx * 3 + 1] = grad[1]; grad_out[idx * 3 + 2] = grad[2];
+  // colour-MLP input row: sin(pts @ B) (33) | normals (3) | feat (31) | ones (13)
+  _Float16 row[80];
+#pragma unroll
+  for (int c = 0; c < 33; ++c) {
+    const float a = (pt[0] * A.color_B[c] + pt[1] * A.color_B[33 + c]) + pt[2] * A.color_B[66 + c];
+    row[c] = (_Float16)sinf(a);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) row[33 + d] = (_Float16)grad[d];
+#pragma unroll
+  for (int c = 0; c < 31; ++c) row[36 + c] = (_Float16)out[1 + c];
+#pragma unroll
+  for (int c = 67; c < 80; ++c) row[c] = (_Float16)1.0f;
+  half8* dst = reinterpret_cast<half8*>(mlp_in + (size_t)idx * 80);
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+    half8 pk;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pk[k] = row[q * 8 + k];
+    dst[q] = pk;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// fused MLP on MFMA.  H^T[neuron][point] = W[neuron][k] X^T[k][point]
+//   A operand (32 neurons x 16 k): lane l holds W[32*mt + (l&31)][16*ks + 8*(l>>5) .. +7]
+//   B operand (16 k x 32 points) : lane l holds X[32*nt + (l&31)][16*ks + 8*(l>>5) .. +7]
+//   C (32 neurons x 32 points)   : lane l, reg r -> neuron 32*mt + (r&3) + 8*(r>>2) + 4*(l>>5),
+//                                  point 32*nt + (l&31)
+// ---------------------------------------------------------------------------------------
+constexpr int HS = 72;   // LDS row stride (halfs) of the wave-private activation tile [64][64]
+
+__device__ __forceinline__ half8 ld8(const _Float16* p) { return *reinterpret_cast<const half8*>(p); }
+
+template <bool RELU>
+__device__ __forceinline__ void store_act(_Float16* hs, const float16v& c, int mt, int nt, int lane) {
+  const int point = 32 * nt + (lane & 31);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    half4 pk;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v = c[q * 4 + k];
+      if (RELU) v = fmaxf(v, 0.0f);
+      pk[k] = (_Float16)v;
+    }
+    *reinterpret_cast<half4*>(hs + point * HS + 32 * mt + 8 * q + 4 * (lane >> 5)) = pk;
+  }
+}
+
+__global__ __launch_bounds__(256) void neus_mlp_kernel(const _Float16* __restrict__ x, int ld_x,
+                                                       const _Float16* __restrict__ w, const uint8_t* __restrict__ mask,
+                                                       _Float16* __restrict__ out, int n_out, int ld_out, int np,
+                                                       int apply_sigmoid, int n_tiles) {
+  __shared__ _Float16 lds[4][64 * HS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  _Float16* hs = lds[wave];
+  const _Float16* W1 = w;                 // [64][80]
+  const _Float16* W2 = w + 64 * 80;       // [64][64]
+  const _Float16* W3 = w + 64 * 80 + 64 * 64;   // [16][64]
+  const int r = lane & 31, kh = 8 * (lane >> 5);
+  // weights live in registers for the whole launch
+  half8 a1[2][5], a2[2][4], a3[4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) a1[mt][ks] = ld8(W1 + (32 * mt + r) * 80 + 16 * ks + kh);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a2[mt][ks] = ld8(W2 + (32 * mt + r) * 64 + 16 * ks + kh);
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    a3[ks] = (r < 16) ? ld8(W3 + r * 64 + 16 * ks + kh) : z;
+  }
+  // every wave of the workgroup runs the same number of iterations (barriers below); tiles past
+  // the end are computed on clamped rows and never stored
+  for (int t0 = blockIdx.x * 4; t0 < n_tiles; t0 += gridDim.x * 4) {
+    const int tile = t0 + wave;
+    const int p0 = tile * 64;
+    // ---- layer 1: B fragments straight from the [point][80] rows
+    float16v c[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[mt][nt][e] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int pnt = max(0, min(p0 + 32 * nt + r, np - 1));
+      const _Float16* xr = x + (size_t)pnt * ld_x + kh;
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {
+        const half8 b = ld8(xr + 16 * ks);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[mt][ks], b, c[mt][nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) store_act<true>(hs, c[mt][nt], mt, nt, lane);
+    __syncthreads();
+    // ---- layer 2
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[mt][nt][e] = 0.f;
+    half8 bfr[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bfr[nt][ks] = ld8(hs + (32 * nt + r) * HS + 16 * ks + kh);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[mt][ks], bfr[nt][ks], c[mt][nt], 0, 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) store_act<true>(hs, c[mt][nt], mt, nt, lane);
+    __syncthreads();
+    // ---- output layer (16 rows, padded to the 32-row tile with zero weights)
+    float16v co[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) co[nt][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const half8 b = ld8(hs + (32 * nt + r) * HS + 16 * ks + kh);
+        co[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3[ks], b, co[nt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    // neurons 0..3 sit in regs 0..3 of lanes 0..31
+    if (lane < 32) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int pnt = p0 + 32 * nt + lane;
+        if (pnt < np) {
+          const bool on = mask ? (mask[pnt] != 0) : true;
+          for (int o = 0; o < n_out; ++o) {
+            float v = (float)(_Float16)co[nt][o];          // network output is fp16
+            if (apply_sigmoid) v = 1.0f / (1.0f + expf(-v));
+            out[(size_t)pnt * ld_out + o] = on ? (_Float16)v : (_Float16)0.0f;
+          }
+        }
+      }
+    }
+  }
+}
+
+// generic-width input (tcnn.Network API): pad [n, n_in] fp16 rows to 80 with ones
+__global__ __launch_bounds__(256) void mlp_pad_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ xp,
+                                                      int n, int n_in) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)n * 80) return;
+  const int c = (int)(i % 80);
+  const size_t row = i / 80;
+  xp[i] = (c < n_in) ? x[row * n_in + c] : (_Float16)1.0f;
+}
+
+// ---------------------------------------------------------------------------------------
+// per-ray compositing (InstantNeuS.py:343-358)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void neus_ray_kernel(const float* __restrict__ alpha, const _Float16* __restrict__ rgb,
+                                                       const float* __restrict__ zmid, const float* __restrict__ grad,
+                                                       const uint8_t* __restrict__ mask, float* __restrict__ color,
+                                                       float* __restrict__ depth, float* __restrict__ depth_var,
+                                                       float* __restrict__ normal, float* __restrict__ weight_sum,
+                                                       float* __restrict__ gerr, int n, int s) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const size_t b = (size_t)r * s;
+  float T = 1.0f, wsum = 0.f, col[3] = {0.f, 0.f, 0.f}, dep = 0.f, nrm[3] = {0.f, 0.f, 0.f}, ge = 0.f;
+  for (int k = 0; k < s; ++k) {
+    const float a = alpha[b + k];
+    const float w = a * T;
+    T = T * (1.0f - a + 1e-7f);
+    wsum += w;
+    dep += zmid[b + k] * w;
+    const float mk = mask[b + k] ? 1.0f : 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      col[d] += (float)rgb[(b + k) * 3 + d] * w;
+      nrm[d] += grad[(b + k) * 3 + d] * w * mk;
+    }
+    const float gx = grad[(b + k) * 3 + 0], gy = grad[(b + k) * 3 + 1], gz = grad[(b + k) * 3 + 2];
+    const float nr = sqrtf((gx * gx + gy * gy) + gz * gz) - 1.0f;
+    ge += nr * nr * mk;
+  }
+  // second pass needs the final depth; the running product is cheap to redo and avoids a
+  // per-ray scratch array
+  float var = 0.f;
+  T = 1.0f;
+  for (int k = 0; k < s; ++k) {
+    const float a = alpha[b + k];
+    const float w = a * T;
+    T = T * (1.0f - a + 1e-7f);
+    const float dz = zmid[b + k] - dep;
+    var += dz * dz * w;
+  }
+  color[r * 3 + 0] = col[0]; color[r * 3 + 1] = col[1]; color[r * 3 + 2] = col[2];
+  normal[r * 3 + 0] = nrm[0]; normal[r * 3 + 1] = nrm[1]; normal[r * 3 + 2] = nrm[2];
+  depth[r] = dep;
+  depth_var[r] = var;
+  weight_sum[r] = wsum;
+  gerr[r] = ge;
+}
+
+gs_grid_meta host_meta() {
+  gs_grid_meta m;
+  gs_grid_meta_default(&m);
+  return m;
+}
+
+}  // namespace
+
+extern "C" int gs_grid_meta_default(gs_grid_meta* m) {
+  if (!m) return GS_ERR_INVALID_ARG;
+  // tcnn grid.h: grid_scale / grid_resolution / params_in_level in fp32
+  const float log2_s = log2f(1.447269237440378f);
+  uint32_t total = 0;
+  for (int l = 0; l < GS_GRID_LEVELS; ++l) {
+    const float scale = exp2f((float)l * log2_s) * 16.0f - 1.0f;
+    const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+    const double dense = (double)res * res * res;
+    uint64_t n = dense > 4294967295.0 ? 4294967295ull : (uint64_t)dense;
+    n = (n + 7) / 8 * 8;
+    if (n > (1u << 19)) n = 1u << 19;
+    m->scale[l] = scale;
+    m->resolution[l] = res;
+    m->size[l] = (uint32_t)n;
+    m->offset[l] = total;
+    m->hashed[l] = dense > (double)n ? 1u : 0u;
+    total += (uint32_t)n;
+  }
+  m->total = total;
+  return GS_OK;
+}
+
+extern "C" int gs_render_sample(const float* rays_o, const float* rays_d, const float* gt_depth, const float* bound,
+                                const float* t_samples, const float* t_surface, const float* perturb, float gt_max,
+                                float* z_vals, float* dists, int n, int n_samples, int n_surface,
+                                gs_stream_t stream) {
+  GS_REQUIRE(rays_o && rays_d && bound && t_samples && z_vals && dists, "render_sample: null pointer");
+  GS_REQUIRE(n >= 0 && n_samples > 0 && n_surface >= 0, "render_sample: bad shape");
+  GS_REQUIRE(n_surface == 0 || t_surface, "render_sample: t_surface required");
+  if (n == 0) return GS_OK;
+  render_sample_kernel<<<gs_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(
+      rays_o, rays_d, gt_depth, bound, t_samples, t_surface, perturb, gt_max, z_vals, dists, n, n_samples,
+      gt_depth ? n_surface : 0);
+  GS_CHECK_LAUNCH("render_sample");
+  return GS_OK;
+}
+
+extern "C" int gs_grid_encode(const float* x, const void* grid, void* out, float* dy_dx, int n, gs_stream_t stream) {
+  GS_REQUIRE(x && grid && out, "grid_encode: null pointer");
+  GS_REQUIRE(n >= 0, "grid_encode: bad n");
+  if (n == 0) return GS_OK;
+  grid_encode_kernel<<<gs_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(x, (const _Float16*)grid, (_Float16*)out, dy_dx,
+                                                                       n, host_meta());
+  GS_CHECK_LAUNCH("grid_encode");
+  return GS_OK;
+}
+
+extern "C" size_t gs_mlp_workspace_bytes(int n, int n_in) { return n_in == 80 ? 0 : gs_align((size_t)n * 80 * 2) + 256; }
+
+extern "C" int gs_mlp_forward(const void* x, const void* mlp, void* out, int n, int n_in, int n_out,
+                              void* workspace, size_t workspace_bytes, gs_stream_t stream) {
+  GS_REQUIRE(x && mlp && out, "mlp_forward: null pointer");
+  GS_REQUIRE(n >= 0 && n_in > 0 && n_in <= 80 && n_out > 0 && n_out <= 4,
+             "mlp_forward: only the InstantNeuS shape (<=80 inputs, 64x64 hidden, <=4 used outputs) is built");
+  if (n == 0) return GS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const _Float16* xp = (const _Float16*)x;
+  if (n_in != 80) {
+    const size_t need = gs_mlp_workspace_bytes(n, n_in);
+    if (!workspace || workspace_bytes < need) {
+      gs_set_error("mlp_forward: workspace too small (%zu < %zu)", workspace_bytes, need);
+      return GS_ERR_WORKSPACE;
+    }
+    _Float16* pad = (_Float16*)gs_align((size_t)workspace);
+    mlp_pad_kernel<<<(unsigned)(((size_t)n * 80 + 255) / 256), 256, 0, st>>>((const _Float16*)x, pad, n, n_in);
+    GS_CHECK_LAUNCH("mlp_pad");
+    xp = pad;
+  }
+  const int n_tiles = gs_cdiv(n, 64);
+  const int grid = n_tiles < 4 ? 1 : (gs_cdiv(n_tiles, 4) < 1024 ? gs_cdiv(n_tiles, 4) : 1024);
+  neus_mlp_kernel<<<grid, 256, 0, st>>>(xp, 80, (const _Float16*)mlp, nullptr, (_Float16*)out, n_out, n_out, n, 0,
+                                        n_tiles);
+  GS_CHECK_LAUNCH("mlp_forward");
+  return GS_OK;
+}
+
+namespace {
+struct NeusWs {
+  int32_t* count; float* alpha; float* grad; uint8_t* mask; _Float16* mlp_in; _Float16* rgb; size_t total;
+};
+NeusWs carve_neus(void* base, int n, int s) {
+  NeusWs w;
+  size_t off = 0;
+  const size_t np = (size_t)n * s;
+  auto take = [&](size_t bytes) { size_t o = off; off += gs_align(bytes); return (char*)base + o; };
+  w.count = (int32_t*)take(64);
+  w.alpha = (float*)take(np * 4);
+  w.grad = (float*)take(np * 12);
+  w.mask = (uint8_t*)take(np);
+  w.mlp_in = (_Float16*)take(np * 80 * 2);
+  w.rgb = (_Float16*)take(np * 3 * 2 + 64);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t gs_neus_forward_workspace_bytes(int n, int s) {
+  if (n < 0 || s < 0) return 0;
+  return carve_neus(nullptr, n, s).total + 256;
+}
+
+extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const float* z_vals, const float* dists,
+                               const void* grid, const float* sdf_w, const float* sdf_b, const float* color_B,
+                               const void* mlp, float inv_s, const float* bound_host, const float* rt_bound_host,
+                               float* color, float* depth, float* depth_var, float* normal, float* weight_sum,
+                               float* sdf, float* z_mid, float* grad_err_ray, float* alpha_out, void* rgb_out,
+                               float* grad_out, int n, int s, void* workspace, size_t workspace_bytes,
+                               gs_stream_t stream) {
+  GS_REQUIRE(rays_o && rays_d && z_vals && dists && grid && sdf_w && sdf_b && color_B && mlp && bound_host &&
+                 rt_bound_host, "neus_forward: null input");
+  GS_REQUIRE(color && depth && depth_var && normal && weight_sum && sdf && z_mid && grad_err_ray,
+             "neus_forward: null output");
+  GS_REQUIRE(n >= 0 && s > 0, "neus_forward: bad shape");
+  if (n == 0) return GS_OK;
+  const size_t need = gs_neus_forward_workspace_bytes(n, s);
+  if (!workspace || workspace_bytes < need) {
+    gs_set_error("neus_forward: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return GS_ERR_WORKSPACE;
+  }
+  NeusWs ws = carve_neus((void*)gs_align((size_t)workspace), n, s);
+  hipStream_t st = (hipStream_t)stream;
+  NeusArgs A;
+  A.rays_o = rays_o; A.rays_d = rays_d; A.z_vals = z_vals; A.dists = dists;
+  A.grid = (const _Float16*)grid; A.sdf_w = sdf_w; A.sdf_b = sdf_b; A.color_B = color_B;
+  A.inv_s = inv_s;
+  for (int k = 0; k < 6; ++k) { A.bound[k] = bound_host[k]; A.rt_bound[k] = rt_bound_host[k]; }
+  A.n = n; A.s = s;
+  const int np = n * s;
+  float* alpha = alpha_out ? alpha_out : ws.alpha;
+  float* grad = grad_out ? grad_out : ws.grad;
+  _Float16* rgb = rgb_out ? (_Float16*)rgb_out : ws.rgb;
+  if (hipMemsetAsync(ws.count, 0, 4, st) != hipSuccess) { gs_set_error("neus_forward: memset failed"); return GS_ERR_LAUNCH; }
+  neus_count_kernel<<<gs_cdiv(np, 256), 256, 0, st>>>(A, ws.count);
+  GS_CHECK_LAUNCH("neus_count");
+  neus_point_kernel<<<gs_cdiv(np, 256), 256, 0, st>>>(A, host_meta(), ws.count, sdf, z_mid, alpha, grad, ws.mask,
+                                                      ws.mlp_in);
+  GS_CHECK_LAUNCH("neus_point");
+  const int n_tiles = gs_cdiv(np, 64);
+  const int grid_mlp = gs_cdiv(n_tiles, 4) < 1024 ? gs_cdiv(n_tiles, 4) : 1024;
+  neus_mlp_kernel<<<grid_mlp, 256, 0, st>>>(ws.mlp_in, 80, (const _Float16*)mlp, ws.mask, rgb, 3, 3, np, 1, n_tiles);
+  GS_CHECK_LAUNCH("neus_mlp");
+  neus_ray_kernel<<<gs_cdiv(n, 256), 256, 0, st>>>(alpha, rgb, z_mid, grad, ws.mask, color, depth, depth_var, normal,
+                                                   weight_sum, grad_err_ray, n, s);
+  GS_CHECK_LAUNCH("neus_ray");
+  return GS_OK;
+}

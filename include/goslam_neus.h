@@ -1,0 +1,82 @@
+/*
+ * goslam_neus.h -- C ABI of the mapping hot path (hash-grid NeuS renderer) in libgoslam_hip.so.
+ *
+ * Replaces the reference's use of tiny-cuda-nn (`tcnn.Encoding`, `tcnn.Network`;
+ * reference src/InstantNeuS.py:62,192) and the PyTorch op chains of
+ * `Renderer.render_batch_ray` (src/render.py:73-175) and `InstantNeuS.forward`
+ * (src/InstantNeuS.py:295-370).  Conventions as in goslam_hip.h: device pointers unless the name
+ * ends in `_host`, dense row-major tensors, hipStream_t as void*, no sync / no allocation.
+ */
+#ifndef GOSLAM_NEUS_H
+#define GOSLAM_NEUS_H
+
+#include "goslam_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Hash-grid geometry shared by host and device (tiny-cuda-nn HashGrid as configured at
+ * src/InstantNeuS.py:44-52: 16 levels x 2 features, T=2^19, base 16, scale 1.447269237440378). */
+#define GS_GRID_LEVELS 16
+#define GS_GRID_FEATS 2
+typedef struct {
+  float scale[GS_GRID_LEVELS];
+  uint32_t resolution[GS_GRID_LEVELS];
+  uint32_t size[GS_GRID_LEVELS];     /* entries in the level's table */
+  uint32_t offset[GS_GRID_LEVELS];   /* first entry of the level in the flat table */
+  uint32_t hashed[GS_GRID_LEVELS];   /* 1 if the level is hashed, 0 if dense */
+  uint32_t total;                    /* total entries (x GS_GRID_FEATS parameters) */
+} gs_grid_meta;
+
+/* Fill `meta_host` for the InstantNeuS configuration (tcnn grid.h constructor arithmetic). */
+int gs_grid_meta_default(gs_grid_meta* meta_host);
+
+/* Renderer.render_batch_ray sample placement (src/render.py:99-171): ray/AABB far bound,
+ * stratified + near-surface samples, per-ray sort (merge of the two sorted runs), dists.
+ *   rays_o/rays_d f32 [n,3]; gt_depth f32 [n] or NULL (then n_surface is ignored);
+ *   bound f32 [3,2] (device); t_samples f32 [n_samples] = torch.linspace(0,1,n_samples),
+ *   t_surface f32 [n_surface] likewise; perturb f32 [n_samples] = the shared
+ *   torch.rand(N_samples) vector (:159) or NULL; gt_max = gt_depth.max() (host scalar);
+ *   -> z_vals, dists f32 [n, n_samples + n_surface].                                          */
+int gs_render_sample(const float* rays_o, const float* rays_d, const float* gt_depth,
+                     const float* bound, const float* t_samples, const float* t_surface,
+                     const float* perturb, float gt_max, float* z_vals, float* dists,
+                     int n, int n_samples, int n_surface, gs_stream_t stream);
+
+/* tcnn.Encoding.__call__ (src/InstantNeuS.py:62,86): x f32 [n,3] in [0,1], grid f16
+ * [total*2] -> out f16 [n,32]; optional dy_dx f32 [n,32,3] (analytic d out / d x).            */
+int gs_grid_encode(const float* x, const void* grid, void* out, float* dy_dx, int n,
+                   gs_stream_t stream);
+
+/* tcnn.Network.__call__ (src/InstantNeuS.py:192,201): FullyFusedMLP n_in(->80, padded with
+ * ones)->64->64->n_out(->16), ReLU, no bias; mlp f16 [64*80+64*64+16*64] row-major [out,in] per
+ * layer; x f16 [n,n_in] -> out f16 [n,n_out].  Workspace only needed when n_in != 80.         */
+size_t gs_mlp_workspace_bytes(int n, int n_in);
+int gs_mlp_forward(const void* x, const void* mlp, void* out, int n, int n_in, int n_out,
+                   void* workspace, size_t workspace_bytes, gs_stream_t stream);
+
+/* InstantNeuS.forward (src/InstantNeuS.py:295-370) for one chunk of rays, forward only:
+ * hash-grid encode + SDF linear + analytic SDF gradient + NeuS alpha + colour MLP + compositing.
+ *   grid f16 [total*2], sdf_w f32 [32,35], sdf_b f32 [32], color_B f32 [3,33], mlp f16 [10240];
+ *   inv_s = clip(exp(10*variance), 1e-6, 1e6) (host scalar);
+ *   bound_host / rt_bound_host: HOST f32 [3,2] (static bound for normalisation, realtime bound
+ *   for the in-bound mask; 6 floats each, passed by value to the kernels).
+ * Outputs f32: color [n,3], depth [n], depth_var [n], normal [n,3], weight_sum [n], sdf [n,s],
+ *   z_mid [n,s] (= z_vals + dists/2), grad_err_ray [n] (per-ray sum of (|grad|-1)^2 * mask; the
+ *   caller divides the total by n*s); optional per-point alpha f32 [n,s], rgb f16 [n,s,3],
+ *   grad f32 [n,s,3] (NULL = keep in the workspace).                                           */
+size_t gs_neus_forward_workspace_bytes(int n, int s);
+int gs_neus_forward(const float* rays_o, const float* rays_d, const float* z_vals,
+                    const float* dists, const void* grid, const float* sdf_w, const float* sdf_b,
+                    const float* color_B, const void* mlp, float inv_s,
+                    const float* bound_host, const float* rt_bound_host,
+                    float* color, float* depth, float* depth_var, float* normal,
+                    float* weight_sum, float* sdf, float* z_mid, float* grad_err_ray,
+                    float* alpha_out, void* rgb_out, float* grad_out, int n, int s,
+                    void* workspace, size_t workspace_bytes, gs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOSLAM_NEUS_H */

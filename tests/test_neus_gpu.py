@@ -1,0 +1,187 @@
+"""GPU parity of the mapping hot path (hash-grid NeuS renderer) vs oracle/neus_oracle.py.
+
+Tolerances: sample placement bit-exact (ray/box intersection and sorted samples);
+hash indices bit-exact (checked through dense/hash KAT levels); grid features fp16-level
+(atol 1 fp16 ulp of the level amplitude); dy_dx rtol 1e-4; MLP fp16-level rtol 5e-3/atol 2e-3;
+full forward: sdf rtol 1e-4, alpha atol 2e-4, colour/depth atol 3e-3 (fp16 rgb), grad rtol 1e-3.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def N(built_lib):
+    import go_slam_amd.neus as neus
+    return neus
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import neus_oracle
+    return neus_oracle
+
+
+def _rays(n, seed=1, zero_frac=0.1):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.rand(n, 3, generator=g) * 4 - 2
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+    gt = torch.rand(n, generator=g) * 3.5 + 0.5
+    gt[torch.rand(n, generator=g) < zero_frac] = 0
+    return o, d, gt
+
+
+def _load(model, P):
+    with torch.no_grad():
+        model.sdf_network.encoding.encoding.params.copy_(P["grid"])
+        model.sdf_network.sdf_layer.weight.copy_(P["sdf_w"])
+        model.sdf_network.sdf_layer.bias.copy_(P["sdf_b"])
+        model.color_network._B.copy_(P["color_B"])
+        model.color_network.network.params.copy_(P["mlp"])
+        model.variance_network.variance.fill_(P["variance"])
+
+
+@pytest.mark.parametrize("with_depth,perturb", [(True, True), (True, False), (False, True)])
+def test_render_sample_bit_exact(N, O, dev, with_depth, perturb):
+    o, d, gt = _rays(257, seed=3)
+    bound = torch.tensor([[-5.0, 5.0], [-4.0, 4.5], [-3.0, 6.0]])
+    g = torch.Generator().manual_seed(9)
+    pr = torch.rand(24, generator=g) if perturb else None
+    zr, dr = O.render_sample(o, d, gt if with_depth else None, bound, 24, 48, pr)
+    R = N.Renderer(N_samples=24, N_surface=48, perturb=1.0 if perturb else 0.0)
+    z, dd = R.sample(o.to(dev), d.to(dev), bound.to(dev), gt.to(dev) if with_depth else None,
+                     pr.to(dev) if perturb else None)
+    assert z.shape == zr.shape
+    assert torch.equal(z.cpu(), zr), f"max diff {(z.cpu() - zr).abs().max()}"
+    assert torch.equal(dd.cpu()[:, :-1], dr[:, :-1])
+    # last column = mean over N_samples identical values of (far-near)/N_samples (render.py:149):
+    # the reduction order of that mean is backend-defined, so 1-2 ulp is the meaningful bar
+    torch.testing.assert_close(dd.cpu()[:, -1], dr[:, -1], rtol=3e-7, atol=0)
+
+
+def test_grid_encode_matches_oracle(N, O, dev):
+    P = O.make_params(2, grid_init=0.5)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(500, 3, generator=g)
+    x[0] = 0.0
+    x[1] = 1.0                      # the far corner (resolution edge)
+    x[2] = torch.tensor([0.5, 0.25, 0.125])
+    enc_r, dy_r = O.grid_encode(x, P["grid"], want_grad=True)
+    enc_m = N.Encoding(3, dict(otype="HashGrid")).to(dev)
+    with torch.no_grad():
+        enc_m.params.copy_(P["grid"])
+        enc, dy = enc_m(x.to(dev), return_dy_dx=True)
+    assert enc.dtype == torch.float16 and tuple(enc.shape) == (500, 32)
+    # fp16 rounding of an fp32 interpolation: at most 1 ulp apart
+    diff = (enc.cpu().float() - enc_r.float()).abs()
+    ulp = torch.maximum(enc_r.float().abs(), torch.tensor(6e-5)) * 2 ** -10
+    assert (diff <= ulp).all(), float((diff / ulp).max())
+    assert (diff == 0).float().mean() > 0.999
+    torch.testing.assert_close(dy.cpu(), dy_r, rtol=1e-4, atol=1e-5)
+
+
+def test_grid_meta_matches_oracle(N, O):
+    from go_slam_amd import _lib
+    m = _lib.grid_meta()
+    r = O.grid_meta()
+    assert list(m.resolution) == r["resolution"].tolist()
+    assert list(m.size) == r["size"].tolist()
+    assert list(m.offset) == r["offset"].tolist()
+    assert list(m.hashed) == r["hashed"].tolist()
+    assert [float(v) for v in m.scale] == [float(v) for v in r["scale"]], "fp32 level scales must agree bit-for-bit"
+    assert int(m.total) * 2 == 12599920
+
+
+@pytest.mark.parametrize("n", [1, 64, 1000])
+def test_mlp_matches_oracle(N, O, dev, n):
+    P = O.make_params(5)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(n, 67, generator=g)
+    ref = O.mlp_forward(x, P["mlp"])
+    net = N.Network(67, 3, dict(otype="FullyFusedMLP", activation="ReLU", output_activation="none", n_neurons=64,
+                                n_hidden_layers=2)).to(dev)
+    with torch.no_grad():
+        net.params.copy_(P["mlp"])
+        out = net(x.to(dev))
+    assert out.dtype == torch.float16 and tuple(out.shape) == (n, 3)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=5e-3, atol=2e-3)
+
+
+def test_mlp_layout_is_not_transposed(N, dev):
+    """Asymmetric weights: output o must depend on W3 row o only (catches a row/col swap)."""
+    net = N.Network(67, 3).to(dev)
+    w = torch.zeros(64 * 80 + 64 * 64 + 16 * 64)
+    W1 = w[:5120].view(64, 80); W2 = w[5120:5120 + 4096].view(64, 64); W3 = w[9216:].view(16, 64)
+    W1[5, 7] = 1.0       # hidden1[5] = x[7]
+    W2[9, 5] = 2.0       # hidden2[9] = 2 * hidden1[5]
+    W3[1, 9] = 0.5       # out[1] = 0.5 * hidden2[9]
+    with torch.no_grad():
+        net.params.copy_(w)
+        x = torch.zeros(3, 67)
+        x[:, 7] = torch.tensor([1.0, 2.0, -1.0])
+        out = net(x.to(dev)).cpu().float()
+    assert torch.allclose(out[:, 1], torch.tensor([1.0, 2.0, 0.0]))
+    assert out[:, 0].abs().max() == 0 and out[:, 2].abs().max() == 0
+
+
+@pytest.mark.parametrize("grid_init", [1e-4, 0.3])
+def test_neus_forward_matches_oracle(N, O, dev, grid_init):
+    P = O.make_params(7, grid_init=grid_init, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    P["rt_bound"] = torch.tensor([[-2.2, 2.3], [-2.4, 2.1], [-2.0, 2.2]])
+    o, d, gt = _rays(300, seed=8)
+    g = torch.Generator().manual_seed(10)
+    z, dist = O.render_sample(o, d, gt, P["bound"], 24, 48, torch.rand(24, generator=g))
+    ref = O.neus_forward(o, d, z, dist, P)
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    model.update_bound(P["rt_bound"])
+    with torch.no_grad():
+        out = model(o.to(dev), d.to(dev), z.to(dev), dist.to(dev))
+    assert set(out) == {"color", "depth", "depth_variance", "normal", "weight_sum", "sdf_variance", "sdf", "z_vals",
+                        "gradient_error"}
+    c = {k: v.cpu() for k, v in out.items()}
+    assert torch.equal(c["z_vals"], ref["z_vals"])
+    assert torch.equal(c["sdf"] == 100.0, ref["sdf"] == 100.0), "in-bound masks must agree exactly"
+    torch.testing.assert_close(c["sdf"], ref["sdf"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(c["weight_sum"], ref["weight_sum"], rtol=0, atol=5e-4)
+    torch.testing.assert_close(c["depth"], ref["depth"], rtol=0, atol=2e-3)
+    torch.testing.assert_close(c["depth_variance"], ref["depth_variance"], rtol=1e-2, atol=2e-3)
+    torch.testing.assert_close(c["color"], ref["color"], rtol=0, atol=4e-3)
+    torch.testing.assert_close(c["normal"], ref["normal"], rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(c["gradient_error"], ref["gradient_error"], rtol=2e-3, atol=1e-5)
+    torch.testing.assert_close(c["sdf_variance"], ref["sdf_variance"])
+
+
+def test_neus_forward_no_point_in_bound_forces_first_100(N, O, dev):
+    """Q14 (InstantNeuS.py:311-312): realtime bound far away => first 100 points forced valid."""
+    P = O.make_params(11, grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    P["rt_bound"] = torch.tensor([[50.0, 51.0], [50.0, 51.0], [50.0, 51.0]])
+    o, d, gt = _rays(8, seed=12)
+    z, dist = O.render_sample(o, d, gt, P["bound"], 24, 48, None)
+    ref = O.neus_forward(o, d, z, dist, P)
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    model.update_bound(P["rt_bound"])
+    with torch.no_grad():
+        out = model(o.to(dev), d.to(dev), z.to(dev), dist.to(dev))
+    assert int((out["sdf"] != 100.0).sum()) == 100 == int((ref["sdf"] != 100.0).sum())
+    torch.testing.assert_close(out["sdf"].cpu(), ref["sdf"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(out["color"].cpu(), ref["color"], rtol=0, atol=4e-3)
+
+
+def test_training_path_fails_loudly(N, dev):
+    model = N.InstantNeuS({}, [[-1, 1]] * 3).to(dev)
+    o = torch.zeros(4, 3, device=dev)
+    d = torch.ones(4, 3, device=dev)
+    z = torch.rand(4, 8, device=dev)
+    with pytest.raises(NotImplementedError):
+        model(o, d, z, z)
