@@ -135,6 +135,33 @@ def op_breakdown(video, update_op, graph):
     return out
 
 
+def neus_render_bench(device, n_rays=4096, iters=20):
+    """Second half of the BASELINE metric: NeuS render rays/s = N / wall time of
+    Renderer.render_batch_ray (+ InstantNeuS.forward) for N rays x 72 samples, forward only."""
+    import go_slam_amd.neus as neus
+    g = torch.Generator().manual_seed(43)
+    model = neus.InstantNeuS({}, [[-5.0, 5.0]] * 3).to(device)
+    with torch.no_grad():       # non-degenerate ("trained-like") field, SURVEY 8(d)
+        model.sdf_network.encoding.encoding.params.copy_((torch.rand(model.sdf_network.encoding.encoding.params.shape, generator=g) - 0.5) * 0.1)
+        model.sdf_network.sdf_layer.weight[:, 3:] = torch.randn(32, 32, generator=g).to(device) * 0.1
+    R = neus.Renderer(N_samples=24, N_surface=48)
+    o = (torch.rand(n_rays, 3, generator=g) * 6 - 3).to(device)
+    d = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=1).to(device)
+    gt = torch.rand(n_rays, generator=g) * 3.5 + 0.5
+    gt[torch.rand(n_rays, generator=g) < 0.1] = 0
+    gt = gt.to(device)
+    with torch.no_grad():
+        ms = time_op(lambda: R.render_batch_ray(o, d, model, None, device, gt), iters=iters, warm=3)
+        z, dist = R.sample(o, d, model.bound, gt)
+        ms_fwd = time_op(lambda: model(o, d, z, dist), iters=iters, warm=3)
+    pts = n_rays * 72
+    return {"metric": "NeuS render rays/s (Renderer.render_batch_ray + InstantNeuS.forward, 72 samples/ray)",
+            "value": n_rays / (ms * 1e-3), "unit": "rays/s", "rays_per_batch": n_rays, "ms_per_batch": ms,
+            "forward_ms": ms_fwd, "dtype": "f16 grid/MLP, f32 elsewhere",
+            # SURVEY 8(d): 512 B of grid gathers per sample point (L2 / Infinity-Cache resident table)
+            "gather_GBps": pts * 512.0 / (ms_fwd * 1e-3) / 1e9}
+
+
 def cpu_baseline(sample_updates=1):
     """The CPU oracle (+ the same UpdateModule on the host, fp32) on a bounded sample of the same
     workload: `sample_updates` update calls = sample_updates/6 keyframe."""
@@ -244,6 +271,7 @@ def main():
                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                             "algorithmic_bytes_per_launch": algo_bytes}
+        line["neus_render"] = neus_render_bench(device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(3)
         print(json.dumps(line))

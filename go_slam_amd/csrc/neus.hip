@@ -104,6 +104,84 @@ __global__ __launch_bounds__(256) void render_sample_kernel(
   dd[total - 1] = span / (float)ns;    // mean over identical columns of (far-near)/N_samples (:149)
 }
 
+// Wave-per-ray variant (n_samples, n_surface <= 64): lane j owns stratified sample j and
+// near-surface sample j; the merge position of each is its index plus its rank in the other run
+// (ties resolved like the sequential merge: stratified first), so every lane writes its own
+// slot and all global traffic is coalesced.  Values are bit-identical to the sequential kernel.
+__global__ __launch_bounds__(256) void render_sample_wave_kernel(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
+    const float* __restrict__ bound, const float* __restrict__ t_samples, const float* __restrict__ t_surface,
+    const float* __restrict__ perturb, float gt_max, float* __restrict__ z_vals, float* __restrict__ dists,
+    int n, int ns, int nsurf) {
+  __shared__ float sa[4][64], sb[4][64], sz[4][128];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= n) return;
+  float far_bb = INFINITY;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float o = rays_o[r * 3 + k], d = rays_d[r * 3 + k];
+    const float t0 = (bound[2 * k + 0] - o) / d;
+    const float t1 = (bound[2 * k + 1] - o) / d;
+    const float tm = (t0 != t0 || t1 != t1) ? NAN : fmaxf(t0, t1);
+    far_bb = (tm != tm || far_bb != far_bb) ? NAN : fminf(far_bb, tm);
+  }
+  far_bb = far_bb + 0.01f;
+  const bool has_depth = gt_depth != nullptr;
+  const float gd = has_depth ? gt_depth[r] : 0.0f;
+  float nearv, farv;
+  if (has_depth) {
+    nearv = gd * 0.01f;
+    farv = fminf(fmaxf(far_bb, 0.0f), gt_max * 1.2f);
+    if (far_bb != far_bb) farv = far_bb;
+  } else {
+    nearv = 0.01f;
+    farv = far_bb;
+    nsurf = 0;
+  }
+  const int total = ns + nsurf;
+  const float span = farv - nearv;
+  auto zu = [&](int j) { return nearv + span * t_samples[j]; };
+  float za = INFINITY, zb = INFINITY;
+  if (lane < ns) {
+    const int j = lane;
+    float z = zu(j);
+    if (perturb) {
+      const float lo = (j == 0) ? z : 0.5f * (zu(j - 1) + z);
+      const float hi = (j == ns - 1) ? z : 0.5f * (z + zu(j + 1));
+      z = lo + (hi - lo) * perturb[j];
+    }
+    za = z;
+  }
+  if (lane < nsurf) {
+    const float t = t_surface[lane];
+    if (gd > 0.0f) {
+      const float snr = (1.0f - 0.1f) * gd, sfar = (1.0f + 0.1f) * gd;
+      zb = (snr + (sfar - snr) * t) * 1.0f + (0.001f + (gt_max - 0.001f) * t) * (1.0f - 1.0f);
+    } else {
+      const float vd = gd * 0.0f;
+      const float snr = (1.0f - 0.1f) * vd, sfar = (1.0f + 0.1f) * vd;
+      zb = (snr + (sfar - snr) * t) * 0.0f + (0.001f + (gt_max - 0.001f) * t) * (1.0f - 0.0f);
+    }
+  }
+  sa[wave][lane] = za;
+  sb[wave][lane] = zb;
+  __syncthreads();
+  int ra = 0, rb = 0;      // #surface < za ; #stratified <= zb
+  for (int k = 0; k < nsurf; ++k) ra += (sb[wave][k] < za) ? 1 : 0;
+  for (int k = 0; k < ns; ++k) rb += (sa[wave][k] <= zb) ? 1 : 0;
+  if (lane < ns) sz[wave][lane + ra] = za;
+  if (lane < nsurf) sz[wave][lane + rb] = zb;
+  __syncthreads();
+  float* zo = z_vals + (size_t)r * total;
+  float* dd = dists + (size_t)r * total;
+  for (int k = lane; k < total; k += 64) {
+    const float z = sz[wave][k];
+    zo[k] = z;
+    dd[k] = (k + 1 < total) ? sz[wave][k + 1] - z : span / (float)ns;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // hash grid
 // ---------------------------------------------------------------------------------------
@@ -218,12 +296,13 @@ __device__ __forceinline__ bool point_of(const NeusArgs& A, int idx, float pt[3]
          (pt[2] < A.rt_bound[5]) && (pt[2] > A.rt_bound[4]);
 }
 
+// "is any point in bound?" -- only the predicate matters (InstantNeuS.py:311), so waves that see
+// an in-bound point store 1 (same value from everyone, no atomics, no contention).
 __global__ __launch_bounds__(256) void neus_count_kernel(NeusArgs A, int32_t* __restrict__ count) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   float pt[3], dir[3], zm, dist;
   const bool in = (idx < A.n * A.s) && point_of(A, idx, pt, dir, zm, dist);
-  const unsigned long long b = __ballot(in);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (int)__popcll(b));
+  if (__ballot(in) != 0ull && (threadIdx.x & 63) == 0) *count = 1;
 }
 
 __global__ __launch_bounds__(256) void neus_point_kernel(NeusArgs A, gs_grid_meta m, const int32_t* __restrict__ count,
@@ -294,25 +373,22 @@ __global__ __launch_bounds__(256) void neus_point_kernel(NeusArgs A, gs_grid_met
   sdf_out[idx] = sdf;
   alpha_out[idx] = alpha;
   grad_out[idx * 3 + 0] = grad[0]; grad_out[idx * 3 + 1] = grad[1]; grad_out[idx * 3 + 2] = grad[2];
-  // colour-MLP input row: sin(pts @ B) (33) | normals (3) | feat (31) | ones (13)
-  _Float16 row[80];
-#pragma unroll
-  for (int c = 0; c < 33; ++c) {
-    const float a = (pt[0] * A.color_B[c] + pt[1] * A.color_B[33 + c]) + pt[2] * A.color_B[66 + c];
-    row[c] = (_Float16)sinf(a);
-  }
-#pragma unroll
-  for (int d = 0; d < 3; ++d) row[33 + d] = (_Float16)grad[d];
-#pragma unroll
-  for (int c = 0; c < 31; ++c) row[36 + c] = (_Float16)out[1 + c];
-#pragma unroll
-  for (int c = 67; c < 80; ++c) row[c] = (_Float16)1.0f;
+  // colour-MLP input row: sin(pts @ B) (33) | normals (3) | feat (31) | ones (13), emitted eight
+  // columns (16 B) at a time so the row never sits in registers as a whole
   half8* dst = reinterpret_cast<half8*>(mlp_in + (size_t)idx * 80);
 #pragma unroll
   for (int q = 0; q < 10; ++q) {
     half8 pk;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) pk[k] = row[q * 8 + k];
+    for (int k = 0; k < 8; ++k) {
+      const int c = q * 8 + k;
+      float v;
+      if (c < 33) v = sinf((pt[0] * A.color_B[c] + pt[1] * A.color_B[33 + c]) + pt[2] * A.color_B[66 + c]);
+      else if (c < 36) v = grad[c - 33];
+      else if (c < 67) v = out[1 + (c - 36)];
+      else v = 1.0f;
+      pk[k] = (_Float16)v;
+    }
     dst[q] = pk;
   }
 }
@@ -468,49 +544,84 @@ __global__ __launch_bounds__(256) void mlp_pad_kernel(const _Float16* __restrict
 // ---------------------------------------------------------------------------------------
 // per-ray compositing (InstantNeuS.py:343-358)
 // ---------------------------------------------------------------------------------------
+// One wave per ray: lanes own samples (64 per pass), the exclusive transmittance product is a
+// wave prefix scan, the per-ray sums are wave reductions; every load is coalesced.
+__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float u = __shfl_up(v, off, 64);
+    if (lane >= off) v = v * u;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(256) void neus_ray_kernel(const float* __restrict__ alpha, const _Float16* __restrict__ rgb,
                                                        const float* __restrict__ zmid, const float* __restrict__ grad,
                                                        const uint8_t* __restrict__ mask, float* __restrict__ color,
                                                        float* __restrict__ depth, float* __restrict__ depth_var,
                                                        float* __restrict__ normal, float* __restrict__ weight_sum,
                                                        float* __restrict__ gerr, int n, int s) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n) return;
   const size_t b = (size_t)r * s;
-  float T = 1.0f, wsum = 0.f, col[3] = {0.f, 0.f, 0.f}, dep = 0.f, nrm[3] = {0.f, 0.f, 0.f}, ge = 0.f;
-  for (int k = 0; k < s; ++k) {
-    const float a = alpha[b + k];
-    const float w = a * T;
-    T = T * (1.0f - a + 1e-7f);
-    wsum += w;
-    dep += zmid[b + k] * w;
-    const float mk = mask[b + k] ? 1.0f : 0.0f;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      col[d] += (float)rgb[(b + k) * 3 + d] * w;
-      nrm[d] += grad[(b + k) * 3 + d] * w * mk;
+  float wsum = 0.f, col[3] = {0.f, 0.f, 0.f}, dep = 0.f, nrm[3] = {0.f, 0.f, 0.f}, ge = 0.f;
+  float Trun = 1.0f;
+  for (int base = 0; base < s; base += 64) {
+    const int k = base + lane;
+    const bool on = k < s;
+    const float a = on ? alpha[b + k] : 0.0f;
+    const float t = on ? (1.0f - a + 1e-7f) : 1.0f;
+    const float incl = wave_incl_prod(t, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.0f;
+    const float w = a * (Trun * excl);
+    Trun = Trun * __shfl(incl, 63, 64);
+    if (on) {
+      wsum += w;
+      dep += zmid[b + k] * w;
+      const float mk = mask[b + k] ? 1.0f : 0.0f;
+      const float gx = grad[(b + k) * 3 + 0], gy = grad[(b + k) * 3 + 1], gz = grad[(b + k) * 3 + 2];
+      col[0] += (float)rgb[(b + k) * 3 + 0] * w;
+      col[1] += (float)rgb[(b + k) * 3 + 1] * w;
+      col[2] += (float)rgb[(b + k) * 3 + 2] * w;
+      nrm[0] += gx * w * mk; nrm[1] += gy * w * mk; nrm[2] += gz * w * mk;
+      const float nr = sqrtf((gx * gx + gy * gy) + gz * gz) - 1.0f;
+      ge += nr * nr * mk;
     }
-    const float gx = grad[(b + k) * 3 + 0], gy = grad[(b + k) * 3 + 1], gz = grad[(b + k) * 3 + 2];
-    const float nr = sqrtf((gx * gx + gy * gy) + gz * gz) - 1.0f;
-    ge += nr * nr * mk;
   }
-  // second pass needs the final depth; the running product is cheap to redo and avoids a
-  // per-ray scratch array
+  wsum = gs_wave_sum(wsum);
+  dep = gs_wave_sum(dep);
+  ge = gs_wave_sum(ge);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { col[d] = gs_wave_sum(col[d]); nrm[d] = gs_wave_sum(nrm[d]); }
+  // variance needs the final depth: redo the (cheap) scan
   float var = 0.f;
-  T = 1.0f;
-  for (int k = 0; k < s; ++k) {
-    const float a = alpha[b + k];
-    const float w = a * T;
-    T = T * (1.0f - a + 1e-7f);
-    const float dz = zmid[b + k] - dep;
-    var += dz * dz * w;
+  Trun = 1.0f;
+  for (int base = 0; base < s; base += 64) {
+    const int k = base + lane;
+    const bool on = k < s;
+    const float a = on ? alpha[b + k] : 0.0f;
+    const float t = on ? (1.0f - a + 1e-7f) : 1.0f;
+    const float incl = wave_incl_prod(t, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.0f;
+    const float w = a * (Trun * excl);
+    Trun = Trun * __shfl(incl, 63, 64);
+    if (on) {
+      const float dz = zmid[b + k] - dep;
+      var += dz * dz * w;
+    }
   }
-  color[r * 3 + 0] = col[0]; color[r * 3 + 1] = col[1]; color[r * 3 + 2] = col[2];
-  normal[r * 3 + 0] = nrm[0]; normal[r * 3 + 1] = nrm[1]; normal[r * 3 + 2] = nrm[2];
-  depth[r] = dep;
-  depth_var[r] = var;
-  weight_sum[r] = wsum;
-  gerr[r] = ge;
+  var = gs_wave_sum(var);
+  if (lane == 0) {
+    color[r * 3 + 0] = col[0]; color[r * 3 + 1] = col[1]; color[r * 3 + 2] = col[2];
+    normal[r * 3 + 0] = nrm[0]; normal[r * 3 + 1] = nrm[1]; normal[r * 3 + 2] = nrm[2];
+    depth[r] = dep;
+    depth_var[r] = var;
+    weight_sum[r] = wsum;
+    gerr[r] = ge;
+  }
 }
 
 gs_grid_meta host_meta() {
@@ -552,9 +663,14 @@ extern "C" int gs_render_sample(const float* rays_o, const float* rays_d, const 
   GS_REQUIRE(n >= 0 && n_samples > 0 && n_surface >= 0, "render_sample: bad shape");
   GS_REQUIRE(n_surface == 0 || t_surface, "render_sample: t_surface required");
   if (n == 0) return GS_OK;
-  render_sample_kernel<<<gs_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(
-      rays_o, rays_d, gt_depth, bound, t_samples, t_surface, perturb, gt_max, z_vals, dists, n, n_samples,
-      gt_depth ? n_surface : 0);
+  if (n_samples <= 64 && n_surface <= 64)
+    render_sample_wave_kernel<<<gs_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(
+        rays_o, rays_d, gt_depth, bound, t_samples, t_surface, perturb, gt_max, z_vals, dists, n, n_samples,
+        gt_depth ? n_surface : 0);
+  else
+    render_sample_kernel<<<gs_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(
+        rays_o, rays_d, gt_depth, bound, t_samples, t_surface, perturb, gt_max, z_vals, dists, n, n_samples,
+        gt_depth ? n_surface : 0);
   GS_CHECK_LAUNCH("render_sample");
   return GS_OK;
 }
@@ -663,7 +779,7 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
   const int grid_mlp = gs_cdiv(n_tiles, 4) < 1024 ? gs_cdiv(n_tiles, 4) : 1024;
   neus_mlp_kernel<<<grid_mlp, 256, 0, st>>>(ws.mlp_in, 80, (const _Float16*)mlp, ws.mask, rgb, 3, 3, np, 1, n_tiles);
   GS_CHECK_LAUNCH("neus_mlp");
-  neus_ray_kernel<<<gs_cdiv(n, 256), 256, 0, st>>>(alpha, rgb, z_mid, grad, ws.mask, color, depth, depth_var, normal,
+  neus_ray_kernel<<<gs_cdiv(n, 4), 256, 0, st>>>(alpha, rgb, z_mid, grad, ws.mask, color, depth, depth_var, normal,
                                                    weight_sum, grad_err_ray, n, s);
   GS_CHECK_LAUNCH("neus_ray");
   return GS_OK;
