@@ -401,7 +401,6 @@ def ba_edge_terms(poses, disps, intrinsics, targets, weights, ii, jj):
     wv = torch.where(close, torch.zeros_like(z), 0.001 * wt[:, 1])
     ru = tg[:, 0] - (fx * d * x + cx)
     rv = tg[:, 1] - (fy * d * y + cy)
-    o = torch.zeros_like(x)
 
     def row(Jj, Jz, w, r):
         C = w * Jz * Jz
@@ -416,12 +415,7 @@ def ba_edge_terms(poses, disps, intrinsics, targets, weights, ii, jj):
         Ej = (w * Jz)[..., None] * Jj
         return C, b, H, vv, Ei, Ej
 
-    Jj_u = torch.stack([fx * (h * d), fx * o, fx * (-x * h * d2), fx * (-x * y * d2),
-                        fx * (1 + x * x * d2), fx * (-y * d)], dim=-1)
-    Jz_u = fx * (tij[:, None, 0] * d - tij[:, None, 2] * (x * d2))
-    Jj_v = torch.stack([fy * o, fy * (h * d), fy * (-y * h * d2), fy * (-1 - y * y * d2),
-                        fy * (x * y * d2), fy * (x * d)], dim=-1)
-    Jz_v = fy * (tij[:, None, 1] * d - tij[:, None, 2] * (y * d2))
+    Jj_u, Jz_u, Jj_v, Jz_v = _jacobian_rows(fx, fy, x, y, h, d, d2, tij)
 
     Cu, bu, Hu, vu, Eiu, Eju = row(Jj_u, Jz_u, wu, ru)
     Cv, bv, Hv, vv, Eiv, Ejv = row(Jj_v, Jz_v, wv, rv)
@@ -432,6 +426,39 @@ def ba_edge_terms(poses, disps, intrinsics, targets, weights, ii, jj):
     Eii = (Eiu + Eiv).permute(0, 2, 1).contiguous()
     Eij = (Eju + Ejv).permute(0, 2, 1).contiguous()
     return Hs, vs, Eii, Eij, Cu + Cv, bu + bv
+
+
+def _jacobian_rows(fx, fy, x, y, h, d, d2, tij):
+    """lib/droid_kernels.cu:312-319,345-352: pose-j rows and depth column of the 2x(6|1) Jacobian."""
+    o = torch.zeros_like(x)
+    Jj_u = torch.stack([fx * (h * d), fx * o, fx * (-x * h * d2), fx * (-x * y * d2),
+                        fx * (1 + x * x * d2), fx * (-y * d)], dim=-1)
+    Jz_u = fx * (tij[:, None, 0] * d - tij[:, None, 2] * (x * d2))
+    Jj_v = torch.stack([fy * o, fy * (h * d), fy * (-y * h * d2), fy * (-1 - y * y * d2),
+                        fy * (x * y * d2), fy * (x * d)], dim=-1)
+    Jz_v = fy * (tij[:, None, 1] * d - tij[:, None, 2] * (y * d2))
+    return Jj_u, Jz_u, Jj_v, Jz_v
+
+
+def edge_jacobians(poses, disps, intrinsics, ii, jj):
+    """Raw per-pixel Jacobians of the kernel's residual (no weights): returns
+    (Ji [E,HW,2,6], Jj [E,HW,2,6], Jz [E,HW,2], z [E,HW]) for cross-checks against the
+    reference's Python formulation (geom/projective_ops.py:114-144 with jacobian=True)."""
+    E = len(ii)
+    ht, wd = disps.shape[-2:]
+    HW = ht * wd
+    u, v = _grid(ht, wd)
+    fx, fy, cx, cy = intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]
+    tij, qij = _rel_pose_kernel(poses, ii, jj, stereo_override=True)
+    Xi = torch.stack([((u - cx) / fx).expand(E, -1, -1), ((v - cy) / fy).expand(E, -1, -1),
+                      torch.ones(E, ht, wd), disps[ii]], dim=-1).reshape(E, HW, 4)
+    Xj = se3.act_se3(tij[:, None], qij[:, None], Xi)
+    x, y, z, h = Xj.unbind(-1)
+    d = torch.where(z < MIN_DEPTH, torch.zeros_like(z), 1.0 / z)
+    Jj_u, Jz_u, Jj_v, Jz_v = _jacobian_rows(fx, fy, x, y, h, d, d * d, tij)
+    Ji_u = -se3.adj_se3(tij[:, None], qij[:, None], Jj_u)
+    Ji_v = -se3.adj_se3(tij[:, None], qij[:, None], Jj_v)
+    return (torch.stack([Ji_u, Ji_v], 2), torch.stack([Jj_u, Jj_v], 2), torch.stack([Jz_u, Jz_v], 2), z)
 
 
 def _accum(data, ix, jx):

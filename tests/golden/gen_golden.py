@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""Generate golden vectors by RUNNING THE REFERENCE'S OWN PYTHON CODE in the build container.
+
+    python tests/golden/gen_golden.py            # needs /root/reference (absent on the GPU box)
+
+The reference's native extensions cannot run here (CUDA-only `droid_backends`, `lietorch`
+submodule empty, `tinycudann` not installed), so those imports are satisfied by stand-ins:
+
+  droid_backends  -> thin wrappers over oracle/droid_oracle.py   (only so `import` succeeds and
+                     CorrBlock.__call__'s level/permute/concat plumbing can execute)
+  lietorch        -> go_slam_amd/lietorch_shim.py                (published SE3 conventions)
+  tinycudann      -> autograd-capable wrappers over oracle/neus_oracle.py's HashGrid / MLP
+  mcubes, trimesh -> empty modules (only used by mesh extraction)
+
+What the fixtures therefore PIN is every line of reference Python on the hot path:
+  * modules/corr.py      CorrBlock.corr + pyramid build (pure torch)          -> corr_*.npz
+  * geom/projective_ops  projective_transform with and without Jacobians      -> proj_*.npz
+  * render.py            Renderer.render_batch_ray sample placement           -> render_sample.npz
+  * InstantNeuS.py       normalisation, masking, sdf gradient by autograd.grad, get_alpha,
+                         compositing, compute_sdf_error                       -> neus_forward.npz
+The stand-ins themselves (tcnn / lietorch / CUDA kernels) stay "parity unpinned" (DESIGN.md 4).
+The reference is only imported, never copied; outputs are small .npz files next to this script.
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from go_slam_amd import lietorch_shim, synth  # noqa: E402
+from oracle import droid_oracle as DO, neus_oracle as NO  # noqa: E402
+
+
+def install_stubs():
+    # --- droid_backends
+    db = types.ModuleType("droid_backends")
+    db.corr_index_forward = lambda vol, coords, r: DO.corr_index_forward(vol, coords, r)
+    db.corr_index_backward = lambda vol, coords, g, r: DO.corr_index_backward(vol, coords, g, r)
+    db.altcorr_forward = lambda f1, f2, c, r: DO.altcorr_forward(f1, f2, c, r)
+    sys.modules["droid_backends"] = db
+    # --- lietorch
+    lt = types.ModuleType("lietorch")
+    lt.SE3, lt.Sim3, lt.cat = lietorch_shim.SE3, lietorch_shim.Sim3, lietorch_shim.cat
+    sys.modules["lietorch"] = lt
+    # --- tinycudann
+    tc = types.ModuleType("tinycudann")
+
+    class _GridFn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, params):
+            enc, dydx = NO.grid_encode(x, params, want_grad=True)
+            ctx.save_for_backward(dydx)
+            return enc
+
+        @staticmethod
+        def backward(ctx, g):
+            dydx, = ctx.saved_tensors
+            # tcnn: dL/dx = sum_c float(dL/dy_c as fp16) * dy_dx
+            return torch.einsum("nc,ncd->nd", g.to(torch.float16).float(), dydx), None
+
+    class Encoding(torch.nn.Module):
+        def __init__(self, n_input_dims, encoding_config, **kw):
+            super().__init__()
+            self.n_input_dims, self.n_output_dims = n_input_dims, 32
+            self.params = torch.nn.Parameter(torch.zeros(int(NO.grid_meta()["total"]) * 2))
+
+        def forward(self, x):
+            return _GridFn.apply(x, self.params)
+
+    class Network(torch.nn.Module):
+        def __init__(self, n_input_dims, n_output_dims, network_config, **kw):
+            super().__init__()
+            self.n_input_dims, self.n_output_dims = n_input_dims, n_output_dims
+            self.params = torch.nn.Parameter(torch.zeros(NO.mlp_num_params(n_input_dims, n_output_dims)))
+
+        def forward(self, x):
+            return NO.mlp_forward(x, self.params, self.n_input_dims, self.n_output_dims)
+
+    tc.Encoding, tc.Network = Encoding, Network
+    sys.modules["tinycudann"] = tc
+    for name in ("mcubes", "trimesh"):
+        sys.modules[name] = types.ModuleType(name)
+    # the reference wraps tcnn construction in `with torch.cuda.device(device)`; no GPU here
+    class _NoDev:
+        def __init__(self, *a, **k): pass
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+    torch.cuda.device = _NoDev
+    # synthetic package so relative imports work without executing src/__init__.py
+    pkg = types.ModuleType("refsrc")
+    pkg.__path__ = [os.path.join(REF, "src")]
+    sys.modules["refsrc"] = pkg
+    for sub in ("modules", "geom"):
+        sp = types.ModuleType(f"refsrc.{sub}")
+        sp.__path__ = [os.path.join(REF, "src", sub)]
+        sys.modules[f"refsrc.{sub}"] = sp
+
+
+def save(name, **arrays):
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name, {k: v.shape for k, v in out.items()})
+
+
+def gen_corr():
+    corr = importlib.import_module("refsrc.modules.corr")
+    g = torch.Generator().manual_seed(101)
+    for tag, dt in (("f32", torch.float32), ("f16", torch.float16)):
+        f1 = torch.randn(1, 2, 128, 16, 16, generator=g).to(dt)
+        f2 = torch.randn(1, 2, 128, 16, 16, generator=g).to(dt)
+        blk = corr.CorrBlock(f1, f2)
+        coords = torch.stack(torch.meshgrid(torch.arange(16.0), torch.arange(16.0), indexing="xy"), -1)
+        coords = coords[None, None].repeat(1, 2, 1, 1, 1) + 2.5 * torch.randn(1, 2, 16, 16, 2, generator=g)
+        out = blk(coords)
+        save(f"corr_{tag}.npz", fmap1=f1.float(), fmap2=f2.float(), coords=coords, lookup=out.float(),
+             **{f"pyr{i}": p.float() for i, p in enumerate(blk.corr_pyramid)})
+
+
+def gen_proj():
+    pops = importlib.import_module("refsrc.geom.projective_ops")
+    vid = synth.make_video(7, "tiny", seed=103)
+    ii, jj = synth.make_graph(7, 18, seed=103)
+    ii = torch.cat([ii, torch.tensor([3])])
+    jj = torch.cat([jj, torch.tensor([3])])            # one stereo edge
+    Gs = lietorch_shim.SE3(vid["poses"][None])
+    coords, valid = pops.projective_transform(Gs, vid["disps"][None], vid["intrinsics"][None], ii, jj)
+    c2, v2, (Ji, Jj, Jz) = pops.projective_transform(Gs, vid["disps"][None], vid["intrinsics"][None], ii, jj,
+                                                     jacobian=True)
+    save("proj.npz", poses=vid["poses"], disps=vid["disps"], intrinsics=vid["intrinsics"], ii=ii, jj=jj,
+         coords=coords, valid=valid, Ji=Ji, Jj=Jj, Jz=Jz)
+
+
+def gen_render():
+    render = importlib.import_module("refsrc.render")
+    cfg = {"rendering": {"lindisp": False, "perturb": 1.0, "N_samples": 24, "N_surface": 48}}
+    slam = types.SimpleNamespace(H=480, W=640, fx=577.0, fy=578.0, cx=319.0, cy=242.0)
+    R = render.Renderer(cfg, None, slam)
+    g = torch.Generator().manual_seed(107)
+    n = 97
+    o = torch.rand(n, 3, generator=g) * 4 - 2
+    d = torch.randn(n, 3, generator=g)
+    gt = torch.rand(n, generator=g) * 3.5 + 0.5
+    gt[::9] = 0
+    bound = torch.tensor([[-5.0, 5.0], [-4.0, 4.5], [-3.0, 6.0]])
+    grabbed = {}
+
+    class Net:
+        def __init__(self): self.bound = bound
+        def __call__(self, ro, rd, zv, ds, render_params=None):
+            grabbed["z"], grabbed["d"] = zv.clone(), ds.clone()
+            return {"z": zv}
+    torch.manual_seed(1234)
+    R.render_batch_ray(o, d, Net(), None, device="cpu", gt_depth=gt)
+    torch.manual_seed(1234)
+    pr = torch.rand(24)
+    z1, d1 = grabbed["z"], grabbed["d"]
+    torch.manual_seed(1234)
+    R.render_batch_ray(o, d, Net(), None, device="cpu", gt_depth=None)
+    save("render_sample.npz", rays_o=o, rays_d=d, gt_depth=gt, bound=bound, perturb=pr, z_depth=z1, dists_depth=d1,
+         z_nodepth=grabbed["z"], dists_nodepth=grabbed["d"])
+
+
+def gen_neus():
+    neus = importlib.import_module("refsrc.InstantNeuS")
+    P = NO.make_params(109, grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    rt = torch.tensor([[-2.2, 2.3], [-2.4, 2.1], [-2.0, 2.2]])
+    cfg = {"sdf_network": {"d_in": 3, "d_out": 32}, "color_network": {"d_in": 3, "d_feat": 31, "d_hidden": 64, "n_layers": 2},
+           "variance_network": {"init_val": 0.2, "scale_factor": 10.0}, "sdf_smooth_std": 0.005,
+           "sdf_sparse_factor": 5, "sdf_truncation": 0.16, "sdf_random_weight": 0.04}
+    torch.manual_seed(5)
+    net = neus.InstantNeuS(cfg, P["bound"].tolist(), device="cpu")
+    with torch.no_grad():
+        net.sdf_network.encoding.encoding.params.copy_(P["grid"])
+        net.sdf_network.sdf_layer.weight.copy_(P["sdf_w"])
+        net.sdf_network.sdf_layer.bias.copy_(P["sdf_b"])
+        net.color_network._B.copy_(P["color_B"])
+        net.color_network.network.params.copy_(P["mlp"])
+    net.update_bound(rt)
+    g = torch.Generator().manual_seed(113)
+    n = 40
+    o = torch.rand(n, 3, generator=g) * 4 - 2
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+    gt = torch.rand(n, generator=g) * 3.5 + 0.5
+    gt[::7] = 0
+    z, dist = NO.render_sample(o, d, gt, P["bound"], 24, 48, torch.rand(24, generator=g))
+    out = net(o, d, z, dist)
+    sdf_err, sdf_front = net.compute_sdf_error(out["sdf"], out["z_vals"], gt)
+    save("neus_forward.npz", seed=109, rt_bound=rt, rays_o=o, rays_d=d, gt_depth=gt, z_in=z, dists_in=dist,
+         sdf_error=sdf_err, sdf_front_error=sdf_front, **{k: v for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "the reference tree is needed to (re)generate the fixtures"
+    install_stubs()
+    with torch.no_grad():
+        gen_corr()
+        gen_proj()
+        gen_render()
+    gen_neus()

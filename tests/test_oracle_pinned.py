@@ -1,0 +1,259 @@
+"""CPU: pin the oracle against golden vectors produced by the reference's own Python code
+(tests/golden/gen_golden.py) and against analytic known-answer tests.  No GPU, no /root/reference
+at run time.  This is what makes `oracle/` trustworthy as the checker of the HIP path."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from go_slam_amd import synth
+from oracle import droid_oracle as DO, neus_oracle as NO, se3
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    d = np.load(os.path.join(G, name))
+    return {k: torch.from_numpy(d[k]) for k in d.files}
+
+
+# ------------------------------------------------------------------ tracking path ---------
+
+@pytest.mark.parametrize("tag,dt", [("f32", torch.float32), ("f16", torch.float16)])
+def test_corr_pyramid_matches_reference_corrblock(tag, dt):
+    """reference src/modules/corr.py:26-41,67-76 executed verbatim -> fixture."""
+    g = _load(f"corr_{tag}.npz")
+    pyr = DO.corr_pyramid(g["fmap1"].to(dt), g["fmap2"].to(dt))
+    for i in range(4):
+        ref = g[f"pyr{i}"]
+        assert tuple(pyr[i].shape) == tuple(ref.shape)
+        if dt == torch.float32:
+            torch.testing.assert_close(pyr[i].float(), ref, rtol=1e-5, atol=1e-5)
+        else:   # fp16: the GEMM's fp32 accumulation order may differ by one rounding
+            diff = (pyr[i].float() - ref).abs()
+            assert float(diff.max()) <= 2 ** -10 * max(1.0, float(ref.abs().max()))
+            assert float((diff == 0).float().mean()) > 0.98
+    # the lookup plumbing (level scaling, permutes, channel order) of CorrBlock.__call__
+    pyr_ref = [g[f"pyr{i}"].to(dt) for i in range(4)]
+    out = DO.corr_lookup(pyr_ref, g["coords"], 3)
+    assert torch.equal(out.float(), g["lookup"])
+
+
+def test_reproject_matches_reference_projective_transform():
+    """reference src/geom/projective_ops.py:114-144 (jacobian=False) -> fixture."""
+    g = _load("proj.npz")
+    c, v = DO.reproject(g["poses"], g["disps"], g["intrinsics"], g["ii"], g["jj"])
+    assert torch.equal(v, g["valid"])
+    torch.testing.assert_close(c, g["coords"], rtol=1e-6, atol=2e-5)
+
+
+def test_ba_jacobians_match_reference_python_formulation():
+    """The CUDA kernel's Jacobians (restated in the oracle, droid_kernels.cu:312-352) against the
+    reference's independent PyTorch formulation (projective_ops.py jacobian=True: Jp @ Ja,
+    Ji = -AdjT(Gij) Jj, Jz = Jp @ (Gij * [0,0,0,1]))."""
+    g = _load("proj.npz")
+    K = g["intrinsics"][0].contiguous()
+    Ji, Jj, Jz, z = DO.edge_jacobians(g["poses"], g["disps"], K, g["ii"], g["jj"])
+    E, ht, wd = len(g["ii"]), 12, 16
+    ok = (z > 0.3).view(E, ht, wd)                 # away from both codes' near-plane special cases
+    assert ok.float().mean() > 0.95
+    rJi, rJj, rJz = g["Ji"][0], g["Jj"][0], g["Jz"][0][..., 0]
+    torch.testing.assert_close(Jj.view(E, ht, wd, 2, 6)[ok], rJj[ok], rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(Ji.view(E, ht, wd, 2, 6)[ok], rJi[ok], rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(Jz.view(E, ht, wd, 2)[ok], rJz[ok], rtol=2e-4, atol=2e-4)
+
+
+def test_ba_gradient_is_the_derivative_of_the_cost():
+    """Finite differences: b = -dC/dxi for C = 1/2 sum w r^2 under the kernel's left retraction,
+    and bz likewise for the disparities -- an independent check of every Jacobian sign/row."""
+    p = synth.make_ba_problem(5, 10, "tiny", seed=3, rgbd=False)
+    c, _ = DO.reproject(p["poses"], p["disps"], p["intrinsics"], p["ii"], p["jj"])
+    p = synth.make_ba_problem(5, 10, "tiny", seed=3, rgbd=False, coords=c[0], noise_px=0.7)
+    K = p["intrinsics"][0].contiguous()
+    poses, disps = p["poses"].double(), p["disps"].double()
+
+    def cost(poses, disps):
+        E = len(p["ii"])
+        ht, wd = disps.shape[-2:]
+        u, v = DO._grid(ht, wd)
+        u, v = u.double(), v.double()
+        fx, fy, cx, cy = [K[k].double() for k in range(4)]
+        tij, qij = se3.rel_se3(poses[p["ii"], :3], poses[p["ii"], 3:], poses[p["jj"], :3], poses[p["jj"], 3:])
+        Xi = torch.stack([((u - cx) / fx).expand(E, -1, -1), ((v - cy) / fy).expand(E, -1, -1),
+                          torch.ones(E, ht, wd, dtype=torch.float64), disps[p["ii"]]], -1)
+        Xj = se3.act_se3(tij[:, None, None], qij[:, None, None], Xi)
+        ru = p["target"][:, 0].double() - (fx * Xj[..., 0] / Xj[..., 2] + cx)
+        rv = p["target"][:, 1].double() - (fy * Xj[..., 1] / Xj[..., 2] + cy)
+        w = 0.001 * p["weight"].double()
+        return 0.5 * (w[:, 0] * ru ** 2 + w[:, 1] * rv ** 2).sum()
+
+    Hs, vs, Eii, Eij, Cii, bz = DO.ba_edge_terms(p["poses"], p["disps"], K, p["target"], p["weight"], p["ii"], p["jj"])
+    k = 2                                   # a keyframe that is both a source and a target
+    b_k = vs[0][p["ii"] == k].sum(0) + vs[1][p["jj"] == k].sum(0)
+    eps = 1e-6
+    for n in range(6):
+        xi = torch.zeros(6, dtype=torch.float64)
+        xi[n] = eps
+        tp, qp = se3.retr_se3(xi[None], poses[k:k + 1, :3], poses[k:k + 1, 3:])
+        pp = poses.clone(); pp[k, :3], pp[k, 3:] = tp[0], qp[0]
+        tm, qm = se3.retr_se3(-xi[None], poses[k:k + 1, :3], poses[k:k + 1, 3:])
+        pm = poses.clone(); pm[k, :3], pm[k, 3:] = tm[0], qm[0]
+        fd = (cost(pp, disps) - cost(pm, disps)) / (2 * eps)
+        assert abs(float(fd) + float(b_k[n])) < 2e-3 * max(1.0, abs(float(b_k[n]))), (n, float(fd), float(b_k[n]))
+    # depth gradient at a few pixels of frame k
+    w_k = bz[p["ii"] == k].double().sum(0)
+    for pix in (5, 77, 150):
+        dp = disps.clone(); dp[k].view(-1)[pix] += eps
+        dm = disps.clone(); dm[k].view(-1)[pix] -= eps
+        fd = (cost(poses, dp) - cost(poses, dm)) / (2 * eps)
+        assert abs(float(fd) + float(w_k[pix])) < 2e-3 * max(1e-3, abs(float(w_k[pix])))
+
+
+def test_ba_schur_solution_solves_the_full_system():
+    """The oracle's Schur-complement dx must equal the pose part of the dense joint solve
+    [[H, E],[E^T, C]] [dx, dz] = [v, w] built from the same edge terms (no quirks involved in dx)."""
+    p = synth.make_ba_problem(6, 14, "tiny", seed=5)
+    c, _ = DO.reproject(p["poses"], p["disps"], p["intrinsics"], p["ii"], p["jj"])
+    p = synth.make_ba_problem(6, 14, "tiny", seed=5, coords=c[0])
+    K = p["intrinsics"][0].contiguous()
+    ii, jj, t0, t1 = p["ii"], p["jj"], 1, 6
+    P, HW = t1 - t0, 12 * 16
+    Hs, vs, Eii, Eij, Cii, bz = DO.ba_edge_terms(p["poses"], p["disps"], K, p["target"], p["weight"], ii, jj)
+    kx = torch.unique(torch.cat([torch.arange(t0, t1), ii]))
+    M = len(kx)
+    pos = {int(k): n for n, k in enumerate(kx)}
+    A = torch.zeros(6 * P + M * HW, 6 * P + M * HW, dtype=torch.float64)
+    rhs = torch.zeros(6 * P + M * HW, dtype=torch.float64)
+    for e in range(len(ii)):
+        i, j, m = int(ii[e]) - t0, int(jj[e]) - t0, pos[int(ii[e])]
+        blocks = {(i, i): Hs[0][e], (i, j): Hs[1][e], (j, i): Hs[2][e], (j, j): Hs[3][e]}
+        for (a, b), blk in blocks.items():
+            if 0 <= a < P and 0 <= b < P:
+                A[6 * a:6 * a + 6, 6 * b:6 * b + 6] += blk
+        for a, vv, EE in ((i, vs[0][e], Eii[e]), (j, vs[1][e], Eij[e])):
+            if 0 <= a < P:
+                rhs[6 * a:6 * a + 6] += vv
+                cols = 6 * P + m * HW + torch.arange(HW)
+                A[6 * a:6 * a + 6, cols] += EE.double()
+                A[cols, 6 * a:6 * a + 6] += EE.double().t()
+        d = 6 * P + m * HW + torch.arange(HW)
+        A[d, d] += Cii[e].double()
+        rhs[d] += bz[e].double()
+    msk = (p["disps_sens"][kx] > 0).double().view(M, HW)
+    prior_C = msk * 0.05 + (1 - msk) * p["eta"].double().view(M, HW)
+    prior_w = -msk * 0.05 * (p["disps"][kx] - p["disps_sens"][kx]).double().view(M, HW)
+    d = 6 * P + torch.arange(M * HW)
+    A[d, d] += prior_C.reshape(-1)
+    rhs[d] += prior_w.reshape(-1)
+    lm, ep = 1e-4, 0.1
+    # the reference damps the REDUCED system: apply the same damping after the Schur step
+    Hpp, Hpd, Hdd = A[:6 * P, :6 * P], A[:6 * P, 6 * P:], A[6 * P:, 6 * P:].diagonal()
+    S = Hpp - (Hpd / Hdd) @ Hpd.t()
+    r = rhs[:6 * P] - (Hpd / Hdd) @ rhs[6 * P:]
+    S = S + torch.diag(ep + lm * S.diagonal())
+    dx_ref = torch.linalg.solve(S, r).view(P, 6)
+    po, do = p["poses"].clone(), p["disps"].clone()
+    dx, dz = DO.ba(po, do, K, p["disps_sens"], p["target"], p["weight"], p["eta"], ii, jj, t0, t1, 1, lm, ep, False)
+    torch.testing.assert_close(dx.double(), dx_ref, rtol=2e-4, atol=1e-7)
+
+
+def test_ba_reduces_the_reprojection_cost():
+    p = synth.make_ba_problem(8, 22, "tiny", seed=7)
+    c, _ = DO.reproject(p["poses"], p["disps"], p["intrinsics"], p["ii"], p["jj"])
+    p = synth.make_ba_problem(8, 22, "tiny", seed=7, coords=c[0], noise_px=0.0)
+    K = p["intrinsics"][0].contiguous()
+    g = torch.Generator().manual_seed(1)
+    po = p["poses"].clone()
+    po[2:, :3] += 0.02 * torch.randn(6, 3, generator=g)          # perturb the window
+
+    def cost(poses, disps):
+        cc, _ = DO.projmap(poses, disps, K, p["ii"], p["jj"])
+        r = p["target"].permute(0, 2, 3, 1) - cc[..., :2]
+        return float((p["weight"].permute(0, 2, 3, 1) * r ** 2).sum())
+    do = p["disps"].clone()
+    c0 = cost(po, do)
+    DO.ba(po, do, K, p["disps_sens"], p["target"], p["weight"], p["eta"], p["ii"], p["jj"], 1, 8, 4, 1e-4, 0.1, False)
+    assert cost(po, do) < 0.2 * c0
+
+
+def test_se3_kats():
+    q = torch.tensor([[0.0, 0.0, math.sin(math.pi / 4), math.cos(math.pi / 4)]])     # 90 deg about z
+    torch.testing.assert_close(se3.act_so3(q, torch.tensor([[1.0, 0.0, 0.0]])), torch.tensor([[0.0, 1.0, 0.0]]),
+                               atol=1e-6, rtol=0)
+    xi = torch.tensor([[0.1, -0.2, 0.3, 0.2, 0.1, -0.3]])
+    t, qq = se3.exp_se3(xi)
+    from go_slam_amd.lietorch_shim import SE3
+    e = SE3.exp(xi)
+    torch.testing.assert_close(torch.cat([t, qq], -1), e.data, atol=1e-6, rtol=0)
+    torch.testing.assert_close(e.log(), xi, atol=1e-5, rtol=0)
+    ident = (e * e.inv()).data
+    torch.testing.assert_close(ident, torch.tensor([[0, 0, 0, 0, 0, 0, 1.0]]), atol=1e-6, rtol=0)
+
+
+# ------------------------------------------------------------------ mapping path ----------
+
+def test_render_sample_matches_reference_renderer():
+    """reference src/render.py:99-171 executed verbatim -> fixture."""
+    g = _load("render_sample.npz")
+    z, d = NO.render_sample(g["rays_o"], g["rays_d"], g["gt_depth"], g["bound"], 24, 48, g["perturb"])
+    assert torch.equal(z, g["z_depth"]) and torch.equal(d, g["dists_depth"])
+    z, d = NO.render_sample(g["rays_o"], g["rays_d"], None, g["bound"], 24, 48, g["perturb"])
+    assert torch.equal(z, g["z_nodepth"]) and torch.equal(d, g["dists_nodepth"])
+
+
+def test_neus_forward_matches_reference_instantneus():
+    """reference src/InstantNeuS.py:295-400 executed verbatim (masking, normalisation, the sdf
+    gradient by autograd.grad through cat/Linear/encoding, get_alpha, compositing, sdf losses)
+    on top of the tcnn stand-in -> fixture.  Pins the oracle's analytic restatement."""
+    g = _load("neus_forward.npz")
+    P = NO.make_params(int(g["seed"]), grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    P["rt_bound"] = g["rt_bound"]
+    out = NO.neus_forward(g["rays_o"], g["rays_d"], g["z_in"], g["dists_in"], P)
+    assert torch.equal(out["z_vals"], g["z_vals"])
+    torch.testing.assert_close(out["sdf"], g["sdf"], rtol=1e-5, atol=1e-5)
+    for k, tol in (("color", 1e-3), ("depth", 2e-4), ("depth_variance", 2e-4), ("normal", 1e-3), ("weight_sum", 1e-4)):
+        torch.testing.assert_close(out[k], g[k], rtol=1e-3, atol=tol), k
+    torch.testing.assert_close(out["gradient_error"], g["gradient_error"], rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(out["sdf_variance"], g["sdf_variance"])
+    e, f = NO.compute_sdf_error(out["sdf"], out["z_vals"], g["gt_depth"], 0.16, 5)
+    torch.testing.assert_close(e, g["sdf_error"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(f, g["sdf_front_error"], rtol=1e-4, atol=1e-6)
+
+
+def test_hash_grid_known_answers():
+    """SURVEY App. B KATs for the tcnn index function (T = 2^19)."""
+    m = NO.grid_meta()
+    assert m["resolution"].tolist() == [16, 24, 34, 49, 71, 102, 148, 213, 308, 446, 646, 934, 1352, 1956, 2831, 4096]
+    assert int(m["total"]) * 2 == 12599920
+    u = lambda *v: [np.array([x], np.uint32) for x in v]
+    h = lambda x, y, z: int(NO._grid_index(m, 10, *u(x, y, z))[0])
+    assert [h(0, 0, 0), h(1, 0, 0), h(0, 1, 0), h(0, 0, 1), h(1, 1, 1), h(101, 57, 33), h(4095, 4095, 4095)] == \
+        [0, 1, 489905, 153493, 339493, 479801, 352731]
+    assert int(NO._grid_index(m, 2, *u(3, 4, 5))[0]) == 5919          # dense level: x + y*34 + z*34^2
+
+
+def test_grid_dy_dx_is_the_derivative_of_the_encoding():
+    """Along one axis the trilinear interpolation is linear inside a cell, so a central difference
+    over 2e-3 (a small fraction of the level-0/1 cells) must reproduce dy_dx for those levels."""
+    P = NO.make_params(3, grid_init=0.3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(64, 3, generator=g) * 0.8 + 0.1
+    enc, dy = NO.grid_encode(x, P["grid"], want_grad=True)
+    eps = 2e-3
+    for d in range(3):
+        xp, xm = x.clone(), x.clone()
+        xp[:, d] += eps
+        xm[:, d] -= eps
+        fd = (NO.grid_encode(xp, P["grid"]).float() - NO.grid_encode(xm, P["grid"]).float())[:, :4] / (2 * eps)
+        ok = (fd - dy[:, :4, d]).abs() <= 0.05 * dy[:, :4, d].abs() + 0.15
+        assert ok.float().mean() > 0.85, float(ok.float().mean())     # the rest straddle a cell face
+
+
+def test_lib_grid_meta_equals_oracle(built_lib):
+    from go_slam_amd import _lib
+    m, r = _lib.grid_meta(), NO.grid_meta()
+    assert [float(v) for v in m.scale] == [float(v) for v in r["scale"]]
+    assert list(m.size) == r["size"].tolist() and list(m.offset) == r["offset"].tolist()
+    assert list(m.hashed) == r["hashed"].tolist() and int(m.total) == int(r["total"])
