@@ -25,6 +25,7 @@ SIGNATURES = {
     "gs_corr_index_forward": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
     "gs_corr_index_backward": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
     "gs_corr_lookup_pyramid": (c_int, [_P] * 6 + [c_int] * 8 + [_P]),
+    "gs_altcorr_forward": (c_int, [_P] * 4 + [c_int] * 9 + [_P]),
     "gs_reproject": (c_int, [_P] * 7 + [c_int] * 3 + [_P]),
     "gs_projmap": (c_int, [_P] * 7 + [c_int] * 3 + [_P]),
     "gs_frame_distance": (c_int, [_P] * 6 + [c_int] * 3 + [c_float, _P]),

@@ -53,3 +53,45 @@ class CorrBlock:
         for i in range(self.num_levels):
             self.corr_pyramid[i] = self.corr_pyramid[i][index].contiguous()
         return self
+
+
+class AltCorrBlock:
+    """Low-memory correlation (src/modules/corr.py:95-145): no [h,w,h,w] volumes; the 7x7 windows
+    are correlated on the fly from a channels-last feature pyramid.  Same interface:
+    AltCorrBlock(fmaps)(coords, ii, jj).  The pyramid stays fp16 (the reference casts it to fp32
+    per call, corr.py:125; the kernel accumulates fp16 products in fp32, which is exact for them)."""
+
+    def __init__(self, fmaps, num_levels=4, radius=3):
+        self.num_levels = num_levels
+        self.radius = radius
+        B, N, C, H, W = fmaps.shape
+        f = fmaps.reshape(B * N, C, H, W) / 4.0
+        self.pyramid = []
+        for i in range(num_levels):
+            self.pyramid.append(f.permute(0, 2, 3, 1).contiguous().view(B, N, H // 2 ** i, W // 2 ** i, C))
+            if i + 1 < num_levels:
+                f = F.avg_pool2d(f, kernel_size=2, stride=2)
+
+    def corr_fn(self, coords, ii, jj):
+        B, N, H, W, S, _ = coords.shape
+        coords = coords.permute(0, 1, 4, 2, 3, 5)
+        out = []
+        for i in range(self.num_levels):
+            f1 = self.pyramid[0][:, ii]
+            f2 = self.pyramid[i][:, jj]
+            ci = (coords / 2 ** i).reshape(B * N, S, H, W, 2).contiguous()
+            f1 = f1.reshape((B * N,) + f1.shape[2:]).contiguous()
+            f2 = f2.reshape((B * N,) + f2.shape[2:]).contiguous()
+            corr, = droid_backends.altcorr_forward(f1, f2, ci.float(), self.radius)
+            out.append(corr.float().view(B, N, S, -1, H, W).permute(0, 1, 3, 4, 5, 2))
+        return torch.cat(out, dim=2)
+
+    def __call__(self, coords, ii, jj):
+        squeeze = False
+        if coords.dim() == 5:
+            coords = coords.unsqueeze(-2)
+            squeeze = True
+        corr = self.corr_fn(coords, ii, jj)
+        if squeeze:
+            corr = corr.squeeze(-1)
+        return corr.contiguous()

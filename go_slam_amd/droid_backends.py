@@ -219,8 +219,24 @@ def reproject(poses, disps, intrinsics, ii, jj):
 
 
 def altcorr_forward(fmap1, fmap2, coords, radius):
-    """droid.cpp:173-184 -> [corr [B,S,(2r+1)^2,H,W]]."""
-    raise NotImplementedError("altcorr_forward: HIP kernel lands with the global-BA row (SURVEY 8 a3)")
+    """droid.cpp:173-184: fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C], coords f32 [B,S,H1,W1,2]
+    -> [corr [B,S,(2r+1)^2,H1,W1]] in fmap1's dtype."""
+    _chk("fmap1", fmap1)
+    _chk("fmap2", fmap2, fmap1.dtype)
+    _chk("coords", coords, torch.float32)
+    if fmap1.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError(f"altcorr_forward: unsupported dtype {fmap1.dtype}")
+    B, H1, W1, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    S = coords.shape[1]
+    rd = 2 * radius + 1
+    corr = torch.empty(B, S, rd * rd, H1, W1, dtype=fmap1.dtype, device=fmap1.device)
+    with torch.cuda.device(fmap1.device):
+        rc = _lib.lib().gs_altcorr_forward(_lib.ptr(fmap1), _lib.ptr(fmap2), _lib.ptr(coords), _lib.ptr(corr), B, S,
+                                           H1, W1, H2, W2, C, int(radius), _DT[fmap1.dtype],
+                                           _lib.stream_ptr(fmap1.device))
+    _lib.check(rc, "droid_backends.altcorr_forward")
+    return [corr]
 
 
 def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):

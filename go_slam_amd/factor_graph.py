@@ -6,7 +6,7 @@ UpdateModule (MIOpen convs) -> dense BA (HIP, no host round trips) -> convex ups
 """
 import torch
 
-from .corr import CorrBlock
+from .corr import AltCorrBlock, CorrBlock
 
 
 def coords_grid(ht, wd, device):
@@ -21,7 +21,7 @@ class FactorGraph:
         """`channels_last`: keep the per-edge GRU state (net, inp) and the looked-up correlation
         features in NHWC memory so MIOpen runs its NHWC fp16 kernels (1.4x on the update operator
         on MI355X); shapes and values are unchanged."""
-        assert corr_impl == "volume", "the low-memory (alt-corr) path lives in update_lowmem"
+        assert corr_impl in ("volume", "alt")
         self.channels_last = channels_last
         self.video = video
         self.update_op = update_op
@@ -52,13 +52,14 @@ class FactorGraph:
         if ii.numel() == 0:
             return
         net = self._fmt(self.video.nets[ii]).unsqueeze(0)
-        c = (ii == jj).long()                       # stereo edges read the right-view feature map
-        fmap1 = self.video.fmaps[ii, 0].unsqueeze(0)
-        fmap2 = self.video.fmaps[jj, c].unsqueeze(0)
-        corr = CorrBlock(fmap1, fmap2, channels_last=self.channels_last)
-        self.corr = corr if self.corr is None else self.corr.cat(corr)
-        inp = self._fmt(self.video.inps[ii]).unsqueeze(0)
-        self.inp = inp if self.inp is None else self._cat_edges(self.inp, inp)
+        if self.corr_impl == "volume":              # the alt path correlates on the fly (no volumes)
+            c = (ii == jj).long()                   # stereo edges read the right-view feature map
+            fmap1 = self.video.fmaps[ii, 0].unsqueeze(0)
+            fmap2 = self.video.fmaps[jj, c].unsqueeze(0)
+            corr = CorrBlock(fmap1, fmap2, channels_last=self.channels_last)
+            self.corr = corr if self.corr is None else self.corr.cat(corr)
+            inp = self._fmt(self.video.inps[ii]).unsqueeze(0)
+            self.inp = inp if self.inp is None else self._cat_edges(self.inp, inp)
         with torch.autocast("cuda", enabled=False):
             target, _ = self.video.reproject(ii, jj)
             weight = torch.zeros_like(target)
@@ -87,9 +88,10 @@ class FactorGraph:
             self.weight_inac = torch.cat([self.weight_inac, self.weight[:, mask]], 1)
         keep = ~mask
         self.ii, self.jj, self.age = self.ii[keep], self.jj[keep], self.age[keep]
-        self.corr = self.corr[keep]
+        if self.corr_impl == "volume":
+            self.corr = self.corr[keep]
+            self.inp = self._fmt(self.inp[0][keep]).unsqueeze(0)
         self.net = self._fmt(self.net[0][keep]).unsqueeze(0)
-        self.inp = self._fmt(self.inp[0][keep]).unsqueeze(0)
         self.target = self.target[:, keep]
         self.weight = self.weight[:, keep]
 
@@ -135,3 +137,48 @@ class FactorGraph:
         if self.upsample:
             self.video.upsample(torch.unique(self.ii, sorted=True), upmask[0])
         self.age += 1
+
+    @torch.no_grad()
+    def update_lowmem(self, t0=None, t1=None, iters=2, use_inactive=False, EPS=1e-7, steps=8, max_t=None,
+                      ba_type="dense", motion_only=False):
+        """Reduced-memory update for global / loop-closure BA (src/factor_graph.py:255-321): alt-corr
+        lookups in chunks of 13 source keyframes, one dense BA over all edges per step."""
+        cur_t = self.video.counter
+        t = max_t if max_t is not None else cur_t
+        fm = self.video.fmaps[:cur_t + 2]
+        num, rig, ch, ht, wd = fm.shape
+        corr_op = AltCorrBlock(fm.reshape(1, num * rig, ch, ht, wd))
+        if t0 is None:
+            t0 = max(1, int(self.ii.min()) + 1)
+        t0 = max(1, t0)
+        if t1 is None:
+            t1 = max(int(self.ii.max()), int(self.jj.max())) + 1
+        for _ in range(steps):
+            coords1, mask = self.video.reproject(self.ii, self.jj)
+            motion = torch.cat([coords1 - self.coords0, self.target - coords1], dim=-1)
+            motion = motion.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
+            s = 13
+            lo, hi = int(self.ii.min()), int(self.ii.max())
+            for i in range(lo, hi + 1, s):
+                v = (self.ii >= i) & (self.ii < i + s)
+                if int(v.sum()) < 1:
+                    continue
+                iis, jjs = self.ii[v], self.jj[v]
+                corr1 = corr_op(coords1[:, v], rig * iis, rig * jjs + (iis == jjs).long())
+                with torch.autocast("cuda", dtype=torch.float16):
+                    net, delta, weight, damping, upmask = self.update_op(
+                        self.net[:, v], self._fmt(self.video.inps[iis]).unsqueeze(0), corr1, motion[:, v], iis, jjs)
+                    if self.upsample:
+                        self.video.upsample(torch.unique(iis, sorted=True), upmask[0])
+                self.net[:, v] = net.to(self.net.dtype)
+                self.target[:, v] = coords1[:, v] + delta.float()
+                self.weight[:, v] = weight.float()
+                self.damping[torch.unique(iis, sorted=True)] = damping.float()
+            damping_index = torch.unique(torch.cat([torch.arange(t0, t1, device=self.ii.device), self.ii]), sorted=True)
+            damping = 0.2 * self.damping[damping_index].contiguous() + EPS
+            target = self.target.view(-1, self.ht, self.wd, 2).permute(0, 3, 1, 2).contiguous()
+            weight = self.weight.view(-1, self.ht, self.wd, 2).permute(0, 3, 1, 2).contiguous()
+            lm, ep = (1e-4, 1e-1) if ba_type == "loop" else (1e-5, 1e-2)
+            self.video.ba(target, weight, damping, self.ii.contiguous(), self.jj.contiguous(), t0=t0, t1=t1,
+                          iters=iters, lm=lm, ep=ep, motion_only=motion_only, ba_type=ba_type)
+            self.video.dirty[:t] = True

@@ -63,6 +63,13 @@ int gs_corr_lookup_pyramid(const void* vol0, const void* vol1, const void* vol2,
                            int n, int h1, int w1, int h2, int w2, int radius, int dtype,
                            int channels_last, gs_stream_t stream);
 
+/* droid_backends.altcorr_forward (droid.cpp:173-184, altcorr_kernel.cu:27-149,290-319).
+ * fmap1 [b,h1,w1,c], fmap2 [b,h2,w2,c] (channels-last, c in {64,128,256}), coords f32
+ * [b,s,h1,w1,2] -> corr [b,s,(2r+1)^2,h1,w1]; dtype f16 or f32, fp32 accumulation.             */
+int gs_altcorr_forward(const void* fmap1, const void* fmap2, const float* coords, void* corr,
+                       int b, int s, int h1, int w1, int h2, int w2, int c, int radius, int dtype,
+                       gs_stream_t stream);
+
 /* ------------------------------------------------------------------- geometry ------ */
 
 /* DepthVideo.reproject -> pops.projective_transform(jacobian=False)

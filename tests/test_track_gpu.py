@@ -282,3 +282,40 @@ def test_ba_large_window_blocked_cholesky(db, O, dev):
     torch.testing.assert_close(out[0].cpu(), ref[0], rtol=2e-3, atol=5e-6)
     torch.testing.assert_close(pg, po, rtol=0, atol=2e-5)
     torch.testing.assert_close(dg, do, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_altcorr_forward_matches_oracle(db, O, dev, dtype):
+    """droid_backends.altcorr_forward vs the restatement of altcorr_kernel.cu:27-149: windows
+    straddling every border, a pooled (smaller) fmap2, S = 2 coordinate sets."""
+    g = torch.Generator().manual_seed(41)
+    B, H1, W1, H2, W2, C, S = 3, 9, 13, 5, 7, 128, 2
+    f1 = (torch.randn(B, H1, W1, C, generator=g) / 4).to(dtype)
+    f2 = (torch.randn(B, H2, W2, C, generator=g) / 4).to(dtype)
+    ys, xs = torch.meshgrid(torch.arange(H1, dtype=torch.float32), torch.arange(W1, dtype=torch.float32), indexing="ij")
+    base = torch.stack([xs * (W2 / W1), ys * (H2 / H1)], -1)
+    coords = base[None, None] + 2.0 * torch.randn(B, S, H1, W1, 2, generator=g)
+    coords[:, :, 0, 0] = torch.tensor([-9.0, 2.0])
+    coords[:, :, 0, 1] = torch.tensor([3.0, 2.0])
+    ref, = O.altcorr_forward(f1.float(), f2.float(), coords, 3)
+    out, = db.altcorr_forward(f1.to(dev), f2.to(dev), coords.to(dev), 3)
+    assert out.dtype == dtype and tuple(out.shape) == (B, S, 49, H1, W1)
+    if dtype == torch.float32:
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+    else:   # fp16 inputs, fp32 accumulation, fp16 output
+        torch.testing.assert_close(out.cpu().float(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_altcorr_block_matches_oracle_lookup(O, dev, built_lib):
+    """AltCorrBlock(fmaps)(coords, ii, jj) == corr.py:95-145 on the oracle (4 levels, 196 channels)."""
+    from go_slam_amd.corr import AltCorrBlock
+    ht, wd, _ = synth.SHAPES["Scan"]
+    fm = synth.make_features(5, "Scan", seed=43)[None]                 # [1,5,128,h,w] f16
+    ii = torch.tensor([0, 1, 2, 4, 3, 1])
+    jj = torch.tensor([1, 0, 4, 2, 3, 3])
+    coords = _rand_coords(6, ht, wd, ht, wd, seed=44, spread=3.0).permute(0, 2, 3, 1)[None].contiguous()
+    ref = O.altcorr_lookup(O.altcorr_pyramid(fm), coords, ii, jj, 3)
+    blk = AltCorrBlock(fm.to(dev))
+    out = blk(coords.to(dev), ii.to(dev), jj.to(dev))
+    assert tuple(out.shape) == (1, 6, 196, ht, wd) and out.dtype == torch.float32
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-3, atol=2e-3)
