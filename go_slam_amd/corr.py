@@ -28,6 +28,13 @@ class CorrBlock:
 
     @staticmethod
     def build_pyramid(fmap1, fmap2, num_levels=4):
+        batch, num, dim, ht, wd = fmap1.shape
+        f1 = fmap1.reshape(batch * num, dim, ht, wd)
+        if fmap1.is_cuda and num_levels == 4 and droid_backends.corr_volume_supported(f1):
+            # fused HIP path: MFMA GEMM + the three pools, volume written exactly once
+            return droid_backends.corr_volume_pyramid(f1.contiguous(),
+                                                      fmap2.reshape(batch * num, dim, ht, wd).contiguous())
+        # shapes the fused kernel does not cover (odd widths, w > 80): hipBLASLt + avg_pool2d
         corr = CorrBlock.corr(fmap1, fmap2)
         batch, num, h1, w1, h2, w2 = corr.shape
         corr = corr.reshape(batch * num * h1 * w1, 1, h2, w2)

@@ -1,0 +1,226 @@
+// All-pairs correlation volume + 4-level average-pool pyramid in one pass
+// (reference: src/modules/corr.py:26-41 CorrBlock.__init__ and :67-76 CorrBlock.corr, which run a
+// batched fp16 GEMM and then three avg_pool2d passes that re-read the 46 MB/edge volume).
+//
+// The op is HBM-WRITE bound (2.656*HW^2 bytes vs 256*HW^2 flops per edge, AI ~ 96 flop/B), so the
+// kernel is organised around writing every byte exactly once:
+//   corr_prep_kernel   : [n,128,HW] -> channels-last [n,HW,128] fp16, scaled by 1/4 (corr.py:71-72),
+//                        so both MFMA operands are K-contiguous 16-byte fragments
+//   corr_volume_kernel : one workgroup = 64 source pixels (p1) x 8 full rows of the target map
+//                        (p2 = 8*w columns).  v_mfma_f32_32x32x16_f16 with A = f2 rows, B = f1 rows
+//                        (so each lane ends up holding 4 consecutive p2 of one p1 -> 8-byte LDS
+//                        writes); the fp16 tile is staged in LDS, written to level 0 with 16-byte
+//                        coalesced stores, and the 2x2 / 4x4 / 8x8 pooled levels are produced from
+//                        that LDS tile (each level from the fp16-rounded level below, exactly as
+//                        avg_pool2d on a half tensor does) -- the volume is never read back.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+constexpr int KDIM = 128;
+constexpr int BM = 64;          // source pixels per workgroup
+constexpr int ROWS = 8;         // target rows per workgroup (covers one 8x8 pooling block row)
+constexpr int MAXT = 5;         // n-tiles (32 columns) per wave: 8*w/32/4 <= 5  <=>  w <= 80
+
+__global__ __launch_bounds__(256) void corr_prep_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out,
+                                                        int hw) {
+  __shared__ _Float16 t[32][34];
+  const int e = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int p = p0 + tx;
+    t[k][tx] = (p < hw) ? in[((size_t)e * KDIM + c0 + k) * hw + p] : (_Float16)0;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int p = p0 + k;
+    if (p < hw) out[((size_t)e * hw + p) * KDIM + c0 + tx] = t[tx][k] / (_Float16)4.0f;
+  }
+}
+
+__device__ __forceinline__ half8 ld8(const _Float16* p) { return *reinterpret_cast<const half8*>(p); }
+
+__global__ __launch_bounds__(256) void corr_volume_kernel(
+    const _Float16* __restrict__ f1t, const _Float16* __restrict__ f2t, _Float16* __restrict__ v0,
+    _Float16* __restrict__ v1, _Float16* __restrict__ v2, _Float16* __restrict__ v3, int h, int w) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  const int hw = h * w;
+  const int BN = ROWS * w;                 // columns of the tile (multiple of 32)
+  const int LD0 = BN + 8;                  // LDS row strides (halfs)
+  const int LD1 = (ROWS / 2) * (w / 2) + 2;
+  const int LD2 = (ROWS / 4) * (w / 4) + 2;
+  _Float16* c0 = lds;                      // [BM][LD0]
+  _Float16* c1 = c0 + BM * LD0;            // [BM][LD1]
+  _Float16* c2 = c1 + BM * LD1;            // [BM][LD2]
+  const int e = blockIdx.z;
+  const int p1_0 = blockIdx.x * BM;
+  const int y2_0 = blockIdx.y * ROWS;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = lane & 31, kh = 8 * (lane >> 5);
+  const int ntile = BN / 32;
+  const _Float16* A = f2t + (size_t)e * hw * KDIM;   // rows p2
+  const _Float16* B = f1t + (size_t)e * hw * KDIM;   // rows p1
+
+  // B fragments (source pixels) for the two 32-wide p1 tiles, all 8 k-steps
+  half8 bf[2][8];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int p1 = min(p1_0 + 32 * mt + r, hw - 1);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) bf[mt][ks] = ld8(B + (size_t)p1 * KDIM + 16 * ks + kh);
+  }
+  float16v acc[MAXT][2];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][mt][i] = 0.f;
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int nt = wave + 4 * t;
+    if (nt < ntile) {
+      const int p2 = min(y2_0 * w + 32 * nt + r, hw - 1);
+      const _Float16* ar = A + (size_t)p2 * KDIM + kh;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const half8 af = ld8(ar + 16 * ks);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[mt][ks], acc[t][mt], 0, 0, 0);
+      }
+    }
+  }
+  // D[p2][p1]: lane -> p1 = 32*mt + (lane&31); reg q*4+k -> p2 = 32*nt + 8*q + 4*(lane>>5) + k
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int nt = wave + 4 * t;
+    if (nt < ntile) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        _Float16* row = c0 + (size_t)(32 * mt + r) * LD0 + 32 * nt + 4 * (lane >> 5);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          half4 pk;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) pk[k] = (_Float16)acc[t][mt][q * 4 + k];
+          *reinterpret_cast<half4*>(row + 8 * q) = pk;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int rows_valid = min(ROWS, h - y2_0);          // target rows of this tile inside the map
+  const int m_valid = min(BM, hw - p1_0);
+  // ---- level 0: [e][p1][y2][x2], the tile is rows_valid*w contiguous halfs per p1
+  {
+    const int seg = rows_valid * w;                    // halfs per p1 row (multiple of 4 since w%4==0)
+    const int vec = seg / 8;                           // 16-byte vectors (seg % 8 == 0 when w % 8 == 0)
+    if ((seg & 7) == 0) {
+      for (int i = threadIdx.x; i < m_valid * vec; i += 256) {
+        const int m = i / vec, j = i - m * vec;
+        const half8 v = *reinterpret_cast<const half8*>(c0 + (size_t)m * LD0 + 8 * j);
+        *reinterpret_cast<half8*>(v0 + ((size_t)e * hw + p1_0 + m) * hw + (size_t)y2_0 * w + 8 * j) = v;
+      }
+    } else {
+      const int vec4 = seg / 4;
+      for (int i = threadIdx.x; i < m_valid * vec4; i += 256) {
+        const int m = i / vec4, j = i - m * vec4;
+        const half4 v = *reinterpret_cast<const half4*>(c0 + (size_t)m * LD0 + 4 * j);
+        *reinterpret_cast<half4*>(v0 + ((size_t)e * hw + p1_0 + m) * hw + (size_t)y2_0 * w + 4 * j) = v;
+      }
+    }
+  }
+  // ---- level 1 (2x2 average of the fp16 level-0 values; ((a+b)+c)+d in fp32, x0.25, round)
+  const int h1 = h >> 1, w1 = w >> 1, h2 = h >> 2, w2 = w >> 2, h3 = h >> 3, w3 = w >> 3;
+  {
+    const int r1 = ROWS / 2;
+    for (int i = threadIdx.x; i < BM * r1 * w1; i += 256) {
+      const int m = i / (r1 * w1), rem = i - m * (r1 * w1);
+      const int yy = rem / w1, xx = rem - yy * w1;
+      const _Float16* s = c0 + (size_t)m * LD0 + (2 * yy) * w + 2 * xx;
+      const float a = (float)s[0], b = (float)s[1], c = (float)s[w], d = (float)s[w + 1];
+      const _Float16 o = (_Float16)((((a + b) + c) + d) * 0.25f);
+      c1[(size_t)m * LD1 + yy * w1 + xx] = o;
+      const int gy = (y2_0 >> 1) + yy;
+      if (m < m_valid && gy < h1)
+        v1[((size_t)e * hw + p1_0 + m) * ((size_t)h1 * w1) + (size_t)gy * w1 + xx] = o;
+    }
+  }
+  __syncthreads();
+  {
+    const int r2 = ROWS / 4;
+    for (int i = threadIdx.x; i < BM * r2 * w2; i += 256) {
+      const int m = i / (r2 * w2), rem = i - m * (r2 * w2);
+      const int yy = rem / w2, xx = rem - yy * w2;
+      const _Float16* s = c1 + (size_t)m * LD1 + (2 * yy) * w1 + 2 * xx;
+      const float a = (float)s[0], b = (float)s[1], c = (float)s[w1], d = (float)s[w1 + 1];
+      const _Float16 o = (_Float16)((((a + b) + c) + d) * 0.25f);
+      c2[(size_t)m * LD2 + yy * w2 + xx] = o;
+      const int gy = (y2_0 >> 2) + yy;
+      if (m < m_valid && gy < h2 && xx < w2)
+        v2[((size_t)e * hw + p1_0 + m) * ((size_t)h2 * w2) + (size_t)gy * w2 + xx] = o;
+    }
+  }
+  __syncthreads();
+  {
+    for (int i = threadIdx.x; i < BM * w3; i += 256) {
+      const int m = i / w3, xx = i - m * w3;
+      const _Float16* s = c2 + (size_t)m * LD2 + 2 * xx;
+      const float a = (float)s[0], b = (float)s[1], c = (float)s[w2], d = (float)s[w2 + 1];
+      const _Float16 o = (_Float16)((((a + b) + c) + d) * 0.25f);
+      const int gy = y2_0 >> 3;
+      if (m < m_valid && gy < h3)
+        v3[((size_t)e * hw + p1_0 + m) * ((size_t)h3 * w3) + (size_t)gy * w3 + xx] = o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t gs_corr_volume_workspace_bytes(int n, int dim, int h, int w) {
+  if (n < 0 || dim != KDIM || h <= 0 || w <= 0) return 0;
+  return 2 * gs_align((size_t)n * h * w * KDIM * 2) + 256;
+}
+
+extern "C" int gs_corr_volume_pyramid(const void* fmap1, const void* fmap2, void* vol0, void* vol1, void* vol2,
+                                      void* vol3, int n, int dim, int h, int w, void* workspace,
+                                      size_t workspace_bytes, gs_stream_t stream) {
+  GS_REQUIRE(fmap1 && fmap2 && vol0 && vol1 && vol2 && vol3, "corr_volume_pyramid: null pointer");
+  GS_REQUIRE(dim == KDIM, "corr_volume_pyramid: feature dim %d (DROID uses 128)", dim);
+  GS_REQUIRE(n >= 0 && h >= 8 && w >= 8, "corr_volume_pyramid: bad shape");
+  GS_REQUIRE(w % 8 == 0 && w <= 16 * MAXT, "corr_volume_pyramid: map width %d must be a multiple of 8 and <= %d",
+             w, 16 * MAXT);
+  if (n == 0) return GS_OK;
+  GS_REQUIRE(n <= 65535, "corr_volume_pyramid: n=%d exceeds grid.z limit", n);
+  const size_t need = gs_corr_volume_workspace_bytes(n, dim, h, w);
+  if (!workspace || workspace_bytes < need) {
+    gs_set_error("corr_volume_pyramid: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return GS_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int hw = h * w;
+  _Float16* f1t = (_Float16*)gs_align((size_t)workspace);
+  _Float16* f2t = f1t + gs_align((size_t)n * hw * KDIM * 2) / 2;
+  dim3 pg(gs_cdiv(hw, 32), KDIM / 32, n);
+  corr_prep_kernel<<<pg, 256, 0, st>>>((const _Float16*)fmap1, f1t, hw);
+  corr_prep_kernel<<<pg, 256, 0, st>>>((const _Float16*)fmap2, f2t, hw);
+  GS_CHECK_LAUNCH("corr_prep");
+  const int BN = ROWS * w;
+  const size_t lds = (size_t)(BM * (BN + 8) + BM * ((ROWS / 2) * (w / 2) + 2) + BM * ((ROWS / 4) * (w / 4) + 2)) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)corr_volume_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(gs_cdiv(hw, BM), gs_cdiv(h, ROWS), n);
+  corr_volume_kernel<<<grid, 256, lds, st>>>(f1t, f2t, (_Float16*)vol0, (_Float16*)vol1, (_Float16*)vol2,
+                                             (_Float16*)vol3, h, w);
+  GS_CHECK_LAUNCH("corr_volume");
+  return GS_OK;
+}

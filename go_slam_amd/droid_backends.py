@@ -242,3 +242,29 @@ def altcorr_forward(fmap1, fmap2, coords, radius):
 def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
     """droid.cpp (altcorr_backward): training-only in the reference."""
     raise NotImplementedError("altcorr_backward: training-only path, not built yet")
+
+
+def corr_volume_supported(fmap1):
+    n, dim, h, w = fmap1.shape
+    return fmap1.dtype == torch.float16 and dim == 128 and h >= 8 and w % 8 == 0 and 8 <= w <= 80
+
+
+def corr_volume_pyramid(fmap1, fmap2):
+    """CorrBlock.__init__ + CorrBlock.corr (src/modules/corr.py:26-41,67-76) in one pass:
+    fmap1, fmap2 f16 [n,128,h,w] -> list of 4 tensors [n,h,w,h>>l,w>>l] (MFMA GEMM fused with the
+    three average pools; the volume is written once and never re-read)."""
+    _chk("fmap1", fmap1, torch.float16)
+    _chk("fmap2", fmap2, torch.float16)
+    if fmap1.shape != fmap2.shape or not corr_volume_supported(fmap1):
+        raise RuntimeError(f"corr_volume_pyramid: unsupported shape {tuple(fmap1.shape)} / {tuple(fmap2.shape)}")
+    n, dim, h, w = fmap1.shape
+    dev = fmap1.device
+    vols = [torch.empty(n, h, w, h >> l, w >> l, dtype=torch.float16, device=dev) for l in range(4)]
+    L = _lib.lib()
+    need = L.gs_corr_volume_workspace_bytes(n, dim, h, w)
+    ws = _workspace(dev, need + 256)
+    with torch.cuda.device(dev):
+        rc = L.gs_corr_volume_pyramid(_lib.ptr(fmap1), _lib.ptr(fmap2), *[_lib.ptr(v) for v in vols], n, dim, h, w,
+                                      _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "corr_volume_pyramid")
+    return vols

@@ -63,6 +63,15 @@ int gs_corr_lookup_pyramid(const void* vol0, const void* vol1, const void* vol2,
                            int n, int h1, int w1, int h2, int w2, int radius, int dtype,
                            int channels_last, gs_stream_t stream);
 
+/* CorrBlock.__init__ + CorrBlock.corr (src/modules/corr.py:26-41,67-76): all-pairs volume of
+ * fp16 feature maps fmap1[e], fmap2[e] ([n,128,h,w], both divided by 4) plus the 3 average-pooled
+ * levels, each pooled level computed from the fp16-rounded level below (avg_pool2d on half).
+ * Outputs vol[l] f16 [n,h,w,h>>l,w>>l].  Requires w % 8 == 0, w <= 80, h >= 8.                  */
+size_t gs_corr_volume_workspace_bytes(int n, int dim, int h, int w);
+int gs_corr_volume_pyramid(const void* fmap1, const void* fmap2, void* vol0, void* vol1, void* vol2,
+                           void* vol3, int n, int dim, int h, int w,
+                           void* workspace, size_t workspace_bytes, gs_stream_t stream);
+
 /* droid_backends.altcorr_forward (droid.cpp:173-184, altcorr_kernel.cu:27-149,290-319).
  * fmap1 [b,h1,w1,c], fmap2 [b,h2,w2,c] (channels-last, c in {64,128,256}), coords f32
  * [b,s,h1,w1,2] -> corr [b,s,(2r+1)^2,h1,w1]; dtype f16 or f32, fp32 accumulation.             */

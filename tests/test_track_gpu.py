@@ -319,3 +319,29 @@ def test_altcorr_block_matches_oracle_lookup(O, dev, built_lib):
     out = blk(coords.to(dev), ii.to(dev), jj.to(dev))
     assert tuple(out.shape) == (1, 6, 196, ht, wd) and out.dtype == torch.float32
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("shape", ["tiny", "Scan", "Rep"])
+def test_corr_volume_pyramid_matches_oracle(db, O, dev, shape):
+    """Fused MFMA volume + pyramid vs CorrBlock.corr/avg_pool2d restated on the CPU.  Level 0 may
+    differ by one fp16 rounding of the fp32 dot product (summation order); pooled levels must be
+    EXACTLY the average-pool of the level below (checked against the GPU's own lower level)."""
+    import torch.nn.functional as F
+    ht, wd, _ = synth.SHAPES[shape]
+    n = 2
+    f1 = synth.make_features(n, shape, seed=51)
+    f2 = synth.make_features(n, shape, seed=52)
+    ref = O.corr_pyramid(f1[None], f2[None])
+    out = db.corr_volume_pyramid(f1.to(dev), f2.to(dev))
+    for l in range(4):
+        assert tuple(out[l].shape) == tuple(ref[l].shape), (l, out[l].shape, ref[l].shape)
+    o0, r0 = out[0].cpu().float(), ref[0].float()
+    diff = (o0 - r0).abs()
+    assert float(diff.max()) <= 2 ** -10 * max(1.0, float(r0.abs().max())) * 1.01
+    assert float((diff == 0).float().mean()) > 0.97
+    for l in range(1, 4):
+        low = out[l - 1].cpu()
+        nn_, h1, w1, hl, wl = low.shape
+        pooled = F.avg_pool2d(low.reshape(-1, 1, hl, wl).float(), 2, 2).to(torch.float16)
+        assert torch.equal(out[l].cpu().reshape(-1, 1, hl // 2, wl // 2), pooled), f"level {l}"
+        torch.testing.assert_close(out[l].cpu().float(), ref[l].float(), rtol=0, atol=2e-3)
