@@ -42,7 +42,9 @@ SIGNATURES = {
     "gs_mlp_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gs_mlp_forward": (c_int, [_P] * 3 + [c_int] * 3 + [_P, c_size_t, _P]),
     "gs_neus_forward_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "gs_neus_forward": (c_int, [_P] * 9 + [c_float] + [_P] * 13 + [c_int, c_int, _P, c_size_t, _P]),
+    "gs_neus_forward": (c_int, [_P] * 9 + [c_float] + [_P] * 15 + [c_int, c_int, _P, c_size_t, _P]),
+    "gs_neus_backward_rays": (c_int, [_P] * 13 + [c_int, c_int, _P]),
+    "gs_neus_backward_points": (c_int, [_P] * 7 + [c_float] + [_P] * 16 + [c_int, c_int, _P]),
 }
 
 

@@ -320,6 +320,11 @@ __global__ __launch_bounds__(256) void neus_point_kernel(NeusArgs A, gs_grid_met
     sdf_out[idx] = 100.0f;
     alpha_out[idx] = 0.0f;
     grad_out[idx * 3 + 0] = 0.f; grad_out[idx * 3 + 1] = 0.f; grad_out[idx * 3 + 2] = 0.f;
+    // keep the MLP input row finite: the training path runs GEMMs over ALL rows (0 * NaN = NaN)
+    half8* dst = reinterpret_cast<half8*>(mlp_in + (size_t)idx * 80);
+    const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 10; ++q) dst[q] = zero;
     return;
   }
   // normalized_3d_coordinate (InstantNeuS.py:12-32) with the STATIC bound, clamped to [-1,1]
@@ -744,8 +749,8 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
                                const void* mlp, float inv_s, const float* bound_host, const float* rt_bound_host,
                                float* color, float* depth, float* depth_var, float* normal, float* weight_sum,
                                float* sdf, float* z_mid, float* grad_err_ray, float* alpha_out, void* rgb_out,
-                               float* grad_out, int n, int s, void* workspace, size_t workspace_bytes,
-                               gs_stream_t stream) {
+                               float* grad_out, uint8_t* mask_out, void* mlp_in_out, int n, int s, void* workspace,
+                               size_t workspace_bytes, gs_stream_t stream) {
   GS_REQUIRE(rays_o && rays_d && z_vals && dists && grid && sdf_w && sdf_b && color_B && mlp && bound_host &&
                  rt_bound_host, "neus_forward: null input");
   GS_REQUIRE(color && depth && depth_var && normal && weight_sum && sdf && z_mid && grad_err_ray,
@@ -769,6 +774,8 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
   float* alpha = alpha_out ? alpha_out : ws.alpha;
   float* grad = grad_out ? grad_out : ws.grad;
   _Float16* rgb = rgb_out ? (_Float16*)rgb_out : ws.rgb;
+  if (mask_out) ws.mask = mask_out;
+  if (mlp_in_out) ws.mlp_in = (_Float16*)mlp_in_out;
   if (hipMemsetAsync(ws.count, 0, 4, st) != hipSuccess) { gs_set_error("neus_forward: memset failed"); return GS_ERR_LAUNCH; }
   neus_count_kernel<<<gs_cdiv(np, 256), 256, 0, st>>>(A, ws.count);
   GS_CHECK_LAUNCH("neus_count");

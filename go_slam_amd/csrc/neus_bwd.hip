@@ -1,0 +1,361 @@
+// Backward of the NeuS renderer for the mapper's training step (reference: the autograd graph of
+// src/InstantNeuS.py:295-370 incl. autograd.grad(create_graph=True) at :141-148 and tiny-cuda-nn's
+// grid backward / double-backward kernels).
+//
+//   neus_ray_bwd_kernel    one wave per ray: recompute transmittance with a prefix scan, form
+//                          dL/dw_k, and turn it into dL/dalpha_k with a reverse suffix scan
+//                          (T_j, j>k, all depend on alpha_k); emits d_rgb and the normal-output
+//                          share of d_grad.
+//   neus_point_bwd_kernel  one lane per sample point: NeuS-alpha chain, SDF linear layer, and the
+//                          hash grid -- both the value path (d enc * w_corner) and the second-order
+//                          path through d sdf / d x (d dy_dx * +-scale * w_other) are scattered with
+//                          fp32 atomics into the table gradient; small dense parameter gradients
+//                          are emitted as per-point rows and reduced by GEMM / column sums on the
+//                          host side of the C ABI's caller.
+#include "common.h"
+#include "neus_common.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float u = __shfl_up(v, off, 64);
+    if (lane >= off) v = v * u;
+  }
+  return v;
+}
+
+// inclusive suffix sum over lanes (lane k gets sum_{j>=k} v_j)
+__device__ __forceinline__ float wave_incl_suffix_sum(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float u = __shfl_down(v, off, 64);
+    if (lane + off < 64) v = v + u;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void neus_ray_bwd_kernel(
+    const float* __restrict__ alpha, const _Float16* __restrict__ rgb, const float* __restrict__ zmid,
+    const float* __restrict__ grad, const uint8_t* __restrict__ mask, const float* __restrict__ d_color,
+    const float* __restrict__ d_depth, const float* __restrict__ d_dvar, const float* __restrict__ d_normal,
+    const float* __restrict__ d_wsum, float* __restrict__ d_alpha, float* __restrict__ d_rgb,
+    float* __restrict__ d_grad, int n, int s) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const size_t b = (size_t)r * s;
+  // two samples per lane: k0 = lane, k1 = lane + 64   (s <= 128)
+  float a[2], z[2], T[2], w[2], mk[2], g[2][3], c[2][3];
+  bool on[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int k = lane + 64 * h;
+    on[h] = k < s;
+    a[h] = on[h] ? alpha[b + k] : 0.0f;
+    z[h] = on[h] ? zmid[b + k] : 0.0f;
+    mk[h] = (on[h] && mask[b + k]) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      g[h][d] = on[h] ? grad[(b + k) * 3 + d] : 0.0f;
+      c[h][d] = on[h] ? (float)rgb[(b + k) * 3 + d] : 0.0f;
+    }
+  }
+  float Trun = 1.0f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float t = on[h] ? (1.0f - a[h] + 1e-7f) : 1.0f;
+    const float incl = wave_incl_prod(t, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.0f;
+    T[h] = Trun * excl;
+    w[h] = a[h] * T[h];
+    Trun = Trun * __shfl(incl, 63, 64);
+  }
+  const float wsum = gs_wave_sum(w[0] + w[1]);
+  const float dep = gs_wave_sum(z[0] * w[0] + z[1] * w[1]);
+  const float dc[3] = {d_color[r * 3 + 0], d_color[r * 3 + 1], d_color[r * 3 + 2]};
+  const float dn[3] = {d_normal[r * 3 + 0], d_normal[r * 3 + 1], d_normal[r * 3 + 2]};
+  const float ddv = d_dvar[r], dws = d_wsum[r];
+  // depth also enters depth_var: d depth_var / d depth = -2 sum_k w_k (z_k - depth)
+  const float dd_tot = d_depth[r] - 2.0f * ddv * (dep - dep * wsum);
+  float dLdw[2], u[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float dz = z[h] - dep;
+    float v = (dc[0] * c[h][0] + dc[1] * c[h][1] + dc[2] * c[h][2]) + dd_tot * z[h] + dws + ddv * dz * dz;
+    v += (dn[0] * g[h][0] + dn[1] * g[h][1] + dn[2] * g[h][2]) * mk[h];
+    dLdw[h] = on[h] ? v : 0.0f;
+    u[h] = dLdw[h] * w[h];
+  }
+  // R_k = sum_{j>k} u_j  (suffix over the 128 virtual positions, second half first)
+  float R[2];
+  {
+    const float inc1 = wave_incl_suffix_sum(u[1], lane);
+    R[1] = inc1 - u[1];
+    const float tot1 = __shfl(inc1, 0, 64);
+    const float inc0 = wave_incl_suffix_sum(u[0], lane);
+    R[0] = (inc0 - u[0]) + tot1;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int k = lane + 64 * h;
+    if (!on[h]) continue;
+    const float da = dLdw[h] * T[h] - R[h] / (1.0f - a[h] + 1e-7f);
+    d_alpha[b + k] = da * mk[h];                       // stored alpha = alpha * mask
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      d_rgb[(b + k) * 3 + d] = dc[d] * w[h] * mk[h];   // masked-out points have rgb == 0 (no grad)
+      d_grad[(b + k) * 3 + d] = dn[d] * w[h] * mk[h];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t grid_index(const gs_grid_meta& m, int l, uint32_t cx, uint32_t cy, uint32_t cz) {
+  const uint32_t size = m.size[l];
+  uint32_t idx;
+  if (m.hashed[l]) {
+    idx = (cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u);
+  } else {
+    const uint32_t res = m.resolution[l];
+    idx = cx + cy * res + cz * res * res;
+  }
+  return idx % size;
+}
+
+struct BwdArgs {
+  const float* rays_o; const float* rays_d; const float* z_vals; const float* dists;
+  const _Float16* grid; const float* sdf_w; const float* color_B;
+  float inv_s; float bound[6];
+  const float* sdf; const float* grad; const uint8_t* mask;
+  const float* d_alpha; const float* d_sdf; const float* d_grad; const float* dX;
+  const float* d_gerr_ray;
+  float* grid_grad; float* d_out; float* lin_in; float* dw0; float* d_arg; float* pts; float* d_inv_s;
+  int n, s;
+};
+
+__global__ __launch_bounds__(256) void neus_point_bwd_kernel(BwdArgs A, gs_grid_meta m) {
+  __shared__ float red[4];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int np = A.n * A.s;
+  const bool valid = idx < np;
+  const int i = valid ? idx : np - 1;
+  const bool on = valid && A.mask[i] != 0;
+  const int ray = i / A.s;
+  const float dist = A.dists[i];
+  const float zm = A.z_vals[i] + dist / 2.0f;
+  float pt[3], dir[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    dir[d] = A.rays_d[ray * 3 + d];
+    pt[d] = A.rays_o[ray * 3 + d] + dir[d] * zm;
+  }
+  float d_invs_local = 0.f;
+  if (valid) {
+    A.pts[(size_t)i * 3 + 0] = pt[0]; A.pts[(size_t)i * 3 + 1] = pt[1]; A.pts[(size_t)i * 3 + 2] = pt[2];
+  }
+  if (on) {
+    const float sdf = A.sdf[i];
+    const float g[3] = {A.grad[i * 3 + 0], A.grad[i * 3 + 1], A.grad[i * 3 + 2]};
+    const float* dx = A.dX + (size_t)i * 80;
+    // ---- total gradient w.r.t. sdf and grad ------------------------------------------------
+    float d_sdf = A.d_sdf[i];
+    float dg[3];
+    const float gn = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
+    const float eik = (gn > 0.f) ? A.d_gerr_ray[ray] * 2.0f * (gn - 1.0f) / gn : 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) dg[d] = A.d_grad[i * 3 + d] + eik * g[d] + dx[33 + d];
+    {   // NeuS alpha (InstantNeuS.py:276-293)
+      const float da = A.d_alpha[i];
+      const float cosv = (dir[0] * g[0] + dir[1] * g[1]) + dir[2] * g[2];
+      const float c = -fmaxf(-cosv, 0.0f);
+      const float est_next = sdf + c * dist / 2.0f, est_prev = sdf - c * dist / 2.0f;
+      const float p = 1.0f / (1.0f + expf(-(est_prev * A.inv_s)));
+      const float q = 1.0f / (1.0f + expf(-(est_next * A.inv_s)));
+      const float raw = (p - q + 1e-5f) / (p + 1e-5f);
+      if (da != 0.0f && raw >= 0.0f && raw <= 1.0f) {    // torch.clip passes the gradient on [min, max]
+        const float dp = da * q / ((p + 1e-5f) * (p + 1e-5f));
+        const float dq = -da / (p + 1e-5f);
+        const float dprev = dp * p * (1.0f - p), dnext = dq * q * (1.0f - q);
+        d_invs_local = dprev * est_prev + dnext * est_next;
+        d_sdf += (dprev + dnext) * A.inv_s;
+        const float dc = (dnext - dprev) * A.inv_s * dist / 2.0f;
+        if (cosv < 0.0f) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) dg[d] += dc * dir[d];
+        }
+      }
+    }
+    // ---- SDF network ---------------------------------------------------------------------------
+    float p_[3], view[3], dG[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float span = A.bound[2 * d + 1] - A.bound[2 * d];
+      float qn = (pt[d] - A.bound[2 * d]) / span * 2.0f - 1.0f;
+      const float inside = (qn >= -1.0f && qn <= 1.0f) ? 1.0f : 0.0f;
+      qn = fminf(fmaxf(qn, -1.0f), 1.0f);
+      p_[d] = qn;
+      view[d] = (qn + 1.0f) / 2.0f;
+      dG[d] = dg[d] * inside * 2.0f / span;
+    }
+    float* dout = A.d_out + (size_t)i * 32;
+    float* lin = A.lin_in + (size_t)i * 35;
+    float* w0 = A.dw0 + (size_t)i * 35;
+    float dov[32];
+    dov[0] = d_sdf;
+#pragma unroll
+    for (int o = 1; o < 32; ++o) dov[o] = dx[36 + (o - 1)];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) dout[o] = dov[o];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { lin[d] = p_[d]; w0[d] = dG[d]; }
+#pragma unroll 1
+    for (int l = 0; l < GS_GRID_LEVELS; ++l) {
+      const float scale = m.scale[l];
+      float f[3];
+      uint32_t gi[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const float pos = fmaf(scale, view[d], 0.5f);
+        const float fl = floorf(pos);
+        gi[d] = (uint32_t)(int)fl;
+        f[d] = pos - fl;
+      }
+      const size_t off = (size_t)m.offset[l];
+      uint32_t cidx[8];
+      float v[8][2];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        cidx[c] = grid_index(m, l, gi[0] + (c & 1), gi[1] + ((c >> 1) & 1), gi[2] + ((c >> 2) & 1));
+        const uint32_t raw = *reinterpret_cast<const uint32_t*>(A.grid + (off + cidx[c]) * 2);
+        v[c][0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw & 0xffffu));
+        v[c][1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw >> 16));
+      }
+      float wc[8], e0 = 0.f, e1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float w = 1.0f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) w = w * (((c >> d) & 1) ? f[d] : (1.0f - f[d]));
+        wc[c] = w;
+        e0 = fmaf(w, v[c][0], e0);
+        e1 = fmaf(w, v[c][1], e1);
+      }
+      lin[3 + 2 * l] = (float)(_Float16)e0;
+      lin[3 + 2 * l + 1] = (float)(_Float16)e1;
+      // value path: d enc_f = sum_o d_out[o] W[o][3+2l+f]
+      const float* wl = A.sdf_w + 3 + 2 * l;
+      float de0 = 0.f, de1 = 0.f;
+#pragma unroll
+      for (int o = 0; o < 32; ++o) { de0 = fmaf(dov[o], wl[o * 35], de0); de1 = fmaf(dov[o], wl[o * 35 + 1], de1); }
+      // gradient path: grad_d = (W0[d] + 1/2 sum g_lf dydx_lf,d) * inside * 2/span
+      const float g0 = (float)(_Float16)wl[0], g1 = (float)(_Float16)wl[1];
+      float dy0[3], dy1[3];       // dy_dx of this level (needed for d W0[3+2l+f])
+      float gacc[8][2];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { gacc[c][0] = de0 * wc[c]; gacc[c][1] = de1 * wc[c]; }
+#pragma unroll
+      for (int gd = 0; gd < 3; ++gd) {
+        const int o0 = (gd == 0) ? 1 : 0, o1 = (gd == 2) ? 1 : 2;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float w = scale;
+          w = w * ((k & 1) ? f[o0] : (1.0f - f[o0]));
+          w = w * ((k & 2) ? f[o1] : (1.0f - f[o1]));
+          const int cl = ((k & 1) << o0) | (((k >> 1) & 1) << o1);
+          const int cr = cl | (1 << gd);
+          a0 = fmaf(w, v[cr][0] - v[cl][0], a0);
+          a1 = fmaf(w, v[cr][1] - v[cl][1], a1);
+          const float s0 = 0.5f * dG[gd] * g0 * w, s1 = 0.5f * dG[gd] * g1 * w;
+          gacc[cr][0] += s0; gacc[cl][0] -= s0;
+          gacc[cr][1] += s1; gacc[cl][1] -= s1;
+        }
+        dy0[gd] = a0;
+        dy1[gd] = a1;
+      }
+      w0[3 + 2 * l] = 0.5f * ((dG[0] * dy0[0] + dG[1] * dy0[1]) + dG[2] * dy0[2]);
+      w0[3 + 2 * l + 1] = 0.5f * ((dG[0] * dy1[0] + dG[1] * dy1[1]) + dG[2] * dy1[2]);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float* gp = A.grid_grad + (off + cidx[c]) * 2;
+        if (gacc[c][0] != 0.0f) atomicAdd(gp, gacc[c][0]);
+        if (gacc[c][1] != 0.0f) atomicAdd(gp + 1, gacc[c][1]);
+      }
+    }
+    // ---- colour embedding sin(pts @ B): d arg = d emb * cos(arg)
+    float* da_ = A.d_arg + (size_t)i * 33;
+#pragma unroll
+    for (int c = 0; c < 33; ++c) {
+      const float arg = (pt[0] * A.color_B[c] + pt[1] * A.color_B[33 + c]) + pt[2] * A.color_B[66 + c];
+      da_[c] = dx[c] * cosf(arg);
+    }
+  } else if (valid) {
+    float* dout = A.d_out + (size_t)i * 32;
+    float* lin = A.lin_in + (size_t)i * 35;
+    float* w0 = A.dw0 + (size_t)i * 35;
+    float* da_ = A.d_arg + (size_t)i * 33;
+    for (int o = 0; o < 32; ++o) dout[o] = 0.f;
+    for (int o = 0; o < 35; ++o) { lin[o] = 0.f; w0[o] = 0.f; }
+    for (int o = 0; o < 33; ++o) da_[o] = 0.f;
+  }
+  // one atomic per workgroup for d inv_s
+  const float ws = gs_wave_sum(d_invs_local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (red[0] + red[1]) + (red[2] + red[3]);
+    if (t != 0.0f) atomicAdd(A.d_inv_s, t);
+  }
+}
+
+gs_grid_meta host_meta() {
+  gs_grid_meta m;
+  gs_grid_meta_default(&m);
+  return m;
+}
+
+}  // namespace
+
+extern "C" int gs_neus_backward_rays(const float* alpha, const void* rgb, const float* z_mid, const float* grad,
+                                     const uint8_t* mask, const float* d_color, const float* d_depth,
+                                     const float* d_depth_var, const float* d_normal, const float* d_weight_sum,
+                                     float* d_alpha, float* d_rgb, float* d_grad, int n, int s, gs_stream_t stream) {
+  GS_REQUIRE(alpha && rgb && z_mid && grad && mask && d_color && d_depth && d_depth_var && d_normal && d_weight_sum &&
+                 d_alpha && d_rgb && d_grad, "neus_backward_rays: null pointer");
+  GS_REQUIRE(n >= 0 && s > 0 && s <= 128, "neus_backward_rays: 1 <= samples per ray <= 128 (got %d)", s);
+  if (n == 0) return GS_OK;
+  neus_ray_bwd_kernel<<<gs_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(alpha, (const _Float16*)rgb, z_mid, grad, mask,
+                                                                     d_color, d_depth, d_depth_var, d_normal,
+                                                                     d_weight_sum, d_alpha, d_rgb, d_grad, n, s);
+  GS_CHECK_LAUNCH("neus_backward_rays");
+  return GS_OK;
+}
+
+extern "C" int gs_neus_backward_points(const float* rays_o, const float* rays_d, const float* z_vals,
+                                       const float* dists, const void* grid, const float* sdf_w,
+                                       const float* color_B, float inv_s, const float* bound_host, const float* sdf,
+                                       const float* grad, const uint8_t* mask, const float* d_alpha,
+                                       const float* d_sdf, const float* d_grad, const float* dX, const float* d_gerr_ray,
+                                       float* grid_grad, float* d_out, float* lin_in, float* dw0, float* d_arg,
+                                       float* pts, float* d_inv_s, int n, int s, gs_stream_t stream) {
+  GS_REQUIRE(rays_o && rays_d && z_vals && dists && grid && sdf_w && color_B && bound_host && sdf && grad && mask &&
+                 d_alpha && d_sdf && d_grad && dX && d_gerr_ray && grid_grad && d_out && lin_in && dw0 && d_arg && pts && d_inv_s,
+             "neus_backward_points: null pointer");
+  GS_REQUIRE(n >= 0 && s > 0, "neus_backward_points: bad shape");
+  if (n == 0) return GS_OK;
+  BwdArgs A;
+  A.rays_o = rays_o; A.rays_d = rays_d; A.z_vals = z_vals; A.dists = dists;
+  A.grid = (const _Float16*)grid; A.sdf_w = sdf_w; A.color_B = color_B; A.inv_s = inv_s;
+  for (int k = 0; k < 6; ++k) A.bound[k] = bound_host[k];
+  A.sdf = sdf; A.grad = grad; A.mask = mask; A.d_alpha = d_alpha; A.d_sdf = d_sdf; A.d_grad = d_grad; A.dX = dX;
+  A.d_gerr_ray = d_gerr_ray;
+  A.grid_grad = grid_grad; A.d_out = d_out; A.lin_in = lin_in; A.dw0 = dw0; A.d_arg = d_arg; A.pts = pts;
+  A.d_inv_s = d_inv_s; A.n = n; A.s = s;
+  neus_point_bwd_kernel<<<gs_cdiv(n * s, 256), 256, 0, (hipStream_t)stream>>>(A, host_meta());
+  GS_CHECK_LAUNCH("neus_backward_points");
+  return GS_OK;
+}

@@ -116,34 +116,34 @@ class InstantNeuS(nn.Module):
             self._host_bounds = ((ctypes.c_float * 6)(*b), (ctypes.c_float * 6)(*r))
         return self._host_bounds
 
+    def _inv_s(self):
+        var = float(self.variance_network.variance.detach())          # host scalar (1 small D2H)
+        return var, min(max(math.exp(var * self.variance_network.scale_factor), 1e-6), 1e6)
+
+    def _needs_grad(self):
+        ps = [self.sdf_network.encoding.encoding.params, self.sdf_network.sdf_layer.weight,
+              self.sdf_network.sdf_layer.bias, self.color_network._B, self.color_network.network.params,
+              self.variance_network.variance]
+        return torch.is_grad_enabled() and any(p.requires_grad for p in ps)
+
     def forward(self, rays_o, rays_d, z_vals, dists, render_params=None):
-        """src/InstantNeuS.py:295-370; returns the same dict of 9 tensors."""
+        """src/InstantNeuS.py:295-370; returns the same dict of 9 tensors.  With gradients enabled
+        the outputs carry an autograd node whose backward runs the HIP backward kernels."""
         net = self.sdf_network
-        _require_inference(rays_o, rays_d, net.encoding.encoding.params, net.sdf_layer.weight,
-                           self.color_network.network.params)
         dev = rays_o.device
         n, s = z_vals.shape
+        var, inv_s = self._inv_s()
         f32 = dict(dtype=torch.float32, device=dev)
-        color, normal = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32)
-        depth, dvar, wsum, gerr = (torch.empty(n, 1, **f32) for _ in range(4))
-        sdf, zmid = torch.empty(n, s, **f32), torch.empty(n, s, **f32)
-        var = float(self.variance_network.variance.detach())          # host scalar (1 small D2H)
-        inv_s = min(max(math.exp(var * self.variance_network.scale_factor), 1e-6), 1e6)
-        bh, rh = self._bounds_host()
-        L = _lib.lib()
-        ws = _workspace(dev, L.gs_neus_forward_workspace_bytes(n, s) + 256)
-        grid = net.encoding.encoding.params_half()
-        mlp = self.color_network.network.params_half()
-        args = [rays_o.detach().float().contiguous(), rays_d.detach().float().contiguous(),
-                z_vals.detach().float().contiguous(), dists.detach().float().contiguous(), grid,
-                net.sdf_layer.weight.detach().float().contiguous(), net.sdf_layer.bias.detach().float().contiguous(),
-                self.color_network._B.detach().float().contiguous(), mlp]
-        with torch.cuda.device(dev):
-            rc = L.gs_neus_forward(*[_lib.ptr(a) for a in args], float(inv_s), bh, rh,
-                                   _lib.ptr(color), _lib.ptr(depth), _lib.ptr(dvar), _lib.ptr(normal), _lib.ptr(wsum),
-                                   _lib.ptr(sdf), _lib.ptr(zmid), _lib.ptr(gerr), None, None, None, n, s,
-                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
-        _lib.check(rc, "InstantNeuS.forward")
+        if self._needs_grad():
+            color, depth, dvar, normal, wsum, sdf, gerr, zmid = _NeusRenderFn.apply(
+                self, rays_o.detach().float().contiguous(), rays_d.detach().float().contiguous(),
+                z_vals.detach().float().contiguous(), dists.detach().float().contiguous(),
+                net.encoding.encoding.params, net.sdf_layer.weight, net.sdf_layer.bias, self.color_network._B,
+                self.color_network.network.params, self.variance_network.variance)
+        else:
+            color, depth, dvar, normal, wsum, sdf, gerr, zmid = _neus_forward_raw(
+                self, rays_o.detach().float().contiguous(), rays_d.detach().float().contiguous(),
+                z_vals.detach().float().contiguous(), dists.detach().float().contiguous(), inv_s, save=False)[:8]
         return {
             "color": color, "depth": depth, "depth_variance": dvar, "normal": normal, "weight_sum": wsum,
             "sdf_variance": torch.full((n, 1), 1.0 / math.exp(var * self.variance_network.scale_factor), **f32),
@@ -165,3 +165,125 @@ class InstantNeuS(nn.Module):
         fl = torch.max(torch.exp((-self.sdf_sparse_factor * pred).clamp(max=10.0)) - torch.ones_like(pred),
                        pred - bnd).clamp(min=0.0) * front
         return ((torch.abs(pred - bnd) * sm).sum(1) / nvs).sum() / nvr, (fl.sum(1) / nvs).sum() / nvr
+
+
+# ------------------------------------------------------------------------------------------
+# fused forward / backward plumbing
+# ------------------------------------------------------------------------------------------
+
+def _neus_forward_raw(model, rays_o, rays_d, z_vals, dists, inv_s, save):
+    net = model.sdf_network
+    dev = rays_o.device
+    n, s = z_vals.shape
+    f32 = dict(dtype=torch.float32, device=dev)
+    color, normal = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32)
+    depth, dvar, wsum, gerr = (torch.empty(n, 1, **f32) for _ in range(4))
+    sdf, zmid = torch.empty(n, s, **f32), torch.empty(n, s, **f32)
+    saved = {}
+    if save:
+        saved = dict(alpha=torch.empty(n, s, **f32), rgb=torch.empty(n, s, 3, dtype=torch.float16, device=dev),
+                     grad=torch.empty(n, s, 3, **f32), mask=torch.empty(n, s, dtype=torch.uint8, device=dev),
+                     mlp_in=torch.empty(n * s, 80, dtype=torch.float16, device=dev))
+    bh, rh = model._bounds_host()
+    L = _lib.lib()
+    ws = _workspace(dev, L.gs_neus_forward_workspace_bytes(n, s) + 256)
+    grid = net.encoding.encoding.params_half()
+    mlp = model.color_network.network.params_half()
+    sdf_w = net.sdf_layer.weight.detach().float().contiguous()
+    sdf_b = net.sdf_layer.bias.detach().float().contiguous()
+    cB = model.color_network._B.detach().float().contiguous()
+    with torch.cuda.device(dev):
+        rc = L.gs_neus_forward(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z_vals), _lib.ptr(dists), _lib.ptr(grid),
+                               _lib.ptr(sdf_w), _lib.ptr(sdf_b), _lib.ptr(cB), _lib.ptr(mlp), float(inv_s), bh, rh,
+                               _lib.ptr(color), _lib.ptr(depth), _lib.ptr(dvar), _lib.ptr(normal), _lib.ptr(wsum),
+                               _lib.ptr(sdf), _lib.ptr(zmid), _lib.ptr(gerr),
+                               _lib.ptr(saved.get("alpha")), _lib.ptr(saved.get("rgb")), _lib.ptr(saved.get("grad")),
+                               _lib.ptr(saved.get("mask")), _lib.ptr(saved.get("mlp_in")), n, s,
+                               _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "InstantNeuS.forward")
+    saved.update(grid=grid, mlp=mlp, sdf_w=sdf_w, cB=cB)
+    return color, depth, dvar, normal, wsum, sdf, gerr, zmid, saved
+
+
+class _NeusRenderFn(torch.autograd.Function):
+    """Differentiable wrapper of the fused renderer.  Inputs 6.. are the trained parameters; the
+    returned gradients are exactly what autograd produces for the reference's graph (incl. the
+    second-order path of `autograd.grad(create_graph=True)`, InstantNeuS.py:141-148)."""
+
+    @staticmethod
+    def forward(ctx, model, rays_o, rays_d, z_vals, dists, grid_p, sdf_w_p, sdf_b_p, cB_p, mlp_p, var_p):
+        var, inv_s = model._inv_s()
+        color, depth, dvar, normal, wsum, sdf, gerr, zmid, saved = _neus_forward_raw(
+            model, rays_o, rays_d, z_vals, dists, inv_s, save=True)
+        ctx.model, ctx.saved, ctx.inv_s, ctx.var = model, saved, inv_s, var
+        ctx.inputs = (rays_o, rays_d, z_vals, dists, sdf, zmid)
+        ctx.mark_non_differentiable(zmid)
+        return color, depth, dvar, normal, wsum, sdf, gerr, zmid
+
+    @staticmethod
+    def backward(ctx, d_color, d_depth, d_dvar, d_normal, d_wsum, d_sdf, d_gerr, _d_zmid):
+        model, S = ctx.model, ctx.saved
+        rays_o, rays_d, z_vals, dists, sdf, zmid = ctx.inputs
+        dev = rays_o.device
+        n, s = z_vals.shape
+        np_ = n * s
+        f32 = dict(dtype=torch.float32, device=dev)
+        z = lambda t, shape: (torch.zeros(shape, **f32) if t is None else t.float().contiguous())
+        d_color, d_normal = z(d_color, (n, 3)), z(d_normal, (n, 3))
+        d_depth, d_dvar, d_wsum, d_gerr = z(d_depth, (n, 1)), z(d_dvar, (n, 1)), z(d_wsum, (n, 1)), z(d_gerr, (n, 1))
+        d_sdf = z(d_sdf, (n, s))
+        L = _lib.lib()
+        st = _lib.stream_ptr(dev)
+        d_alpha = torch.empty(n, s, **f32)
+        d_rgb = torch.empty(np_, 3, **f32)
+        d_grad = torch.empty(np_, 3, **f32)
+        with torch.cuda.device(dev):
+            rc = L.gs_neus_backward_rays(_lib.ptr(S["alpha"]), _lib.ptr(S["rgb"]), _lib.ptr(zmid), _lib.ptr(S["grad"]),
+                                         _lib.ptr(S["mask"]), _lib.ptr(d_color), _lib.ptr(d_depth), _lib.ptr(d_dvar),
+                                         _lib.ptr(d_normal), _lib.ptr(d_wsum), _lib.ptr(d_alpha), _lib.ptr(d_rgb),
+                                         _lib.ptr(d_grad), n, s, st)
+        _lib.check(rc, "InstantNeuS.backward(rays)")
+        # ---- colour MLP backward (hipBLASLt GEMMs; an MFMA kernel replaces this in a later round)
+        X = S["mlp_in"]                                     # [np,80] f16
+        W = S["mlp"]
+        W1, W2, W3 = W[:5120].view(64, 80), W[5120:9216].view(64, 64), W[9216:].view(16, 64)
+        H1 = torch.relu(X @ W1.t())
+        H2 = torch.relu(H1 @ W2.t())
+        y = S["rgb"].view(np_, 3).float()
+        dpre = d_rgb * y * (1.0 - y)                        # sigmoid'
+        H2f, H1f = H2.float(), H1.float()
+        dW3 = torch.zeros(16, 64, **f32)
+        dW3[:3] = dpre.t() @ H2f
+        dH2 = (dpre @ W3[:3].float()) * (H2f > 0)
+        dW2 = dH2.t() @ H1f
+        dH1 = (dH2 @ W2.float()) * (H1f > 0)
+        Xf = X.float()
+        dW1 = dH1.t() @ Xf
+        dX = (dH1 @ W1.float()).contiguous()                # [np,80]
+        g_mlp = torch.cat([dW1.reshape(-1), dW2.reshape(-1), dW3.reshape(-1)])
+        # ---- per-point backward: alpha chain, SDF linear, hash grid (value + second-order paths)
+        grid_grad = torch.zeros(S["grid"].numel(), **f32)
+        d_out = torch.empty(np_, 32, **f32)
+        lin_in = torch.empty(np_, 35, **f32)
+        dw0 = torch.empty(np_, 35, **f32)
+        d_arg = torch.empty(np_, 33, **f32)
+        pts = torch.empty(np_, 3, **f32)
+        d_invs = torch.zeros(1, **f32)
+        bh, _ = model._bounds_host()
+        with torch.cuda.device(dev):
+            rc = L.gs_neus_backward_points(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z_vals), _lib.ptr(dists),
+                                           _lib.ptr(S["grid"]), _lib.ptr(S["sdf_w"]), _lib.ptr(S["cB"]),
+                                           float(ctx.inv_s), bh, _lib.ptr(sdf.contiguous()), _lib.ptr(S["grad"]),
+                                           _lib.ptr(S["mask"]), _lib.ptr(d_alpha), _lib.ptr(d_sdf), _lib.ptr(d_grad),
+                                           _lib.ptr(dX), _lib.ptr(d_gerr.reshape(-1).contiguous()),
+                                           _lib.ptr(grid_grad), _lib.ptr(d_out), _lib.ptr(lin_in), _lib.ptr(dw0),
+                                           _lib.ptr(d_arg), _lib.ptr(pts), _lib.ptr(d_invs), n, s, st)
+        _lib.check(rc, "InstantNeuS.backward(points)")
+        g_sdf_w = d_out.t() @ lin_in
+        g_sdf_w[0] += dw0.sum(0)
+        g_sdf_b = d_out.sum(0)
+        g_cB = pts.t() @ d_arg
+        sf = model.variance_network.scale_factor
+        raw = math.exp(ctx.var * sf)
+        g_var = (d_invs[0] * sf * ctx.inv_s) if 1e-6 <= raw <= 1e6 else torch.zeros((), **f32)
+        return (None, None, None, None, None, grid_grad, g_sdf_w, g_sdf_b, g_cB, g_mlp, g_var.reshape(()))

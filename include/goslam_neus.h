@@ -65,7 +65,8 @@ int gs_mlp_forward(const void* x, const void* mlp, void* out, int n, int n_in, i
  * Outputs f32: color [n,3], depth [n], depth_var [n], normal [n,3], weight_sum [n], sdf [n,s],
  *   z_mid [n,s] (= z_vals + dists/2), grad_err_ray [n] (per-ray sum of (|grad|-1)^2 * mask; the
  *   caller divides the total by n*s); optional per-point alpha f32 [n,s], rgb f16 [n,s,3],
- *   grad f32 [n,s,3] (NULL = keep in the workspace).                                           */
+ *   grad f32 [n,s,3], mask u8 [n,s], mlp_in f16 [n,s,80] (NULL = keep in the workspace; the
+ *   training path saves them for gs_neus_backward_*).                                          */
 size_t gs_neus_forward_workspace_bytes(int n, int s);
 int gs_neus_forward(const float* rays_o, const float* rays_d, const float* z_vals,
                     const float* dists, const void* grid, const float* sdf_w, const float* sdf_b,
@@ -73,8 +74,36 @@ int gs_neus_forward(const float* rays_o, const float* rays_d, const float* z_val
                     const float* bound_host, const float* rt_bound_host,
                     float* color, float* depth, float* depth_var, float* normal,
                     float* weight_sum, float* sdf, float* z_mid, float* grad_err_ray,
-                    float* alpha_out, void* rgb_out, float* grad_out, int n, int s,
+                    float* alpha_out, void* rgb_out, float* grad_out, uint8_t* mask_out,
+                    void* mlp_in_out, int n, int s,
                     void* workspace, size_t workspace_bytes, gs_stream_t stream);
+
+/* Backward of InstantNeuS.forward, stage 1 (per ray): from the upstream gradients of the ray
+ * outputs -- d_color [n,3], d_depth [n], d_depth_var [n], d_normal [n,3], d_weight_sum [n] --
+ * and the saved per-point alpha / rgb / z_mid / grad / mask, produce d_alpha f32 [n,s] (w.r.t. the
+ * unmasked alpha), d_rgb f32 [n,s,3] and the normal-output part of d_grad f32 [n,s,3].  s <= 128.  */
+int gs_neus_backward_rays(const float* alpha, const void* rgb, const float* z_mid, const float* grad,
+                          const uint8_t* mask, const float* d_color, const float* d_depth,
+                          const float* d_depth_var, const float* d_normal, const float* d_weight_sum,
+                          float* d_alpha, float* d_rgb, float* d_grad, int n, int s, gs_stream_t stream);
+
+/* Stage 2 (per sample point): chain d_alpha, d_sdf (loss on the sdf samples), d_grad (stage 1 +
+ * the eikonal term d_gerr_ray[ray] * d(|grad|-1)^2 * mask + the colour MLP's input gradient dX[:,33:36]),
+ * d_feat = dX[:,36:67] and d_emb = dX[:,0:33] through NeuS alpha, the SDF linear layer and the hash
+ * grid, INCLUDING the second-order path through d sdf / d x (tiny-cuda-nn's double backward).
+ *   dX f32 [n*s,80] is the colour MLP's input gradient (computed by the caller's MLP backward).
+ * Outputs: grid_grad f32 [total*2] (atomically accumulated; zero it first), d_out f32 [n*s,32]
+ * and lin_in f32 [n*s,35] (d sdf_layer.weight = d_out^T @ lin_in, d bias = colsum(d_out)),
+ * dw0 f32 [n*s,35] (extra per-point contribution to sdf_layer.weight row 0: colsum),
+ * d_arg f32 [n*s,33] (d color_B = pts^T @ d_arg), pts f32 [n*s,3], d_inv_s f32 [1] (atomic; zero it). */
+int gs_neus_backward_points(const float* rays_o, const float* rays_d, const float* z_vals,
+                            const float* dists, const void* grid, const float* sdf_w,
+                            const float* color_B, float inv_s, const float* bound_host,
+                            const float* sdf, const float* grad, const uint8_t* mask,
+                            const float* d_alpha, const float* d_sdf, const float* d_grad,
+                            const float* dX, const float* d_gerr_ray,
+                            float* grid_grad, float* d_out, float* lin_in, float* dw0, float* d_arg,
+                            float* pts, float* d_inv_s, int n, int s, gs_stream_t stream);
 
 #ifdef __cplusplus
 }

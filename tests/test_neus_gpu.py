@@ -178,10 +178,80 @@ def test_neus_forward_no_point_in_bound_forces_first_100(N, O, dev):
     torch.testing.assert_close(out["color"].cpu(), ref["color"], rtol=0, atol=4e-3)
 
 
-def test_training_path_fails_loudly(N, dev):
-    model = N.InstantNeuS({}, [[-1, 1]] * 3).to(dev)
-    o = torch.zeros(4, 3, device=dev)
-    d = torch.ones(4, 3, device=dev)
-    z = torch.rand(4, 8, device=dev)
-    with pytest.raises(NotImplementedError):
-        model(o, d, z, z)
+def _rel(a, b):
+    return float((a - b).norm() / b.norm().clamp(min=1e-12))
+
+
+@pytest.mark.parametrize("grid_init", [0.3])
+def test_training_gradients_match_autograd_oracle(N, O, dev, grid_init):
+    """Mapper loss (reference src/mapping.py:96-132) -> gradients of every trained parameter:
+    fused HIP backward vs torch.autograd on the differentiable CPU restatement, including the
+    second-order path through d sdf/d x (eikonal, normals into the colour net and alpha)."""
+    from oracle import neus_autograd as NA
+    P = O.make_params(21, grid_init=grid_init, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    P["rt_bound"] = torch.tensor([[-2.2, 2.3], [-2.4, 2.1], [-2.0, 2.2]])
+    o, d, gt = _rays(48, seed=22)
+    g = torch.Generator().manual_seed(23)
+    z, dist = O.render_sample(o, d, gt, P["bound"], 24, 48, torch.rand(24, generator=g))
+    col = torch.rand(48, 3, generator=g)
+    # ---- oracle
+    Pd = {k: (v.clone().requires_grad_(True) if k in ("grid", "sdf_w", "sdf_b", "color_B", "mlp") else v)
+          for k, v in P.items()}
+    Pd["variance"] = torch.tensor(0.2, requires_grad=True)
+    ref_out = NA.neus_forward_diff(o, d, z, dist, Pd)
+    ref_loss = NA.mapping_loss(ref_out, col, gt)
+    ref_loss.backward()
+    # ---- HIP
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    model.update_bound(P["rt_bound"])
+    out = model(o.to(dev), d.to(dev), z.to(dev), dist.to(dev))
+    loss = NA.mapping_loss({k: v for k, v in out.items()}, col.to(dev), gt.to(dev))
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), ref_loss.detach(), rtol=2e-3, atol=1e-4)
+    pairs = {
+        "grid": (model.sdf_network.encoding.encoding.params.grad, Pd["grid"].grad),
+        "sdf_w": (model.sdf_network.sdf_layer.weight.grad, Pd["sdf_w"].grad),
+        "sdf_b": (model.sdf_network.sdf_layer.bias.grad, Pd["sdf_b"].grad),
+        "color_B": (model.color_network._B.grad, Pd["color_B"].grad),
+        "mlp": (model.color_network.network.params.grad, Pd["mlp"].grad),
+        "variance": (model.variance_network.variance.grad.reshape(1), Pd["variance"].grad.reshape(1)),
+    }
+    report = {k: _rel(a.cpu().float(), b) for k, (a, b) in pairs.items()}
+    for k, r in report.items():
+        assert r < 3e-2, report
+
+
+def test_training_step_reduces_loss(N, O, dev):
+    """Plain gradient descent along the fused backward's gradient decreases the mapper loss
+    monotonically; then the reference's optimiser setup (AdamW + clip 35, mapping.py:55-58,135)
+    runs a step with finite results."""
+    from oracle import neus_autograd as NA
+    P = O.make_params(31, grid_init=0.05, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    o, d, gt = _rays(256, seed=32)
+    g = torch.Generator().manual_seed(33)
+    z, dist = O.render_sample(o, d, gt, P["bound"], 24, 48, torch.rand(24, generator=g))
+    col = torch.rand(256, 3, generator=g).to(dev)
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    params = model.get_training_parameters() + model.get_volume_parameters()
+    args = [t.to(dev) for t in (o, d, z, dist)]
+    opt = torch.optim.SGD(params, lr=1e-4)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = NA.mapping_loss(model(*args), col, gt.to(dev))
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(b < a for a, b in zip(losses, losses[1:])), losses
+    assert losses[-1] < 0.99 * losses[0], losses
+    opt = torch.optim.AdamW([{"params": model.get_training_parameters(), "lr": 1e-3},
+                             {"params": model.get_volume_parameters(), "lr": 1e-2}],
+                            betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    opt.zero_grad()
+    loss = NA.mapping_loss(model(*args), col, gt.to(dev))
+    loss.backward()
+    gn = torch.nn.utils.clip_grad_norm_(params, 35.0)
+    opt.step()
+    assert math.isfinite(float(gn)) and all(torch.isfinite(p).all() for p in params)
