@@ -162,6 +162,51 @@ def neus_render_bench(device, n_rays=4096, iters=20):
             "gather_GBps": pts * 512.0 / (ms_fwd * 1e-3) / 1e9}
 
 
+def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768):
+    """Mapping step (render + losses + backward + grad all-reduce + clip + AdamW) on a GLOBAL batch
+    of 32768 rays x 72 samples sharded over `world` GPUs (strong scaling, BASELINE configs[4])."""
+    import go_slam_amd.neus as neus
+    from go_slam_amd.neus.mapper import MapTrainer
+    g = torch.Generator().manual_seed(43)
+    model = neus.InstantNeuS({}, [[-5.0, 5.0]] * 3).to(device)
+    with torch.no_grad():
+        model.sdf_network.encoding.encoding.params.copy_((torch.rand(model.sdf_network.encoding.encoding.params.shape, generator=g) - 0.5) * 0.02)
+        model.sdf_network.sdf_layer.weight[:, 3:] = torch.randn(32, 32, generator=g).to(device) * 0.1
+    R = neus.Renderer(N_samples=24, N_surface=48)
+    n = global_rays
+    o = (torch.rand(n, 3, generator=g) * 6 - 3).to(device)
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1).to(device)
+    gt = torch.rand(n, generator=g) * 3.5 + 0.5
+    gt[torch.rand(n, generator=g) < 0.1] = 0
+    gt = gt.to(device)
+    col = torch.rand(n, 3, generator=g).to(device)
+    pr = torch.rand(24, generator=g).to(device)
+    tr = MapTrainer(model, R, rank=rank, world=world)
+    import torch.distributed as dist
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warm):
+        loss = tr.step(o, d, col, gt, pr)
+    sync()
+    tic = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(o, d, col, gt, pr)
+    sync()
+    dt = time.perf_counter() - tic
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms = 1e3 * dt / steps
+    return {"metric": "NeuS mapping train step rays/s (render + loss + backward + all-reduce + clip + AdamW)",
+            "value": n / (ms * 1e-3), "unit": "rays/s", "global_rays": n, "rays_per_gpu": n // world, "ms_per_step": ms,
+            "scaling": "strong", "allreduce_bytes": 4 * sum(p.numel() for p in tr.train_params) if world > 1 else 0,
+            "final_loss": loss}
+
+
 def cpu_baseline(sample_updates=1):
     """The CPU oracle (+ the same UpdateModule on the host, fp32) on a bounded sample of the same
     workload: `sample_updates` update calls = sample_updates/6 keyframe."""
@@ -260,7 +305,9 @@ def main():
                    "parallelism": f"replicas x{world} (tracking does not shard)"},
         "updates_per_s": value * UPDATES_PER_KF, "state_finite": finite,
     }
+    train = neus_train_bench(device, rank, world)      # collective: every rank takes part
     if rank == 0:
+        line["neus_train"] = train
         br = op_breakdown(video, update_op, graph)
         line["breakdown_ms"] = {k: round(v, 4) for k, v in br.items() if k.endswith("_ms")}
         ht, wd = graph.ht, graph.wd

@@ -137,9 +137,46 @@ struct BwdArgs {
   int n, s;
 };
 
+// Scatter one level's 8 corners x 2 features.  Lanes are consecutive samples of a ray, so
+// neighbours often sit in the SAME cell (always at the coarse levels): runs of equal cells are
+// pre-reduced inside the wave with a segmented scan and only the run's last lane issues atomics --
+// at the coarse levels this removes ~10x of the (memory-side, heavily contended) atomic traffic.
+__device__ __forceinline__ void lvl_scatter(float* __restrict__ tab, const uint32_t (&cidx)[8], float (&gacc)[8][2],
+                                            const uint32_t (&gi)[3], bool on, int lane) {
+  const uint32_t p0 = __shfl_up(gi[0], 1, 64), p1 = __shfl_up(gi[1], 1, 64), p2 = __shfl_up(gi[2], 1, 64);
+  const int on_prev = __shfl_up((int)on, 1, 64);
+  const bool same = (lane > 0) && on && on_prev && p0 == gi[0] && p1 == gi[1] && p2 == gi[2];
+  const unsigned long long same_mask = __ballot(same);
+  bool tail = true;
+  if (same_mask != 0ull) {                            // wave-uniform
+    const unsigned long long starts = ~same_mask;     // bit set where a run begins
+    const unsigned long long below = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int run_start = 63 - __builtin_clzll(below);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const bool take = (lane - off) >= run_start;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float u0 = __shfl_up(gacc[c][0], off, 64), u1 = __shfl_up(gacc[c][1], off, 64);
+        if (take) { gacc[c][0] += u0; gacc[c][1] += u1; }
+      }
+    }
+    tail = (lane == 63) || (((starts >> (lane + 1)) & 1ull) != 0ull);
+  }
+  if (on && tail) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float* gp = tab + (size_t)cidx[c] * 2;
+      if (gacc[c][0] != 0.0f) atomicAdd(gp, gacc[c][0]);
+      if (gacc[c][1] != 0.0f) atomicAdd(gp + 1, gacc[c][1]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void neus_point_bwd_kernel(BwdArgs A, gs_grid_meta m) {
   __shared__ float red[4];
   const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int np = A.n * A.s;
   const bool valid = idx < np;
   const int i = valid ? idx : np - 1;
@@ -153,154 +190,148 @@ __global__ __launch_bounds__(256) void neus_point_bwd_kernel(BwdArgs A, gs_grid_
     dir[d] = A.rays_d[ray * 3 + d];
     pt[d] = A.rays_o[ray * 3 + d] + dir[d] * zm;
   }
-  float d_invs_local = 0.f;
   if (valid) {
     A.pts[(size_t)i * 3 + 0] = pt[0]; A.pts[(size_t)i * 3 + 1] = pt[1]; A.pts[(size_t)i * 3 + 2] = pt[2];
   }
-  if (on) {
-    const float sdf = A.sdf[i];
-    const float g[3] = {A.grad[i * 3 + 0], A.grad[i * 3 + 1], A.grad[i * 3 + 2]};
-    const float* dx = A.dX + (size_t)i * 80;
-    // ---- total gradient w.r.t. sdf and grad ------------------------------------------------
-    float d_sdf = A.d_sdf[i];
-    float dg[3];
-    const float gn = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
-    const float eik = (gn > 0.f) ? A.d_gerr_ray[ray] * 2.0f * (gn - 1.0f) / gn : 0.0f;
+  // Every lane runs the whole body (wave-level run reduction below needs uniform control flow);
+  // lanes that are out of bound / past the end carry zero upstream gradients and store nothing.
+  const float live = on ? 1.0f : 0.0f;
+  const float sdf = A.sdf[i];
+  const float g[3] = {A.grad[i * 3 + 0], A.grad[i * 3 + 1], A.grad[i * 3 + 2]};
+  const float* dx = A.dX + (size_t)i * 80;
+  // ---- total gradient w.r.t. sdf and grad ----------------------------------------------------
+  float d_sdf = A.d_sdf[i] * live;
+  float dg[3];
+  const float gn = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
+  const float eik = (gn > 0.f) ? A.d_gerr_ray[ray] * 2.0f * (gn - 1.0f) / gn : 0.0f;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) dg[d] = A.d_grad[i * 3 + d] + eik * g[d] + dx[33 + d];
-    {   // NeuS alpha (InstantNeuS.py:276-293)
-      const float da = A.d_alpha[i];
-      const float cosv = (dir[0] * g[0] + dir[1] * g[1]) + dir[2] * g[2];
-      const float c = -fmaxf(-cosv, 0.0f);
-      const float est_next = sdf + c * dist / 2.0f, est_prev = sdf - c * dist / 2.0f;
-      const float p = 1.0f / (1.0f + expf(-(est_prev * A.inv_s)));
-      const float q = 1.0f / (1.0f + expf(-(est_next * A.inv_s)));
-      const float raw = (p - q + 1e-5f) / (p + 1e-5f);
-      if (da != 0.0f && raw >= 0.0f && raw <= 1.0f) {    // torch.clip passes the gradient on [min, max]
-        const float dp = da * q / ((p + 1e-5f) * (p + 1e-5f));
-        const float dq = -da / (p + 1e-5f);
-        const float dprev = dp * p * (1.0f - p), dnext = dq * q * (1.0f - q);
-        d_invs_local = dprev * est_prev + dnext * est_next;
-        d_sdf += (dprev + dnext) * A.inv_s;
-        const float dc = (dnext - dprev) * A.inv_s * dist / 2.0f;
-        if (cosv < 0.0f) {
+  for (int d = 0; d < 3; ++d) dg[d] = (A.d_grad[i * 3 + d] + eik * g[d] + dx[33 + d]) * live;
+  float d_invs_local = 0.f;
+  {   // NeuS alpha (InstantNeuS.py:276-293)
+    const float da = A.d_alpha[i] * live;
+    const float cosv = (dir[0] * g[0] + dir[1] * g[1]) + dir[2] * g[2];
+    const float c = -fmaxf(-cosv, 0.0f);
+    const float est_next = sdf + c * dist / 2.0f, est_prev = sdf - c * dist / 2.0f;
+    const float p = 1.0f / (1.0f + expf(-(est_prev * A.inv_s)));
+    const float q = 1.0f / (1.0f + expf(-(est_next * A.inv_s)));
+    const float raw = (p - q + 1e-5f) / (p + 1e-5f);
+    if (da != 0.0f && raw >= 0.0f && raw <= 1.0f) {    // torch.clip passes the gradient on [min, max]
+      const float dp = da * q / ((p + 1e-5f) * (p + 1e-5f));
+      const float dq = -da / (p + 1e-5f);
+      const float dprev = dp * p * (1.0f - p), dnext = dq * q * (1.0f - q);
+      d_invs_local = dprev * est_prev + dnext * est_next;
+      d_sdf += (dprev + dnext) * A.inv_s;
+      const float dc = (dnext - dprev) * A.inv_s * dist / 2.0f;
+      if (cosv < 0.0f) {
 #pragma unroll
-          for (int d = 0; d < 3; ++d) dg[d] += dc * dir[d];
-        }
+        for (int d = 0; d < 3; ++d) dg[d] += dc * dir[d];
       }
     }
-    // ---- SDF network ---------------------------------------------------------------------------
-    float p_[3], view[3], dG[3];
+  }
+  // ---- SDF network -------------------------------------------------------------------------------
+  float p_[3], view[3], dG[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const float span = A.bound[2 * d + 1] - A.bound[2 * d];
-      float qn = (pt[d] - A.bound[2 * d]) / span * 2.0f - 1.0f;
-      const float inside = (qn >= -1.0f && qn <= 1.0f) ? 1.0f : 0.0f;
-      qn = fminf(fmaxf(qn, -1.0f), 1.0f);
-      p_[d] = qn;
-      view[d] = (qn + 1.0f) / 2.0f;
-      dG[d] = dg[d] * inside * 2.0f / span;
-    }
-    float* dout = A.d_out + (size_t)i * 32;
-    float* lin = A.lin_in + (size_t)i * 35;
-    float* w0 = A.dw0 + (size_t)i * 35;
-    float dov[32];
-    dov[0] = d_sdf;
+  for (int d = 0; d < 3; ++d) {
+    const float span = A.bound[2 * d + 1] - A.bound[2 * d];
+    float qn = (pt[d] - A.bound[2 * d]) / span * 2.0f - 1.0f;
+    const float inside = (qn >= -1.0f && qn <= 1.0f) ? 1.0f : 0.0f;
+    qn = fminf(fmaxf(qn, -1.0f), 1.0f);
+    p_[d] = qn;
+    view[d] = (qn + 1.0f) / 2.0f;
+    dG[d] = dg[d] * inside * 2.0f / span;
+  }
+  float* dout = A.d_out + (size_t)i * 32;
+  float* lin = A.lin_in + (size_t)i * 35;
+  float* w0 = A.dw0 + (size_t)i * 35;
+  float dov[32];
+  dov[0] = d_sdf;
 #pragma unroll
-    for (int o = 1; o < 32; ++o) dov[o] = dx[36 + (o - 1)];
+  for (int o = 1; o < 32; ++o) dov[o] = dx[36 + (o - 1)] * live;
+  if (valid) {
 #pragma unroll
     for (int o = 0; o < 32; ++o) dout[o] = dov[o];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { lin[d] = p_[d]; w0[d] = dG[d]; }
+    for (int d = 0; d < 3; ++d) { lin[d] = p_[d] * live; w0[d] = dG[d]; }
+  }
 #pragma unroll 1
-    for (int l = 0; l < GS_GRID_LEVELS; ++l) {
-      const float scale = m.scale[l];
-      float f[3];
-      uint32_t gi[3];
+  for (int l = 0; l < GS_GRID_LEVELS; ++l) {
+    const float scale = m.scale[l];
+    float f[3];
+    uint32_t gi[3];
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const float pos = fmaf(scale, view[d], 0.5f);
-        const float fl = floorf(pos);
-        gi[d] = (uint32_t)(int)fl;
-        f[d] = pos - fl;
+    for (int d = 0; d < 3; ++d) {
+      const float pos = fmaf(scale, view[d], 0.5f);
+      const float fl = floorf(pos);
+      gi[d] = (uint32_t)(int)fl;
+      f[d] = pos - fl;
+    }
+    const size_t off = (size_t)m.offset[l];
+    uint32_t cidx[8];
+    float v[8][2];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      cidx[c] = grid_index(m, l, gi[0] + (c & 1), gi[1] + ((c >> 1) & 1), gi[2] + ((c >> 2) & 1));
+      const uint32_t raw = *reinterpret_cast<const uint32_t*>(A.grid + (off + cidx[c]) * 2);
+      v[c][0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw & 0xffffu));
+      v[c][1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw >> 16));
+    }
+    float wc[8], e0 = 0.f, e1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float w = 1.0f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) w = w * (((c >> d) & 1) ? f[d] : (1.0f - f[d]));
+      wc[c] = w;
+      e0 = fmaf(w, v[c][0], e0);
+      e1 = fmaf(w, v[c][1], e1);
+    }
+    // value path: d enc_f = sum_o d_out[o] W[o][3+2l+f]
+    const float* wl = A.sdf_w + 3 + 2 * l;
+    float de0 = 0.f, de1 = 0.f;
+#pragma unroll
+    for (int o = 0; o < 32; ++o) { de0 = fmaf(dov[o], wl[o * 35], de0); de1 = fmaf(dov[o], wl[o * 35 + 1], de1); }
+    // gradient path: grad_d = (W0[d] + 1/2 sum g_lf dydx_lf,d) * inside * 2/span
+    const float g0 = (float)(_Float16)wl[0], g1 = (float)(_Float16)wl[1];
+    float dy0[3], dy1[3];
+    float gacc[8][2];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { gacc[c][0] = de0 * wc[c]; gacc[c][1] = de1 * wc[c]; }
+#pragma unroll
+    for (int gd = 0; gd < 3; ++gd) {
+      const int o0 = (gd == 0) ? 1 : 0, o1 = (gd == 2) ? 1 : 2;
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float w = scale;
+        w = w * ((k & 1) ? f[o0] : (1.0f - f[o0]));
+        w = w * ((k & 2) ? f[o1] : (1.0f - f[o1]));
+        const int cl = ((k & 1) << o0) | (((k >> 1) & 1) << o1);
+        const int cr = cl | (1 << gd);
+        a0 = fmaf(w, v[cr][0] - v[cl][0], a0);
+        a1 = fmaf(w, v[cr][1] - v[cl][1], a1);
+        const float s0 = 0.5f * dG[gd] * g0 * w, s1 = 0.5f * dG[gd] * g1 * w;
+        gacc[cr][0] += s0; gacc[cl][0] -= s0;
+        gacc[cr][1] += s1; gacc[cl][1] -= s1;
       }
-      const size_t off = (size_t)m.offset[l];
-      uint32_t cidx[8];
-      float v[8][2];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        cidx[c] = grid_index(m, l, gi[0] + (c & 1), gi[1] + ((c >> 1) & 1), gi[2] + ((c >> 2) & 1));
-        const uint32_t raw = *reinterpret_cast<const uint32_t*>(A.grid + (off + cidx[c]) * 2);
-        v[c][0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw & 0xffffu));
-        v[c][1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw >> 16));
-      }
-      float wc[8], e0 = 0.f, e1 = 0.f;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        float w = 1.0f;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) w = w * (((c >> d) & 1) ? f[d] : (1.0f - f[d]));
-        wc[c] = w;
-        e0 = fmaf(w, v[c][0], e0);
-        e1 = fmaf(w, v[c][1], e1);
-      }
-      lin[3 + 2 * l] = (float)(_Float16)e0;
-      lin[3 + 2 * l + 1] = (float)(_Float16)e1;
-      // value path: d enc_f = sum_o d_out[o] W[o][3+2l+f]
-      const float* wl = A.sdf_w + 3 + 2 * l;
-      float de0 = 0.f, de1 = 0.f;
-#pragma unroll
-      for (int o = 0; o < 32; ++o) { de0 = fmaf(dov[o], wl[o * 35], de0); de1 = fmaf(dov[o], wl[o * 35 + 1], de1); }
-      // gradient path: grad_d = (W0[d] + 1/2 sum g_lf dydx_lf,d) * inside * 2/span
-      const float g0 = (float)(_Float16)wl[0], g1 = (float)(_Float16)wl[1];
-      float dy0[3], dy1[3];       // dy_dx of this level (needed for d W0[3+2l+f])
-      float gacc[8][2];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { gacc[c][0] = de0 * wc[c]; gacc[c][1] = de1 * wc[c]; }
-#pragma unroll
-      for (int gd = 0; gd < 3; ++gd) {
-        const int o0 = (gd == 0) ? 1 : 0, o1 = (gd == 2) ? 1 : 2;
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float w = scale;
-          w = w * ((k & 1) ? f[o0] : (1.0f - f[o0]));
-          w = w * ((k & 2) ? f[o1] : (1.0f - f[o1]));
-          const int cl = ((k & 1) << o0) | (((k >> 1) & 1) << o1);
-          const int cr = cl | (1 << gd);
-          a0 = fmaf(w, v[cr][0] - v[cl][0], a0);
-          a1 = fmaf(w, v[cr][1] - v[cl][1], a1);
-          const float s0 = 0.5f * dG[gd] * g0 * w, s1 = 0.5f * dG[gd] * g1 * w;
-          gacc[cr][0] += s0; gacc[cl][0] -= s0;
-          gacc[cr][1] += s1; gacc[cl][1] -= s1;
-        }
-        dy0[gd] = a0;
-        dy1[gd] = a1;
-      }
+      dy0[gd] = a0;
+      dy1[gd] = a1;
+    }
+    if (valid) {
+      lin[3 + 2 * l] = (float)(_Float16)e0 * live;
+      lin[3 + 2 * l + 1] = (float)(_Float16)e1 * live;
       w0[3 + 2 * l] = 0.5f * ((dG[0] * dy0[0] + dG[1] * dy0[1]) + dG[2] * dy0[2]);
       w0[3 + 2 * l + 1] = 0.5f * ((dG[0] * dy1[0] + dG[1] * dy1[1]) + dG[2] * dy1[2]);
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        float* gp = A.grid_grad + (off + cidx[c]) * 2;
-        if (gacc[c][0] != 0.0f) atomicAdd(gp, gacc[c][0]);
-        if (gacc[c][1] != 0.0f) atomicAdd(gp + 1, gacc[c][1]);
-      }
     }
-    // ---- colour embedding sin(pts @ B): d arg = d emb * cos(arg)
+    lvl_scatter(A.grid_grad + off * 2, cidx, gacc, gi, on, lane);
+  }
+  // ---- colour embedding sin(pts @ B): d arg = d emb * cos(arg)
+  if (valid) {
     float* da_ = A.d_arg + (size_t)i * 33;
 #pragma unroll
     for (int c = 0; c < 33; ++c) {
       const float arg = (pt[0] * A.color_B[c] + pt[1] * A.color_B[33 + c]) + pt[2] * A.color_B[66 + c];
-      da_[c] = dx[c] * cosf(arg);
+      da_[c] = dx[c] * cosf(arg) * live;
     }
-  } else if (valid) {
-    float* dout = A.d_out + (size_t)i * 32;
-    float* lin = A.lin_in + (size_t)i * 35;
-    float* w0 = A.dw0 + (size_t)i * 35;
-    float* da_ = A.d_arg + (size_t)i * 33;
-    for (int o = 0; o < 32; ++o) dout[o] = 0.f;
-    for (int o = 0; o < 35; ++o) { lin[o] = 0.f; w0[o] = 0.f; }
-    for (int o = 0; o < 33; ++o) da_[o] = 0.f;
   }
   // one atomic per workgroup for d inv_s
   const float ws = gs_wave_sum(d_invs_local);

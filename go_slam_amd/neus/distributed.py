@@ -1,0 +1,91 @@
+"""Data-parallel mapping across the GPUs of one node: the mapper's ray batch is
+sharded over ranks, every rank holds a full replica of the 12.6 M-entry grid and the MLPs, and one
+exchange step per iteration sums the gradients over RCCL / xGMI.
+
+The reference has no distributed code at all (its only multi-device knob is mapping.device); DDP
+cannot be used because the loss needs `autograd.grad` (InstantNeuS.py:139), so the exchange is an
+explicit all-reduce of ONE flat fp32 buffer (50.4 MB: a single large collective suits xGMI's
+per-link-bound rings better than per-parameter calls).  For single-GPU parity the loss terms,
+which are means over *valid* rays, are normalised with GLOBAL counts, so the SUM of the rank
+gradients is exactly the gradient of the single-GPU loss.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous, near-even split of n rays: [lo, hi) for `rank`."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_rays(tensors, rank, world):
+    lo, hi = shard_bounds(tensors[0].shape[0], rank, world)
+    return [t[lo:hi] for t in tensors]
+
+
+def all_reduce_sum_(t, group=None):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def mapping_loss_sharded(ret, rays_color, rays_depth, compute_sdf_error, group=None, w_color=2.0, w_sdf=2.0,
+                         w_eikonal=0.1, uncertainty=True):
+    """Mapper.optimize_map's loss (reference src/mapping.py:96-132) on this rank's ray shard,
+    normalised by global counts.  `compute_sdf_error(sdf, z_vals, gt_depth)` is the model's
+    (InstantNeuS.py:372-400).  Returns (local_loss, global_loss_value): local_loss.backward()
+    followed by an all-reduce(SUM) of the gradients reproduces the single-GPU gradient."""
+    rd = rays_depth.reshape(-1, 1)
+    vm = (rd > 0).reshape(-1)
+    n_local = torch.tensor([float(vm.sum()), float(rd.shape[0])], device=rd.device, dtype=torch.float64)
+    n_glob = all_reduce_sum_(n_local.clone(), group)
+    nv_l, nr_l = float(n_local[0]), float(n_local[1])
+    nv_g, nr_g = float(n_glob[0]), float(n_glob[1])
+    rdv, rcv = rd[vm], rays_color[vm]
+    est_c, est_d = ret["color"][vm], ret["depth"][vm]
+    dv = ret["depth_variance"][vm]
+    uw = 1.0 / torch.sqrt(dv.detach() + 1e-10) if uncertainty else torch.ones_like(dv)
+    total = torch.abs(est_c - rcv).sum() / (3.0 * nv_g) * w_color
+    total = total + (torch.abs(est_d - rdv) * uw).sum() / nv_g
+    if nv_l > 0:
+        e, f = compute_sdf_error(ret["sdf"][vm], ret["z_vals"][vm], rdv)     # means over LOCAL valid rays
+        total = total + (e + f) * (nv_l / nv_g) * w_sdf
+    total = total + w_eikonal * ret["gradient_error"].mean() * (nr_l / nr_g)
+    glob = all_reduce_sum_(total.detach().clone().double(), group)
+    return total, float(glob)
+
+
+class FlatGradReducer:
+    """All-reduce(SUM) of the gradients of `params` through one persistent flat buffer."""
+
+    def __init__(self, params, dtype=torch.float32):
+        self.params = [p for p in params]
+        self.sizes = [p.numel() for p in self.params]
+        self.dtype = dtype
+        self.flat = None
+
+    def nbytes(self):
+        return sum(self.sizes) * torch.empty((), dtype=self.dtype).element_size()
+
+    def reduce(self, group=None):
+        p0 = self.params[0]
+        if self.flat is None or self.flat.device != p0.device:
+            self.flat = torch.zeros(sum(self.sizes), dtype=self.dtype, device=p0.device)
+        off = 0
+        for p, k in zip(self.params, self.sizes):
+            if p.grad is None:
+                self.flat[off:off + k].zero_()
+            else:
+                self.flat[off:off + k].copy_(p.grad.reshape(-1))
+            off += k
+        all_reduce_sum_(self.flat, group)
+        off = 0
+        for p, k in zip(self.params, self.sizes):
+            g = self.flat[off:off + k].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += k
