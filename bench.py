@@ -314,10 +314,15 @@ def main():
         algo_bytes = 912.0 * ht * wd * br["edges"]            # 912*HW B per edge per lookup
         t_s = br["corr_lookup_ms"] * 1e-3
         achieved = algo_bytes / t_s / 1e9
-        line["roofline"] = {"kernel": "corr_pyramid_kernel<f16> (fused 4-level lookup)", "bound": "hbm",
+        traffic = None      # HBM bytes per launch from the committed PMC passes (same workload)
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_corr_lookup.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+        line["roofline"] = {"kernel": "corr_pyramid_kernel<f16,NHWC> (fused 4-level lookup)", "bound": "hbm",
                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                            "algorithmic_bytes_per_launch": algo_bytes}
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                            "algorithmic_bytes_per_launch": algo_bytes,
+                            "kernel_avg_us": br["corr_lookup_ms"] * 1e3}
         line["neus_render"] = neus_render_bench(device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(3)
