@@ -27,42 +27,60 @@ __global__ void chol_damp_kernel(double* __restrict__ A, int n, double lm, doubl
   }
 }
 
-// Factor the diagonal block [k0,k0+nb) in LDS (all workgroups redundantly) and compute
-// L21 = A21 * L11^-T for this workgroup's PR rows.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned int lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffu), lane);
+  const unsigned int hi = __builtin_amdgcn_readlane((int)(u >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// Factor the diagonal block [k0,k0+nb) (every workgroup redundantly -- cheaper than a dependent
+// launch) and compute L21 = A21 * L11^-T for this workgroup's PR rows.
+// The 32x32 factorisation is wave-synchronous and register-resident: lane i holds row i
+// (32 doubles), pivots and column entries are broadcast with v_readlane, no LDS, no barriers
+// (~1.5 us instead of 32 x 3 barrier-separated LDS sweeps).
 __global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ A, int n, int k0,
                                                         int32_t* fail_flag) {
   __shared__ double D[NB][NB + 1];
-  __shared__ int bad;
   const int lane = threadIdx.x;
   const int nb = min(NB, n - k0);
-  if (lane == 0) bad = 0;
-  for (int idx = lane; idx < NB * NB; idx += 64) {
-    const int r = idx / NB, c = idx % NB;
-    D[r][c] = (r < nb && c <= r) ? A[(size_t)(k0 + r) * n + (k0 + c)] : 0.0;
+  double a[NB];
+  {
+    const int r = lane & (NB - 1);
+    const bool live = (lane < NB) && (r < nb);
+    const double* Ar = A + (size_t)(k0 + (live ? r : 0)) * n + k0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      double v = (live && c <= r && c < nb) ? Ar[c] : 0.0;
+      if (!live && c == r) v = 1.0;            // identity padding keeps the recurrence well-defined
+      a[c] = v;
+    }
+  }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const double piv = readlane_f64(a[j], j);
+    if (j < nb && !(piv > 0.0) && piv == piv) bad = true;   // pivot <= 0 (NaN falls through like Eigen)
+    const double dj = sqrt(piv);
+    if (lane == j) a[j] = dj;
+    else if (lane > j) a[j] = a[j] / dj;
+#pragma unroll
+    for (int c = j + 1; c < NB; ++c) {
+      const double lcj = readlane_f64(a[j], c);
+      if (lane >= c) a[c] -= a[j] * lcj;
+    }
+  }
+  if (lane < NB) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c) D[lane][c] = a[c];
   }
   __syncthreads();
-  for (int j = 0; j < nb; ++j) {
-    const double piv = D[j][j];
-    if (!(piv > 0.0) && piv == piv) {   // pivot <= 0 -> numerical issue (NaN falls through like Eigen)
-      if (lane == 0) bad = 1;
-    }
-    const double dj = sqrt(piv);
-    __syncthreads();
-    if (lane == 0) D[j][j] = dj;
-    for (int i = j + 1 + lane; i < nb; i += 64) D[i][j] = D[i][j] / dj;
-    __syncthreads();
-    // rank-1 update of the remaining lower triangle
-    const int rem = nb - (j + 1);
-    for (int idx = lane; idx < rem * rem; idx += 64) {
-      const int i = j + 1 + idx / rem, c = j + 1 + idx % rem;
-      if (c <= i) D[i][c] -= D[i][j] * D[c][j];
-    }
-    __syncthreads();
-  }
   if (blockIdx.x == 0) {
-    for (int idx = lane; idx < NB * NB; idx += 64) {
-      const int r = idx / NB, c = idx % NB;
-      if (r < nb && c <= r) A[(size_t)(k0 + r) * n + (k0 + c)] = D[r][c];
+    if (lane < nb) {
+      double* Ar = A + (size_t)(k0 + lane) * n + k0;
+#pragma unroll
+      for (int c = 0; c < NB; ++c)
+        if (c <= lane) Ar[c] = a[c];
     }
     if (lane == 0 && bad) *fail_flag = 1;
   }
@@ -136,11 +154,14 @@ __global__ __launch_bounds__(256) void chol_trail_kernel(double* __restrict__ A,
   }
 }
 
-// Blocked forward (L y = b) and backward (L^T x = y) substitution by one workgroup.
+// Blocked forward (L y = b) and backward (L^T x = y) substitution by one workgroup.  The
+// sequential part of each 64-wide diagonal block is wave-synchronous and register-resident:
+// forward, lane i holds ROW i of the block and the solved entries are broadcast with v_readlane;
+// backward, lane j holds COLUMN j (coalesced loads) -- 64 steps of {readlane, fma} instead of 64
+// barrier-separated LDS sweeps.  The off-diagonal updates use all 256 threads.
 __global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restrict__ L, double* __restrict__ b,
                                                          int n, float* __restrict__ dx,
                                                          int32_t* fail_flag, int32_t* fail_count) {
-  __shared__ double Ld[SB][SB + 1];
   __shared__ double y[SB];
   const int tid = threadIdx.x;
   if (*fail_flag) {   // reference: zero update on failure (droid_kernels.cu:1207-1210)
@@ -152,20 +173,25 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restric
   // ---- forward
   for (int kb = 0; kb < nblk; ++kb) {
     const int k0 = kb * SB, nb = min(SB, n - k0);
-    for (int idx = tid; idx < SB * SB; idx += 256) {
-      const int r = idx / SB, c = idx % SB;
-      Ld[r][c] = (r < nb && c <= r) ? L[(size_t)(k0 + r) * n + (k0 + c)] : 0.0;
+    if (tid < 64) {
+      const int i = tid;
+      const bool live = i < nb;
+      double a[SB];
+      const double* Lr = L + (size_t)(k0 + (live ? i : 0)) * n + k0;
+#pragma unroll
+      for (int c = 0; c < SB; ++c) a[c] = (live && c < i) ? Lr[c] : 0.0;
+      const double inv_dg = live ? 1.0 / Lr[i] : 1.0;
+      double bv = live ? b[k0 + i] : 0.0;
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        const double yj = readlane_f64(bv * inv_dg, j);
+        if (i == j) bv = yj;
+        else if (i > j) bv -= a[j] * yj;
+      }
+      y[i] = bv;
+      if (live) b[k0 + i] = bv;
     }
-    if (tid < SB) y[tid] = (tid < nb) ? b[k0 + tid] : 0.0;
     __syncthreads();
-    for (int j = 0; j < nb; ++j) {   // column-oriented, nb <= 64 sequential steps
-      const double yj = y[j] / Ld[j][j];
-      __syncthreads();
-      if (tid == j) y[j] = yj;
-      if (tid > j && tid < nb) y[tid] -= Ld[tid][j] * yj;
-      __syncthreads();
-    }
-    if (tid < nb) b[k0 + tid] = y[tid];
     // b[r] -= L[r][k0:k0+nb] . y  for rows below the block
     for (int r = k0 + nb + tid; r < n; r += 256) {
       const double* Lr = L + (size_t)r * n + k0;
@@ -178,20 +204,24 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restric
   // ---- backward
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int k0 = kb * SB, nb = min(SB, n - k0);
-    for (int idx = tid; idx < SB * SB; idx += 256) {
-      const int r = idx / SB, c = idx % SB;
-      Ld[r][c] = (r < nb && c <= r) ? L[(size_t)(k0 + r) * n + (k0 + c)] : 0.0;
+    if (tid < 64) {
+      const int j = tid;
+      const bool live = j < nb;
+      double c_[SB];                      // column j of the block: L[k0+i][k0+j], i > j
+#pragma unroll
+      for (int i = 0; i < SB; ++i) c_[i] = (live && i > j && i < nb) ? L[(size_t)(k0 + i) * n + k0 + j] : 0.0;
+      const double inv_dg = live ? 1.0 / L[(size_t)(k0 + j) * n + k0 + j] : 1.0;
+      double yv = live ? b[k0 + j] : 0.0;
+#pragma unroll
+      for (int i = SB - 1; i >= 0; --i) {
+        const double xi = readlane_f64(yv * inv_dg, i);
+        if (j == i) yv = xi;
+        else if (j < i) yv -= c_[i] * xi;
+      }
+      y[j] = yv;
+      if (live) { b[k0 + j] = yv; dx[k0 + j] = (float)yv; }
     }
-    if (tid < SB) y[tid] = (tid < nb) ? b[k0 + tid] : 0.0;
     __syncthreads();
-    for (int j = nb - 1; j >= 0; --j) {
-      const double xj = y[j] / Ld[j][j];
-      __syncthreads();
-      if (tid == j) y[j] = xj;
-      if (tid < j) y[tid] -= Ld[j][tid] * xj;
-      __syncthreads();
-    }
-    if (tid < nb) { b[k0 + tid] = y[tid]; dx[k0 + tid] = (float)y[tid]; }
     // b[c] -= sum_r L[k0+r][c] * x[r]  for columns left of the block
     for (int c = tid; c < k0; c += 256) {
       double s = 0.0;
