@@ -265,12 +265,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path)"
+    # GS_BENCH_SMOKE_ONE_GPU=1: functional smoke test of the N>1 code path on a 1-GPU box (all ranks
+    # on cuda:0, gloo instead of RCCL -- RCCL refuses two ranks on one device).  Never used for numbers.
+    smoke_one_gpu = os.environ.get("GS_BENCH_SMOKE_ONE_GPU") == "1"
+    if smoke_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if smoke_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     video, update_op, graph, _ = build_state(device)
 

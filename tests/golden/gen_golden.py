@@ -16,6 +16,7 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
   * modules/corr.py      CorrBlock.corr + pyramid build (pure torch)          -> corr_*.npz
   * geom/projective_ops  projective_transform with and without Jacobians      -> proj_*.npz
   * render.py            Renderer.render_batch_ray sample placement           -> render_sample.npz
+  * nerf_func.py         build_rays                                            -> build_rays.npz
   * InstantNeuS.py       normalisation, masking, sdf gradient by autograd.grad, get_alpha,
                          compositing, compute_sdf_error                       -> neus_forward.npz
 The stand-ins themselves (tcnn / lietorch / CUDA kernels) stay "parity unpinned" (DESIGN.md 4).
@@ -196,6 +197,21 @@ def gen_neus():
          sdf_error=sdf_err, sdf_front_error=sdf_front, **{k: v for k, v in out.items()})
 
 
+def gen_rays():
+    nf = importlib.import_module("refsrc.nerf_func")
+    g = torch.Generator().manual_seed(127)
+    H, W = 24, 32
+    depth = torch.rand(H, W, generator=g) * 3 + 0.5
+    color = torch.rand(H, W, 3, generator=g)
+    mask = torch.rand(H, W, generator=g) > 0.3
+    c2w = torch.eye(4)
+    c2w[:3, :3] = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    c2w[:3, 3] = torch.tensor([0.3, -0.2, 1.0])
+    torch.manual_seed(77)
+    o, d, dep, col = nf.build_rays(2, 22, 3, 29, 50, H, W, 30.0, 31.0, 15.5, 11.5, c2w, depth, color, "cpu", mask=mask)
+    save("build_rays.npz", depth=depth, color=color, mask=mask, c2w=c2w, rays_o=o, rays_d=d, ray_depth=dep, ray_color=col)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate the fixtures"
     install_stubs()
@@ -203,4 +219,5 @@ if __name__ == "__main__":
         gen_corr()
         gen_proj()
         gen_render()
+        gen_rays()
     gen_neus()

@@ -257,3 +257,14 @@ def test_lib_grid_meta_equals_oracle(built_lib):
     assert [float(v) for v in m.scale] == [float(v) for v in r["scale"]]
     assert list(m.size) == r["size"].tolist() and list(m.offset) == r["offset"].tolist()
     assert list(m.hashed) == r["hashed"].tolist() and int(m.total) == int(r["total"])
+
+
+def test_build_rays_matches_reference():
+    """go_slam_amd.neus.rays.build_rays (host PyTorch) vs reference src/nerf_func.py:115-181."""
+    from go_slam_amd.neus.rays import build_rays
+    g = _load("build_rays.npz")
+    torch.manual_seed(77)
+    o, d, dep, col = build_rays(2, 22, 3, 29, 50, 24, 32, 30.0, 31.0, 15.5, 11.5, g["c2w"], g["depth"], g["color"],
+                                "cpu", mask=g["mask"])
+    assert torch.equal(o, g["rays_o"]) and torch.equal(d, g["rays_d"])
+    assert torch.equal(dep, g["ray_depth"]) and torch.equal(col, g["ray_color"])
