@@ -78,3 +78,30 @@ def test_product_path_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "from .. import oracle" in src:
                     bad.append(f)
     assert not bad, bad
+
+
+def test_dropin_install_registers_reference_module_names(built_lib):
+    """`import droid_backends / tinycudann / lietorch / torch_scatter` of the unmodified reference
+    resolve to this package after dropin.install()."""
+    import importlib
+    import sys
+    saved = {k: sys.modules.get(k) for k in ("droid_backends", "tinycudann", "lietorch", "torch_scatter")}
+    try:
+        from go_slam_amd import dropin
+        dropin.install()
+        db = importlib.import_module("droid_backends")
+        assert callable(db.ba) and callable(db.corr_index_forward)
+        tc = importlib.import_module("tinycudann")
+        assert hasattr(tc, "Encoding") and hasattr(tc, "Network")
+        lt = importlib.import_module("lietorch")
+        assert hasattr(lt, "SE3") and callable(lt.cat)
+        ts = importlib.import_module("torch_scatter")
+        x = torch.tensor([[1.0, 3.0, 5.0, 7.0]]).view(1, 4, 1)
+        out = ts.scatter_mean(x, torch.tensor([0, 0, 1, 1]), dim=1)
+        assert out.view(-1).tolist() == [2.0, 6.0]
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
