@@ -488,7 +488,7 @@ def _solve(H, b, lm, ep):
 
 
 def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
-       t0, t1, iterations, lm, ep, motion_only, return_system=False):
+       t0, t1, iterations, lm, ep, motion_only, return_system=False, evt_quirk=True):
     """lib/droid_kernels.cu:1314-1434 (ba_cuda) incl. :1117-1311 (SparseBlock, schur_block).
 
     Mutates `poses` and `disps` in place, returns [dx [P,6], dz [M,HW] or None].
@@ -567,7 +567,7 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
             dx = dxv.view(P, 6)
 
             # back-substitution (:1408-1417) with the EvT `<=0` quirk (:1105)
-            keep = (pose_n > 0) & (pose_n < P)
+            keep = ((pose_n > 0) if evt_quirk else (pose_n >= 0)) & (pose_n < P)   # evt_quirk=False: tests only
             dxn = dx[pose_n.clamp(0, P - 1)]                                 # [P+E,6]
             dw = torch.einsum('nip,ni->np', Eall, dxn)
             dw = torch.where(keep[:, None], dw, torch.zeros_like(dw))

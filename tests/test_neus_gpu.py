@@ -255,3 +255,24 @@ def test_training_step_reduces_loss(N, O, dev):
     gn = torch.nn.utils.clip_grad_norm_(params, 35.0)
     opt.step()
     assert math.isfinite(float(gn)) and all(torch.isfinite(p).all() for p in params)
+
+
+def test_quirk_q15_static_bound_normalisation_with_clamp(N, O, dev):
+    """Q15 (InstantNeuS.py:12-32,310,317): points are normalised with the STATIC bound and clamped to
+    [-1,1] while the in-bound mask uses the REALTIME bound.  With a realtime bound larger than the
+    static one, points outside the static box are encoded at the clamped position and their SDF
+    gradient is zero along the clamped axis."""
+    P = O.make_params(71, grid_init=0.3, bound=((-1.0, 1.0), (-1.0, 1.0), (-1.0, 1.0)))
+    P["rt_bound"] = torch.tensor([[-3.0, 3.0], [-3.0, 3.0], [-3.0, 3.0]])
+    o, d, gt = _rays(64, seed=72)
+    z, dist = O.render_sample(o, d, gt, P["rt_bound"], 24, 48, None)
+    ref = O.neus_forward(o, d, z, dist, P)
+    assert (ref["_grad"].abs().sum(-1) == 0).float().mean() < 0.5 and (ref["_grad"] == 0).any()
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    model.update_bound(P["rt_bound"])
+    with torch.no_grad():
+        out = model(o.to(dev), d.to(dev), z.to(dev), dist.to(dev))
+    torch.testing.assert_close(out["sdf"].cpu(), ref["sdf"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(out["normal"].cpu(), ref["normal"], rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(out["gradient_error"].cpu(), ref["gradient_error"], rtol=2e-3, atol=1e-5)

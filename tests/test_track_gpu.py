@@ -345,3 +345,35 @@ def test_corr_volume_pyramid_matches_oracle(db, O, dev, shape):
         pooled = F.avg_pool2d(low.reshape(-1, 1, hl, wl).float(), 2, 2).to(torch.float16)
         assert torch.equal(out[l].cpu().reshape(-1, 1, hl // 2, wl // 2), pooled), f"level {l}"
         torch.testing.assert_close(out[l].cpu().float(), ref[l].float(), rtol=0, atol=2e-3)
+
+
+def test_quirk_q1_first_window_pose_never_feeds_back_into_dz(db, O, dev):
+    """SURVEY App. A Q1 (droid_kernels.cu:1105): entries whose pose index - t0 <= 0 are skipped in
+    dz = Q (w - E^T dx).  The HIP path must match the oracle WITH the quirk and differ from a
+    'corrected' back-substitution."""
+    prob = _ba_problem(O, 8, 22, "tiny", seed=61)
+    K = prob["intrinsics"][0].contiguous()
+    args = (K, prob["disps_sens"], prob["target"], prob["weight"], prob["eta"], prob["ii"], prob["jj"],
+            prob["t0"], prob["t1"], 1, 1e-4, 0.1, False)
+    with_q = O.ba(prob["poses"].clone(), prob["disps"].clone(), *args)
+    without_q = O.ba(prob["poses"].clone(), prob["disps"].clone(), *args, evt_quirk=False)
+    _, _, out, _ = _run_ba_pair(db, O, dev, prob, 1, 1e-4, 0.1, False)
+    torch.testing.assert_close(out[1].cpu(), with_q[1], rtol=1e-3, atol=1e-5)
+    assert (with_q[1] - without_q[1]).abs().max() > 50 * (out[1].cpu() - with_q[1]).abs().max()
+
+
+def test_quirk_q2_two_min_depths(db, O, dev):
+    """Q2: the kernels use MIN_DEPTH 0.25 (droid_kernels.cu:26), the Python reprojection 0.2
+    (projective_ops.py:4).  A point that lands at z = 0.22 is valid for reproject, invalid for projmap."""
+    ht, wd = 12, 16
+    vid = synth.make_video(2, "tiny", seed=63)
+    vid["poses"][:] = torch.tensor([0.0, 0, 0, 0, 0, 0, 1])
+    vid["poses"][1, 2] = -0.78                       # frame 1 sits 0.78 m ahead along z
+    vid["disps"][:] = 1.0                            # all points at depth 1 => z in frame 1 = 0.22
+    ii, jj = torch.tensor([0]), torch.tensor([1])
+    K = vid["intrinsics"][0].contiguous()
+    c, v = db.reproject(vid["poses"].to(dev), vid["disps"].to(dev), vid["intrinsics"].to(dev), ii.to(dev), jj.to(dev))
+    pc, pv = db.projmap(vid["poses"].to(dev), vid["disps"].to(dev), K.to(dev), ii.to(dev), jj.to(dev))
+    assert v.min() == 1.0 and pv.max() == 0.0
+    rc, rv = O.reproject(vid["poses"], vid["disps"], vid["intrinsics"], ii, jj)
+    assert torch.equal(v.cpu(), rv)
