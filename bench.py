@@ -113,7 +113,7 @@ def op_breakdown(video, update_op, graph):
     out["corr_lookup_ms"] = time_op(lambda: graph.corr(coords1))
 
     def gru():
-        with torch.autocast("cuda", dtype=torch.float16):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
             update_op(graph.net, graph.inp, corr, motion, ii, jj)
     out["update_module_ms"] = time_op(gru, iters=5)
     t0, t1 = 1, NUM_KF

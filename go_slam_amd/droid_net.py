@@ -52,6 +52,7 @@ class ConvGRU(nn.Module):
     def __init__(self, h_planes=128, i_planes=128):
         super().__init__()
         self.do_checkpoint = False
+        self.fuse_gates = True          # HIP gate fusion on the inference path (fp16, NHWC, no grad)
         c = h_planes + i_planes
         self.convz = nn.Conv2d(c, h_planes, 3, padding=1)
         self.convr = nn.Conv2d(c, h_planes, 3, padding=1)
@@ -61,7 +62,53 @@ class ConvGRU(nn.Module):
         self.convr_glo = nn.Conv2d(h_planes, h_planes, 1)
         self.convq_glo = nn.Conv2d(h_planes, h_planes, 1)
 
+    def _fusable(self, net, inputs):
+        cl = torch.channels_last
+        return (net.is_cuda and not torch.is_grad_enabled() and net.dtype == torch.float16 and net.shape[1] == 128
+                and net.is_contiguous(memory_format=cl) and all(t.dtype == torch.float16 for t in inputs))
+
+    def _half_weights(self):
+        """fp16 NHWC copies of the conv weights (convz|convr fused to one 448->256 conv), cached."""
+        key = (self.convz.weight._version, self.convr.weight._version, self.convq.weight._version,
+               self.convz.bias._version, self.convr.bias._version, self.convq.bias._version, self.convz.weight.device)
+        if getattr(self, "_hw_key", None) != key:
+            cl = torch.channels_last
+            wzr = torch.cat([self.convz.weight, self.convr.weight], 0).detach().half().contiguous(memory_format=cl)
+            wq = self.convq.weight.detach().half().contiguous(memory_format=cl)
+            bzr = torch.cat([self.convz.bias, self.convr.bias]).detach().float().contiguous()
+            bq = self.convq.bias.detach().float().contiguous()
+            self._hw, self._hw_key = (wzr, wq, bzr, bq), key
+        return self._hw
+
+    def _forward_fused(self, net, inputs):
+        """Same mathematics as forward(); the three 3x3 convolutions stay MIOpen, everything between
+        them is two HIP kernels (gs_gru_gate_zr / gs_gru_gate_q) and ONE 448-channel cat."""
+        from . import _lib
+        b, c, h, w = net.shape
+        hw = h * w
+        hx = torch.cat([net, *inputs], dim=1)
+        if not hx.is_contiguous(memory_format=torch.channels_last):
+            hx = hx.contiguous(memory_format=torch.channels_last)
+        glo = (torch.sigmoid(self.w(net)) * net).mean(dim=(2, 3), keepdim=True)
+        gzr = torch.cat([self.convz_glo(glo), self.convr_glo(glo)], 1).reshape(b, 256).float().contiguous()
+        gq = self.convq_glo(glo).reshape(b, 128).float().contiguous()
+        wzr, wq, bzr, bq = self._half_weights()
+        with torch.autocast("cuda", enabled=False):
+            zr_pre = F.conv2d(hx, wzr, None, padding=1)
+            z = torch.empty_like(net)
+            L = _lib.lib()
+            st = _lib.stream_ptr(net.device)
+            _lib.check(L.gs_gru_gate_zr(_lib.ptr(zr_pre), _lib.ptr(bzr), _lib.ptr(gzr), _lib.ptr(hx), _lib.ptr(z),
+                                        b, hw, hx.shape[1], st), "gru_gate_zr")
+            q_pre = F.conv2d(hx, wq, None, padding=1)
+            out = torch.empty_like(net)
+            _lib.check(L.gs_gru_gate_q(_lib.ptr(q_pre), _lib.ptr(bq), _lib.ptr(gq), _lib.ptr(z), _lib.ptr(net),
+                                       _lib.ptr(out), b, hw, st), "gru_gate_q")
+        return out
+
     def forward(self, net, *inputs):
+        if self.fuse_gates and self._fusable(net, inputs):
+            return self._forward_fused(net, inputs)
         inp = torch.cat(inputs, dim=1)
         hx = torch.cat([net, inp], dim=1)
         b, c, h, w = net.shape

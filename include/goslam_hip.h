@@ -111,6 +111,19 @@ int gs_depth_filter(const float* poses, const float* disps, const float* intrins
                     const int64_t* ix, const float* thresh, float* counter,
                     int n, int num, int h, int w, gs_stream_t stream);
 
+/* ------------------------------------------- update-operator gate fusions ---- */
+
+/* ConvGRU gates of src/modules/gru.py:20-33 around MIOpen's convolutions; all NHWC fp16.
+ * gs_gru_gate_zr: zr_pre f16 [n,hw,256] = fused convz|convr output WITHOUT bias, bias_zr f32 [256],
+ *   glo_zr f32 [n,256] (the 1x1 global-context terms), hx f16 [n,hw,ldx] whose first 128 channels
+ *   hold `net` on entry and r*net on exit, z_out f16 [n,hw,128].
+ * gs_gru_gate_q : q_pre f16 [n,hw,128] (convq output without bias), bias_q f32 [128], glo_q f32
+ *   [n,128], z / net f16 [n,hw,128] -> net_out = (1-z)*net + z*tanh(q_pre + bias + glo).         */
+int gs_gru_gate_zr(const void* zr_pre, const float* bias_zr, const float* glo_zr, void* hx, void* z_out,
+                   int n, int hw, int ldx, gs_stream_t stream);
+int gs_gru_gate_q(const void* q_pre, const float* bias_q, const float* glo_q, const void* z,
+                  const void* net, void* net_out, int n, int hw, gs_stream_t stream);
+
 /* ------------------------------------------------------ dense bundle adjustment ---- */
 
 /* Workspace size for gs_ba (bytes).  n_edges = len(ii), n_poses = t1-t0, n_depth = rows of

@@ -76,3 +76,24 @@ def test_distance_matrix_matches_oracle(built_lib):
     ref = 0.5 * (O.frame_distance(vid["poses"][:N], vid["disps"], K, ii, jj, 0.75) +
                  O.frame_distance(vid["poses"][:N], vid["disps"], K, jj, ii, 0.75))
     torch.testing.assert_close(d.cpu().reshape(-1), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_fused_gru_gates_match_plain_module(built_lib):
+    """ConvGRU with the HIP gate fusion (one cat, fused convz|convr, two gate kernels) vs the plain
+    PyTorch formulation of src/modules/gru.py:20-33 under the same autocast: fp16-level agreement."""
+    from go_slam_amd.droid_net import ConvGRU
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    gru = ConvGRU(128, 128 + 128 + 64).to(dev).eval().to(memory_format=torch.channels_last)
+    cl = torch.channels_last
+    net = torch.tanh(torch.randn(5, 128, 12, 16, device=dev)).half().contiguous(memory_format=cl)
+    inp = torch.relu(torch.randn(5, 128, 12, 16, device=dev)).half().contiguous(memory_format=cl)
+    corr = torch.relu(torch.randn(5, 128, 12, 16, device=dev)).half().contiguous(memory_format=cl)
+    flow = torch.relu(torch.randn(5, 64, 12, 16, device=dev)).half().contiguous(memory_format=cl)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        gru.fuse_gates = True
+        a = gru(net, inp, corr, flow)
+        gru.fuse_gates = False
+        b = gru(net, inp, corr, flow)
+    assert a.shape == b.shape and a.dtype == b.dtype == torch.float16
+    torch.testing.assert_close(a.float(), b.float(), rtol=2e-2, atol=4e-3)
