@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void gru_gate_q_kernel(const _Float16* __restr
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int c = c8 * 8 + k;
-    const float q = tanhf((float)qp[k] + bias[c] + glo[(size_t)n * 128 + c]);
+    const float a = (float)qp[k] + bias[c] + glo[(size_t)n * 128 + c];
+    const float q = 1.0f - 2.0f / (1.0f + __expf(2.0f * a));      // tanh (|err| ~1e-7, result goes to fp16)
     const float zf = (float)zz[k];
     out[k] = (_Float16)((1.0f - zf) * (float)nn[k] + zf * q);
   }

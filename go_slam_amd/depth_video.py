@@ -41,6 +41,21 @@ class DepthVideo:
                 jj.to(device=device, dtype=torch.long).reshape(-1).contiguous())
 
     def upsample(self, ix, mask):
+        """disps_up[ix] = cvx_upsample(disps[ix], mask) (src/depth_video.py:194-196).  fp16 masks go
+        through the fused HIP kernel (no gather / unfold / softmax / index_put passes)."""
+        m = mask.reshape(-1, 576, self.ht, self.wd)
+        if m.dtype == torch.float16 and m.is_cuda:
+            cl = m.is_contiguous(memory_format=torch.channels_last)
+            if not cl:
+                m = m.contiguous()
+            ix = ix.to(device=self.device, dtype=torch.long).contiguous()
+            from . import _lib
+            with torch.cuda.device(self.device):
+                rc = _lib.lib().gs_cvx_upsample(_lib.ptr(self.disps), _lib.ptr(m), _lib.ptr(ix),
+                                                _lib.ptr(self.disps_up), ix.numel(), self.ht, self.wd, int(cl),
+                                                _lib.stream_ptr(self.device))
+            _lib.check(rc, "DepthVideo.upsample")
+            return
         up = cvx_upsample(self.disps[ix].unsqueeze(-1), mask)
         self.disps_up[ix] = up.squeeze(-1).float()
 

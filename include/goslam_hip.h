@@ -124,6 +124,13 @@ int gs_gru_gate_zr(const void* zr_pre, const float* bias_zr, const float* glo_zr
 int gs_gru_gate_q(const void* q_pre, const float* bias_q, const float* glo_q, const void* z,
                   const void* net, void* net_out, int n, int hw, gs_stream_t stream);
 
+/* DepthVideo.upsample -> cvx_upsample (src/depth_video.py:194-196, src/droid_net.py:9-23):
+ * out[ix[n]] (f32 [*,8h,8w]) = convex 8x upsampling of disps[ix[n]] (f32 [*,h,w]) with the softmax
+ * of mask f16 [m,576,h,w] (logical NCHW; mask_channels_last != 0: NHWC strides).  ix i64 [m] or
+ * NULL (identity).                                                                            */
+int gs_cvx_upsample(const float* disps, const void* mask, const int64_t* ix, float* out,
+                    int m, int h, int w, int mask_channels_last, gs_stream_t stream);
+
 /* ------------------------------------------------------ dense bundle adjustment ---- */
 
 /* Workspace size for gs_ba (bytes).  n_edges = len(ii), n_poses = t1-t0, n_depth = rows of

@@ -97,3 +97,25 @@ def test_fused_gru_gates_match_plain_module(built_lib):
         b = gru(net, inp, corr, flow)
     assert a.shape == b.shape and a.dtype == b.dtype == torch.float16
     torch.testing.assert_close(a.float(), b.float(), rtol=2e-2, atol=4e-3)
+
+
+@pytest.mark.parametrize("channels_last", [True, False])
+def test_cvx_upsample_kernel_matches_reference_formulation(built_lib, channels_last):
+    """DepthVideo.upsample (HIP) vs cvx_upsample restated in PyTorch (src/droid_net.py:9-23)."""
+    from go_slam_amd.depth_video import DepthVideo
+    from go_slam_amd.droid_net import cvx_upsample
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    video = DepthVideo(12, 16, buffer=9, device=dev)
+    video.disps.copy_(torch.rand(9, 12, 16, generator=g) + 0.1)
+    ix = torch.tensor([1, 4, 7, 8], device=dev)
+    mask = (torch.randn(4, 576, 12, 16, generator=g) * 3).half().to(dev)
+    if channels_last:
+        mask = mask.contiguous(memory_format=torch.channels_last)
+    ref = cvx_upsample(video.disps[ix].unsqueeze(-1), mask).squeeze(-1).float()
+    video.upsample(ix, mask[None])
+    out = video.disps_up[ix]
+    # softmax weights are fp16: a 1-ulp difference of exp() can flip one rounding (5e-4 relative)
+    torch.testing.assert_close(out, ref, rtol=0, atol=2e-4)
+    assert float(((out - ref).abs() <= 1e-6).float().mean()) > 0.995
+    assert video.disps_up[0].abs().sum() == 0, "frames outside ix are untouched"
