@@ -96,3 +96,41 @@ extern "C" int gs_gru_gate_q(const void* q_pre, const float* bias_q, const float
   GS_CHECK_LAUNCH("gru_gate_q");
   return GS_OK;
 }
+
+// ---- bias + activation epilogue for the update operator's other convolutions ----------------
+// MIOpen's NHWC fp16 convolutions are launched without bias; this one in-place pass adds the
+// bias and applies ReLU / sigmoid (PyTorch runs add_ and relu_ as two separate passes).
+namespace {
+template <int ACT>   // 0 none, 1 relu, 2 sigmoid
+__global__ __launch_bounds__(256) void bias_act_kernel(_Float16* __restrict__ x, const float* __restrict__ bias,
+                                                       int c8n /* C/8 */, size_t total /* rows*C/8 */) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int c8 = (int)(t % c8n);
+  half8* p = reinterpret_cast<half8*>(x) + t;
+  half8 v = *p;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float f = (float)v[k] + bias[c8 * 8 + k];
+    if (ACT == 1) f = fmaxf(f, 0.0f);
+    if (ACT == 2) f = sigm(f);
+    v[k] = (_Float16)f;
+  }
+  *p = v;
+}
+}  // namespace
+
+extern "C" int gs_bias_act(void* x, const float* bias, int rows, int channels, int act, gs_stream_t stream) {
+  GS_REQUIRE(x && bias, "bias_act: null pointer");
+  GS_REQUIRE(rows >= 0 && channels > 0 && channels % 8 == 0, "bias_act: channels must be a multiple of 8");
+  GS_REQUIRE(act >= 0 && act <= 2, "bias_act: act in {0 none, 1 relu, 2 sigmoid}");
+  if (rows == 0) return GS_OK;
+  const size_t total = (size_t)rows * (channels / 8);
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (act == 0) bias_act_kernel<0><<<grid, 256, 0, st>>>((_Float16*)x, bias, channels / 8, total);
+  else if (act == 1) bias_act_kernel<1><<<grid, 256, 0, st>>>((_Float16*)x, bias, channels / 8, total);
+  else bias_act_kernel<2><<<grid, 256, 0, st>>>((_Float16*)x, bias, channels / 8, total);
+  GS_CHECK_LAUNCH("bias_act");
+  return GS_OK;
+}

@@ -46,6 +46,42 @@ def cvx_upsample(data, mask):
     return up.permute(0, 4, 2, 5, 3, 1).reshape(b, 8 * h, 8 * w, d)
 
 
+class _HalfWeights:
+    """fp16 / NHWC copies of conv weights (+ fp32 biases) for the inference fast path, refreshed when
+    the parameters change (load_state_dict, .to, optimiser steps bump `_version`)."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, conv):
+        key = (conv.weight._version, conv.bias._version, conv.weight.device, conv.weight.data_ptr())
+        hit = self._cache.get(id(conv))
+        if hit is None or hit[0] != key:
+            w = conv.weight.detach().half().contiguous(memory_format=torch.channels_last)
+            b = conv.bias.detach().float().contiguous()
+            hit = (key, w, b)
+            self._cache[id(conv)] = hit
+        return hit[1], hit[2]
+
+
+_ACT = {"none": 0, "relu": 1, "sigmoid": 2}
+
+
+def conv_bias_act(cache, conv, x, act):
+    """act(conv(x) + bias) for NHWC fp16 x: bias-free MIOpen convolution + one fused HIP epilogue
+    (PyTorch issues conv, add_(bias) and relu_ as three passes)."""
+    from . import _lib
+    w, b = cache.get(conv)
+    with torch.autocast("cuda", enabled=False):
+        y = F.conv2d(x, w, None, stride=conv.stride, padding=conv.padding)
+    if not y.is_contiguous(memory_format=torch.channels_last):
+        y = y.contiguous(memory_format=torch.channels_last)
+    n, c, h, wd = y.shape
+    rc = _lib.lib().gs_bias_act(_lib.ptr(y), _lib.ptr(b), n * h * wd, c, _ACT[act], _lib.stream_ptr(y.device))
+    _lib.check(rc, "conv_bias_act")
+    return y
+
+
 class ConvGRU(nn.Module):
     """src/modules/gru.py:5-33: ConvGRU with a global-context gate."""
 
@@ -162,9 +198,54 @@ class UpdateModule(nn.Module):
             nn.Conv2d(128, 2, 3, padding=1), GradientClip())
         self.gru = ConvGRU(128, 128 + 128 + 64)
         self.agg = GraphAgg()
+        self.fuse_epilogues = True      # inference fast path: bias-free convs + fused HIP epilogues
+        self._hw = _HalfWeights()
+
+    def _forward_fast(self, net, inp, corr, flow, ii, jj):
+        """forward() with every 128/64-channel convolution run bias-free on MIOpen and its
+        bias + activation applied by one HIP pass; same mathematics, fp16 NHWC throughout."""
+        batch, num, ch, ht, wd = net.shape
+        cl = torch.channels_last
+        hwc = self._hw
+        out_dim = (batch, num, -1, ht, wd)
+        net4 = net.view(batch * num, -1, ht, wd)
+        inp4 = inp.view(batch * num, -1, ht, wd).half().contiguous(memory_format=cl)
+        c4 = corr.view(batch * num, -1, ht, wd).half().contiguous(memory_format=cl)
+        if flow is None:
+            flow = torch.zeros(batch, num, 4, ht, wd, device=net.device)
+        f4 = flow.view(batch * num, -1, ht, wd).half().contiguous(memory_format=cl)
+        c4 = conv_bias_act(hwc, self.corr_encoder[0], c4, "relu")
+        c4 = conv_bias_act(hwc, self.corr_encoder[2], c4, "relu")
+        f4 = conv_bias_act(hwc, self.flow_encoder[0], f4, "relu")
+        f4 = conv_bias_act(hwc, self.flow_encoder[2], f4, "relu")
+        net4 = self.gru(net4, inp4, c4, f4)
+        d = conv_bias_act(hwc, self.delta[0], net4, "relu")
+        delta = self.delta[2](d).view(*out_dim).permute(0, 1, 3, 4, 2)[..., :2].contiguous()
+        wgt = conv_bias_act(hwc, self.weight[0], net4, "relu")
+        weight = torch.sigmoid(self.weight[2](wgt)).view(*out_dim).permute(0, 1, 3, 4, 2)[..., :2].contiguous()
+        net = net4.view(*out_dim)
+        if ii is None:
+            return net, delta, weight
+        # GraphAgg (src/droid_net.py:49-67)
+        agg = self.agg
+        x = conv_bias_act(hwc, agg.conv1, net4, "relu")
+        uniq, ix = torch.unique(ii.to(net.device), sorted=True, return_inverse=True)
+        x = segment_mean(x, ix, uniq.numel()).contiguous(memory_format=cl)
+        x = conv_bias_act(hwc, agg.conv2, x, "relu")
+        eta = agg.eta(x).view(batch, -1, ht, wd)
+        upmask = conv_bias_act(hwc, agg.upmask[0], x, "none").view(batch, -1, 8 * 8 * 9, ht, wd)
+        return net, delta, weight, 0.01 * eta, upmask
+
+    def _fast_ok(self, net, inp, corr):
+        cl = torch.channels_last
+        n4 = net.view(-1, *net.shape[2:])
+        return (self.fuse_epilogues and net.is_cuda and not torch.is_grad_enabled() and net.dtype == torch.float16
+                and n4.is_contiguous(memory_format=cl) and torch.is_autocast_enabled())
 
     def forward(self, net, inp, corr, flow=None, ii=None, jj=None):
         batch, num, ch, ht, wd = net.shape
+        if self._fast_ok(net, inp, corr):
+            return self._forward_fast(net, inp, corr, flow, ii, jj)
         if flow is None:
             flow = torch.zeros(batch, num, 4, ht, wd, device=net.device)
         out_dim = (batch, num, -1, ht, wd)

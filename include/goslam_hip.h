@@ -123,6 +123,9 @@ int gs_gru_gate_zr(const void* zr_pre, const float* bias_zr, const float* glo_zr
                    int n, int hw, int ldx, gs_stream_t stream);
 int gs_gru_gate_q(const void* q_pre, const float* bias_q, const float* glo_q, const void* z,
                   const void* net, void* net_out, int n, int hw, gs_stream_t stream);
+/* In-place x = act(x + bias) on an NHWC fp16 tensor viewed as [rows, channels] (channels % 8 == 0);
+ * act: 0 none, 1 ReLU, 2 sigmoid.  Epilogue of the bias-free MIOpen convolutions.               */
+int gs_bias_act(void* x, const float* bias, int rows, int channels, int act, gs_stream_t stream);
 
 /* DepthVideo.upsample -> cvx_upsample (src/depth_video.py:194-196, src/droid_net.py:9-23):
  * out[ix[n]] (f32 [*,8h,8w]) = convex 8x upsampling of disps[ix[n]] (f32 [*,h,w]) with the softmax

@@ -119,3 +119,30 @@ def test_cvx_upsample_kernel_matches_reference_formulation(built_lib, channels_l
     torch.testing.assert_close(out, ref, rtol=0, atol=2e-4)
     assert float(((out - ref).abs() <= 1e-6).float().mean()) > 0.995
     assert video.disps_up[0].abs().sum() == 0, "frames outside ix are untouched"
+
+
+def test_update_module_fast_path_matches_plain(built_lib):
+    """UpdateModule inference fast path (bias-free MIOpen convs + HIP epilogues + fused GRU gates)
+    vs the plain nn.Sequential formulation of src/droid_net.py:107-140, same autocast."""
+    from go_slam_amd.droid_net import UpdateModule
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    cl = torch.channels_last
+    op = UpdateModule().to(dev).eval().to(memory_format=cl)
+    E, h, w = 6, 12, 16
+    mk = lambda c, f: f(torch.randn(E, c, h, w, device=dev)).half().contiguous(memory_format=cl).unsqueeze(0)
+    net, inp = mk(128, torch.tanh), mk(128, torch.relu)
+    corr = mk(196, lambda t: 0.5 * t)
+    motion = torch.randn(1, E, h, w, 4, device=dev).permute(0, 1, 4, 2, 3)
+    ii = torch.tensor([0, 0, 1, 2, 2, 3], device=dev)
+    jj = torch.tensor([1, 2, 0, 1, 3, 2], device=dev)
+    outs = []
+    for fast in (True, False):
+        op.fuse_epilogues = fast
+        op.gru.fuse_gates = fast
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            outs.append(op(net, inp, corr, motion, ii, jj))
+    names = ["net", "delta", "weight", "eta", "upmask"]
+    for name, a, b in zip(names, outs[0], outs[1]):
+        assert a.shape == b.shape, name
+        torch.testing.assert_close(a.float(), b.float(), rtol=3e-2, atol=1e-2, msg=lambda m: f"{name}: {m}")
