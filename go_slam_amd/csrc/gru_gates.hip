@@ -98,39 +98,165 @@ extern "C" int gs_gru_gate_q(const void* q_pre, const float* bias_q, const float
 }
 
 // ---- bias + activation epilogue for the update operator's other convolutions ----------------
-// MIOpen's NHWC fp16 convolutions are launched without bias; this one in-place pass adds the
-// bias and applies ReLU / sigmoid (PyTorch runs add_ and relu_ as two separate passes).
+// MIOpen's NHWC fp16 convolutions are launched without bias; this one pass adds the bias, applies
+// ReLU / sigmoid (PyTorch runs add_ and relu_ as two passes) and can write straight into a channel
+// slice of a wider NHWC tensor (the GRU's 448-channel input), which removes the torch.cat pass.
 namespace {
-template <int ACT>   // 0 none, 1 relu, 2 sigmoid
-__global__ __launch_bounds__(256) void bias_act_kernel(_Float16* __restrict__ x, const float* __restrict__ bias,
-                                                       int c8n /* C/8 */, size_t total /* rows*C/8 */) {
+template <int ACT, bool BIAS>   // ACT: 0 none, 1 relu, 2 sigmoid
+__global__ __launch_bounds__(256) void bias_act_kernel(const _Float16* __restrict__ x, const float* __restrict__ bias,
+                                                       _Float16* __restrict__ y, int c8n /* C/8 */, int ldy,
+                                                       size_t total /* rows*C/8 */) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= total) return;
   const int c8 = (int)(t % c8n);
-  half8* p = reinterpret_cast<half8*>(x) + t;
-  half8 v = *p;
+  const size_t row = t / c8n;
+  half8 v = reinterpret_cast<const half8*>(x)[t];
+  if (BIAS || ACT) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float f = (float)v[k] + bias[c8 * 8 + k];
-    if (ACT == 1) f = fmaxf(f, 0.0f);
-    if (ACT == 2) f = sigm(f);
-    v[k] = (_Float16)f;
+    for (int k = 0; k < 8; ++k) {
+      float f = (float)v[k];
+      if (BIAS) f += bias[c8 * 8 + k];
+      if (ACT == 1) f = fmaxf(f, 0.0f);
+      if (ACT == 2) f = sigm(f);
+      v[k] = (_Float16)f;
+    }
   }
-  *p = v;
+  *reinterpret_cast<half8*>(y + row * ldy + c8 * 8) = v;
+}
+
+// mean over the edges of each segment (GraphAgg's scatter_mean over source keyframes), CSR form
+__global__ __launch_bounds__(256) void segment_mean_kernel(const _Float16* __restrict__ x, const int* __restrict__ off,
+                                                           const int* __restrict__ edges, _Float16* __restrict__ out,
+                                                           int row8 /* row_elems/8 */, size_t total) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int seg = (int)(t / row8);
+  const int col = (int)(t % row8);
+  const int b = off[seg], e = off[seg + 1];
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k = b; k < e; ++k) {
+    const half8 v = reinterpret_cast<const half8*>(x)[(size_t)edges[k] * row8 + col];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+  }
+  const float inv = e > b ? 1.0f / (float)(e - b) : 0.0f;
+  half8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (_Float16)(acc[j] * inv);
+  reinterpret_cast<half8*>(out)[t] = o;
+}
+
+// partial[n, chunk, 128] = sum over the chunk's pixels of sigmoid(w_pre + bias) * net
+__global__ __launch_bounds__(256) void glo_pool_kernel(const _Float16* __restrict__ w_pre, const float* __restrict__ bias,
+                                                       const _Float16* __restrict__ net, float* __restrict__ partial,
+                                                       int hw, int nchunk) {
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int c8 = threadIdx.x & 15, lane = threadIdx.x >> 4;          // 16 channel groups x 16 pixel lanes
+  const int p0 = (int)((long)hw * chunk / nchunk), p1 = (int)((long)hw * (chunk + 1) / nchunk);
+  float b[8], acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { b[k] = bias[c8 * 8 + k]; acc[k] = 0.0f; }
+  for (int p = p0 + lane; p < p1; p += 16) {
+    const size_t o = ((size_t)n * hw + p) * 128 + c8 * 8;
+    const half8 w = *reinterpret_cast<const half8*>(w_pre + o);
+    const half8 h = *reinterpret_cast<const half8*>(net + o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      // the reference rounds sigmoid(.) and the product to fp16 (autocast elementwise ops)
+      const _Float16 g = (_Float16)sigm((float)(_Float16)((float)w[k] + b[k]));
+      acc[k] += (float)(_Float16)((float)g * (float)h[k]);
+    }
+  }
+  __shared__ float red[16][129];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[lane][c8 * 8 + k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    float s = 0.0f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) s += red[l][threadIdx.x];
+    partial[((size_t)n * nchunk + chunk) * 128 + threadIdx.x] = s;
+  }
+}
+
+// glo = mean -> the three 1x1 "global context" convolutions (128x128 mat-vecs) of the ConvGRU
+__global__ __launch_bounds__(384) void glo_heads_kernel(const float* __restrict__ partial, int nchunk, float inv_hw,
+                                                        const _Float16* __restrict__ wz, const _Float16* __restrict__ wr,
+                                                        const _Float16* __restrict__ wq, const float* __restrict__ bz,
+                                                        const float* __restrict__ br, const float* __restrict__ bq,
+                                                        float* __restrict__ gzr, float* __restrict__ gq) {
+  const int n = blockIdx.x, t = threadIdx.x;
+  __shared__ float g[128];
+  if (t < 128) {
+    float s = 0.0f;
+    for (int c = 0; c < nchunk; ++c) s += partial[((size_t)n * nchunk + c) * 128 + t];
+    g[t] = (float)(_Float16)(s * inv_hw);
+  }
+  __syncthreads();
+  const int head = t >> 7, o = t & 127;
+  const _Float16* w = (head == 0 ? wz : head == 1 ? wr : wq) + (size_t)o * 128;
+  float s = (head == 0 ? bz : head == 1 ? br : bq)[o];
+#pragma unroll 4
+  for (int k8 = 0; k8 < 16; ++k8) {
+    const half8 v = *reinterpret_cast<const half8*>(w + k8 * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s = fmaf((float)v[k], g[k8 * 8 + k], s);
+  }
+  s = (float)(_Float16)s;
+  if (head < 2) gzr[(size_t)n * 256 + head * 128 + o] = s;
+  else gq[(size_t)n * 128 + o] = s;
 }
 }  // namespace
 
-extern "C" int gs_bias_act(void* x, const float* bias, int rows, int channels, int act, gs_stream_t stream) {
-  GS_REQUIRE(x && bias, "bias_act: null pointer");
+extern "C" int gs_bias_act(const void* x, const float* bias, void* y, int rows, int channels, int y_stride, int act,
+                           gs_stream_t stream) {
+  GS_REQUIRE(x && y, "bias_act: null pointer");
   GS_REQUIRE(rows >= 0 && channels > 0 && channels % 8 == 0, "bias_act: channels must be a multiple of 8");
+  GS_REQUIRE(y_stride >= channels && y_stride % 8 == 0, "bias_act: y_stride must be >= channels and a multiple of 8");
   GS_REQUIRE(act >= 0 && act <= 2, "bias_act: act in {0 none, 1 relu, 2 sigmoid}");
   if (rows == 0) return GS_OK;
   const size_t total = (size_t)rows * (channels / 8);
   const unsigned grid = (unsigned)((total + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
-  if (act == 0) bias_act_kernel<0><<<grid, 256, 0, st>>>((_Float16*)x, bias, channels / 8, total);
-  else if (act == 1) bias_act_kernel<1><<<grid, 256, 0, st>>>((_Float16*)x, bias, channels / 8, total);
-  else bias_act_kernel<2><<<grid, 256, 0, st>>>((_Float16*)x, bias, channels / 8, total);
+  const _Float16* xi = (const _Float16*)x;
+  _Float16* yo = (_Float16*)y;
+  const int c8n = channels / 8;
+#define GS_BA(A, B) bias_act_kernel<A, B><<<grid, 256, 0, st>>>(xi, bias, yo, c8n, y_stride, total)
+  if (bias) { if (act == 0) GS_BA(0, true); else if (act == 1) GS_BA(1, true); else GS_BA(2, true); }
+  else      { if (act == 0) GS_BA(0, false); else if (act == 1) GS_BA(1, false); else GS_BA(2, false); }
+#undef GS_BA
   GS_CHECK_LAUNCH("bias_act");
+  return GS_OK;
+}
+
+extern "C" int gs_segment_mean(const void* x, const int* seg_offsets, const int* seg_edges, void* out, int n_seg,
+                               int row_elems, gs_stream_t stream) {
+  GS_REQUIRE(x && seg_offsets && seg_edges && out, "segment_mean: null pointer");
+  GS_REQUIRE(n_seg >= 0 && row_elems > 0 && row_elems % 8 == 0, "segment_mean: row_elems must be a multiple of 8");
+  if (n_seg == 0) return GS_OK;
+  const size_t total = (size_t)n_seg * (row_elems / 8);
+  segment_mean_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      (const _Float16*)x, seg_offsets, seg_edges, (_Float16*)out, row_elems / 8, total);
+  GS_CHECK_LAUNCH("segment_mean");
+  return GS_OK;
+}
+
+extern "C" size_t gs_gru_glo_workspace_bytes(int n) { return (size_t)(n > 0 ? n : 0) * 8 * 128 * sizeof(float); }
+
+extern "C" int gs_gru_glo(const void* w_pre, const float* w_bias, const void* net, const void* wz, const void* wr,
+                          const void* wq, const float* bz, const float* br, const float* bq, float* gzr, float* gq,
+                          int n, int hw, void* workspace, size_t workspace_bytes, gs_stream_t stream) {
+  GS_REQUIRE(w_pre && w_bias && net && wz && wr && wq && bz && br && bq && gzr && gq, "gru_glo: null pointer");
+  GS_REQUIRE(n >= 0 && hw > 0, "gru_glo: bad shape");
+  if (n == 0) return GS_OK;
+  GS_REQUIRE(workspace && workspace_bytes >= gs_gru_glo_workspace_bytes(n), "gru_glo: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nchunk = 8;
+  glo_pool_kernel<<<dim3(nchunk, n), 256, 0, st>>>((const _Float16*)w_pre, w_bias, (const _Float16*)net,
+                                                   (float*)workspace, hw, nchunk);
+  GS_CHECK_LAUNCH("gru_glo pool");
+  glo_heads_kernel<<<n, 384, 0, st>>>((const float*)workspace, nchunk, 1.0f / (float)hw, (const _Float16*)wz,
+                                      (const _Float16*)wr, (const _Float16*)wq, bz, br, bq, gzr, gq);
+  GS_CHECK_LAUNCH("gru_glo heads");
   return GS_OK;
 }

@@ -36,6 +36,30 @@ def segment_mean(x, index, num_segments):
     return (avg @ x.reshape(n, -1)).view((num_segments,) + tuple(x.shape[1:]))
 
 
+def build_segments(index):
+    """CSR grouping of edges by source keyframe for GraphAgg: returns dict(uniq, ix, offsets, order, n).
+    `index` is the edge list ii; uniq/ix are torch.unique(ii, sorted=True, return_inverse=True)
+    (src/droid_net.py:57), offsets/order (int32) list each segment's edges."""
+    uniq, ix = torch.unique(index, sorted=True, return_inverse=True)
+    order = torch.argsort(ix, stable=True).to(torch.int32)
+    counts = torch.bincount(ix, minlength=uniq.numel())
+    offsets = torch.zeros(uniq.numel() + 1, dtype=torch.int32, device=index.device)
+    offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return {"uniq": uniq, "ix": ix, "offsets": offsets, "order": order.contiguous(), "n": int(uniq.numel())}
+
+
+def segment_mean_hip(x, seg):
+    """scatter_mean over source keyframes for NHWC fp16 x [E,C,h,w] through gs_segment_mean (one
+    HBM-bound pass: reads x once, writes the means)."""
+    from . import _lib
+    E, C, h, w = x.shape
+    out = torch.empty((seg["n"], C, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    rc = _lib.lib().gs_segment_mean(_lib.ptr(x), _lib.ptr(seg["offsets"]), _lib.ptr(seg["order"]), _lib.ptr(out),
+                                    seg["n"], C * h * w, _lib.stream_ptr(x.device))
+    _lib.check(rc, "segment_mean")
+    return out
+
+
 def cvx_upsample(data, mask):
     """Convex 8x upsampling (src/droid_net.py:9-23): data [b,h,w,d], mask [b,576,h,w]."""
     b, h, w, d = data.shape
@@ -67,9 +91,10 @@ class _HalfWeights:
 _ACT = {"none": 0, "relu": 1, "sigmoid": 2}
 
 
-def conv_bias_act(cache, conv, x, act):
+def conv_bias_act(cache, conv, x, act, out=None, out_channel=0):
     """act(conv(x) + bias) for NHWC fp16 x: bias-free MIOpen convolution + one fused HIP epilogue
-    (PyTorch issues conv, add_(bias) and relu_ as three passes)."""
+    (PyTorch issues conv, add_(bias) and relu_ as three passes).  With `out` (an NHWC fp16 tensor
+    with more channels) the result lands in out[:, out_channel:out_channel+C] -- no torch.cat."""
     from . import _lib
     w, b = cache.get(conv)
     with torch.autocast("cuda", enabled=False):
@@ -77,9 +102,20 @@ def conv_bias_act(cache, conv, x, act):
     if not y.is_contiguous(memory_format=torch.channels_last):
         y = y.contiguous(memory_format=torch.channels_last)
     n, c, h, wd = y.shape
-    rc = _lib.lib().gs_bias_act(_lib.ptr(y), _lib.ptr(b), n * h * wd, c, _ACT[act], _lib.stream_ptr(y.device))
+    dst, ldy, off = (y, c, 0) if out is None else (out, out.shape[1], out_channel)
+    rc = _lib.lib().gs_bias_act(_lib.ptr(y), _lib.ptr(b), dst.data_ptr() + 2 * off, n * h * wd, c, ldy, _ACT[act],
+                                _lib.stream_ptr(y.device))
     _lib.check(rc, "conv_bias_act")
-    return y
+    return y if out is None else out
+
+
+def copy_channels(x, out, out_channel):
+    """out[:, out_channel:out_channel+C] = x for NHWC fp16 tensors (strided 16-byte copies)."""
+    from . import _lib
+    n, c, h, wd = x.shape
+    rc = _lib.lib().gs_bias_act(_lib.ptr(x), None, out.data_ptr() + 2 * out_channel, n * h * wd, c, out.shape[1], 0,
+                                _lib.stream_ptr(x.device))
+    _lib.check(rc, "copy_channels")
 
 
 class ConvGRU(nn.Module):
@@ -105,35 +141,51 @@ class ConvGRU(nn.Module):
 
     def _half_weights(self):
         """fp16 NHWC copies of the conv weights (convz|convr fused to one 448->256 conv), cached."""
-        key = (self.convz.weight._version, self.convr.weight._version, self.convq.weight._version,
-               self.convz.bias._version, self.convr.bias._version, self.convq.bias._version, self.convz.weight.device)
+        mods = (self.convz, self.convr, self.convq, self.w, self.convz_glo, self.convr_glo, self.convq_glo)
+        key = tuple(m.weight._version for m in mods) + tuple(m.bias._version for m in mods) + \
+            (self.convz.weight.device, self.convz.weight.data_ptr())
         if getattr(self, "_hw_key", None) != key:
             cl = torch.channels_last
             wzr = torch.cat([self.convz.weight, self.convr.weight], 0).detach().half().contiguous(memory_format=cl)
             wq = self.convq.weight.detach().half().contiguous(memory_format=cl)
             bzr = torch.cat([self.convz.bias, self.convr.bias]).detach().float().contiguous()
             bq = self.convq.bias.detach().float().contiguous()
-            self._hw, self._hw_key = (wzr, wq, bzr, bq), key
+            ww = self.w.weight.detach().half().contiguous(memory_format=cl)
+            bw = self.w.bias.detach().float().contiguous()
+            glo = [m.weight.detach().half().reshape(128, 128).contiguous()
+                   for m in (self.convz_glo, self.convr_glo, self.convq_glo)]
+            glo += [m.bias.detach().float().contiguous() for m in (self.convz_glo, self.convr_glo, self.convq_glo)]
+            self._hw, self._hw_key = (wzr, wq, bzr, bq, ww, bw, glo), key
         return self._hw
 
     def _forward_fused(self, net, inputs):
-        """Same mathematics as forward(); the three 3x3 convolutions stay MIOpen, everything between
-        them is two HIP kernels (gs_gru_gate_zr / gs_gru_gate_q) and ONE 448-channel cat."""
-        from . import _lib
-        b, c, h, w = net.shape
-        hw = h * w
+        """Same mathematics as forward(); the 3x3 convolutions stay MIOpen, everything between them is
+        HIP (gs_gru_glo, gs_gru_gate_zr, gs_gru_gate_q) and ONE 448-channel cat."""
         hx = torch.cat([net, *inputs], dim=1)
         if not hx.is_contiguous(memory_format=torch.channels_last):
             hx = hx.contiguous(memory_format=torch.channels_last)
-        glo = (torch.sigmoid(self.w(net)) * net).mean(dim=(2, 3), keepdim=True)
-        gzr = torch.cat([self.convz_glo(glo), self.convr_glo(glo)], 1).reshape(b, 256).float().contiguous()
-        gq = self.convq_glo(glo).reshape(b, 128).float().contiguous()
-        wzr, wq, bzr, bq = self._half_weights()
+        return self.forward_hx(net, hx)
+
+    def forward_hx(self, net, hx):
+        """GRU step given hx = [net | inputs] already laid out as one NHWC fp16 tensor.  hx[:, :128] is
+        overwritten with r*net (the q-convolution's input)."""
+        from . import _lib
+        b, c, h, w = net.shape
+        hw = h * w
+        wzr, wq, bzr, bq, ww, bw, gw = self._half_weights()
+        L = _lib.lib()
+        st = _lib.stream_ptr(net.device)
+        dev = net.device
         with torch.autocast("cuda", enabled=False):
+            w_pre = F.conv2d(net, ww, None)
+            gzr = torch.empty(b, 256, dtype=torch.float32, device=dev)
+            gq = torch.empty(b, 128, dtype=torch.float32, device=dev)
+            ws = torch.empty(L.gs_gru_glo_workspace_bytes(b), dtype=torch.uint8, device=dev)
+            _lib.check(L.gs_gru_glo(_lib.ptr(w_pre), _lib.ptr(bw), _lib.ptr(net), _lib.ptr(gw[0]), _lib.ptr(gw[1]),
+                                    _lib.ptr(gw[2]), _lib.ptr(gw[3]), _lib.ptr(gw[4]), _lib.ptr(gw[5]),
+                                    _lib.ptr(gzr), _lib.ptr(gq), b, hw, _lib.ptr(ws), ws.numel(), st), "gru_glo")
             zr_pre = F.conv2d(hx, wzr, None, padding=1)
             z = torch.empty_like(net)
-            L = _lib.lib()
-            st = _lib.stream_ptr(net.device)
             _lib.check(L.gs_gru_gate_zr(_lib.ptr(zr_pre), _lib.ptr(bzr), _lib.ptr(gzr), _lib.ptr(hx), _lib.ptr(z),
                                         b, hw, hx.shape[1], st), "gru_gate_zr")
             q_pre = F.conv2d(hx, wq, None, padding=1)
@@ -201,24 +253,46 @@ class UpdateModule(nn.Module):
         self.fuse_epilogues = True      # inference fast path: bias-free convs + fused HIP epilogues
         self._hw = _HalfWeights()
 
-    def _forward_fast(self, net, inp, corr, flow, ii, jj):
+    def _hx_buffer(self, inp, n, ht, wd):
+        """The GRU's 448-channel NHWC input [net | inp | corr | flow].  Kept across calls; the inp slice
+        is rewritten only when `inp` is a different tensor (or was modified) -- in the factor graph it
+        changes only when edges are added or removed."""
+        import weakref
+        hx = getattr(self, "_hx", None)
+        if hx is None or hx.shape[0] != n or hx.shape[2:] != (ht, wd) or hx.device != inp.device:
+            hx = torch.empty((n, 448, ht, wd), dtype=torch.float16, device=inp.device,
+                             memory_format=torch.channels_last)
+            self._hx, self._hx_inp = hx, None
+        tag = self._hx_inp
+        if tag is None or tag[0]() is not inp or tag[1] != inp._version:
+            inp4 = inp.view(n, -1, ht, wd)
+            if inp4.dtype != torch.float16 or not inp4.is_contiguous(memory_format=torch.channels_last):
+                inp4 = inp4.half().contiguous(memory_format=torch.channels_last)
+            copy_channels(inp4, hx, 128)
+            self._hx_inp = (weakref.ref(inp), inp._version)
+        return hx
+
+    def _forward_fast(self, net, inp, corr, flow, ii, jj, seg=None):
         """forward() with every 128/64-channel convolution run bias-free on MIOpen and its
-        bias + activation applied by one HIP pass; same mathematics, fp16 NHWC throughout."""
+        bias + activation applied by one HIP pass that also writes the encoder outputs straight into
+        the GRU's 448-channel input (no torch.cat); same mathematics, fp16 NHWC throughout."""
         batch, num, ch, ht, wd = net.shape
         cl = torch.channels_last
         hwc = self._hw
         out_dim = (batch, num, -1, ht, wd)
-        net4 = net.view(batch * num, -1, ht, wd)
-        inp4 = inp.view(batch * num, -1, ht, wd).half().contiguous(memory_format=cl)
-        c4 = corr.view(batch * num, -1, ht, wd).half().contiguous(memory_format=cl)
+        n = batch * num
+        net4 = net.view(n, -1, ht, wd)
+        c4 = corr.view(n, -1, ht, wd).half().contiguous(memory_format=cl)
         if flow is None:
             flow = torch.zeros(batch, num, 4, ht, wd, device=net.device)
-        f4 = flow.view(batch * num, -1, ht, wd).half().contiguous(memory_format=cl)
+        f4 = flow.view(n, -1, ht, wd).half().contiguous(memory_format=cl)
+        hx = self._hx_buffer(inp, n, ht, wd)
+        copy_channels(net4, hx, 0)
         c4 = conv_bias_act(hwc, self.corr_encoder[0], c4, "relu")
-        c4 = conv_bias_act(hwc, self.corr_encoder[2], c4, "relu")
+        conv_bias_act(hwc, self.corr_encoder[2], c4, "relu", out=hx, out_channel=256)
         f4 = conv_bias_act(hwc, self.flow_encoder[0], f4, "relu")
-        f4 = conv_bias_act(hwc, self.flow_encoder[2], f4, "relu")
-        net4 = self.gru(net4, inp4, c4, f4)
+        conv_bias_act(hwc, self.flow_encoder[2], f4, "relu", out=hx, out_channel=384)
+        net4 = self.gru.forward_hx(net4, hx)
         d = conv_bias_act(hwc, self.delta[0], net4, "relu")
         delta = self.delta[2](d).view(*out_dim).permute(0, 1, 3, 4, 2)[..., :2].contiguous()
         wgt = conv_bias_act(hwc, self.weight[0], net4, "relu")
@@ -229,8 +303,9 @@ class UpdateModule(nn.Module):
         # GraphAgg (src/droid_net.py:49-67)
         agg = self.agg
         x = conv_bias_act(hwc, agg.conv1, net4, "relu")
-        uniq, ix = torch.unique(ii.to(net.device), sorted=True, return_inverse=True)
-        x = segment_mean(x, ix, uniq.numel()).contiguous(memory_format=cl)
+        if seg is None:
+            seg = build_segments(ii.to(net.device))
+        x = segment_mean_hip(x, seg)
         x = conv_bias_act(hwc, agg.conv2, x, "relu")
         eta = agg.eta(x).view(batch, -1, ht, wd)
         upmask = conv_bias_act(hwc, agg.upmask[0], x, "none").view(batch, -1, 8 * 8 * 9, ht, wd)
@@ -240,12 +315,14 @@ class UpdateModule(nn.Module):
         cl = torch.channels_last
         n4 = net.view(-1, *net.shape[2:])
         return (self.fuse_epilogues and net.is_cuda and not torch.is_grad_enabled() and net.dtype == torch.float16
-                and n4.is_contiguous(memory_format=cl) and torch.is_autocast_enabled())
+                and net.shape[2] == 128 and n4.is_contiguous(memory_format=cl) and torch.is_autocast_enabled())
 
-    def forward(self, net, inp, corr, flow=None, ii=None, jj=None):
+    def forward(self, net, inp, corr, flow=None, ii=None, jj=None, seg=None):
+        """`seg` (optional, not in the reference): build_segments(ii) cached by the caller, which
+        saves the per-call torch.unique (a sort + host sync)."""
         batch, num, ch, ht, wd = net.shape
         if self._fast_ok(net, inp, corr):
-            return self._forward_fast(net, inp, corr, flow, ii, jj)
+            return self._forward_fast(net, inp, corr, flow, ii, jj, seg)
         if flow is None:
             flow = torch.zeros(batch, num, 4, ht, wd, device=net.device)
         out_dim = (batch, num, -1, ht, wd)

@@ -44,6 +44,38 @@ class FactorGraph:
         self.target_inac = z(1, 0, self.ht, self.wd, 2)
         self.weight_inac = z(1, 0, self.ht, self.wd, 2)
 
+    def _edge_index(self, t0, t1, use_inactive):
+        """Everything update() derives from the edge lists alone -- BA window, GraphAgg segments, damping
+        rows, the active+inactive edge list -- computed once per graph topology on a host copy of ii/jj
+        and cached until an edge list is replaced or written to.  The reference recomputes these every
+        update with torch.unique / min / max / boolean indexing on the GPU (src/factor_graph.py:213-240),
+        each a sort or a host sync; here a steady-state update issues none."""
+        from .droid_net import build_segments
+        tens = (self.ii, self.jj, self.ii_inac, self.jj_inac)
+        key = tuple(x._version for x in tens) + (t0, t1, bool(use_inactive))
+        c = getattr(self, "_eidx", None)
+        if c is not None and c["key"] == key and all(a is b for a, b in zip(c["tens"], tens)):
+            return c
+        dev = self.device
+        ii_c, jj_c = self.ii.cpu(), self.jj.cpu()
+        a0 = max(1, int(ii_c.min()) + 1) if t0 is None else t0
+        a0 = max(1, a0)
+        a1 = (max(int(ii_c.max()), int(jj_c.max())) + 1) if t1 is None else t1
+        c = {"key": key, "tens": tens, "t0": a0, "t1": a1, "seg": build_segments(self.ii), "sel": None}
+        ii_all = ii_c
+        if use_inactive:
+            iin, jin = self.ii_inac.cpu(), self.jj_inac.cpu()
+            m = (iin >= a0 - 3) & (jin >= a0 - 3)
+            c["sel"] = torch.nonzero(m).reshape(-1).to(dev)
+            ii_all = torch.cat([iin[m], ii_c])
+            c["ii"] = ii_all.to(dev)
+            c["jj"] = torch.cat([jin[m], jj_c]).to(dev)
+        else:
+            c["ii"], c["jj"] = self.ii.contiguous(), self.jj.contiguous()
+        c["damping_index"] = torch.unique(torch.cat([torch.arange(a0, a1), ii_all]), sorted=True).to(dev)
+        self._eidx = c
+        return c
+
     @torch.no_grad()
     def add_factors(self, ii, jj, remove=False):
         """add edges ii->jj (src/factor_graph.py:80-130): builds their correlation pyramids."""
@@ -98,6 +130,8 @@ class FactorGraph:
     @torch.no_grad()
     def update(self, t0=None, t1=None, iters=2, use_inactive=False, EPS=1e-7, motion_only=False):
         """run the update operator on the factor graph (src/factor_graph.py:199-252)."""
+        idx = self._edge_index(t0, t1, use_inactive)
+        t0, t1, seg = idx["t0"], idx["t1"], idx["seg"]
         coords1, mask = self.video.reproject(self.ii, self.jj)
         motion = torch.cat([coords1 - self.coords0, self.target - coords1], dim=-1)
         motion = motion.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
@@ -105,37 +139,28 @@ class FactorGraph:
         corr = self.corr(coords1)
         with torch.autocast("cuda", dtype=torch.float16):
             self.net, delta, weight, damping, upmask = self.update_op(
-                self.net, self.inp, corr, motion, self.ii, self.jj)
-
-        if t0 is None:
-            t0 = max(1, int(self.ii.min()) + 1)
-        t0 = max(1, t0)
-        if t1 is None:
-            t1 = max(int(self.ii.max()), int(self.jj.max())) + 1
+                self.net, self.inp, corr, motion, self.ii, self.jj, seg=seg)
 
         self.target = coords1 + delta.float()
         self.weight = weight.float()
         ht, wd = self.ht, self.wd
-        self.damping[torch.unique(self.ii, sorted=True)] = damping.float()
+        self.damping[seg["uniq"]] = damping.float()
 
         if use_inactive:
-            m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
-            ii = torch.cat([self.ii_inac[m], self.ii])
-            jj = torch.cat([self.jj_inac[m], self.jj])
-            target = torch.cat([self.target_inac[:, m], self.target], 1)
-            weight = torch.cat([self.weight_inac[:, m], self.weight], 1)
+            sel = idx["sel"]
+            target = torch.cat([self.target_inac[:, sel], self.target], 1)
+            weight = torch.cat([self.weight_inac[:, sel], self.weight], 1)
         else:
-            ii, jj, target, weight = self.ii, self.jj, self.target, self.weight
+            target, weight = self.target, self.weight
 
-        damping_index = torch.unique(torch.cat([torch.arange(t0, t1, device=ii.device), ii]), sorted=True)
-        damping = 0.2 * self.damping[damping_index].contiguous() + EPS
+        damping = 0.2 * self.damping[idx["damping_index"]].contiguous() + EPS
         target = target.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
         weight = weight.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
 
-        self.video.ba(target, weight, damping, ii.contiguous(), jj.contiguous(), t0=t0, t1=t1, iters=iters,
+        self.video.ba(target, weight, damping, idx["ii"], idx["jj"], t0=t0, t1=t1, iters=iters,
                       lm=1e-4, ep=0.1, motion_only=motion_only)
         if self.upsample:
-            self.video.upsample(torch.unique(self.ii, sorted=True), upmask[0])
+            self.video.upsample(seg["uniq"], upmask[0])
         self.age += 1
 
     @torch.no_grad()

@@ -123,9 +123,26 @@ int gs_gru_gate_zr(const void* zr_pre, const float* bias_zr, const float* glo_zr
                    int n, int hw, int ldx, gs_stream_t stream);
 int gs_gru_gate_q(const void* q_pre, const float* bias_q, const float* glo_q, const void* z,
                   const void* net, void* net_out, int n, int hw, gs_stream_t stream);
-/* In-place x = act(x + bias) on an NHWC fp16 tensor viewed as [rows, channels] (channels % 8 == 0);
- * act: 0 none, 1 ReLU, 2 sigmoid.  Epilogue of the bias-free MIOpen convolutions.               */
-int gs_bias_act(void* x, const float* bias, int rows, int channels, int act, gs_stream_t stream);
+/* y[row, 0:channels] = act(x[row, :] + bias) for NHWC fp16 data viewed as [rows, channels]
+ * (channels % 8 == 0); y rows are y_stride elements apart, so y may be x itself (in place,
+ * y_stride == channels) or a channel slice of a wider NHWC tensor (replaces torch.cat).  bias may be
+ * NULL (plain strided copy when act == 0).  act: 0 none, 1 ReLU, 2 sigmoid.
+ * Epilogue of the bias-free MIOpen convolutions of src/droid_net.py:69-140.                       */
+int gs_bias_act(const void* x, const float* bias, void* y, int rows, int channels, int y_stride, int act,
+                gs_stream_t stream);
+/* GraphAgg's scatter_mean over source keyframes (src/droid_net.py:57-60, torch_scatter):
+ * out[s, :] = mean over k in [seg_offsets[s], seg_offsets[s+1]) of x[seg_edges[k], :], fp16 rows of
+ * row_elems (= h*w*C, % 8 == 0) elements, fp32 accumulation.                                       */
+int gs_segment_mean(const void* x, const int* seg_offsets, const int* seg_edges, void* out, int n_seg,
+                    int row_elems, gs_stream_t stream);
+/* ConvGRU global context (src/modules/gru.py:22-27): glo = mean_hw(sigmoid(w_pre + w_bias) * net),
+ * then the three 1x1 convolutions convz_glo | convr_glo (-> gzr [n,256]) and convq_glo (-> gq [n,128]).
+ * w_pre = bias-free 1x1 conv of net, NHWC fp16 [n,hw,128]; wz/wr/wq fp16 [128 out,128 in]; outputs f32
+ * holding fp16-rounded values (what autocast produces).                                           */
+size_t gs_gru_glo_workspace_bytes(int n);
+int gs_gru_glo(const void* w_pre, const float* w_bias, const void* net, const void* wz, const void* wr,
+               const void* wq, const float* bz, const float* br, const float* bq, float* gzr, float* gq,
+               int n, int hw, void* workspace, size_t workspace_bytes, gs_stream_t stream);
 
 /* DepthVideo.upsample -> cvx_upsample (src/depth_video.py:194-196, src/droid_net.py:9-23):
  * out[ix[n]] (f32 [*,8h,8w]) = convex 8x upsampling of disps[ix[n]] (f32 [*,h,w]) with the softmax

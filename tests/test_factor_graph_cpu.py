@@ -1,0 +1,69 @@
+"""Host-side index logic of FactorGraph.update (CPU): the cached edge index must equal what the
+reference derives per update (src/factor_graph.py:213-240) and must refresh when an edge list changes."""
+import types
+
+import torch
+
+from go_slam_amd.factor_graph import FactorGraph
+
+
+def _graph():
+    video = types.SimpleNamespace(ht=6, wd=8, disps=torch.ones(16, 6, 8))
+    g = FactorGraph(video, update_op=None, device="cpu")
+    g.ii = torch.tensor([3, 3, 4, 5, 5, 5, 6])
+    g.jj = torch.tensor([4, 5, 3, 3, 4, 6, 5])
+    g.ii_inac = torch.tensor([0, 1, 2, 2, 3])
+    g.jj_inac = torch.tensor([1, 2, 1, 3, 2])
+    return g
+
+
+def _reference(g, t0, t1, use_inactive):
+    if t0 is None:
+        t0 = max(1, int(g.ii.min()) + 1)
+    t0 = max(1, t0)
+    if t1 is None:
+        t1 = max(int(g.ii.max()), int(g.jj.max())) + 1
+    if use_inactive:
+        m = (g.ii_inac >= t0 - 3) & (g.jj_inac >= t0 - 3)
+        ii = torch.cat([g.ii_inac[m], g.ii])
+        jj = torch.cat([g.jj_inac[m], g.jj])
+    else:
+        m, ii, jj = None, g.ii, g.jj
+    dix = torch.unique(torch.cat([torch.arange(t0, t1), ii]), sorted=True)
+    return t0, t1, m, ii, jj, dix
+
+
+def test_edge_index_matches_reference_logic():
+    g = _graph()
+    for t0, t1, inac in [(None, None, True), (None, None, False), (2, 9, True), (0, None, True)]:
+        c = g._edge_index(t0, t1, inac)
+        r0, r1, m, ii, jj, dix = _reference(g, t0, t1, inac)
+        assert (c["t0"], c["t1"]) == (r0, r1)
+        assert torch.equal(c["ii"], ii) and torch.equal(c["jj"], jj)
+        assert torch.equal(c["damping_index"], dix)
+        if inac:
+            assert torch.equal(c["sel"], torch.nonzero(m).reshape(-1))
+        uniq, ix = torch.unique(g.ii, sorted=True, return_inverse=True)
+        seg = c["seg"]
+        assert torch.equal(seg["uniq"], uniq) and torch.equal(seg["ix"], ix)
+        for s in range(seg["n"]):
+            edges = seg["order"][seg["offsets"][s]:seg["offsets"][s + 1]].long()
+            assert torch.equal(torch.sort(edges).values, torch.nonzero(ix == s).reshape(-1))
+
+
+def test_edge_index_cache_invalidation():
+    g = _graph()
+    a = g._edge_index(None, None, True)
+    assert g._edge_index(None, None, True) is a                 # steady state: cached
+    assert g._edge_index(None, None, False) is not a            # different arguments
+    b = g._edge_index(None, None, True)
+    g.ii[g.ii >= 5] -= 1                                        # in-place edit (rm_keyframe style)
+    c = g._edge_index(None, None, True)
+    assert c is not b and torch.equal(c["seg"]["uniq"], torch.unique(g.ii))
+    g.jj = torch.cat([g.jj[:-1], torch.tensor([9])])            # replaced tensor (add/rm_factors style)
+    d = g._edge_index(None, None, True)
+    assert d is not c and d["t1"] == 10
+    g.ii_inac = g.ii_inac[:-1]
+    g.jj_inac = g.jj_inac[:-1]
+    e = g._edge_index(None, None, True)
+    assert e is not d and e["ii"].numel() == d["ii"].numel() - 1

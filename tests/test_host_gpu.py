@@ -146,3 +146,58 @@ def test_update_module_fast_path_matches_plain(built_lib):
     for name, a, b in zip(names, outs[0], outs[1]):
         assert a.shape == b.shape, name
         torch.testing.assert_close(a.float(), b.float(), rtol=3e-2, atol=1e-2, msg=lambda m: f"{name}: {m}")
+
+
+def test_segment_mean_and_glo_kernels(built_lib):
+    """gs_segment_mean vs index_add mean; gs_gru_glo vs the torch formulation of src/modules/gru.py:22-27."""
+    from go_slam_amd import _lib
+    from go_slam_amd.droid_net import build_segments, segment_mean_hip, ConvGRU
+    import torch.nn.functional as F
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    cl = torch.channels_last
+    E, h, w = 11, 12, 16
+    x = torch.randn(E, 128, h, w, device=dev).half().contiguous(memory_format=cl)
+    ii = torch.tensor([4, 2, 2, 7, 4, 4, 9, 2, 7, 0, 9], device=dev)
+    seg = build_segments(ii)
+    out = segment_mean_hip(x, seg)
+    ref = torch.zeros(seg["n"], 128, h, w, device=dev)
+    ref.index_add_(0, seg["ix"], x.float())
+    ref /= torch.bincount(seg["ix"]).float().view(-1, 1, 1, 1)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=1e-3)
+    assert torch.equal(seg["uniq"], torch.unique(ii))
+
+    gru = ConvGRU(128, 320).to(dev).eval()
+    net = torch.tanh(torch.randn(E, 128, h, w, device=dev)).half().contiguous(memory_format=cl)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        glo = (torch.sigmoid(gru.w(net)) * net).view(E, 128, h * w).mean(-1).view(E, 128, 1, 1)
+        rz, rr, rq = gru.convz_glo(glo), gru.convr_glo(glo), gru.convq_glo(glo)
+    wzr, wq, bzr, bq, ww, bw, gw = gru._half_weights()
+    L = _lib.lib()
+    with torch.no_grad():
+        w_pre = F.conv2d(net, ww, None)
+    gzr = torch.empty(E, 256, device=dev)
+    gq = torch.empty(E, 128, device=dev)
+    ws = torch.empty(L.gs_gru_glo_workspace_bytes(E), dtype=torch.uint8, device=dev)
+    rc = L.gs_gru_glo(_lib.ptr(w_pre), _lib.ptr(bw), _lib.ptr(net), *[_lib.ptr(t) for t in gw], _lib.ptr(gzr),
+                      _lib.ptr(gq), E, h * w, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "gru_glo")
+    torch.testing.assert_close(gzr[:, :128], rz.reshape(E, 128).float(), rtol=1e-2, atol=2e-3)
+    torch.testing.assert_close(gzr[:, 128:], rr.reshape(E, 128).float(), rtol=1e-2, atol=2e-3)
+    torch.testing.assert_close(gq, rq.reshape(E, 128).float(), rtol=1e-2, atol=2e-3)
+
+
+def test_bias_act_into_channel_slice(built_lib):
+    from go_slam_amd import _lib
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    cl = torch.channels_last
+    x = torch.randn(3, 64, 5, 7, device=dev).half().contiguous(memory_format=cl)
+    b = torch.randn(64, device=dev)
+    out = torch.full((3, 160, 5, 7), 7.0, device=dev).half().contiguous(memory_format=cl)
+    rc = _lib.lib().gs_bias_act(_lib.ptr(x), _lib.ptr(b), out.data_ptr() + 2 * 32, 3 * 35, 64, 160, 1,
+                                _lib.stream_ptr(dev))
+    _lib.check(rc, "bias_act")
+    ref = torch.relu(x.float() + b.view(1, -1, 1, 1)).half()
+    assert torch.equal(out[:, 32:96], ref)
+    assert bool((out[:, :32] == 7).all()) and bool((out[:, 96:] == 7).all())
