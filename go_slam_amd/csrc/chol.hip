@@ -232,10 +232,276 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restric
   }
 }
 
+
+// ---- single-launch path for the frontend window (6P <= 192) -------------------------------
+// The multi-kernel path above spends its time in launch-to-launch dependencies: 6P = 150 is 5 panel
+// + 4 trailing launches + the solve, ~230 us for 1.1 MFLOP.  Here ONE workgroup keeps the packed
+// lower triangle (n(n+1)/2 doubles, 90 KB at n = 150; CDNA4's 160 KB LDS holds n <= 192) in LDS
+// and does damping, the blocked factorisation, both substitutions and the failure fallback in one
+// launch; the only global traffic is one read of H and b and the fp32 dx.
+constexpr int SMALL_N = 192;
+#ifdef CHOL_TIMING   // scratch/chol_bench.hip only: per-phase wall-clock stamps (100 MHz)
+__device__ long long g_chol_t[64];
+#define CHOL_STAMP(i) do { if (threadIdx.x == 0) g_chol_t[i] = wall_clock64(); } while (0)
+#else
+#define CHOL_STAMP(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ int tri(int r, int c) { return ((r * (r + 1)) >> 1) + c; }
+
+// sqrt and reciprocal sqrt of a pivot from v_rsq_f64 + two coupled Goldschmidt steps (full fp64
+// accuracy, ~12 dependent FMAs instead of the ~35-instruction sqrt + divide sequences).
+__device__ __forceinline__ void sqrt_rsqrt(double x, double& s, double& rs) {
+  const double r = __builtin_amdgcn_rsq(x);
+  double g = x * r, h = 0.5 * r;
+  double e = fma(-g, h, 0.5);
+  g = fma(g, e, g); h = fma(h, e, h);
+  e = fma(-g, h, 0.5);
+  g = fma(g, e, g); h = fma(h, e, h);
+  s = g; rs = h + h;
+}
+
+__global__ __launch_bounds__(256) void chol_small_kernel(const double* __restrict__ H, const double* __restrict__ bg,
+                                                         int n, double lm, double ep, float* __restrict__ dx,
+                                                         int32_t* fail_flag, int32_t* fail_count) {
+  extern __shared__ double sm[];
+  double* Lp = sm;                                 // packed lower triangle, row r at r(r+1)/2
+  double* bv = sm + ((n * (n + 1)) >> 1);          // right-hand side / solution
+  double* invd = bv + n;                           // 1 / L[j][j]
+  __shared__ double ys[NB];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) s_bad = 0;
+  CHOL_STAMP(0);
+  // lower triangle only, 16 independent loads in flight per thread: a lone workgroup is bound by
+  // global-load latency, not bandwidth (a one-load-per-iteration loop cost ~90 us here)
+  const int npk = (n * (n + 1)) >> 1;
+  for (int base = 0; base < npk; base += 256 * 16) {
+    double v[16];
+    int rr[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = base + u * 256 + tid;
+      int r = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+      while (((r + 1) * (r + 2)) >> 1 <= idx) ++r;
+      while ((r * (r + 1)) >> 1 > idx) --r;
+      const int c = idx - ((r * (r + 1)) >> 1);
+      rr[u] = (c == r) ? 1 : 0;
+      v[u] = idx < npk ? H[(size_t)r * n + c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = base + u * 256 + tid;
+      if (idx < npk) Lp[idx] = rr[u] ? v[u] + (ep + lm * v[u]) : v[u];
+    }
+  }
+  for (int i = tid; i < n; i += 256) bv[i] = bg[i];
+  __syncthreads();
+  CHOL_STAMP(1);
+
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int nb = min(NB, n - k0);
+    const int rem = n - k0 - nb;
+    CHOL_STAMP(2 + 4 * (k0 / NB));
+    // (a) diagonal block: wave 0, register-resident, lane r holds row r
+    if (tid < 64) {
+      const int r = lane & (NB - 1);
+      const bool live = (lane < NB) && (r < nb);
+      double a[NB];
+      const double* Ar = Lp + tri(k0 + (live ? r : 0), k0);
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        double v = (live && c <= r) ? Ar[c] : 0.0;
+        if (!live && c == r) v = 1.0;
+        a[c] = v;
+      }
+      bool bad = false;
+      double my_inv = 1.0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const double piv = readlane_f64(a[j], j);
+        if (j < nb && !(piv > 0.0) && piv == piv) bad = true;
+        double dj, inv;
+        sqrt_rsqrt(piv, dj, inv);
+        if (lane == j) { a[j] = dj; my_inv = inv; }
+        else if (lane > j) a[j] = a[j] * inv;
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) {
+          const double lcj = readlane_f64(a[j], c);
+          if (lane >= c) a[c] = fma(-a[j], lcj, a[c]);
+        }
+      }
+      if (live) {
+        double* Aw = Lp + tri(k0 + r, k0);
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+          if (c <= r) Aw[c] = a[c];
+        invd[k0 + r] = my_inv;
+      }
+      if (bad && lane == 0) s_bad = 1;
+    }
+    __syncthreads();
+    CHOL_STAMP(3 + 4 * (k0 / NB));
+    // (b) panel rows: L21 = A21 L11^-T, one row per thread
+    if (tid < rem) {
+      double* Ar = Lp + tri(k0 + nb + tid, k0);
+      double x[NB];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) x[c] = (c < nb) ? Ar[c] : 0.0;
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        if (c < nb) {
+          const double* Dc = Lp + tri(k0 + c, k0);
+          double sacc = x[c];
+#pragma unroll
+          for (int t = 0; t < NB; ++t)
+            if (t < c) sacc = fma(-x[t], Dc[t], sacc);
+          x[c] = sacc * invd[k0 + c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NB; ++c)
+        if (c < nb) Ar[c] = x[c];
+    }
+    __syncthreads();
+    CHOL_STAMP(4 + 4 * (k0 / NB));
+    // (c) trailing update A22 -= L21 L21^T on 4x4 register tiles of the lower triangle
+    if (rem > 0) {
+      const int T = (rem + 3) >> 2, ntile = (T * (T + 1)) >> 1;
+      const int s0 = k0 + nb;
+      for (int t = tid; t < ntile; t += 256) {
+        int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while (((ti + 1) * (ti + 2)) >> 1 <= t) ++ti;
+        while ((ti * (ti + 1)) >> 1 > t) --ti;
+        const int tj = t - ((ti * (ti + 1)) >> 1);
+        const int r0 = s0 + 4 * ti, c0 = s0 + 4 * tj;
+        const double* pr[4];
+        const double* pc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          pr[i] = Lp + tri(min(r0 + i, n - 1), k0);
+          pc[i] = Lp + tri(min(c0 + i, n - 1), k0);
+        }
+        double acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+        for (int k = 0; k < nb; ++k) {
+          double a[4], b[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { a[i] = pr[i][k]; b[i] = pc[i][k]; }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = r0 + i;
+          if (r >= n) continue;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j;
+            if (c <= r) Lp[tri(r, c)] -= acc[i][j];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (s_bad) {   // reference: zero update on failure (droid_kernels.cu:1207-1210)
+    for (int i = tid; i < n; i += 256) dx[i] = 0.0f;
+    if (tid == 0) { *fail_flag = 1; *fail_count += 1; }
+    return;
+  }
+  if (tid == 0) *fail_flag = 0;
+  CHOL_STAMP(40);
+
+  // ---- forward substitution L y = b
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int nb = min(NB, n - k0);
+    if (tid < 64) {
+      const int i = lane & (NB - 1);
+      const bool live = (lane < NB) && (i < nb);
+      double a[NB];
+      const double* Lr = Lp + tri(k0 + (live ? i : 0), k0);
+#pragma unroll
+      for (int c = 0; c < NB; ++c) a[c] = (live && c < i) ? Lr[c] : 0.0;
+      const double inv_dg = live ? invd[k0 + i] : 1.0;
+      double v = live ? bv[k0 + i] : 0.0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const double yj = readlane_f64(v * inv_dg, j);
+        if (lane == j) v = yj;
+        else if (lane > j && lane < NB) v = fma(-a[j], yj, v);
+      }
+      if (lane < NB) ys[lane] = live ? v : 0.0;
+      if (live) bv[k0 + i] = v;
+    }
+    __syncthreads();
+    for (int r = k0 + nb + tid; r < n; r += 256) {
+      const double* Lr = Lp + tri(r, k0);
+      double sacc = 0.0;
+      for (int c = 0; c < nb; ++c) sacc = fma(Lr[c], ys[c], sacc);
+      bv[r] -= sacc;
+    }
+    __syncthreads();
+  }
+  CHOL_STAMP(41);
+  // ---- backward substitution L^T x = y
+  const int last = ((n - 1) / NB) * NB;
+  for (int k0 = last; k0 >= 0; k0 -= NB) {
+    const int nb = min(NB, n - k0);
+    if (tid < 64) {
+      const int j = lane & (NB - 1);
+      const bool live = (lane < NB) && (j < nb);
+      double c_[NB];                      // column j of the block: L[k0+i][k0+j], i > j
+#pragma unroll
+      for (int i = 0; i < NB; ++i) c_[i] = (live && i > j && i < nb) ? Lp[tri(k0 + i, k0 + j)] : 0.0;
+      const double inv_dg = live ? invd[k0 + j] : 1.0;
+      double v = live ? bv[k0 + j] : 0.0;
+#pragma unroll
+      for (int i = NB - 1; i >= 0; --i) {
+        const double xi = readlane_f64(v * inv_dg, i);
+        if (lane == i) v = xi;
+        else if (lane < i) v = fma(-c_[i], xi, v);
+      }
+      if (lane < NB) ys[lane] = live ? v : 0.0;
+      if (live) { bv[k0 + j] = v; dx[k0 + j] = (float)v; }
+    }
+    __syncthreads();
+    for (int c = tid; c < k0; c += 256) {
+      double sacc = 0.0;
+      for (int r = 0; r < nb; ++r) sacc = fma(Lp[tri(k0 + r, c)], ys[r], sacc);
+      bv[c] -= sacc;
+    }
+    __syncthreads();
+  }
+  CHOL_STAMP(42);
+}
+
 }  // namespace
 
 int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float* dx_out, int32_t* fail_flag,
                          int32_t* fail_count, hipStream_t st) {
+  if (n <= SMALL_N) {
+    const size_t lds = ((size_t)n * (n + 1) / 2 + 2 * (size_t)n) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+      const size_t cap = ((size_t)SMALL_N * (SMALL_N + 1) / 2 + 2 * SMALL_N) * sizeof(double);
+      if (hipFuncSetAttribute((const void*)chol_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)cap) != hipSuccess) {
+        gs_set_error("chol: cannot raise the dynamic LDS limit to %zu bytes", cap);
+        return GS_ERR_LAUNCH;
+      }
+      attr_set = true;
+    }
+    chol_small_kernel<<<1, 256, lds, st>>>(H, b, n, (double)lm, (double)ep, dx_out, fail_flag, fail_count);
+    GS_CHECK_LAUNCH("chol_small");
+    return GS_OK;
+  }
   chol_damp_kernel<<<gs_cdiv(n, 256), 256, 0, st>>>(H, n, (double)lm, (double)ep, fail_flag);
   GS_CHECK_LAUNCH("chol_damp");
   for (int k0 = 0; k0 < n; k0 += NB) {

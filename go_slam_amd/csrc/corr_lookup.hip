@@ -36,20 +36,10 @@ template <> struct VecRow<_Float16> { typedef struct __attribute__((packed, alig
 template <> struct VecRow<float>    { typedef struct __attribute__((packed, aligned(4))) { float v[8]; } type; };
 template <> struct VecRow<double>   { typedef struct __attribute__((packed, aligned(8))) { double v[8]; } type; };
 
-// Sample one level for one pixel; writes 49 taps to out[(i*7+j)*plane] (plane == 0: `out` is a
-// 49-entry register array).
-template <typename T>
-__device__ __forceinline__ void lookup_r3(const T* __restrict__ slice, int h2, int w2,
-                                          float x0, float y0, T* __restrict__ out, size_t plane) {
-  const float fx0 = floorf(x0), fy0 = floorf(y0);
-  const float dx = x0 - fx0, dy = y0 - fy0;
-  const int xs = safe_int(fx0) - 3, ys = safe_int(fy0) - 3;
-  const T w_nw = wcast<T>(dx * dy);
-  const T w_ne = wcast<T>(dx * (1.0f - dy));
-  const T w_sw = wcast<T>((1.0f - dx) * dy);
-  const T w_se = wcast<T>((1.0f - dx) * (1.0f - dy));
 
-  T s[8][8];   // s[i][j]: i = x offset, j = y offset
+// 8x8 window s[i][j] = slice[ys+j][xs+i] (0 outside the plane).
+template <typename T>
+__device__ __forceinline__ void load_window(const T* __restrict__ slice, int h2, int w2, int xs, int ys, T (&s)[8][8]) {
   const bool xin = (xs >= 0) && (xs + 8 <= w2);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -68,6 +58,67 @@ __device__ __forceinline__ void lookup_r3(const T* __restrict__ slice, int h2, i
       }
     }
   }
+}
+
+// fp16 (the production dtype): no per-element border path.  Every row is ONE unaligned 128-bit load
+// from the start column clamped into the plane (planes are >= 8 wide at every pyramid level the
+// fused kernels accept), then a 128-bit funnel shift by the clamp distance moves the taps into place
+// and shifts zeros in for the columns outside the plane.  On the coarse levels (20x15, 10x7 planes)
+// most windows straddle a border, and the element path cost 64 two-byte loads per lane there.
+template <>
+__device__ __forceinline__ void load_window<_Float16>(const _Float16* __restrict__ slice, int h2, int w2, int xs,
+                                                      int ys, _Float16 (&s)[8][8]) {
+  typedef unsigned __int128 u128;
+  if (w2 < 8) {   // never on the fused path; keeps the ABI entry total
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int x1 = xs + i, y1 = ys + j;
+        const bool in = (y1 >= 0) && (y1 < h2) && (x1 >= 0) && (x1 < w2);
+        s[i][j] = in ? slice[(size_t)(in ? y1 : 0) * w2 + (in ? x1 : 0)] : (_Float16)0;
+      }
+    return;
+  }
+  const int xc = min(max(xs, 0), w2 - 8);
+  const int d = min(max(xs - xc, -8), 8);       // s[i] = row[i + d]
+  const bool none = (d <= -8) || (d >= 8);
+  const int sh = 16 * (d < 0 ? -d : d);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int y1 = ys + j;
+    const bool yin = (y1 >= 0) && (y1 < h2) && !none;
+    u128 v = 0;
+    if (yin) {
+      typedef struct __attribute__((packed, aligned(2))) { u128 q; } U;
+      v = reinterpret_cast<const U*>(slice + (size_t)y1 * w2 + xc)->q;
+      if (d > 0) v >>= sh;
+      else if (d < 0) v <<= sh;
+    }
+    const unsigned long long lo = (unsigned long long)v, hi = (unsigned long long)(v >> 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned short bits = (unsigned short)((i < 4 ? lo : hi) >> (16 * (i & 3)));
+      s[i][j] = __builtin_bit_cast(_Float16, bits);
+    }
+  }
+}
+
+// Sample one level for one pixel; writes 49 taps to out[(i*7+j)*plane] (plane == 0: `out` is a
+// 49-entry register array).
+template <typename T>
+__device__ __forceinline__ void lookup_r3(const T* __restrict__ slice, int h2, int w2,
+                                          float x0, float y0, T* __restrict__ out, size_t plane) {
+  const float fx0 = floorf(x0), fy0 = floorf(y0);
+  const float dx = x0 - fx0, dy = y0 - fy0;
+  const int xs = safe_int(fx0) - 3, ys = safe_int(fy0) - 3;
+  const T w_nw = wcast<T>(dx * dy);
+  const T w_ne = wcast<T>(dx * (1.0f - dy));
+  const T w_sw = wcast<T>((1.0f - dx) * dy);
+  const T w_se = wcast<T>((1.0f - dx) * (1.0f - dy));
+
+  T s[8][8];   // s[i][j]: i = x offset, j = y offset
+  load_window<T>(slice, h2, w2, xs, ys, s);
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
 #pragma unroll

@@ -19,7 +19,9 @@ __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x
 // zr_pre [n,hw,256]; bias [256] f32; glo [n,256] f32; hx [n,hw,ldx] (first 128 ch = net, in/out); z [n,hw,128]
 __global__ __launch_bounds__(256) void gru_gate_zr_kernel(const _Float16* __restrict__ zr_pre,
                                                           const float* __restrict__ bias,
-                                                          const float* __restrict__ glo, _Float16* __restrict__ hx,
+                                                          const float* __restrict__ glo,
+                                                          const _Float16* __restrict__ inp_pre,
+                                                          _Float16* __restrict__ hx,
                                                           _Float16* __restrict__ z_out, int hw, int ldx,
                                                           size_t total /* n*hw*16 */) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -31,12 +33,17 @@ __global__ __launch_bounds__(256) void gru_gate_zr_kernel(const _Float16* __rest
   const half8 rp = *reinterpret_cast<const half8*>(zr_pre + pix * 256 + 128 + c8 * 8);
   half8* hp = reinterpret_cast<half8*>(hx + pix * ldx + c8 * 8);
   const half8 net = *hp;
+  half8 zi = {0, 0, 0, 0, 0, 0, 0, 0}, ri = zi;
+  if (inp_pre) {   // hoisted convolution over the constant context features (z | r | q channel blocks)
+    zi = *reinterpret_cast<const half8*>(inp_pre + pix * 384 + c8 * 8);
+    ri = *reinterpret_cast<const half8*>(inp_pre + pix * 384 + 128 + c8 * 8);
+  }
   half8 zo, rn;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int c = c8 * 8 + k;
-    const float z = sigm((float)zp[k] + bias[c] + glo[(size_t)n * 256 + c]);
-    const float r = sigm((float)rp[k] + bias[128 + c] + glo[(size_t)n * 256 + 128 + c]);
+    const float z = sigm((float)zp[k] + (float)zi[k] + bias[c] + glo[(size_t)n * 256 + c]);
+    const float r = sigm((float)rp[k] + (float)ri[k] + bias[128 + c] + glo[(size_t)n * 256 + 128 + c]);
     zo[k] = (_Float16)z;
     rn[k] = (_Float16)(r * (float)net[k]);
   }
@@ -48,6 +55,7 @@ __global__ __launch_bounds__(256) void gru_gate_zr_kernel(const _Float16* __rest
 __global__ __launch_bounds__(256) void gru_gate_q_kernel(const _Float16* __restrict__ q_pre,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ glo,
+                                                         const _Float16* __restrict__ inp_pre,
                                                          const _Float16* __restrict__ z, const _Float16* __restrict__ net,
                                                          _Float16* __restrict__ net_out, int hw, size_t total) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -59,11 +67,13 @@ __global__ __launch_bounds__(256) void gru_gate_q_kernel(const _Float16* __restr
   const half8 qp = *reinterpret_cast<const half8*>(q_pre + o);
   const half8 zz = *reinterpret_cast<const half8*>(z + o);
   const half8 nn = *reinterpret_cast<const half8*>(net + o);
+  half8 qi = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (inp_pre) qi = *reinterpret_cast<const half8*>(inp_pre + pix * 384 + 256 + c8 * 8);
   half8 out;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int c = c8 * 8 + k;
-    const float a = (float)qp[k] + bias[c] + glo[(size_t)n * 128 + c];
+    const float a = (float)qp[k] + (float)qi[k] + bias[c] + glo[(size_t)n * 128 + c];
     const float q = 1.0f - 2.0f / (1.0f + __expf(2.0f * a));      // tanh (|err| ~1e-7, result goes to fp16)
     const float zf = (float)zz[k];
     out[k] = (_Float16)((1.0f - zf) * (float)nn[k] + zf * q);
@@ -73,26 +83,28 @@ __global__ __launch_bounds__(256) void gru_gate_q_kernel(const _Float16* __restr
 
 }  // namespace
 
-extern "C" int gs_gru_gate_zr(const void* zr_pre, const float* bias_zr, const float* glo_zr, void* hx, void* z_out,
-                              int n, int hw, int ldx, gs_stream_t stream) {
+extern "C" int gs_gru_gate_zr(const void* zr_pre, const float* bias_zr, const float* glo_zr, const void* inp_pre,
+                              void* hx, void* z_out, int n, int hw, int ldx, gs_stream_t stream) {
   GS_REQUIRE(zr_pre && bias_zr && glo_zr && hx && z_out, "gru_gate_zr: null pointer");
   GS_REQUIRE(n >= 0 && hw > 0 && ldx >= 128 && ldx % 8 == 0, "gru_gate_zr: bad shape");
   if (n == 0) return GS_OK;
   const size_t total = (size_t)n * hw * 16;
   gru_gate_zr_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-      (const _Float16*)zr_pre, bias_zr, glo_zr, (_Float16*)hx, (_Float16*)z_out, hw, ldx, total);
+      (const _Float16*)zr_pre, bias_zr, glo_zr, (const _Float16*)inp_pre, (_Float16*)hx, (_Float16*)z_out, hw, ldx,
+      total);
   GS_CHECK_LAUNCH("gru_gate_zr");
   return GS_OK;
 }
 
-extern "C" int gs_gru_gate_q(const void* q_pre, const float* bias_q, const float* glo_q, const void* z,
-                             const void* net, void* net_out, int n, int hw, gs_stream_t stream) {
+extern "C" int gs_gru_gate_q(const void* q_pre, const float* bias_q, const float* glo_q, const void* inp_pre,
+                             const void* z, const void* net, void* net_out, int n, int hw, gs_stream_t stream) {
   GS_REQUIRE(q_pre && bias_q && glo_q && z && net && net_out, "gru_gate_q: null pointer");
   GS_REQUIRE(n >= 0 && hw > 0, "gru_gate_q: bad shape");
   if (n == 0) return GS_OK;
   const size_t total = (size_t)n * hw * 16;
   gru_gate_q_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-      (const _Float16*)q_pre, bias_q, glo_q, (const _Float16*)z, (const _Float16*)net, (_Float16*)net_out, hw, total);
+      (const _Float16*)q_pre, bias_q, glo_q, (const _Float16*)inp_pre, (const _Float16*)z, (const _Float16*)net,
+      (_Float16*)net_out, hw, total);
   GS_CHECK_LAUNCH("gru_gate_q");
   return GS_OK;
 }
@@ -104,13 +116,13 @@ extern "C" int gs_gru_gate_q(const void* q_pre, const float* bias_q, const float
 namespace {
 template <int ACT, bool BIAS>   // ACT: 0 none, 1 relu, 2 sigmoid
 __global__ __launch_bounds__(256) void bias_act_kernel(const _Float16* __restrict__ x, const float* __restrict__ bias,
-                                                       _Float16* __restrict__ y, int c8n /* C/8 */, int ldy,
+                                                       _Float16* __restrict__ y, int c8n /* C/8 */, int ldx, int ldy,
                                                        size_t total /* rows*C/8 */) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= total) return;
   const int c8 = (int)(t % c8n);
   const size_t row = t / c8n;
-  half8 v = reinterpret_cast<const half8*>(x)[t];
+  half8 v = *reinterpret_cast<const half8*>(x + row * ldx + c8 * 8);
   if (BIAS || ACT) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -208,10 +220,11 @@ __global__ __launch_bounds__(384) void glo_heads_kernel(const float* __restrict_
 }
 }  // namespace
 
-extern "C" int gs_bias_act(const void* x, const float* bias, void* y, int rows, int channels, int y_stride, int act,
-                           gs_stream_t stream) {
+extern "C" int gs_bias_act(const void* x, const float* bias, void* y, int rows, int channels, int x_stride,
+                           int y_stride, int act, gs_stream_t stream) {
   GS_REQUIRE(x && y, "bias_act: null pointer");
   GS_REQUIRE(rows >= 0 && channels > 0 && channels % 8 == 0, "bias_act: channels must be a multiple of 8");
+  GS_REQUIRE(x_stride >= channels && x_stride % 8 == 0, "bias_act: x_stride must be >= channels and a multiple of 8");
   GS_REQUIRE(y_stride >= channels && y_stride % 8 == 0, "bias_act: y_stride must be >= channels and a multiple of 8");
   GS_REQUIRE(act >= 0 && act <= 2, "bias_act: act in {0 none, 1 relu, 2 sigmoid}");
   if (rows == 0) return GS_OK;
@@ -221,7 +234,7 @@ extern "C" int gs_bias_act(const void* x, const float* bias, void* y, int rows, 
   const _Float16* xi = (const _Float16*)x;
   _Float16* yo = (_Float16*)y;
   const int c8n = channels / 8;
-#define GS_BA(A, B) bias_act_kernel<A, B><<<grid, 256, 0, st>>>(xi, bias, yo, c8n, y_stride, total)
+#define GS_BA(A, B) bias_act_kernel<A, B><<<grid, 256, 0, st>>>(xi, bias, yo, c8n, x_stride, y_stride, total)
   if (bias) { if (act == 0) GS_BA(0, true); else if (act == 1) GS_BA(1, true); else GS_BA(2, true); }
   else      { if (act == 0) GS_BA(0, false); else if (act == 1) GS_BA(1, false); else GS_BA(2, false); }
 #undef GS_BA

@@ -91,31 +91,39 @@ class _HalfWeights:
 _ACT = {"none": 0, "relu": 1, "sigmoid": 2}
 
 
+def bias_act(y, b, act, out=None, out_channel=0, in_channel=0, channels=None):
+    """act(y[:, in_channel:in_channel+channels] + b) through gs_bias_act; in place by default, or into
+    out[:, out_channel:...] (both NHWC fp16, any channel counts that are multiples of 8)."""
+    from . import _lib
+    n, cy, h, wd = y.shape
+    c = cy - in_channel if channels is None else channels
+    dst, ldy, off = (y, cy, in_channel) if out is None else (out, out.shape[1], out_channel)
+    rc = _lib.lib().gs_bias_act(y.data_ptr() + 2 * in_channel, _lib.ptr(b), dst.data_ptr() + 2 * off, n * h * wd, c,
+                                cy, ldy, _ACT[act], _lib.stream_ptr(y.device))
+    _lib.check(rc, "bias_act")
+    return dst
+
+
+def conv_nobias(x, w, stride=1, padding=0):
+    with torch.autocast("cuda", enabled=False):
+        y = F.conv2d(x, w, None, stride=stride, padding=padding)
+    if not y.is_contiguous(memory_format=torch.channels_last):
+        y = y.contiguous(memory_format=torch.channels_last)
+    return y
+
+
 def conv_bias_act(cache, conv, x, act, out=None, out_channel=0):
     """act(conv(x) + bias) for NHWC fp16 x: bias-free MIOpen convolution + one fused HIP epilogue
     (PyTorch issues conv, add_(bias) and relu_ as three passes).  With `out` (an NHWC fp16 tensor
     with more channels) the result lands in out[:, out_channel:out_channel+C] -- no torch.cat."""
-    from . import _lib
     w, b = cache.get(conv)
-    with torch.autocast("cuda", enabled=False):
-        y = F.conv2d(x, w, None, stride=conv.stride, padding=conv.padding)
-    if not y.is_contiguous(memory_format=torch.channels_last):
-        y = y.contiguous(memory_format=torch.channels_last)
-    n, c, h, wd = y.shape
-    dst, ldy, off = (y, c, 0) if out is None else (out, out.shape[1], out_channel)
-    rc = _lib.lib().gs_bias_act(_lib.ptr(y), _lib.ptr(b), dst.data_ptr() + 2 * off, n * h * wd, c, ldy, _ACT[act],
-                                _lib.stream_ptr(y.device))
-    _lib.check(rc, "conv_bias_act")
-    return y if out is None else out
+    y = conv_nobias(x, w, conv.stride, conv.padding)
+    return bias_act(y, b, act, out, out_channel)
 
 
 def copy_channels(x, out, out_channel):
     """out[:, out_channel:out_channel+C] = x for NHWC fp16 tensors (strided 16-byte copies)."""
-    from . import _lib
-    n, c, h, wd = x.shape
-    rc = _lib.lib().gs_bias_act(_lib.ptr(x), None, out.data_ptr() + 2 * out_channel, n * h * wd, c, out.shape[1], 0,
-                                _lib.stream_ptr(x.device))
-    _lib.check(rc, "copy_channels")
+    bias_act(x, None, "none", out, out_channel)
 
 
 class ConvGRU(nn.Module):
@@ -155,6 +163,14 @@ class ConvGRU(nn.Module):
             glo = [m.weight.detach().half().reshape(128, 128).contiguous()
                    for m in (self.convz_glo, self.convr_glo, self.convq_glo)]
             glo += [m.bias.detach().float().contiguous() for m in (self.convz_glo, self.convr_glo, self.convq_glo)]
+            # hoisted form: the z|r|q convolutions split into the part over the constant context
+            # features inp (input channels 128:256 -> one 128->384 conv, run once per edge set) and the
+            # part over [net | corr | flow] (320 input channels, run every update)
+            keep = list(range(0, 128)) + list(range(256, self.convz.weight.shape[1]))
+            w_all = torch.cat([self.convz.weight, self.convr.weight, self.convq.weight], 0).detach()
+            self._hw_hoist = (w_all[:, 128:256].half().contiguous(memory_format=cl),
+                              w_all[:256][:, keep].half().contiguous(memory_format=cl),
+                              w_all[256:][:, keep].half().contiguous(memory_format=cl))
             self._hw, self._hw_key = (wzr, wq, bzr, bq, ww, bw, glo), key
         return self._hw
 
@@ -166,13 +182,24 @@ class ConvGRU(nn.Module):
             hx = hx.contiguous(memory_format=torch.channels_last)
         return self.forward_hx(net, hx)
 
-    def forward_hx(self, net, hx):
+    def inp_gates(self, inp):
+        """[n,384,h,w] fp16 NHWC: the z | r | q convolutions restricted to the context features (bias-free).
+        By linearity conv(W, [net|inp|corr|flow]) = conv(W_inp, inp) + conv(W_rest, [net|corr|flow]); inp
+        is constant while an edge lives, so this term is computed once per edge set instead of in
+        every update (2 x 28.6 % of the GRU's convolution FLOPs)."""
+        self._half_weights()
+        return conv_nobias(inp, self._hw_hoist[0], padding=1)
+
+    def forward_hx(self, net, hx, inp_pre=None):
         """GRU step given hx = [net | inputs] already laid out as one NHWC fp16 tensor.  hx[:, :128] is
-        overwritten with r*net (the q-convolution's input)."""
+        overwritten with r*net (the q-convolution's input).  With `inp_pre` (= inp_gates(inp)) hx is
+        [net | corr | flow] and the context-feature term is added inside the gate kernels."""
         from . import _lib
         b, c, h, w = net.shape
         hw = h * w
         wzr, wq, bzr, bq, ww, bw, gw = self._half_weights()
+        if inp_pre is not None:
+            wzr, wq = self._hw_hoist[1], self._hw_hoist[2]
         L = _lib.lib()
         st = _lib.stream_ptr(net.device)
         dev = net.device
@@ -186,12 +213,12 @@ class ConvGRU(nn.Module):
                                     _lib.ptr(gzr), _lib.ptr(gq), b, hw, _lib.ptr(ws), ws.numel(), st), "gru_glo")
             zr_pre = F.conv2d(hx, wzr, None, padding=1)
             z = torch.empty_like(net)
-            _lib.check(L.gs_gru_gate_zr(_lib.ptr(zr_pre), _lib.ptr(bzr), _lib.ptr(gzr), _lib.ptr(hx), _lib.ptr(z),
-                                        b, hw, hx.shape[1], st), "gru_gate_zr")
+            _lib.check(L.gs_gru_gate_zr(_lib.ptr(zr_pre), _lib.ptr(bzr), _lib.ptr(gzr), _lib.ptr(inp_pre), _lib.ptr(hx),
+                                        _lib.ptr(z), b, hw, hx.shape[1], st), "gru_gate_zr")
             q_pre = F.conv2d(hx, wq, None, padding=1)
             out = torch.empty_like(net)
-            _lib.check(L.gs_gru_gate_q(_lib.ptr(q_pre), _lib.ptr(bq), _lib.ptr(gq), _lib.ptr(z), _lib.ptr(net),
-                                       _lib.ptr(out), b, hw, st), "gru_gate_q")
+            _lib.check(L.gs_gru_gate_q(_lib.ptr(q_pre), _lib.ptr(bq), _lib.ptr(gq), _lib.ptr(inp_pre), _lib.ptr(z),
+                                       _lib.ptr(net), _lib.ptr(out), b, hw, st), "gru_gate_q")
         return out
 
     def forward(self, net, *inputs):
@@ -253,29 +280,46 @@ class UpdateModule(nn.Module):
         self.fuse_epilogues = True      # inference fast path: bias-free convs + fused HIP epilogues
         self._hw = _HalfWeights()
 
-    def _hx_buffer(self, inp, n, ht, wd):
-        """The GRU's 448-channel NHWC input [net | inp | corr | flow].  Kept across calls; the inp slice
-        is rewritten only when `inp` is a different tensor (or was modified) -- in the factor graph it
-        changes only when edges are added or removed."""
+    def drop_edge_caches(self):
+        """Forget what is cached per edge set (the hoisted context-feature convolutions).  Happens by
+        itself when `inp` is a different tensor; callers that reuse one tensor object can force it."""
+        self._inp_tag = None
+
+    def _edge_state(self, inp, n, ht, wd):
+        """(hx, inp_pre): the GRU's per-update input buffer [net | corr | flow] (320 ch, NHWC fp16) and
+        the hoisted z|r|q convolutions over `inp`, recomputed only when `inp` is a different tensor or
+        was written to -- in the factor graph that is when edges are added or removed."""
         import weakref
         hx = getattr(self, "_hx", None)
         if hx is None or hx.shape[0] != n or hx.shape[2:] != (ht, wd) or hx.device != inp.device:
-            hx = torch.empty((n, 448, ht, wd), dtype=torch.float16, device=inp.device,
+            hx = torch.empty((n, 320, ht, wd), dtype=torch.float16, device=inp.device,
                              memory_format=torch.channels_last)
-            self._hx, self._hx_inp = hx, None
-        tag = self._hx_inp
+            self._hx, self._inp_tag = hx, None
+        tag = getattr(self, "_inp_tag", None)
         if tag is None or tag[0]() is not inp or tag[1] != inp._version:
             inp4 = inp.view(n, -1, ht, wd)
             if inp4.dtype != torch.float16 or not inp4.is_contiguous(memory_format=torch.channels_last):
                 inp4 = inp4.half().contiguous(memory_format=torch.channels_last)
-            copy_channels(inp4, hx, 128)
-            self._hx_inp = (weakref.ref(inp), inp._version)
-        return hx
+            self._inp_pre = self.gru.inp_gates(inp4)
+            self._inp_tag = (weakref.ref(inp), inp._version)
+        return hx, self._inp_pre
+
+    def _head_weights(self):
+        """delta[0] | weight[0] | agg.conv1 read the same tensor: one 128->384 convolution."""
+        mods = (self.delta[0], self.weight[0], self.agg.conv1)
+        key = tuple(m.weight._version for m in mods) + tuple(m.bias._version for m in mods) + \
+            (mods[0].weight.device, mods[0].weight.data_ptr())
+        if getattr(self, "_heads_key", None) != key:
+            w = torch.cat([m.weight for m in mods], 0).detach().half().contiguous(memory_format=torch.channels_last)
+            b = [m.bias.detach().float().contiguous() for m in mods]
+            self._heads, self._heads_key = (w, b), key
+        return self._heads
 
     def _forward_fast(self, net, inp, corr, flow, ii, jj, seg=None):
-        """forward() with every 128/64-channel convolution run bias-free on MIOpen and its
-        bias + activation applied by one HIP pass that also writes the encoder outputs straight into
-        the GRU's 448-channel input (no torch.cat); same mathematics, fp16 NHWC throughout."""
+        """forward() on the inference path: bias-free MIOpen convolutions, each followed by one HIP
+        epilogue (bias + activation, written straight into the next consumer's buffer -- no torch.cat),
+        the context-feature part of the GRU convolutions hoisted out of the update loop, the three
+        128->128 head convolutions merged into one; same mathematics, fp16 NHWC throughout."""
         batch, num, ch, ht, wd = net.shape
         cl = torch.channels_last
         hwc = self._hw
@@ -286,23 +330,26 @@ class UpdateModule(nn.Module):
         if flow is None:
             flow = torch.zeros(batch, num, 4, ht, wd, device=net.device)
         f4 = flow.view(n, -1, ht, wd).half().contiguous(memory_format=cl)
-        hx = self._hx_buffer(inp, n, ht, wd)
+        hx, inp_pre = self._edge_state(inp, n, ht, wd)
         copy_channels(net4, hx, 0)
         c4 = conv_bias_act(hwc, self.corr_encoder[0], c4, "relu")
-        conv_bias_act(hwc, self.corr_encoder[2], c4, "relu", out=hx, out_channel=256)
+        conv_bias_act(hwc, self.corr_encoder[2], c4, "relu", out=hx, out_channel=128)
         f4 = conv_bias_act(hwc, self.flow_encoder[0], f4, "relu")
-        conv_bias_act(hwc, self.flow_encoder[2], f4, "relu", out=hx, out_channel=384)
-        net4 = self.gru.forward_hx(net4, hx)
-        d = conv_bias_act(hwc, self.delta[0], net4, "relu")
-        delta = self.delta[2](d).view(*out_dim).permute(0, 1, 3, 4, 2)[..., :2].contiguous()
-        wgt = conv_bias_act(hwc, self.weight[0], net4, "relu")
-        weight = torch.sigmoid(self.weight[2](wgt)).view(*out_dim).permute(0, 1, 3, 4, 2)[..., :2].contiguous()
+        conv_bias_act(hwc, self.flow_encoder[2], f4, "relu", out=hx, out_channel=256)
+        net4 = self.gru.forward_hx(net4, hx, inp_pre)
         net = net4.view(*out_dim)
+        hw_, hb = self._head_weights()
+        heads = conv_nobias(net4, hw_ if ii is not None else hw_[:256], padding=1)
+        mk = lambda: torch.empty_like(net4)
+        d = bias_act(heads, hb[0], "relu", out=mk(), in_channel=0, channels=128)
+        wgt = bias_act(heads, hb[1], "relu", out=mk(), in_channel=128, channels=128)
+        delta = self.delta[2](d).view(*out_dim).permute(0, 1, 3, 4, 2)[..., :2].contiguous()
+        weight = torch.sigmoid(self.weight[2](wgt)).view(*out_dim).permute(0, 1, 3, 4, 2)[..., :2].contiguous()
         if ii is None:
             return net, delta, weight
         # GraphAgg (src/droid_net.py:49-67)
         agg = self.agg
-        x = conv_bias_act(hwc, agg.conv1, net4, "relu")
+        x = bias_act(heads, hb[2], "relu", out=mk(), in_channel=256, channels=128)
         if seg is None:
             seg = build_segments(ii.to(net.device))
         x = segment_mean_hip(x, seg)

@@ -61,7 +61,8 @@ class FactorGraph:
         a0 = max(1, int(ii_c.min()) + 1) if t0 is None else t0
         a0 = max(1, a0)
         a1 = (max(int(ii_c.max()), int(jj_c.max())) + 1) if t1 is None else t1
-        c = {"key": key, "tens": tens, "t0": a0, "t1": a1, "seg": build_segments(self.ii), "sel": None}
+        seg = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in build_segments(ii_c).items()}
+        c = {"key": key, "tens": tens, "t0": a0, "t1": a1, "seg": seg, "sel": None}
         ii_all = ii_c
         if use_inactive:
             iin, jin = self.ii_inac.cpu(), self.jj_inac.cpu()

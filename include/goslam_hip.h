@@ -118,18 +118,21 @@ int gs_depth_filter(const float* poses, const float* disps, const float* intrins
  *   glo_zr f32 [n,256] (the 1x1 global-context terms), hx f16 [n,hw,ldx] whose first 128 channels
  *   hold `net` on entry and r*net on exit, z_out f16 [n,hw,128].
  * gs_gru_gate_q : q_pre f16 [n,hw,128] (convq output without bias), bias_q f32 [128], glo_q f32
- *   [n,128], z / net f16 [n,hw,128] -> net_out = (1-z)*net + z*tanh(q_pre + bias + glo).         */
-int gs_gru_gate_zr(const void* zr_pre, const float* bias_zr, const float* glo_zr, void* hx, void* z_out,
-                   int n, int hw, int ldx, gs_stream_t stream);
-int gs_gru_gate_q(const void* q_pre, const float* bias_q, const float* glo_q, const void* z,
+ *   [n,128], z / net f16 [n,hw,128] -> net_out = (1-z)*net + z*tanh(q_pre + bias + glo).
+ * inp_pre (may be NULL): f16 [n,hw,384] = the z | r | q convolutions restricted to the context
+ *   features `inp`, which are constant while an edge lives; by linearity they are hoisted out of the
+ *   update loop and added to the pre-activations here (zr_pre / q_pre then cover net, corr, flow).  */
+int gs_gru_gate_zr(const void* zr_pre, const float* bias_zr, const float* glo_zr, const void* inp_pre, void* hx,
+                   void* z_out, int n, int hw, int ldx, gs_stream_t stream);
+int gs_gru_gate_q(const void* q_pre, const float* bias_q, const float* glo_q, const void* inp_pre, const void* z,
                   const void* net, void* net_out, int n, int hw, gs_stream_t stream);
-/* y[row, 0:channels] = act(x[row, :] + bias) for NHWC fp16 data viewed as [rows, channels]
- * (channels % 8 == 0); y rows are y_stride elements apart, so y may be x itself (in place,
- * y_stride == channels) or a channel slice of a wider NHWC tensor (replaces torch.cat).  bias may be
+/* y[row, 0:channels] = act(x[row, 0:channels] + bias) for NHWC fp16 data viewed as [rows, channels]
+ * (channels % 8 == 0); x / y rows are x_stride / y_stride elements apart, so y may be x itself (in
+ * place) and either side may be a channel slice of a wider NHWC tensor (replaces torch.cat / split).  bias may be
  * NULL (plain strided copy when act == 0).  act: 0 none, 1 ReLU, 2 sigmoid.
  * Epilogue of the bias-free MIOpen convolutions of src/droid_net.py:69-140.                       */
-int gs_bias_act(const void* x, const float* bias, void* y, int rows, int channels, int y_stride, int act,
-                gs_stream_t stream);
+int gs_bias_act(const void* x, const float* bias, void* y, int rows, int channels, int x_stride, int y_stride,
+                int act, gs_stream_t stream);
 /* GraphAgg's scatter_mean over source keyframes (src/droid_net.py:57-60, torch_scatter):
  * out[s, :] = mean over k in [seg_offsets[s], seg_offsets[s+1]) of x[seg_edges[k], :], fp16 rows of
  * row_elems (= h*w*C, % 8 == 0) elements, fp32 accumulation.                                       */

@@ -195,9 +195,16 @@ def test_bias_act_into_channel_slice(built_lib):
     x = torch.randn(3, 64, 5, 7, device=dev).half().contiguous(memory_format=cl)
     b = torch.randn(64, device=dev)
     out = torch.full((3, 160, 5, 7), 7.0, device=dev).half().contiguous(memory_format=cl)
-    rc = _lib.lib().gs_bias_act(_lib.ptr(x), _lib.ptr(b), out.data_ptr() + 2 * 32, 3 * 35, 64, 160, 1,
+    rc = _lib.lib().gs_bias_act(_lib.ptr(x), _lib.ptr(b), out.data_ptr() + 2 * 32, 3 * 35, 64, 64, 160, 1,
                                 _lib.stream_ptr(dev))
     _lib.check(rc, "bias_act")
     ref = torch.relu(x.float() + b.view(1, -1, 1, 1)).half()
     assert torch.equal(out[:, 32:96], ref)
     assert bool((out[:, :32] == 7).all()) and bool((out[:, 96:] == 7).all())
+    # strided source: channels 96:160 of `out` (all 7) -> sigmoid(7 + b) into a dense tensor
+    dense = torch.empty(3, 64, 5, 7, device=dev, dtype=torch.float16).contiguous(memory_format=cl)
+    rc = _lib.lib().gs_bias_act(out.data_ptr() + 2 * 96, _lib.ptr(b), _lib.ptr(dense), 3 * 35, 64, 160, 64, 2,
+                                _lib.stream_ptr(dev))
+    _lib.check(rc, "bias_act")
+    ref2 = torch.sigmoid(7.0 + b).half().view(1, -1, 1, 1).expand(3, 64, 5, 7)
+    torch.testing.assert_close(dense.float(), ref2.float(), rtol=2e-3, atol=1e-3)

@@ -284,6 +284,16 @@ def test_ba_large_window_blocked_cholesky(db, O, dev):
     torch.testing.assert_close(dg, do, rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("num_kf", [23, 33])
+def test_ba_single_launch_cholesky_limits(db, O, dev, num_kf):
+    """6P = 132 (not a panel multiple) and 6P = 192 (the LDS-resident path's cap: 151 KB of LDS)."""
+    prob = _ba_problem(O, num_kf, 5 * num_kf, "tiny", seed=41)
+    ref, (po, do), out, (pg, dg) = _run_ba_pair(db, O, dev, prob, 2, 1e-4, 0.1, False)
+    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=2e-3, atol=5e-6)
+    torch.testing.assert_close(pg, po, rtol=0, atol=2e-5)
+    torch.testing.assert_close(dg, do, rtol=0, atol=2e-5)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_altcorr_forward_matches_oracle(db, O, dev, dtype):
     """droid_backends.altcorr_forward vs the restatement of altcorr_kernel.cu:27-149: windows
