@@ -35,7 +35,8 @@ SIGNATURES = {
     "gs_depth_filter": (c_int, [_P] * 6 + [c_int] * 4 + [_P]),
     "gs_cvx_upsample": (c_int, [_P] * 4 + [c_int] * 4 + [_P]),
     "gs_bias_act": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "gs_segment_mean": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "gs_conv3x3_head": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_float, _P, c_int, c_int, c_int, _P]),
+    "gs_segment_mean": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gs_gru_glo_workspace_bytes": (c_size_t, [c_int]),
     "gs_gru_glo": (c_int, [_P] * 11 + [c_int, c_int, _P, c_size_t, _P]),
     "gs_gru_gate_zr": (c_int, [_P] * 6 + [c_int] * 3 + [_P]),

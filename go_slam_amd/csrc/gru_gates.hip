@@ -136,20 +136,35 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const _Float16* __restric
   *reinterpret_cast<half8*>(y + row * ldy + c8 * 8) = v;
 }
 
-// mean over the edges of each segment (GraphAgg's scatter_mean over source keyframes), CSR form
-__global__ __launch_bounds__(256) void segment_mean_kernel(const _Float16* __restrict__ x, const int* __restrict__ off,
-                                                           const int* __restrict__ edges, _Float16* __restrict__ out,
-                                                           int row8 /* row_elems/8 */, size_t total) {
+// mean over the edges of each segment (GraphAgg's scatter_mean over source keyframes), CSR form;
+// optionally applies the producer convolution's bias + ReLU on the fly and reads a channel slice
+__global__ __launch_bounds__(256) void segment_mean_kernel(const _Float16* __restrict__ x, int ldx,
+                                                           const float* __restrict__ in_bias, int in_relu,
+                                                           const int* __restrict__ off, const int* __restrict__ edges,
+                                                           _Float16* __restrict__ out, int hw, int c8n, size_t total) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= total) return;
-  const int seg = (int)(t / row8);
-  const int col = (int)(t % row8);
+  const int c8 = (int)(t % c8n);
+  const size_t sp = t / c8n;                 // seg * hw + p
+  const int seg = (int)(sp / hw);
+  const int p = (int)(sp - (size_t)seg * hw);
   const int b = off[seg], e = off[seg + 1];
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int k = b; k < e; ++k) {
-    const half8 v = reinterpret_cast<const half8*>(x)[(size_t)edges[k] * row8 + col];
+  float bias[8], acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+  for (int j = 0; j < 8; ++j) { bias[j] = in_bias ? in_bias[c8 * 8 + j] : 0.0f; acc[j] = 0.0f; }
+  const bool touch = (in_bias != nullptr) || in_relu;
+  for (int k = b; k < e; ++k) {
+    const half8 v = *reinterpret_cast<const half8*>(x + ((size_t)edges[k] * hw + p) * ldx + c8 * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = (float)v[j];
+      if (touch) {
+        f += bias[j];
+        if (in_relu) f = fmaxf(f, 0.0f);
+        f = (float)(_Float16)f;              // the activation the reference materialises in fp16
+      }
+      acc[j] += f;
+    }
   }
   const float inv = e > b ? 1.0f / (float)(e - b) : 0.0f;
   half8 o;
@@ -242,14 +257,15 @@ extern "C" int gs_bias_act(const void* x, const float* bias, void* y, int rows, 
   return GS_OK;
 }
 
-extern "C" int gs_segment_mean(const void* x, const int* seg_offsets, const int* seg_edges, void* out, int n_seg,
-                               int row_elems, gs_stream_t stream) {
+extern "C" int gs_segment_mean(const void* x, int x_stride, const float* in_bias, int in_relu, const int* seg_offsets,
+                               const int* seg_edges, void* out, int n_seg, int hw, int channels, gs_stream_t stream) {
   GS_REQUIRE(x && seg_offsets && seg_edges && out, "segment_mean: null pointer");
-  GS_REQUIRE(n_seg >= 0 && row_elems > 0 && row_elems % 8 == 0, "segment_mean: row_elems must be a multiple of 8");
+  GS_REQUIRE(n_seg >= 0 && hw > 0 && channels > 0 && channels % 8 == 0, "segment_mean: channels must be a multiple of 8");
+  GS_REQUIRE(x_stride >= channels && x_stride % 8 == 0, "segment_mean: x_stride must be >= channels, multiple of 8");
   if (n_seg == 0) return GS_OK;
-  const size_t total = (size_t)n_seg * (row_elems / 8);
+  const size_t total = (size_t)n_seg * hw * (channels / 8);
   segment_mean_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-      (const _Float16*)x, seg_offsets, seg_edges, (_Float16*)out, row_elems / 8, total);
+      (const _Float16*)x, x_stride, in_bias, in_relu, seg_offsets, seg_edges, (_Float16*)out, hw, channels / 8, total);
   GS_CHECK_LAUNCH("segment_mean");
   return GS_OK;
 }

@@ -48,15 +48,53 @@ def build_segments(index):
     return {"uniq": uniq, "ix": ix, "offsets": offsets, "order": order.contiguous(), "n": int(uniq.numel())}
 
 
-def segment_mean_hip(x, seg):
+def segment_mean_hip(x, seg, in_channel=0, channels=None, in_bias=None, in_relu=False):
     """scatter_mean over source keyframes for NHWC fp16 x [E,C,h,w] through gs_segment_mean (one
-    HBM-bound pass: reads x once, writes the means)."""
+    HBM-bound pass: reads x once, writes the means).  Optionally reads the channel slice
+    [in_channel, in_channel+channels) and applies relu(x + in_bias) on the fly."""
     from . import _lib
     E, C, h, w = x.shape
-    out = torch.empty((seg["n"], C, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-    rc = _lib.lib().gs_segment_mean(_lib.ptr(x), _lib.ptr(seg["offsets"]), _lib.ptr(seg["order"]), _lib.ptr(out),
-                                    seg["n"], C * h * w, _lib.stream_ptr(x.device))
+    c = C - in_channel if channels is None else channels
+    out = torch.empty((seg["n"], c, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    rc = _lib.lib().gs_segment_mean(x.data_ptr() + 2 * in_channel, C, _lib.ptr(in_bias), int(in_relu),
+                                    _lib.ptr(seg["offsets"]), _lib.ptr(seg["order"]), _lib.ptr(out),
+                                    seg["n"], h * w, c, _lib.stream_ptr(x.device))
     _lib.check(rc, "segment_mean")
+    return out
+
+
+def pack_head_weight(weight):
+    """MFMA A-fragments for gs_conv3x3_head from a [O,128,3,3] convolution weight: fp16 [8,64,8] with
+    wpack[ks][l][e] = W[o][16 ks + 8 (l>>5) + e][ky][kx], (l & 31) = (3 ky + kx) O + o."""
+    O = weight.shape[0]
+    assert weight.shape[1:] == (128, 3, 3) and O in (1, 2)
+    w = weight.detach().float()
+    pack = torch.zeros(8, 64, 8, dtype=torch.float32, device=w.device)
+    cols = w.permute(2, 3, 0, 1).reshape(9 * O, 128)                 # [(ky,kx,o), ch]
+    full = torch.zeros(32, 128, device=w.device)
+    full[:9 * O] = cols
+    full = full.view(32, 8, 2, 8)                                     # [col, ks, half, e]
+    pack = full.permute(1, 2, 0, 3).reshape(8, 64, 8)                 # lane = half*32 + col
+    return pack.half().contiguous()
+
+
+def conv3x3_head(x, conv, cache, epilogue="none", out_scale=1.0, in_channel=0, in_bias=None, in_relu=False):
+    """epi(conv(relu?(x[:, in_channel:in_channel+128] + in_bias)) + bias) * out_scale -> fp32 [n,h,w,O]
+    (values are the reference's fp16 results), one HIP launch (gs_conv3x3_head)."""
+    from . import _lib
+    key = (conv.weight._version, conv.bias._version, conv.weight.device, conv.weight.data_ptr())
+    hit = cache.get(id(conv))
+    if hit is None or hit[0] != key:
+        hit = (key, pack_head_weight(conv.weight), conv.bias.detach().float().contiguous())
+        cache[id(conv)] = hit
+    n, C, h, w = x.shape
+    O = conv.weight.shape[0]
+    out = torch.empty(n, h, w, O, dtype=torch.float32, device=x.device)
+    epi = {"none": 0, "sigmoid": 1, "softplus": 2}[epilogue]
+    rc = _lib.lib().gs_conv3x3_head(x.data_ptr() + 2 * in_channel, C, _lib.ptr(in_bias), int(in_relu),
+                                    _lib.ptr(hit[1]), _lib.ptr(hit[2]), O, epi, float(out_scale), _lib.ptr(out),
+                                    n, h, w, _lib.stream_ptr(x.device))
+    _lib.check(rc, "conv3x3_head")
     return out
 
 
@@ -279,6 +317,7 @@ class UpdateModule(nn.Module):
         self.agg = GraphAgg()
         self.fuse_epilogues = True      # inference fast path: bias-free convs + fused HIP epilogues
         self._hw = _HalfWeights()
+        self._head_cache = {}
 
     def drop_edge_caches(self):
         """Forget what is cached per edge set (the hoisted context-feature convolutions).  Happens by
@@ -340,23 +379,22 @@ class UpdateModule(nn.Module):
         net = net4.view(*out_dim)
         hw_, hb = self._head_weights()
         heads = conv_nobias(net4, hw_ if ii is not None else hw_[:256], padding=1)
-        mk = lambda: torch.empty_like(net4)
-        d = bias_act(heads, hb[0], "relu", out=mk(), in_channel=0, channels=128)
-        wgt = bias_act(heads, hb[1], "relu", out=mk(), in_channel=128, channels=128)
-        delta = self.delta[2](d).view(*out_dim).permute(0, 1, 3, 4, 2)[..., :2].contiguous()
-        weight = torch.sigmoid(self.weight[2](wgt)).view(*out_dim).permute(0, 1, 3, 4, 2)[..., :2].contiguous()
+        hc = self._head_cache
+        # delta[2] / weight[2] read the merged convolution's pre-activations directly (bias + ReLU on the fly)
+        delta = conv3x3_head(heads, self.delta[2], hc, "none", in_channel=0, in_bias=hb[0], in_relu=True)
+        weight = conv3x3_head(heads, self.weight[2], hc, "sigmoid", in_channel=128, in_bias=hb[1], in_relu=True)
+        delta, weight = delta.view(batch, num, ht, wd, 2), weight.view(batch, num, ht, wd, 2)
         if ii is None:
             return net, delta, weight
         # GraphAgg (src/droid_net.py:49-67)
         agg = self.agg
-        x = bias_act(heads, hb[2], "relu", out=mk(), in_channel=256, channels=128)
         if seg is None:
             seg = build_segments(ii.to(net.device))
-        x = segment_mean_hip(x, seg)
+        x = segment_mean_hip(heads, seg, in_channel=256, channels=128, in_bias=hb[2], in_relu=True)
         x = conv_bias_act(hwc, agg.conv2, x, "relu")
-        eta = agg.eta(x).view(batch, -1, ht, wd)
+        eta = conv3x3_head(x, agg.eta[0], hc, "softplus", out_scale=0.01).view(batch, -1, ht, wd)
         upmask = conv_bias_act(hwc, agg.upmask[0], x, "none").view(batch, -1, 8 * 8 * 9, ht, wd)
-        return net, delta, weight, 0.01 * eta, upmask
+        return net, delta, weight, eta, upmask
 
     def _fast_ok(self, net, inp, corr):
         cl = torch.channels_last

@@ -133,11 +133,24 @@ int gs_gru_gate_q(const void* q_pre, const float* bias_q, const float* glo_q, co
  * Epilogue of the bias-free MIOpen convolutions of src/droid_net.py:69-140.                       */
 int gs_bias_act(const void* x, const float* bias, void* y, int rows, int channels, int x_stride, int y_stride,
                 int act, gs_stream_t stream);
+/* 3x3 convolution (padding 1) from 128 channels to n_out in {1,2} channels, NHWC fp16 in, fp32 out
+ * [n,h,w,n_out]: the flow-revision / confidence heads delta[2], weight[2] (src/droid_net.py:83-92) and
+ * GraphAgg's eta[0] (src/droid_net.py:43).  x rows are x_stride elements apart (a channel slice of a
+ * wider tensor is fine).  If in_bias != NULL or in_relu, the operand is relu?(x + in_bias) applied on
+ * the fly (the producer convolution's epilogue).  wpack: fp16 [8][64][8] MFMA A-fragments,
+ * wpack[ks][l][e] = W[o][16 ks + 8 (l>>5) + e][ky][kx] with (l & 31) = (3 ky + kx) n_out + o (0 beyond
+ * 9 n_out).  out = out_scale * epi(half(conv + bias)); epilogue: 0 none, 1 sigmoid (rounded to fp16),
+ * 2 softplus (fp32).                                                                              */
+int gs_conv3x3_head(const void* x, int x_stride, const float* in_bias, int in_relu, const void* wpack,
+                    const float* bias, int n_out, int epilogue, float out_scale, float* out, int n, int h, int w,
+                    gs_stream_t stream);
 /* GraphAgg's scatter_mean over source keyframes (src/droid_net.py:57-60, torch_scatter):
- * out[s, :] = mean over k in [seg_offsets[s], seg_offsets[s+1]) of x[seg_edges[k], :], fp16 rows of
- * row_elems (= h*w*C, % 8 == 0) elements, fp32 accumulation.                                       */
-int gs_segment_mean(const void* x, const int* seg_offsets, const int* seg_edges, void* out, int n_seg,
-                    int row_elems, gs_stream_t stream);
+ * out[s, p, :] = mean over k in [seg_offsets[s], seg_offsets[s+1]) of act(x[seg_edges[k], p, :]), NHWC
+ * fp16 [*, hw, channels] (channels % 8 == 0, x rows x_stride elements apart), fp32 accumulation.
+ * act = relu?(. + in_bias) rounded to fp16 when in_bias != NULL or in_relu (the producer
+ * convolution's epilogue applied on the fly), identity otherwise.                                   */
+int gs_segment_mean(const void* x, int x_stride, const float* in_bias, int in_relu, const int* seg_offsets,
+                    const int* seg_edges, void* out, int n_seg, int hw, int channels, gs_stream_t stream);
 /* ConvGRU global context (src/modules/gru.py:22-27): glo = mean_hw(sigmoid(w_pre + w_bias) * net),
  * then the three 1x1 convolutions convz_glo | convr_glo (-> gzr [n,256]) and convq_glo (-> gq [n,128]).
  * w_pre = bias-free 1x1 conv of net, NHWC fp16 [n,hw,128]; wz/wr/wq fp16 [128 out,128 in]; outputs f32

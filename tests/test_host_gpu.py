@@ -165,6 +165,15 @@ def test_segment_mean_and_glo_kernels(built_lib):
     ref.index_add_(0, seg["ix"], x.float())
     ref /= torch.bincount(seg["ix"]).float().view(-1, 1, 1, 1)
     torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=1e-3)
+    # channel slice + producer bias/ReLU applied on the fly
+    wide = torch.randn(E, 256, h, w, device=dev).half().contiguous(memory_format=cl)
+    bias = torch.randn(64, device=dev)
+    out2 = segment_mean_hip(wide, seg, in_channel=64, channels=64, in_bias=bias, in_relu=True)
+    act = torch.relu(wide[:, 64:128].float() + bias.view(1, -1, 1, 1)).half().float()
+    ref2 = torch.zeros(seg["n"], 64, h, w, device=dev)
+    ref2.index_add_(0, seg["ix"], act)
+    ref2 /= torch.bincount(seg["ix"]).float().view(-1, 1, 1, 1)
+    torch.testing.assert_close(out2.float(), ref2, rtol=2e-3, atol=1e-3)
     assert torch.equal(seg["uniq"], torch.unique(ii))
 
     gru = ConvGRU(128, 320).to(dev).eval()
@@ -208,3 +217,34 @@ def test_bias_act_into_channel_slice(built_lib):
     _lib.check(rc, "bias_act")
     ref2 = torch.sigmoid(7.0 + b).half().view(1, -1, 1, 1).expand(3, 64, 5, 7)
     torch.testing.assert_close(dense.float(), ref2.float(), rtol=2e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("n_out,epi", [(2, "none"), (2, "sigmoid"), (1, "softplus")])
+def test_conv3x3_head_kernel(built_lib, n_out, epi):
+    """gs_conv3x3_head (MFMA tap products + LDS gather) vs F.conv2d on relu(x + b), odd sizes, channel slice."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from go_slam_amd.droid_net import conv3x3_head
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    cl = torch.channels_last
+    n, h, w = 3, 13, 21                       # 13 rows: 3 row tiles, the last one short
+    x = torch.randn(n, 384, h, w, device=dev).half().contiguous(memory_format=cl)
+    b_in = torch.randn(128, device=dev) * 0.5
+    conv = nn.Conv2d(128, n_out, 3, padding=1).to(dev)
+    got = conv3x3_head(x, conv, {}, epi, out_scale=0.01 if epi == "softplus" else 1.0, in_channel=128,
+                       in_bias=b_in, in_relu=True)
+    act = torch.relu(x[:, 128:256].float() + b_in.view(1, -1, 1, 1)).half().float()
+    ref = F.conv2d(act, conv.weight.half().float(), conv.bias.float(), padding=1).half().float()
+    if epi == "sigmoid":
+        ref = torch.sigmoid(ref).half().float()
+    elif epi == "softplus":
+        ref = 0.01 * F.softplus(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    assert got.shape == ref.shape
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3 if epi != "softplus" else 2e-5)
+    # plain operand (no producer epilogue), dense 128-channel input
+    x2 = torch.randn(2, 128, 7, 9, device=dev).half().contiguous(memory_format=cl)
+    got2 = conv3x3_head(x2, conv, {}, "none")
+    ref2 = F.conv2d(x2.float(), conv.weight.half().float(), conv.bias.float(), padding=1).half().float()
+    torch.testing.assert_close(got2, ref2.permute(0, 2, 3, 1), rtol=2e-3, atol=2e-3)
