@@ -236,15 +236,34 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restric
 // ---- single-launch path for the frontend window (6P <= 192) -------------------------------
 // The multi-kernel path above spends its time in launch-to-launch dependencies: 6P = 150 is 5 panel
 // + 4 trailing launches + the solve, ~230 us for 1.1 MFLOP.  Here ONE workgroup keeps the packed
-// lower triangle (n(n+1)/2 doubles, 90 KB at n = 150; CDNA4's 160 KB LDS holds n <= 192) in LDS
-// and does damping, the blocked factorisation, both substitutions and the failure fallback in one
-// launch; the only global traffic is one read of H and b and the fp32 dx.
+// lower triangle in LDS (90 KB at n = 150; CDNA4's 160 KB holds n <= 192) and does damping, the
+// factorisation, both substitutions and the failure fallback in one launch; the only global traffic
+// is one read of H and b and the fp32 dx.
+//
+// Two-level right-looking factorisation.  Inner step = one camera block (6 pivots): the 6x6 diagonal
+// block is factored REDUNDANTLY by every thread in registers (no broadcast step), each thread solves
+// its own panel row and applies the rank-6 update to that row's remaining columns of the current
+// 30-wide panel only.  Once per panel the rank-30 update of the rest of the matrix runs on 4x4
+// register tiles -- the LDS read-modify-write traffic of the far matrix is paid 5x, not 25x.
+// b rides along as row n of the matrix, so the forward substitution L y = b falls out of the panel
+// steps for free; the backward substitution is column-oriented (x block known -> every remaining
+// y[c] is updated independently, no reductions).
 constexpr int SMALL_N = 192;
+constexpr int CB = 6;      // camera block
+constexpr int SMALL_NT = 1024;   // one workgroup, 16 waves: latency hiding for the LDS-resident steps
+constexpr int PW = 30;     // panel width (5 camera blocks): far updates are deferred per panel
+
 #ifdef CHOL_TIMING   // scratch/chol_bench.hip only: per-phase wall-clock stamps (100 MHz)
 __device__ long long g_chol_t[64];
 #define CHOL_STAMP(i) do { if (threadIdx.x == 0) g_chol_t[i] = wall_clock64(); } while (0)
+#define CHOL_ACC_DECL long long t_acc[5] = {0, 0, 0, 0, 0}; long long t_last = wall_clock64()
+#define CHOL_ACC(i) do { const long long t_now = wall_clock64(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
+#define CHOL_ACC_DUMP do { if (threadIdx.x == 0) for (int q = 0; q < 5; ++q) g_chol_t[10 + q] = t_acc[q]; } while (0)
 #else
 #define CHOL_STAMP(i) do { } while (0)
+#define CHOL_ACC_DECL do { } while (0)
+#define CHOL_ACC(i) do { } while (0)
+#define CHOL_ACC_DUMP do { } while (0)
 #endif
 
 __device__ __forceinline__ int tri(int r, int c) { return ((r * (r + 1)) >> 1) + c; }
@@ -261,136 +280,152 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double& s, double& rs) {
   s = g; rs = h + h;
 }
 
-__global__ __launch_bounds__(256) void chol_small_kernel(const double* __restrict__ H, const double* __restrict__ bg,
+__global__ __launch_bounds__(SMALL_NT) void chol_small_kernel(const double* __restrict__ H, const double* __restrict__ bg,
                                                          int n, double lm, double ep, float* __restrict__ dx,
                                                          int32_t* fail_flag, int32_t* fail_count) {
   extern __shared__ double sm[];
-  double* Lp = sm;                                 // packed lower triangle, row r at r(r+1)/2
-  double* bv = sm + ((n * (n + 1)) >> 1);          // right-hand side / solution
-  double* invd = bv + n;                           // 1 / L[j][j]
-  __shared__ double ys[NB];
-  __shared__ int s_bad;
-  const int tid = threadIdx.x, lane = tid & 63;
-  if (tid == 0) s_bad = 0;
+  double* Lp = sm;                                   // packed lower triangle of [A; b^T], n+1 rows
+  double* invd = sm + (((n + 1) * (n + 2)) >> 1);    // 1 / L[j][j]
+  const int tid = threadIdx.x;
   CHOL_STAMP(0);
-  // lower triangle only, 16 independent loads in flight per thread: a lone workgroup is bound by
-  // global-load latency, not bandwidth (a one-load-per-iteration loop cost ~90 us here)
+  // lower triangle only, 4 independent loads in flight per thread (x 1024 threads): a lone workgroup is bound by
+  // global-load latency, not bandwidth
   const int npk = (n * (n + 1)) >> 1;
-  for (int base = 0; base < npk; base += 256 * 16) {
-    double v[16];
-    int rr[16];
+  for (int base = 0; base < npk; base += SMALL_NT * 4) {
+    double v[4];
+    int dg[4];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = base + u * 256 + tid;
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * SMALL_NT + tid;
       int r = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
       while (((r + 1) * (r + 2)) >> 1 <= idx) ++r;
       while ((r * (r + 1)) >> 1 > idx) --r;
       const int c = idx - ((r * (r + 1)) >> 1);
-      rr[u] = (c == r) ? 1 : 0;
+      dg[u] = (c == r) ? 1 : 0;
       v[u] = idx < npk ? H[(size_t)r * n + c] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = base + u * 256 + tid;
-      if (idx < npk) Lp[idx] = rr[u] ? v[u] + (ep + lm * v[u]) : v[u];
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * SMALL_NT + tid;
+      if (idx < npk) Lp[idx] = dg[u] ? v[u] + (ep + lm * v[u]) : v[u];
     }
   }
-  for (int i = tid; i < n; i += 256) bv[i] = bg[i];
+  for (int i = tid; i <= n; i += SMALL_NT) Lp[npk + i] = (i < n) ? bg[i] : 0.0;    // row n = b^T
   __syncthreads();
   CHOL_STAMP(1);
 
-  for (int k0 = 0; k0 < n; k0 += NB) {
-    const int nb = min(NB, n - k0);
-    const int rem = n - k0 - nb;
-    CHOL_STAMP(2 + 4 * (k0 / NB));
-    // (a) diagonal block: wave 0, register-resident, lane r holds row r
-    if (tid < 64) {
-      const int r = lane & (NB - 1);
-      const bool live = (lane < NB) && (r < nb);
-      double a[NB];
-      const double* Ar = Lp + tri(k0 + (live ? r : 0), k0);
+  __shared__ int s_bad;
+  bool bad = false;                                   // thread 0 takes part in every diagonal block
+  CHOL_ACC_DECL;
+  for (int p0 = 0; p0 < n; p0 += PW) {
+    const int pend = min(p0 + PW, n);                 // panel = columns [p0, pend)
+    for (int k0 = p0; k0 < pend; k0 += CB) {
+      // (1) 6x6 diagonal block, redundantly in every wave that owns panel rows, registers
+      const int s0 = k0 + CB;
+      const int rows = n + 1 - s0;
+      const bool need = tid < ((max(rows, CB) + 63) & ~63);
+      double l[CB][CB], inv[CB];
+      if (need) {
 #pragma unroll
-      for (int c = 0; c < NB; ++c) {
-        double v = (live && c <= r) ? Ar[c] : 0.0;
-        if (!live && c == r) v = 1.0;
-        a[c] = v;
-      }
-      bool bad = false;
-      double my_inv = 1.0;
+        for (int i = 0; i < CB; ++i)
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const double piv = readlane_f64(a[j], j);
-        if (j < nb && !(piv > 0.0) && piv == piv) bad = true;
-        double dj, inv;
-        sqrt_rsqrt(piv, dj, inv);
-        if (lane == j) { a[j] = dj; my_inv = inv; }
-        else if (lane > j) a[j] = a[j] * inv;
+          for (int j = 0; j <= i; ++j) l[i][j] = Lp[tri(k0 + i, k0 + j)];
 #pragma unroll
-        for (int c = j + 1; c < NB; ++c) {
-          const double lcj = readlane_f64(a[j], c);
-          if (lane >= c) a[c] = fma(-a[j], lcj, a[c]);
+        for (int j = 0; j < CB; ++j) {
+          double piv = l[j][j];
+#pragma unroll
+          for (int t = 0; t < j; ++t) piv = fma(-l[j][t], l[j][t], piv);
+          if (!(piv > 0.0) && piv == piv) bad = true; // pivot <= 0 (NaN falls through like Eigen)
+          sqrt_rsqrt(piv, l[j][j], inv[j]);
+#pragma unroll
+          for (int i = j + 1; i < CB; ++i) {
+            double sacc = l[i][j];
+#pragma unroll
+            for (int t = 0; t < j; ++t) sacc = fma(-l[i][t], l[j][t], sacc);
+            l[i][j] = sacc * inv[j];
+          }
         }
       }
-      if (live) {
-        double* Aw = Lp + tri(k0 + r, k0);
+      CHOL_ACC(0);
+      __syncthreads();                                // all reads of the old diagonal block are done
+      if (tid < CB) {
 #pragma unroll
-        for (int c = 0; c < NB; ++c)
-          if (c <= r) Aw[c] = a[c];
-        invd[k0 + r] = my_inv;
+        for (int i = 0; i < CB; ++i)
+          if (i == tid) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) Lp[tri(k0 + i, k0 + j)] = l[i][j];
+            invd[k0 + i] = inv[i];
+          }
       }
-      if (bad && lane == 0) s_bad = 1;
-    }
-    __syncthreads();
-    CHOL_STAMP(3 + 4 * (k0 / NB));
-    // (b) panel rows: L21 = A21 L11^-T, one row per thread
-    if (tid < rem) {
-      double* Ar = Lp + tri(k0 + nb + tid, k0);
-      double x[NB];
+      // (2) panel rows (the b row included): x = a L11^-T, then (3) the rank-6 update of this row's
+      // remaining PANEL columns only; the matrix right of the panel is updated once per panel (4).
+      const int pc = pend - s0;                       // panel columns still to be factored
+      if (tid < rows) {                               // rows <= 187: one thread per row
+        double* Ar = Lp + tri(s0 + tid, k0);
+        double x[CB];
 #pragma unroll
-      for (int c = 0; c < NB; ++c) x[c] = (c < nb) ? Ar[c] : 0.0;
+        for (int j = 0; j < CB; ++j) {
+          double s = Ar[j];
 #pragma unroll
-      for (int c = 0; c < NB; ++c) {
-        if (c < nb) {
-          const double* Dc = Lp + tri(k0 + c, k0);
-          double sacc = x[c];
+          for (int u = 0; u < j; ++u) s = fma(-x[u], l[j][u], s);
+          x[j] = s * inv[j];
+        }
 #pragma unroll
-          for (int t = 0; t < NB; ++t)
-            if (t < c) sacc = fma(-x[t], Dc[t], sacc);
-          x[c] = sacc * invd[k0 + c];
+        for (int j = 0; j < CB; ++j) Ar[j] = x[j];
+      }
+      CHOL_ACC(1);
+      __syncthreads();
+      {                                               // 4 threads per row, columns interleaved
+        const int rq = tid >> 2, q = tid & 3;
+        if (rq < rows && pc > 0) {
+          const int r = s0 + rq;
+          const double* Xr = Lp + tri(r, k0);
+          double x[CB];
+#pragma unroll
+          for (int k = 0; k < CB; ++k) x[k] = Xr[k];
+          double* Ar = Lp + tri(r, s0);
+          const int cmax = min(pc, rq + 1);           // lower triangle: c <= r
+          for (int c = q; c < cmax; c += 4) {
+            const double* Lc = Lp + tri(s0 + c, k0);
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < CB; ++k) acc = fma(x[k], Lc[k], acc);
+            Ar[c] -= acc;
+          }
         }
       }
-#pragma unroll
-      for (int c = 0; c < NB; ++c)
-        if (c < nb) Ar[c] = x[c];
+      CHOL_ACC(2);
+      __syncthreads();
+      CHOL_ACC(3);
     }
-    __syncthreads();
-    CHOL_STAMP(4 + 4 * (k0 / NB));
-    // (c) trailing update A22 -= L21 L21^T on 4x4 register tiles of the lower triangle
-    if (rem > 0) {
-      const int T = (rem + 3) >> 2, ntile = (T * (T + 1)) >> 1;
-      const int s0 = k0 + nb;
-      for (int t = tid; t < ntile; t += 256) {
+    // (4) rank-PW update of everything right of / below the panel, 8x4 register tiles
+    const int s1 = pend;
+    const int rows1 = n + 1 - s1;                     // rows s1..n (b row included)
+    const int pw = pend - p0;
+    if (rows1 > 1) {
+      const int T = (rows1 + 3) >> 2, ntile = (T * (T + 1)) >> 1;
+      for (int t = tid; t < ntile; t += SMALL_NT) {
         int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
         while (((ti + 1) * (ti + 2)) >> 1 <= t) ++ti;
         while ((ti * (ti + 1)) >> 1 > t) --ti;
         const int tj = t - ((ti * (ti + 1)) >> 1);
-        const int r0 = s0 + 4 * ti, c0 = s0 + 4 * tj;
-        const double* pr[4];
-        const double* pc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          pr[i] = Lp + tri(min(r0 + i, n - 1), k0);
-          pc[i] = Lp + tri(min(c0 + i, n - 1), k0);
-        }
+        const int r0 = s1 + 4 * ti, c0 = s1 + 4 * tj;
         double acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-        for (int k = 0; k < nb; ++k) {
+        const double* pr[4];
+        const double* pcn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          pr[i] = Lp + tri(min(r0 + i, n), p0);
+          pcn[i] = Lp + tri(min(c0 + i, n), p0);
+        }
+        for (int k = 0; k < pw; ++k) {
           double a[4], b[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { a[i] = pr[i][k]; b[i] = pc[i][k]; }
+          for (int i = 0; i < 4; ++i) { a[i] = pr[i][k]; b[i] = pcn[i][k]; }
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -398,99 +433,77 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const double* __restric
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int r = r0 + i;
-          if (r >= n) continue;
+          const int rr = r0 + i;
+          if (rr > n) continue;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int c = c0 + j;
-            if (c <= r) Lp[tri(r, c)] -= acc[i][j];
+            if (c > rr || c >= n) continue;           // column n (the b row's own diagonal) is unused
+            Lp[tri(rr, c)] -= acc[i][j];
           }
         }
       }
     }
     __syncthreads();
+    CHOL_ACC(4);
   }
+  CHOL_ACC_DUMP;
+  CHOL_STAMP(2);
 
+  if (tid == 0) s_bad = bad ? 1 : 0;
+  __syncthreads();
   if (s_bad) {   // reference: zero update on failure (droid_kernels.cu:1207-1210)
-    for (int i = tid; i < n; i += 256) dx[i] = 0.0f;
+    for (int i = tid; i < n; i += SMALL_NT) dx[i] = 0.0f;
     if (tid == 0) { *fail_flag = 1; *fail_count += 1; }
     return;
   }
   if (tid == 0) *fail_flag = 0;
-  CHOL_STAMP(40);
 
-  // ---- forward substitution L y = b
-  for (int k0 = 0; k0 < n; k0 += NB) {
-    const int nb = min(NB, n - k0);
-    if (tid < 64) {
-      const int i = lane & (NB - 1);
-      const bool live = (lane < NB) && (i < nb);
-      double a[NB];
-      const double* Lr = Lp + tri(k0 + (live ? i : 0), k0);
+  // ---- backward substitution L^T x = y (y sits in row n), column-oriented, 6 unknowns per step
+  double* y = Lp + npk;
+  for (int k0 = n - CB; k0 >= 0; k0 -= CB) {
+    const bool need = tid < ((max(k0, CB) + 63) & ~63);
+    double x[CB];
+    if (need) {
+      double l[CB][CB];
 #pragma unroll
-      for (int c = 0; c < NB; ++c) a[c] = (live && c < i) ? Lr[c] : 0.0;
-      const double inv_dg = live ? invd[k0 + i] : 1.0;
-      double v = live ? bv[k0 + i] : 0.0;
+      for (int i = 0; i < CB; ++i)
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const double yj = readlane_f64(v * inv_dg, j);
-        if (lane == j) v = yj;
-        else if (lane > j && lane < NB) v = fma(-a[j], yj, v);
+        for (int j = 0; j <= i; ++j) l[i][j] = Lp[tri(k0 + i, k0 + j)];
+#pragma unroll
+      for (int i = CB - 1; i >= 0; --i) {
+        double sacc = y[k0 + i];
+#pragma unroll
+        for (int t = i + 1; t < CB; ++t) sacc = fma(-l[t][i], x[t], sacc);
+        x[i] = sacc * invd[k0 + i];
       }
-      if (lane < NB) ys[lane] = live ? v : 0.0;
-      if (live) bv[k0 + i] = v;
     }
-    __syncthreads();
-    for (int r = k0 + nb + tid; r < n; r += 256) {
-      const double* Lr = Lp + tri(r, k0);
-      double sacc = 0.0;
-      for (int c = 0; c < nb; ++c) sacc = fma(Lr[c], ys[c], sacc);
-      bv[r] -= sacc;
+    __syncthreads();                                  // everyone has read y[k0..k0+5] before it is reused
+    if (tid < CB) {
+#pragma unroll
+      for (int i = 0; i < CB; ++i)
+        if (i == tid) dx[k0 + i] = (float)x[i];
+    }
+    for (int c = tid; c < k0; c += SMALL_NT) {
+      double s = y[c];
+#pragma unroll
+      for (int i = 0; i < CB; ++i) s = fma(-Lp[tri(k0 + i, c)], x[i], s);
+      y[c] = s;
     }
     __syncthreads();
   }
-  CHOL_STAMP(41);
-  // ---- backward substitution L^T x = y
-  const int last = ((n - 1) / NB) * NB;
-  for (int k0 = last; k0 >= 0; k0 -= NB) {
-    const int nb = min(NB, n - k0);
-    if (tid < 64) {
-      const int j = lane & (NB - 1);
-      const bool live = (lane < NB) && (j < nb);
-      double c_[NB];                      // column j of the block: L[k0+i][k0+j], i > j
-#pragma unroll
-      for (int i = 0; i < NB; ++i) c_[i] = (live && i > j && i < nb) ? Lp[tri(k0 + i, k0 + j)] : 0.0;
-      const double inv_dg = live ? invd[k0 + j] : 1.0;
-      double v = live ? bv[k0 + j] : 0.0;
-#pragma unroll
-      for (int i = NB - 1; i >= 0; --i) {
-        const double xi = readlane_f64(v * inv_dg, i);
-        if (lane == i) v = xi;
-        else if (lane < i) v = fma(-c_[i], xi, v);
-      }
-      if (lane < NB) ys[lane] = live ? v : 0.0;
-      if (live) { bv[k0 + j] = v; dx[k0 + j] = (float)v; }
-    }
-    __syncthreads();
-    for (int c = tid; c < k0; c += 256) {
-      double sacc = 0.0;
-      for (int r = 0; r < nb; ++r) sacc = fma(Lp[tri(k0 + r, c)], ys[r], sacc);
-      bv[c] -= sacc;
-    }
-    __syncthreads();
-  }
-  CHOL_STAMP(42);
+  CHOL_STAMP(3);
 }
 
 }  // namespace
 
 int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float* dx_out, int32_t* fail_flag,
                          int32_t* fail_count, hipStream_t st) {
-  if (n <= SMALL_N) {
-    const size_t lds = ((size_t)n * (n + 1) / 2 + 2 * (size_t)n) * sizeof(double);
+  if (n <= SMALL_N && n % CB == 0) {
+    const size_t lds = ((size_t)(n + 1) * (n + 2) / 2 + (size_t)n) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-      const size_t cap = ((size_t)SMALL_N * (SMALL_N + 1) / 2 + 2 * SMALL_N) * sizeof(double);
+      const size_t cap = ((size_t)(SMALL_N + 1) * (SMALL_N + 2) / 2 + SMALL_N) * sizeof(double);
       if (hipFuncSetAttribute((const void*)chol_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)cap) != hipSuccess) {
         gs_set_error("chol: cannot raise the dynamic LDS limit to %zu bytes", cap);
@@ -498,7 +511,7 @@ int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float*
       }
       attr_set = true;
     }
-    chol_small_kernel<<<1, 256, lds, st>>>(H, b, n, (double)lm, (double)ep, dx_out, fail_flag, fail_count);
+    chol_small_kernel<<<1, SMALL_NT, lds, st>>>(H, b, n, (double)lm, (double)ep, dx_out, fail_flag, fail_count);
     GS_CHECK_LAUNCH("chol_small");
     return GS_OK;
   }
