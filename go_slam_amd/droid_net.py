@@ -78,6 +78,33 @@ def pack_head_weight(weight):
     return pack.half().contiguous()
 
 
+def pack_1x1_weight(weight):
+    """MFMA A-fragments for gs_conv1x1 from a [N,K,1,1] weight: fp16 [N/32][KS][64][8]."""
+    N, K = weight.shape[0], weight.shape[1]
+    KS = 8 if K <= 128 else 13
+    w = torch.zeros(N, KS * 16, dtype=torch.float32, device=weight.device)
+    w[:, :K] = weight.detach().float().reshape(N, K)
+    w = w.view(N // 32, 32, KS, 2, 8)                                  # [nb, col, ks, half, e]
+    return w.permute(0, 2, 3, 1, 4).reshape(N // 32, KS, 64, 8).half().contiguous()
+
+
+def conv1x1_bias_act(cache, conv, x, act):
+    """act(conv1x1(x) + bias) for NHWC fp16 x in one HIP launch (gs_conv1x1)."""
+    from . import _lib
+    key = (conv.weight._version, conv.bias._version, conv.weight.device, conv.weight.data_ptr())
+    hit = cache.get(id(conv))
+    if hit is None or hit[0] != key:
+        hit = (key, pack_1x1_weight(conv.weight), conv.bias.detach().float().contiguous())
+        cache[id(conv)] = hit
+    n, K, h, w = x.shape
+    N = conv.weight.shape[0]
+    y = torch.empty((n, N, h, w), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    rc = _lib.lib().gs_conv1x1(_lib.ptr(x), K, K, _lib.ptr(hit[1]), _lib.ptr(hit[2]), _ACT[act], _lib.ptr(y), N, N,
+                               n * h * w, _lib.stream_ptr(x.device))
+    _lib.check(rc, "conv1x1")
+    return y
+
+
 def conv3x3_head(x, conv, cache, epilogue="none", out_scale=1.0, in_channel=0, in_bias=None, in_relu=False):
     """epi(conv(relu?(x[:, in_channel:in_channel+128] + in_bias)) + bias) * out_scale -> fp32 [n,h,w,O]
     (values are the reference's fp16 results), one HIP launch (gs_conv3x3_head)."""
@@ -371,7 +398,7 @@ class UpdateModule(nn.Module):
         f4 = flow.view(n, -1, ht, wd).half().contiguous(memory_format=cl)
         hx, inp_pre = self._edge_state(inp, n, ht, wd)
         copy_channels(net4, hx, 0)
-        c4 = conv_bias_act(hwc, self.corr_encoder[0], c4, "relu")
+        c4 = conv1x1_bias_act(self._head_cache, self.corr_encoder[0], c4, "relu")
         conv_bias_act(hwc, self.corr_encoder[2], c4, "relu", out=hx, out_channel=128)
         f4 = conv_bias_act(hwc, self.flow_encoder[0], f4, "relu")
         conv_bias_act(hwc, self.flow_encoder[2], f4, "relu", out=hx, out_channel=256)
@@ -393,7 +420,7 @@ class UpdateModule(nn.Module):
         x = segment_mean_hip(heads, seg, in_channel=256, channels=128, in_bias=hb[2], in_relu=True)
         x = conv_bias_act(hwc, agg.conv2, x, "relu")
         eta = conv3x3_head(x, agg.eta[0], hc, "softplus", out_scale=0.01).view(batch, -1, ht, wd)
-        upmask = conv_bias_act(hwc, agg.upmask[0], x, "none").view(batch, -1, 8 * 8 * 9, ht, wd)
+        upmask = conv1x1_bias_act(hc, agg.upmask[0], x, "none").view(batch, -1, 8 * 8 * 9, ht, wd)
         return net, delta, weight, eta, upmask
 
     def _fast_ok(self, net, inp, corr):

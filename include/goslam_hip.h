@@ -133,6 +133,14 @@ int gs_gru_gate_q(const void* q_pre, const float* bias_q, const float* glo_q, co
  * Epilogue of the bias-free MIOpen convolutions of src/droid_net.py:69-140.                       */
 int gs_bias_act(const void* x, const float* bias, void* y, int rows, int channels, int x_stride, int y_stride,
                 int act, gs_stream_t stream);
+/* 1x1 convolution + bias + activation as one memory-bound MFMA GEMM: y[p, 0:n_out] = act(W x[p, 0:k_in] + b)
+ * over `rows` NHWC fp16 pixels (corr_encoder[0] 196->128 ReLU, src/droid_net.py:75; GraphAgg upmask
+ * 128->576, src/droid_net.py:45).  x / y rows are x_stride / y_stride elements apart.  k_in % 4 == 0,
+ * k_in <= 208; n_out % 32 == 0.  wpack: fp16 [n_out/32][KS][64][8] A-fragments with KS = 8 (k_in <= 128)
+ * or 13, wpack[nb][ks][l][e] = W[32 nb + (l & 31)][16 ks + 8 (l >> 5) + e] (0 for k >= k_in).
+ * bias may be NULL; act: 0 none, 1 ReLU.                                                            */
+int gs_conv1x1(const void* x, int x_stride, int k_in, const void* wpack, const float* bias, int act, void* y,
+               int y_stride, int n_out, long long rows, gs_stream_t stream);
 /* 3x3 convolution (padding 1) from 128 channels to n_out in {1,2} channels, NHWC fp16 in, fp32 out
  * [n,h,w,n_out]: the flow-revision / confidence heads delta[2], weight[2] (src/droid_net.py:83-92) and
  * GraphAgg's eta[0] (src/droid_net.py:43).  x rows are x_stride elements apart (a channel slice of a

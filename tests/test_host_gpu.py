@@ -248,3 +248,22 @@ def test_conv3x3_head_kernel(built_lib, n_out, epi):
     got2 = conv3x3_head(x2, conv, {}, "none")
     ref2 = F.conv2d(x2.float(), conv.weight.half().float(), conv.bias.float(), padding=1).half().float()
     torch.testing.assert_close(got2, ref2.permute(0, 2, 3, 1), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("k_in,n_out,act", [(196, 128, "relu"), (128, 576, "none"), (64, 32, "relu")])
+def test_conv1x1_kernel(built_lib, k_in, n_out, act):
+    """gs_conv1x1 (MFMA GEMM + fused bias/activation) vs F.conv2d; 196 exercises the ragged last k-step,
+    the pixel count is not a multiple of 32."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from go_slam_amd.droid_net import conv1x1_bias_act
+    dev = torch.device("cuda:0")
+    torch.manual_seed(8)
+    x = torch.randn(3, k_in, 9, 11, device=dev).half().contiguous(memory_format=torch.channels_last)
+    conv = nn.Conv2d(k_in, n_out, 1).to(dev)
+    got = conv1x1_bias_act({}, conv, x, act)
+    ref = F.conv2d(x.float(), conv.weight.half().float(), conv.bias.float())
+    if act == "relu":
+        ref = torch.relu(ref)
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(got.float(), ref, rtol=2e-3, atol=2e-3)
