@@ -24,9 +24,10 @@ SIGNATURES = {
     "gs_last_error": (ctypes.c_char_p, []),
     "gs_corr_index_forward": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
     "gs_corr_index_backward": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
-    "gs_corr_lookup_pyramid": (c_int, [_P] * 6 + [c_int] * 8 + [_P]),
+    "gs_corr_lookup_pyramid": (c_int, [_P] * 6 + [c_int] * 9 + [_P]),
     "gs_corr_volume_workspace_bytes": (c_size_t, [c_int] * 4),
-    "gs_corr_volume_pyramid": (c_int, [_P] * 6 + [c_int] * 4 + [_P, c_size_t, _P]),
+    "gs_corr_volume_pyramid": (c_int, [_P] * 6 + [c_int] * 5 + [_P, c_size_t, _P]),
+    "gs_corr_level_elems": (c_size_t, [c_int] * 4),
     "gs_altcorr_forward": (c_int, [_P] * 4 + [c_int] * 9 + [_P]),
     "gs_reproject": (c_int, [_P] * 7 + [c_int] * 3 + [_P]),
     "gs_projmap": (c_int, [_P] * 7 + [c_int] * 3 + [_P]),

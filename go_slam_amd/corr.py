@@ -16,7 +16,14 @@ class CorrBlock:
         self.num_levels = num_levels
         self.radius = radius
         self.channels_last = channels_last      # memory format of the looked-up features
-        self.corr_pyramid = CorrBlock.build_pyramid(fmap1, fmap2, num_levels)
+        self.map_size = tuple(fmap2.shape[-2:])
+        # tile8: levels 0-1 in 128-byte tiles (1.6x fewer L2 lines per lookup window); private to the
+        # fused build -> lookup pair, so only used when both ends are the HIP kernels
+        f1 = fmap1.reshape(-1, *fmap1.shape[2:])
+        self.layout = droid_backends.CORR_TILE8 if (channels_last and fmap1.is_cuda and fmap1.dtype == torch.float16
+                                                    and droid_backends.corr_tile8_supported(f1)) \
+            else droid_backends.CORR_ROWMAJOR
+        self.corr_pyramid = CorrBlock.build_pyramid(fmap1, fmap2, num_levels, self.layout)
 
     @staticmethod
     def corr(fmap1, fmap2):
@@ -27,13 +34,14 @@ class CorrBlock:
         return torch.matmul(f1.transpose(1, 2), f2).view(batch, num, ht, wd, ht, wd)
 
     @staticmethod
-    def build_pyramid(fmap1, fmap2, num_levels=4):
+    def build_pyramid(fmap1, fmap2, num_levels=4, layout=0):
         batch, num, dim, ht, wd = fmap1.shape
         f1 = fmap1.reshape(batch * num, dim, ht, wd)
         if fmap1.is_cuda and num_levels == 4 and droid_backends.corr_volume_supported(f1):
             # fused HIP path: MFMA GEMM + the three pools, volume written exactly once
             return droid_backends.corr_volume_pyramid(f1.contiguous(),
-                                                      fmap2.reshape(batch * num, dim, ht, wd).contiguous())
+                                                      fmap2.reshape(batch * num, dim, ht, wd).contiguous(), layout)
+        assert layout == droid_backends.CORR_ROWMAJOR
         # shapes the fused kernel does not cover (odd widths, w > 80): hipBLASLt + avg_pool2d
         corr = CorrBlock.corr(fmap1, fmap2)
         batch, num, h1, w1, h2, w2 = corr.shape
@@ -48,7 +56,8 @@ class CorrBlock:
     def __call__(self, coords):
         batch, num, ht, wd, _ = coords.shape
         c = coords.reshape(batch * num, ht, wd, 2).float().contiguous()
-        out = droid_backends.corr_lookup_pyramid(self.corr_pyramid, c, self.radius, self.channels_last)
+        out = droid_backends.corr_lookup_pyramid(self.corr_pyramid, c, self.radius, self.channels_last,
+                                                 self.layout, self.map_size)
         return out.view(batch, num, -1, ht, wd)
 
     def cat(self, other):

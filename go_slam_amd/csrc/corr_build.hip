@@ -47,7 +47,7 @@ __device__ __forceinline__ half8 ld8(const _Float16* p) { return *reinterpret_ca
 
 __global__ __launch_bounds__(256) void corr_volume_kernel(
     const _Float16* __restrict__ f1t, const _Float16* __restrict__ f2t, _Float16* __restrict__ v0,
-    _Float16* __restrict__ v1, _Float16* __restrict__ v2, _Float16* __restrict__ v3, int h, int w) {
+    _Float16* __restrict__ v1, _Float16* __restrict__ v2, _Float16* __restrict__ v3, int h, int w, int tiled) {
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
   const int hw = h * w;
   const int BN = ROWS * w;                 // columns of the tile (multiple of 32)
@@ -118,7 +118,22 @@ __global__ __launch_bounds__(256) void corr_volume_kernel(
   const int rows_valid = min(ROWS, h - y2_0);          // target rows of this tile inside the map
   const int m_valid = min(BM, hw - p1_0);
   // ---- level 0: [e][p1][y2][x2], the tile is rows_valid*w contiguous halfs per p1
-  {
+  if (tiled) {
+    // tile8 layout: the plane is cut into 8x8-element (128-byte) tiles, tile (ty,tx) at ((ty*ntx+tx)*64,
+    // row-major inside).  This workgroup's 8 target rows are exactly tile row y2_0/8; consecutive lanes
+    // write consecutive 16-byte pieces of it (piece d = 8*tx + y).
+    const int ntx = w >> 3;
+    const size_t plane = (size_t)ntx * ((h + 7) >> 3) * 64;
+    const int vec = ntx * 8;
+    for (int i = threadIdx.x; i < m_valid * vec; i += 256) {
+      const int m = i / vec, d = i - m * vec;
+      const int tx = d >> 3, y = d & 7;
+      if (y < rows_valid) {
+        const half8 v = *reinterpret_cast<const half8*>(c0 + (size_t)m * LD0 + y * w + 8 * tx);
+        *reinterpret_cast<half8*>(v0 + ((size_t)e * hw + p1_0 + m) * plane + ((size_t)(y2_0 >> 3) * ntx) * 64 + 8 * d) = v;
+      }
+    }
+  } else {
     const int seg = rows_valid * w;                    // halfs per p1 row (multiple of 4 since w%4==0)
     const int vec = seg / 8;                           // 16-byte vectors (seg % 8 == 0 when w % 8 == 0)
     if ((seg & 7) == 0) {
@@ -148,8 +163,15 @@ __global__ __launch_bounds__(256) void corr_volume_kernel(
       const _Float16 o = (_Float16)((((a + b) + c) + d) * 0.25f);
       c1[(size_t)m * LD1 + yy * w1 + xx] = o;
       const int gy = (y2_0 >> 1) + yy;
-      if (m < m_valid && gy < h1)
-        v1[((size_t)e * hw + p1_0 + m) * ((size_t)h1 * w1) + (size_t)gy * w1 + xx] = o;
+      if (m < m_valid && gy < h1) {
+        if (tiled) {
+          const int ntx1 = w1 >> 3;
+          const size_t plane1 = (size_t)ntx1 * ((h1 + 7) >> 3) * 64;
+          v1[((size_t)e * hw + p1_0 + m) * plane1 + ((size_t)(gy >> 3) * ntx1 + (xx >> 3)) * 64 + (gy & 7) * 8 + (xx & 7)] = o;
+        } else {
+          v1[((size_t)e * hw + p1_0 + m) * ((size_t)h1 * w1) + (size_t)gy * w1 + xx] = o;
+        }
+      }
     }
   }
   __syncthreads();
@@ -188,9 +210,18 @@ extern "C" size_t gs_corr_volume_workspace_bytes(int n, int dim, int h, int w) {
   return 2 * gs_align((size_t)n * h * w * KDIM * 2) + 256;
 }
 
+extern "C" size_t gs_corr_level_elems(int h, int w, int level, int layout) {
+  if (h <= 0 || w <= 0 || level < 0 || level > 3) return 0;
+  const int hl = h >> level, wl = w >> level;
+  if (layout == GS_CORR_TILE8 && level <= 1) return (size_t)((wl + 7) >> 3) * ((hl + 7) >> 3) * 64;
+  return (size_t)hl * wl;
+}
+
 extern "C" int gs_corr_volume_pyramid(const void* fmap1, const void* fmap2, void* vol0, void* vol1, void* vol2,
-                                      void* vol3, int n, int dim, int h, int w, void* workspace,
+                                      void* vol3, int n, int dim, int h, int w, int layout, void* workspace,
                                       size_t workspace_bytes, gs_stream_t stream) {
+  GS_REQUIRE(layout == GS_CORR_ROWMAJOR || layout == GS_CORR_TILE8, "corr_volume_pyramid: unknown layout %d", layout);
+  GS_REQUIRE(layout == GS_CORR_ROWMAJOR || w % 16 == 0, "corr_volume_pyramid: the tile8 layout needs w %% 16 == 0");
   GS_REQUIRE(fmap1 && fmap2 && vol0 && vol1 && vol2 && vol3, "corr_volume_pyramid: null pointer");
   GS_REQUIRE(dim == KDIM, "corr_volume_pyramid: feature dim %d (DROID uses 128)", dim);
   GS_REQUIRE(n >= 0 && h >= 8 && w >= 8, "corr_volume_pyramid: bad shape");
@@ -220,7 +251,7 @@ extern "C" int gs_corr_volume_pyramid(const void* fmap1, const void* fmap2, void
   }
   dim3 grid(gs_cdiv(hw, BM), gs_cdiv(h, ROWS), n);
   corr_volume_kernel<<<grid, 256, lds, st>>>(f1t, f2t, (_Float16*)vol0, (_Float16*)vol1, (_Float16*)vol2,
-                                             (_Float16*)vol3, h, w);
+                                             (_Float16*)vol3, h, w, layout == GS_CORR_TILE8);
   GS_CHECK_LAUNCH("corr_volume");
   return GS_OK;
 }

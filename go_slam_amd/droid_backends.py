@@ -175,18 +175,31 @@ def corr_index_backward(volume, coords, corr_grad, radius):
     return [grad]
 
 
-def corr_lookup_pyramid(pyramid, coords, radius=3, channels_last=False):
+CORR_ROWMAJOR, CORR_TILE8 = 0, 1
+
+
+def corr_lookup_pyramid(pyramid, coords, radius=3, channels_last=False, layout=CORR_ROWMAJOR, map_size=None):
     """Fused 4-level form of CorrBlock.__call__ (src/modules/corr.py:43-53): one launch.
     pyramid: 4 tensors [n,h1,w1,h2>>l,w2>>l]; coords f32 [n,h1,w1,2] -> [n,196,h1,w1]
-    (memory format torch.channels_last when `channels_last`)."""
+    (memory format torch.channels_last when `channels_last`).  With layout=CORR_TILE8 (fp16,
+    channels_last) levels 0-1 are the [n,h1,w1,plane] tile8 tensors of corr_volume_pyramid and
+    map_size=(h2, w2) must be given."""
     assert len(pyramid) == 4
     for i, v in enumerate(pyramid):
         _chk(f"pyramid[{i}]", v, pyramid[0].dtype)
     _chk("coords", coords, torch.float32)
-    n, h1, w1, h2, w2 = pyramid[0].shape
-    for l in range(4):
-        if tuple(pyramid[l].shape) != (n, h1, w1, h2 >> l, w2 >> l):
-            raise RuntimeError(f"pyramid level {l} has shape {tuple(pyramid[l].shape)}")
+    if layout == CORR_TILE8:
+        n, h1, w1 = pyramid[0].shape[:3]
+        h2, w2 = map_size
+        for l in range(4):
+            want = (n, h1, w1, _lib.lib().gs_corr_level_elems(h2, w2, l, layout)) if l < 2 else (n, h1, w1, h2 >> l, w2 >> l)
+            if tuple(pyramid[l].shape) != want:
+                raise RuntimeError(f"tile8 pyramid level {l} has shape {tuple(pyramid[l].shape)}, expected {want}")
+    else:
+        n, h1, w1, h2, w2 = pyramid[0].shape
+        for l in range(4):
+            if tuple(pyramid[l].shape) != (n, h1, w1, h2 >> l, w2 >> l):
+                raise RuntimeError(f"pyramid level {l} has shape {tuple(pyramid[l].shape)}")
     rd = 2 * radius + 1
     corr = torch.empty((n, 4 * rd * rd, h1, w1), dtype=pyramid[0].dtype, device=coords.device,
                        memory_format=torch.channels_last if channels_last else torch.contiguous_format)
@@ -194,7 +207,7 @@ def corr_lookup_pyramid(pyramid, coords, radius=3, channels_last=False):
         rc = _lib.lib().gs_corr_lookup_pyramid(_lib.ptr(pyramid[0]), _lib.ptr(pyramid[1]), _lib.ptr(pyramid[2]),
                                                _lib.ptr(pyramid[3]), _lib.ptr(coords), _lib.ptr(corr), n, h1, w1,
                                                h2, w2, int(radius), _DT[pyramid[0].dtype], int(bool(channels_last)),
-                                               _lib.stream_ptr(coords.device))
+                                               int(layout), _lib.stream_ptr(coords.device))
     _lib.check(rc, "corr_lookup_pyramid")
     return corr
 
@@ -249,22 +262,42 @@ def corr_volume_supported(fmap1):
     return fmap1.dtype == torch.float16 and dim == 128 and h >= 8 and w % 8 == 0 and 8 <= w <= 80
 
 
-def corr_volume_pyramid(fmap1, fmap2):
+def corr_tile8_supported(fmap):
+    return corr_volume_supported(fmap) and fmap.shape[-1] % 16 == 0
+
+
+def corr_untile8(vol, hl, wl):
+    """[n,h,w,plane] tile8 level -> the reference's [n,h,w,hl,wl] planes (tests / debugging)."""
+    n, h, w, plane = vol.shape
+    nty, ntx = (hl + 7) // 8, (wl + 7) // 8
+    t = vol.view(n, h, w, nty, ntx, 8, 8).permute(0, 1, 2, 3, 5, 4, 6).reshape(n, h, w, nty * 8, ntx * 8)
+    return t[..., :hl, :wl].contiguous()
+
+
+def corr_volume_pyramid(fmap1, fmap2, layout=CORR_ROWMAJOR):
     """CorrBlock.__init__ + CorrBlock.corr (src/modules/corr.py:26-41,67-76) in one pass:
     fmap1, fmap2 f16 [n,128,h,w] -> list of 4 tensors [n,h,w,h>>l,w>>l] (MFMA GEMM fused with the
-    three average pools; the volume is written once and never re-read)."""
+    three average pools; the volume is written once and never re-read).  layout=CORR_TILE8 returns
+    levels 0-1 as [n,h,w,plane] in the lookup-friendly tile layout (include/goslam_hip.h)."""
     _chk("fmap1", fmap1, torch.float16)
     _chk("fmap2", fmap2, torch.float16)
     if fmap1.shape != fmap2.shape or not corr_volume_supported(fmap1):
         raise RuntimeError(f"corr_volume_pyramid: unsupported shape {tuple(fmap1.shape)} / {tuple(fmap2.shape)}")
     n, dim, h, w = fmap1.shape
     dev = fmap1.device
-    vols = [torch.empty(n, h, w, h >> l, w >> l, dtype=torch.float16, device=dev) for l in range(4)]
     L = _lib.lib()
+    if layout == CORR_TILE8:
+        if not corr_tile8_supported(fmap1):
+            raise RuntimeError(f"corr_volume_pyramid: tile8 layout needs w % 16 == 0, got {tuple(fmap1.shape)}")
+        vols = [torch.empty(n, h, w, L.gs_corr_level_elems(h, w, l, layout), dtype=torch.float16, device=dev)
+                for l in range(2)]
+        vols += [torch.empty(n, h, w, h >> l, w >> l, dtype=torch.float16, device=dev) for l in (2, 3)]
+    else:
+        vols = [torch.empty(n, h, w, h >> l, w >> l, dtype=torch.float16, device=dev) for l in range(4)]
     need = L.gs_corr_volume_workspace_bytes(n, dim, h, w)
     ws = _workspace(dev, need + 256)
     with torch.cuda.device(dev):
         rc = L.gs_corr_volume_pyramid(_lib.ptr(fmap1), _lib.ptr(fmap2), *[_lib.ptr(v) for v in vols], n, dim, h, w,
-                                      _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+                                      int(layout), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "corr_volume_pyramid")
     return vols

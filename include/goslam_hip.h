@@ -57,19 +57,29 @@ int gs_corr_index_backward(const float* coords, const void* corr_grad, void* vol
 /* CorrBlock.__call__ (src/modules/corr.py:43-53) in ONE launch: the 4 pyramid levels
  * vol[l] [n,h1,w1,h2>>l,w2>>l] are sampled at coords/2^l (coords f32 [n,h1,w1,2], the layout
  * FactorGraph hands over) and written as corr [n, 4*(2r+1)^2, h1, w1] (level-major channels);
- * channels_last != 0 stores the same logical tensor with NHWC strides ([n,h1,w1,196] in memory). */
+ * channels_last != 0 stores the same logical tensor with NHWC strides ([n,h1,w1,196] in memory).
+ * layout: GS_CORR_ROWMAJOR = the reference's planes; GS_CORR_TILE8 (fp16 + channels_last only) =
+ * levels 0-1 as written by gs_corr_volume_pyramid(layout = GS_CORR_TILE8), see below.               */
+#define GS_CORR_ROWMAJOR 0
+#define GS_CORR_TILE8 1
 int gs_corr_lookup_pyramid(const void* vol0, const void* vol1, const void* vol2, const void* vol3,
                            const float* coords, void* corr,
                            int n, int h1, int w1, int h2, int w2, int radius, int dtype,
-                           int channels_last, gs_stream_t stream);
+                           int channels_last, int layout, gs_stream_t stream);
 
 /* CorrBlock.__init__ + CorrBlock.corr (src/modules/corr.py:26-41,67-76): all-pairs volume of
  * fp16 feature maps fmap1[e], fmap2[e] ([n,128,h,w], both divided by 4) plus the 3 average-pooled
  * levels, each pooled level computed from the fp16-rounded level below (avg_pool2d on half).
- * Outputs vol[l] f16 [n,h,w,h>>l,w>>l].  Requires w % 8 == 0, w <= 80, h >= 8.                  */
+ * Outputs vol[l] f16 [n,h,w,h>>l,w>>l].  Requires w % 8 == 0, w <= 80, h >= 8.
+ * layout GS_CORR_TILE8 (w % 16 == 0): a private layout for the lookup's benefit -- the planes of levels
+ * 0 and 1 are stored as 8x8-element (128-byte = one L2 line) tiles, element (y,x) of a plane at
+ * ((y>>3) * ceil(wl/8) + (x>>3)) * 64 + (y&7) * 8 + (x&7), plane size gs_corr_level_elems(); an 8x8
+ * lookup window then touches <= 4 lines instead of ~9.  Levels 2-3 stay row-major.  Rows beyond
+ * h>>l inside the last tile row are never read and left unwritten.                                 */
 size_t gs_corr_volume_workspace_bytes(int n, int dim, int h, int w);
+size_t gs_corr_level_elems(int h, int w, int level, int layout);   /* elements per plane of one level */
 int gs_corr_volume_pyramid(const void* fmap1, const void* fmap2, void* vol0, void* vol1, void* vol2,
-                           void* vol3, int n, int dim, int h, int w,
+                           void* vol3, int n, int dim, int h, int w, int layout,
                            void* workspace, size_t workspace_bytes, gs_stream_t stream);
 
 /* droid_backends.altcorr_forward (droid.cpp:173-184, altcorr_kernel.cu:27-149,290-319).

@@ -357,6 +357,27 @@ def test_corr_volume_pyramid_matches_oracle(db, O, dev, shape):
         torch.testing.assert_close(out[l].cpu().float(), ref[l].float(), rtol=0, atol=2e-3)
 
 
+@pytest.mark.parametrize("shape", ["tiny", "Rep", "S480"])
+def test_corr_tile8_layout_is_a_pure_relayout(db, dev, shape):
+    """The tile8 volume layout (levels 0-1 in 128-byte tiles) must hold exactly the row-major values, and
+    the lookup through it must be bit-identical, including windows hanging over every border."""
+    ht, wd, _ = synth.SHAPES[shape]
+    n = 2 if shape != "S480" else 1
+    f1 = synth.make_features(n, shape, seed=71).to(dev)
+    f2 = synth.make_features(n, shape, seed=72).to(dev)
+    rm = db.corr_volume_pyramid(f1, f2)
+    t8 = db.corr_volume_pyramid(f1, f2, layout=db.CORR_TILE8)
+    for l in range(2):
+        assert torch.equal(db.corr_untile8(t8[l], ht >> l, wd >> l), rm[l]), f"level {l}"
+    for l in (2, 3):
+        assert torch.equal(t8[l], rm[l])
+    for spread in (3.0, 40.0):               # 40 px: many windows partly or wholly outside the map
+        coords = _rand_coords(n, ht, wd, ht, wd, seed=73, spread=spread).permute(0, 2, 3, 1).contiguous().to(dev)
+        a = db.corr_lookup_pyramid(rm, coords, 3, channels_last=True)
+        b = db.corr_lookup_pyramid(t8, coords, 3, channels_last=True, layout=db.CORR_TILE8, map_size=(ht, wd))
+        assert torch.equal(a, b), f"spread {spread}"
+
+
 def test_quirk_q1_first_window_pose_never_feeds_back_into_dz(db, O, dev):
     """SURVEY App. A Q1 (droid_kernels.cu:1105): entries whose pose index - t0 <= 0 are skipped in
     dz = Q (w - E^T dx).  The HIP path must match the oracle WITH the quirk and differ from a

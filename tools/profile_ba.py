@@ -1,6 +1,6 @@
 """torch.profiler table of the dense-BA launches alone on the bench workload (P=25, E=75, 60x80)."""
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from torch.profiler import profile, ProfilerActivity
 dev = torch.device('cuda:0')
