@@ -237,6 +237,141 @@ __device__ __forceinline__ void lookup_r3_packed(const _Float16* __restrict__ sl
   blend_packed(R, dx, dy, lv);
 }
 
+// ---- wave-cooperative fused lookup (fp16, NHWC): 8 lanes per pixel, one window ROW per lane --------
+// PMC on the lane-per-pixel kernel (tools/profile_lookup_only.py; TA_BUSY ~100 %, TCP_PENDING_STALL ~100 %
+// of the kernel's cycles, VALU < 10 %) shows it is bound by the L1/TA miss machinery, not by HBM bytes or
+// ALU work: every load instruction presents 64 unrelated addresses, i.e. 64 tag lookups and up to 64
+// outstanding misses, and the 8 rows of a window are fetched by 8-16 separate instructions that all
+// hit the same few lines.  Here the 8 rows of a window are loaded by 8 adjacent lanes with ONE
+// instruction (two for a straddled tile8 row), so the TA sees the window as 2-4 whole 128-byte lines;
+// the row below comes from the neighbouring lane (ds_bpermute), each lane blends the 7 taps of its
+// row two at a time (packed fp16, see blend_packed), and the 196 channels of 8 consecutive pixels are
+// assembled in LDS and stored as one contiguous 3136-byte run.
+template <bool TILED>
+__device__ __forceinline__ void load_row_coop(const _Float16* __restrict__ plane, int h2, int w2, int xs, int y1,
+                                              unsigned int (&R)[4]) {
+  typedef unsigned __int128 u128;
+  u128 v = 0;
+  const bool yin = (y1 >= 0) && (y1 < h2);
+  if constexpr (TILED) {
+    const int ntx = w2 >> 3;
+    const int tx0 = xs >> 3, ox = xs & 7;
+    const _Float16* row = plane + ((size_t)(y1 >> 3) * ntx) * 64 + (y1 & 7) * 8;
+    u128 lo = 0, hi = 0;
+    if (yin && tx0 >= 0 && tx0 < ntx) lo = *reinterpret_cast<const u128*>(row + (size_t)tx0 * 64);
+    if (yin && ox != 0 && tx0 + 1 >= 0 && tx0 + 1 < ntx) hi = *reinterpret_cast<const u128*>(row + (size_t)(tx0 + 1) * 64);
+    v = lo;
+    if (ox != 0) v = (lo >> (16 * ox)) | (hi << (128 - 16 * ox));
+  } else if (w2 >= 8) {
+    const int xc = min(max(xs, 0), w2 - 8);
+    const int d = min(max(xs - xc, -8), 8);
+    if (yin && d > -8 && d < 8) {
+      typedef struct __attribute__((packed, aligned(2))) { u128 q; } U;
+      v = reinterpret_cast<const U*>(plane + (size_t)y1 * w2 + xc)->q;
+      if (d > 0) v >>= 16 * d;
+      else if (d < 0) v <<= -16 * d;
+    }
+  } else {   // planes narrower than a window (unit-test sizes only)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int x1 = xs + i;
+      const bool in = yin && (x1 >= 0) && (x1 < w2);
+      const unsigned short bits = in ? __builtin_bit_cast(unsigned short, plane[(size_t)(in ? y1 : 0) * w2 + (in ? x1 : 0)]) : 0;
+      v |= (u128)bits << (16 * i);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) R[k] = (unsigned int)(v >> (32 * k));
+}
+
+template <int L, bool TILED>
+__device__ __forceinline__ void level_coop(const _Float16* __restrict__ vol, size_t pix, bool valid, int h2, int w2,
+                                           float2 c, int j, _Float16* __restrict__ tile_px) {
+  const int h2l = h2 >> L, w2l = w2 >> L;
+  const float sc = 1.0f / (float)(1 << L);
+  const float x0 = c.x * sc, y0 = c.y * sc;
+  const float fx0 = floorf(x0), fy0 = floorf(y0);
+  const float dx = x0 - fx0, dy = y0 - fy0;
+  const int xs = safe_int(fx0) - 3, ys = safe_int(fy0) - 3;
+  unsigned int R[4] = {0, 0, 0, 0};
+  if (valid) {
+    if constexpr (TILED && L <= 1) {
+      const size_t plane = (size_t)((w2l + 7) >> 3) * ((h2l + 7) >> 3) * 64;
+      load_row_coop<true>(vol + pix * plane, h2l, w2l, xs, ys + j, R);
+    } else {
+      load_row_coop<false>(vol + pix * (size_t)(h2l * w2l), h2l, w2l, xs, ys + j, R);
+    }
+  }
+  unsigned int Rn[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) Rn[k] = (unsigned int)__shfl_down((int)R[k], 1);      // row j+1 (lane j = 7: unused)
+  const _Float16 w_nw = wcast<_Float16>(dx * dy);
+  const _Float16 w_ne = wcast<_Float16>(dx * (1.0f - dy));
+  const _Float16 w_sw = wcast<_Float16>((1.0f - dx) * dy);
+  const _Float16 w_se = wcast<_Float16>((1.0f - dx) * (1.0f - dy));
+  const half2v Wnw = {w_nw, w_nw}, Wne = {w_ne, w_ne}, Wsw = {w_sw, w_sw}, Wse = {w_se, w_se};
+  _Float16 o[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // taps (i, j), i = 2k, 2k+1:  ((s[i][j] w_se + s[i][j+1] w_sw) + s[i+1][j] w_ne) + s[i+1][j+1] w_nw
+    const unsigned int q = (k < 3) ? __builtin_amdgcn_alignbit(R[k + 1], R[k], 16) : (R[3] >> 16);
+    const unsigned int qn = (k < 3) ? __builtin_amdgcn_alignbit(Rn[k + 1], Rn[k], 16) : (Rn[3] >> 16);
+    half2v acc = pin2(as_h2(R[k]) * Wse);
+    acc = pin2(acc + pin2(as_h2(Rn[k]) * Wsw));
+    acc = pin2(acc + pin2(as_h2(q) * Wne));
+    acc = pin2(acc + pin2(as_h2(qn) * Wnw));
+    o[2 * k] = acc[0];
+    o[2 * k + 1] = acc[1];
+  }
+  if (j < 7) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) tile_px[49 * L + i * 7 + j] = o[i];
+  }
+}
+
+constexpr int COOP_PXW = 32;     // pixels per wave (4 passes of 8)
+
+template <bool TILED>
+__global__ __launch_bounds__(256) void corr_pyramid_coop_kernel(
+    const _Float16* __restrict__ v0, const _Float16* __restrict__ v1, const _Float16* __restrict__ v2,
+    const _Float16* __restrict__ v3, const float* __restrict__ coords, _Float16* __restrict__ corr, int hw1, int h2,
+    int w2) {
+  __shared__ __attribute__((aligned(16))) _Float16 tiles[4][8 * 196];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n = blockIdx.y;
+  const int pw0 = (blockIdx.x * 4 + wv) * COOP_PXW;
+  if (pw0 >= hw1) return;
+  const int pp = lane >> 3, j = lane & 7;
+  _Float16* tile = tiles[wv];
+#pragma unroll 1
+  for (int pass = 0; pass < COOP_PXW / 8; ++pass) {
+    const int pb = pw0 + 8 * pass;
+    if (pb >= hw1) break;
+    const int p = pb + pp;
+    const bool valid = p < hw1;
+    const size_t pix = (size_t)n * hw1 + (valid ? p : pb);
+    const float2 c = reinterpret_cast<const float2*>(coords)[pix];
+    _Float16* tp = tile + pp * 196;
+    level_coop<0, TILED>(v0, pix, valid, h2, w2, c, j, tp);
+    level_coop<1, TILED>(v1, pix, valid, h2, w2, c, j, tp);
+    level_coop<2, TILED>(v2, pix, valid, h2, w2, c, j, tp);
+    level_coop<3, TILED>(v3, pix, valid, h2, w2, c, j, tp);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int npiece = min(8, hw1 - pb) * 49;                    // 8-byte pieces of the contiguous output run
+    uint2* dst = reinterpret_cast<uint2*>(corr + ((size_t)n * hw1 + pb) * 196);
+    const uint2* src = reinterpret_cast<const uint2*>(tile);
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const int idx = r * 64 + lane;
+      if (idx < npiece) dst[idx] = src[idx];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // Sample one level for one pixel; writes 49 taps to out[(i*7+j)*plane] (plane == 0: `out` is a
 // 49-entry register array).
 template <typename T, bool TILED = false>
@@ -449,6 +584,19 @@ int launch_pyramid(const void* v0, const void* v1, const void* v2, const void* v
                    void* corr, int n, int h1, int w1, int h2, int w2, int nhwc, int layout, hipStream_t st) {
   const int hw1 = h1 * w1;
   dim3 grid(gs_cdiv(hw1, 256), n), block(256);
+  if constexpr (sizeof(T) == 2) {
+    if (nhwc) {          // production path: wave-cooperative kernel, either volume layout
+      GS_REQUIRE(layout != GS_CORR_TILE8 || w2 % 16 == 0, "corr_lookup_pyramid: tile8 needs w2 %% 16 == 0");
+      dim3 cgrid(gs_cdiv(hw1, 4 * COOP_PXW), n);
+      const _Float16 *a = (const _Float16*)v0, *b = (const _Float16*)v1, *c = (const _Float16*)v2, *d = (const _Float16*)v3;
+      if (layout == GS_CORR_TILE8)
+        corr_pyramid_coop_kernel<true><<<cgrid, block, 0, st>>>(a, b, c, d, coords, (_Float16*)corr, hw1, h2, w2);
+      else
+        corr_pyramid_coop_kernel<false><<<cgrid, block, 0, st>>>(a, b, c, d, coords, (_Float16*)corr, hw1, h2, w2);
+      GS_CHECK_LAUNCH("corr_lookup_pyramid");
+      return GS_OK;
+    }
+  }
   if (layout == GS_CORR_TILE8) {
     if constexpr (sizeof(T) == 2) {
       GS_REQUIRE(nhwc && w2 % 16 == 0, "corr_lookup_pyramid: tile8 needs channels_last output and w2 %% 16 == 0");
