@@ -332,7 +332,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_corr_lookup.json")
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-        line["roofline"] = {"kernel": "corr_pyramid_kernel<f16,NHWC> (fused 4-level lookup)", "bound": "hbm",
+        line["roofline"] = {"kernel": "corr_pyramid_coop_kernel<tile8> (fp16 NHWC, wave-cooperative fused 4-level lookup)", "bound": "hbm",
                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                             "algorithmic_bytes_per_launch": algo_bytes,

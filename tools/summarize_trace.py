@@ -50,9 +50,12 @@ def main():
         while "reproject_kernel" not in rows[i]["Kernel_Name"]:
             i -= 1
         return i
-    lo, hi = update_start(first), (neus if neus < len(rows) else len(rows) - 1)
+    lo = update_start(first)
+    hi = neus if neus < len(rows) else len(rows) - 1
+    while hi > lo and "ba_update_kernel" not in rows[hi - 1]["Kernel_Name"] and "cvx_upsample" not in rows[hi - 1]["Kernel_Name"]:
+        hi -= 1                      # end of the last timed update (host-side NeuS set-up follows)
     region = rows[lo:hi]
-    wall = (int(rows[hi]["Start_Timestamp"]) - int(rows[lo]["Start_Timestamp"])) / 1e6
+    wall = (int(rows[hi - 1]["End_Timestamp"]) - int(rows[lo]["Start_Timestamp"])) / 1e6
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in region:
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
