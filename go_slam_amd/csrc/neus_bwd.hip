@@ -133,7 +133,7 @@ struct BwdArgs {
   const float* sdf; const float* grad; const uint8_t* mask;
   const float* d_alpha; const float* d_sdf; const float* d_grad; const float* dX;
   const float* d_gerr_ray;
-  float* grid_grad; float* d_out; float* lin_in; float* dw0; float* d_arg; float* pts; float* d_inv_s;
+  float* grid_grad; _Float16* grid_grad16; float grad_scale16; float* d_out; float* lin_in; float* dw0; float* d_arg; float* pts; float* d_inv_s;
   int n, s;
 };
 
@@ -141,7 +141,12 @@ struct BwdArgs {
 // neighbours often sit in the SAME cell (always at the coarse levels): runs of equal cells are
 // pre-reduced inside the wave with a segmented scan and only the run's last lane issues atomics --
 // at the coarse levels this removes ~10x of the (memory-side, heavily contended) atomic traffic.
-__device__ __forceinline__ void lvl_scatter(float* __restrict__ tab, const uint32_t (&cidx)[8], float (&gacc)[8][2],
+// `tab16` != nullptr: tiny-cuda-nn's own accumulation mode -- the table gradient is fp16, both features
+// of an entry go out as ONE packed atomic (global_atomic_pk_add_f16), pre-multiplied by the loss scale
+// (tcnn: 128) so that small contributions stay above fp16's subnormal range; half the atomic count.
+typedef _Float16 half2a __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lvl_scatter(float* __restrict__ tab, _Float16* __restrict__ tab16, float scale16,
+                                            const uint32_t (&cidx)[8], float (&gacc)[8][2],
                                             const uint32_t (&gi)[3], bool on, int lane) {
   const uint32_t p0 = __shfl_up(gi[0], 1, 64), p1 = __shfl_up(gi[1], 1, 64), p2 = __shfl_up(gi[2], 1, 64);
   const int on_prev = __shfl_up((int)on, 1, 64);
@@ -164,11 +169,22 @@ __device__ __forceinline__ void lvl_scatter(float* __restrict__ tab, const uint3
     tail = (lane == 63) || (((starts >> (lane + 1)) & 1ull) != 0ull);
   }
   if (on && tail) {
+    if (tab16) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float* gp = tab + (size_t)cidx[c] * 2;
-      if (gacc[c][0] != 0.0f) atomicAdd(gp, gacc[c][0]);
-      if (gacc[c][1] != 0.0f) atomicAdd(gp + 1, gacc[c][1]);
+      for (int c = 0; c < 8; ++c) {
+        if (gacc[c][0] != 0.0f || gacc[c][1] != 0.0f) {
+          const half2a v = {(_Float16)(gacc[c][0] * scale16), (_Float16)(gacc[c][1] * scale16)};
+          __builtin_amdgcn_global_atomic_fadd_v2f16(
+              (__attribute__((address_space(1))) half2a*)(tab16 + (size_t)cidx[c] * 2), v);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float* gp = tab + (size_t)cidx[c] * 2;
+        if (gacc[c][0] != 0.0f) atomicAdd(gp, gacc[c][0]);
+        if (gacc[c][1] != 0.0f) atomicAdd(gp + 1, gacc[c][1]);
+      }
     }
   }
 }
@@ -322,7 +338,8 @@ __global__ __launch_bounds__(256) void neus_point_bwd_kernel(BwdArgs A, gs_grid_
       w0[3 + 2 * l] = 0.5f * ((dG[0] * dy0[0] + dG[1] * dy0[1]) + dG[2] * dy0[2]);
       w0[3 + 2 * l + 1] = 0.5f * ((dG[0] * dy1[0] + dG[1] * dy1[1]) + dG[2] * dy1[2]);
     }
-    lvl_scatter(A.grid_grad + off * 2, cidx, gacc, gi, on, lane);
+    lvl_scatter(A.grid_grad ? A.grid_grad + off * 2 : nullptr, A.grid_grad16 ? A.grid_grad16 + off * 2 : nullptr,
+                A.grad_scale16, cidx, gacc, gi, on, lane);
   }
   // ---- colour embedding sin(pts @ B): d arg = d emb * cos(arg)
   if (valid) {
@@ -371,8 +388,10 @@ extern "C" int gs_neus_backward_points(const float* rays_o, const float* rays_d,
                                        const float* color_B, float inv_s, const float* bound_host, const float* sdf,
                                        const float* grad, const uint8_t* mask, const float* d_alpha,
                                        const float* d_sdf, const float* d_grad, const float* dX, const float* d_gerr_ray,
-                                       float* grid_grad, float* d_out, float* lin_in, float* dw0, float* d_arg,
-                                       float* pts, float* d_inv_s, int n, int s, gs_stream_t stream) {
+                                       void* grid_grad, int grid_grad_dtype, float grid_grad_scale, float* d_out,
+                                       float* lin_in, float* dw0, float* d_arg, float* pts, float* d_inv_s, int n,
+                                       int s, gs_stream_t stream) {
+  GS_REQUIRE(grid_grad_dtype == GS_F32 || grid_grad_dtype == GS_F16, "neus_backward_points: grid_grad dtype f32 or f16");
   GS_REQUIRE(rays_o && rays_d && z_vals && dists && grid && sdf_w && color_B && bound_host && sdf && grad && mask &&
                  d_alpha && d_sdf && d_grad && dX && d_gerr_ray && grid_grad && d_out && lin_in && dw0 && d_arg && pts && d_inv_s,
              "neus_backward_points: null pointer");
@@ -384,7 +403,10 @@ extern "C" int gs_neus_backward_points(const float* rays_o, const float* rays_d,
   for (int k = 0; k < 6; ++k) A.bound[k] = bound_host[k];
   A.sdf = sdf; A.grad = grad; A.mask = mask; A.d_alpha = d_alpha; A.d_sdf = d_sdf; A.d_grad = d_grad; A.dX = dX;
   A.d_gerr_ray = d_gerr_ray;
-  A.grid_grad = grid_grad; A.d_out = d_out; A.lin_in = lin_in; A.dw0 = dw0; A.d_arg = d_arg; A.pts = pts;
+  A.grid_grad = grid_grad_dtype == GS_F32 ? (float*)grid_grad : nullptr;
+  A.grid_grad16 = grid_grad_dtype == GS_F16 ? (_Float16*)grid_grad : nullptr;
+  A.grad_scale16 = grid_grad_scale;
+  A.d_out = d_out; A.lin_in = lin_in; A.dw0 = dw0; A.d_arg = d_arg; A.pts = pts;
   A.d_inv_s = d_inv_s; A.n = n; A.s = s;
   neus_point_bwd_kernel<<<gs_cdiv(n * s, 256), 256, 0, (hipStream_t)stream>>>(A, host_meta());
   GS_CHECK_LAUNCH("neus_backward_points");

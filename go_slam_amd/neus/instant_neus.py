@@ -92,6 +92,10 @@ class InstantNeuS(nn.Module):
         self.sdf_random_weight = cfg.get("sdf_random_weight", 0.04)
         self.cos_anneal_ratio = 1.0
         self._host_bounds = None
+        # hash-table gradient accumulation: torch.float16 = tiny-cuda-nn's behaviour (fp16 gradient,
+        # half2 atomics, loss scale 128, unscaled before the optimiser sees it); torch.float32 = exact
+        self.grid_grad_dtype = torch.float16
+        self.grid_grad_scale = 128.0
 
     def get_training_parameters(self, ignore_keys=()):
         groups = {"sdf_network": list(self.sdf_network.get_training_parameters()["network"]),
@@ -283,7 +287,10 @@ class _NeusRenderFn(torch.autograd.Function):
         dX = (dH1 @ W1.float()).contiguous()                # [np,80]
         g_mlp = torch.cat([dW1.reshape(-1), dW2.reshape(-1), dW3.reshape(-1)])
         # ---- per-point backward: alpha chain, SDF linear, hash grid (value + second-order paths)
-        grid_grad = torch.zeros(S["grid"].numel(), **f32)
+        # hash-table gradient: tcnn's mode (fp16, packed atomics, loss scale 128) or fp32 atomics
+        half_grads = model.grid_grad_dtype == torch.float16
+        gscale = float(model.grid_grad_scale) if half_grads else 1.0
+        grid_acc = torch.zeros(S["grid"].numel(), dtype=model.grid_grad_dtype, device=dev)
         d_out = torch.empty(np_, 32, **f32)
         lin_in = torch.empty(np_, 35, **f32)
         dw0 = torch.empty(np_, 35, **f32)
@@ -297,9 +304,11 @@ class _NeusRenderFn(torch.autograd.Function):
                                            float(ctx.inv_s), bh, _lib.ptr(sdf.contiguous()), _lib.ptr(S["grad"]),
                                            _lib.ptr(S["mask"]), _lib.ptr(d_alpha), _lib.ptr(d_sdf), _lib.ptr(d_grad),
                                            _lib.ptr(dX), _lib.ptr(d_gerr.reshape(-1).contiguous()),
-                                           _lib.ptr(grid_grad), _lib.ptr(d_out), _lib.ptr(lin_in), _lib.ptr(dw0),
+                                           _lib.ptr(grid_acc), 0 if half_grads else 1, gscale,
+                                           _lib.ptr(d_out), _lib.ptr(lin_in), _lib.ptr(dw0),
                                            _lib.ptr(d_arg), _lib.ptr(pts), _lib.ptr(d_invs), n, s, st)
         _lib.check(rc, "InstantNeuS.backward(points)")
+        grid_grad = grid_acc.float().mul_(1.0 / gscale) if half_grads else grid_acc
         g_sdf_w = _tn(d_out, lin_in)
         g_sdf_w[0] += _colsum(dw0)
         g_sdf_b = _colsum(d_out)

@@ -92,7 +92,10 @@ int gs_neus_backward_rays(const float* alpha, const void* rgb, const float* z_mi
  * d_feat = dX[:,36:67] and d_emb = dX[:,0:33] through NeuS alpha, the SDF linear layer and the hash
  * grid, INCLUDING the second-order path through d sdf / d x (tiny-cuda-nn's double backward).
  *   dX f32 [n*s,80] is the colour MLP's input gradient (computed by the caller's MLP backward).
- * Outputs: grid_grad f32 [total*2] (atomically accumulated; zero it first), d_out f32 [n*s,32]
+ * Outputs: grid_grad [total*2] (atomically accumulated; zero it first) -- dtype GS_F32, or GS_F16 =
+ * tiny-cuda-nn's mode: fp16 table gradient, both features of an entry added with one packed atomic,
+ * every contribution pre-multiplied by grid_grad_scale (tcnn's loss scale, 128; the caller divides it
+ * out) -- d_out f32 [n*s,32]
  * and lin_in f32 [n*s,35] (d sdf_layer.weight = d_out^T @ lin_in, d bias = colsum(d_out)),
  * dw0 f32 [n*s,35] (extra per-point contribution to sdf_layer.weight row 0: colsum),
  * d_arg f32 [n*s,33] (d color_B = pts^T @ d_arg), pts f32 [n*s,3], d_inv_s f32 [1] (atomic; zero it). */
@@ -102,8 +105,9 @@ int gs_neus_backward_points(const float* rays_o, const float* rays_d, const floa
                             const float* sdf, const float* grad, const uint8_t* mask,
                             const float* d_alpha, const float* d_sdf, const float* d_grad,
                             const float* dX, const float* d_gerr_ray,
-                            float* grid_grad, float* d_out, float* lin_in, float* dw0, float* d_arg,
-                            float* pts, float* d_inv_s, int n, int s, gs_stream_t stream);
+                            void* grid_grad, int grid_grad_dtype, float grid_grad_scale, float* d_out,
+                            float* lin_in, float* dw0, float* d_arg, float* pts, float* d_inv_s, int n, int s,
+                            gs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -182,8 +182,9 @@ def _rel(a, b):
     return float((a - b).norm() / b.norm().clamp(min=1e-12))
 
 
+@pytest.mark.parametrize("grad_dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("grid_init", [0.3])
-def test_training_gradients_match_autograd_oracle(N, O, dev, grid_init):
+def test_training_gradients_match_autograd_oracle(N, O, dev, grid_init, grad_dtype):
     """Mapper loss (reference src/mapping.py:96-132) -> gradients of every trained parameter:
     fused HIP backward vs torch.autograd on the differentiable CPU restatement, including the
     second-order path through d sdf/d x (eikonal, normals into the colour net and alpha)."""
@@ -205,6 +206,7 @@ def test_training_gradients_match_autograd_oracle(N, O, dev, grid_init):
     model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
     _load(model, P)
     model.update_bound(P["rt_bound"])
+    model.grid_grad_dtype = grad_dtype      # fp32 atomics, or tcnn's fp16 packed atomics with loss scale 128
     out = model(o.to(dev), d.to(dev), z.to(dev), dist.to(dev))
     loss = NA.mapping_loss({k: v for k, v in out.items()}, col.to(dev), gt.to(dev))
     loss.backward()
