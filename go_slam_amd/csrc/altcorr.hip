@@ -147,3 +147,80 @@ extern "C" int gs_altcorr_forward(const void* fmap1, const void* fmap2, const fl
   gs_set_error("altcorr_forward: unsupported dtype %d", dtype);
   return GS_ERR_UNSUPPORTED;
 }
+
+// ---- backward (reference: src/lib/altcorr_kernel.cu:151-283, fp32 only, training path) ---------
+// d fmap1[p] = sum_{s,iy,ix} g * fmap2[window(iy,ix)],  d fmap2[window(iy,ix)] += g * fmap1[p]  with
+// g = the four bilinear-weighted corr_grad taps that touched that window cell in the forward pass;
+// coords receive no gradient (the reference returns zeros).  One wave per source pixel: lane L first
+// computes g for window cell L (8x8 cells), then the lanes switch to channels -- a window cell's C
+// floats are one coalesced load and one coalesced run of atomics.
+namespace {
+__global__ __launch_bounds__(256) void altcorr_backward_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                               const float* __restrict__ coords,
+                                                               const float* __restrict__ cg, float* __restrict__ g1,
+                                                               float* __restrict__ g2, int S, int H1, int W1, int H2,
+                                                               int W2, int C, size_t npix) {
+  __shared__ float gs[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t pw = (size_t)blockIdx.x * 4 + wv;           // b*H1*W1 + p
+  if (pw >= npix) return;
+  const int hw1 = H1 * W1;
+  const int b = (int)(pw / hw1), p = (int)(pw % hw1);
+  const int iy = lane >> 3, ix = lane & 7;
+  const float* f1p = f1 + pw * (size_t)C;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};                     // C <= 256: channels lane, lane+64, ...
+  for (int s = 0; s < S; ++s) {
+    const float* cp = coords + ((size_t)(b * S + s) * hw1 + p) * 2;
+    const float x2 = cp[0], y2 = cp[1];
+    const float fx = floorf(x2), fy = floorf(y2);
+    const float dx = x2 - fx, dy = y2 - fy;
+    const float* gp = cg + ((size_t)(b * S + s) * 49) * hw1 + p;      // channel stride hw1
+    float g = 0.0f;
+    if (iy > 0 && ix > 0) g += gp[(size_t)((iy - 1) + 7 * (ix - 1)) * hw1] * dy * dx;
+    if (iy > 0 && ix < 7) g += gp[(size_t)((iy - 1) + 7 * ix) * hw1] * dy * (1.0f - dx);
+    if (iy < 7 && ix > 0) g += gp[(size_t)(iy + 7 * (ix - 1)) * hw1] * (1.0f - dy) * dx;
+    if (iy < 7 && ix < 7) g += gp[(size_t)(iy + 7 * ix) * hw1] * (1.0f - dy) * (1.0f - dx);
+    gs[wv][lane] = g;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int y0 = (int)fminf(fmaxf(fy, -1.0e6f), 1.0e6f) - 3, x0 = (int)fminf(fmaxf(fx, -1.0e6f), 1.0e6f) - 3;
+    for (int cell = 0; cell < 64; ++cell) {
+      const int h2 = y0 + (cell >> 3), w2 = x0 + (cell & 7);
+      if (h2 < 0 || h2 >= H2 || w2 < 0 || w2 >= W2) continue;       // wave-uniform
+      const float gc = gs[wv][cell];
+      const size_t o2 = ((size_t)(b * H2 + h2) * W2 + w2) * C;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) {
+          acc[k] = fmaf(gc, f2[o2 + c], acc[k]);
+          atomicAdd(g2 + o2 + c, gc * f1p[c]);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = lane + 64 * k;
+    if (c < C) g1[pw * (size_t)C + c] = acc[k];
+  }
+}
+}  // namespace
+
+extern "C" int gs_altcorr_backward(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad,
+                                   float* fmap1_grad, float* fmap2_grad, int b, int s, int h1, int w1, int h2, int w2,
+                                   int c, int radius, gs_stream_t stream) {
+  GS_REQUIRE(fmap1 && fmap2 && coords && corr_grad && fmap1_grad && fmap2_grad, "altcorr_backward: null pointer");
+  GS_REQUIRE(b >= 0 && s > 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0, "altcorr_backward: bad shape");
+  GS_REQUIRE(radius == 3, "altcorr_backward: only radius 3 (the reference's value) is built");
+  GS_REQUIRE(c > 0 && c <= 256, "altcorr_backward: channels %d > 256", c);
+  if (b == 0) return GS_OK;
+  const size_t npix = (size_t)b * h1 * w1;
+  altcorr_backward_kernel<<<(unsigned)((npix + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      fmap1, fmap2, coords, corr_grad, fmap1_grad, fmap2_grad, s, h1, w1, h2, w2, c, npix);
+  GS_CHECK_LAUNCH("altcorr_backward");
+  return GS_OK;
+}

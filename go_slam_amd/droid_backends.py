@@ -253,8 +253,22 @@ def altcorr_forward(fmap1, fmap2, coords, radius):
 
 
 def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
-    """droid.cpp (altcorr_backward): training-only in the reference."""
-    raise NotImplementedError("altcorr_backward: training-only path, not built yet")
+    """droid.cpp:186-199 (training path): fp32 tensors -> [fmap1_grad, fmap2_grad, coords_grad]; as in the
+    reference, coords_grad is all zeros (altcorr_kernel.cu never writes it)."""
+    for name, t in (("fmap1", fmap1), ("fmap2", fmap2), ("coords", coords), ("corr_grad", corr_grad)):
+        _chk(name, t, torch.float32)
+    B, H1, W1, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    S = coords.shape[1]
+    g1 = torch.empty_like(fmap1)
+    g2 = torch.zeros_like(fmap2)
+    gc = torch.zeros_like(coords)
+    with torch.cuda.device(fmap1.device):
+        rc = _lib.lib().gs_altcorr_backward(_lib.ptr(fmap1), _lib.ptr(fmap2), _lib.ptr(coords), _lib.ptr(corr_grad),
+                                            _lib.ptr(g1), _lib.ptr(g2), B, S, H1, W1, H2, W2, C, int(radius),
+                                            _lib.stream_ptr(fmap1.device))
+    _lib.check(rc, "droid_backends.altcorr_backward")
+    return [g1, g2, gc]
 
 
 def corr_volume_supported(fmap1):

@@ -89,6 +89,14 @@ int gs_altcorr_forward(const void* fmap1, const void* fmap2, const float* coords
                        int b, int s, int h1, int w1, int h2, int w2, int c, int radius, int dtype,
                        gs_stream_t stream);
 
+/* droid_backends.altcorr_backward (droid.cpp:186-199, altcorr_kernel.cu:151-283,322-354): fp32 only, as the
+ * reference instantiates it.  fmap1 [b,h1,w1,c], fmap2 [b,h2,w2,c], coords [b,s,h1,w1,2], corr_grad
+ * [b,s,49,h1,w1] -> fmap1_grad (written), fmap2_grad (atomically accumulated; zero it first).  coords get
+ * no gradient (the reference returns zeros).  c <= 256.                                              */
+int gs_altcorr_backward(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad,
+                        float* fmap1_grad, float* fmap2_grad, int b, int s, int h1, int w1, int h2, int w2,
+                        int c, int radius, gs_stream_t stream);
+
 /* ------------------------------------------------------------------- geometry ------ */
 
 /* DepthVideo.reproject -> pops.projective_transform(jacobian=False)

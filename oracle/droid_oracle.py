@@ -187,6 +187,18 @@ def altcorr_forward(fmap1, fmap2, coords, r):
     return [corr]
 
 
+def altcorr_backward(fmap1, fmap2, coords, corr_grad, r):
+    """lib/altcorr_kernel.cu:151-283,322-354 (fp32, training path): the kernel accumulates exactly the
+    vector-Jacobian products of altcorr_forward w.r.t. fmap1 and fmap2 (g = the bilinear-weighted corr_grad
+    taps of a window cell; f1_grad += g*f2, f2_grad += g*f1) and never writes coords_grad, which is
+    returned as zeros.  Restated as torch.autograd over the forward restatement above."""
+    f1 = fmap1.detach().clone().float().requires_grad_(True)
+    f2 = fmap2.detach().clone().float().requires_grad_(True)
+    (corr,) = altcorr_forward(f1, f2, coords.float(), r)
+    g1, g2 = torch.autograd.grad(corr, [f1, f2], corr_grad.float())
+    return [g1, g2, torch.zeros_like(coords)]
+
+
 def altcorr_pyramid(fmaps, num_levels=4):
     """modules/corr.py:98-110 (AltCorrBlock.__init__): fmaps [B,N,C,H,W] -> channels-last
     feature pyramid (features / 4, avg-pooled)."""

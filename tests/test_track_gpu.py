@@ -331,6 +331,34 @@ def test_altcorr_block_matches_oracle_lookup(O, dev, built_lib):
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("C", [64, 128])
+def test_altcorr_backward_matches_oracle(db, O, dev, C):
+    """altcorr_backward (training path, fp32) vs autograd over the oracle's forward restatement; target
+    map smaller than the source map (a pooled pyramid level), windows hanging over the borders."""
+    g = torch.Generator().manual_seed(81)
+    B, S, H1, W1, H2, W2 = 2, 3, 6, 9, 5, 7
+    f1 = torch.randn(B, H1, W1, C, generator=g)
+    f2 = torch.randn(B, H2, W2, C, generator=g)
+    coords = torch.stack([torch.rand(B, S, H1, W1, generator=g) * (W2 + 4) - 2,
+                          torch.rand(B, S, H1, W1, generator=g) * (H2 + 4) - 2], -1).contiguous()
+    cg = torch.randn(B, S, 49, H1, W1, generator=g)
+    ref = O.altcorr_backward(f1, f2, coords, cg, 3)
+    out = db.altcorr_backward(f1.to(dev), f2.to(dev), coords.to(dev), cg.to(dev), 3)
+    assert len(out) == 3 and not bool(out[2].any())                     # coords_grad: zeros, as the reference
+    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out[1].cpu(), ref[1], rtol=1e-4, atol=1e-4)
+
+
+def test_ba_global_window_200_keyframes(db, O, dev):
+    """BASELINE configs[3] stress shape: >= 200 keyframes in one dense BA (6P = 1254 unknowns, 1000 edges):
+    multi-kernel blocked Cholesky, long CSR rows, Schur pair lists."""
+    prob = _ba_problem(O, 210, 1000, "tiny", seed=83)
+    ref, (po, do), out, (pg, dg) = _run_ba_pair(db, O, dev, prob, 2, 1e-5, 1e-2, False)
+    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=5e-3, atol=1e-5)
+    torch.testing.assert_close(pg, po, rtol=0, atol=5e-5)
+    torch.testing.assert_close(dg, do, rtol=0, atol=5e-5)
+
+
 @pytest.mark.parametrize("shape", ["tiny", "Scan", "Rep"])
 def test_corr_volume_pyramid_matches_oracle(db, O, dev, shape):
     """Fused MFMA volume + pyramid vs CorrBlock.corr/avg_pool2d restated on the CPU.  Level 0 may
