@@ -218,10 +218,26 @@ def _tn(A, B, chunk=8192):
     main = c * chunk if K >= chunk else 0
     out = torch.zeros(A.shape[1], B.shape[1], dtype=torch.float32, device=A.device)
     if main:
-        out += torch.bmm(A[:main].view(c, chunk, -1).transpose(1, 2), B[:main].view(c, chunk, -1)).sum(0)
+        out += _bmm_f32(A[:main].view(c, chunk, -1).transpose(1, 2), B[:main].view(c, chunk, -1)).sum(0)
     if main < K:
-        out += A[main:].t() @ B[main:]
+        out += _bmm_f32(A[main:].t().unsqueeze(0), B[main:].unsqueeze(0))[0]
     return out
+
+
+_BMM_OUT_DTYPE = [True]
+
+
+def _bmm_f32(a, b):
+    """bmm with an fp32 result; fp16 operands use the fp32-output GEMM when this torch build has it
+    (each chunk's 8192-term sum is otherwise rounded to fp16 before the cross-chunk fp32 sum)."""
+    if a.dtype == torch.float32:
+        return torch.bmm(a, b)
+    if _BMM_OUT_DTYPE[0]:
+        try:
+            return torch.bmm(a, b, out_dtype=torch.float32)
+        except (RuntimeError, TypeError, NotImplementedError):
+            _BMM_OUT_DTYPE[0] = False
+    return torch.bmm(a, b).float()
 
 
 def _colsum(A, chunk=8192):
@@ -268,23 +284,24 @@ class _NeusRenderFn(torch.autograd.Function):
                                          _lib.ptr(d_normal), _lib.ptr(d_wsum), _lib.ptr(d_alpha), _lib.ptr(d_rgb),
                                          _lib.ptr(d_grad), n, s, st)
         _lib.check(rc, "InstantNeuS.backward(rays)")
-        # ---- colour MLP backward (hipBLASLt GEMMs; an MFMA kernel replaces this in a later round)
+        # ---- colour MLP backward: fp16 GEMMs with fp32 accumulation and tiny-cuda-nn's loss scale (128)
+        # on every gradient that lives in fp16 -- the reference's network trains exactly like this
+        # (tcnn FullyFusedMLP backward); fp32 copies of the [np,64] activations are never made.
+        LS = float(model.grid_grad_scale)
         X = S["mlp_in"]                                     # [np,80] f16
         W = S["mlp"]
         W1, W2, W3 = W[:5120].view(64, 80), W[5120:9216].view(64, 64), W[9216:].view(16, 64)
         H1 = torch.relu(X @ W1.t())
         H2 = torch.relu(H1 @ W2.t())
         y = S["rgb"].view(np_, 3).float()
-        dpre = d_rgb * y * (1.0 - y)                        # sigmoid'
-        H2f, H1f = H2.float(), H1.float()
-        dW3 = torch.zeros(16, 64, **f32)
-        dW3[:3] = _tn(dpre, H2f)
-        dH2 = (dpre @ W3[:3].float()) * (H2f > 0)
-        dW2 = _tn(dH2, H1f)
-        dH1 = (dH2 @ W2.float()) * (H1f > 0)
-        Xf = X.float()
-        dW1 = _tn(dH1, Xf)
-        dX = (dH1 @ W1.float()).contiguous()                # [np,80]
+        dpre = torch.zeros(np_, 16, dtype=torch.float16, device=dev)
+        dpre[:, :3] = (d_rgb * y * (1.0 - y)) * LS          # sigmoid', scaled, padded to the 16 output rows
+        dW3 = _tn(dpre, H2) / LS                            # [16,64]; rows 3.. are zero
+        dH2 = (dpre @ W3) * (H2 > 0)
+        dW2 = _tn(dH2, H1) / LS
+        dH1 = (dH2 @ W2) * (H1 > 0)
+        dW1 = _tn(dH1, X) / LS
+        dX = (dH1 @ W1).float().mul_(1.0 / LS)              # [np,80] f32 for the per-point kernel
         g_mlp = torch.cat([dW1.reshape(-1), dW2.reshape(-1), dW3.reshape(-1)])
         # ---- per-point backward: alpha chain, SDF linear, hash grid (value + second-order paths)
         # hash-table gradient: tcnn's mode (fp16, packed atomics, loss scale 128) or fp32 atomics
