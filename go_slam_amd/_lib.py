@@ -37,6 +37,8 @@ SIGNATURES = {
     "gs_depth_filter": (c_int, [_P] * 6 + [c_int] * 4 + [_P]),
     "gs_cvx_upsample": (c_int, [_P] * 4 + [c_int] * 4 + [_P]),
     "gs_bias_act": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "gs_motion_features": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "gs_ba_inputs": (c_int, [_P] * 6 + [c_int, c_int, c_int, _P]),
     "gs_conv1x1": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, c_int, c_int, ctypes.c_longlong, _P]),
     "gs_conv3x3_head": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_float, _P, c_int, c_int, c_int, _P]),
     "gs_segment_mean": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),

@@ -289,3 +289,68 @@ extern "C" int gs_gru_glo(const void* w_pre, const float* w_bias, const void* ne
   GS_CHECK_LAUNCH("gru_glo heads");
   return GS_OK;
 }
+
+// ---- FactorGraph.update glue around the operator (reference src/factor_graph.py:201-207, 222-247) ----
+namespace {
+// motion features: clamp([coords1 - coords0, target - coords1], +-64) as the NHWC fp16 tensor the flow
+// encoder consumes (the reference builds it with sub, sub, cat, permute, clamp + the autocast cast)
+__global__ __launch_bounds__(256) void motion_features_kernel(const float2* __restrict__ coords1,
+                                                              const float2* __restrict__ target,
+                                                              _Float16* __restrict__ out, int hw, int w, size_t total) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int p = (int)(t % hw);
+  const float gx = (float)(p % w), gy = (float)(p / w);
+  const float2 c = coords1[t], tg = target[t];
+  typedef _Float16 half4m __attribute__((ext_vector_type(4)));
+  half4m o;
+  o[0] = (_Float16)fminf(fmaxf(c.x - gx, -64.0f), 64.0f);
+  o[1] = (_Float16)fminf(fmaxf(c.y - gy, -64.0f), 64.0f);
+  o[2] = (_Float16)fminf(fmaxf(tg.x - c.x, -64.0f), 64.0f);
+  o[3] = (_Float16)fminf(fmaxf(tg.y - c.y, -64.0f), 64.0f);
+  reinterpret_cast<half4m*>(out)[t] = o;
+}
+
+// target = coords1 + delta (kept as [E,h,w,2] state) and the BA-layout copies target/weight [E,2,h,w]
+__global__ __launch_bounds__(256) void ba_inputs_kernel(const float2* __restrict__ coords1, const float2* __restrict__ delta,
+                                                        const float2* __restrict__ weight, float2* __restrict__ target,
+                                                        float* __restrict__ ba_target, float* __restrict__ ba_weight,
+                                                        int hw, size_t total) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const size_t e = t / hw;
+  const int p = (int)(t - e * hw);
+  const float2 c = coords1[t], d = delta[t], wt = weight[t];
+  const float2 tg = make_float2(c.x + d.x, c.y + d.y);
+  target[t] = tg;
+  float* bt = ba_target + e * 2 * hw + p;
+  bt[0] = tg.x; bt[hw] = tg.y;
+  float* bw = ba_weight + e * 2 * hw + p;
+  bw[0] = wt.x; bw[hw] = wt.y;
+}
+}  // namespace
+
+extern "C" int gs_motion_features(const float* coords1, const float* target, void* out, int n, int h, int w,
+                                  gs_stream_t stream) {
+  GS_REQUIRE(coords1 && target && out, "motion_features: null pointer");
+  GS_REQUIRE(n >= 0 && h > 0 && w > 0, "motion_features: bad shape");
+  if (n == 0) return GS_OK;
+  const size_t total = (size_t)n * h * w;
+  motion_features_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      (const float2*)coords1, (const float2*)target, (_Float16*)out, h * w, w, total);
+  GS_CHECK_LAUNCH("motion_features");
+  return GS_OK;
+}
+
+extern "C" int gs_ba_inputs(const float* coords1, const float* delta, const float* weight, float* target,
+                            float* ba_target, float* ba_weight, int n, int h, int w, gs_stream_t stream) {
+  GS_REQUIRE(coords1 && delta && weight && target && ba_target && ba_weight, "ba_inputs: null pointer");
+  GS_REQUIRE(n >= 0 && h > 0 && w > 0, "ba_inputs: bad shape");
+  if (n == 0) return GS_OK;
+  const size_t total = (size_t)n * h * w;
+  ba_inputs_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      (const float2*)coords1, (const float2*)delta, (const float2*)weight, (float2*)target, ba_target, ba_weight,
+      h * w, total);
+  GS_CHECK_LAUNCH("ba_inputs");
+  return GS_OK;
+}

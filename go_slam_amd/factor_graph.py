@@ -77,6 +77,28 @@ class FactorGraph:
         self._eidx = c
         return c
 
+    def _glue_fusable(self, coords1):
+        return coords1.is_cuda and self.channels_last and self.target.dtype == torch.float32 \
+            and self.target.is_contiguous() and coords1.is_contiguous()
+
+    def _ba_buffers(self, idx, use_inactive):
+        """[E_all,2,h,w] target / weight operands of droid_backends.ba, kept with the cached edge index: the
+        inactive edges' rows are transposed once per edge set, the active rows are rewritten each update."""
+        if "ba_target" not in idx:
+            ht, wd = self.ht, self.wd
+            E = self.ii.numel()
+            if use_inactive and idx["sel"].numel():
+                ti = self.target_inac[0, idx["sel"]].permute(0, 3, 1, 2)
+                wi = self.weight_inac[0, idx["sel"]].permute(0, 3, 1, 2)
+            else:
+                ti = wi = torch.zeros(0, 2, ht, wd, device=self.device)
+            n_in = ti.shape[0]
+            bt = torch.empty(n_in + E, 2, ht, wd, device=self.device)
+            bw = torch.empty(n_in + E, 2, ht, wd, device=self.device)
+            bt[:n_in], bw[:n_in] = ti, wi
+            idx["ba_target"], idx["ba_weight"], idx["n_inactive"] = bt, bw, n_in
+        return idx["ba_target"], idx["ba_weight"], idx["n_inactive"]
+
     @torch.no_grad()
     def add_factors(self, ii, jj, remove=False):
         """add edges ii->jj (src/factor_graph.py:80-130): builds their correlation pyramids."""
@@ -134,29 +156,49 @@ class FactorGraph:
         idx = self._edge_index(t0, t1, use_inactive)
         t0, t1, seg = idx["t0"], idx["t1"], idx["seg"]
         coords1, mask = self.video.reproject(self.ii, self.jj)
-        motion = torch.cat([coords1 - self.coords0, self.target - coords1], dim=-1)
-        motion = motion.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
+        fused = self._glue_fusable(coords1)
+        ht, wd = self.ht, self.wd
+        E = self.ii.numel()
+        if fused:
+            from . import _lib
+            L, st = _lib.lib(), _lib.stream_ptr(self.device)
+            m4 = torch.empty(E, ht, wd, 4, dtype=torch.float16, device=self.device)
+            _lib.check(L.gs_motion_features(_lib.ptr(coords1), _lib.ptr(self.target), _lib.ptr(m4), E, ht, wd, st),
+                       "motion_features")
+            motion = m4.permute(0, 3, 1, 2).unsqueeze(0)          # logical [1,E,4,h,w], NHWC memory
+        else:
+            motion = torch.cat([coords1 - self.coords0, self.target - coords1], dim=-1)
+            motion = motion.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
 
         corr = self.corr(coords1)
         with torch.autocast("cuda", dtype=torch.float16):
             self.net, delta, weight, damping, upmask = self.update_op(
                 self.net, self.inp, corr, motion, self.ii, self.jj, seg=seg)
 
-        self.target = coords1 + delta.float()
-        self.weight = weight.float()
-        ht, wd = self.ht, self.wd
         self.damping[seg["uniq"]] = damping.float()
-
-        if use_inactive:
-            sel = idx["sel"]
-            target = torch.cat([self.target_inac[:, sel], self.target], 1)
-            weight = torch.cat([self.weight_inac[:, sel], self.weight], 1)
+        if fused and delta.dtype == torch.float32 and weight.dtype == torch.float32:
+            # one pass: target = coords1 + delta, and the [E,2,h,w] BA operands written behind the
+            # (cached, already transposed) inactive edges
+            bt, bw, n_in = self._ba_buffers(idx, use_inactive)
+            target_new = torch.empty_like(coords1)
+            _lib.check(L.gs_ba_inputs(_lib.ptr(coords1), _lib.ptr(delta.contiguous()), _lib.ptr(weight.contiguous()),
+                                      _lib.ptr(target_new), bt[n_in:].data_ptr(), bw[n_in:].data_ptr(), E, ht, wd, st),
+                       "ba_inputs")
+            self.target, self.weight = target_new, weight
+            target, weight = bt, bw
         else:
-            target, weight = self.target, self.weight
+            self.target = coords1 + delta.float()
+            self.weight = weight.float()
+            if use_inactive:
+                sel = idx["sel"]
+                target = torch.cat([self.target_inac[:, sel], self.target], 1)
+                weight = torch.cat([self.weight_inac[:, sel], self.weight], 1)
+            else:
+                target, weight = self.target, self.weight
+            target = target.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
+            weight = weight.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
 
         damping = 0.2 * self.damping[idx["damping_index"]].contiguous() + EPS
-        target = target.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
-        weight = weight.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
 
         self.video.ba(target, weight, damping, idx["ii"], idx["jj"], t0=t0, t1=t1, iters=iters,
                       lm=1e-4, ep=0.1, motion_only=motion_only)

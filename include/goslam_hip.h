@@ -151,6 +151,15 @@ int gs_gru_gate_q(const void* q_pre, const float* bias_q, const float* glo_q, co
  * Epilogue of the bias-free MIOpen convolutions of src/droid_net.py:69-140.                       */
 int gs_bias_act(const void* x, const float* bias, void* y, int rows, int channels, int x_stride, int y_stride,
                 int act, gs_stream_t stream);
+/* FactorGraph.update glue (src/factor_graph.py:201-207): out [n,h,w,4] fp16 (NHWC; logical [n,4,h,w]) =
+ * clamp([coords1 - pixel grid, target - coords1], -64, 64), coords1 / target f32 [n,h,w,2].            */
+int gs_motion_features(const float* coords1, const float* target, void* out, int n, int h, int w,
+                       gs_stream_t stream);
+/* FactorGraph.update glue (src/factor_graph.py:222-223,244-247): target [n,h,w,2] = coords1 + delta, plus
+ * the [n,2,h,w] copies of target and weight that droid_backends.ba takes (ba_target / ba_weight point at
+ * the first of these n edges inside the caller's [E_all,2,h,w] buffers).  All f32.                    */
+int gs_ba_inputs(const float* coords1, const float* delta, const float* weight, float* target,
+                 float* ba_target, float* ba_weight, int n, int h, int w, gs_stream_t stream);
 /* 1x1 convolution + bias + activation as one memory-bound MFMA GEMM: y[p, 0:n_out] = act(W x[p, 0:k_in] + b)
  * over `rows` NHWC fp16 pixels (corr_encoder[0] 196->128 ReLU, src/droid_net.py:75; GraphAgg upmask
  * 128->576, src/droid_net.py:45).  x / y rows are x_stride / y_stride elements apart.  k_in % 4 == 0,
