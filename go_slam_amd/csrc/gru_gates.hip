@@ -153,17 +153,26 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const _Float16* __res
 #pragma unroll
   for (int j = 0; j < 8; ++j) { bias[j] = in_bias ? in_bias[c8 * 8 + j] : 0.0f; acc[j] = 0.0f; }
   const bool touch = (in_bias != nullptr) || in_relu;
-  for (int k = b; k < e; ++k) {
-    const half8 v = *reinterpret_cast<const half8*>(x + ((size_t)edges[k] * hw + p) * ldx + c8 * 8);
+  for (int k0 = b; k0 < e; k0 += 4) {           // 4 independent row loads in flight
+    half8 v[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float f = (float)v[j];
-      if (touch) {
-        f += bias[j];
-        if (in_relu) f = fmaxf(f, 0.0f);
-        f = (float)(_Float16)f;              // the activation the reference materialises in fp16
+    for (int u = 0; u < 4; ++u) {
+      const int k = min(k0 + u, e - 1);
+      v[u] = *reinterpret_cast<const half8*>(x + ((size_t)edges[k] * hw + p) * ldx + c8 * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (k0 + u >= e) continue;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = (float)v[u][j];
+        if (touch) {
+          f += bias[j];
+          if (in_relu) f = fmaxf(f, 0.0f);
+          f = (float)(_Float16)f;              // the activation the reference materialises in fp16
+        }
+        acc[j] += f;
       }
-      acc[j] += f;
     }
   }
   const float inv = e > b ? 1.0f / (float)(e - b) : 0.0f;
@@ -270,7 +279,8 @@ extern "C" int gs_segment_mean(const void* x, int x_stride, const float* in_bias
   return GS_OK;
 }
 
-extern "C" size_t gs_gru_glo_workspace_bytes(int n) { return (size_t)(n > 0 ? n : 0) * 8 * 128 * sizeof(float); }
+constexpr int GLO_CHUNKS = 32;   // pixel chunks per edge: 2400 workgroups at E = 75 (8 chunks left the GPU a third empty)
+extern "C" size_t gs_gru_glo_workspace_bytes(int n) { return (size_t)(n > 0 ? n : 0) * GLO_CHUNKS * 128 * sizeof(float); }
 
 extern "C" int gs_gru_glo(const void* w_pre, const float* w_bias, const void* net, const void* wz, const void* wr,
                           const void* wq, const float* bz, const float* br, const float* bq, float* gzr, float* gq,
@@ -280,7 +290,7 @@ extern "C" int gs_gru_glo(const void* w_pre, const float* w_bias, const void* ne
   if (n == 0) return GS_OK;
   GS_REQUIRE(workspace && workspace_bytes >= gs_gru_glo_workspace_bytes(n), "gru_glo: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  const int nchunk = 8;
+  const int nchunk = GLO_CHUNKS;
   glo_pool_kernel<<<dim3(nchunk, n), 256, 0, st>>>((const _Float16*)w_pre, w_bias, (const _Float16*)net,
                                                    (float*)workspace, hw, nchunk);
   GS_CHECK_LAUNCH("gru_glo pool");

@@ -131,9 +131,10 @@ struct BwdArgs {
   const _Float16* grid; const float* sdf_w; const float* color_B;
   float inv_s; float bound[6];
   const float* sdf; const float* grad; const uint8_t* mask;
-  const float* d_alpha; const float* d_sdf; const float* d_grad; const float* dX;
+  const float* d_alpha; const float* d_sdf; const float* d_grad; const void* dX;
   const float* d_gerr_ray;
-  float* grid_grad; _Float16* grid_grad16; float grad_scale16; float* d_out; float* lin_in; float* dw0; float* d_arg; float* pts; float* d_inv_s;
+  float* grid_grad; _Float16* grid_grad16; float grad_scale16; void* d_out; void* lin_in; void* dw0; void* d_arg; void* pts; float* d_inv_s;
+  int rows16; float row_scale; int dx16; float dx_inv_scale;
   int n, s;
 };
 
@@ -189,6 +190,26 @@ __device__ __forceinline__ void lvl_scatter(float* __restrict__ tab, _Float16* _
   }
 }
 
+// 8 consecutive entries of row i of dX (fp32, or loss-scaled fp16 straight from the MLP-backward GEMM)
+__device__ __forceinline__ void load_dx8(const BwdArgs& A, int i, int c, float* out) {
+  if (A.dx16) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const h8 v = *reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(A.dX) + (size_t)i * 80 + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = (float)v[e] * A.dx_inv_scale;
+  } else {
+    const float4* r = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(A.dX) + (size_t)i * 80 + c);
+    const float4 a = r[0], b = r[1];
+    out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+  }
+}
+
+// per-point rows (reduced by the caller's split-K GEMMs) in fp32 or fp16
+__device__ __forceinline__ void st_row(void* base, bool h16, size_t idx, float v) {
+  if (h16) reinterpret_cast<_Float16*>(base)[idx] = (_Float16)v;
+  else reinterpret_cast<float*>(base)[idx] = v;
+}
+
 __global__ __launch_bounds__(256) void neus_point_bwd_kernel(BwdArgs A, gs_grid_meta m) {
   __shared__ float red[4];
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -207,21 +228,27 @@ __global__ __launch_bounds__(256) void neus_point_bwd_kernel(BwdArgs A, gs_grid_
     pt[d] = A.rays_o[ray * 3 + d] + dir[d] * zm;
   }
   if (valid) {
-    A.pts[(size_t)i * 3 + 0] = pt[0]; A.pts[(size_t)i * 3 + 1] = pt[1]; A.pts[(size_t)i * 3 + 2] = pt[2];
+    const size_t o3 = (size_t)i * (A.rows16 ? 8 : 3);      // fp16 rows are padded to multiples of 8 (GEMM alignment)
+    st_row(A.pts, A.rows16, o3 + 0, pt[0]); st_row(A.pts, A.rows16, o3 + 1, pt[1]);
+    st_row(A.pts, A.rows16, o3 + 2, pt[2]);
   }
   // Every lane runs the whole body (wave-level run reduction below needs uniform control flow);
   // lanes that are out of bound / past the end carry zero upstream gradients and store nothing.
   const float live = on ? 1.0f : 0.0f;
   const float sdf = A.sdf[i];
   const float g[3] = {A.grad[i * 3 + 0], A.grad[i * 3 + 1], A.grad[i * 3 + 2]};
-  const float* dx = A.dX + (size_t)i * 80;
+  // colour-MLP input gradient row dX[i, 32:72] (normal / feature part; the embedding part is re-read at the
+  // end so that it does not occupy registers across the level loop)
+  float dxh[40];
+#pragma unroll
+  for (int c = 0; c < 40; c += 8) load_dx8(A, i, 32 + c, &dxh[c]);
   // ---- total gradient w.r.t. sdf and grad ----------------------------------------------------
   float d_sdf = A.d_sdf[i] * live;
   float dg[3];
   const float gn = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
   const float eik = (gn > 0.f) ? A.d_gerr_ray[ray] * 2.0f * (gn - 1.0f) / gn : 0.0f;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) dg[d] = (A.d_grad[i * 3 + d] + eik * g[d] + dx[33 + d]) * live;
+  for (int d = 0; d < 3; ++d) dg[d] = (A.d_grad[i * 3 + d] + eik * g[d] + dxh[1 + d]) * live;
   float d_invs_local = 0.f;
   {   // NeuS alpha (InstantNeuS.py:276-293)
     const float da = A.d_alpha[i] * live;
@@ -256,18 +283,18 @@ __global__ __launch_bounds__(256) void neus_point_bwd_kernel(BwdArgs A, gs_grid_
     view[d] = (qn + 1.0f) / 2.0f;
     dG[d] = dg[d] * inside * 2.0f / span;
   }
-  float* dout = A.d_out + (size_t)i * 32;
-  float* lin = A.lin_in + (size_t)i * 35;
-  float* w0 = A.dw0 + (size_t)i * 35;
+  const bool r16 = A.rows16 != 0;
+  const float rs = A.row_scale;
+  const size_t o32 = (size_t)i * 32, o35 = (size_t)i * (r16 ? 40 : 35);
   float dov[32];
   dov[0] = d_sdf;
 #pragma unroll
-  for (int o = 1; o < 32; ++o) dov[o] = dx[36 + (o - 1)] * live;
+  for (int o = 1; o < 32; ++o) dov[o] = dxh[4 + (o - 1)] * live;
   if (valid) {
 #pragma unroll
-    for (int o = 0; o < 32; ++o) dout[o] = dov[o];
+    for (int o = 0; o < 32; ++o) st_row(A.d_out, r16, o32 + o, dov[o] * rs);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { lin[d] = p_[d] * live; w0[d] = dG[d]; }
+    for (int d = 0; d < 3; ++d) { st_row(A.lin_in, r16, o35 + d, p_[d] * live); st_row(A.dw0, r16, o35 + d, dG[d] * rs); }
   }
 #pragma unroll 1
   for (int l = 0; l < GS_GRID_LEVELS; ++l) {
@@ -333,21 +360,23 @@ __global__ __launch_bounds__(256) void neus_point_bwd_kernel(BwdArgs A, gs_grid_
       dy1[gd] = a1;
     }
     if (valid) {
-      lin[3 + 2 * l] = (float)(_Float16)e0 * live;
-      lin[3 + 2 * l + 1] = (float)(_Float16)e1 * live;
-      w0[3 + 2 * l] = 0.5f * ((dG[0] * dy0[0] + dG[1] * dy0[1]) + dG[2] * dy0[2]);
-      w0[3 + 2 * l + 1] = 0.5f * ((dG[0] * dy1[0] + dG[1] * dy1[1]) + dG[2] * dy1[2]);
+      st_row(A.lin_in, r16, o35 + 3 + 2 * l, (float)(_Float16)e0 * live);
+      st_row(A.lin_in, r16, o35 + 3 + 2 * l + 1, (float)(_Float16)e1 * live);
+      st_row(A.dw0, r16, o35 + 3 + 2 * l, rs * 0.5f * ((dG[0] * dy0[0] + dG[1] * dy0[1]) + dG[2] * dy0[2]));
+      st_row(A.dw0, r16, o35 + 3 + 2 * l + 1, rs * 0.5f * ((dG[0] * dy1[0] + dG[1] * dy1[1]) + dG[2] * dy1[2]));
     }
     lvl_scatter(A.grid_grad ? A.grid_grad + off * 2 : nullptr, A.grid_grad16 ? A.grid_grad16 + off * 2 : nullptr,
                 A.grad_scale16, cidx, gacc, gi, on, lane);
   }
   // ---- colour embedding sin(pts @ B): d arg = d emb * cos(arg)
   if (valid) {
-    float* da_ = A.d_arg + (size_t)i * 33;
+    float dxe[40];
+#pragma unroll
+    for (int c = 0; c < 40; c += 8) load_dx8(A, i, c, &dxe[c]);
 #pragma unroll
     for (int c = 0; c < 33; ++c) {
       const float arg = (pt[0] * A.color_B[c] + pt[1] * A.color_B[33 + c]) + pt[2] * A.color_B[66 + c];
-      da_[c] = dx[c] * cosf(arg) * live;
+      st_row(A.d_arg, r16, (size_t)i * (r16 ? 40 : 33) + c, dxe[c] * cosf(arg) * live * rs);
     }
   }
   // one atomic per workgroup for d inv_s
@@ -387,10 +416,14 @@ extern "C" int gs_neus_backward_points(const float* rays_o, const float* rays_d,
                                        const float* dists, const void* grid, const float* sdf_w,
                                        const float* color_B, float inv_s, const float* bound_host, const float* sdf,
                                        const float* grad, const uint8_t* mask, const float* d_alpha,
-                                       const float* d_sdf, const float* d_grad, const float* dX, const float* d_gerr_ray,
-                                       void* grid_grad, int grid_grad_dtype, float grid_grad_scale, float* d_out,
-                                       float* lin_in, float* dw0, float* d_arg, float* pts, float* d_inv_s, int n,
-                                       int s, gs_stream_t stream) {
+                                       const float* d_sdf, const float* d_grad, const void* dX, int dx_dtype,
+                                       float dx_scale, const float* d_gerr_ray,
+                                       void* grid_grad, int grid_grad_dtype, float grid_grad_scale, void* d_out,
+                                       void* lin_in, void* dw0, void* d_arg, void* pts, int row_dtype,
+                                       float row_scale, float* d_inv_s, int n, int s, gs_stream_t stream) {
+  GS_REQUIRE(dx_dtype == GS_F32 || dx_dtype == GS_F16, "neus_backward_points: dX dtype f32 or f16");
+  GS_REQUIRE(row_dtype == GS_F32 || row_dtype == GS_F16, "neus_backward_points: row dtype f32 or f16");
+  GS_REQUIRE(dx_scale > 0.0f && row_scale > 0.0f, "neus_backward_points: scales must be positive");
   GS_REQUIRE(grid_grad_dtype == GS_F32 || grid_grad_dtype == GS_F16, "neus_backward_points: grid_grad dtype f32 or f16");
   GS_REQUIRE(rays_o && rays_d && z_vals && dists && grid && sdf_w && color_B && bound_host && sdf && grad && mask &&
                  d_alpha && d_sdf && d_grad && dX && d_gerr_ray && grid_grad && d_out && lin_in && dw0 && d_arg && pts && d_inv_s,
@@ -407,6 +440,7 @@ extern "C" int gs_neus_backward_points(const float* rays_o, const float* rays_d,
   A.grid_grad16 = grid_grad_dtype == GS_F16 ? (_Float16*)grid_grad : nullptr;
   A.grad_scale16 = grid_grad_scale;
   A.d_out = d_out; A.lin_in = lin_in; A.dw0 = dw0; A.d_arg = d_arg; A.pts = pts;
+  A.rows16 = row_dtype == GS_F16; A.row_scale = row_scale; A.dx16 = dx_dtype == GS_F16; A.dx_inv_scale = 1.0f / dx_scale;
   A.d_inv_s = d_inv_s; A.n = n; A.s = s;
   neus_point_bwd_kernel<<<gs_cdiv(n * s, 256), 256, 0, (hipStream_t)stream>>>(A, host_meta());
   GS_CHECK_LAUNCH("neus_backward_points");

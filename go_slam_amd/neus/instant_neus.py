@@ -242,8 +242,8 @@ def _bmm_f32(a, b):
 
 def _colsum(A, chunk=8192):
     """Column sums of a tall matrix via the same split (a strided torch.sum(0) takes 18 ms here)."""
-    ones = torch.ones(A.shape[0], 1, dtype=A.dtype, device=A.device)
-    return _tn(ones, A, chunk).reshape(-1)
+    ones = torch.ones(A.shape[0], 8 if A.dtype == torch.float16 else 1, dtype=A.dtype, device=A.device)
+    return _tn(ones, A, chunk)[0].reshape(-1)
 
 
 class _NeusRenderFn(torch.autograd.Function):
@@ -301,18 +301,19 @@ class _NeusRenderFn(torch.autograd.Function):
         dW2 = _tn(dH2, H1) / LS
         dH1 = (dH2 @ W2) * (H1 > 0)
         dW1 = _tn(dH1, X) / LS
-        dX = (dH1 @ W1).float().mul_(1.0 / LS)              # [np,80] f32 for the per-point kernel
+        dX = (dH1 @ W1).contiguous()                        # [np,80] f16, loss-scaled; unscaled inside the per-point kernel
         g_mlp = torch.cat([dW1.reshape(-1), dW2.reshape(-1), dW3.reshape(-1)])
         # ---- per-point backward: alpha chain, SDF linear, hash grid (value + second-order paths)
         # hash-table gradient: tcnn's mode (fp16, packed atomics, loss scale 128) or fp32 atomics
         half_grads = model.grid_grad_dtype == torch.float16
         gscale = float(model.grid_grad_scale) if half_grads else 1.0
         grid_acc = torch.zeros(S["grid"].numel(), dtype=model.grid_grad_dtype, device=dev)
-        d_out = torch.empty(np_, 32, **f32)
-        lin_in = torch.empty(np_, 35, **f32)
-        dw0 = torch.empty(np_, 35, **f32)
-        d_arg = torch.empty(np_, 33, **f32)
-        pts = torch.empty(np_, 3, **f32)
+        f16 = dict(dtype=torch.float16, device=dev)        # per-point rows: fp16, gradient rows loss-scaled
+        d_out = torch.empty(np_, 32, **f16)                 # row strides padded to multiples of 8: odd fp16
+        lin_in = torch.zeros(np_, 40, **f16)                # leading dimensions send hipBLASLt down a 10x slower path
+        dw0 = torch.zeros(np_, 40, **f16)
+        d_arg = torch.zeros(np_, 40, **f16)
+        pts = torch.zeros(np_, 8, **f16)
         d_invs = torch.zeros(1, **f32)
         bh, _ = model._bounds_host()
         with torch.cuda.device(dev):
@@ -320,16 +321,16 @@ class _NeusRenderFn(torch.autograd.Function):
                                            _lib.ptr(S["grid"]), _lib.ptr(S["sdf_w"]), _lib.ptr(S["cB"]),
                                            float(ctx.inv_s), bh, _lib.ptr(sdf.contiguous()), _lib.ptr(S["grad"]),
                                            _lib.ptr(S["mask"]), _lib.ptr(d_alpha), _lib.ptr(d_sdf), _lib.ptr(d_grad),
-                                           _lib.ptr(dX), _lib.ptr(d_gerr.reshape(-1).contiguous()),
+                                           _lib.ptr(dX), 0, LS, _lib.ptr(d_gerr.reshape(-1).contiguous()),
                                            _lib.ptr(grid_acc), 0 if half_grads else 1, gscale,
                                            _lib.ptr(d_out), _lib.ptr(lin_in), _lib.ptr(dw0),
-                                           _lib.ptr(d_arg), _lib.ptr(pts), _lib.ptr(d_invs), n, s, st)
+                                           _lib.ptr(d_arg), _lib.ptr(pts), 0, LS, _lib.ptr(d_invs), n, s, st)
         _lib.check(rc, "InstantNeuS.backward(points)")
         grid_grad = grid_acc.float().mul_(1.0 / gscale) if half_grads else grid_acc
-        g_sdf_w = _tn(d_out, lin_in)
-        g_sdf_w[0] += _colsum(dw0)
-        g_sdf_b = _colsum(d_out)
-        g_cB = _tn(pts, d_arg)
+        g_sdf_w = _tn(d_out, lin_in)[:, :35] / LS
+        g_sdf_w[0] += _colsum(dw0)[:35] / LS
+        g_sdf_b = _colsum(d_out) / LS
+        g_cB = _tn(pts, d_arg)[:3, :33] / LS
         sf = model.variance_network.scale_factor
         raw = math.exp(ctx.var * sf)
         g_var = (d_invs[0] * sf * ctx.inv_s) if 1e-6 <= raw <= 1e6 else torch.zeros((), **f32)

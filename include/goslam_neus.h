@@ -91,7 +91,12 @@ int gs_neus_backward_rays(const float* alpha, const void* rgb, const float* z_mi
  * the eikonal term d_gerr_ray[ray] * d(|grad|-1)^2 * mask + the colour MLP's input gradient dX[:,33:36]),
  * d_feat = dX[:,36:67] and d_emb = dX[:,0:33] through NeuS alpha, the SDF linear layer and the hash
  * grid, INCLUDING the second-order path through d sdf / d x (tiny-cuda-nn's double backward).
- *   dX f32 [n*s,80] is the colour MLP's input gradient (computed by the caller's MLP backward).
+ *   dX [n*s,80] is the colour MLP's input gradient (computed by the caller's MLP backward): f32, or f16
+ *   holding dx_scale * gradient (the loss-scaled output of an fp16 GEMM).
+ *   The per-point rows d_out, lin_in, dw0, d_arg, pts are f32 or f16 (row_dtype); the gradient-valued ones
+ *   (d_out, dw0, d_arg) are multiplied by row_scale before they are stored (loss scale for fp16 rows).
+ *   f16 rows are padded to GEMM-friendly strides -- lin_in / dw0 / d_arg 40, pts 8 (d_out stays 32) -- and
+ *   only the real columns are written: zero the buffers once.
  * Outputs: grid_grad [total*2] (atomically accumulated; zero it first) -- dtype GS_F32, or GS_F16 =
  * tiny-cuda-nn's mode: fp16 table gradient, both features of an entry added with one packed atomic,
  * every contribution pre-multiplied by grid_grad_scale (tcnn's loss scale, 128; the caller divides it
@@ -104,10 +109,10 @@ int gs_neus_backward_points(const float* rays_o, const float* rays_d, const floa
                             const float* color_B, float inv_s, const float* bound_host,
                             const float* sdf, const float* grad, const uint8_t* mask,
                             const float* d_alpha, const float* d_sdf, const float* d_grad,
-                            const float* dX, const float* d_gerr_ray,
-                            void* grid_grad, int grid_grad_dtype, float grid_grad_scale, float* d_out,
-                            float* lin_in, float* dw0, float* d_arg, float* pts, float* d_inv_s, int n, int s,
-                            gs_stream_t stream);
+                            const void* dX, int dx_dtype, float dx_scale, const float* d_gerr_ray,
+                            void* grid_grad, int grid_grad_dtype, float grid_grad_scale, void* d_out,
+                            void* lin_in, void* dw0, void* d_arg, void* pts, int row_dtype, float row_scale,
+                            float* d_inv_s, int n, int s, gs_stream_t stream);
 
 #ifdef __cplusplus
 }
