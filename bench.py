@@ -210,7 +210,7 @@ def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768):
     return {"metric": "NeuS mapping train step rays/s (render + loss + backward + all-reduce + clip + AdamW)",
             "value": n / (ms * 1e-3), "unit": "rays/s", "global_rays": n, "rays_per_gpu": n // world, "ms_per_step": ms,
             "scaling": "strong", "allreduce_bytes": 4 * sum(p.numel() for p in tr.train_params) if world > 1 else 0,
-            "final_loss": loss}
+            "final_loss": float(loss)}
 
 
 def cpu_baseline(sample_updates=1):

@@ -35,26 +35,28 @@ def mapping_loss_sharded(ret, rays_color, rays_depth, compute_sdf_error, group=N
                          w_eikonal=0.1, uncertainty=True):
     """Mapper.optimize_map's loss (reference src/mapping.py:96-132) on this rank's ray shard,
     normalised by global counts.  `compute_sdf_error(sdf, z_vals, gt_depth)` is the model's
-    (InstantNeuS.py:372-400).  Returns (local_loss, global_loss_value): local_loss.backward()
+    (InstantNeuS.py:372-400).  Returns (local_loss, global_loss as a 0-dim tensor): local_loss.backward()
     followed by an all-reduce(SUM) of the gradients reproduces the single-GPU gradient."""
+    # Sync-free formulation: the reference gathers the valid rays with boolean indexing (`x[mask]`: a nonzero
+    # + host sync per use, ~25 of them with their backward index_puts); every term is a masked sum divided by
+    # a count, so the same numbers come from multiplying by the 0/1 mask -- no gather, no host round trip.
+    # At 4096 rays per GPU (8-way sharding of a 32768-ray batch) the gathers were a quarter of the step.
     rd = rays_depth.reshape(-1, 1)
-    vm = (rd > 0).reshape(-1)
-    n_local = torch.tensor([float(vm.sum()), float(rd.shape[0])], device=rd.device, dtype=torch.float64)
+    vmf = (rd > 0).to(rd.dtype)                                    # [n,1] 1 for rays with a depth measurement
+    n_local = torch.stack([vmf.sum().double(), torch.tensor(float(rd.shape[0]), dtype=torch.float64, device=rd.device)])
     n_glob = all_reduce_sum_(n_local.clone(), group)
-    nv_l, nr_l = float(n_local[0]), float(n_local[1])
-    nv_g, nr_g = float(n_glob[0]), float(n_glob[1])
-    rdv, rcv = rd[vm], rays_color[vm]
-    est_c, est_d = ret["color"][vm], ret["depth"][vm]
-    dv = ret["depth_variance"][vm]
+    nv_l, nr_l = n_local[0].to(rd.dtype), n_local[1].to(rd.dtype)
+    nv_g, nr_g = n_glob[0].to(rd.dtype), n_glob[1].to(rd.dtype)
+    dv = ret["depth_variance"]
     uw = 1.0 / torch.sqrt(dv.detach() + 1e-10) if uncertainty else torch.ones_like(dv)
-    total = torch.abs(est_c - rcv).sum() / (3.0 * nv_g) * w_color
-    total = total + (torch.abs(est_d - rdv) * uw).sum() / nv_g
-    if nv_l > 0:
-        e, f = compute_sdf_error(ret["sdf"][vm], ret["z_vals"][vm], rdv)     # means over LOCAL valid rays
-        total = total + (e + f) * (nv_l / nv_g) * w_sdf
+    total = (torch.abs(ret["color"] - rays_color) * vmf).sum() / (3.0 * nv_g) * w_color
+    total = total + (torch.abs(ret["depth"] - rd) * uw * vmf).sum() / nv_g
+    e, f = compute_sdf_error(ret["sdf"], ret["z_vals"], rd)           # means over LOCAL valid rays
+    sdf_term = (e + f) * (nv_l / nv_g) * w_sdf
+    total = total + torch.where(nv_l > 0, sdf_term, torch.zeros_like(sdf_term))
     total = total + w_eikonal * ret["gradient_error"].mean() * (nr_l / nr_g)
     glob = all_reduce_sum_(total.detach().clone().double(), group)
-    return total, float(glob)
+    return total, glob
 
 
 class FlatGradReducer:

@@ -155,15 +155,16 @@ class InstantNeuS(nn.Module):
         }
 
     def compute_sdf_error(self, sdf, z_vals, gt_depth):
-        """src/InstantNeuS.py:372-400 (plain PyTorch, as in the reference)."""
+        """src/InstantNeuS.py:372-400.  The reference first gathers the rays with gt_depth > 0 (boolean
+        indexing = nonzero + host sync); here those rays are masked out instead, which yields the same sums."""
         n, s = z_vals.shape
         pred = sdf.reshape(n, s)
         gt = gt_depth.reshape(n, 1)
-        vm = (gt > 0).reshape(-1)
-        gt, z, pred = gt[vm], z_vals[vm], pred[vm]
-        front = z < (gt - self.sdf_truncation)
+        vm = gt > 0                                      # [n,1]; rays without depth contribute exact zeros
+        z = z_vals
+        front = (z < (gt - self.sdf_truncation)) & vm
         bnd = gt - z
-        sm = bnd.abs() <= self.sdf_truncation
+        sm = (bnd.abs() <= self.sdf_truncation) & vm
         nvs = front.sum(1) + sm.sum(1) + 1e-8
         nvr = vm.sum()
         fl = torch.max(torch.exp((-self.sdf_sparse_factor * pred).clamp(max=10.0)) - torch.ones_like(pred),

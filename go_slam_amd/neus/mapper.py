@@ -25,7 +25,7 @@ class MapTrainer:
 
     def step(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand=None):
         """One joint iteration on the GLOBAL batch (every rank passes the same tensors; each renders
-        its contiguous shard).  Returns the global loss value."""
+        its contiguous shard).  Returns the global loss as a 0-dim tensor (no host sync in the step)."""
         if self.world > 1:
             rays_o, rays_d, rays_color, rays_depth = shard_rays([rays_o, rays_d, rays_color, rays_depth],
                                                                 self.rank, self.world)

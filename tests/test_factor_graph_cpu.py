@@ -67,3 +67,22 @@ def test_edge_index_cache_invalidation():
     g.jj_inac = g.jj_inac[:-1]
     e = g._edge_index(None, None, True)
     assert e is not d and e["ii"].numel() == d["ii"].numel() - 1
+
+
+def test_masked_sdf_error_equals_gather_formulation():
+    """InstantNeuS.compute_sdf_error masks rays without depth instead of gathering the valid ones
+    (reference src/InstantNeuS.py:372-400 uses boolean indexing); both must give the same two numbers."""
+    from go_slam_amd.neus import InstantNeuS
+    from oracle import neus_oracle as NO
+    g = torch.Generator().manual_seed(5)
+    n, s = 37, 72
+    gt = torch.rand(n, generator=g) * 3 + 0.5
+    gt[torch.rand(n, generator=g) < 0.3] = 0.0
+    z = torch.sort(torch.rand(n, s, generator=g) * 4, dim=1).values
+    sdf = torch.randn(n, s, generator=g) * 0.2
+    model = InstantNeuS({}, [[-1.0, 1.0]] * 3, device="cpu")
+    e, f = model.compute_sdf_error(sdf, z, gt)
+    re, rf = NO.compute_sdf_error(sdf[gt > 0], z[gt > 0], gt[gt > 0].reshape(-1, 1), model.sdf_truncation,
+                                  model.sdf_sparse_factor)
+    torch.testing.assert_close(e, re, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(f, rf, rtol=1e-5, atol=1e-7)
