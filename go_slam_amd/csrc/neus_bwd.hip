@@ -204,14 +204,45 @@ __device__ __forceinline__ void load_dx8(const BwdArgs& A, int i, int c, float* 
   }
 }
 
+// fp16 per-point rows leave through a wave-private LDS tile: a lane-per-point store of 2-byte values puts 64
+// unrelated addresses into every store instruction (138 of them per point), which the write path handles
+// at a fraction of HBM speed; the tile turns them into contiguous 16-byte pieces of the wave's 64 rows.
+constexpr int ROW_TS = 41;                       // tile row stride in dwords (lin 20 | w0 20 | pad)
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// store `ndw` dwords per point (a multiple of 4) from tile[point][off .. off+ndw) to rows of `ndw` dwords
+__device__ __forceinline__ void tile_flush(const uint32_t* __restrict__ tile, int off, int ndw, void* __restrict__ base,
+                                           size_t p0, size_t np, int lane) {
+  const int ppp = ndw >> 2;                       // 16-byte pieces per point
+  uint4* dst = reinterpret_cast<uint4*>(base) + p0 * ppp;
+  for (int idx = lane; idx < 64 * ppp; idx += 64) {
+    const int pt = idx / ppp, part = idx - pt * ppp;
+    if (p0 + pt < np) {
+      const uint32_t* t = tile + pt * ROW_TS + off + 4 * part;
+      dst[idx] = make_uint4(t[0], t[1], t[2], t[3]);
+    }
+  }
+}
+__device__ __forceinline__ uint32_t pack2h(float a, float b) {
+  return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)a) |
+         ((uint32_t)__builtin_bit_cast(unsigned short, (_Float16)b) << 16);
+}
+
 // per-point rows (reduced by the caller's split-K GEMMs) in fp32 or fp16
 __device__ __forceinline__ void st_row(void* base, bool h16, size_t idx, float v) {
   if (h16) reinterpret_cast<_Float16*>(base)[idx] = (_Float16)v;
   else reinterpret_cast<float*>(base)[idx] = v;
 }
 
-__global__ __launch_bounds__(256) void neus_point_bwd_kernel(BwdArgs A, gs_grid_meta m) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void neus_point_bwd_kernel(BwdArgs A, gs_grid_meta m) {
   __shared__ float red[4];
+  __shared__ uint32_t row_tiles[4][64 * ROW_TS];
+  uint32_t* tile = row_tiles[threadIdx.x >> 6];
+  _Float16* tile_h = reinterpret_cast<_Float16*>(tile + (threadIdx.x & 63) * ROW_TS);    // this lane's row
+  const size_t wave_p0 = (size_t)blockIdx.x * 256 + (threadIdx.x >> 6) * 64;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int np = A.n * A.s;
@@ -227,10 +258,9 @@ __global__ __launch_bounds__(256) void neus_point_bwd_kernel(BwdArgs A, gs_grid_
     dir[d] = A.rays_d[ray * 3 + d];
     pt[d] = A.rays_o[ray * 3 + d] + dir[d] * zm;
   }
-  if (valid) {
-    const size_t o3 = (size_t)i * (A.rows16 ? 8 : 3);      // fp16 rows are padded to multiples of 8 (GEMM alignment)
-    st_row(A.pts, A.rows16, o3 + 0, pt[0]); st_row(A.pts, A.rows16, o3 + 1, pt[1]);
-    st_row(A.pts, A.rows16, o3 + 2, pt[2]);
+  if (valid && !A.rows16) {
+    const size_t o3 = (size_t)i * 3;
+    st_row(A.pts, false, o3 + 0, pt[0]); st_row(A.pts, false, o3 + 1, pt[1]); st_row(A.pts, false, o3 + 2, pt[2]);
   }
   // Every lane runs the whole body (wave-level run reduction below needs uniform control flow);
   // lanes that are out of bound / past the end carry zero upstream gradients and store nothing.
@@ -285,16 +315,21 @@ __global__ __launch_bounds__(256) void neus_point_bwd_kernel(BwdArgs A, gs_grid_
   }
   const bool r16 = A.rows16 != 0;
   const float rs = A.row_scale;
-  const size_t o32 = (size_t)i * 32, o35 = (size_t)i * (r16 ? 40 : 35);
+  const size_t o32 = (size_t)i * 32, o35 = (size_t)i * 35;
   float dov[32];
   dov[0] = d_sdf;
 #pragma unroll
   for (int o = 1; o < 32; ++o) dov[o] = dxh[4 + (o - 1)] * live;
-  if (valid) {
+  if (r16) {                                     // lin | w0 rows are built in this lane's tile row
 #pragma unroll
-    for (int o = 0; o < 32; ++o) st_row(A.d_out, r16, o32 + o, dov[o] * rs);
+    for (int d = 0; d < 3; ++d) { tile_h[d] = (_Float16)(p_[d] * live); tile_h[40 + d] = (_Float16)(dG[d] * rs); }
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { st_row(A.lin_in, r16, o35 + d, p_[d] * live); st_row(A.dw0, r16, o35 + d, dG[d] * rs); }
+    for (int d = 35; d < 40; ++d) { tile_h[d] = (_Float16)0.0f; tile_h[40 + d] = (_Float16)0.0f; }
+  } else if (valid) {
+#pragma unroll
+    for (int o = 0; o < 32; ++o) st_row(A.d_out, false, o32 + o, dov[o] * rs);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { st_row(A.lin_in, false, o35 + d, p_[d] * live); st_row(A.dw0, false, o35 + d, dG[d] * rs); }
   }
 #pragma unroll 1
   for (int l = 0; l < GS_GRID_LEVELS; ++l) {
@@ -359,24 +394,62 @@ __global__ __launch_bounds__(256) void neus_point_bwd_kernel(BwdArgs A, gs_grid_
       dy0[gd] = a0;
       dy1[gd] = a1;
     }
-    if (valid) {
-      st_row(A.lin_in, r16, o35 + 3 + 2 * l, (float)(_Float16)e0 * live);
-      st_row(A.lin_in, r16, o35 + 3 + 2 * l + 1, (float)(_Float16)e1 * live);
-      st_row(A.dw0, r16, o35 + 3 + 2 * l, rs * 0.5f * ((dG[0] * dy0[0] + dG[1] * dy0[1]) + dG[2] * dy0[2]));
-      st_row(A.dw0, r16, o35 + 3 + 2 * l + 1, rs * 0.5f * ((dG[0] * dy1[0] + dG[1] * dy1[1]) + dG[2] * dy1[2]));
+    {
+      const float l0 = (float)(_Float16)e0 * live, l1 = (float)(_Float16)e1 * live;
+      const float v0 = rs * 0.5f * ((dG[0] * dy0[0] + dG[1] * dy0[1]) + dG[2] * dy0[2]);
+      const float v1 = rs * 0.5f * ((dG[0] * dy1[0] + dG[1] * dy1[1]) + dG[2] * dy1[2]);
+      if (r16) {
+        tile_h[3 + 2 * l] = (_Float16)l0; tile_h[4 + 2 * l] = (_Float16)l1;
+        tile_h[43 + 2 * l] = (_Float16)v0; tile_h[44 + 2 * l] = (_Float16)v1;
+      } else if (valid) {
+        st_row(A.lin_in, false, o35 + 3 + 2 * l, l0);
+        st_row(A.lin_in, false, o35 + 3 + 2 * l + 1, l1);
+        st_row(A.dw0, false, o35 + 3 + 2 * l, v0);
+        st_row(A.dw0, false, o35 + 3 + 2 * l + 1, v1);
+      }
     }
     lvl_scatter(A.grid_grad ? A.grid_grad + off * 2 : nullptr, A.grid_grad16 ? A.grid_grad16 + off * 2 : nullptr,
                 A.grad_scale16, cidx, gacc, gi, on, lane);
   }
   // ---- colour embedding sin(pts @ B): d arg = d emb * cos(arg)
-  if (valid) {
+  const size_t np_all = (size_t)np;
+  if (r16) {
+    // lin | w0 rows are complete: flush them, then reuse the tile for d_out, d_arg and pts
+    wave_sync_lds();
+    tile_flush(tile, 0, 20, A.lin_in, wave_p0, np_all, lane);
+    tile_flush(tile, 20, 20, A.dw0, wave_p0, np_all, lane);
+    wave_sync_lds();
+    uint32_t* trow = tile + lane * ROW_TS;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) trow[o] = pack2h(dov[2 * o] * rs, dov[2 * o + 1] * rs);
+#pragma unroll 1
+    for (int c0 = 0; c0 < 40; c0 += 8) {           // 8 embedding columns at a time (keeps the tail's registers low)
+      float dxe[8];
+      load_dx8(A, i, c0, dxe);
+      float da[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        const int cc = c < 33 ? c : 32;
+        const float arg = (pt[0] * A.color_B[cc] + pt[1] * A.color_B[33 + cc]) + pt[2] * A.color_B[66 + cc];
+        da[e] = c < 33 ? dxe[e] * cosf(arg) * live * rs : 0.0f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) trow[16 + (c0 >> 1) + e] = pack2h(da[2 * e], da[2 * e + 1]);
+    }
+    trow[36] = pack2h(pt[0], pt[1]); trow[37] = pack2h(pt[2], 0.0f); trow[38] = 0u; trow[39] = 0u;
+    wave_sync_lds();
+    tile_flush(tile, 0, 16, A.d_out, wave_p0, np_all, lane);
+    tile_flush(tile, 16, 20, A.d_arg, wave_p0, np_all, lane);
+    tile_flush(tile, 36, 4, A.pts, wave_p0, np_all, lane);
+  } else if (valid) {
     float dxe[40];
 #pragma unroll
     for (int c = 0; c < 40; c += 8) load_dx8(A, i, c, &dxe[c]);
 #pragma unroll
     for (int c = 0; c < 33; ++c) {
       const float arg = (pt[0] * A.color_B[c] + pt[1] * A.color_B[33 + c]) + pt[2] * A.color_B[66 + c];
-      st_row(A.d_arg, r16, (size_t)i * (r16 ? 40 : 33) + c, dxe[c] * cosf(arg) * live * rs);
+      st_row(A.d_arg, false, (size_t)i * 33 + c, dxe[c] * cosf(arg) * live * rs);
     }
   }
   // one atomic per workgroup for d inv_s

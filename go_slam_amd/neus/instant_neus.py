@@ -311,10 +311,10 @@ class _NeusRenderFn(torch.autograd.Function):
         grid_acc = torch.zeros(S["grid"].numel(), dtype=model.grid_grad_dtype, device=dev)
         f16 = dict(dtype=torch.float16, device=dev)        # per-point rows: fp16, gradient rows loss-scaled
         d_out = torch.empty(np_, 32, **f16)                 # row strides padded to multiples of 8: odd fp16
-        lin_in = torch.zeros(np_, 40, **f16)                # leading dimensions send hipBLASLt down a 10x slower path
-        dw0 = torch.zeros(np_, 40, **f16)
-        d_arg = torch.zeros(np_, 40, **f16)
-        pts = torch.zeros(np_, 8, **f16)
+        lin_in = torch.empty(np_, 40, **f16)                # leading dimensions send hipBLASLt down a 10x slower path;
+        dw0 = torch.empty(np_, 40, **f16)                   # the kernel writes the pad columns as zeros
+        d_arg = torch.empty(np_, 40, **f16)
+        pts = torch.empty(np_, 8, **f16)
         d_invs = torch.zeros(1, **f32)
         bh, _ = model._bounds_host()
         with torch.cuda.device(dev):

@@ -95,8 +95,8 @@ int gs_neus_backward_rays(const float* alpha, const void* rgb, const float* z_mi
  *   holding dx_scale * gradient (the loss-scaled output of an fp16 GEMM).
  *   The per-point rows d_out, lin_in, dw0, d_arg, pts are f32 or f16 (row_dtype); the gradient-valued ones
  *   (d_out, dw0, d_arg) are multiplied by row_scale before they are stored (loss scale for fp16 rows).
- *   f16 rows are padded to GEMM-friendly strides -- lin_in / dw0 / d_arg 40, pts 8 (d_out stays 32) -- and
- *   only the real columns are written: zero the buffers once.
+ *   f16 rows are padded to GEMM-friendly strides -- lin_in / dw0 / d_arg 40, pts 8 (d_out stays 32); the pad
+ *   columns are written as zeros.
  * Outputs: grid_grad [total*2] (atomically accumulated; zero it first) -- dtype GS_F32, or GS_F16 =
  * tiny-cuda-nn's mode: fp16 table gradient, both features of an entry added with one packed atomic,
  * every contribution pre-multiplied by grid_grad_scale (tcnn's loss scale, 128; the caller divides it
