@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak (no sparsity)
 SHAPE = "S480"
 NUM_KF = 25
 NUM_EDGES = 75
@@ -138,6 +139,14 @@ def op_breakdown(video, update_op, graph):
     video.poses.copy_(poses0)
     video.disps.copy_(disps0)
     out["edges"] = E
+    # correlation-volume build (HBM-write bound): 8 new edges, as one add_factors call of a frontend keyframe
+    nb = 8
+    f1 = torch.randn(nb, 128, ht, wd, device=ii.device).half()
+    f2 = torch.randn(nb, 128, ht, wd, device=ii.device).half()
+    layout = db.CORR_TILE8 if db.corr_tile8_supported(f1) else db.CORR_ROWMAJOR
+    out["corr_build_8edges_ms"] = time_op(lambda: db.corr_volume_pyramid(f1, f2, layout), iters=5)
+    out["corr_build_bytes"] = nb * 2.0 * (ht * wd) * sum(
+        int(db._lib.lib().gs_corr_level_elems(ht, wd, l, layout)) for l in range(4))
     return out
 
 
@@ -161,7 +170,15 @@ def neus_render_bench(device, n_rays=4096, iters=20):
         z, dist = R.sample(o, d, model.bound, gt)
         ms_fwd = time_op(lambda: model(o, d, z, dist), iters=iters, warm=3)
     pts = n_rays * 72
+    with torch.no_grad():       # the fused colour MLP alone (MFMA): 2*(80*64 + 64*64 + 64*16) flop per point, padded sizes
+        x = torch.randn(pts, 67, device=device).half()
+        ms_mlp = time_op(lambda: model.color_network.network(x), iters=iters, warm=3)
+    mlp_tflops = pts * 2.0 * (80 * 64 + 64 * 64 + 64 * 16) / (ms_mlp * 1e-3) / 1e12
     return {"metric": "NeuS render rays/s (Renderer.render_batch_ray + InstantNeuS.forward, 72 samples/ray)",
+            "mlp_mfma": {"kernel": "neus_mlp_kernel (67->64->64->3 fused, fp16 MFMA)", "ms": ms_mlp,
+                         "achieved": mlp_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": mlp_tflops / MFMA_F16_PEAK_TFLOPS,
+                         "note": "includes the tcnn-compat wrapper's pad/launch; 295k points x 20.5 kflop is far too little work to fill the MFMA pipes"},
             "value": n_rays / (ms * 1e-3), "unit": "rays/s", "rays_per_batch": n_rays, "ms_per_batch": ms,
             "forward_ms": ms_fwd, "dtype": "f16 grid/MLP, f32 elsewhere",
             # 512 B of grid gathers per sample point (L2 / Infinity-Cache resident table)
@@ -337,7 +354,13 @@ def main():
                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                             "algorithmic_bytes_per_launch": algo_bytes,
                             "kernel_avg_us": br["corr_lookup_ms"] * 1e3}
+        bgb = br["corr_build_bytes"] / (br["corr_build_8edges_ms"] * 1e-3) / 1e9
+        line["roofline_other"] = [
+            {"kernel": "corr_volume_kernel (MFMA all-pairs volume + 3 pooled levels, written once)", "bound": "hbm",
+             "achieved": bgb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bgb / HBM_PEAK_GBS,
+             "bytes_per_launch": br["corr_build_bytes"], "note": "8 edges per launch (one keyframe's new factors)"}]
         line["neus_render"] = neus_render_bench(device)
+        line["roofline_other"].append(dict(line["neus_render"]["mlp_mfma"], bound="mfma"))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(3)
         print(json.dumps(line))

@@ -169,23 +169,50 @@ __device__ __forceinline__ void lvl_scatter(float* __restrict__ tab, _Float16* _
     }
     tail = (lane == 63) || (((starts >> (lane + 1)) & 1ull) != 0ull);
   }
-  if (on && tail) {
-    if (tab16) {
+  if (tab16) {
+    // The atomics are executed memory-side: every (lane, address) pair that is not merged in the TA costs a
+    // fabric transaction, and 128 of them per point are what bound this kernel.  The two x-neighbours of a
+    // cell (corners c, c^1) are ADJACENT table entries whenever the level is dense or x is even (the hash
+    // multiplies x by 1), so lanes 2i / 2i+1 issue them in the SAME instruction -- first for point 2i, then
+    // for point 2i+1 -- which lets the hardware merge the pair into one 64-byte request.
+    const bool act = on && tail;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        if (gacc[c][0] != 0.0f || gacc[c][1] != 0.0f) {
-          const half2a v = {(_Float16)(gacc[c][0] * scale16), (_Float16)(gacc[c][1] * scale16)};
+    for (int cp = 0; cp < 4; ++cp) {
+      const int c0 = 2 * cp, c1 = 2 * cp + 1;
+      const half2a v0 = {(_Float16)(gacc[c0][0] * scale16), (_Float16)(gacc[c0][1] * scale16)};
+      const half2a v1 = {(_Float16)(gacc[c1][0] * scale16), (_Float16)(gacc[c1][1] * scale16)};
+      const int u0 = __builtin_bit_cast(int, v0), u1 = __builtin_bit_cast(int, v1);
+      const int a0 = (act && (gacc[c0][0] != 0.0f || gacc[c0][1] != 0.0f)) ? 1 : 0;
+      const int a1 = (act && (gacc[c1][0] != 0.0f || gacc[c1][1] != 0.0f)) ? 1 : 0;
+      const int i0 = (int)cidx[c0], i1 = (int)cidx[c1];
+      const bool odd = lane & 1;
+      // round A: point 2i -- even lane its own c0, odd lane the even neighbour's c1
+      {
+        const int ni = __builtin_amdgcn_mov_dpp(i1, 0xA0, 0xf, 0xf, true);     // quad_perm [0,0,2,2]
+        const int nu = __builtin_amdgcn_mov_dpp(u1, 0xA0, 0xf, 0xf, true);
+        const int na = __builtin_amdgcn_mov_dpp(a1, 0xA0, 0xf, 0xf, true);
+        const int idx = odd ? ni : i0, uu = odd ? nu : u0, aa = odd ? na : a0;
+        if (aa)
           __builtin_amdgcn_global_atomic_fadd_v2f16(
-              (__attribute__((address_space(1))) half2a*)(tab16 + (size_t)cidx[c] * 2), v);
-        }
+              (__attribute__((address_space(1))) half2a*)(tab16 + (size_t)(uint32_t)idx * 2), __builtin_bit_cast(half2a, uu));
       }
-    } else {
+      // round B: point 2i+1 -- odd lane its own c1, even lane the odd neighbour's c0
+      {
+        const int ni = __builtin_amdgcn_mov_dpp(i0, 0xF5, 0xf, 0xf, true);     // quad_perm [1,1,3,3]
+        const int nu = __builtin_amdgcn_mov_dpp(u0, 0xF5, 0xf, 0xf, true);
+        const int na = __builtin_amdgcn_mov_dpp(a0, 0xF5, 0xf, 0xf, true);
+        const int idx = odd ? i1 : ni, uu = odd ? u1 : nu, aa = odd ? a1 : na;
+        if (aa)
+          __builtin_amdgcn_global_atomic_fadd_v2f16(
+              (__attribute__((address_space(1))) half2a*)(tab16 + (size_t)(uint32_t)idx * 2), __builtin_bit_cast(half2a, uu));
+      }
+    }
+  } else if (on && tail) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        float* gp = tab + (size_t)cidx[c] * 2;
-        if (gacc[c][0] != 0.0f) atomicAdd(gp, gacc[c][0]);
-        if (gacc[c][1] != 0.0f) atomicAdd(gp + 1, gacc[c][1]);
-      }
+    for (int c = 0; c < 8; ++c) {
+      float* gp = tab + (size_t)cidx[c] * 2;
+      if (gacc[c][0] != 0.0f) atomicAdd(gp, gacc[c][0]);
+      if (gacc[c][1] != 0.0f) atomicAdd(gp + 1, gacc[c][1]);
     }
   }
 }
