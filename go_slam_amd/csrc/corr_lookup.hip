@@ -1,15 +1,18 @@
 // Correlation-volume window lookup (reference: src/lib/correlation_kernels.cu:19-124 and the
 // 4-level loop of src/modules/corr.py:43-53).
 //
-// One lane owns one source pixel p=(y,x) of one edge: its correlation slice
-// volume[n][y][x][:][:] is private to the lane, so nothing is shared through LDS; the lane
-// streams the 8 rows of its 8x8 window (16 B of fp16 each, one unaligned 128-bit load per
-// row on the interior fast path) and emits the 49 bilinear taps.  Lanes are laid out along
-// the flattened pixel index so every output channel plane is written 128 B per wave.
-// The bilinear blend is carried in the volume's dtype in the reference's order
-// (i outer, j inner, `corr += s * T(w)`) with at::Half's compute-in-fp32-round-to-fp16
-// operator semantics, which makes fp16 results bit-identical to the reference's
-// fp16-accumulated values; the file is compiled with -ffp-contract=off.
+// Two kernels:
+//  * corr_pyramid_coop_kernel (further down) -- the production path (fp16 volume, NHWC output, all 4
+//    levels fused, row-major or tile8 volume layout): 8 lanes per source pixel, one window row per lane.
+//  * the lane-per-pixel kernels (corr_pyramid_kernel, corr_index_*): fp32/fp64 volumes, planar output,
+//    the reference's single-level ABI and its backward.  One lane owns one source pixel p=(y,x) of one
+//    edge: its correlation slice volume[n][y][x][:][:] is private to the lane, so nothing is shared
+//    through LDS; the lane streams the 8 rows of its 8x8 window (one unaligned 128-bit load per row for
+//    fp16, clamped into the plane + funnel shift at the borders) and emits the 49 bilinear taps.
+// The bilinear blend is carried in the volume's dtype in the reference's order (i outer, j inner,
+// `corr += s * T(w)`) with at::Half's compute-in-fp32-round-to-fp16 operator semantics, which makes
+// fp16 results bit-identical to the reference's fp16-accumulated values; the file is compiled with
+// -ffp-contract=off.
 #include "common.h"
 
 namespace {
@@ -104,138 +107,14 @@ __device__ __forceinline__ void load_window<_Float16>(const _Float16* __restrict
   }
 }
 
-// tile8 layout (levels 0-1 of the fused fp16 pyramid, see gs_corr_volume_pyramid): the plane is stored as
-// 8x8-element tiles of 128 bytes = one L2 line.  A window row is the two aligned 16-byte rows of the
-// (at most) two tiles it straddles, funnel-shifted by xs & 7; the 8 rows touch at most 2x2 tiles, so an
-// 8x8 window costs <= 4 line fetches (3.5 on average) instead of ~9 with 160-byte row-major rows --
-// the lookup is bound by the number of lines it pulls, not by the bytes it uses.
-__device__ __forceinline__ void load_window_tiled(const _Float16* __restrict__ plane, int h2, int w2, int xs, int ys,
-                                                  _Float16 (&s)[8][8]) {
-  typedef unsigned __int128 u128;
-  const int ntx = w2 >> 3;                      // w2 % 8 == 0 in this layout
-  const int tx0 = xs >> 3, ox = xs & 7;
-  const bool lo_in = (tx0 >= 0) && (tx0 < ntx);
-  const bool hi_in = (ox != 0) && (tx0 + 1 >= 0) && (tx0 + 1 < ntx);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int y1 = ys + j;
-    const bool yin = (y1 >= 0) && (y1 < h2);
-    const _Float16* row = plane + ((size_t)(y1 >> 3) * ntx) * 64 + (y1 & 7) * 8;
-    u128 lo = 0, hi = 0;
-    if (yin && lo_in) lo = *reinterpret_cast<const u128*>(row + (size_t)tx0 * 64);
-    if (yin && hi_in) hi = *reinterpret_cast<const u128*>(row + (size_t)(tx0 + 1) * 64);
-    u128 v = lo;
-    if (ox != 0) v = (lo >> (16 * ox)) | (hi << (128 - 16 * ox));
-    const unsigned long long l64 = (unsigned long long)v, h64 = (unsigned long long)(v >> 64);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const unsigned short bits = (unsigned short)((i < 4 ? l64 : h64) >> (16 * (i & 3)));
-      s[i][j] = __builtin_bit_cast(_Float16, bits);
-    }
-  }
-}
-
-// ---- packed fp16 path (the production dtype on the fused NHWC kernel) ----------------------------
+// ---- packed fp16 arithmetic (the production dtype on the fused NHWC kernel) ------------------------
 // at::Half's "compute in fp32, round to fp16" equals a native fp16 operation for a single + or x
 // (fp32's 24-bit significand >= 2*11 + 2, so the double rounding is innocuous), hence v_pk_mul_f16 /
 // v_pk_add_f16 reproduce the reference bit for bit while blending TWO taps per instruction and
-// skipping ~10 conversions per tap.  The scalar emulation above costs ~17 VALU instructions per tap
-// (~9k per pixel), which made the lookup as much issue-bound as memory-bound.
+// skipping ~10 conversions per tap (the scalar emulation above costs ~17 VALU instructions per tap).
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ half2v pin2(half2v v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ half2v as_h2(unsigned int u) { return __builtin_bit_cast(half2v, u); }
-
-// rows of the 8x8 window as 4 dwords each: R[j][k] = (s[2k][j], s[2k+1][j])
-__device__ __forceinline__ void load_rows_rowmajor(const _Float16* __restrict__ slice, int h2, int w2, int xs, int ys,
-                                                   unsigned int (&R)[8][4]) {
-  typedef unsigned __int128 u128;
-  const int xc = min(max(xs, 0), w2 - 8);       // w2 >= 8 on this path
-  const int d = min(max(xs - xc, -8), 8);       // s[i] = row[i + d]
-  const bool none = (d <= -8) || (d >= 8);
-  const int sh = 16 * (d < 0 ? -d : d);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int y1 = ys + j;
-    const bool yin = (y1 >= 0) && (y1 < h2) && !none;
-    u128 v = 0;
-    if (yin) {
-      typedef struct __attribute__((packed, aligned(2))) { u128 q; } U;
-      v = reinterpret_cast<const U*>(slice + (size_t)y1 * w2 + xc)->q;
-      if (d > 0) v >>= sh;
-      else if (d < 0) v <<= sh;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) R[j][k] = (unsigned int)(v >> (32 * k));
-  }
-}
-
-__device__ __forceinline__ void load_rows_tiled(const _Float16* __restrict__ plane, int h2, int w2, int xs, int ys,
-                                                unsigned int (&R)[8][4]) {
-  typedef unsigned __int128 u128;
-  const int ntx = w2 >> 3;                      // w2 % 8 == 0 in this layout
-  const int tx0 = xs >> 3, ox = xs & 7;
-  const bool lo_in = (tx0 >= 0) && (tx0 < ntx);
-  const bool hi_in = (ox != 0) && (tx0 + 1 >= 0) && (tx0 + 1 < ntx);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int y1 = ys + j;
-    const bool yin = (y1 >= 0) && (y1 < h2);
-    const _Float16* row = plane + ((size_t)(y1 >> 3) * ntx) * 64 + (y1 & 7) * 8;
-    u128 lo = 0, hi = 0;
-    if (yin && lo_in) lo = *reinterpret_cast<const u128*>(row + (size_t)tx0 * 64);
-    if (yin && hi_in) hi = *reinterpret_cast<const u128*>(row + (size_t)(tx0 + 1) * 64);
-    u128 v = lo;
-    if (ox != 0) v = (lo >> (16 * ox)) | (hi << (128 - 16 * ox));
-#pragma unroll
-    for (int k = 0; k < 4; ++k) R[j][k] = (unsigned int)(v >> (32 * k));
-  }
-}
-
-// 49 taps from the window rows, two vertically adjacent taps (j, j+1) per packed operation:
-//   C[i][j2] = (s[i][2 j2], s[i][2 j2 + 1]),  D[i][j2] = (s[i][2 j2 + 1], s[i][2 j2 + 2])
-//   (tap(i,2 j2), tap(i,2 j2+1)) = ((C[i] w_se + D[i] w_sw) + C[i+1] w_ne) + D[i+1] w_nw   -- reference order
-__device__ __forceinline__ void blend_packed(const unsigned int (&R)[8][4], float dx, float dy, _Float16 (&lv)[49]) {
-  const _Float16 w_nw = wcast<_Float16>(dx * dy);
-  const _Float16 w_ne = wcast<_Float16>(dx * (1.0f - dy));
-  const _Float16 w_sw = wcast<_Float16>((1.0f - dx) * dy);
-  const _Float16 w_se = wcast<_Float16>((1.0f - dx) * (1.0f - dy));
-  const half2v Wnw = {w_nw, w_nw}, Wne = {w_ne, w_ne}, Wsw = {w_sw, w_sw}, Wse = {w_se, w_se};
-  unsigned int C[8][4], D[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int k = i >> 1;
-    const unsigned int sel = (i & 1) ? 0x07060302u : 0x05040100u;      // high / low halves of both rows
-#pragma unroll
-    for (int j2 = 0; j2 < 4; ++j2) {
-      C[i][j2] = __builtin_amdgcn_perm(R[2 * j2 + 1][k], R[2 * j2][k], sel);
-      D[i][j2] = __builtin_amdgcn_perm(R[j2 < 3 ? 2 * j2 + 2 : 7][k], R[2 * j2 + 1][k], sel);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 7; ++i) {
-#pragma unroll
-    for (int j2 = 0; j2 < 4; ++j2) {
-      half2v c = pin2(as_h2(C[i][j2]) * Wse);
-      c = pin2(c + pin2(as_h2(D[i][j2]) * Wsw));
-      c = pin2(c + pin2(as_h2(C[i + 1][j2]) * Wne));
-      c = pin2(c + pin2(as_h2(D[i + 1][j2]) * Wnw));
-      lv[i * 7 + 2 * j2] = c[0];
-      if (j2 < 3) lv[i * 7 + 2 * j2 + 1] = c[1];
-    }
-  }
-}
-
-template <bool TILED>
-__device__ __forceinline__ void lookup_r3_packed(const _Float16* __restrict__ slice, int h2, int w2, float x0, float y0,
-                                                 _Float16 (&lv)[49]) {
-  const float fx0 = floorf(x0), fy0 = floorf(y0);
-  const float dx = x0 - fx0, dy = y0 - fy0;
-  const int xs = safe_int(fx0) - 3, ys = safe_int(fy0) - 3;
-  unsigned int R[8][4];
-  if constexpr (TILED) load_rows_tiled(slice, h2, w2, xs, ys, R);
-  else load_rows_rowmajor(slice, h2, w2, xs, ys, R);
-  blend_packed(R, dx, dy, lv);
-}
 
 // ---- wave-cooperative fused lookup (fp16, NHWC): 8 lanes per pixel, one window ROW per lane --------
 // PMC on the lane-per-pixel kernel (tools/profile_lookup_only.py; TA_BUSY ~100 %, TCP_PENDING_STALL ~100 %
@@ -245,7 +124,7 @@ __device__ __forceinline__ void lookup_r3_packed(const _Float16* __restrict__ sl
 // hit the same few lines.  Here the 8 rows of a window are loaded by 8 adjacent lanes with ONE
 // instruction (two for a straddled tile8 row), so the TA sees the window as 2-4 whole 128-byte lines;
 // the row below comes from the neighbouring lane (ds_bpermute), each lane blends the 7 taps of its
-// row two at a time (packed fp16, see blend_packed), and the 196 channels of 8 consecutive pixels are
+// row two at a time (packed fp16, see above), and the 196 channels of 8 consecutive pixels are
 // assembled in LDS and stored as one contiguous 3136-byte run.
 template <bool TILED>
 __device__ __forceinline__ void load_row_coop(const _Float16* __restrict__ plane, int h2, int w2, int xs, int y1,
@@ -374,7 +253,7 @@ __global__ __launch_bounds__(256) void corr_pyramid_coop_kernel(
 
 // Sample one level for one pixel; writes 49 taps to out[(i*7+j)*plane] (plane == 0: `out` is a
 // 49-entry register array).
-template <typename T, bool TILED = false>
+template <typename T>
 __device__ __forceinline__ void lookup_r3(const T* __restrict__ slice, int h2, int w2,
                                           float x0, float y0, T* __restrict__ out, size_t plane) {
   const float fx0 = floorf(x0), fy0 = floorf(y0);
@@ -386,8 +265,7 @@ __device__ __forceinline__ void lookup_r3(const T* __restrict__ slice, int h2, i
   const T w_se = wcast<T>((1.0f - dx) * (1.0f - dy));
 
   T s[8][8];   // s[i][j]: i = x offset, j = y offset
-  if constexpr (TILED) load_window_tiled(slice, h2, w2, xs, ys, s);
-  else load_window<T>(slice, h2, w2, xs, ys, s);
+  load_window<T>(slice, h2, w2, xs, ys, s);
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
 #pragma unroll
@@ -427,32 +305,20 @@ __device__ __forceinline__ void emit_nhwc(const T (&lv)[49], T (&carry)[4], T* _
   for (int k = 0; k < total % 4; ++k) carry[k] = tmp[4 * npk + k];
 }
 
-template <typename T, int L, bool TILED>
+template <typename T, int L>
 __device__ __forceinline__ void level_nhwc(const T* __restrict__ vol, size_t pix, int h2, int w2, float2 c,
                                            T (&carry)[4], T* __restrict__ out) {
   const int h2l = h2 >> L, w2l = w2 >> L;
   const float sc = 1.0f / (float)(1 << L);
   T lv[49];
-  if constexpr (sizeof(T) == 2) {
-    const _Float16* hv = reinterpret_cast<const _Float16*>(vol);
-    if constexpr (TILED && L <= 1) {
-      const size_t plane = (size_t)((w2l + 7) >> 3) * ((h2l + 7) >> 3) * 64;
-      lookup_r3_packed<true>(hv + pix * plane, h2l, w2l, c.x * sc, c.y * sc, lv);
-    } else if (w2l >= 8) {
-      lookup_r3_packed<false>(hv + pix * (size_t)(h2l * w2l), h2l, w2l, c.x * sc, c.y * sc, lv);
-    } else {
-      lookup_r3<T>(vol + pix * (size_t)(h2l * w2l), h2l, w2l, c.x * sc, c.y * sc, lv, 0);
-    }
-  } else {
-    lookup_r3<T>(vol + pix * (size_t)(h2l * w2l), h2l, w2l, c.x * sc, c.y * sc, lv, 0);
-  }
+  lookup_r3<T>(vol + pix * (size_t)(h2l * w2l), h2l, w2l, c.x * sc, c.y * sc, lv, 0);
   emit_nhwc<T, L>(lv, carry, out);
 }
 
 // ---- fused 4-level pyramid lookup: coords [n,h1,w1,2] -> corr [n,4*49,h1,w1] ------------
 // NHWC=true writes the same logical tensor with channels-last strides ([n,h1,w1,196] in
 // memory), the layout MIOpen's NHWC convolutions of the update operator consume directly.
-template <typename T, bool NHWC, bool TILED = false>
+template <typename T, bool NHWC>
 __global__ __launch_bounds__(256) void corr_pyramid_kernel(
     const T* __restrict__ v0, const T* __restrict__ v1, const T* __restrict__ v2, const T* __restrict__ v3,
     const float* __restrict__ coords, T* __restrict__ corr, int hw1, int h2, int w2) {
@@ -464,10 +330,10 @@ __global__ __launch_bounds__(256) void corr_pyramid_kernel(
   if constexpr (NHWC) {
     T* out = corr + pix * 196;
     T carry[4];
-    level_nhwc<T, 0, TILED>(v0, pix, h2, w2, c, carry, out);
-    level_nhwc<T, 1, TILED>(v1, pix, h2, w2, c, carry, out);
-    level_nhwc<T, 2, TILED>(v2, pix, h2, w2, c, carry, out);
-    level_nhwc<T, 3, TILED>(v3, pix, h2, w2, c, carry, out);   // (3*49) % 4 + 49 = 52: no remainder
+    level_nhwc<T, 0>(v0, pix, h2, w2, c, carry, out);
+    level_nhwc<T, 1>(v1, pix, h2, w2, c, carry, out);
+    level_nhwc<T, 2>(v2, pix, h2, w2, c, carry, out);
+    level_nhwc<T, 3>(v3, pix, h2, w2, c, carry, out);   // (3*49) % 4 + 49 = 52: no remainder
   } else {
     T* out = corr + (size_t)n * 196 * hw1 + p;
     const T* vols[4] = {v0, v1, v2, v3};
@@ -598,16 +464,8 @@ int launch_pyramid(const void* v0, const void* v1, const void* v2, const void* v
     }
   }
   if (layout == GS_CORR_TILE8) {
-    if constexpr (sizeof(T) == 2) {
-      GS_REQUIRE(nhwc && w2 % 16 == 0, "corr_lookup_pyramid: tile8 needs channels_last output and w2 %% 16 == 0");
-      corr_pyramid_kernel<T, true, true><<<grid, block, 0, st>>>((const T*)v0, (const T*)v1, (const T*)v2, (const T*)v3,
-                                                                 coords, (T*)corr, hw1, h2, w2);
-      GS_CHECK_LAUNCH("corr_lookup_pyramid");
-      return GS_OK;
-    } else {
-      gs_set_error("corr_lookup_pyramid: the tile8 layout is fp16 only");
-      return GS_ERR_UNSUPPORTED;
-    }
+    gs_set_error("corr_lookup_pyramid: the tile8 layout is served by the fp16 channels_last kernel only");
+    return GS_ERR_UNSUPPORTED;
   }
   if (nhwc)
     corr_pyramid_kernel<T, true><<<grid, block, 0, st>>>((const T*)v0, (const T*)v1, (const T*)v2, (const T*)v3,
