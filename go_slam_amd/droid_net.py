@@ -362,12 +362,14 @@ class UpdateModule(nn.Module):
                              memory_format=torch.channels_last)
             self._hx, self._inp_tag = hx, None
         tag = getattr(self, "_inp_tag", None)
-        if tag is None or tag[0]() is not inp or tag[1] != inp._version:
+        self.gru._half_weights()                              # refreshes gru._hw_key if the weights changed
+        wkey = self.gru._hw_key
+        if tag is None or tag[0]() is not inp or tag[1] != inp._version or tag[2] != wkey:
             inp4 = inp.view(n, -1, ht, wd)
             if inp4.dtype != torch.float16 or not inp4.is_contiguous(memory_format=torch.channels_last):
                 inp4 = inp4.half().contiguous(memory_format=torch.channels_last)
             self._inp_pre = self.gru.inp_gates(inp4)
-            self._inp_tag = (weakref.ref(inp), inp._version)
+            self._inp_tag = (weakref.ref(inp), inp._version, wkey)
         return hx, self._inp_pre
 
     def _head_weights(self):
