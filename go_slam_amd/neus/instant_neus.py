@@ -96,6 +96,7 @@ class InstantNeuS(nn.Module):
         # half2 atomics, loss scale 128, unscaled before the optimiser sees it); torch.float32 = exact
         self.grid_grad_dtype = torch.float16
         self.grid_grad_scale = 128.0
+        self.fused_mlp_backward = True         # gs_mlp_backward (one MFMA kernel) instead of hipBLASLt GEMMs
 
     def get_training_parameters(self, ignore_keys=()):
         groups = {"sdf_network": list(self.sdf_network.get_training_parameters()["network"]),
@@ -247,6 +248,43 @@ def _colsum(A, chunk=8192):
     return _tn(ones, A, chunk)[0].reshape(-1)
 
 
+_FRAG_INDEX = {}
+
+
+def _mlp_fragment_index(device):
+    """Gather indices that turn tcnn's parameter vector (+ one trailing zero) into the 40 MFMA A-fragments of
+    gs_mlp_backward ([40,64,8], see include/goslam_neus.h); built once per device."""
+    idx = _FRAG_INDEX.get(device)
+    if idx is not None:
+        return idx
+    import numpy as np
+    ZERO = 10240
+    l = np.arange(64)[:, None]
+    e = np.arange(8)[None, :]
+    r, kk = (l & 31), 8 * (l >> 5) + e                       # row within the 32-row block, k within the 16-wide step
+    frags = []
+
+    def add(n_mt, n_ks, fn):
+        for mt in range(n_mt):
+            for ks in range(n_ks):
+                frags.append(fn(32 * mt + r + 0 * kk, 16 * ks + kk + 0 * r))
+    add(2, 5, lambda row, k: row * 80 + k)                                     # W1
+    add(2, 4, lambda row, k: 5120 + row * 64 + k)                               # W2
+    add(2, 1, lambda row, k: 9216 + k * 64 + row)                               # W3^T
+    add(2, 4, lambda row, k: 5120 + k * 64 + row)                               # W2^T
+    add(3, 4, lambda row, k: np.where(row < 80, k * 80 + row, ZERO))            # W1^T, rows padded to 96
+    idx = torch.from_numpy(np.stack(frags).astype(np.int64).reshape(-1)).to(device)
+    assert idx.numel() == 40 * 64 * 8
+    _FRAG_INDEX[device] = idx
+    return idx
+
+
+def _pack_mlp_fragments(W):
+    """One gather: [10240] fp16 parameters -> [40,64,8] fp16 fragments."""
+    ext = torch.cat([W.reshape(-1), W.new_zeros(1)])
+    return ext[_mlp_fragment_index(W.device)].view(40, 64, 8)
+
+
 class _NeusRenderFn(torch.autograd.Function):
     """Differentiable wrapper of the fused renderer.  Inputs 6.. are the trained parameters; the
     returned gradients are exactly what autograd produces for the reference's graph (incl. the
@@ -285,25 +323,37 @@ class _NeusRenderFn(torch.autograd.Function):
                                          _lib.ptr(d_normal), _lib.ptr(d_wsum), _lib.ptr(d_alpha), _lib.ptr(d_rgb),
                                          _lib.ptr(d_grad), n, s, st)
         _lib.check(rc, "InstantNeuS.backward(rays)")
-        # ---- colour MLP backward: fp16 GEMMs with fp32 accumulation and tiny-cuda-nn's loss scale (128)
-        # on every gradient that lives in fp16 -- the reference's network trains exactly like this
-        # (tcnn FullyFusedMLP backward); fp32 copies of the [np,64] activations are never made.
+        # ---- colour MLP backward in fp16 with fp32 accumulation and tiny-cuda-nn's loss scale (128) on every
+        # gradient that lives in fp16 -- the reference's network trains exactly like this (tcnn FullyFusedMLP
+        # backward).  Default: the fused MFMA kernel; fallback: the same maths as hipBLASLt GEMMs.
         LS = float(model.grid_grad_scale)
         X = S["mlp_in"]                                     # [np,80] f16
         W = S["mlp"]
-        W1, W2, W3 = W[:5120].view(64, 80), W[5120:9216].view(64, 64), W[9216:].view(16, 64)
-        H1 = torch.relu(X @ W1.t())
-        H2 = torch.relu(H1 @ W2.t())
-        y = S["rgb"].view(np_, 3).float()
-        dpre = torch.zeros(np_, 16, dtype=torch.float16, device=dev)
-        dpre[:, :3] = (d_rgb * y * (1.0 - y)) * LS          # sigmoid', scaled, padded to the 16 output rows
-        dW3 = _tn(dpre, H2) / LS                            # [16,64]; rows 3.. are zero
-        dH2 = (dpre @ W3) * (H2 > 0)
-        dW2 = _tn(dH2, H1) / LS
-        dH1 = (dH2 @ W2) * (H1 > 0)
-        dW1 = _tn(dH1, X) / LS
-        dX = (dH1 @ W1).contiguous()                        # [np,80] f16, loss-scaled; unscaled inside the per-point kernel
-        g_mlp = torch.cat([dW1.reshape(-1), dW2.reshape(-1), dW3.reshape(-1)])
+        if model.fused_mlp_backward:
+            # one MFMA kernel: forward recompute + dX + the three weight gradients (gs_mlp_backward)
+            wpack = _pack_mlp_fragments(W)
+            nb = L.gs_mlp_backward_blocks(np_)
+            partial = torch.empty(nb, 10240, **f32)
+            dX = torch.empty(np_, 80, dtype=torch.float16, device=dev)
+            with torch.cuda.device(dev):
+                rc = L.gs_mlp_backward(_lib.ptr(X), _lib.ptr(wpack), _lib.ptr(d_rgb), _lib.ptr(S["rgb"]), LS,
+                                       _lib.ptr(dX), _lib.ptr(partial), np_, st)
+            _lib.check(rc, "InstantNeuS.backward(mlp)")
+            g_mlp = partial.sum(0) / LS
+        else:
+            W1, W2, W3 = W[:5120].view(64, 80), W[5120:9216].view(64, 64), W[9216:].view(16, 64)
+            H1 = torch.relu(X @ W1.t())
+            H2 = torch.relu(H1 @ W2.t())
+            y = S["rgb"].view(np_, 3).float()
+            dpre = torch.zeros(np_, 16, dtype=torch.float16, device=dev)
+            dpre[:, :3] = (d_rgb * y * (1.0 - y)) * LS      # sigmoid', scaled, padded to the 16 output rows
+            dW3 = _tn(dpre, H2) / LS                        # [16,64]; rows 3.. are zero
+            dH2 = (dpre @ W3) * (H2 > 0)
+            dW2 = _tn(dH2, H1) / LS
+            dH1 = (dH2 @ W2) * (H1 > 0)
+            dW1 = _tn(dH1, X) / LS
+            dX = (dH1 @ W1).contiguous()                    # [np,80] f16, loss-scaled; unscaled inside the per-point kernel
+            g_mlp = torch.cat([dW1.reshape(-1), dW2.reshape(-1), dW3.reshape(-1)])
         # ---- per-point backward: alpha chain, SDF linear, hash grid (value + second-order paths)
         # hash-table gradient: tcnn's mode (fp16, packed atomics, loss scale 128) or fp32 atomics
         half_grads = model.grid_grad_dtype == torch.float16

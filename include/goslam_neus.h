@@ -87,6 +87,20 @@ int gs_neus_backward_rays(const float* alpha, const void* rgb, const float* z_mi
                           const float* d_depth_var, const float* d_normal, const float* d_weight_sum,
                           float* d_alpha, float* d_rgb, float* d_grad, int n, int s, gs_stream_t stream);
 
+/* Backward of the fused colour MLP (tcnn FullyFusedMLP 67(->80)->64->64->3(->16), ReLU, sigmoid output) in ONE
+ * kernel: recomputes H1, H2 as gs_mlp_forward does, then dX and the three weight gradients on MFMA.
+ *   x f16 [n,80] (the saved MLP input rows), d_rgb f32 [n,3] (gradient w.r.t. the sigmoid outputs), rgb f16
+ *   [n,3] (the saved outputs), loss_scale (tcnn: 128) multiplies every gradient that travels in fp16.
+ *   wpack f16 [40][64][8]: MFMA A-fragments A[l][e] = M[32 mt + (l&31)][16 ks + 8 (l>>5) + e] of, in this
+ *   order, M = W1 (mt<2, ks<5), W2 (mt<2, ks<4), W3^T (mt<2, ks=0), W2^T (mt<2, ks<4), W1^T zero-padded to 96
+ *   rows (mt<3, ks<4), each block mt-major.
+ * Outputs: dx f16 [n,80] = loss_scale * dL/dx;  partial f32 [gs_mlp_backward_blocks(n)][10240]: per-workgroup
+ *   partial sums of loss_scale * (dW1 [64,80] | dW2 [64,64] | dW3 [16,64]) in tcnn's parameter layout -- sum
+ *   over the first axis and divide by loss_scale.                                                        */
+int gs_mlp_backward_blocks(int n);
+int gs_mlp_backward(const void* x, const void* wpack, const float* d_rgb, const void* rgb, float loss_scale,
+                    void* dx, float* partial, int n, gs_stream_t stream);
+
 /* Stage 2 (per sample point): chain d_alpha, d_sdf (loss on the sdf samples), d_grad (stage 1 +
  * the eikonal term d_gerr_ray[ray] * d(|grad|-1)^2 * mask + the colour MLP's input gradient dX[:,33:36]),
  * d_feat = dX[:,36:67] and d_emb = dX[:,0:33] through NeuS alpha, the SDF linear layer and the hash
