@@ -59,7 +59,7 @@ SIGNATURES = {
     "gs_neus_backward_rays": (c_int, [_P] * 13 + [c_int, c_int, _P]),
     "gs_mlp_backward_blocks": (c_int, [c_int]),
     "gs_mlp_backward": (c_int, [_P, _P, _P, _P, c_float, _P, _P, c_int, _P]),
-    "gs_neus_backward_points": (c_int, [_P] * 7 + [c_float] + [_P] * 8 + [c_int, c_float, _P, _P, c_int, c_float] + [_P] * 5 + [c_int, c_float, _P, c_int, c_int, _P]),
+    "gs_neus_backward_points": (c_int, [_P] * 7 + [c_float] + [_P] * 8 + [c_int, c_float, _P, _P, c_int, c_float] + [_P] * 5 + [c_int, c_float, c_int, _P, c_int, c_int, _P]),
 }
 
 

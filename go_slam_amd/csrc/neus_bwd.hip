@@ -134,7 +134,7 @@ struct BwdArgs {
   const float* d_alpha; const float* d_sdf; const float* d_grad; const void* dX;
   const float* d_gerr_ray;
   float* grid_grad; _Float16* grid_grad16; float grad_scale16; void* d_out; void* lin_in; void* dw0; void* d_arg; void* pts; float* d_inv_s;
-  int rows16; float row_scale; int dx16; float dx_inv_scale;
+  int rows16; float row_scale; int dx16; float dx_inv_scale; int row_stride16;
   int n, s;
 };
 
@@ -241,15 +241,17 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 // store `ndw` dwords per point (a multiple of 4) from tile[point][off .. off+ndw) to rows of `ndw` dwords
+// `stride16` = distance between consecutive points' rows in 16-byte units (0: rows are contiguous)
 __device__ __forceinline__ void tile_flush(const uint32_t* __restrict__ tile, int off, int ndw, void* __restrict__ base,
-                                           size_t p0, size_t np, int lane) {
+                                           size_t p0, size_t np, int lane, int stride16) {
   const int ppp = ndw >> 2;                       // 16-byte pieces per point
-  uint4* dst = reinterpret_cast<uint4*>(base) + p0 * ppp;
+  const int st = stride16 ? stride16 : ppp;
+  uint4* dst = reinterpret_cast<uint4*>(base) + p0 * st;
   for (int idx = lane; idx < 64 * ppp; idx += 64) {
     const int pt = idx / ppp, part = idx - pt * ppp;
     if (p0 + pt < np) {
       const uint32_t* t = tile + pt * ROW_TS + off + 4 * part;
-      dst[idx] = make_uint4(t[0], t[1], t[2], t[3]);
+      dst[(size_t)pt * st + part] = make_uint4(t[0], t[1], t[2], t[3]);
     }
   }
 }
@@ -443,8 +445,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
   if (r16) {
     // lin | w0 rows are complete: flush them, then reuse the tile for d_out, d_arg and pts
     wave_sync_lds();
-    tile_flush(tile, 0, 20, A.lin_in, wave_p0, np_all, lane);
-    tile_flush(tile, 20, 20, A.dw0, wave_p0, np_all, lane);
+    tile_flush(tile, 0, 20, A.lin_in, wave_p0, np_all, lane, A.row_stride16);
+    tile_flush(tile, 20, 20, A.dw0, wave_p0, np_all, lane, A.row_stride16);
     wave_sync_lds();
     uint32_t* trow = tile + lane * ROW_TS;
 #pragma unroll
@@ -464,11 +466,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
 #pragma unroll
       for (int e = 0; e < 4; ++e) trow[16 + (c0 >> 1) + e] = pack2h(da[2 * e], da[2 * e + 1]);
     }
-    trow[36] = pack2h(pt[0], pt[1]); trow[37] = pack2h(pt[2], 0.0f); trow[38] = 0u; trow[39] = 0u;
+    trow[36] = pack2h(pt[0], pt[1]); trow[37] = pack2h(pt[2], 1.0f); trow[38] = 0u; trow[39] = 0u;   // (x, y, z, 1): the 1 yields column sums
     wave_sync_lds();
-    tile_flush(tile, 0, 16, A.d_out, wave_p0, np_all, lane);
-    tile_flush(tile, 16, 20, A.d_arg, wave_p0, np_all, lane);
-    tile_flush(tile, 36, 4, A.pts, wave_p0, np_all, lane);
+    tile_flush(tile, 0, 16, A.d_out, wave_p0, np_all, lane, A.row_stride16);
+    tile_flush(tile, 16, 20, A.d_arg, wave_p0, np_all, lane, A.row_stride16);
+    tile_flush(tile, 36, 4, A.pts, wave_p0, np_all, lane, A.row_stride16);
   } else if (valid) {
     float dxe[40];
 #pragma unroll
@@ -520,7 +522,10 @@ extern "C" int gs_neus_backward_points(const float* rays_o, const float* rays_d,
                                        float dx_scale, const float* d_gerr_ray,
                                        void* grid_grad, int grid_grad_dtype, float grid_grad_scale, void* d_out,
                                        void* lin_in, void* dw0, void* d_arg, void* pts, int row_dtype,
-                                       float row_scale, float* d_inv_s, int n, int s, gs_stream_t stream) {
+                                       float row_scale, int row_stride, float* d_inv_s, int n, int s,
+                                       gs_stream_t stream) {
+  GS_REQUIRE(row_stride == 0 || (row_dtype == GS_F16 && row_stride >= 40 && row_stride % 8 == 0),
+             "neus_backward_points: row_stride needs f16 rows, >= 40, a multiple of 8");
   GS_REQUIRE(dx_dtype == GS_F32 || dx_dtype == GS_F16, "neus_backward_points: dX dtype f32 or f16");
   GS_REQUIRE(row_dtype == GS_F32 || row_dtype == GS_F16, "neus_backward_points: row dtype f32 or f16");
   GS_REQUIRE(dx_scale > 0.0f && row_scale > 0.0f, "neus_backward_points: scales must be positive");
@@ -540,7 +545,7 @@ extern "C" int gs_neus_backward_points(const float* rays_o, const float* rays_d,
   A.grid_grad16 = grid_grad_dtype == GS_F16 ? (_Float16*)grid_grad : nullptr;
   A.grad_scale16 = grid_grad_scale;
   A.d_out = d_out; A.lin_in = lin_in; A.dw0 = dw0; A.d_arg = d_arg; A.pts = pts;
-  A.rows16 = row_dtype == GS_F16; A.row_scale = row_scale; A.dx16 = dx_dtype == GS_F16; A.dx_inv_scale = 1.0f / dx_scale;
+  A.rows16 = row_dtype == GS_F16; A.row_scale = row_scale; A.row_stride16 = row_stride / 8; A.dx16 = dx_dtype == GS_F16; A.dx_inv_scale = 1.0f / dx_scale;
   A.d_inv_s = d_inv_s; A.n = n; A.s = s;
   neus_point_bwd_kernel<<<gs_cdiv(n * s, 256), 256, 0, (hipStream_t)stream>>>(A, host_meta());
   GS_CHECK_LAUNCH("neus_backward_points");

@@ -359,12 +359,12 @@ class _NeusRenderFn(torch.autograd.Function):
         half_grads = model.grid_grad_dtype == torch.float16
         gscale = float(model.grid_grad_scale) if half_grads else 1.0
         grid_acc = torch.zeros(S["grid"].numel(), dtype=model.grid_grad_dtype, device=dev)
-        f16 = dict(dtype=torch.float16, device=dev)        # per-point rows: fp16, gradient rows loss-scaled
-        d_out = torch.empty(np_, 32, **f16)                 # row strides padded to multiples of 8: odd fp16
-        lin_in = torch.empty(np_, 40, **f16)                # leading dimensions send hipBLASLt down a 10x slower path;
-        dw0 = torch.empty(np_, 40, **f16)                   # the kernel writes the pad columns as zeros
-        d_arg = torch.empty(np_, 40, **f16)
-        pts = torch.empty(np_, 8, **f16)
+        # per-point rows: fp16, gradient rows loss-scaled, all five as column blocks of ONE [np,160] matrix
+        # d_out 0:32 | lin_in 32:72 | dw0 72:112 | d_arg 112:152 | pts,1 152:160 -- its Gram matrix (one split-K
+        # GEMM) contains every dense-parameter gradient: d_out^T lin_in, the column sums (via the ones column)
+        # and pts^T d_arg
+        rows = torch.empty(np_, 160, dtype=torch.float16, device=dev)
+        d_out, lin_in, dw0, d_arg, pts = (rows[:, a:b] for a, b in ((0, 32), (32, 72), (72, 112), (112, 152), (152, 160)))
         d_invs = torch.zeros(1, **f32)
         bh, _ = model._bounds_host()
         with torch.cuda.device(dev):
@@ -374,14 +374,15 @@ class _NeusRenderFn(torch.autograd.Function):
                                            _lib.ptr(S["mask"]), _lib.ptr(d_alpha), _lib.ptr(d_sdf), _lib.ptr(d_grad),
                                            _lib.ptr(dX), 0, LS, _lib.ptr(d_gerr.reshape(-1).contiguous()),
                                            _lib.ptr(grid_acc), 0 if half_grads else 1, gscale,
-                                           _lib.ptr(d_out), _lib.ptr(lin_in), _lib.ptr(dw0),
-                                           _lib.ptr(d_arg), _lib.ptr(pts), 0, LS, _lib.ptr(d_invs), n, s, st)
+                                           d_out.data_ptr(), lin_in.data_ptr(), dw0.data_ptr(),
+                                           d_arg.data_ptr(), pts.data_ptr(), 0, LS, 160, _lib.ptr(d_invs), n, s, st)
         _lib.check(rc, "InstantNeuS.backward(points)")
         grid_grad = grid_acc.float().mul_(1.0 / gscale) if half_grads else grid_acc
-        g_sdf_w = _tn(d_out, lin_in)[:, :35] / LS
-        g_sdf_w[0] += _colsum(dw0)[:35] / LS
-        g_sdf_b = _colsum(d_out) / LS
-        g_cB = _tn(pts, d_arg)[:3, :33] / LS
+        G = _tn(rows, rows) / LS                            # [160,160] Gram matrix, fp32
+        g_sdf_w = G[0:32, 32:67].clone()
+        g_sdf_w[0] += G[155, 72:107]                        # column sums of dw0 (row 155 = the ones column)
+        g_sdf_b = G[155, 0:32].clone()
+        g_cB = G[152:155, 112:145].clone()
         sf = model.variance_network.scale_factor
         raw = math.exp(ctx.var * sf)
         g_var = (d_invs[0] * sf * ctx.inv_s) if 1e-6 <= raw <= 1e6 else torch.zeros((), **f32)

@@ -109,8 +109,11 @@ int gs_mlp_backward(const void* x, const void* wpack, const float* d_rgb, const 
  *   holding dx_scale * gradient (the loss-scaled output of an fp16 GEMM).
  *   The per-point rows d_out, lin_in, dw0, d_arg, pts are f32 or f16 (row_dtype); the gradient-valued ones
  *   (d_out, dw0, d_arg) are multiplied by row_scale before they are stored (loss scale for fp16 rows).
- *   f16 rows are padded to GEMM-friendly strides -- lin_in / dw0 / d_arg 40, pts 8 (d_out stays 32); the pad
- *   columns are written as zeros.
+ *   f16 rows are padded to GEMM-friendly widths -- lin_in / dw0 / d_arg 40, pts 8 (d_out stays 32); the pad
+ *   columns are written as zeros, except pts[:,3] = 1 (so that pts^T @ rows also yields column sums).
+ *   row_stride = 0: five separate contiguous buffers; row_stride = R (f16 only, R % 8 == 0): consecutive points'
+ *   rows are R elements apart in every buffer, i.e. the five pointers address column blocks of ONE [n*s, R]
+ *   matrix whose Gram matrix then delivers every dense-parameter gradient in a single GEMM.
  * Outputs: grid_grad [total*2] (atomically accumulated; zero it first) -- dtype GS_F32, or GS_F16 =
  * tiny-cuda-nn's mode: fp16 table gradient, both features of an entry added with one packed atomic,
  * every contribution pre-multiplied by grid_grad_scale (tcnn's loss scale, 128; the caller divides it
@@ -126,7 +129,7 @@ int gs_neus_backward_points(const float* rays_o, const float* rays_d, const floa
                             const void* dX, int dx_dtype, float dx_scale, const float* d_gerr_ray,
                             void* grid_grad, int grid_grad_dtype, float grid_grad_scale, void* d_out,
                             void* lin_in, void* dw0, void* d_arg, void* pts, int row_dtype, float row_scale,
-                            float* d_inv_s, int n, int s, gs_stream_t stream);
+                            int row_stride, float* d_inv_s, int n, int s, gs_stream_t stream);
 
 #ifdef __cplusplus
 }
