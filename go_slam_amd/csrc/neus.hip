@@ -33,8 +33,9 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void render_sample_kernel(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
     const float* __restrict__ bound, const float* __restrict__ t_samples, const float* __restrict__ t_surface,
-    const float* __restrict__ perturb, float gt_max, float* __restrict__ z_vals, float* __restrict__ dists,
-    int n, int ns, int nsurf) {
+    const float* __restrict__ perturb, float gt_max_host, const float* __restrict__ gt_max_dev,
+    float* __restrict__ z_vals, float* __restrict__ dists, int n, int ns, int nsurf) {
+  const float gt_max = gt_max_dev ? *gt_max_dev : gt_max_host;
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= n) return;
   const float o[3] = {rays_o[r * 3 + 0], rays_o[r * 3 + 1], rays_o[r * 3 + 2]};
@@ -111,8 +112,9 @@ __global__ __launch_bounds__(256) void render_sample_kernel(
 __global__ __launch_bounds__(256) void render_sample_wave_kernel(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ gt_depth,
     const float* __restrict__ bound, const float* __restrict__ t_samples, const float* __restrict__ t_surface,
-    const float* __restrict__ perturb, float gt_max, float* __restrict__ z_vals, float* __restrict__ dists,
-    int n, int ns, int nsurf) {
+    const float* __restrict__ perturb, float gt_max_host, const float* __restrict__ gt_max_dev,
+    float* __restrict__ z_vals, float* __restrict__ dists, int n, int ns, int nsurf) {
+  const float gt_max = gt_max_dev ? *gt_max_dev : gt_max_host;
   __shared__ float sa[4][64], sb[4][64], sz[4][128];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + wave;
@@ -662,19 +664,19 @@ extern "C" int gs_grid_meta_default(gs_grid_meta* m) {
 
 extern "C" int gs_render_sample(const float* rays_o, const float* rays_d, const float* gt_depth, const float* bound,
                                 const float* t_samples, const float* t_surface, const float* perturb, float gt_max,
-                                float* z_vals, float* dists, int n, int n_samples, int n_surface,
-                                gs_stream_t stream) {
+                                const float* gt_max_dev, float* z_vals, float* dists, int n, int n_samples,
+                                int n_surface, gs_stream_t stream) {
   GS_REQUIRE(rays_o && rays_d && bound && t_samples && z_vals && dists, "render_sample: null pointer");
   GS_REQUIRE(n >= 0 && n_samples > 0 && n_surface >= 0, "render_sample: bad shape");
   GS_REQUIRE(n_surface == 0 || t_surface, "render_sample: t_surface required");
   if (n == 0) return GS_OK;
   if (n_samples <= 64 && n_surface <= 64)
     render_sample_wave_kernel<<<gs_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(
-        rays_o, rays_d, gt_depth, bound, t_samples, t_surface, perturb, gt_max, z_vals, dists, n, n_samples,
+        rays_o, rays_d, gt_depth, bound, t_samples, t_surface, perturb, gt_max, gt_max_dev, z_vals, dists, n, n_samples,
         gt_depth ? n_surface : 0);
   else
     render_sample_kernel<<<gs_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(
-        rays_o, rays_d, gt_depth, bound, t_samples, t_surface, perturb, gt_max, z_vals, dists, n, n_samples,
+        rays_o, rays_d, gt_depth, bound, t_samples, t_surface, perturb, gt_max, gt_max_dev, z_vals, dists, n, n_samples,
         gt_depth ? n_surface : 0);
   GS_CHECK_LAUNCH("render_sample");
   return GS_OK;

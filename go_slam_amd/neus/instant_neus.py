@@ -122,8 +122,15 @@ class InstantNeuS(nn.Module):
         return self._host_bounds
 
     def _inv_s(self):
-        var = float(self.variance_network.variance.detach())          # host scalar (1 small D2H)
-        return var, min(max(math.exp(var * self.variance_network.scale_factor), 1e-6), 1e6)
+        """(variance, inv_s) as host scalars; the D2H copy happens only when the parameter changed (an
+        optimiser step, load_state_dict) -- rendering with fixed weights issues no host sync."""
+        p = self.variance_network.variance
+        key = (p._version, p.data_ptr())
+        if getattr(self, "_inv_s_key", None) != key:
+            var = float(p.detach())
+            self._inv_s_val = (var, min(max(math.exp(var * self.variance_network.scale_factor), 1e-6), 1e6))
+            self._inv_s_key = key
+        return self._inv_s_val
 
     def _needs_grad(self):
         ps = [self.sdf_network.encoding.encoding.params, self.sdf_network.sdf_layer.weight,

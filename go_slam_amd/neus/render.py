@@ -34,9 +34,10 @@ class Renderer:
         nsurf = self.N_surface if gt_depth is not None else 0
         if gt_depth is not None:
             gt_depth = gt_depth.reshape(-1).float().contiguous()
-            gt_max = float(gt_depth.max())         # the reference also reduces to a scalar here (:121,:140)
+            gt_max_dev = gt_depth.max().reshape(1)  # stays on the device: the kernel reads it (the reference's
+            gt_max = 0.0                            # .max() at :121,:140 costs a host sync per batch)
         else:
-            gt_max = 0.0
+            gt_max, gt_max_dev = 0.0, None
         if self.perturb > 0 and perturb_rand is None:
             perturb_rand = torch.rand(ns, device=dev)           # one vector shared by all rays (:159)
         z = torch.empty(n, ns + nsurf, dtype=torch.float32, device=dev)
@@ -47,7 +48,7 @@ class Renderer:
                 _lib.ptr(gt_depth), _lib.ptr(bound.to(dev).float().contiguous()), _lib.ptr(self._linspace(ns, dev)),
                 _lib.ptr(self._linspace(nsurf, dev) if nsurf else None),
                 _lib.ptr(perturb_rand.float().contiguous() if perturb_rand is not None else None), gt_max,
-                _lib.ptr(z), _lib.ptr(d), n, ns, nsurf, _lib.stream_ptr(dev))
+                _lib.ptr(gt_max_dev), _lib.ptr(z), _lib.ptr(d), n, ns, nsurf, _lib.stream_ptr(dev))
         _lib.check(rc, "Renderer.sample")
         return z, d
 

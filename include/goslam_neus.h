@@ -37,11 +37,12 @@ int gs_grid_meta_default(gs_grid_meta* meta_host);
  *   rays_o/rays_d f32 [n,3]; gt_depth f32 [n] or NULL (then n_surface is ignored);
  *   bound f32 [3,2] (device); t_samples f32 [n_samples] = torch.linspace(0,1,n_samples),
  *   t_surface f32 [n_surface] likewise; perturb f32 [n_samples] = the shared
- *   torch.rand(N_samples) vector (:159) or NULL; gt_max = gt_depth.max() (host scalar);
+ *   torch.rand(N_samples) vector (:159) or NULL; gt_max = gt_depth.max() as a host scalar, or -- when
+ *   gt_max_dev != NULL -- read from that device scalar instead (no host round trip per batch);
  *   -> z_vals, dists f32 [n, n_samples + n_surface].                                          */
 int gs_render_sample(const float* rays_o, const float* rays_d, const float* gt_depth,
                      const float* bound, const float* t_samples, const float* t_surface,
-                     const float* perturb, float gt_max, float* z_vals, float* dists,
+                     const float* perturb, float gt_max, const float* gt_max_dev, float* z_vals, float* dists,
                      int n, int n_samples, int n_surface, gs_stream_t stream);
 
 /* tcnn.Encoding.__call__ (src/InstantNeuS.py:62,86): x f32 [n,3] in [0,1], grid f16
