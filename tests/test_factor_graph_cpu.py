@@ -86,3 +86,39 @@ def test_masked_sdf_error_equals_gather_formulation():
                                   model.sdf_sparse_factor)
     torch.testing.assert_close(e, re, rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(f, rf, rtol=1e-5, atol=1e-7)
+
+
+def test_mfma_fragment_packers_match_their_documented_layouts():
+    """Host-side packing of weights into MFMA A-fragments (gs_conv1x1, gs_conv3x3_head, gs_mlp_backward):
+    element (frag, lane l, e) must be M[32 mt + (l & 31)][16 ks + 8 (l >> 5) + e] of the documented matrix."""
+    from go_slam_amd.droid_net import pack_1x1_weight, pack_head_weight
+    from go_slam_amd.neus.instant_neus import _pack_mlp_fragments
+    g = torch.Generator().manual_seed(9)
+    # 1x1: W [N,K,1,1], K = 196 -> 13 k-steps, zero padded
+    W = torch.randn(64, 196, 1, 1, generator=g)
+    P = pack_1x1_weight(W).float()                         # [N/32, KS, 64, 8]
+    Wp = torch.zeros(64, 208)
+    Wp[:, :196] = W.reshape(64, 196).half().float()
+    for nb, ks, l, e in [(0, 0, 0, 0), (1, 12, 63, 7), (1, 5, 37, 3), (0, 12, 31, 4)]:
+        assert P[nb, ks, l, e] == Wp[32 * nb + (l & 31), 16 * ks + 8 * (l >> 5) + e]
+    # 3x3 heads: W [O,128,3,3] -> wpack[ks][l][e] = W[o][16 ks + 8 (l>>5) + e][ky][kx], (l & 31) = (3 ky + kx) O + o
+    for O in (1, 2):
+        W = torch.randn(O, 128, 3, 3, generator=g)
+        P = pack_head_weight(W).float()
+        Wh = W.half().float()
+        for ks, l, e in [(0, 0, 0), (7, 40, 7), (3, 17, 2), (5, 9 * O - 1, 1), (2, 31, 0), (6, 63, 5)]:
+            col = l & 31
+            want = Wh[col % O, 16 * ks + 8 * (l >> 5) + e, (col // O) // 3, (col // O) % 3] if col < 9 * O else 0.0
+            assert P[ks, l, e] == want, (O, ks, l, e)
+    # colour-MLP backward: 40 fragments of W1 | W2 | W3^T | W2^T | W1^T (padded to 96 rows)
+    Wv = torch.randn(10240, generator=g)
+    P = _pack_mlp_fragments(Wv)
+    W1, W2, W3 = Wv[:5120].view(64, 80), Wv[5120:9216].view(64, 64), Wv[9216:].view(16, 64)
+    mats = [(0, W1, 5), (10, W2, 4), (18, W3.t(), 1), (20, W2.t(), 4)]
+    for base, M, nks in mats:
+        for mt, ks, l, e in [(0, 0, 0, 0), (1, nks - 1, 63, 7), (1, 0, 33, 2)]:
+            assert P[base + mt * nks + ks, l, e] == M[32 * mt + (l & 31), 16 * ks + 8 * (l >> 5) + e]
+    W1T = torch.zeros(96, 64)
+    W1T[:80] = W1.t()
+    for mt, ks, l, e in [(0, 0, 0, 0), (2, 3, 63, 7), (2, 1, 15, 3), (2, 2, 16, 0)]:
+        assert P[28 + mt * 4 + ks, l, e] == W1T[32 * mt + (l & 31), 16 * ks + 8 * (l >> 5) + e]
