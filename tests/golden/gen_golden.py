@@ -17,6 +17,7 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
   * geom/projective_ops  projective_transform with and without Jacobians      -> proj_*.npz
   * render.py            Renderer.render_batch_ray sample placement           -> render_sample.npz
   * nerf_func.py         build_rays                                            -> build_rays.npz
+  * droid_net.py + modules/gru.py  UpdateModule / ConvGRU / GraphAgg / cvx_upsample (CPU fp32)  -> update_module.npz
   * InstantNeuS.py       normalisation, masking, sdf gradient by autograd.grad, get_alpha,
                          compositing, compute_sdf_error                       -> neus_forward.npz
 The stand-ins themselves (tcnn / lietorch / CUDA kernels) stay "parity unpinned" (DESIGN.md 4).
@@ -212,10 +213,62 @@ def gen_rays():
     save("build_rays.npz", depth=depth, color=color, mask=mask, c2w=c2w, rays_o=o, rays_d=d, ray_depth=dep, ray_color=col)
 
 
+def named_weights(state_dict, seed=131):
+    """Deterministic weights by parameter NAME (so the test can rebuild them without storing 10 MB):
+    randn from a generator seeded with the name's crc32, scaled like a fan-in init."""
+    import zlib
+    out = {}
+    for name, t in state_dict.items():
+        g = torch.Generator().manual_seed(seed + zlib.crc32(name.encode()) % (2 ** 31))
+        fan_in = t[0].numel() if t.dim() > 1 else 16
+        out[name] = torch.randn(t.shape, generator=g) / (fan_in ** 0.5)
+    return out
+
+
+def gen_update():
+    """The reference's own UpdateModule / ConvGRU / GraphAgg (src/droid_net.py:34-140, src/modules/gru.py) on a
+    tiny graph, CPU fp32.  torch_scatter is absent: scatter_mean is stood in by its published definition."""
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter_mean(src, index, dim=1):
+        assert dim == 1
+        n = int(index.max()) + 1
+        out = torch.zeros(src.shape[0], n, *src.shape[2:], dtype=src.dtype)
+        out.index_add_(1, index, src)
+        cnt = torch.bincount(index, minlength=n).clamp(min=1).to(src.dtype)
+        return out / cnt.view(1, -1, *([1] * (src.dim() - 2)))
+    ts.scatter_mean = scatter_mean
+    sys.modules["torch_scatter"] = ts
+    mods = sys.modules["refsrc.modules"]
+    mods.GradientClip = importlib.import_module("refsrc.modules.clipping").GradientClip
+    mods.ConvGRU = importlib.import_module("refsrc.modules.gru").ConvGRU
+    mods.BasicEncoder = importlib.import_module("refsrc.modules.extractor").BasicEncoder
+    corr = importlib.import_module("refsrc.modules.corr")
+    mods.CorrBlock, mods.AltCorrBlock = corr.CorrBlock, corr.AltCorrBlock
+    dn = importlib.import_module("refsrc.droid_net")
+    op = dn.UpdateModule().eval()
+    op.load_state_dict(named_weights(op.state_dict()))
+    g = torch.Generator().manual_seed(137)
+    E, h, w = 5, 6, 8
+    net = torch.tanh(torch.randn(1, E, 128, h, w, generator=g))
+    inp = torch.relu(torch.randn(1, E, 128, h, w, generator=g))
+    corr_f = 0.5 * torch.randn(1, E, 196, h, w, generator=g)
+    flow = torch.randn(1, E, 4, h, w, generator=g)
+    ii = torch.tensor([2, 0, 2, 1, 0])
+    jj = torch.tensor([0, 1, 1, 2, 2])
+    n2, delta, weight, eta, upmask = op(net, inp, corr_f, flow, ii, jj)
+    data = torch.rand(3, h, w, 1, generator=g)
+    up = dn.cvx_upsample(data, upmask[0])
+    save("update_module.npz", net=net, inp=inp, corr=corr_f, flow=flow, ii=ii, jj=jj, net_out=n2, delta=delta,
+         weight=weight, eta=eta, upmask=upmask, up_data=data, up_out=up,
+         keys=np.array(sorted(op.state_dict().keys())))
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate the fixtures"
     install_stubs()
     with torch.no_grad():
+        gen_update()
         gen_corr()
         gen_proj()
         gen_render()

@@ -268,3 +268,26 @@ def test_build_rays_matches_reference():
                                 "cpu", mask=g["mask"])
     assert torch.equal(o, g["rays_o"]) and torch.equal(d, g["rays_d"])
     assert torch.equal(dep, g["ray_depth"]) and torch.equal(col, g["ray_color"])
+
+
+def test_update_module_matches_reference_droid_net():
+    """The host mirror of DroidNet.update (go_slam_amd/droid_net.py) against the reference's OWN UpdateModule /
+    ConvGRU / GraphAgg / cvx_upsample run on the CPU (fixture generated by tests/golden/gen_golden.py):
+    identical state-dict keys, and the same outputs for the same name-seeded weights."""
+    import importlib.util
+    from go_slam_amd.droid_net import UpdateModule, cvx_upsample
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(os.path.dirname(__file__), "golden",
+                                                                             "gen_golden.py"))
+    gg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gg)
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "update_module.npz"))
+    op = UpdateModule().eval()
+    assert sorted(op.state_dict().keys()) == [str(k) for k in G["keys"]]
+    op.load_state_dict(gg.named_weights(op.state_dict()))
+    t = lambda k: torch.from_numpy(np.asarray(G[k]))
+    with torch.no_grad():
+        net, delta, weight, eta, upmask = op(t("net"), t("inp"), t("corr"), t("flow"), t("ii"), t("jj"))
+        up = cvx_upsample(t("up_data"), upmask[0])
+    for name, got in (("net_out", net), ("delta", delta), ("weight", weight), ("eta", eta), ("upmask", upmask),
+                      ("up_out", up)):
+        torch.testing.assert_close(got, t(name), rtol=1e-4, atol=1e-5, msg=lambda m, n=name: f"{n}: {m}")
