@@ -93,6 +93,10 @@ class SE3:
     def act(self, p):
         return self * p
 
+    def retr(self, a):
+        """lietorch retraction: exp(a) * X (left perturbation), as used by src/geom/ba.py pose_retr."""
+        return self.__class__.exp(a) * self
+
     def adjT(self, a):
         """Ad(X)^T a for a covector a = [a_tau, a_phi]."""
         t, q = self.data[..., :3], self.data[..., 3:]

@@ -17,6 +17,7 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
   * geom/projective_ops  projective_transform with and without Jacobians      -> proj_*.npz
   * render.py            Renderer.render_batch_ray sample placement           -> render_sample.npz
   * nerf_func.py         build_rays                                            -> build_rays.npz
+  * geom/ba.py + chol.py  BA: the pure-PyTorch dense bundle adjustment (one Gauss-Newton step)  -> ba_python.npz
   * droid_net.py + modules/gru.py  UpdateModule / ConvGRU / GraphAgg / cvx_upsample (CPU fp32)  -> update_module.npz
   * InstantNeuS.py       normalisation, masking, sdf gradient by autograd.grad, get_alpha,
                          compositing, compute_sdf_error                       -> neus_forward.npz
@@ -264,11 +265,46 @@ def gen_update():
          keys=np.array(sorted(op.state_dict().keys())))
 
 
+def gen_ba():
+    """The reference's pure-PyTorch dense bundle adjustment (src/geom/ba.py BA + src/geom/chol.py schur_solve; the
+    formulation its CUDA `ba` kernel was derived from): one Gauss-Newton step on a small monocular graph in
+    which every keyframe is the source of at least one edge (so both paths optimise the same depth maps)."""
+    ts = sys.modules.get("torch_scatter") or types.ModuleType("torch_scatter")
+
+    def scatter_sum(src, index, dim=1, dim_size=None):
+        assert dim == 1
+        out = torch.zeros(src.shape[0], dim_size, *src.shape[2:], dtype=src.dtype)
+        return out.index_add_(1, index, src)
+    ts.scatter_sum = scatter_sum
+    if not hasattr(ts, "scatter_mean"):
+        ts.scatter_mean = None
+    sys.modules["torch_scatter"] = ts
+    sys.modules["projective_ops"] = importlib.import_module("refsrc.geom.projective_ops")   # `import projective_ops`
+    ba = importlib.import_module("refsrc.geom.ba")
+    N, shape = 6, "tiny"
+    p = synth.make_ba_problem(N, 16, shape, seed=139, rgbd=False)
+    ii = torch.cat([p["ii"], torch.arange(N)])                 # every keyframe is a source at least once
+    jj = torch.cat([p["jj"], (torch.arange(N) + 1) % N])
+    c, _ = DO.reproject(p["poses"], p["disps"], p["intrinsics"], ii, jj)
+    g = torch.Generator().manual_seed(149)
+    E = len(ii)
+    ht, wd = p["disps"].shape[-2:]
+    target = c[0] + 0.5 * torch.randn(E, ht, wd, 2, generator=g)
+    weight = torch.rand(E, ht, wd, 2, generator=g)
+    eta = 1e-2 * torch.rand(N, ht, wd, generator=g) + 1e-4
+    Gs = lietorch_shim.SE3(p["poses"][None].clone())
+    poses_out, disps_out = ba.BA(target[None], weight[None], eta[None], Gs, p["disps"][None].clone(),
+                                 p["intrinsics"][None], ii, jj, fixedp=1)
+    save("ba_python.npz", poses=p["poses"], disps=p["disps"], intrinsics=p["intrinsics"], ii=ii, jj=jj,
+         target=target, weight=weight, eta=eta, poses_out=poses_out.data[0], disps_out=disps_out[0])
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate the fixtures"
     install_stubs()
     with torch.no_grad():
         gen_update()
+        gen_ba()
         gen_corr()
         gen_proj()
         gen_render()
