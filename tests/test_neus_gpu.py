@@ -222,8 +222,8 @@ def test_training_gradients_match_autograd_oracle(N, O, dev, grid_init, grad_dty
         "variance": (model.variance_network.variance.grad.reshape(1), Pd["variance"].grad.reshape(1)),
     }
     report = {k: _rel(a.cpu().float(), b) for k, (a, b) in pairs.items()}
-    for k, r in report.items():
-        assert r < 3e-2, report
+    for k, r in report.items():      # measured: <= 4.3e-4 (color_B), 2.1e-4 on the grid with fp16 packed atomics
+        assert r < 5e-3, report
 
 
 def test_training_step_reduces_loss(N, O, dev):
