@@ -145,7 +145,9 @@ def test_update_module_fast_path_matches_plain(built_lib):
     names = ["net", "delta", "weight", "eta", "upmask"]
     for name, a, b in zip(names, outs[0], outs[1]):
         assert a.shape == b.shape, name
-        torch.testing.assert_close(a.float(), b.float(), rtol=3e-2, atol=1e-2, msg=lambda m: f"{name}: {m}")
+        # measured: <= 1.1e-3 on net (one fp16 ulp at |x| ~ 1), <= 5e-4 on delta / weight / upmask; against an fp32
+        # evaluation of the same module the fast path is as close or closer (6e-4) than the plain fp16 path (9e-4)
+        torch.testing.assert_close(a.float(), b.float(), rtol=5e-3, atol=3e-3, msg=lambda m: f"{name}: {m}")
 
 
 def test_segment_mean_and_glo_kernels(built_lib):
