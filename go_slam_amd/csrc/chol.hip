@@ -253,7 +253,7 @@ constexpr int CB = 6;      // camera block
 constexpr int SMALL_NT = 1024;   // one workgroup, 16 waves: latency hiding for the LDS-resident steps
 constexpr int PW = 30;     // panel width (5 camera blocks): far updates are deferred per panel
 
-#ifdef CHOL_TIMING   // scratch/chol_bench.hip only: per-phase wall-clock stamps (100 MHz)
+#ifdef CHOL_TIMING   // tools/chol_bench.hip only: per-phase wall-clock stamps (100 MHz)
 __device__ long long g_chol_t[64];
 #define CHOL_STAMP(i) do { if (threadIdx.x == 0) g_chol_t[i] = wall_clock64(); } while (0)
 #define CHOL_ACC_DECL long long t_acc[5] = {0, 0, 0, 0, 0}; long long t_last = wall_clock64()
