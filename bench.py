@@ -185,9 +185,11 @@ def neus_render_bench(device, n_rays=4096, iters=20):
             "gather_GBps": pts * 512.0 / (ms_fwd * 1e-3) / 1e9}
 
 
-def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768):
-    """Mapping step (render + losses + backward + grad all-reduce + clip + AdamW) on a GLOBAL batch
-    of 32768 rays x 72 samples sharded over `world` GPUs (strong scaling, BASELINE configs[4])."""
+def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768, scaling="strong"):
+    """Mapping step (render + losses + backward + grad all-reduce + clip + AdamW) on a GLOBAL batch of
+    `global_rays` rays x 72 samples sharded over `world` GPUs (BASELINE configs[4]).  Called twice: strong scaling
+    (32768 rays in total) and weak scaling (4096 rays per GPU -- the reference mapper's own per-iteration batch,
+    so 8 GPUs carry the 32768-ray batch of configs[4])."""
     import go_slam_amd.neus as neus
     from go_slam_amd.neus.mapper import MapTrainer
     g = torch.Generator().manual_seed(43)
@@ -226,7 +228,7 @@ def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768):
     ms = 1e3 * dt / steps
     return {"metric": "NeuS mapping train step rays/s (render + loss + backward + all-reduce + clip + AdamW)",
             "value": n / (ms * 1e-3), "unit": "rays/s", "global_rays": n, "rays_per_gpu": n // world, "ms_per_step": ms,
-            "scaling": "strong", "allreduce_bytes": 4 * sum(p.numel() for p in tr.train_params) if world > 1 else 0,
+            "scaling": scaling, "allreduce_bytes": 4 * sum(p.numel() for p in tr.train_params) if world > 1 else 0,
             "final_loss": float(loss)}
 
 
@@ -337,8 +339,10 @@ def main():
         "updates_per_s": value * UPDATES_PER_KF, "state_finite": finite,
     }
     train = neus_train_bench(device, rank, world)      # collective: every rank takes part
+    train_weak = neus_train_bench(device, rank, world, global_rays=4096 * world, scaling="weak")
     if rank == 0:
         line["neus_train"] = train
+        line["neus_train_weak"] = train_weak
         br = op_breakdown(video, update_op, graph)
         line["breakdown_ms"] = {k: round(v, 4) for k, v in br.items() if k.endswith("_ms")}
         ht, wd = graph.ht, graph.wd
