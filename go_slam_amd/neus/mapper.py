@@ -6,11 +6,20 @@ import torch
 from .distributed import FlatGradReducer, mapping_loss_sharded, shard_rays
 
 
-def make_optimizer(model, net_lr=1e-3, grid_lr=1e-2):
-    """reference src/mapping.py:55-58."""
-    return torch.optim.AdamW([{"params": model.get_training_parameters(), "lr": net_lr},
-                              {"params": model.get_volume_parameters(), "lr": grid_lr}],
-                             betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+def make_optimizer(model, net_lr=1e-3, grid_lr=1e-2, fused=None):
+    """reference src/mapping.py:55-58 (same hyper-parameters).  On the GPU the single-kernel (`fused`) AdamW is
+    used: the step is identical, but the 6 parameter tensors are updated by one launch instead of ~20."""
+    groups = [{"params": model.get_training_parameters(), "lr": net_lr},
+              {"params": model.get_volume_parameters(), "lr": grid_lr}]
+    if fused is None:
+        fused = all(p.is_cuda for g in groups for p in g["params"])
+    kw = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    if fused:
+        try:
+            return torch.optim.AdamW(groups, fused=True, **kw)
+        except (RuntimeError, TypeError, ValueError):
+            pass
+    return torch.optim.AdamW(groups, **kw)
 
 
 class MapTrainer:
@@ -37,6 +46,6 @@ class MapTrainer:
         loss.backward()
         if self.reducer is not None:
             self.reducer.reduce(self.group)          # sum of shard gradients == single-GPU gradient
-        torch.nn.utils.clip_grad_norm_(self.train_params, max_norm=35.0)
+        torch.nn.utils.clip_grad_norm_(self.train_params, max_norm=35.0, foreach=True if rays_o.is_cuda else None)
         self.optimizer.step()
         return loss_value
