@@ -115,6 +115,20 @@ def stream_ptr(device=None):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+_EMPTY_SENTINEL = {}
+
+
 def ptr(t):
-    """Device pointer of a tensor (None -> NULL)."""
-    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+    """Device pointer of a tensor (None -> NULL).  A zero-element tensor has no storage (data_ptr() == 0), which
+    the C side would reject as a NULL argument before it reaches its `n == 0 -> nothing to do` early-out; such
+    tensors are represented by a small per-device sentinel buffer that is never dereferenced."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    p = t.data_ptr()
+    if p == 0 and t.numel() == 0 and t.is_cuda:
+        s = _EMPTY_SENTINEL.get(t.device)
+        if s is None:
+            import torch
+            s = _EMPTY_SENTINEL[t.device] = torch.zeros(64, dtype=torch.uint8, device=t.device)
+        p = s.data_ptr()
+    return ctypes.c_void_p(p)

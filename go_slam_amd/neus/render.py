@@ -32,6 +32,9 @@ class Renderer:
         n = rays_o.shape[0]
         ns = self.N_samples
         nsurf = self.N_surface if gt_depth is not None else 0
+        if n == 0:
+            z = torch.zeros(0, ns + nsurf, dtype=torch.float32, device=dev)
+            return z, z.clone()
         if gt_depth is not None:
             gt_depth = gt_depth.reshape(-1).float().contiguous()
             gt_max_dev = gt_depth.max().reshape(1)  # stays on the device: the kernel reads it (the reference's

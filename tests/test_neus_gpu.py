@@ -280,3 +280,14 @@ def test_quirk_q15_static_bound_normalisation_with_clamp(N, O, dev):
     torch.testing.assert_close(out["sdf"].cpu(), ref["sdf"], rtol=1e-4, atol=2e-5)
     torch.testing.assert_close(out["normal"].cpu(), ref["normal"], rtol=2e-3, atol=2e-3)
     torch.testing.assert_close(out["gradient_error"].cpu(), ref["gradient_error"], rtol=2e-3, atol=1e-5)
+
+
+def test_zero_rays_are_a_noop(N, dev):
+    R = N.Renderer(N_samples=24, N_surface=48)
+    model = N.InstantNeuS({}, [[-2.5, 2.5]] * 3).to(dev)
+    z = lambda *s: torch.zeros(*s, device=dev)
+    zv, dd = R.sample(z(0, 3), z(0, 3), model.bound, z(0))
+    assert tuple(zv.shape) == (0, 72) and tuple(dd.shape) == (0, 72)
+    with torch.no_grad():
+        out = model(z(0, 3), z(0, 3), zv, dd)
+    assert tuple(out["color"].shape) == (0, 3) and tuple(out["sdf"].shape) == (0, 72)

@@ -436,3 +436,34 @@ def test_quirk_q2_two_min_depths(db, O, dev):
     assert v.min() == 1.0 and pv.max() == 0.0
     rc, rv = O.reproject(vid["poses"], vid["disps"], vid["intrinsics"], ii, jj)
     assert torch.equal(v.cpu(), rv)
+
+
+def test_empty_inputs_are_noops(db, dev):
+    """Zero edges / frames / rays: every entry point returns correctly shaped empty results instead of launching
+    (the reference's kernels would be launched with a zero-sized grid, which CUDA rejects)."""
+    h, w = 12, 16
+    vid = synth.make_video(4, "tiny", seed=91)
+    poses, disps, K = vid["poses"].to(dev), vid["disps"].to(dev), vid["intrinsics"].to(dev)
+    e = torch.zeros(0, dtype=torch.long, device=dev)
+    c, v = db.reproject(poses, disps, K, e, e)
+    assert tuple(c.shape) == (1, 0, h, w, 2) and tuple(v.shape) == (1, 0, h, w, 1)
+    assert tuple(db.frame_distance(poses, disps, K[0].contiguous(), e, e, 0.3).shape) == (0,)
+    pm = db.projmap(poses, disps, K[0].contiguous(), e, e)
+    assert pm[0].shape[0] == 0
+    vol = torch.zeros(0, h, w, h, w, device=dev, dtype=torch.float16)
+    out, = db.corr_index_forward(vol, torch.zeros(0, 2, h, w, device=dev), 3)
+    assert tuple(out.shape) == (0, 7, 7, h, w)
+    pyr = [torch.zeros(0, h, w, h >> l, w >> l, device=dev, dtype=torch.float16) for l in range(4)]
+    out = db.corr_lookup_pyramid(pyr, torch.zeros(0, h, w, 2, device=dev), 3, channels_last=True)
+    assert tuple(out.shape) == (0, 196, h, w)
+    f = torch.zeros(0, h, w, 128, device=dev)
+    out, = db.altcorr_forward(f, f, torch.zeros(0, 1, h, w, 2, device=dev), 3)
+    assert out.shape[0] == 0
+
+
+def test_oversized_batches_raise(db, dev):
+    """Launch-geometry limits are reported as errors, never silently truncated."""
+    n, h, w = 65536, 2, 2
+    vol = torch.zeros(n, h, w, h, w, device=dev, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="exceeds"):
+        db.corr_index_forward(vol, torch.zeros(n, 2, h, w, device=dev), 3)
