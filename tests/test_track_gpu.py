@@ -467,3 +467,24 @@ def test_oversized_batches_raise(db, dev):
     vol = torch.zeros(n, h, w, h, w, device=dev, dtype=torch.float16)
     with pytest.raises(RuntimeError, match="exceeds"):
         db.corr_index_forward(vol, torch.zeros(n, 2, h, w, device=dev), 3)
+
+
+@pytest.mark.parametrize("hw,expect_fused", [((16, 32), True), ((16, 96), False), ((12, 20), False)])
+def test_corrblock_matches_oracle_on_fused_and_fallback_shapes(O, dev, hw, expect_fused):
+    """CorrBlock (build + 4-level lookup) vs the oracle at a shape the fused MFMA builder covers and at two it does
+    not (width > 80, width not a multiple of 8: hipBLASLt GEMM + avg_pool2d on the GPU, then the same HIP lookup)."""
+    from go_slam_amd import droid_backends as db
+    from go_slam_amd.corr import CorrBlock
+    h, w = hw
+    g = torch.Generator().manual_seed(95)
+    f1 = torch.randn(1, 2, 128, h, w, generator=g).half()
+    f2 = torch.randn(1, 2, 128, h, w, generator=g).half()
+    assert db.corr_volume_supported(f1[0]) == expect_fused
+    coords = _rand_coords(2, h, w, h, w, seed=96, spread=3.0).permute(0, 2, 3, 1)[None].contiguous()
+    ref = O.corr_lookup(O.corr_pyramid(f1, f2), coords, 3)
+    for cl in (False, True):
+        blk = CorrBlock(f1.to(dev), f2.to(dev), channels_last=cl)
+        out = blk(coords.to(dev))
+        assert tuple(out.shape) == (1, 2, 196, h, w)
+        # level 0 may differ by one fp16 rounding of the fp32 dot product between GEMM implementations
+        torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=0, atol=4e-3)
