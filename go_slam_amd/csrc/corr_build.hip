@@ -6,7 +6,7 @@
 // kernel is organised around writing every byte exactly once:
 //   corr_prep_kernel   : [n,128,HW] -> channels-last [n,HW,128] fp16, scaled by 1/4 (corr.py:71-72),
 //                        so both MFMA operands are K-contiguous 16-byte fragments
-//   corr_volume_kernel : one workgroup = 64 source pixels (p1) x 8 full rows of the target map
+//   corr_volume_kernel : one workgroup = 32 source pixels (p1) x 8 full rows of the target map
 //                        (p2 = 8*w columns).  v_mfma_f32_32x32x16_f16 with A = f2 rows, B = f1 rows
 //                        (so each lane ends up holding 4 consecutive p2 of one p1 -> 8-byte LDS
 //                        writes); the fp16 tile is staged in LDS, written to level 0 with 16-byte
@@ -22,7 +22,9 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 constexpr int KDIM = 128;
-constexpr int BM = 64;          // source pixels per workgroup
+constexpr int BM = 32;          // source pixels per workgroup (32: 55 KB of LDS -> 2 workgroups per CU, so one's
+                                // store phase overlaps the other's MFMA phase; 64 left a single workgroup per CU)
+constexpr int MT = BM / 32;     // 32-pixel MFMA column blocks per workgroup
 constexpr int ROWS = 8;         // target rows per workgroup (covers one 8x8 pooling block row)
 constexpr int MAXT = 5;         // n-tiles (32 columns) per wave: 8*w/32/4 <= 5  <=>  w <= 80
 
@@ -67,18 +69,18 @@ __global__ __launch_bounds__(256) void corr_volume_kernel(
   const _Float16* B = f1t + (size_t)e * hw * KDIM;   // rows p1
 
   // B fragments (source pixels) for the two 32-wide p1 tiles, all 8 k-steps
-  half8 bf[2][8];
+  half8 bf[MT][8];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     const int p1 = min(p1_0 + 32 * mt + r, hw - 1);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) bf[mt][ks] = ld8(B + (size_t)p1 * KDIM + 16 * ks + kh);
   }
-  float16v acc[MAXT][2];
+  float16v acc[MAXT][MT];
 #pragma unroll
   for (int t = 0; t < MAXT; ++t)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][mt][i] = 0.f;
 #pragma unroll
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void corr_volume_kernel(
       for (int ks = 0; ks < 8; ++ks) {
         const half8 af = ld8(ar + 16 * ks);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
           acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[mt][ks], acc[t][mt], 0, 0, 0);
       }
     }
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void corr_volume_kernel(
     const int nt = wave + 4 * t;
     if (nt < ntile) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         _Float16* row = c0 + (size_t)(32 * mt + r) * LD0 + 32 * nt + 4 * (lane >> 5);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
