@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void corr_volume_kernel(
   const int hw = h * w;
   const int BN = ROWS * w;                 // columns of the tile (multiple of 32)
   const int LD0 = BN + 8;                  // LDS row strides (halfs)
-  const int LD1 = (ROWS / 2) * (w / 2) + 2;
+  const int LD1 = (ROWS / 2) * (w / 2) + 8;   // multiple of 8 halves when w % 16 == 0: 16-byte LDS stores
   const int LD2 = (ROWS / 4) * (w / 4) + 2;
   _Float16* c0 = lds;                      // [BM][LD0]
   _Float16* c1 = c0 + BM * LD0;            // [BM][LD1]
@@ -157,6 +157,34 @@ __global__ __launch_bounds__(256) void corr_volume_kernel(
   const int h1 = h >> 1, w1 = w >> 1, h2 = h >> 2, w2 = w >> 2, h3 = h >> 3, w3 = w >> 3;
   {
     const int r1 = ROWS / 2;
+    if ((w1 & 7) == 0) {
+      // 8 outputs per thread: two 32-byte LDS row segments in, one 16-byte LDS store and one 16-byte global
+      // store out (the element-wise form below issues 2-byte global stores)
+      const int pc = w1 >> 3;                        // 16-byte pieces per level-1 row
+      for (int i = threadIdx.x; i < BM * r1 * pc; i += 256) {
+        const int m = i / (r1 * pc), rem = i - m * (r1 * pc);
+        const int yy = rem / pc, px = rem - yy * pc;
+        const _Float16* s = c0 + (size_t)m * LD0 + (2 * yy) * w + 16 * px;
+        const half8 a0 = *reinterpret_cast<const half8*>(s), a1 = *reinterpret_cast<const half8*>(s + 8);
+        const half8 b0 = *reinterpret_cast<const half8*>(s + w), b1 = *reinterpret_cast<const half8*>(s + w + 8);
+        half8 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o[k] = (_Float16)(((((float)a0[2 * k] + (float)a0[2 * k + 1]) + (float)b0[2 * k]) + (float)b0[2 * k + 1]) * 0.25f);
+          o[4 + k] = (_Float16)(((((float)a1[2 * k] + (float)a1[2 * k + 1]) + (float)b1[2 * k]) + (float)b1[2 * k + 1]) * 0.25f);
+        }
+        *reinterpret_cast<half8*>(c1 + (size_t)m * LD1 + yy * w1 + 8 * px) = o;
+        const int gy = (y2_0 >> 1) + yy;
+        if (m < m_valid && gy < h1) {
+          if (tiled) {
+            const size_t plane1 = (size_t)pc * ((h1 + 7) >> 3) * 64;
+            *reinterpret_cast<half8*>(v1 + ((size_t)e * hw + p1_0 + m) * plane1 + ((size_t)(gy >> 3) * pc + px) * 64 + (gy & 7) * 8) = o;
+          } else {
+            *reinterpret_cast<half8*>(v1 + ((size_t)e * hw + p1_0 + m) * ((size_t)h1 * w1) + (size_t)gy * w1 + 8 * px) = o;
+          }
+        }
+      }
+    } else {
     for (int i = threadIdx.x; i < BM * r1 * w1; i += 256) {
       const int m = i / (r1 * w1), rem = i - m * (r1 * w1);
       const int yy = rem / w1, xx = rem - yy * w1;
@@ -174,6 +202,7 @@ __global__ __launch_bounds__(256) void corr_volume_kernel(
           v1[((size_t)e * hw + p1_0 + m) * ((size_t)h1 * w1) + (size_t)gy * w1 + xx] = o;
         }
       }
+    }
     }
   }
   __syncthreads();
@@ -245,7 +274,7 @@ extern "C" int gs_corr_volume_pyramid(const void* fmap1, const void* fmap2, void
   corr_prep_kernel<<<pg, 256, 0, st>>>((const _Float16*)fmap2, f2t, hw);
   GS_CHECK_LAUNCH("corr_prep");
   const int BN = ROWS * w;
-  const size_t lds = (size_t)(BM * (BN + 8) + BM * ((ROWS / 2) * (w / 2) + 2) + BM * ((ROWS / 4) * (w / 4) + 2)) * 2;
+  const size_t lds = (size_t)(BM * (BN + 8) + BM * ((ROWS / 2) * (w / 2) + 8) + BM * ((ROWS / 4) * (w / 4) + 2)) * 2;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)corr_volume_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
