@@ -49,12 +49,14 @@ def bench_graph(num_kf, num_edges, seed=43):
             torch.tensor([p[1] for p in pairs], dtype=torch.long))
 
 
-def build_state(device, seed=43):
+def build_state(device, seed=43, num_kf=None, num_edges=None, shape=None, corr_impl="volume", upsample=True):
     from go_slam_amd import synth
     from go_slam_amd.depth_video import DepthVideo
     from go_slam_amd.droid_net import UpdateModule
     from go_slam_amd.factor_graph import FactorGraph
 
+    NUM_KF, NUM_EDGES, SHAPE = (num_kf or globals()["NUM_KF"], num_edges or globals()["NUM_EDGES"],
+                                shape or globals()["SHAPE"])
     ht, wd, _ = synth.SHAPES[SHAPE]
     torch.manual_seed(seed)
     # let MIOpen search its NHWC fp16 solvers once per conv shape (the default immediate-mode
@@ -76,7 +78,7 @@ def build_state(device, seed=43):
     with torch.no_grad():
         update_op.delta[2].weight.mul_(0.05)
         update_op.delta[2].bias.zero_()
-    graph = FactorGraph(video, update_op, device=device, corr_impl="volume", max_factors=NUM_EDGES, upsample=True)
+    graph = FactorGraph(video, update_op, device=device, corr_impl=corr_impl, max_factors=NUM_EDGES, upsample=upsample)
     ii, jj = bench_graph(NUM_KF, NUM_EDGES, seed)
     graph.add_factors(ii.to(device), jj.to(device))
     return video, update_op, graph, (vid, ii, jj)
@@ -91,6 +93,18 @@ def keyframe_step(graph):
     graph.update_op.drop_edge_caches()
     for _ in range(UPDATES_PER_KF):
         graph.update(None, None, use_inactive=True)
+
+
+def global_ba_stress(device, num_kf=200, num_edges=1200, shape="Scan"):
+    """BASELINE configs[3] stress shape: >= 200 keyframes, 1200 edges at 30x40 maps -- wall time of
+    ONE full-BA `update_lowmem` step (alt-corr lookups in chunks of 13 source keyframes + update operator + a
+    dense BA over all edges: 6P = 1194 unknowns, blocked multi-kernel Cholesky)."""
+    video, update_op, graph, _ = build_state(device, seed=47, num_kf=num_kf, num_edges=num_edges, shape=shape,
+                                             corr_impl="alt", upsample=False)
+    ms = time_op(lambda: graph.update_lowmem(steps=1, iters=2), iters=3, warm=1)
+    finite = bool(torch.isfinite(video.poses).all()) and bool(torch.isfinite(video.disps).all())
+    return {"keyframes": num_kf, "edges": int(graph.ii.numel()), "maps": shape, "unknowns": 6 * (num_kf - 1),
+            "update_lowmem_step_ms": ms, "state_finite": finite}
 
 
 def time_op(fn, iters=10, warm=2):
@@ -345,6 +359,8 @@ def main():
         line["neus_train_weak"] = train_weak
         br = op_breakdown(video, update_op, graph)
         line["breakdown_ms"] = {k: round(v, 4) for k, v in br.items() if k.endswith("_ms")}
+        line["ba_gn_iters_per_s"] = 2.0 / (br["ba_2iter_ms"] * 1e-3)
+        line["global_ba_stress"] = global_ba_stress(device)
         ht, wd = graph.ht, graph.wd
         algo_bytes = 912.0 * ht * wd * br["edges"]            # 912*HW B per edge per lookup
         t_s = br["corr_lookup_ms"] * 1e-3
