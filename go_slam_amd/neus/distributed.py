@@ -31,8 +31,39 @@ def all_reduce_sum_(t, group=None):
     return t
 
 
+class _MapLossFn(torch.autograd.Function):
+    """Colour + depth + SDF terms of the mapper's loss and their gradients in one HIP launch (gs_mapping_loss)."""
+
+    @staticmethod
+    def forward(ctx, color, depth, dvar, sdf, z_vals, rays_color, rays_depth, counts, trunc, sparse, w_color, w_sdf,
+                uncertainty):
+        from .. import _lib
+        n, s = sdf.shape
+        f = lambda t: t.detach().float().contiguous()
+        color, depth, dvar, sdf, z_vals = f(color), f(depth), f(dvar), f(sdf), f(z_vals)
+        rays_color, rays_depth, counts = f(rays_color), f(rays_depth), f(counts)
+        d_color = torch.empty_like(color)
+        d_depth = torch.empty(n, 1, dtype=torch.float32, device=sdf.device)
+        d_sdf = torch.empty_like(sdf)
+        loss_rays = torch.empty(n, dtype=torch.float32, device=sdf.device)
+        with torch.cuda.device(sdf.device):
+            rc = _lib.lib().gs_mapping_loss(_lib.ptr(color), _lib.ptr(depth), _lib.ptr(dvar), _lib.ptr(sdf),
+                                            _lib.ptr(z_vals), _lib.ptr(rays_color), _lib.ptr(rays_depth),
+                                            _lib.ptr(counts), float(trunc), float(sparse), float(w_color), float(w_sdf),
+                                            int(bool(uncertainty)), _lib.ptr(d_color), _lib.ptr(d_depth),
+                                            _lib.ptr(d_sdf), _lib.ptr(loss_rays), n, s, _lib.stream_ptr(sdf.device))
+        _lib.check(rc, "mapping_loss")
+        ctx.save_for_backward(d_color, d_depth, d_sdf)
+        return loss_rays.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        d_color, d_depth, d_sdf = ctx.saved_tensors
+        return (d_color * g, d_depth * g, None, d_sdf * g) + (None,) * 9
+
+
 def mapping_loss_sharded(ret, rays_color, rays_depth, compute_sdf_error, group=None, w_color=2.0, w_sdf=2.0,
-                         w_eikonal=0.1, uncertainty=True):
+                         w_eikonal=0.1, uncertainty=True, fused=True):
     """Mapper.optimize_map's loss (reference src/mapping.py:96-132) on this rank's ray shard,
     normalised by global counts.  `compute_sdf_error(sdf, z_vals, gt_depth)` is the model's
     (InstantNeuS.py:372-400).  Returns (local_loss, global_loss as a 0-dim tensor): local_loss.backward()
@@ -48,6 +79,15 @@ def mapping_loss_sharded(ret, rays_color, rays_depth, compute_sdf_error, group=N
     nv_l, nr_l = n_local[0].to(rd.dtype), n_local[1].to(rd.dtype)
     nv_g, nr_g = n_glob[0].to(rd.dtype), n_glob[1].to(rd.dtype)
     dv = ret["depth_variance"]
+    model = getattr(compute_sdf_error, "__self__", None)
+    if rd.is_cuda and fused and model is not None and ret["sdf"].shape[1] <= 128:
+        # one launch for the colour / depth / SDF terms and their gradients; only the eikonal mean stays in torch
+        total = _MapLossFn.apply(ret["color"], ret["depth"], dv, ret["sdf"], ret["z_vals"], rays_color, rd,
+                                 n_glob[:1].float(), model.sdf_truncation, model.sdf_sparse_factor, w_color, w_sdf,
+                                 uncertainty)
+        total = total + w_eikonal * ret["gradient_error"].mean() * (nr_l / nr_g)
+        glob = all_reduce_sum_(total.detach().clone().double(), group)
+        return total, glob
     uw = 1.0 / torch.sqrt(dv.detach() + 1e-10) if uncertainty else torch.ones_like(dv)
     total = (torch.abs(ret["color"] - rays_color) * vmf).sum() / (3.0 * nv_g) * w_color
     total = total + (torch.abs(ret["depth"] - rd) * uw * vmf).sum() / nv_g

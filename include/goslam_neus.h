@@ -132,6 +132,20 @@ int gs_neus_backward_points(const float* rays_o, const float* rays_d, const floa
                             void* lin_in, void* dw0, void* d_arg, void* pts, int row_dtype, float row_scale,
                             int row_stride, float* d_inv_s, int n, int s, gs_stream_t stream);
 
+/* The mapper's loss without the eikonal term (src/mapping.py:96-132 + InstantNeuS.compute_sdf_error,
+ * src/InstantNeuS.py:372-400) and its gradient, one launch.  Rays with rays_depth <= 0 are masked out.
+ *   loss_rays[r] = ( w_color |c - c*|_1 / 3 + |d - d*| uw + w_sdf (e_r + f_r) ) / counts[0]
+ *   with uw = 1/sqrt(depth_var + 1e-10) if `uncertainty` (treated as a constant, as the reference detaches it),
+ *   e_r / f_r the per-ray SDF error / free-space terms; the loss is sum_r loss_rays[r]; counts[0] = number of
+ *   valid rays over ALL ranks (device scalar).  d_color [n,3], d_depth [n], d_sdf [n,s] are d(sum loss)/d(.).
+ * color [n,3], depth [n], depth_var [n], sdf [n,s], z_vals [n,s] (the sample depths InstantNeuS returns),
+ * rays_color [n,3], rays_depth [n]; all f32; s <= 128.                                                      */
+int gs_mapping_loss(const float* color, const float* depth, const float* depth_var, const float* sdf,
+                    const float* z_vals, const float* rays_color, const float* rays_depth, const float* counts,
+                    float truncation, float sparse_factor, float w_color, float w_sdf, int uncertainty,
+                    float* d_color, float* d_depth, float* d_sdf, float* loss_rays, int n, int s,
+                    gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -291,3 +291,34 @@ def test_zero_rays_are_a_noop(N, dev):
     with torch.no_grad():
         out = model(z(0, 3), z(0, 3), zv, dd)
     assert tuple(out["color"].shape) == (0, 3) and tuple(out["sdf"].shape) == (0, 72)
+
+
+def test_fused_mapping_loss_matches_torch_formulation(N, dev):
+    """gs_mapping_loss (value + analytic gradients) vs the masked-sum PyTorch formulation of the mapper's loss
+    (src/mapping.py:96-132) under autograd: rays without depth, samples in front of / around / behind the surface."""
+    from go_slam_amd.neus.distributed import mapping_loss_sharded
+    g = torch.Generator().manual_seed(61)
+    n, s = 301, 72
+    model = N.InstantNeuS({}, [[-2.5, 2.5]] * 3).to(dev)
+    gt = torch.rand(n, generator=g) * 3 + 0.5
+    gt[torch.rand(n, generator=g) < 0.2] = 0.0
+    z = torch.sort(torch.rand(n, s, generator=g) * 4.5, dim=1).values
+    z[:, 30:60] = (gt.clamp(min=0.3)[:, None] + (torch.rand(n, 30, generator=g) - 0.5) * 0.3)   # samples near the surface
+    col = torch.rand(n, 3, generator=g)
+    mk = lambda t: t.to(dev).requires_grad_(True)
+    res = {}
+    for fused in (True, False):
+        ret = {"color": mk(torch.rand(n, 3, generator=torch.Generator().manual_seed(62))),
+               "depth": mk(torch.rand(n, 1, generator=torch.Generator().manual_seed(63)) * 4),
+               "depth_variance": mk(torch.rand(n, 1, generator=torch.Generator().manual_seed(64)) * 0.1),
+               "sdf": mk(torch.randn(n, s, generator=torch.Generator().manual_seed(65)) * 0.2),
+               "z_vals": z.to(dev), "gradient_error": mk(torch.tensor([0.37]))}
+        loss, glob = mapping_loss_sharded(ret, col.to(dev), gt.to(dev), model.compute_sdf_error, None, fused=fused)
+        loss.backward()
+        res[fused] = (loss.detach(), ret["color"].grad, ret["depth"].grad, ret["sdf"].grad, ret["gradient_error"].grad,
+                      ret["depth_variance"].grad)
+    a, b = res[True], res[False]
+    torch.testing.assert_close(a[0], b[0], rtol=1e-5, atol=1e-6)
+    for i, name in ((1, "d_color"), (2, "d_depth"), (3, "d_sdf"), (4, "d_gerr")):
+        torch.testing.assert_close(a[i], b[i], rtol=1e-4, atol=1e-8, msg=lambda m, nm=name: f"{nm}: {m}")
+    assert a[5] is None or not bool(a[5].any())          # the uncertainty weight is detached in both
