@@ -18,7 +18,8 @@ class DepthVideo:
         self.ht, self.wd = ht, wd            # 1/8-resolution map size
         d = self.device
         c = 2 if stereo else 1
-        self.counter = 0
+        self.counter = 0                     # int here; a multiprocessing.Value (`.value`) is accepted too
+        self.stereo = stereo
         self.timestamp = torch.zeros(buffer, device=d, dtype=torch.float32)
         self.poses = torch.zeros(buffer, 7, device=d, dtype=torch.float32)
         self.poses[:, 6] = 1.0
@@ -66,7 +67,7 @@ class DepthVideo:
 
     def distance(self, ii=None, jj=None, beta=0.3, bidirectional=True):
         return_matrix = False
-        N = self.counter
+        N = int(getattr(self.counter, "value", self.counter))
         if ii is None:
             return_matrix = True
             ii, jj = torch.meshgrid(torch.arange(N), torch.arange(N), indexing="ij")

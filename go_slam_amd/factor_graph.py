@@ -41,6 +41,8 @@ class FactorGraph:
         self.weight = z(1, 0, self.ht, self.wd, 2)
         self.ii_inac = torch.zeros(0, dtype=torch.long, device=self.device)
         self.jj_inac = torch.zeros(0, dtype=torch.long, device=self.device)
+        self.ii_bad = torch.zeros(0, dtype=torch.long, device=self.device)
+        self.jj_bad = torch.zeros(0, dtype=torch.long, device=self.device)
         self.target_inac = z(1, 0, self.ht, self.wd, 2)
         self.weight_inac = z(1, 0, self.ht, self.wd, 2)
 
@@ -104,8 +106,16 @@ class FactorGraph:
         """add edges ii->jj (src/factor_graph.py:80-130): builds their correlation pyramids."""
         ii = torch.as_tensor(ii, dtype=torch.long, device=self.device).reshape(-1)
         jj = torch.as_tensor(jj, dtype=torch.long, device=self.device).reshape(-1)
+        ii, jj = self._filter_repeated_edges(ii, jj)
         if ii.numel() == 0:
             return
+        # limit on the number of factors (src/factor_graph.py:99-103): the oldest edges become inactive.  The
+        # reference's mask is `argsort(age) >= max_factors - n_new` (the permutation itself, not the rank) --
+        # kept literally so the same edges retire.
+        if self.max_factors > 0 and self.ii.numel() + ii.numel() > self.max_factors and self.corr is not None \
+                and remove:
+            perm = torch.argsort(self.age, descending=False)
+            self.rm_factors(perm >= self.max_factors - ii.numel(), store=True)
         net = self._fmt(self.video.nets[ii]).unsqueeze(0)
         if self.corr_impl == "volume":              # the alt path correlates on the fly (no volumes)
             c = (ii == jj).long()                   # stereo edges read the right-view feature map
@@ -143,12 +153,151 @@ class FactorGraph:
             self.weight_inac = torch.cat([self.weight_inac, self.weight[:, mask]], 1)
         keep = ~mask
         self.ii, self.jj, self.age = self.ii[keep], self.jj[keep], self.age[keep]
-        if self.corr_impl == "volume":
+        if self.corr_impl == "volume" and self.corr is not None:
             self.corr = self.corr[keep]
+        if self.inp is not None:
             self.inp = self._fmt(self.inp[0][keep]).unsqueeze(0)
-        self.net = self._fmt(self.net[0][keep]).unsqueeze(0)
+        if self.net is not None:
+            self.net = self._fmt(self.net[0][keep]).unsqueeze(0)
         self.target = self.target[:, keep]
         self.weight = self.weight[:, keep]
+
+    # ---- edge-set management (src/factor_graph.py:43-53, 70-83, 159-197, 368-450) -----------------------
+    @staticmethod
+    def _edges_on_host(*pairs):
+        """(i, j) tuples of the given (ii, jj) tensor pairs: one device-to-host copy per tensor (the
+        reference calls .item() per element, a host sync each)."""
+        out = []
+        for a, b in pairs:
+            out += list(zip(a.cpu().tolist(), b.cpu().tolist()))
+        return out
+
+    def _filter_repeated_edges(self, ii, jj):
+        """drop proposed edges that are already active or inactive (src/factor_graph.py:43-53).  As in the
+        reference, duplicates WITHIN the proposal are kept."""
+        have = set(self._edges_on_host((self.ii, self.jj), (self.ii_inac, self.jj_inac)))
+        if not have or ii.numel() == 0:
+            return ii, jj
+        keep = torch.tensor([e not in have for e in zip(ii.cpu().tolist(), jj.cpu().tolist())],
+                            dtype=torch.bool, device=ii.device)
+        return ii[keep], jj[keep]
+
+    @torch.no_grad()
+    def filter_edges(self):
+        """remove low-confidence long-range edges and remember them as bad (src/factor_graph.py:70-77)."""
+        conf = self.weight.mean(dim=(0, 2, 3, 4))
+        mask = ((self.ii - self.jj).abs() > 2) & (conf < 1e-3)
+        self.ii_bad = torch.cat([self.ii_bad, self.ii[mask]])
+        self.jj_bad = torch.cat([self.jj_bad, self.jj[mask]])
+        self.rm_factors(mask, store=False)
+
+    @torch.no_grad()
+    def clear_edges(self):
+        """src/factor_graph.py:79-82"""
+        self.rm_factors(self.ii >= 0)
+        self.net = None
+        self.inp = None
+
+    # per-keyframe buffers the reference shifts in rm_keyframe (src/factor_graph.py:161-179); the host
+    # mirror of DepthVideo holds a subset, a drop-in caller's video object may hold all of them
+    _KEYFRAME_BUFFERS = ("timestamp", "images", "dirty", "red", "poses", "poses_gt", "disps", "disps_sens",
+                         "disps_up", "depths_gt", "intrinsics", "poses_filtered", "disps_filtered",
+                         "mask_filtered", "update_priority", "nets", "inps", "fmaps")
+
+    @torch.no_grad()
+    def rm_keyframe(self, ix):
+        """drop keyframe `ix`: slot ix+1 moves down and every edge touching ix goes, later indices shift by
+        one (src/factor_graph.py:159-197).  The edge lists are REPLACED rather than edited in place, which is
+        what invalidates the cached edge index."""
+        v = self.video
+        for name in self._KEYFRAME_BUFFERS:
+            buf = getattr(v, name, None)
+            if torch.is_tensor(buf):
+                buf[ix] = buf[ix + 1]
+        m = (self.ii_inac == ix) | (self.jj_inac == ix)
+        self.ii_inac = self.ii_inac - (self.ii_inac >= ix).long()
+        self.jj_inac = self.jj_inac - (self.jj_inac >= ix).long()
+        if bool(m.any()):
+            keep = ~m
+            self.ii_inac, self.jj_inac = self.ii_inac[keep], self.jj_inac[keep]
+            self.target_inac, self.weight_inac = self.target_inac[:, keep], self.weight_inac[:, keep]
+        m = (self.ii == ix) | (self.jj == ix)
+        self.ii = self.ii - (self.ii >= ix).long()
+        self.jj = self.jj - (self.jj >= ix).long()
+        self.rm_factors(m, store=False)
+
+    def add_neighborhood_factors(self, t0, t1, r=3):
+        """edges between all frames of [t0, t1) at most r apart (src/factor_graph.py:368-381)."""
+        ii, jj = torch.meshgrid(torch.arange(t0, t1), torch.arange(t0, t1), indexing="ij")
+        ii, jj = ii.reshape(-1), jj.reshape(-1)
+        c = 1 if getattr(self.video, "stereo", False) else 0
+        keep = ((ii - jj).abs() > c) & ((ii - jj).abs() <= r)
+        self.add_factors(ii[keep].to(self.device), jj[keep].to(self.device))
+
+    @staticmethod
+    def propose_proximity_edges(d, existing, t0, t1, t, rad, nms, thresh, max_factors, stereo):
+        """Greedy edge proposal with non-maximum suppression (src/factor_graph.py:402-447), on the host.
+
+        d: float numpy array [t - t0, t - t1] of frame distances, inf where the pair is not a candidate
+        (modified in place); existing: (i, j) pairs already active / bad / inactive.  Returns the list of
+        proposed (i, j) pairs in the reference's order.  The index expressions are the reference's own;
+        NumPy resolves negative indices and slice bounds exactly as torch does, so the corner cases
+        (j < t1, windows clipped at the border) come out the same."""
+        import numpy as np
+        ilen, jlen = t - t0, t - t1
+
+        def suppress(di, dj):
+            d[max(0, di - nms):min(ilen, di + nms + 1), max(0, dj - nms):min(jlen, dj + nms + 1)] = np.inf
+
+        for i, j in existing:                         # edges built before
+            if t0 <= i < t and t1 <= j < t:
+                d[i - t0, j - t1] = np.inf
+                suppress(i - t0, j - t1)
+        es = []
+        for i in range(t0, t):                        # local window [i - rad, i)
+            if stereo:
+                es.append((i, i))
+                d[i - t0, i - t1] = np.inf
+            for j in range(max(i - rad, 0), i):
+                es += [(i, j), (j, i)]
+                d[i - t0, j - t1] = np.inf
+                suppress(i - t0, j - t1)
+        flat = d.reshape(-1)
+        order = np.argsort(flat, kind="stable")       # distance from small to big
+        order = order[flat[order] <= thresh]
+        for k in order.tolist():
+            di, dj = k // jlen, k % jlen
+            if d[di, dj] > thresh:                    # suppressed by an earlier pick
+                continue
+            if len(es) > max_factors:
+                break
+            i, j = t0 + di, t1 + dj
+            es += [(i, j), (j, i)]                    # bidirectional
+            suppress(di, dj)
+        return es
+
+    @torch.no_grad()
+    def add_proximity_factors(self, t0=0, t1=0, rad=2, nms=2, beta=0.25, thresh=16.0, remove=False, max_t=None):
+        """add edges based on frame distance (src/factor_graph.py:383-450): one frame_distance launch pair,
+        ONE device-to-host copy of the distance matrix, then the greedy NMS on the host (the reference keeps
+        d on the GPU and syncs once per candidate)."""
+        cnt = self.video.counter
+        t = max_t if max_t is not None else int(getattr(cnt, "value", cnt))
+        if t <= t0 or t <= t1:
+            return
+        ii, jj = torch.meshgrid(torch.arange(t0, t), torch.arange(t1, t), indexing="ij")
+        ii, jj = ii.reshape(-1), jj.reshape(-1)
+        d = self.video.distance(ii, jj, beta=beta).detach().float().cpu()
+        d[ii - rad < jj] = float("inf")
+        d[d > 100] = float("inf")
+        d = d.reshape(t - t0, t - t1).numpy().copy()
+        existing = self._edges_on_host((self.ii, self.jj), (self.ii_bad, self.jj_bad), (self.ii_inac, self.jj_inac))
+        es = FactorGraph.propose_proximity_edges(d, existing, t0, t1, t, rad, nms, thresh, self.max_factors,
+                                                 bool(getattr(self.video, "stereo", False)))
+        if not es:
+            return
+        e = torch.tensor(es, dtype=torch.long, device=self.device)
+        self.add_factors(e[:, 0], e[:, 1], remove)
 
     @torch.no_grad()
     def update(self, t0=None, t1=None, iters=2, use_inactive=False, EPS=1e-7, motion_only=False):
@@ -212,6 +361,7 @@ class FactorGraph:
         """Reduced-memory update for global / loop-closure BA (src/factor_graph.py:255-321): alt-corr
         lookups in chunks of 13 source keyframes, one dense BA over all edges per step."""
         cur_t = self.video.counter
+        cur_t = int(getattr(cur_t, "value", cur_t))     # the reference's counter is a multiprocessing.Value
         t = max_t if max_t is not None else cur_t
         fm = self.video.fmaps[:cur_t + 2]
         num, rig, ch, ht, wd = fm.shape

@@ -19,6 +19,8 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
   * nerf_func.py         build_rays                                            -> build_rays.npz
   * geom/ba.py + chol.py  BA: the pure-PyTorch dense bundle adjustment (one Gauss-Newton step)  -> ba_python.npz
   * droid_net.py + modules/gru.py  UpdateModule / ConvGRU / GraphAgg / cvx_upsample (CPU fp32)  -> update_module.npz
+  * factor_graph.py      edge management: duplicate filter, max_factors retirement, filter_edges,
+                         rm_keyframe, neighbourhood / proximity proposals with NMS  -> factor_graph_edges.npz
   * InstantNeuS.py       normalisation, masking, sdf gradient by autograd.grad, get_alpha,
                          compositing, compute_sdf_error                       -> neus_forward.npz
 The stand-ins themselves (tcnn / lietorch / CUDA kernels) stay "parity unpinned" (DESIGN.md 4).
@@ -299,12 +301,88 @@ def gen_ba():
          target=target, weight=weight, eta=eta, poses_out=poses_out.data[0], disps_out=disps_out[0])
 
 
+def graph_script(t_total=12, seed=151):
+    """The deterministic edge-management scenario both sides replay: (distance matrix, per-step weights)."""
+    g = torch.Generator().manual_seed(seed)
+    a = torch.rand(t_total, t_total, generator=g) * 30.0
+    dist = 0.5 * (a + a.T) + 3.0 * (torch.arange(t_total)[:, None] - torch.arange(t_total)[None]).abs().float()
+    conf = torch.rand(256, generator=g)                         # per-edge confidences for filter_edges
+    conf = torch.where(conf < 0.35, conf * 1e-3, conf)
+    return dist, conf
+
+
+def run_graph_scenario(graph, video, dist, conf, set_counter, snapshot):
+    """Drives a FactorGraph (the reference's or ours -- same method names) through neighbourhood / proximity
+    proposals, the max_factors retirement, confidence filtering, keyframe removal, ageing and clear_edges,
+    calling snapshot(tag) after every step."""
+    def set_weight():
+        E = graph.ii.shape[0]
+        graph.weight = conf[:E].view(1, E, 1, 1, 1).expand(1, E, graph.ht, graph.wd, 2).clone()
+    set_counter(6)
+    graph.add_neighborhood_factors(0, 6, r=2); snapshot("nbr")
+    graph.age += 1
+    set_counter(9)
+    graph.add_proximity_factors(t0=3, t1=0, rad=2, nms=2, thresh=40.0, remove=True); snapshot("prox1")
+    graph.age += 1
+    set_weight()
+    graph.filter_edges(); snapshot("filter")
+    graph.rm_keyframe(7); snapshot("rmkf")
+    set_counter(12)
+    graph.add_proximity_factors(t0=7, t1=2, rad=2, nms=2, thresh=45.0, remove=True); snapshot("prox2")
+    graph.age += 1
+    graph.rm_factors(graph.age > 2, store=True); snapshot("age")
+    graph.add_proximity_factors(t0=0, t1=0, rad=1, nms=1, thresh=30.0, remove=True); snapshot("prox3")
+    graph.add_proximity_factors(t0=5, t1=1, rad=3, nms=0, beta=0.5, thresh=60.0, remove=False, max_t=10)
+    snapshot("prox4")
+    graph.clear_edges(); snapshot("clear")
+    graph.add_neighborhood_factors(8, 12, r=3); snapshot("nbr2")
+
+
+def gen_graph():
+    """The reference's own FactorGraph edge management (src/factor_graph.py:43-197, 368-450) on CPU with a mocked
+    video (frame distances come from a fixed matrix, reprojection returns zeros); records every edge list after
+    every step of run_graph_scenario."""
+    import contextlib
+    mods = sys.modules["refsrc.modules"]
+    corr = importlib.import_module("refsrc.modules.corr")
+    mods.CorrBlock, mods.AltCorrBlock = corr.CorrBlock, corr.AltCorrBlock
+    fg = importlib.import_module("refsrc.factor_graph")
+    T, h, w = 12, 16, 16
+    dist, conf = graph_script(T)
+    gen = torch.Generator().manual_seed(157)
+    B = T + 2
+    video = types.SimpleNamespace(
+        ht=8 * h, wd=8 * w, stereo=False, counter=types.SimpleNamespace(value=0),
+        get_lock=contextlib.nullcontext,
+        distance=lambda ii, jj, beta=0.3: dist[ii, jj].clone(),
+        reproject=lambda ii, jj: (torch.zeros(1, len(ii), h, w, 2), torch.ones(1, len(ii), h, w, 1)))
+    for name, shape in (("timestamp", ()), ("images", (3, 8 * h, 8 * w)), ("dirty", ()), ("red", ()), ("poses", (7,)),
+                        ("poses_gt", (4, 4)), ("disps", (h, w)), ("disps_sens", (h, w)), ("disps_up", (8 * h, 8 * w)),
+                        ("depths_gt", (8 * h, 8 * w)), ("intrinsics", (4,)), ("poses_filtered", (7,)),
+                        ("disps_filtered", (h, w)), ("mask_filtered", (h, w)), ("update_priority", ()),
+                        ("nets", (4, h, w)), ("inps", (4, h, w)), ("fmaps", (1, 4, h, w))):
+        setattr(video, name, torch.rand(B, *shape, generator=gen))
+    poses0 = video.poses.clone()
+    graph = fg.FactorGraph(video, None, device="cpu", corr_impl="volume", max_factors=40)
+    out = {"dist": dist, "conf": conf, "poses_in": poses0}
+    tags = []
+
+    def snapshot(tag):
+        tags.append(tag)
+        for k in ("ii", "jj", "age", "ii_inac", "jj_inac", "ii_bad", "jj_bad"):
+            out[f"{tag}_{k}"] = getattr(graph, k).clone()
+    run_graph_scenario(graph, video, dist, conf, lambda n: setattr(video.counter, "value", n), snapshot)
+    out["poses_out"] = video.poses
+    save("factor_graph_edges.npz", tags=np.array(tags), **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate the fixtures"
     install_stubs()
     with torch.no_grad():
         gen_update()
         gen_ba()
+        gen_graph()
         gen_corr()
         gen_proj()
         gen_render()

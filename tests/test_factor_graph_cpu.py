@@ -122,3 +122,79 @@ def test_mfma_fragment_packers_match_their_documented_layouts():
     W1T[:80] = W1.t()
     for mt, ks, l, e in [(0, 0, 0, 0), (2, 3, 63, 7), (2, 1, 15, 3), (2, 2, 16, 0)]:
         assert P[28 + mt * 4 + ks, l, e] == W1T[32 * mt + (l & 31), 16 * ks + 8 * (l >> 5) + e]
+
+
+class _FakeCorr:
+    """stand-in for the HIP CorrBlock on the CPU: tracks only how many edges it holds."""
+
+    def __init__(self, fmap1, fmap2, **kw):
+        self.n = fmap1.shape[1]
+
+    def cat(self, other):
+        self.n += other.n
+        return self
+
+    def __getitem__(self, keep):
+        assert keep.numel() == self.n
+        self.n = int(keep.sum())
+        return self
+
+
+def test_edge_management_matches_reference_golden(monkeypatch):
+    """Replay tests/golden/gen_golden.py's scenario (neighbourhood + proximity proposals with NMS, duplicate filter,
+    max_factors retirement, filter_edges, rm_keyframe, ageing, clear_edges) on our FactorGraph and compare every
+    edge list after every step with what the reference's own FactorGraph produced (src/factor_graph.py:43-197,
+    368-450; fixture factor_graph_edges.npz)."""
+    import importlib.util
+    import os
+
+    import numpy as np
+
+    import go_slam_amd.factor_graph as FG
+    here = os.path.dirname(__file__)
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(here, "golden", "gen_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gold = np.load(os.path.join(here, "golden", "factor_graph_edges.npz"))
+    dist, conf = torch.from_numpy(gold["dist"]), torch.from_numpy(gold["conf"])
+    d2, c2 = gen.graph_script(dist.shape[0])
+    assert torch.equal(d2, dist) and torch.equal(c2, conf)          # the scenario is the committed one
+    monkeypatch.setattr(FG, "CorrBlock", _FakeCorr)
+    T, h, w = dist.shape[0], 4, 4
+    B = T + 2
+    video = types.SimpleNamespace(
+        ht=h, wd=w, stereo=False, counter=0, disps=torch.ones(B, h, w), poses=torch.from_numpy(gold["poses_in"]).clone(),
+        nets=torch.rand(B, 4, h, w), inps=torch.rand(B, 4, h, w), fmaps=torch.rand(B, 1, 4, h, w),
+        distance=lambda ii, jj, beta=0.3: dist[ii, jj].clone(),
+        reproject=lambda ii, jj: (torch.zeros(1, len(ii), h, w, 2), torch.ones(1, len(ii), h, w, 1)))
+    g = FactorGraph(video, update_op=None, device="cpu", corr_impl="volume", max_factors=40, channels_last=False)
+    seen = []
+
+    def snapshot(tag):
+        seen.append(tag)
+        for k in ("ii", "jj", "age", "ii_inac", "jj_inac", "ii_bad", "jj_bad"):
+            assert np.array_equal(getattr(g, k).numpy(), gold[f"{tag}_{k}"]), (tag, k)
+        E = g.ii.numel()
+        assert g.target.shape[1] == E and g.weight.shape[1] == E and g.target_inac.shape[1] == g.ii_inac.numel()
+        assert (g.corr.n if g.corr is not None else 0) == E
+        if g.net is not None:
+            assert g.net.shape[1] == E and g.inp.shape[1] == E
+    gen.run_graph_scenario(g, video, dist, conf, lambda n: setattr(video, "counter", n), snapshot)
+    assert seen == list(gold["tags"])
+    assert np.array_equal(video.poses.numpy(), gold["poses_out"])   # rm_keyframe moved slot ix+1 down
+
+
+def test_proximity_proposal_corner_cases():
+    """propose_proximity_edges: max_factors = -1 stops after the local window (the reference's `len(es) >
+    max_factors` test, src/factor_graph.py:436), stereo adds the (i, i) edges, suppressed candidates are skipped."""
+    import numpy as np
+    d = np.full((4, 6), 5.0, dtype=np.float32)
+    es = FactorGraph.propose_proximity_edges(d.copy(), [], 2, 0, 6, 1, 1, 16.0, -1, False)
+    assert es == [(2, 1), (1, 2), (3, 2), (2, 3), (4, 3), (3, 4), (5, 4), (4, 5)]
+    es = FactorGraph.propose_proximity_edges(d.copy(), [], 2, 0, 6, 1, 1, 16.0, -1, True)
+    assert es[:3] == [(2, 2), (2, 1), (1, 2)] and (5, 5) in es
+    d2 = d.copy()
+    d2[3, 0] = 1.0                                                  # (5, 0): the only candidate left after NMS
+    es = FactorGraph.propose_proximity_edges(d2, [(3, 1)], 2, 0, 6, 1, 1, 16.0, 100, False)
+    assert es[8:10] == [(5, 0), (0, 5)]
+    assert all(e != (3, 1) and e != (2, 0) for e in es[8:])         # existing edge and its NMS neighbourhood
