@@ -21,6 +21,7 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
   * droid_net.py + modules/gru.py  UpdateModule / ConvGRU / GraphAgg / cvx_upsample (CPU fp32)  -> update_module.npz
   * factor_graph.py      edge management: duplicate filter, max_factors retirement, filter_edges,
                          rm_keyframe, neighbourhood / proximity proposals with NMS  -> factor_graph_edges.npz
+  * backend.py           Backend.ba edge proposal (dense + loop closure)       -> backend_edges.npz
   * InstantNeuS.py       normalisation, masking, sdf gradient by autograd.grad, get_alpha,
                          compositing, compute_sdf_error                       -> neus_forward.npz
 The stand-ins themselves (tcnn / lietorch / CUDA kernels) stay "parity unpinned" (DESIGN.md 4).
@@ -376,6 +377,84 @@ def gen_graph():
     save("factor_graph_edges.npz", tags=np.array(tags), **out)
 
 
+BACKEND_CASES = (  # name, t_start, t_end, nms, radius, thresh, max_factors, t_start_loop, loop, stereo
+    ("dense", 0, 14, 2, 2, 28.0, 112, None, False, False),
+    ("dense_off", 3, 17, 1, 1, 35.0, 84, None, False, False),
+    ("stereo", 0, 10, 1, 2, 30.0, 90, None, False, True),
+    ("capped", 0, 16, 0, 1, 50.0, 40, None, False, False),
+    ("loop", 0, 20, 2, 3, 34.0, 64, 12, True, False),
+    ("loop_stereo", 2, 18, 1, 2, 40.0, 48, 9, True, True),
+    ("few", 0, 2, 2, 2, 1.0, 16, None, False, False),
+)
+
+
+class RecorderGraph:
+    """stands in for FactorGraph in Backend.ba: records what the backend asks of it."""
+
+    def __init__(self):
+        self.ii = torch.zeros(0, dtype=torch.long)
+        self.calls = []
+
+    def add_factors(self, ii, jj, remove=False):
+        self.calls.append(("add_factors", bool(remove)))
+        self.es = torch.stack([torch.as_tensor(ii), torch.as_tensor(jj)], 1).long()
+        self.ii = self.es[:, 0]
+
+    def update_lowmem(self, **kw):
+        self.calls.append(("update_lowmem", tuple(sorted(kw.items()))))
+
+    def clear_edges(self):
+        self.calls.append(("clear_edges",))
+
+
+def backend_distance(t_total=20, seed=163):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.rand(t_total, t_total, generator=g) * 40.0
+    a = 0.5 * (a + a.T)
+    # a band of revisits so the loop detector sees 3x3 neighbourhoods below threshold
+    for k in range(3):
+        for o in (-1, 0, 1):
+            for p in (-1, 0, 1):
+                a[15 + k + o, 2 + k + p] = a[2 + k + p, 15 + k + o] = 6.0 + k + 0.1 * o + 0.01 * p
+    return a
+
+
+def backend_cfg():
+    return {"tracking": {"upsample": False, "beta": 0.75, "backend": {
+        "thresh": 25.0, "radius": 1, "nms": 5, "loop_window": 25, "loop_thresh": 25.0, "loop_radius": 1,
+        "loop_nms": 12}}}
+
+
+def run_backend_cases(backend_cls, dist):
+    """Replays BACKEND_CASES through a Backend class (the reference's or ours)."""
+    out = {}
+    for name, ts, te, nms, rad, th, mf, tsl, loop, stereo in BACKEND_CASES:
+        video = types.SimpleNamespace(stereo=stereo, dirty=torch.zeros(dist.shape[0], dtype=torch.bool),
+                                      distance=lambda ii, jj, beta=0.3: dist[ii, jj].clone())
+        be = backend_cls(types.SimpleNamespace(update=None), video, types.SimpleNamespace(device="cpu"), backend_cfg())
+        graph = RecorderGraph()
+        n = be.ba(ts, te, 4, graph, nms, rad, th, mf, t_start_loop=tsl, loop=loop, motion_only=(name == "loop"))
+        out[name] = {"ret": n, "es": getattr(graph, "es", torch.zeros(0, 2, dtype=torch.long)), "calls": graph.calls,
+                     "dirty": video.dirty.clone()}
+    return out
+
+
+def gen_backend():
+    """The reference's Backend.ba edge proposal (src/backend.py:25-120), dense and loop-closure mode, on CPU with a
+    fixed distance matrix and a recording graph."""
+    importlib.import_module("refsrc.factor_graph")
+    be = importlib.import_module("refsrc.backend")
+    dist = backend_distance()
+    res = run_backend_cases(be.Backend, dist)
+    arrays = {"dist": dist}
+    for name, r in res.items():
+        arrays[f"{name}_es"] = r["es"]
+        arrays[f"{name}_ret"] = np.array(r["ret"])
+        arrays[f"{name}_dirty"] = r["dirty"]
+        arrays[f"{name}_calls"] = np.array(repr(r["calls"]))
+    save("backend_edges.npz", **arrays)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate the fixtures"
     install_stubs()
@@ -383,6 +462,7 @@ if __name__ == "__main__":
         gen_update()
         gen_ba()
         gen_graph()
+        gen_backend()
         gen_corr()
         gen_proj()
         gen_render()
