@@ -22,6 +22,7 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
   * factor_graph.py      edge management: duplicate filter, max_factors retirement, filter_edges,
                          rm_keyframe, neighbourhood / proximity proposals with NMS  -> factor_graph_edges.npz
   * backend.py           Backend.ba edge proposal (dense + loop closure)       -> backend_edges.npz
+  * frontend.py          Frontend: call sequence into the graph / loop closure  -> frontend_trace.npz
   * InstantNeuS.py       normalisation, masking, sdf gradient by autograd.grad, get_alpha,
                          compositing, compute_sdf_error                       -> neus_forward.npz
 The stand-ins themselves (tcnn / lietorch / CUDA kernels) stay "parity unpinned" (DESIGN.md 4).
@@ -455,6 +456,126 @@ def gen_backend():
     save("backend_edges.npz", **arrays)
 
 
+class TraceGraph:
+    """stands in for FactorGraph under Frontend: keeps just enough state (ii, age, corr) for the frontend's
+    control flow and records every call with its arguments."""
+    trace = None
+
+    def __init__(self, video, update_op, device="cpu", corr_impl="volume", max_factors=-1, upsample=False):
+        self.video = video
+        self.ii = torch.zeros(0, dtype=torch.long)
+        self.jj = torch.zeros(0, dtype=torch.long)
+        self.age = torch.zeros(0, dtype=torch.long)
+        self.corr = None
+        TraceGraph.trace.append(("graph", corr_impl, max_factors, bool(upsample)))
+
+    def _add(self, lo, hi):
+        new = torch.arange(lo, hi)
+        self.ii = torch.cat([self.ii, new])
+        self.jj = torch.cat([self.jj, new])
+        self.age = torch.cat([self.age, torch.zeros_like(new)])
+        self.corr = "volumes"
+
+    def add_neighborhood_factors(self, t0, t1, r=3):
+        TraceGraph.trace.append(("nbr", t0, t1, r))
+        self._add(t0, t1)
+
+    def add_proximity_factors(self, t0=0, t1=0, rad=2, nms=2, beta=0.25, thresh=16.0, remove=False, max_t=None):
+        cnt = self.video.counter
+        TraceGraph.trace.append(("prox", t0, t1, rad, nms, beta, thresh, bool(remove), max_t))
+        self._add(max(t0, 0), int(getattr(cnt, "value", cnt)))
+
+    def rm_factors(self, mask, store=False):
+        TraceGraph.trace.append(("rm", mask.tolist(), bool(store)))
+        self.ii, self.jj, self.age = self.ii[~mask], self.jj[~mask], self.age[~mask]
+
+    def rm_keyframe(self, ix):
+        TraceGraph.trace.append(("rmkf", int(ix)))
+        m = (self.ii == ix)
+        self.ii, self.jj, self.age = self.ii[~m], self.jj[~m], self.age[~m]
+        self.video.poses[ix] = self.video.poses[ix + 1]
+        self.video.disps[ix] = self.video.disps[ix + 1]
+
+    def update(self, t0=None, t1=None, iters=2, use_inactive=False, EPS=1e-7, motion_only=False):
+        TraceGraph.trace.append(("update", t0, t1, iters, bool(use_inactive), bool(motion_only)))
+        self.age += 1
+        n = self.ii.max() + 1
+        self.video.poses[1:n] += 0.01                   # any deterministic state change the frontend reads back
+        self.video.disps[1:n] *= 1.01
+
+
+class TraceLoop:
+    def __init__(self, net, video, args, cfg):
+        pass
+
+    def loop_ba(self, t_start, t_end, steps=6, motion_only=False, local_graph=None):
+        TraceGraph.trace.append(("loop_ba", t_start, t_end, steps, bool(motion_only), local_graph is not None))
+        return t_end - t_start, 42
+
+
+FRONTEND_DISTANCES = (0.5, 3.0, 3.0, 0.2, 3.0, 2.3, 2.2, 3.0, 9.0, 0.1, 4.0, 4.0)
+
+
+def frontend_cfg(enable_loop):
+    return {"verbose": False, "tracking": {"warmup": 8, "upsample": True, "beta": 0.75, "frontend": {
+        "max_factors": 75, "nms": 1, "keyframe_thresh": 2.25, "window": 10, "thresh": 16.0, "radius": 2,
+        "enable_loop": enable_loop}, "backend": backend_cfg()["tracking"]["backend"]}}
+
+
+def run_frontend_trace(frontend_cls, enable_loop, value_counter):
+    """Feeds 8 warm-up keyframes, then one new keyframe per entry of FRONTEND_DISTANCES (the scripted keyframe
+    distance decides keep / drop), through a Frontend class; returns (trace, video)."""
+    import contextlib
+    TraceGraph.trace = []
+    B, h, w = 40, 3, 4
+    g = torch.Generator().manual_seed(167)
+    dq = list(FRONTEND_DISTANCES)
+
+    def distance(ii, jj, beta=0.3, bidirectional=True):
+        TraceGraph.trace.append(("distance", [int(x) for x in ii], [int(x) for x in jj], beta, bool(bidirectional)))
+        return torch.tensor([dq.pop(0)])
+    video = types.SimpleNamespace(
+        poses=torch.rand(B, 7, generator=g), disps=torch.rand(B, h, w, generator=g) + 0.5,
+        disps_sens=torch.rand(B, h, w, generator=g) * (torch.rand(B, h, w, generator=g) > 0.5),
+        timestamp=torch.arange(B).float(), dirty=torch.zeros(B, dtype=torch.bool),
+        counter=types.SimpleNamespace(value=0) if value_counter else 0, ready=types.SimpleNamespace(value=0),
+        get_lock=contextlib.nullcontext, distance=distance, stereo=False)
+
+    def bump():
+        if value_counter:
+            video.counter.value += 1
+        else:
+            video.counter += 1
+    fe = frontend_cls(types.SimpleNamespace(update=None), video, types.SimpleNamespace(device="cpu"),
+                      frontend_cfg(enable_loop))
+    for _ in range(8):
+        bump()
+        fe()                                             # no-ops until the warm-up count is reached, then initialise
+    while dq:
+        bump()
+        fe()
+        TraceGraph.trace.append(("state", fe.t1, fe.count, fe.last_loop_t,
+                                 video.counter.value if value_counter else video.counter))
+    fe()                                                 # nothing new: must be a no-op
+    return TraceGraph.trace, video, fe
+
+
+def gen_frontend():
+    """The reference's Frontend (src/frontend.py:9-160) driven over a scripted keyframe stream with a tracing graph:
+    records the exact sequence of graph / loop-closure calls and the video state it leaves."""
+    fe = importlib.import_module("refsrc.frontend")
+    fe.FactorGraph, fe.LoopClosing = TraceGraph, TraceLoop
+    arrays = {}
+    for loop in (False, True):
+        trace, video, f = run_frontend_trace(fe.Frontend, loop, True)
+        tag = "loop" if loop else "noloop"
+        arrays[f"{tag}_trace"] = np.array(repr(trace))
+        arrays[f"{tag}_poses"], arrays[f"{tag}_disps"], arrays[f"{tag}_dirty"] = video.poses, video.disps, video.dirty
+        arrays[f"{tag}_last"] = torch.cat([f.last_pose, f.last_disp.reshape(-1), f.last_time.reshape(-1)])
+        arrays[f"{tag}_ready"] = np.array(video.ready.value)
+    save("frontend_trace.npz", **arrays)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate the fixtures"
     install_stubs()
@@ -463,6 +584,7 @@ if __name__ == "__main__":
         gen_ba()
         gen_graph()
         gen_backend()
+        gen_frontend()
         gen_corr()
         gen_proj()
         gen_render()

@@ -73,3 +73,28 @@ def test_dense_and_loop_ba_budgets(monkeypatch):
     a, k = seen[-1]
     assert made[-1].kw["max_factors"] == 200 and torch.equal(made[-1].ii, local.ii) and made[-1].ii is not local.ii
     assert a[4:] == (12, 2, 26.0, 200 - 6) and k == {"t_start_loop": 35, "loop": True, "motion_only": True}
+
+
+def test_frontend_call_sequence_matches_reference_golden(monkeypatch):
+    """Our Frontend, driven over the scripted keyframe stream of gen_golden.run_frontend_trace with the same tracing
+    graph, must issue the reference Frontend's exact call sequence (src/frontend.py:48-160: age-based retirement,
+    proximity proposal arguments, 4 + 2 updates, keyframe drop, loop-closure hand-off) and leave the same video
+    state.  Runs with both counter flavours (plain int and multiprocessing.Value-like)."""
+    import go_slam_amd.frontend as F
+    gen = _gen()
+    gold = np.load(os.path.join(HERE, "golden", "frontend_trace.npz"))
+    monkeypatch.setattr(F, "FactorGraph", gen.TraceGraph)
+    monkeypatch.setattr(F, "LoopClosing", gen.TraceLoop)
+    for loop in (False, True):
+        tag = "loop" if loop else "noloop"
+        for value_counter in (True, False):
+            trace, video, fe = gen.run_frontend_trace(F.Frontend, loop, value_counter)
+            assert repr(trace) == str(gold[f"{tag}_trace"]), (tag, value_counter)
+            assert np.allclose(video.poses.numpy(), gold[f"{tag}_poses"], rtol=0, atol=1e-6)
+            assert np.allclose(video.disps.numpy(), gold[f"{tag}_disps"], rtol=1e-6, atol=0)
+            assert np.array_equal(video.dirty.numpy(), gold[f"{tag}_dirty"])
+            last = torch.cat([fe.last_pose, fe.last_disp.reshape(-1), fe.last_time.reshape(-1)])
+            assert np.allclose(last.numpy(), gold[f"{tag}_last"], atol=1e-6)
+            assert video.ready.value == int(gold[f"{tag}_ready"]) == 1
+    assert "loop_ba" in str(gold["loop_trace"]) and "loop_ba" not in str(gold["noloop_trace"])
+    assert "rmkf" in str(gold["loop_trace"])
