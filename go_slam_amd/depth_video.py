@@ -13,7 +13,9 @@ from .droid_net import cvx_upsample
 
 
 class DepthVideo:
-    def __init__(self, ht, wd, buffer=512, device="cuda:0", stereo=False):
+    def __init__(self, ht, wd, buffer=512, device="cuda:0", stereo=False, full_res=False):
+        """`full_res`: also keep the per-keyframe full-resolution buffers of the reference (images, depths_gt,
+        poses_gt; src/depth_video.py:41-49) that MotionFilter.track fills -- 8h x 8w, allocated only on request."""
         self.device = torch.device(device)
         self.ht, self.wd = ht, wd            # 1/8-resolution map size
         d = self.device
@@ -31,6 +33,82 @@ class DepthVideo:
         self.nets = torch.zeros(buffer, 128, ht, wd, device=d, dtype=torch.half)
         self.inps = torch.zeros(buffer, 128, ht, wd, device=d, dtype=torch.half)
         self.dirty = torch.zeros(buffer, device=d, dtype=torch.bool)
+        if full_res:
+            self.images = torch.zeros(buffer, 3, 8 * ht, 8 * wd, device=d, dtype=torch.float32)
+            self.depths_gt = torch.zeros(buffer, 8 * ht, 8 * wd, device=d, dtype=torch.float32)
+            self.poses_gt = torch.eye(4, device=d, dtype=torch.float32).repeat(buffer, 1, 1)
+
+    @classmethod
+    def from_config(cls, cfg, args):
+        """the reference's constructor form DepthVideo(cfg, args) (src/depth_video.py:13-36)."""
+        return cls(cfg["cam"]["H_out"] // 8, cfg["cam"]["W_out"] // 8, buffer=cfg["tracking"]["buffer"],
+                   device=args.device, stereo=(cfg["mode"] == "stereo"), full_res=True)
+
+    def get_lock(self):
+        """single-process host mirror: nothing to lock (the reference guards IPC-shared buffers)."""
+        import contextlib
+        return contextlib.nullcontext()
+
+    def _count(self):
+        return int(getattr(self.counter, "value", self.counter))
+
+    def _set_count(self, n):
+        if hasattr(self.counter, "value"):
+            self.counter.value = int(n)
+        else:
+            self.counter = int(n)
+
+    def __setitem__(self, index, item):
+        """item = (timestamp, image, pose | None, disp | None, depth | None, intrinsics | None[, fmap, net, inp,
+        gt_pose]) -- src/depth_video.py:80-121.  A sensor depth is sub-sampled at the (3, 3) phase of every 8x8
+        cell and becomes both the prior (disps_sens) and the initial disparity."""
+        n = self._count()
+        if isinstance(index, int) and index >= n:
+            self._set_count(index + 1)
+        elif torch.is_tensor(index) and int(index.max()) > n:
+            self._set_count(int(index.max()) + 1)
+        self.timestamp[index] = item[0]
+        if hasattr(self, "images"):
+            self.images[index] = item[1]
+        if item[2] is not None:
+            self.poses[index] = item[2]
+        if item[3] is not None:
+            self.disps[index] = item[3]
+        if item[4] is not None:
+            if hasattr(self, "depths_gt"):
+                self.depths_gt[index] = item[4]
+            depth = item[4][..., 3::8, 3::8].to(self.device)
+            self.disps_sens[index] = torch.where(depth > 0, 1.0 / depth, depth)
+            self.disps[index] = self.disps_sens[index].clone()
+        if item[5] is not None:
+            self.intrinsics[index] = item[5]
+        if len(item) > 6:
+            self.fmaps[index] = item[6]
+        if len(item) > 7:
+            self.nets[index] = item[7]
+        if len(item) > 8:
+            self.inps[index] = item[8]
+        if len(item) > 9 and item[9] is not None and hasattr(self, "poses_gt"):
+            self.poses_gt[index] = item[9].to(self.poses_gt.device)
+
+    def __getitem__(self, index):
+        """(poses, disps, intrinsics, fmaps, nets, inps) at `index` (src/depth_video.py:127-143; the reference
+        offsets POSITIVE int indices by the counter -- kept)."""
+        if isinstance(index, int) and index > 0:
+            index = self._count() + index
+        return (self.poses[index], self.disps[index], self.intrinsics[index], self.fmaps[index], self.nets[index],
+                self.inps[index])
+
+    def append(self, *item):
+        self[self._count()] = item
+
+    def normalize(self):
+        """unit mean disparity over the keyframes so far; translations scale with it (src/depth_video.py:198-205)"""
+        n = self._count()
+        s = self.disps[:n].mean()
+        self.disps[:n] /= s
+        self.poses[:n, :3] *= s
+        self.dirty[:n] = True
 
     @staticmethod
     def format_indices(ii, jj, device="cuda"):

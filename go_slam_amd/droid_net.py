@@ -452,3 +452,27 @@ class UpdateModule(nn.Module):
             eta, upmask = self.agg(net, ii.to(net.device))
             return net, delta, weight, eta, upmask
         return net, delta, weight
+
+
+class DroidNet(nn.Module):
+    """fnet (instance-norm features, 128 ch) + cnet (context: 128 hidden + 128 input ch) + the update operator
+    (src/droid_net.py:143-148); sub-module names are the checkpoint's."""
+
+    def __init__(self):
+        super().__init__()
+        from .extractor import BasicEncoder
+        self.fnet = BasicEncoder(out_dim=128, norm_fn="instance")
+        self.cnet = BasicEncoder(out_dim=256, norm_fn="none")
+        self.update = UpdateModule()
+
+
+def load_pretrained(net, state_dict):
+    """Load a DROID-SLAM checkpoint into `net` the way src/slam.py:196-208 does: strip the DataParallel `module.`
+    prefix and keep only the first 2 output channels of the weight / delta heads (trained with 3)."""
+    sd = {k.replace("module.", ""): v for k, v in state_dict.items()}
+    for head in ("weight", "delta"):
+        for p in ("weight", "bias"):
+            k = f"update.{head}.2.{p}"
+            sd[k] = sd[k][:2]
+    net.load_state_dict(sd)
+    return net

@@ -23,6 +23,8 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
                          rm_keyframe, neighbourhood / proximity proposals with NMS  -> factor_graph_edges.npz
   * backend.py           Backend.ba edge proposal (dense + loop closure)       -> backend_edges.npz
   * frontend.py          Frontend: call sequence into the graph / loop closure  -> frontend_trace.npz
+  * modules/extractor.py BasicEncoder (fnet / cnet) + DroidNet checkpoint keys   -> encoders.npz
+  * motion_filter.py     MotionFilter.track keyframe decisions + appended items  -> motion_filter.npz
   * InstantNeuS.py       normalisation, masking, sdf gradient by autograd.grad, get_alpha,
                          compositing, compute_sdf_error                       -> neus_forward.npz
 The stand-ins themselves (tcnn / lietorch / CUDA kernels) stay "parity unpinned" (DESIGN.md 4).
@@ -576,6 +578,104 @@ def gen_frontend():
     save("frontend_trace.npz", **arrays)
 
 
+def droid_modules():
+    """wire the reference's sub-modules into the synthetic `refsrc` package and import its droid_net."""
+    if "torch_scatter" not in sys.modules:
+        ts = types.ModuleType("torch_scatter")
+        ts.scatter_mean = None
+        sys.modules["torch_scatter"] = ts
+    mods = sys.modules["refsrc.modules"]
+    mods.GradientClip = importlib.import_module("refsrc.modules.clipping").GradientClip
+    mods.ConvGRU = importlib.import_module("refsrc.modules.gru").ConvGRU
+    mods.BasicEncoder = importlib.import_module("refsrc.modules.extractor").BasicEncoder
+    corr = importlib.import_module("refsrc.modules.corr")
+    mods.CorrBlock, mods.AltCorrBlock = corr.CorrBlock, corr.AltCorrBlock
+    return importlib.import_module("refsrc.droid_net")
+
+
+def gen_encoder():
+    """The reference's BasicEncoder (src/modules/extractor.py:61-126) in the two configurations DroidNet uses
+    (instance norm -> 128 ch, no norm -> 256 ch) on a 2-view 64x96 input, CPU fp32; plus DroidNet's checkpoint keys."""
+    dn = droid_modules()
+    net = dn.DroidNet().eval()
+    sd = named_weights(net.state_dict(), seed=173)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(179)
+    x = torch.randn(1, 2, 3, 64, 96, generator=g)
+    save("encoders.npz", x=x, fnet=net.fnet(x), cnet=net.cnet(x),
+         keys=np.array(list(net.state_dict().keys())),
+         shapes=np.array([str(tuple(v.shape)) for v in net.state_dict().values()]))
+
+
+MOTION_SCRIPT = (None, 1.0, 3.1, 0.2, 2.6, 2.4, 9.0)      # mean flow the update operator reports, per frame
+
+
+def digest(x):
+    """small fingerprint of a large tensor: sum, abs-sum and a strided sample"""
+    x = torch.as_tensor(x).double().reshape(-1)
+    if x.numel() <= 64:
+        return x
+    return torch.cat([x.sum()[None], x.abs().sum()[None], x[::37][:384]])
+
+
+def run_motion_filter(mf_cls, net, stereo, value_counter=True):
+    """Feeds len(MOTION_SCRIPT) frames through a MotionFilter class whose update operator is scripted; returns the
+    list of video.append argument tuples plus the filter's skip counter after each frame."""
+    g = torch.Generator().manual_seed(181)
+    dq = list(MOTION_SCRIPT[1:])
+    appended, counts = [], []
+
+    class Video:
+        def __init__(self):
+            self.counter = types.SimpleNamespace(value=0) if value_counter else 0
+
+        def append(self, *item):
+            appended.append(tuple(x.clone() if torch.is_tensor(x) else x for x in item))
+            if value_counter:
+                self.counter.value += 1
+            else:
+                self.counter += 1
+
+    def update(net_, inp_, corr_):
+        assert net_.shape == inp_.shape == (1, 1, 128, 16, 16) and corr_.shape == (1, 1, 196, 16, 16)
+        m = dq.pop(0)
+        delta = torch.zeros(1, 1, 16, 16, 2)
+        delta[..., 0] = m
+        return net_, delta, torch.ones_like(delta)
+    parts = types.SimpleNamespace(cnet=net.cnet, fnet=net.fnet, update=update)
+    mf = mf_cls(parts, Video(), thresh=2.5, device="cpu")
+    b = 2 if stereo else 1
+    for t in range(len(MOTION_SCRIPT)):
+        image = torch.rand(b, 3, 128, 128, generator=g)
+        depth = torch.rand(128, 128, generator=g) * 4 if t % 4 != 2 else None
+        intr = torch.tensor([50.0, 52.0, 48.0, 32.0])
+        mf.track(float(t), image, depth, intr, gt_pose=torch.eye(4) * (t + 1))
+        counts.append(mf.count)
+    return appended, counts
+
+
+def gen_motion_filter():
+    """The reference's MotionFilter.track (src/motion_filter.py:41-90) with its own encoders (CPU fp32) and CorrBlock
+    (sampler stood in by the oracle) and a scripted update operator: which frames become keyframes and what is
+    appended to the video for each."""
+    dn = droid_modules()
+    mfm = importlib.import_module("refsrc.motion_filter")
+    net = dn.DroidNet().eval()
+    net.load_state_dict(named_weights(net.state_dict(), seed=173))
+    arrays = {}
+    for stereo in (False, True):
+        appended, counts = run_motion_filter(mfm.MotionFilter, net, stereo)
+        tag = "stereo" if stereo else "mono"
+        arrays[f"{tag}_counts"] = np.array(counts)
+        arrays[f"{tag}_n"] = np.array(len(appended))
+        for k, item in enumerate(appended):
+            arrays[f"{tag}_{k}_none"] = np.array([x is None for x in item])
+            for a, x in enumerate(item):
+                if x is not None:
+                    arrays[f"{tag}_{k}_{a}"] = digest(x)
+    save("motion_filter.npz", **arrays)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate the fixtures"
     install_stubs()
@@ -585,6 +685,8 @@ if __name__ == "__main__":
         gen_graph()
         gen_backend()
         gen_frontend()
+        gen_encoder()
+        gen_motion_filter()
         gen_corr()
         gen_proj()
         gen_render()

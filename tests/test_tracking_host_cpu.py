@@ -1,0 +1,130 @@
+"""Per-frame host pieces of the tracker on the CPU: the encoders, the DroidNet checkpoint contract, MotionFilter and
+the DepthVideo item setter -- against fixtures produced by the reference's own modules (tests/golden/gen_golden.py:
+gen_encoder, gen_motion_filter)."""
+import importlib.util
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from go_slam_amd.depth_video import DepthVideo
+from go_slam_amd.droid_net import DroidNet, load_pretrained
+
+HERE = os.path.dirname(__file__)
+
+
+def _gen():
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(HERE, "golden", "gen_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    return gen
+
+
+@pytest.fixture(scope="module")
+def net():
+    gen = _gen()
+    n = DroidNet().eval()
+    n.load_state_dict(gen.named_weights(n.state_dict(), seed=173))
+    return n
+
+
+def test_droidnet_checkpoint_contract():
+    """same parameter names, order and shapes as the reference's DroidNet (strict load_state_dict, src/slam.py:196-208);
+    load_pretrained strips `module.` and slices the 3-channel heads of the published checkpoint to 2."""
+    gold = np.load(os.path.join(HERE, "golden", "encoders.npz"))
+    n = DroidNet()
+    sd = n.state_dict()
+    assert list(sd.keys()) == list(gold["keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(gold["shapes"])
+    ckpt = {"module." + k: v.clone() for k, v in sd.items()}
+    for head in ("weight", "delta"):
+        for p in ("weight", "bias"):
+            k = f"module.update.{head}.2.{p}"
+            ckpt[k] = torch.cat([ckpt[k], torch.full_like(ckpt[k][:1], 7.0)])       # 3 output channels, as trained
+    m = load_pretrained(DroidNet(), ckpt)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+
+
+def test_encoders_match_reference(net):
+    """BasicEncoder in both DroidNet configurations vs the reference's (src/modules/extractor.py:61-126), CPU fp32"""
+    gold = np.load(os.path.join(HERE, "golden", "encoders.npz"))
+    x = torch.from_numpy(gold["x"])
+    with torch.no_grad():
+        f, c = net.fnet(x), net.cnet(x)
+    assert f.shape == (1, 2, 128, 8, 12) and c.shape == (1, 2, 256, 8, 12)
+    assert np.allclose(f.numpy(), gold["fnet"], rtol=1e-4, atol=1e-4)
+    assert np.allclose(c.numpy(), gold["cnet"], rtol=1e-4, atol=1e-4)
+
+
+class _ZeroCorr:
+    """the HIP CorrBlock cannot run on the CPU; the scripted update operator ignores the features anyway"""
+
+    def __init__(self, fmap1, fmap2):
+        assert fmap1.shape == fmap2.shape and fmap1.shape[:3] == (1, 1, 128)
+
+    def __call__(self, coords):
+        return torch.zeros(1, 1, 196, *coords.shape[2:4])
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+def test_motion_filter_matches_reference(net, stereo, monkeypatch):
+    """keyframe decisions and every argument of video.append vs the reference's MotionFilter.track
+    (src/motion_filter.py:41-90): first frame with identity pose and unit disparity, later keyframes with None,
+    intrinsics / 8, left-view net / inp, both views' feature maps, the in-place normalised image alias."""
+    import go_slam_amd.motion_filter as MF
+    gen = _gen()
+    gold = np.load(os.path.join(HERE, "golden", "motion_filter.npz"))
+    monkeypatch.setattr(MF, "CorrBlock", _ZeroCorr)
+    tag = "stereo" if stereo else "mono"
+    for value_counter in (True, False):
+        appended, counts = gen.run_motion_filter(MF.MotionFilter, net, stereo, value_counter)
+        assert counts == list(gold[f"{tag}_counts"])
+        assert len(appended) == int(gold[f"{tag}_n"])
+        for k, item in enumerate(appended):
+            assert [x is None for x in item] == list(gold[f"{tag}_{k}_none"]), k
+            for a, x in enumerate(item):
+                if x is not None:
+                    assert np.allclose(gen.digest(x).numpy(), gold[f"{tag}_{k}_{a}"], rtol=1e-4, atol=1e-4), (k, a)
+
+
+def test_depth_video_item_setter_and_normalize():
+    """DepthVideo.append / __setitem__ / __getitem__ / normalize (src/depth_video.py:80-143, 198-205)"""
+    v = DepthVideo(4, 6, buffer=8, device="cpu", stereo=True, full_res=True)
+    g = torch.Generator().manual_seed(1)
+    depth = torch.rand(32, 48, generator=g) * 3
+    depth[::5] = 0.0                                                  # missing sensor depth stays 0
+    img = torch.rand(3, 32, 48, generator=g)
+    fmap = torch.rand(2, 128, 4, 6, generator=g)
+    net_, inp_ = torch.rand(128, 4, 6, generator=g), torch.rand(128, 4, 6, generator=g)
+    intr = torch.tensor([10.0, 11.0, 3.0, 2.0])
+    ident = torch.tensor([0, 0, 0, 0, 0, 0, 1.0])
+    v.append(0.5, img, ident, 1.0, depth, intr, fmap, net_, inp_, torch.eye(4) * 2)
+    assert v.counter == 1 and float(v.timestamp[0]) == 0.5
+    sub = depth[3::8, 3::8]
+    want = torch.where(sub > 0, 1.0 / sub, sub)
+    assert torch.equal(v.disps_sens[0], want) and torch.equal(v.disps[0], want)      # sensor depth overrides 1.0
+    assert torch.equal(v.images[0], img) and torch.equal(v.depths_gt[0], depth)
+    assert torch.equal(v.fmaps[0], fmap.half()) and torch.equal(v.nets[0], net_.half())
+    assert torch.equal(v.poses_gt[0], torch.eye(4) * 2)
+    v.append(1.5, img, None, None, None, intr, fmap, net_, inp_, None)
+    assert v.counter == 2 and torch.equal(v.poses[1], ident) and torch.all(v.disps[1] == 1.0)
+    v[5] = (9.0, img, None, 0.25, None, None)                         # sparse write moves the counter
+    assert v.counter == 6 and torch.all(v.disps[5] == 0.25)
+    poses, disps, intrinsics, fmaps, nets, inps = v[0]
+    assert torch.equal(disps, v.disps[0]) and torch.equal(intrinsics, intr)
+    v.counter = 2
+    v.poses[:2, :3] = torch.tensor([[1.0, 2.0, 3.0], [2.0, 0.0, 1.0]])
+    before = v.disps[:2].clone()
+    s = before.mean()
+    v.normalize()
+    assert torch.allclose(v.disps[:2], before / s) and torch.allclose(v.disps[:2].mean(), torch.tensor(1.0))
+    assert torch.allclose(v.poses[0, :3], torch.tensor([1.0, 2.0, 3.0]) * s) and bool(v.dirty[:2].all())
+    lean = DepthVideo(4, 6, buffer=4, device="cpu")                   # hot-path-only mirror: no full-res buffers
+    lean.append(0.0, img, ident, 1.0, depth, intr, fmap[:1], net_, inp_, None)
+    assert lean.counter == 1 and not hasattr(lean, "images")
+    cfg = {"cam": {"H_out": 32, "W_out": 48}, "tracking": {"buffer": 5}, "mode": "rgbd"}
+    fc = DepthVideo.from_config(cfg, types.SimpleNamespace(device="cpu"))
+    assert (fc.ht, fc.wd) == (4, 6) and fc.images.shape == (5, 3, 32, 48) and not fc.stereo
