@@ -37,6 +37,15 @@ class DepthVideo:
             self.images = torch.zeros(buffer, 3, 8 * ht, 8 * wd, device=d, dtype=torch.float32)
             self.depths_gt = torch.zeros(buffer, 8 * ht, 8 * wd, device=d, dtype=torch.float32)
             self.poses_gt = torch.eye(4, device=d, dtype=torch.float32).repeat(buffer, 1, 1)
+            # tracker -> mapper hand-off, written by MultiviewFilter (src/depth_video.py:57-69)
+            self.scale_factor = 8
+            self.poses_filtered = self.poses.clone()
+            self.disps_filtered = torch.zeros(buffer, 8 * ht, 8 * wd, device=d, dtype=torch.float32)
+            self.mask_filtered = torch.zeros(buffer, 8 * ht, 8 * wd, device=d, dtype=torch.float32)
+            self.filtered_id = torch.tensor([-1], dtype=torch.int32, device=d)
+            self.update_priority = torch.zeros(buffer, device=d, dtype=torch.float32)
+            self.bound = torch.zeros(1, 3, 2, device=d, dtype=torch.float32)
+            self.pose_compensate = torch.tensor([[0, 0, 0, 0, 0, 0, 1.0]], device=d)
 
     @classmethod
     def from_config(cls, cfg, args):

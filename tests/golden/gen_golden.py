@@ -25,6 +25,7 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
   * frontend.py          Frontend: call sequence into the graph / loop closure  -> frontend_trace.npz
   * modules/extractor.py BasicEncoder (fnet / cnet) + DroidNet checkpoint keys   -> encoders.npz
   * motion_filter.py     MotionFilter.track keyframe decisions + appended items  -> motion_filter.npz
+  * multiview_filter.py  MultiviewFilter.forward host logic (masks, bound, priority) -> multiview_filter.npz
   * InstantNeuS.py       normalisation, masking, sdf gradient by autograd.grad, get_alpha,
                          compositing, compute_sdf_error                       -> neus_forward.npz
 The stand-ins themselves (tcnn / lietorch / CUDA kernels) stay "parity unpinned" (DESIGN.md 4).
@@ -53,6 +54,15 @@ def install_stubs():
     db.corr_index_forward = lambda vol, coords, r: DO.corr_index_forward(vol, coords, r)
     db.corr_index_backward = lambda vol, coords, g, r: DO.corr_index_backward(vol, coords, g, r)
     db.altcorr_forward = lambda f1, f2, c, r: DO.altcorr_forward(f1, f2, c, r)
+    db.iproj = lambda poses, disps, intr: DO.iproj(poses, disps, intr)
+    db.depth_filter = lambda poses, disps, intr, ix, th: DO.depth_filter(poses, disps, intr, ix, th)
+    if "colorama" not in sys.modules:
+        try:
+            importlib.import_module("colorama")
+        except ImportError:
+            col = types.ModuleType("colorama")
+            col.Fore = col.Style = types.SimpleNamespace(CYAN="", RESET_ALL="")
+            sys.modules["colorama"] = col
     sys.modules["droid_backends"] = db
     # --- lietorch
     lt = types.ModuleType("lietorch")
@@ -676,6 +686,65 @@ def gen_motion_filter():
     save("motion_filter.npz", **arrays)
 
 
+MVF_CASES = (("k3", 3, 12), ("k1", 1, 12), ("kinf", "inf", 12), ("k5_part", 5, 9), ("few", 3, 12))
+
+
+def make_filter_video(cur_t, seed=191):
+    """a 12-keyframe synthetic video laid out like the reference's DepthVideo for MultiviewFilter (full-res buffers
+    at the `tiny` 12x16 shape; intrinsics stored at 1/8 scale)."""
+    import contextlib
+    vid = synth.make_video(12, "tiny", seed=9)
+    g = torch.Generator().manual_seed(seed)
+    B, (h, w) = 14, vid["disps"].shape[-2:]
+    pad = lambda x, fill: torch.cat([x, fill.expand(B - x.shape[0], *x.shape[1:])])
+    ident = torch.tensor([0, 0, 0, 0, 0, 0, 1.0])
+    pf = pad(vid["poses"], ident[None]).clone()
+    pf[:, :3] += 0.05 * torch.randn(B, 3, generator=g)                 # the previously filtered poses differ a bit
+    comp = torch.tensor([[0.1, -0.2, 0.05, 0.0, 0.0, 0.0, 1.0]])
+    comp[0, 3:] = torch.nn.functional.normalize(torch.tensor([0.02, -0.03, 0.01, 1.0]), dim=0)
+    lockable = types.SimpleNamespace(get_lock=contextlib.nullcontext)
+    return types.SimpleNamespace(
+        counter=types.SimpleNamespace(value=cur_t), get_lock=contextlib.nullcontext, mapping=lockable, scale_factor=8,
+        poses=pad(vid["poses"], ident[None]), disps_up=pad(vid["disps"], torch.ones(1, h, w)),
+        intrinsics=(vid["intrinsics"][:1] / 8.0).repeat(B, 1), pose_compensate=comp, poses_filtered=pf,
+        disps_filtered=torch.zeros(B, h, w), mask_filtered=torch.zeros(B, h, w),
+        filtered_id=torch.tensor([-1], dtype=torch.int32), update_priority=torch.rand(B, generator=g),
+        bound=torch.zeros(1, 3, 2))
+
+
+def run_filter_cases(filter_cls):
+    out = {}
+    for name, kernel, cur_t in MVF_CASES:
+        video = make_filter_video(cur_t)
+        cfg = {"tracking": {"warmup": 8, "multiview_filter": {
+            "thresh": 0.2 if name != "few" else 1e-5, "visible_num": 2 if name != "few" else 6,
+            "kernel_size": kernel, "bound_enlarge_scale": 1.1}}}
+        slam = types.SimpleNamespace(net=None, video=video, verbose=False, mode="rgbd", H=12, W=16, fx=1, fy=1, cx=1,
+                                     cy=1)
+        f = filter_cls(cfg, types.SimpleNamespace(device="cpu"), slam)
+        f()
+        out[name] = {k: getattr(video, k).clone() for k in ("update_priority", "mask_filtered", "disps_filtered",
+                                                           "poses_filtered", "filtered_id", "bound")}
+        video.counter.value = 8                            # at the warm-up count: must not run
+        video.filtered_id[0] = -1
+        before = video.bound.clone()
+        f()
+        assert torch.equal(video.bound, before) and int(video.filtered_id) == -1
+    return out
+
+
+def gen_multiview_filter():
+    """The reference's MultiviewFilter.forward (src/multiview_filter.py:99-173) on CPU, with droid_backends.iproj /
+    depth_filter stood in by the oracle: masks, filtered disparities / poses, priorities and the scene bound."""
+    mvf = importlib.import_module("refsrc.multiview_filter")
+    res = run_filter_cases(mvf.MultiviewFilter)
+    arrays = {}
+    for name, r in res.items():
+        for k, v in r.items():
+            arrays[f"{name}_{k}"] = v
+    save("multiview_filter.npz", **arrays)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate the fixtures"
     install_stubs()
@@ -687,6 +756,7 @@ if __name__ == "__main__":
         gen_frontend()
         gen_encoder()
         gen_motion_filter()
+        gen_multiview_filter()
         gen_corr()
         gen_proj()
         gen_render()

@@ -128,3 +128,41 @@ def test_depth_video_item_setter_and_normalize():
     cfg = {"cam": {"H_out": 32, "W_out": 48}, "tracking": {"buffer": 5}, "mode": "rgbd"}
     fc = DepthVideo.from_config(cfg, types.SimpleNamespace(device="cpu"))
     assert (fc.ht, fc.wd) == (4, 6) and fc.images.shape == (5, 3, 32, 48) and not fc.stereo
+
+
+def test_multiview_filter_matches_reference(monkeypatch):
+    """MultiviewFilter.forward host logic vs the reference's (src/multiview_filter.py:99-173; fixture
+    multiview_filter.npz): masks after dilation + strict in-bound test, filtered disparities / poses, pose-change
+    priorities, scene bound, the two `< 100 points` early-outs and the warm-up gate.  The two native calls (iproj,
+    depth_filter; parity-tested on the GPU in test_track_gpu.py) are stood in by the oracle on both sides, so this pins
+    the device-resident masked-reduction formulation against the reference's host-side boolean indexing."""
+    import go_slam_amd.multiview_filter as MV
+    from oracle import droid_oracle as DO
+    gen = _gen()
+    gold = np.load(os.path.join(HERE, "golden", "multiview_filter.npz"))
+    monkeypatch.setattr(MV, "droid_backends", types.SimpleNamespace(iproj=DO.iproj, depth_filter=DO.depth_filter))
+    res = gen.run_filter_cases(MV.MultiviewFilter)
+    assert set(res) == {c[0] for c in gen.MVF_CASES}
+    for name, r in res.items():
+        assert np.array_equal(r["mask_filtered"].numpy(), gold[f"{name}_mask_filtered"]), name
+        assert np.array_equal(r["filtered_id"].numpy(), gold[f"{name}_filtered_id"]), name
+        assert np.array_equal(r["disps_filtered"].numpy(), gold[f"{name}_disps_filtered"]), name
+        assert np.array_equal(r["poses_filtered"].numpy(), gold[f"{name}_poses_filtered"]), name
+        assert np.allclose(r["bound"].numpy(), gold[f"{name}_bound"], rtol=0, atol=1e-6), name
+        assert np.allclose(r["update_priority"].numpy(), gold[f"{name}_update_priority"], rtol=1e-6, atol=1e-6), name
+    assert int(gold["few_filtered_id"][0]) == -1 and int(gold["k3_filtered_id"][0]) == 12
+
+
+def test_masked_bound_equals_compaction():
+    from go_slam_amd.multiview_filter import in_bound, masked_bound
+    g = torch.Generator().manual_seed(3)
+    pts = torch.randn(5, 7, 9, 3, generator=g)
+    m = torch.rand(5, 7, 9, generator=g) > 0.6
+    sel = pts[m]
+    want = torch.stack([sel.min(0).values, sel.max(0).values], -1)
+    assert torch.equal(masked_bound(pts, m), want)
+    grown = masked_bound(pts, m, enlarge_scale=1.5)
+    assert torch.allclose(grown[:, 1] - grown[:, 0], 1.5 * (want[:, 1] - want[:, 0]))
+    inside = in_bound(pts, want)
+    assert inside.shape == m.shape and not bool(inside[m].all())       # extremal points sit ON the box: strict test
+    assert int(inside[m].sum()) >= int(m.sum()) - 6

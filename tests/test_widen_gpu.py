@@ -1,0 +1,110 @@
+"""GPU: the callers either side of the hot path (SURVEY 8 f) running on the HIP kernels end to end --
+MotionFilter.track -> DepthVideo.append -> Frontend (edge proposals, update operator, dense BA, keyframe removal)
+-> Backend.dense_ba (alt-corr global BA) -> MultiviewFilter (iproj + depth_filter hand-off to the mapper)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(__file__)
+
+
+def _cfg(enable_loop=False):
+    return {"verbose": False, "mode": "rgbd", "cam": {"H_out": 128, "W_out": 128}, "tracking": {
+        "buffer": 32, "warmup": 8, "upsample": True, "beta": 0.75,
+        "frontend": {"max_factors": 75, "nms": 1, "keyframe_thresh": 0.05, "window": 10, "thresh": 1e4, "radius": 2,
+                     "enable_loop": enable_loop},
+        "backend": {"thresh": 1e4, "radius": 1, "nms": 2, "loop_window": 8, "loop_thresh": 1e4, "loop_radius": 1,
+                    "loop_nms": 2},
+        "multiview_filter": {"thresh": 0.2, "visible_num": 2, "kernel_size": 3, "bound_enlarge_scale": 1.1}}}
+
+
+def _scene_frame(t, g):
+    """a slowly translating textured plane at depth ~2 m (image [1,3,128,128] in [0,1], depth [128,128])"""
+    v, u = torch.meshgrid(torch.arange(128.0), torch.arange(128.0), indexing="ij")
+    tex = 0.5 + 0.25 * torch.sin((u + 3.0 * t) * 0.31) * torch.cos(v * 0.23) + 0.2 * torch.sin((u + 3.0 * t + v) * 0.11)
+    img = torch.stack([tex, tex.roll(5, 1), tex.roll(9, 0)])[None].clamp(0, 1)
+    depth = 2.0 + 0.3 * torch.sin(u * 0.05) + 0.01 * torch.rand(128, 128, generator=g)
+    return img.contiguous(), depth
+
+
+def test_tracker_callers_end_to_end(built_lib):
+    from go_slam_amd.backend import Backend
+    from go_slam_amd.depth_video import DepthVideo
+    from go_slam_amd.droid_net import DroidNet
+    from go_slam_amd.frontend import Frontend
+    from go_slam_amd.motion_filter import MotionFilter
+    dev = "cuda:0"
+    torch.manual_seed(11)
+    cfg, args = _cfg(), types.SimpleNamespace(device=dev)
+    net = DroidNet().to(dev).eval()
+    with torch.no_grad():                                  # random-init heads: keep the flow updates small
+        net.update.delta[2].weight.mul_(0.05)
+        net.update.delta[2].bias.zero_()
+    video = DepthVideo.from_config(cfg, args)
+    assert (video.ht, video.wd) == (16, 16)
+    mf = MotionFilter(net, video, thresh=0.0, device=dev)  # every frame with any predicted motion is a keyframe
+    fe = Frontend(net, video, args, cfg)
+    intr = torch.tensor([120.0, 120.0, 64.0, 64.0])
+    g = torch.Generator().manual_seed(5)
+    n_frames = 13
+    for t in range(n_frames):
+        img, depth = _scene_frame(t, g)
+        mf.track(float(t), img, depth, intr, gt_pose=torch.eye(4))
+        fe()
+    assert fe.is_initialized and fe.count >= 1
+    n = video.counter
+    assert 8 <= n <= n_frames and fe.t1 == n
+    assert torch.allclose(video.intrinsics[0].cpu(), intr / 8.0)
+    assert float(video.disps_sens[:n].min()) > 0               # sensor depth reached the prior
+    assert bool(torch.isfinite(video.poses[:n + 1]).all()) and bool(torch.isfinite(video.disps[:n + 1]).all())
+    assert fe.graph.ii.numel() > 0 and fe.graph.ii_inac.numel() > 0     # warm-up edges were retired to inactive
+    E = fe.graph.ii.numel()
+    assert fe.graph.net.shape[1] == E and fe.graph.target.shape[1] == E and fe.graph.corr.corr_pyramid[0].shape[0] == E
+    assert bool(video.dirty[:n].any())
+    assert float(video.disps_up[:n].abs().sum()) > 0           # convex upsampling ran
+    # global BA over everything (alt-corr graph)
+    be = Backend(net, video, args, cfg)
+    p0 = video.poses[:n].clone()
+    n_kf, n_edges = be.dense_ba(0, n, steps=2)
+    assert n_kf == n and n_edges >= 2 * (n - 1)
+    assert bool(torch.isfinite(video.poses[:n]).all()) and bool(torch.isfinite(video.disps[:n]).all())
+    assert torch.equal(video.poses[0], p0[0])                  # the first pose is the gauge
+    assert bool(video.dirty[:n].all())
+    # loop-closure BA seeded with the frontend's graph
+    lk, le = be.loop_ba(0, n, steps=2, local_graph=fe.graph)
+    assert lk == min(n, 8) and bool(torch.isfinite(video.poses[:n]).all())
+
+
+def test_multiview_filter_on_device_matches_golden(built_lib):
+    """the device-resident MultiviewFilter (HIP iproj + depth_filter, masked reductions in HBM) reproduces what the
+    reference's host-side formulation produced on the same video (fixture multiview_filter.npz)."""
+    import importlib.util
+    import go_slam_amd.multiview_filter as MV
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(HERE, "golden", "gen_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gold = np.load(os.path.join(HERE, "golden", "multiview_filter.npz"))
+    dev = "cuda:0"
+    for name, kernel, cur_t in gen.MVF_CASES:
+        video = gen.make_filter_video(cur_t)
+        for k, v in list(vars(video).items()):
+            if torch.is_tensor(v):
+                setattr(video, k, v.to(dev))
+        cfg = {"tracking": {"warmup": 8, "multiview_filter": {
+            "thresh": 0.2 if name != "few" else 1e-5, "visible_num": 2 if name != "few" else 6,
+            "kernel_size": kernel, "bound_enlarge_scale": 1.1}}}
+        slam = types.SimpleNamespace(net=None, video=video, verbose=False, mode="rgbd")
+        MV.MultiviewFilter(cfg, types.SimpleNamespace(device=dev), slam)()
+        assert int(video.filtered_id) == int(gold[f"{name}_filtered_id"][0]), name
+        if name == "few":
+            continue
+        mask = video.mask_filtered.cpu().numpy()
+        assert int((mask != gold[f"{name}_mask_filtered"]).sum()) <= 4, name     # fp-borderline pixels only
+        assert np.allclose(video.bound.cpu().numpy(), gold[f"{name}_bound"], atol=2e-3), name
+        assert np.array_equal(video.disps_filtered.cpu().numpy(), gold[f"{name}_disps_filtered"]), name
+        assert np.allclose(video.update_priority.cpu().numpy(), gold[f"{name}_update_priority"], atol=1e-5), name
