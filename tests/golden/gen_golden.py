@@ -26,6 +26,7 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
   * modules/extractor.py BasicEncoder (fnet / cnet) + DroidNet checkpoint keys   -> encoders.npz
   * motion_filter.py     MotionFilter.track keyframe decisions + appended items  -> motion_filter.npz
   * multiview_filter.py  MultiviewFilter.forward host logic (masks, bound, priority) -> multiview_filter.npz
+  * trajectory_filler.py PoseTrajectoryFiller: bracketing, interpolation, parked items, edges -> trajectory_filler.npz
   * InstantNeuS.py       normalisation, masking, sdf gradient by autograd.grad, get_alpha,
                          compositing, compute_sdf_error                       -> neus_forward.npz
 The stand-ins themselves (tcnn / lietorch / CUDA kernels) stay "parity unpinned" (DESIGN.md 4).
@@ -745,6 +746,81 @@ def gen_multiview_filter():
     save("multiview_filter.npz", **arrays)
 
 
+FILLER_KF_TIMES = (0.0, 2.0, 5.0, 6.0, 9.0)
+
+
+def run_filler(filler_cls, net, graph_attr_module, n_frames=19):
+    """Runs a PoseTrajectoryFiller class over n_frames frames (one full batch of 16 + a remainder; timestamps before,
+    between and after the keyframes) with a recording graph in place of FactorGraph.  Returns (poses [n,7], record)."""
+    g = torch.Generator().manual_seed(193)
+    rec = {"set": [], "factors": [], "updates": [], "counter": []}
+
+    class Video:
+        def __init__(self):
+            K = len(FILLER_KF_TIMES)
+            self.counter = types.SimpleNamespace(value=K)
+            self.timestamp = torch.zeros(40)
+            self.timestamp[:K] = torch.tensor(FILLER_KF_TIMES)
+            self.poses = torch.zeros(40, 7)
+            self.poses[:, 6] = 1.0
+            xi = 0.3 * torch.randn(K, 6, generator=g)
+            self.poses[:K] = lietorch_shim.SE3.exp(xi).data
+
+        def __setitem__(self, index, item):
+            rec["set"].append((index.start, index.stop, [None if x is None else digest(x) for x in item]))
+            rec["counter"].append(self.counter.value)
+            self.poses[index] = item[2]
+
+    class Graph:
+        def __init__(self, video, update_op, **kw):
+            self.video = video
+
+        def add_factors(self, ii, jj, remove=False):
+            rec["factors"].append((ii.tolist(), jj.tolist()))
+
+        def update(self, t0=None, t1=None, iters=2, use_inactive=False, EPS=1e-7, motion_only=False):
+            rec["updates"].append((t0, t1, bool(motion_only), bool(use_inactive)))
+            self.video.poses[t0:t1, :3] += 0.01            # stands in for the motion-only BA
+
+    graph_attr_module.FactorGraph = Graph
+    video = Video()
+    filler = filler_cls(types.SimpleNamespace(cnet=net.cnet, fnet=net.fnet, update=None), video, device="cpu")
+
+    def stream():
+        for k in range(n_frames):
+            t = -0.5 + 0.55 * k
+            depth = torch.rand(64, 96, generator=g) + 1.0
+            yield t, torch.rand(1, 3, 64, 96, generator=g), depth, torch.tensor([50.0, 52.0, 48.0, 32.0]), None
+    out = filler(stream())
+    assert video.counter.value == len(FILLER_KF_TIMES)
+    return out.data, rec
+
+
+def gen_filler():
+    """The reference's PoseTrajectoryFiller (src/trajectory_filler.py:8-112) on CPU: keyframe bracketing,
+    constant-velocity SE3 interpolation (through the lietorch stand-in), what is parked in the video, the edges and
+    the motion-only update calls.  `.cuda()` is made a no-op for the run (the reference hard-codes it)."""
+    dn = droid_modules()
+    tf = importlib.import_module("refsrc.trajectory_filler")
+    net = dn.DroidNet().eval()
+    net.load_state_dict(named_weights(net.state_dict(), seed=173))
+    keep = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        poses, rec = run_filler(tf.PoseTrajectoryFiller, net, tf)
+    finally:
+        torch.Tensor.cuda = keep
+    arrays = {"poses": poses, "factors": np.array(repr(rec["factors"])), "updates": np.array(repr(rec["updates"])),
+              "counter": np.array(rec["counter"]), "n_set": np.array(len(rec["set"]))}
+    for k, (a, b, items) in enumerate(rec["set"]):
+        arrays[f"set{k}_range"] = np.array([a, b])
+        arrays[f"set{k}_none"] = np.array([x is None for x in items])
+        for j, x in enumerate(items):
+            if x is not None:
+                arrays[f"set{k}_{j}"] = x
+    save("trajectory_filler.npz", **arrays)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate the fixtures"
     install_stubs()
@@ -757,6 +833,7 @@ if __name__ == "__main__":
         gen_encoder()
         gen_motion_filter()
         gen_multiview_filter()
+        gen_filler()
         gen_corr()
         gen_proj()
         gen_render()

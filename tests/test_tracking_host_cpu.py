@@ -122,6 +122,15 @@ def test_depth_video_item_setter_and_normalize():
     v.normalize()
     assert torch.allclose(v.disps[:2], before / s) and torch.allclose(v.disps[:2].mean(), torch.tensor(1.0))
     assert torch.allclose(v.poses[0, :3], torch.tensor([1.0, 2.0, 3.0]) * s) and bool(v.dirty[:2].all())
+    # slice write as PoseTrajectoryFiller does (src/trajectory_filler.py:64): the counter is NOT moved by it
+    v.counter = 2
+    tt = torch.tensor([7.0, 8.0])
+    Gs = ident.repeat(2, 1)
+    Gs[:, 0] = torch.tensor([0.5, 0.6])
+    v[2:4] = (tt, torch.stack([img, img]), Gs, 1, torch.stack([depth, depth]), intr.repeat(2, 1) / 8.0,
+              torch.stack([fmap, fmap]))
+    assert v.counter == 2 and torch.equal(v.timestamp[2:4], tt) and torch.equal(v.poses[2:4], Gs)
+    assert torch.equal(v.disps[2], want) and torch.equal(v.fmaps[3], fmap.half())
     lean = DepthVideo(4, 6, buffer=4, device="cpu")                   # hot-path-only mirror: no full-res buffers
     lean.append(0.0, img, ident, 1.0, depth, intr, fmap[:1], net_, inp_, None)
     assert lean.counter == 1 and not hasattr(lean, "images")
@@ -166,3 +175,25 @@ def test_masked_bound_equals_compaction():
     inside = in_bound(pts, want)
     assert inside.shape == m.shape and not bool(inside[m].all())       # extremal points sit ON the box: strict test
     assert int(inside[m].sum()) >= int(m.sum()) - 6
+
+
+def test_trajectory_filler_matches_reference(net):
+    """PoseTrajectoryFiller vs the reference's (src/trajectory_filler.py:29-112; fixture trajectory_filler.npz):
+    keyframe bracketing incl. the `-1` bracket of a frame earlier than the first keyframe, constant-velocity SE3
+    interpolation, the items parked behind the keyframes (timestamps, left image, poses, unit disparity, depth,
+    intrinsics / 8, features), the two edge sets per batch, six motion-only updates over [N, N + M), batches of 16."""
+    import go_slam_amd.trajectory_filler as TF
+    gen = _gen()
+    gold = np.load(os.path.join(HERE, "golden", "trajectory_filler.npz"))
+    with torch.no_grad():
+        poses, rec = gen.run_filler(TF.PoseTrajectoryFiller, net, TF)
+    assert np.allclose(poses.numpy(), gold["poses"], atol=1e-5)
+    assert repr(rec["factors"]) == str(gold["factors"])
+    assert repr(rec["updates"]) == str(gold["updates"])
+    assert rec["counter"] == list(gold["counter"]) and len(rec["set"]) == int(gold["n_set"])
+    for k, (a, b, items) in enumerate(rec["set"]):
+        assert [a, b] == list(gold[f"set{k}_range"])
+        assert [x is None for x in items] == list(gold[f"set{k}_none"])
+        for j, x in enumerate(items):
+            if x is not None:
+                assert np.allclose(x.numpy(), gold[f"set{k}_{j}"], rtol=1e-4, atol=1e-4), (k, j)
