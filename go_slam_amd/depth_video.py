@@ -111,6 +111,22 @@ class DepthVideo:
     def append(self, *item):
         self[self._count()] = item
 
+    def get_bound(self):
+        return self.bound[0]
+
+    def get_mapping_item(self, index, device="cuda:0", decay=0.1):
+        """(image [H,W,3], depth [H,W], c2w [4,4], gt_c2w [4,4], mask [H,W]) of a filtered keyframe for the mapper
+        (src/depth_video.py:153-177); each hand-out decays the keyframe's update priority."""
+        from .lietorch_shim import SE3
+        image = self.images[index].permute(1, 2, 0).contiguous().to(device)
+        mask = self.mask_filtered[index].clone().to(device)
+        depth = 1.0 / (self.disps_filtered[index].to(device) + 1e-7)
+        w2c = SE3(self.poses_filtered[index].clone()).to(device)
+        c2w = (SE3(self.pose_compensate[0].clone()).to(device) * w2c.inv()).matrix()      # origin alignment
+        gt_c2w = self.poses_gt[index].clone().to(device)
+        self.update_priority[index] *= decay
+        return image, depth, c2w, gt_c2w, mask
+
     def normalize(self):
         """unit mean disparity over the keyframes so far; translations scale with it (src/depth_video.py:198-205)"""
         n = self._count()

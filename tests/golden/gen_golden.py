@@ -27,6 +27,7 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
   * motion_filter.py     MotionFilter.track keyframe decisions + appended items  -> motion_filter.npz
   * multiview_filter.py  MultiviewFilter.forward host logic (masks, bound, priority) -> multiview_filter.npz
   * trajectory_filler.py PoseTrajectoryFiller: bracketing, interpolation, parked items, edges -> trajectory_filler.npz
+  * mapping.py + depth_video.get_mapping_item  Mapper keyframe schedule and ray batches -> mapper.npz
   * InstantNeuS.py       normalisation, masking, sdf gradient by autograd.grad, get_alpha,
                          compositing, compute_sdf_error                       -> neus_forward.npz
 The stand-ins themselves (tcnn / lietorch / CUDA kernels) stay "parity unpinned" (DESIGN.md 4).
@@ -62,7 +63,10 @@ def install_stubs():
             importlib.import_module("colorama")
         except ImportError:
             col = types.ModuleType("colorama")
-            col.Fore = col.Style = types.SimpleNamespace(CYAN="", RESET_ALL="")
+            class _Blank:
+                def __getattr__(self, name):
+                    return ""
+            col.Fore = col.Style = _Blank()
             sys.modules["colorama"] = col
     sys.modules["droid_backends"] = db
     # --- lietorch
@@ -821,6 +825,101 @@ def gen_filler():
     save("trajectory_filler.npz", **arrays)
 
 
+def mapper_cfg():
+    return {"mode": "rgbd", "cam": {"H_out": 32, "W_out": 48}, "tracking": {"buffer": 40},
+            "mapping": {"device": "cpu", "iters": 2, "decay": 0.5, "w_color_loss": 2.0, "w_sdf_loss": 2.0,
+                        "w_eikonal_loss": 0.1, "uncertainty_weight_loss": True, "BA": False, "BA_cam_lr": 1e-3,
+                        "pixels": 960, "mapping_window_size": 16, "net_lr": 1e-3, "grid_lr": 1e-2}}
+
+
+def fill_mapping_video(video, n=30, seed=197):
+    """synthetic filtered keyframes in a DepthVideo (the reference's or ours: same buffer names)"""
+    g = torch.Generator().manual_seed(seed)
+    H, W = 32, 48
+    video.images[:n] = torch.rand(n, 3, H, W, generator=g)
+    video.disps_filtered[:n] = 0.2 + torch.rand(n, H, W, generator=g)
+    video.mask_filtered[:n] = (torch.rand(n, H, W, generator=g) > 0.3).float()
+    video.mask_filtered[3] = 0.0                                            # a keyframe with no valid pixel
+    video.mask_filtered[3, :2, :30] = 1.0                                   # ... except 60: fewer than 2 x n_rays
+    video.poses_filtered[:n] = lietorch_shim.SE3.exp(0.2 * torch.randn(n, 6, generator=g)).data
+    video.poses_gt[:n] = torch.eye(4) + 0.01 * torch.randn(n, 4, 4, generator=g)
+    video.pose_compensate[0] = lietorch_shim.SE3.exp(0.1 * torch.randn(1, 6, generator=g)).data[0]
+    video.update_priority[:n] = torch.rand(n, generator=g)
+    video.timestamp[:n] = torch.arange(n).float()
+    video.bound[0] = torch.tensor([[-3.0, 3.0], [-2.0, 2.5], [-1.0, 4.0]])
+
+
+def run_mapper(mapper_cls, video, schedule=((1, False), (5, False), (5, False), (14, False), (30, False), (30, True))):
+    """Drives a Mapper class through `schedule` = (filtered_id, the_end) calls with optimize_map replaced by a
+    recorder; NumPy and torch RNGs are re-seeded before every call so both implementations draw the same pixels."""
+    rec = []
+
+    class Net:
+        def __init__(self):
+            self.realtime_bound = torch.zeros(3, 2)
+            self.p = torch.nn.Parameter(torch.zeros(3))
+
+        def get_training_parameters(self, ignore_keys=()):
+            return [self.p]
+
+        def get_volume_parameters(self):
+            return []
+
+        def update_bound(self, b):
+            self.realtime_bound[:] = b
+            rec.append(("bound", digest(b)))
+
+        def to(self, device):
+            return self
+    import tempfile
+    slam = types.SimpleNamespace(verbose=False, bound=torch.zeros(3, 2), video=video, mapping_net=Net(), renderer=None,
+                                 reload_map=torch.zeros(1).int(), output=tempfile.mkdtemp(), H=32, W=48, fx=40.0,
+                                 fy=41.0, cx=24.0, cy=16.0)
+    mapper = mapper_cls(mapper_cfg(), types.SimpleNamespace(device="cpu"), slam)
+
+    def optimize_map(rays_o, rays_d, rays_color, rays_depth, optimizer, num_joint_iters):
+        rec.append(("opt", num_joint_iters, tuple(rays_o.shape), digest(rays_o), digest(rays_d), digest(rays_color),
+                    digest(rays_depth)))
+    mapper.optimize_map = optimize_map
+    for k, (fid, the_end) in enumerate(schedule):
+        video.filtered_id[0] = fid
+        np.random.seed(1000 + k)
+        torch.manual_seed(2000 + k)
+        mapper(the_end=the_end)
+        rec.append(("state", mapper.last_visit, bool(mapper.init), int(slam.reload_map), digest(video.update_priority)))
+    return rec, mapper
+
+
+def flatten_mapper_record(rec):
+    """record -> (structure string, list of digests)"""
+    struct, nums = [], []
+    for r in rec:
+        struct.append(tuple(x for x in r if not torch.is_tensor(x)))
+        nums += [x for x in r if torch.is_tensor(x)]
+    return repr(struct), nums
+
+
+def gen_mapper():
+    """The reference's Mapper.__call__ (src/mapping.py:151-302) on the reference's OWN DepthVideo (CPU): keyframe
+    schedule (new / recent / priority / random), priority decay, bound hand-over and every ray batch it assembles."""
+    sys.modules["refsrc.geom"].projective_ops = importlib.import_module("refsrc.geom.projective_ops")
+    droid_modules()
+    dv = importlib.import_module("refsrc.depth_video")
+    mp = importlib.import_module("refsrc.mapping")
+    torch.autograd.set_detect_anomaly(False)                                # mapping.py switches it on at import
+    video = dv.DepthVideo(mapper_cfg(), types.SimpleNamespace(device="cpu"))
+    fill_mapping_video(video)
+    item = video.get_mapping_item(7, "cpu", decay=1.0)
+    rec, mapper = run_mapper(mp.Mapper, video)
+    struct, nums = flatten_mapper_record(rec)
+    arrays = {"struct": np.array(struct), "n": np.array(len(nums))}
+    for k, x in enumerate(nums):
+        arrays[f"d{k}"] = x
+    for k, x in enumerate(item):
+        arrays[f"item7_{k}"] = x
+    save("mapper.npz", **arrays)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate the fixtures"
     install_stubs()
@@ -834,6 +933,7 @@ if __name__ == "__main__":
         gen_motion_filter()
         gen_multiview_filter()
         gen_filler()
+        gen_mapper()
         gen_corr()
         gen_proj()
         gen_render()

@@ -197,3 +197,31 @@ def test_trajectory_filler_matches_reference(net):
         for j, x in enumerate(items):
             if x is not None:
                 assert np.allclose(x.numpy(), gold[f"set{k}_{j}"], rtol=1e-4, atol=1e-4), (k, j)
+
+
+def test_mapper_schedule_and_ray_batches_match_reference():
+    """Mapper.__call__ + DepthVideo.get_mapping_item vs the reference's Mapper running on the reference's own
+    DepthVideo (src/mapping.py:151-302, src/depth_video.py:153-177; fixture mapper.npz): which keyframes are visited
+    (new, two most recent, 10 highest priority, stratified-random old ones), the 10x first-call factor and the
+    `the_end` factor, priority decay per hand-out (duplicates decay twice), the bound hand-over, and every ray batch
+    (origins, directions, colours, depths) under the same seeds."""
+    from go_slam_amd.neus.mapping import Mapper
+    gen = _gen()
+    gold = np.load(os.path.join(HERE, "golden", "mapper.npz"))
+    video = DepthVideo.from_config(gen.mapper_cfg(), types.SimpleNamespace(device="cpu"))
+    gen.fill_mapping_video(video)
+    item = video.get_mapping_item(7, "cpu", decay=1.0)
+    for k, x in enumerate(item):
+        assert np.allclose(x.numpy(), gold[f"item7_{k}"], rtol=1e-5, atol=1e-6), k
+    rec, mapper = gen.run_mapper(Mapper, video)
+    struct, nums = gen.flatten_mapper_record(rec)
+    assert struct == str(gold["struct"])
+    assert len(nums) == int(gold["n"])
+    for k, x in enumerate(nums):
+        assert np.allclose(x.numpy(), gold[f"d{k}"], rtol=1e-5, atol=1e-5), k
+    with pytest.raises(NotImplementedError):
+        cfg = gen.mapper_cfg()
+        cfg["mapping"]["BA"] = True
+        Mapper(cfg, types.SimpleNamespace(device="cpu"), types.SimpleNamespace(
+            bound=None, video=video, mapping_net=mapper.mapping_net, renderer=None, reload_map=torch.zeros(1).int(),
+            H=32, W=48, fx=1, fy=1, cx=1, cy=1))
