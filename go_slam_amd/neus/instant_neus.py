@@ -54,6 +54,44 @@ class SDFNetwork(nn.Module):
         return {"network": list(self.sdf_layer.parameters()) + [self.encoding._B],
                 "volume": list(self.encoding.encoding.parameters())}
 
+    # ---- forward-only point queries (meshing / colouring; src/InstantNeuS.py:121-159).  Training goes through the
+    # fused ray pipeline (_NeusRenderFn), never through these.
+    @torch.no_grad()
+    def _query(self, pts, bound, want_gradient):
+        pts = pts.reshape(-1, 3).float()
+        if bound is not None:
+            b = bound.to(pts.device).float()
+            span = b[:, 1] - b[:, 0]
+            p = (pts - b[:, 0]) / span * 2.0 - 1.0
+            inside = ((p >= -1.0) & (p <= 1.0)).float()
+            p = p.clamp(min=-1.0, max=1.0)
+        else:
+            p, span, inside = pts, None, None
+        W, bias = self.sdf_layer.weight.detach().float(), self.sdf_layer.bias.detach().float()
+        if want_gradient:
+            enc, dydx = self.encoding.encoding((p + 1) / 2, return_dy_dx=True)
+        else:
+            enc, dydx = self.encoding.encoding((p + 1) / 2), None
+        out = torch.addmm(bias, torch.cat([p, enc.float()], dim=-1), W.t())
+        grad = None
+        if want_gradient:
+            # d sdf / d pts: Linear row 0 through cat([x, enc]); the encoding's input gradient is dy_dx contracted
+            # with the fp16-cast upstream gradient (tcnn), the view transform (x+1)/2 and the normalisation
+            g_enc = W[0, 3:].to(torch.float16).float()
+            grad = W[0, :3][None] + torch.einsum("ncd,c->nd", dydx, g_enc) / 2
+            if span is not None:
+                grad = grad * inside * 2.0 / span
+        return out[:, :1], out[:, 1:], grad
+
+    def forward(self, pts, bound=None):
+        sdf, feat, _ = self._query(pts, bound, False)
+        return sdf, feat
+
+    def sdf(self, pts, bound=None, require_feature=False, require_gradient=False):
+        sdf, feat, grad = self._query(pts, bound, require_gradient)
+        out = (sdf,) + ((feat,) if require_feature else ()) + ((grad,) if require_gradient else ())
+        return out if len(out) > 1 else sdf
+
 
 class ColorNetwork(nn.Module):
     """src/InstantNeuS.py:162-205."""
@@ -64,6 +102,14 @@ class ColorNetwork(nn.Module):
         self.network = TcnnNetwork(33 + 3 + d_feat, 3, dict(otype="FullyFusedMLP", activation="ReLU",
                                                            output_activation="none", n_neurons=d_hidden,
                                                            n_hidden_layers=n_layers))
+
+
+    @torch.no_grad()
+    def forward(self, view_pts, view_dirs, sdf, normals, feature_vectors):
+        """forward-only colour query (src/InstantNeuS.py:195-205); view_dirs and sdf are unused, as there."""
+        emb = torch.sin(view_pts.float() @ self._B.detach().to(view_pts.device))
+        x = self.network(torch.cat([emb, normals.float(), feature_vectors.float()], dim=1))
+        return torch.sigmoid(x.float())
 
 
 class SingleVarianceNetwork(nn.Module):
@@ -111,6 +157,46 @@ class InstantNeuS(nn.Module):
     def update_bound(self, bound):
         self.realtime_bound[:] = bound.float().to(self.realtime_bound.device)
         self._host_bounds = None
+
+    @staticmethod
+    def in_bound(pts, bound):
+        """strictly inside the box (src/InstantNeuS.py:259-274)"""
+        b = bound.to(pts.device)
+        return ((pts > b[:, 0]) & (pts < b[:, 1])).all(dim=-1)
+
+    @torch.no_grad()
+    def extract_fields(self, bound_min, bound_max, resolution, chunk=1 << 21):
+        """-sdf on a resolution^3 lattice over [bound_min, bound_max] as a float32 NumPy array, -100 outside the
+        realtime bound (src/InstantNeuS.py:422-455; the marching-cubes input).  The reference walks 64^3 blocks with
+        a boolean gather, a scatter and a `.cpu()` each (512 round trips at 512^3); here the lattice is evaluated in
+        flat chunks by the fused encode kernel with the out-of-bound value applied by a select, and the volume
+        crosses PCIe once."""
+        dev = self.bound.device
+        lin = [torch.linspace(float(bound_min[k]), float(bound_max[k]), resolution, device=dev) for k in range(3)]
+        bound = torch.stack([bound_min.to(dev).float(), bound_max.to(dev).float()], dim=1)
+        rt = self.realtime_bound
+        u = torch.empty(resolution ** 3, dtype=torch.float32, device=dev)
+        r2 = resolution * resolution
+        for start in range(0, resolution ** 3, chunk):
+            idx = torch.arange(start, min(start + chunk, resolution ** 3), device=dev)
+            pts = torch.stack([lin[0][idx // r2], lin[1][(idx // resolution) % resolution], lin[2][idx % resolution]],
+                              dim=1)
+            sdf = self.sdf_network.sdf(pts, bound=bound)
+            u[start:start + idx.numel()] = torch.where(self.in_bound(pts, rt), -sdf[:, 0],
+                                                       torch.full_like(sdf[:, 0], -100.0))
+        return u.view(resolution, resolution, resolution).cpu().numpy()
+
+    @torch.no_grad()
+    def extract_color(self, bound, vertices):
+        """uint8 vertex colours (src/InstantNeuS.py:402-420)"""
+        import numpy as np
+        pts_all = torch.as_tensor(vertices).float().to(bound.device)
+        rgbs = []
+        for pts in torch.split(pts_all, 64 * 64 * 64, dim=0):
+            sdf, feat, grad = self.sdf_network.sdf(pts, bound=bound, require_feature=True, require_gradient=True)
+            rgbs.append(self.color_network(pts, None, sdf, grad, feat))
+        rgb = torch.cat(rgbs, dim=0).cpu().numpy()
+        return (np.clip(rgb, 0, 1) * 255).astype(np.uint8)
 
     def _bounds_host(self):
         """(bound, realtime_bound) as two 6-float host arrays; cached so the hot path has no D2H."""

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from .distributed import mapping_loss_sharded
+from .mapper import make_optimizer
 from .rays import build_rays
 
 
@@ -47,10 +48,7 @@ class Mapper:
         net_param = self.mapping_net.get_training_parameters(ignore_keys=())
         grid_param = self.mapping_net.get_volume_parameters()
         self.train_params = list(net_param) + list(grid_param)
-        fused = {"fused": True} if self.train_params and self.train_params[0].is_cuda else {}
-        self.optimizer = torch.optim.AdamW([{"params": net_param, "lr": m["net_lr"]},
-                                            {"params": grid_param, "lr": m["grid_lr"]}],
-                                           betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, **fused)
+        self.optimizer = make_optimizer(self.mapping_net, m["net_lr"], m["grid_lr"])   # AdamW, fused on the GPU
 
     def optimize_map(self, rays_o, rays_d, rays_color, rays_depth, optimizer, num_joint_iters):
         """mapping iterations on one ray batch (src/mapping.py:59-148)"""

@@ -171,3 +171,51 @@ def test_mapper_runs_joint_iterations_on_device(built_lib):
     step = mapper.global_step
     mapper()
     assert mapper.global_step == step
+
+
+def test_point_queries_and_extract_fields_match_oracle(built_lib):
+    """SDFNetwork.sdf / ColorNetwork.forward / InstantNeuS.extract_fields (forward-only queries used for meshing,
+    src/InstantNeuS.py:121-159, 195-205, 422-455) vs the oracle's restatement: sdf rtol 1e-4, features fp16-level,
+    analytic gradient rtol 1e-3, the lattice -sdf volume incl. the -100 fill outside the realtime bound."""
+    import go_slam_amd.neus as N
+    from oracle import neus_oracle as O
+    dev = "cuda:0"
+    P = O.make_params(83, grid_init=0.2, bound=((-2.0, 2.0), (-1.5, 2.5), (-1.0, 3.0)))
+    model = N.InstantNeuS({}, P["bound"].tolist(), device=dev).to(dev)
+    with torch.no_grad():
+        model.sdf_network.encoding.encoding.params.copy_(P["grid"])
+        model.sdf_network.sdf_layer.weight.copy_(P["sdf_w"])
+        model.sdf_network.sdf_layer.bias.copy_(P["sdf_b"])
+        model.color_network._B.copy_(P["color_B"])
+        model.color_network.network.params.copy_(P["mlp"])
+    g = torch.Generator().manual_seed(5)
+    pts = torch.rand(999, 3, generator=g) * torch.tensor([5.0, 5.0, 5.0]) - torch.tensor([2.5, 2.0, 1.5])  # some outside
+    sdf_r, feat_r, grad_r = O.sdf_and_gradient(pts, P["bound"], P["grid"], P["sdf_w"], P["sdf_b"])
+    sdf, feat, grad = model.sdf_network.sdf(pts.to(dev), bound=P["bound"].to(dev), require_feature=True,
+                                            require_gradient=True)
+    torch.testing.assert_close(sdf.cpu(), sdf_r, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(feat.cpu(), feat_r, rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(grad.cpu(), grad_r, rtol=1e-3, atol=1e-4)
+    only = model.sdf_network.sdf(pts.to(dev), bound=P["bound"].to(dev))
+    assert torch.equal(only, sdf)
+    # colour query: sigmoid(MLP(sin(x B) | n | feat)) with the fp16 MLP
+    emb = torch.sin(pts @ P["color_B"])
+    rgb_r = torch.sigmoid(O.mlp_forward(torch.cat([emb, grad_r, feat_r], 1), P["mlp"], 67, 3).float())
+    rgb = model.color_network(pts.to(dev), None, sdf, grad, feat)
+    torch.testing.assert_close(rgb.cpu(), rgb_r, rtol=0, atol=6e-3)
+    # lattice over the static bound with a smaller realtime bound
+    model.update_bound(torch.tensor([[-1.0, 1.5], [-1.0, 2.0], [-0.5, 2.0]]))
+    res = 21
+    u = model.extract_fields(model.bound[:, 0], model.bound[:, 1], res, chunk=4000)
+    assert u.shape == (res, res, res) and u.dtype == np.float32
+    lin = [torch.linspace(float(P["bound"][k, 0]), float(P["bound"][k, 1]), res) for k in range(3)]
+    xx, yy, zz = torch.meshgrid(*lin, indexing="ij")
+    lat = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], 1)
+    inb = O.in_bound(lat, model.realtime_bound.cpu())
+    want = torch.full((res ** 3,), -100.0)
+    want[inb] = -O.sdf_and_gradient(lat[inb], P["bound"], P["grid"], P["sdf_w"], P["sdf_b"])[0][:, 0]
+    assert 0 < int(inb.sum()) < res ** 3
+    torch.testing.assert_close(torch.from_numpy(u).reshape(-1), want, rtol=1e-4, atol=3e-5)
+    cols = model.extract_color(P["bound"].to(dev), pts[:100].numpy())
+    assert cols.shape == (100, 3) and cols.dtype == np.uint8
+    assert int(np.abs(cols.astype(np.int32) - (np.clip(rgb_r[:100].numpy(), 0, 1) * 255).astype(np.int32)).max()) <= 2
