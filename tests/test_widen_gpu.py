@@ -78,6 +78,18 @@ def test_tracker_callers_end_to_end(built_lib):
     # loop-closure BA seeded with the frontend's graph
     lk, le = be.loop_ba(0, n, steps=2, local_graph=fe.graph)
     assert lk == min(n, 8) and bool(torch.isfinite(video.poses[:n]).all())
+    # poses of 5 in-between frames: parked behind the keyframes, refined by motion-only updates, counter restored
+    from go_slam_amd.trajectory_filler import PoseTrajectoryFiller
+    kf_poses = video.poses[:n].clone()
+
+    def stream():
+        for k in range(5):
+            img, depth = _scene_frame(0.5 + 2.0 * k, g)
+            yield 0.5 + 2.0 * k, img, depth, intr, None
+    traj = PoseTrajectoryFiller(net, video, device=dev)(stream())
+    assert tuple(traj.data.shape) == (5, 7) and bool(torch.isfinite(traj.data).all())
+    assert video.counter == n and torch.equal(video.poses[:n], kf_poses)      # keyframes untouched (motion-only)
+    assert torch.allclose(traj.data[:, 3:].norm(dim=-1), torch.ones(5, device=dev), atol=1e-4)
 
 
 def test_multiview_filter_on_device_matches_golden(built_lib):
