@@ -1,0 +1,176 @@
+// 3x3 / pad 1 / stride 1 convolution, NHWC fp16 -> NHWC fp16 (fp32 accumulation), as an implicit GEMM on MFMA:
+// the five large convolutions of the update operator (GRU z|r 320->256 and q 320->128, the merged heads 128->384,
+// corr_encoder[2] 128->128, the hoisted context gates 128->384; reference src/modules/gru.py:10-12,
+// src/droid_net.py:76,83-92,40) -- 1.27 TFLOP of an update's 1.6.
+//
+// Organisation (EXPERIMENTAL in round 1: opt-in through GOSLAM_CONV3X3=hip; MIOpen stays the default until this
+// kernel has been profiled):
+//  * a workgroup (4 waves) owns a 16x16-pixel tile x 128 output channels; K = 9 taps x C runs in chunks of 32
+//    input channels;
+//  * per chunk the 18x18-pixel input patch (20.7 KB) is staged in LDS ONCE and serves all 9 taps -- a generic
+//    implicit GEMM re-gathers it per tap; the tap is just an offset into the patch;
+//  * weights are pre-packed per (128-channel block, chunk, tap) into the exact LDS image (8 KB), double-buffered in
+//    LDS with the next tap's image in flight in registers while the current tap is on the matrix cores;
+//  * weights are the MFMA A operand (rows = output channels), pixels the B operand: a wave's 64-channel x 128-pixel
+//    register tile needs 2 + 4 LDS fragment reads per 8 MFMAs (24 B/clk/wave), and the accumulator layout gives each
+//    lane 4 consecutive channels of one pixel -- packed 8-byte LDS writes in the epilogue;
+//  * patch and weight planes are laid out [8-channel group][pixel | channel][8] so that 32 consecutive lanes read 32
+//    consecutive 16-byte vectors (bank-conflict free);
+//  * the epilogue goes through a wave-private LDS tile so that global stores are 128 B per pixel (8 lanes x 16 B).
+// LDS: 37 KB per workgroup; 2 workgroups per CU at <= 256 VGPRs.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+constexpr int TH = 16, TW = 16;            // output tile (pixels)
+constexpr int PH = TH + 2, PW = TW + 2;    // input patch
+constexpr int NP = PH * PW;                // 324 patch pixels
+constexpr int KC = 32, KG = KC / 8;        // input channels per chunk, 8-channel groups per chunk
+constexpr int BN = 128;                    // output channels per workgroup
+constexpr int WTAP = KG * BN;              // 16-byte vectors of one tap's weight image (512 = 8 KB)
+constexpr int TS = 72;                     // epilogue tile row stride in halves (144 B, staggers the banks)
+
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restrict__ x, int xs, int C,
+                                                         const half8* __restrict__ wpack, _Float16* __restrict__ y,
+                                                         int ys, int H, int W, int tiles_x, int tiles_y) {
+  __shared__ half8 smem[KG * NP + 2 * WTAP];             // patch [KG][NP] | weights [2][KG][BN]
+  half8* patch = smem;
+  half8* wbuf = smem + KG * NP;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv & 1, wn = wv >> 1;                    // pixel half (tile rows 8 wm ..), channel half (64 wn ..)
+  const int r = lane & 31, kgl = lane >> 5;
+  int t = blockIdx.x;
+  const int tx0 = (t % tiles_x) * TW;
+  t /= tiles_x;
+  const int ty0 = (t % tiles_y) * TH;
+  const int img = t / tiles_y;
+  const int nb = blockIdx.y;
+  const int nchunk = C / KC;
+  const _Float16* ximg = x + (size_t)img * H * W * xs;
+  const half8* wsrc = wpack + (size_t)nb * nchunk * 9 * WTAP;
+
+  // patch offsets of this lane's pixel in the 4 pixel fragments (32 pixels = 2 tile rows each)
+  int pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pb[i] = (wm * 8 + 2 * i + (r >> 4)) * PW + (r & 15);
+
+  float16v acc[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.0f;
+
+  const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int ck = 0; ck < nchunk; ++ck) {
+    // ---- stage the input patch of this channel chunk (4 lanes read the 64 contiguous bytes of a pixel)
+    for (int it = tid; it < KG * NP; it += 256) {
+      const int kg = it & (KG - 1), p = it >> 2;
+      const int py = p / PW, px = p - py * PW;
+      const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+      half8 v = zero8;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+        v = *reinterpret_cast<const half8*>(ximg + ((size_t)gy * W + gx) * xs + ck * KC + kg * 8);
+      patch[kg * NP + p] = v;
+    }
+    // ---- and the first tap's weights
+    const half8* wck = wsrc + (size_t)ck * 9 * WTAP;
+    wbuf[tid] = wck[tid];
+    wbuf[tid + 256] = wck[tid + 256];
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      half8 n0 = zero8, n1 = zero8;
+      if (tap < 8) {                                      // next tap's image: global -> registers, in flight
+        n0 = wck[(tap + 1) * WTAP + tid];
+        n1 = wck[(tap + 1) * WTAP + tid + 256];
+      }
+      __builtin_amdgcn_sched_barrier(0);                  // keep the prefetch at the top of the tap (the scheduler
+                                                          // otherwise sinks it to its use and exposes the latency)
+      const half8* wb = wbuf + (tap & 1) * WTAP;
+      const int toff = (tap / 3) * PW + (tap % 3);
+      half8 a[KC / 16][2], b[KC / 16][4];                 // all fragments of the tap first: one LDS latency per 16 MFMAs
+#pragma unroll
+      for (int s = 0; s < KC / 16; ++s) {
+        const int kg = 2 * s + kgl;
+        a[s][0] = wb[kg * BN + wn * 64 + r];
+        a[s][1] = wb[kg * BN + wn * 64 + 32 + r];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[s][i] = patch[kg * NP + pb[i] + toff];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < KC / 16; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][0], b[s][i], acc[0][i], 0, 0, 0);
+          acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][1], b[s][i], acc[1][i], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap < 8) {
+        half8* wnext = wbuf + ((tap + 1) & 1) * WTAP;     // last read during tap - 1: every wave is past that barrier
+        wnext[tid] = n0;
+        wnext[tid + 256] = n1;
+      }
+      __syncthreads();                                    // tap 8: also frees the patch and wbuf[0] for the next chunk
+    }
+  }
+
+  // ---- epilogue: [32 pixels][64 channels] at a time through a wave-private LDS tile (aliases the patch; all waves
+  // are past the last barrier, and a wave only touches its own 4.6 KB)
+  _Float16* tile = reinterpret_cast<_Float16*>(smem) + wv * 32 * TS;
+  _Float16* yimg = y + (size_t)img * H * W * ys + nb * BN + wn * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {                       // C layout: row (channel) = 8 g + 4 (lane >> 5) + e, col = pixel
+        half4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc[j][i][4 * g + e];
+        *reinterpret_cast<half4*>(tile + r * TS + j * 32 + 8 * g + 4 * kgl) = o;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int pxr = it * 8 + (lane >> 3), piece = lane & 7;
+      const int gy = ty0 + wm * 8 + 2 * i + (pxr >> 4), gx = tx0 + (pxr & 15);
+      if (gy < H && gx < W) {
+        const half8 v = *reinterpret_cast<const half8*>(tile + pxr * TS + piece * 8);
+        *reinterpret_cast<half8*>(yimg + ((size_t)gy * W + gx) * ys + piece * 8) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace
+
+extern "C" size_t gs_conv3x3_wpack_elems(int c_in, int n_out) { return (size_t)9 * c_in * n_out; }
+
+extern "C" int gs_conv3x3(const void* x, int x_stride, int c_in, const void* wpack, void* y, int y_stride, int n_out,
+                          int n, int h, int w, gs_stream_t stream) {
+  GS_REQUIRE(x && wpack && y, "conv3x3: null pointer");
+  GS_REQUIRE(c_in > 0 && c_in % KC == 0, "conv3x3: c_in must be a multiple of %d", KC);
+  GS_REQUIRE(n_out > 0 && n_out % BN == 0, "conv3x3: n_out must be a multiple of %d", BN);
+  GS_REQUIRE(x_stride >= c_in && x_stride % 8 == 0, "conv3x3: x_stride must be >= c_in and a multiple of 8");
+  GS_REQUIRE(y_stride >= n_out && y_stride % 8 == 0, "conv3x3: y_stride must be >= n_out and a multiple of 8");
+  GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3: bad shape");
+  if (n == 0) return GS_OK;
+  const int tiles_x = gs_cdiv(w, TW), tiles_y = gs_cdiv(h, TH);
+  const long long blocks = (long long)n * tiles_x * tiles_y;
+  GS_REQUIRE(blocks < (1ll << 31), "conv3x3: too many tiles");
+  conv3x3_kernel<<<dim3((unsigned)blocks, n_out / BN), 256, 0, (hipStream_t)stream>>>(
+      (const _Float16*)x, x_stride, c_in, (const half8*)wpack, (_Float16*)y, y_stride, h, w, tiles_x, tiles_y);
+  GS_CHECK_LAUNCH("conv3x3");
+  return GS_OK;
+}

@@ -7,6 +7,8 @@ convolutions stay ATen/MIOpen; the hand-written HIP kernels are the ops around t
 
 `torch_scatter.scatter_mean` (absent in this image) is replaced by an index_add segment mean.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -169,7 +171,50 @@ def bias_act(y, b, act, out=None, out_channel=0, in_channel=0, channels=None):
     return dst
 
 
+# Implementation of the large 3x3 convolutions on the inference fast path: "miopen" (default) or "hip" = the
+# package's own implicit-GEMM MFMA kernel gs_conv3x3 (csrc/conv3x3.hip) -- experimental in round 1, opt-in through
+# the environment (GOSLAM_CONV3X3=hip) or by assigning this module attribute.
+CONV3X3_IMPL = os.environ.get("GOSLAM_CONV3X3", "miopen")
+_CONV3X3_PACKS = {}
+
+
+def pack_conv3x3_weight(weight):
+    """[O, C, 3, 3] -> gs_conv3x3's fp16 LDS images [O/128][C/32][9][4][128][8] (include/goslam_hip.h):
+    wpack[nb][ck][3 ky + kx][kg][r][e] = W[128 nb + r][32 ck + 8 kg + e][ky][kx]."""
+    O, C, kh, kw = weight.shape
+    assert (kh, kw) == (3, 3) and O % 128 == 0 and C % 32 == 0
+    w = weight.detach().half().reshape(O // 128, 128, C // 32, 4, 8, 3, 3)      # nb r ck kg e ky kx
+    return w.permute(0, 2, 5, 6, 3, 1, 4).contiguous().reshape(-1)             # nb ck ky kx kg r e
+
+
+def conv3x3_hip_supported(x, w):
+    return (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
+            and w.shape[0] % 128 == 0 and w.shape[1] % 32 == 0 and x.shape[1] == w.shape[1]
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def conv3x3_hip(x, w):
+    """bias-free 3x3 / pad 1 convolution of an NHWC fp16 tensor through gs_conv3x3; `w` is the [O,C,3,3] weight
+    (its packed image is cached per weight tensor and version)."""
+    from . import _lib
+    key = (w.data_ptr(), w._version, w.device, tuple(w.shape))
+    hit = _CONV3X3_PACKS.get(id(w))
+    if hit is None or hit[0] != key:
+        hit = (key, pack_conv3x3_weight(w), w)              # keeps `w` alive so that id(w) stays unique
+        _CONV3X3_PACKS[id(w)] = hit
+    n, c, h, wd = x.shape
+    O = w.shape[0]
+    y = torch.empty((n, O, h, wd), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().gs_conv3x3(_lib.ptr(x), c, c, _lib.ptr(hit[1]), _lib.ptr(y), O, O, n, h, wd,
+                                   _lib.stream_ptr(x.device))
+    _lib.check(rc, "conv3x3")
+    return y
+
+
 def conv_nobias(x, w, stride=1, padding=0):
+    if CONV3X3_IMPL == "hip" and stride in (1, (1, 1)) and padding in (1, (1, 1)) and conv3x3_hip_supported(x, w):
+        return conv3x3_hip(x, w)
     with torch.autocast("cuda", enabled=False):
         y = F.conv2d(x, w, None, stride=stride, padding=padding)
     if not y.is_contiguous(memory_format=torch.channels_last):
@@ -276,11 +321,11 @@ class ConvGRU(nn.Module):
             _lib.check(L.gs_gru_glo(_lib.ptr(w_pre), _lib.ptr(bw), _lib.ptr(net), _lib.ptr(gw[0]), _lib.ptr(gw[1]),
                                     _lib.ptr(gw[2]), _lib.ptr(gw[3]), _lib.ptr(gw[4]), _lib.ptr(gw[5]),
                                     _lib.ptr(gzr), _lib.ptr(gq), b, hw, _lib.ptr(ws), ws.numel(), st), "gru_glo")
-            zr_pre = F.conv2d(hx, wzr, None, padding=1)
+            zr_pre = conv_nobias(hx, wzr, padding=1)
             z = torch.empty_like(net)
             _lib.check(L.gs_gru_gate_zr(_lib.ptr(zr_pre), _lib.ptr(bzr), _lib.ptr(gzr), _lib.ptr(inp_pre), _lib.ptr(hx),
                                         _lib.ptr(z), b, hw, hx.shape[1], st), "gru_gate_zr")
-            q_pre = F.conv2d(hx, wq, None, padding=1)
+            q_pre = conv_nobias(hx, wq, padding=1)
             out = torch.empty_like(net)
             _lib.check(L.gs_gru_gate_q(_lib.ptr(q_pre), _lib.ptr(bq), _lib.ptr(gq), _lib.ptr(inp_pre), _lib.ptr(z),
                                        _lib.ptr(net), _lib.ptr(out), b, hw, st), "gru_gate_q")

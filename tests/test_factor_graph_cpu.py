@@ -198,3 +198,24 @@ def test_proximity_proposal_corner_cases():
     es = FactorGraph.propose_proximity_edges(d2, [(3, 1)], 2, 0, 6, 1, 1, 16.0, 100, False)
     assert es[8:10] == [(5, 0), (0, 5)]
     assert all(e != (3, 1) and e != (2, 0) for e in es[8:])         # existing edge and its NMS neighbourhood
+
+
+def test_conv3x3_weight_image_layout():
+    """pack_conv3x3_weight produces the LDS images gs_conv3x3 documents (include/goslam_hip.h): contracting them
+    with the zero-padded input exactly the way the kernel indexes them reproduces F.conv2d."""
+    import torch.nn.functional as F
+    from go_slam_amd.droid_net import pack_conv3x3_weight
+    g = torch.Generator().manual_seed(9)
+    O, C, H, W = 256, 64, 5, 7
+    w = (torch.randn(O, C, 3, 3, generator=g) * 0.1).half()
+    x = torch.randn(1, C, H, W, generator=g).half()
+    wp = pack_conv3x3_weight(w).float().view(O // 128, C // 32, 9, 4, 128, 8)
+    xp = F.pad(x.float(), (1, 1, 1, 1))[0].permute(1, 2, 0)                     # [H+2, W+2, C]
+    out = torch.zeros(O, H, W)
+    for ck in range(C // 32):
+        for tap in range(9):
+            ky, kx = tap // 3, tap % 3
+            win = xp[ky:ky + H, kx:kx + W, 32 * ck:32 * ck + 32].reshape(H, W, 4, 8)        # [.., kg, e]
+            out += torch.einsum("nkre,hwke->nrhw", wp[:, ck, tap], win).reshape(O, H, W)
+    ref = F.conv2d(x.float(), w.float(), padding=1)[0]
+    assert torch.allclose(out, ref, rtol=1e-4, atol=1e-4)

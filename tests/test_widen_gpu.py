@@ -231,3 +231,54 @@ def test_point_queries_and_extract_fields_match_oracle(built_lib):
     cols = model.extract_color(P["bound"].to(dev), pts[:100].numpy())
     assert cols.shape == (100, 3) and cols.dtype == np.uint8
     assert int(np.abs(cols.astype(np.int32) - (np.clip(rgb_r[:100].numpy(), 0, 1) * 255).astype(np.int32)).max()) <= 2
+
+
+@pytest.mark.parametrize("n,h,w,c,xs,o", [(3, 30, 40, 320, 320, 256), (2, 12, 16, 128, 128, 384), (1, 60, 80, 128, 128, 128),
+                                          (2, 17, 23, 64, 96, 128)])
+def test_conv3x3_implicit_gemm_matches_reference(built_lib, n, h, w, c, xs, o):
+    """gs_conv3x3 (own implicit-GEMM MFMA convolution, experimental) vs F.conv2d in fp32 on the same fp16 operands:
+    partial tiles (h, w not multiples of 16), a channel slice of a wider tensor (xs > c), 1-3 output blocks.
+    Tolerance: one fp16 rounding of the output (the products are exact in fp32, the sum order differs)."""
+    from go_slam_amd import _lib
+    from go_slam_amd.droid_net import pack_conv3x3_weight
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(n * 1000 + c)
+    x = torch.randn(n, h, w, xs, generator=g).half().to(dev)
+    wt = (torch.randn(o, c, 3, 3, generator=g) / (3.0 * c ** 0.5)).half().to(dev)
+    wp = pack_conv3x3_weight(wt)
+    assert wp.numel() == _lib.lib().gs_conv3x3_wpack_elems(c, o)
+    y = torch.full((n, h, w, o + 8), 7.0, dtype=torch.float16, device=dev)          # y_stride > n_out: the tail stays
+    rc = _lib.lib().gs_conv3x3(_lib.ptr(x), xs, c, _lib.ptr(wp), _lib.ptr(y), o + 8, o, n, h, w, _lib.stream_ptr(dev))
+    _lib.check(rc, "conv3x3")
+    ref = torch.nn.functional.conv2d(x[..., :c].permute(0, 3, 1, 2).float(), wt.float(), padding=1).permute(0, 2, 3, 1)
+    assert bool((y[..., o:] == 7.0).all())
+    torch.testing.assert_close(y[..., :o].float(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_update_operator_with_own_conv3x3_matches_miopen_path(built_lib):
+    """UpdateModule's inference fast path with CONV3X3_IMPL = "hip" (all large 3x3 convolutions on gs_conv3x3) vs the
+    same path on MIOpen: same outputs within fp16 accumulation-order noise."""
+    import go_slam_amd.droid_net as DN
+    dev = "cuda:0"
+    torch.manual_seed(5)
+    op = DN.UpdateModule().to(dev).eval().to(memory_format=torch.channels_last)
+    E, h, w = 7, 24, 32
+    g = torch.Generator().manual_seed(6)
+    cl = lambda t: t.half().to(dev).contiguous(memory_format=torch.channels_last).unsqueeze(0)
+    net = cl(torch.tanh(torch.randn(E, 128, h, w, generator=g)))
+    inp = cl(torch.relu(torch.randn(E, 128, h, w, generator=g)))
+    corr = cl(0.5 * torch.randn(E, 196, h, w, generator=g))
+    flow = torch.randn(1, E, 4, h, w, generator=g).to(dev)
+    ii = torch.tensor([0, 0, 1, 2, 2, 3, 3], device=dev)
+    out = {}
+    keep = DN.CONV3X3_IMPL
+    try:
+        for impl in ("miopen", "hip"):
+            DN.CONV3X3_IMPL = impl
+            op.drop_edge_caches()
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                out[impl] = [t.float() for t in op(net.clone(), inp, corr, flow, ii, ii)]
+    finally:
+        DN.CONV3X3_IMPL = keep
+    for a, b, name in zip(out["hip"], out["miopen"], ("net", "delta", "weight", "eta", "upmask")):
+        torch.testing.assert_close(a, b, rtol=5e-3, atol=3e-3, msg=lambda m, nm=name: f"{nm}: {m}")

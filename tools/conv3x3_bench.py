@@ -1,0 +1,46 @@
+"""Micro-benchmark: the package's implicit-GEMM 3x3 convolution (gs_conv3x3) vs MIOpen on the update operator's layer
+shapes at the bench workload (75 edges, 60x80 maps).  Prints one JSON object."""
+import json
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from go_slam_amd import droid_net as DN  # noqa: E402
+
+LAYERS = (("gru_zr", 320, 256), ("gru_q", 320, 128), ("heads", 128, 384), ("corr_enc2", 128, 128))
+
+
+def time_op(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main(E=75, h=60, w=80):
+    dev = "cuda:0"
+    torch.backends.cudnn.benchmark = True
+    out = {"edges": E, "map": [h, w]}
+    for name, c, o in LAYERS:
+        x = torch.randn(E, c, h, w, device=dev).half().contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn(o, c, 3, 3, device=dev) / (3 * c ** 0.5)).half().contiguous(memory_format=torch.channels_last)
+        flops = 2.0 * E * h * w * 9 * c * o
+        ms_m = time_op(lambda: F.conv2d(x, wt, None, padding=1))
+        ms_h = time_op(lambda: DN.conv3x3_hip(x, wt))
+        err = float((DN.conv3x3_hip(x, wt).float() - F.conv2d(x, wt, None, padding=1).float()).abs().max())
+        out[name] = {"miopen_ms": round(ms_m, 4), "hip_ms": round(ms_h, 4), "miopen_tflops": round(flops / ms_m / 1e9, 1),
+                     "hip_tflops": round(flops / ms_h / 1e9, 1), "max_abs_diff": err}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
