@@ -29,15 +29,18 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 constexpr int TH = 16, TW = 16;            // output tile (pixels)
 constexpr int PH = TH + 2, PW = TW + 2;    // input patch
 constexpr int NP = PH * PW;                // 324 patch pixels
-constexpr int KC = 32, KG = KC / 8;        // input channels per chunk, 8-channel groups per chunk
 constexpr int BN = 128;                    // output channels per workgroup
-constexpr int WTAP = KG * BN;              // 16-byte vectors of one tap's weight image (512 = 8 KB)
 constexpr int TS = 72;                     // epilogue tile row stride in halves (144 B, staggers the banks)
 
+// KC = input channels per chunk (32: 37 KB of LDS, a barrier every 16 MFMAs per wave; 64: 74 KB, every 32 MFMAs)
+template <int KC>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restrict__ x, int xs, int C,
                                                          const half8* __restrict__ wpack, _Float16* __restrict__ y,
                                                          int ys, int H, int W, int tiles_x, int tiles_y) {
-  __shared__ half8 smem[KG * NP + 2 * WTAP];             // patch [KG][NP] | weights [2][KG][BN]
+  constexpr int KG = KC / 8;                             // 8-channel groups per chunk
+  constexpr int WTAP = KG * BN;                          // 16-byte vectors of one tap's weight image
+  constexpr int WPT = WTAP / 256;                        // ... per thread
+  extern __shared__ half8 smem[];                        // patch [KG][NP] | weights [2][KG][BN]
   half8* patch = smem;
   half8* wbuf = smem + KG * NP;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restr
   for (int ck = 0; ck < nchunk; ++ck) {
     // ---- stage the input patch of this channel chunk (4 lanes read the 64 contiguous bytes of a pixel)
     for (int it = tid; it < KG * NP; it += 256) {
-      const int kg = it & (KG - 1), p = it >> 2;
+      const int kg = it & (KG - 1), p = it / KG;
       const int py = p / PW, px = p - py * PW;
       const int gy = ty0 + py - 1, gx = tx0 + px - 1;
       half8 v = zero8;
@@ -80,42 +83,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restr
     }
     // ---- and the first tap's weights
     const half8* wck = wsrc + (size_t)ck * 9 * WTAP;
-    wbuf[tid] = wck[tid];
-    wbuf[tid + 256] = wck[tid + 256];
+#pragma unroll
+    for (int q = 0; q < WPT; ++q) wbuf[tid + 256 * q] = wck[tid + 256 * q];
     __syncthreads();
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      half8 n0 = zero8, n1 = zero8;
+      half8 nx[WPT];
       if (tap < 8) {                                      // next tap's image: global -> registers, in flight
-        n0 = wck[(tap + 1) * WTAP + tid];
-        n1 = wck[(tap + 1) * WTAP + tid + 256];
+#pragma unroll
+        for (int q = 0; q < WPT; ++q) nx[q] = wck[(tap + 1) * WTAP + tid + 256 * q];
       }
       __builtin_amdgcn_sched_barrier(0);                  // keep the prefetch at the top of the tap (the scheduler
                                                           // otherwise sinks it to its use and exposes the latency)
       const half8* wb = wbuf + (tap & 1) * WTAP;
       const int toff = (tap / 3) * PW + (tap % 3);
-      half8 a[KC / 16][2], b[KC / 16][4];                 // all fragments of the tap first: one LDS latency per 16 MFMAs
 #pragma unroll
-      for (int s = 0; s < KC / 16; ++s) {
-        const int kg = 2 * s + kgl;
-        a[s][0] = wb[kg * BN + wn * 64 + r];
-        a[s][1] = wb[kg * BN + wn * 64 + 32 + r];
+      for (int grp = 0; grp < KC / 32; ++grp) {           // 32 channels at a time: 12 fragment reads, then 16 MFMAs
+        half8 a[2][2], b[2][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) b[s][i] = patch[kg * NP + pb[i] + toff];
-      }
-      __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < 2; ++s) {
+          const int kg = 4 * grp + 2 * s + kgl;
+          a[s][0] = wb[kg * BN + wn * 64 + r];
+          a[s][1] = wb[kg * BN + wn * 64 + 32 + r];
 #pragma unroll
-      for (int s = 0; s < KC / 16; ++s)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][0], b[s][i], acc[0][i], 0, 0, 0);
-          acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][1], b[s][i], acc[1][i], 0, 0, 0);
+          for (int i = 0; i < 4; ++i) b[s][i] = patch[kg * NP + pb[i] + toff];
         }
-      __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][0], b[s][i], acc[0][i], 0, 0, 0);
+            acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][1], b[s][i], acc[1][i], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (tap < 8) {
         half8* wnext = wbuf + ((tap + 1) & 1) * WTAP;     // last read during tap - 1: every wave is past that barrier
-        wnext[tid] = n0;
-        wnext[tid + 256] = n1;
+#pragma unroll
+        for (int q = 0; q < WPT; ++q) wnext[tid + 256 * q] = nx[q];
       }
       __syncthreads();                                    // tap 8: also frees the patch and wbuf[0] for the next chunk
     }
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restr
 
   // ---- epilogue: [32 pixels][64 channels] at a time through a wave-private LDS tile (aliases the patch; all waves
   // are past the last barrier, and a wave only touches its own 4.6 KB)
-  _Float16* tile = reinterpret_cast<_Float16*>(smem) + wv * 32 * TS;
+  _Float16* tile = reinterpret_cast<_Float16*>(smem) + wv * 32 * TS;   // 18 KB in all: inside the patch for any KC
   _Float16* yimg = y + (size_t)img * H * W * ys + nb * BN + wn * 64;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -153,24 +159,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restr
   }
 }
 
+template <int KC>
+int launch3x3(const void* x, int x_stride, int c_in, const void* wpack, void* y, int y_stride, int n_out, int n, int h,
+              int w, hipStream_t st) {
+  constexpr size_t lds = (size_t)((KC / 8) * NP + 2 * (KC / 8) * BN) * sizeof(half8);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv3x3_kernel<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess) {
+      gs_set_error("conv3x3: cannot raise the dynamic LDS limit to %zu bytes", lds);
+      return GS_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int tiles_x = gs_cdiv(w, TW), tiles_y = gs_cdiv(h, TH);
+  const long long blocks = (long long)n * tiles_x * tiles_y;
+  GS_REQUIRE(blocks < (1ll << 31), "conv3x3: too many tiles");
+  conv3x3_kernel<KC><<<dim3((unsigned)blocks, n_out / BN), 256, lds, st>>>(
+      (const _Float16*)x, x_stride, c_in, (const half8*)wpack, (_Float16*)y, y_stride, h, w, tiles_x, tiles_y);
+  GS_CHECK_LAUNCH("conv3x3");
+  return GS_OK;
+}
+
 }  // namespace
 
 extern "C" size_t gs_conv3x3_wpack_elems(int c_in, int n_out) { return (size_t)9 * c_in * n_out; }
 
-extern "C" int gs_conv3x3(const void* x, int x_stride, int c_in, const void* wpack, void* y, int y_stride, int n_out,
-                          int n, int h, int w, gs_stream_t stream) {
+extern "C" int gs_conv3x3(const void* x, int x_stride, int c_in, const void* wpack, int kc, void* y, int y_stride,
+                          int n_out, int n, int h, int w, gs_stream_t stream) {
   GS_REQUIRE(x && wpack && y, "conv3x3: null pointer");
-  GS_REQUIRE(c_in > 0 && c_in % KC == 0, "conv3x3: c_in must be a multiple of %d", KC);
+  GS_REQUIRE(kc == 32 || kc == 64, "conv3x3: kc (channels per chunk of the packed weights) must be 32 or 64");
+  GS_REQUIRE(c_in > 0 && c_in % kc == 0, "conv3x3: c_in must be a multiple of kc = %d", kc);
   GS_REQUIRE(n_out > 0 && n_out % BN == 0, "conv3x3: n_out must be a multiple of %d", BN);
   GS_REQUIRE(x_stride >= c_in && x_stride % 8 == 0, "conv3x3: x_stride must be >= c_in and a multiple of 8");
   GS_REQUIRE(y_stride >= n_out && y_stride % 8 == 0, "conv3x3: y_stride must be >= n_out and a multiple of 8");
   GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3: bad shape");
   if (n == 0) return GS_OK;
-  const int tiles_x = gs_cdiv(w, TW), tiles_y = gs_cdiv(h, TH);
-  const long long blocks = (long long)n * tiles_x * tiles_y;
-  GS_REQUIRE(blocks < (1ll << 31), "conv3x3: too many tiles");
-  conv3x3_kernel<<<dim3((unsigned)blocks, n_out / BN), 256, 0, (hipStream_t)stream>>>(
-      (const _Float16*)x, x_stride, c_in, (const half8*)wpack, (_Float16*)y, y_stride, h, w, tiles_x, tiles_y);
-  GS_CHECK_LAUNCH("conv3x3");
-  return GS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (kc == 32) return launch3x3<32>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, st);
+  return launch3x3<64>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, st);
 }

@@ -171,20 +171,27 @@ def bias_act(y, b, act, out=None, out_channel=0, in_channel=0, channels=None):
     return dst
 
 
-# Implementation of the large 3x3 convolutions on the inference fast path: "miopen" (default) or "hip" = the
-# package's own implicit-GEMM MFMA kernel gs_conv3x3 (csrc/conv3x3.hip) -- experimental in round 1, opt-in through
-# the environment (GOSLAM_CONV3X3=hip) or by assigning this module attribute.
-CONV3X3_IMPL = os.environ.get("GOSLAM_CONV3X3", "miopen")
-_CONV3X3_PACKS = {}
+# Implementation of the large 3x3 convolutions on the inference fast path:
+#   "hip"    the package's own implicit-GEMM MFMA kernel gs_conv3x3 (csrc/conv3x3.hip) wherever it applies,
+#   "miopen" always MIOpen,
+#   "auto"   (default) gs_conv3x3 when its 16x16-pixel tiles cover the map with <= 10 % padding waste (e.g. 60x80:
+#            6 %), MIOpen otherwise (30x40 and 40x80 maps waste 22 % / 17 % of the tile).
+# Measured on MI355X at the bench shape (75 edges, 60x80; tools/conv3x3_bench.py, profiles/r01_conv3x3_bench.json):
+# 844 / 846 / 866 / 722 TFLOP/s against MIOpen's 772 / 672 / 738 / 690 on the GRU z|r, GRU q, heads and
+# corr_encoder[2] layers.  Override with GOSLAM_CONV3X3 or by assigning this attribute.
+CONV3X3_IMPL = os.environ.get("GOSLAM_CONV3X3", "auto")
+CONV3X3_KC = 32            # input channels per LDS chunk of gs_conv3x3 (32 or 64; fixes the weight image layout)
+_CONV3X3_PACKS = {}        # (data_ptr, version, shape, device, kc) -> (packed image, weight tensor kept alive)
+_CONV3X3_PACKS_MAX = 32
 
 
-def pack_conv3x3_weight(weight):
-    """[O, C, 3, 3] -> gs_conv3x3's fp16 LDS images [O/128][C/32][9][4][128][8] (include/goslam_hip.h):
-    wpack[nb][ck][3 ky + kx][kg][r][e] = W[128 nb + r][32 ck + 8 kg + e][ky][kx]."""
+def pack_conv3x3_weight(weight, kc=32):
+    """[O, C, 3, 3] -> gs_conv3x3's fp16 LDS images [O/128][C/kc][9][kc/8][128][8] (include/goslam_hip.h):
+    wpack[nb][ck][3 ky + kx][kg][r][e] = W[128 nb + r][kc ck + 8 kg + e][ky][kx]."""
     O, C, kh, kw = weight.shape
-    assert (kh, kw) == (3, 3) and O % 128 == 0 and C % 32 == 0
-    w = weight.detach().half().reshape(O // 128, 128, C // 32, 4, 8, 3, 3)      # nb r ck kg e ky kx
-    return w.permute(0, 2, 5, 6, 3, 1, 4).contiguous().reshape(-1)             # nb ck ky kx kg r e
+    assert (kh, kw) == (3, 3) and O % 128 == 0 and C % kc == 0 and kc in (32, 64)
+    w = weight.detach().half().reshape(O // 128, 128, C // kc, kc // 8, 8, 3, 3)   # nb r ck kg e ky kx
+    return w.permute(0, 2, 5, 6, 3, 1, 4).contiguous().reshape(-1)                # nb ck ky kx kg r e
 
 
 def conv3x3_hip_supported(x, w):
@@ -193,27 +200,44 @@ def conv3x3_hip_supported(x, w):
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
-def conv3x3_hip(x, w):
-    """bias-free 3x3 / pad 1 convolution of an NHWC fp16 tensor through gs_conv3x3; `w` is the [O,C,3,3] weight
-    (its packed image is cached per weight tensor and version)."""
+def conv3x3_tile_efficiency(h, w):
+    """fraction of gs_conv3x3's 16x16-pixel tiles that is real output"""
+    return (h * w) / float(((h + 15) // 16 * 16) * ((w + 15) // 16 * 16))
+
+
+def _use_own_conv3x3(x, w, stride, padding):
+    if CONV3X3_IMPL == "miopen" or stride not in (1, (1, 1)) or padding not in (1, (1, 1)):
+        return False
+    if not conv3x3_hip_supported(x, w):
+        return False
+    return CONV3X3_IMPL == "hip" or conv3x3_tile_efficiency(x.shape[2], x.shape[3]) >= 0.9
+
+
+def conv3x3_hip(x, w, kc=None):
+    """bias-free 3x3 / pad 1 convolution of an NHWC fp16 tensor through gs_conv3x3; `w` is the [O,C,3,3] weight.
+    Its packed image is cached per (storage address, version, shape); the entry keeps the weight tensor alive, so the
+    address cannot be recycled for different values while the entry exists."""
     from . import _lib
-    key = (w.data_ptr(), w._version, w.device, tuple(w.shape))
-    hit = _CONV3X3_PACKS.get(id(w))
-    if hit is None or hit[0] != key:
-        hit = (key, pack_conv3x3_weight(w), w)              # keeps `w` alive so that id(w) stays unique
-        _CONV3X3_PACKS[id(w)] = hit
+    kc = kc or (CONV3X3_KC if w.shape[1] % CONV3X3_KC == 0 else 32)
+    key = (w.data_ptr(), w._version, tuple(w.shape), w.device, kc)
+    hit = _CONV3X3_PACKS.pop(key, None)
+    if hit is None:
+        hit = (pack_conv3x3_weight(w, kc), w)
+        while len(_CONV3X3_PACKS) >= _CONV3X3_PACKS_MAX:
+            _CONV3X3_PACKS.pop(next(iter(_CONV3X3_PACKS)))
+    _CONV3X3_PACKS[key] = hit                                # re-inserted last: least recently used goes first
     n, c, h, wd = x.shape
     O = w.shape[0]
     y = torch.empty((n, O, h, wd), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
-        rc = _lib.lib().gs_conv3x3(_lib.ptr(x), c, c, _lib.ptr(hit[1]), _lib.ptr(y), O, O, n, h, wd,
+        rc = _lib.lib().gs_conv3x3(_lib.ptr(x), c, c, _lib.ptr(hit[0]), kc, _lib.ptr(y), O, O, n, h, wd,
                                    _lib.stream_ptr(x.device))
     _lib.check(rc, "conv3x3")
     return y
 
 
 def conv_nobias(x, w, stride=1, padding=0):
-    if CONV3X3_IMPL == "hip" and stride in (1, (1, 1)) and padding in (1, (1, 1)) and conv3x3_hip_supported(x, w):
+    if _use_own_conv3x3(x, w, stride, padding):
         return conv3x3_hip(x, w)
     with torch.autocast("cuda", enabled=False):
         y = F.conv2d(x, w, None, stride=stride, padding=padding)

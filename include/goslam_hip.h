@@ -172,13 +172,13 @@ int gs_conv1x1(const void* x, int x_stride, int k_in, const void* wpack, const f
  * NHWC fp16 [n,h,w,n_out] (y_stride apart), fp32 accumulation, as an implicit GEMM on MFMA with the 18x18 input
  * patch of a 16x16-pixel tile staged once in LDS for all 9 taps.  Covers the large convolutions of the update
  * operator: ConvGRU convz|convr and convq (src/modules/gru.py:10-12), the first layers of the delta / weight / agg
- * heads (src/droid_net.py:83,88,40) and corr_encoder[2] (src/droid_net.py:76).  c_in % 32 == 0, n_out % 128 == 0.
- * wpack: fp16 [n_out/128][c_in/32][9][4][128][8],
- * wpack[nb][ck][3 ky + kx][kg][r][e] = W[128 nb + r][32 ck + 8 kg + e][ky][kx] (gs_conv3x3_wpack_elems halves).
- * EXPERIMENTAL in round 1 (opt-in from the host mirror; MIOpen remains the default for these layers).   */
+ * heads (src/droid_net.py:83,88,40) and corr_encoder[2] (src/droid_net.py:76).  n_out % 128 == 0; kc in {32, 64}
+ * is the number of input channels staged per LDS chunk (c_in % kc == 0) and fixes the weight image layout:
+ * wpack: fp16 [n_out/128][c_in/kc][9][kc/8][128][8],
+ * wpack[nb][ck][3 ky + kx][kg][r][e] = W[128 nb + r][kc ck + 8 kg + e][ky][kx] (gs_conv3x3_wpack_elems halves). */
 size_t gs_conv3x3_wpack_elems(int c_in, int n_out);
-int gs_conv3x3(const void* x, int x_stride, int c_in, const void* wpack, void* y, int y_stride, int n_out, int n,
-               int h, int w, gs_stream_t stream);
+int gs_conv3x3(const void* x, int x_stride, int c_in, const void* wpack, int kc, void* y, int y_stride, int n_out,
+               int n, int h, int w, gs_stream_t stream);
 /* 3x3 convolution (padding 1) from 128 channels to n_out in {1,2} channels, NHWC fp16 in, fp32 out
  * [n,h,w,n_out]: the flow-revision / confidence heads delta[2], weight[2] (src/droid_net.py:83-92) and
  * GraphAgg's eta[0] (src/droid_net.py:43).  x rows are x_stride elements apart (a channel slice of a

@@ -209,13 +209,14 @@ def test_conv3x3_weight_image_layout():
     O, C, H, W = 256, 64, 5, 7
     w = (torch.randn(O, C, 3, 3, generator=g) * 0.1).half()
     x = torch.randn(1, C, H, W, generator=g).half()
-    wp = pack_conv3x3_weight(w).float().view(O // 128, C // 32, 9, 4, 128, 8)
     xp = F.pad(x.float(), (1, 1, 1, 1))[0].permute(1, 2, 0)                     # [H+2, W+2, C]
-    out = torch.zeros(O, H, W)
-    for ck in range(C // 32):
-        for tap in range(9):
-            ky, kx = tap // 3, tap % 3
-            win = xp[ky:ky + H, kx:kx + W, 32 * ck:32 * ck + 32].reshape(H, W, 4, 8)        # [.., kg, e]
-            out += torch.einsum("nkre,hwke->nrhw", wp[:, ck, tap], win).reshape(O, H, W)
     ref = F.conv2d(x.float(), w.float(), padding=1)[0]
-    assert torch.allclose(out, ref, rtol=1e-4, atol=1e-4)
+    for kc in (32, 64):
+        wp = pack_conv3x3_weight(w, kc).float().view(O // 128, C // kc, 9, kc // 8, 128, 8)
+        out = torch.zeros(O, H, W)
+        for ck in range(C // kc):
+            for tap in range(9):
+                ky, kx = tap // 3, tap % 3
+                win = xp[ky:ky + H, kx:kx + W, kc * ck:kc * ck + kc].reshape(H, W, kc // 8, 8)   # [.., kg, e]
+                out += torch.einsum("nkre,hwke->nrhw", wp[:, ck, tap], win).reshape(O, H, W)
+        assert torch.allclose(out, ref, rtol=1e-4, atol=1e-4), kc

@@ -233,22 +233,24 @@ def test_point_queries_and_extract_fields_match_oracle(built_lib):
     assert int(np.abs(cols.astype(np.int32) - (np.clip(rgb_r[:100].numpy(), 0, 1) * 255).astype(np.int32)).max()) <= 2
 
 
+@pytest.mark.parametrize("kc", [32, 64])
 @pytest.mark.parametrize("n,h,w,c,xs,o", [(3, 30, 40, 320, 320, 256), (2, 12, 16, 128, 128, 384), (1, 60, 80, 128, 128, 128),
                                           (2, 17, 23, 64, 96, 128)])
-def test_conv3x3_implicit_gemm_matches_reference(built_lib, n, h, w, c, xs, o):
+def test_conv3x3_implicit_gemm_matches_reference(built_lib, n, h, w, c, xs, o, kc):
     """gs_conv3x3 (own implicit-GEMM MFMA convolution, experimental) vs F.conv2d in fp32 on the same fp16 operands:
     partial tiles (h, w not multiples of 16), a channel slice of a wider tensor (xs > c), 1-3 output blocks.
-    Tolerance: one fp16 rounding of the output (the products are exact in fp32, the sum order differs)."""
+    Both chunk sizes (kc = 32 / 64 input channels staged per LDS chunk).  Tolerance: one fp16 rounding of the output (the products are exact in fp32, the sum order differs)."""
     from go_slam_amd import _lib
     from go_slam_amd.droid_net import pack_conv3x3_weight
     dev = "cuda:0"
     g = torch.Generator().manual_seed(n * 1000 + c)
     x = torch.randn(n, h, w, xs, generator=g).half().to(dev)
     wt = (torch.randn(o, c, 3, 3, generator=g) / (3.0 * c ** 0.5)).half().to(dev)
-    wp = pack_conv3x3_weight(wt)
+    wp = pack_conv3x3_weight(wt, kc)
     assert wp.numel() == _lib.lib().gs_conv3x3_wpack_elems(c, o)
     y = torch.full((n, h, w, o + 8), 7.0, dtype=torch.float16, device=dev)          # y_stride > n_out: the tail stays
-    rc = _lib.lib().gs_conv3x3(_lib.ptr(x), xs, c, _lib.ptr(wp), _lib.ptr(y), o + 8, o, n, h, w, _lib.stream_ptr(dev))
+    rc = _lib.lib().gs_conv3x3(_lib.ptr(x), xs, c, _lib.ptr(wp), kc, _lib.ptr(y), o + 8, o, n, h, w,
+                               _lib.stream_ptr(dev))
     _lib.check(rc, "conv3x3")
     ref = torch.nn.functional.conv2d(x[..., :c].permute(0, 3, 1, 2).float(), wt.float(), padding=1).permute(0, 2, 3, 1)
     assert bool((y[..., o:] == 7.0).all())

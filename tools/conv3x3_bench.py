@@ -35,10 +35,14 @@ def main(E=75, h=60, w=80):
         wt = (torch.randn(o, c, 3, 3, device=dev) / (3 * c ** 0.5)).half().contiguous(memory_format=torch.channels_last)
         flops = 2.0 * E * h * w * 9 * c * o
         ms_m = time_op(lambda: F.conv2d(x, wt, None, padding=1))
-        ms_h = time_op(lambda: DN.conv3x3_hip(x, wt))
-        err = float((DN.conv3x3_hip(x, wt).float() - F.conv2d(x, wt, None, padding=1).float()).abs().max())
-        out[name] = {"miopen_ms": round(ms_m, 4), "hip_ms": round(ms_h, 4), "miopen_tflops": round(flops / ms_m / 1e9, 1),
-                     "hip_tflops": round(flops / ms_h / 1e9, 1), "max_abs_diff": err}
+        row = {"miopen_ms": round(ms_m, 4), "miopen_tflops": round(flops / ms_m / 1e9, 1)}
+        ref = F.conv2d(x, wt, None, padding=1).float()
+        for kc in (32, 64):
+            ms_h = time_op(lambda: DN.conv3x3_hip(x, wt, kc))
+            row[f"hip_kc{kc}_ms"] = round(ms_h, 4)
+            row[f"hip_kc{kc}_tflops"] = round(flops / ms_h / 1e9, 1)
+            row[f"hip_kc{kc}_max_abs_diff"] = float((DN.conv3x3_hip(x, wt, kc).float() - ref).abs().max())
+        out[name] = row
     print(json.dumps(out))
 
 
