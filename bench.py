@@ -380,6 +380,22 @@ def main():
             {"kernel": "corr_volume_kernel (MFMA all-pairs volume + 3 pooled levels, written once)", "bound": "hbm",
              "achieved": bgb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bgb / HBM_PEAK_GBS,
              "bytes_per_launch": br["corr_build_bytes"], "note": "8 edges per launch (one keyframe's new factors)"}]
+        try:    # the update operator's largest convolution (GRU z|r, 320 -> 256) on the package's implicit-GEMM kernel
+            from go_slam_amd import droid_net as DN
+            E = int(br["edges"])
+            xz = torch.randn(E, 320, ht, wd, device=device).half().contiguous(memory_format=torch.channels_last)
+            wz = (torch.randn(256, 320, 3, 3, device=device) / 160.0).half()
+            if DN.conv3x3_hip_supported(xz, wz):
+                ms = time_op(lambda: DN.conv3x3_hip(xz, wz), iters=10, warm=3)
+                tf = 2.0 * E * ht * wd * 9 * 320 * 256 / (ms * 1e-3) / 1e12
+                line["roofline_other"].append(
+                    {"kernel": "conv3x3_kernel (implicit-GEMM 3x3 conv, GRU z|r 320->256, fp16 MFMA / fp32 accumulate)",
+                     "bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tf / MFMA_F16_PEAK_TFLOPS, "kernel_avg_us": ms * 1e3,
+                     "in_use": DN._use_own_conv3x3(xz, wz, 1, 1), "impl": DN.CONV3X3_IMPL})
+            del xz, wz
+        except Exception as exc:                       # never lose the bench line over an auxiliary measurement
+            line["roofline_other"].append({"kernel": "conv3x3_kernel", "error": repr(exc)})
         line["neus_render"] = neus_render_bench(device)
         line["roofline_other"].append(dict(line["neus_render"]["mlp_mfma"], bound="mfma"))
         if world == 1 and not args.no_cpu_baseline:

@@ -177,10 +177,13 @@ def bias_act(y, b, act, out=None, out_channel=0, in_channel=0, channels=None):
 #   "auto"   (default) gs_conv3x3 when its 16x16-pixel tiles cover the map with <= 10 % padding waste (e.g. 60x80:
 #            6 %), MIOpen otherwise (30x40 and 40x80 maps waste 22 % / 17 % of the tile).
 # Measured on MI355X at the bench shape (75 edges, 60x80; tools/conv3x3_bench.py, profiles/r01_conv3x3_bench.json):
-# 844 / 846 / 866 / 722 TFLOP/s against MIOpen's 772 / 672 / 738 / 690 on the GRU z|r, GRU q, heads and
-# corr_encoder[2] layers.  Override with GOSLAM_CONV3X3 or by assigning this attribute.
+# 885 / 896 / 917 / 859 TFLOP/s against MIOpen's 795 / 706 / 792 / 658 on the GRU z|r, GRU q, heads and
+# corr_encoder[2] layers; end to end 53.9 -> 59.7 keyframes/s (tools/update_ab.py, profiles/r01_update_ab.json).
+# Override with GOSLAM_CONV3X3 or by assigning this attribute.
 CONV3X3_IMPL = os.environ.get("GOSLAM_CONV3X3", "auto")
-CONV3X3_KC = 32            # input channels per LDS chunk of gs_conv3x3 (32 or 64; fixes the weight image layout)
+# input channels per LDS chunk of gs_conv3x3: 32, 64 or "auto" = 64 except for the 320 -> 256 GRU z|r layer, where
+# 32 measured faster (885 vs 802 TFLOP/s; q / heads / corr_encoder[2]: 853 / 888 / 705 at 32, 896 / 917 / 859 at 64)
+CONV3X3_KC = "auto"
 _CONV3X3_PACKS = {}        # (data_ptr, version, shape, device, kc) -> (packed image, weight tensor kept alive)
 _CONV3X3_PACKS_MAX = 32
 
@@ -198,6 +201,14 @@ def conv3x3_hip_supported(x, w):
     return (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
             and w.shape[0] % 128 == 0 and w.shape[1] % 32 == 0 and x.shape[1] == w.shape[1]
             and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def conv3x3_chunk(c_in, n_out):
+    """channels per LDS chunk for a layer (see CONV3X3_KC)"""
+    kc = CONV3X3_KC
+    if kc == "auto":
+        kc = 32 if (c_in >= 320 and n_out >= 256) else 64
+    return kc if c_in % kc == 0 else 32
 
 
 def conv3x3_tile_efficiency(h, w):
@@ -218,7 +229,7 @@ def conv3x3_hip(x, w, kc=None):
     Its packed image is cached per (storage address, version, shape); the entry keeps the weight tensor alive, so the
     address cannot be recycled for different values while the entry exists."""
     from . import _lib
-    kc = kc or (CONV3X3_KC if w.shape[1] % CONV3X3_KC == 0 else 32)
+    kc = kc or conv3x3_chunk(w.shape[1], w.shape[0])
     key = (w.data_ptr(), w._version, tuple(w.shape), w.device, kc)
     hit = _CONV3X3_PACKS.pop(key, None)
     if hit is None:
