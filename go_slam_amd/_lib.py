@@ -42,6 +42,7 @@ SIGNATURES = {
     "gs_conv1x1": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, c_int, c_int, ctypes.c_longlong, _P]),
     "gs_conv3x3_wpack_elems": (c_size_t, [c_int, c_int]),
     "gs_conv3x3": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "gs_conv3x3_stacked": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "gs_conv3x3_head": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_float, _P, c_int, c_int, c_int, _P]),
     "gs_segment_mean": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gs_gru_glo_workspace_bytes": (c_size_t, [c_int]),

@@ -159,6 +159,167 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row-stacked variant: the n images are treated as ONE image of n*H rows (they are contiguous in NHWC memory), so
+// 256-pixel tiles of TH = 256 / TW rows run across image boundaries and only the very last tile of the batch is
+// partial in y -- no tile padding for H = 60, 40 or 30.  What a tile must not do is let a pixel of image k see rows
+// of image k +- 1 through the vertical taps: the B fragments of tap row 0 are zeroed for pixels with y == 0, those of
+// tap row 2 for pixels with y == H - 1 (a per-lane select, 4 dwords per fragment).  TW in {8, 16, 32} picks the tile
+// width that divides the map width best (40 -> 8, 80 -> 16).
+template <int KC, int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_stacked_kernel(const _Float16* __restrict__ x, int xs, int C,
+                                                                 const half8* __restrict__ wpack,
+                                                                 _Float16* __restrict__ y, int ys, int H, int W,
+                                                                 int rows, int tiles_x) {
+  constexpr int TH_ = 256 / TW, PW_ = TW + 2, NP_ = (TH_ + 2) * PW_;
+  constexpr int KG = KC / 8, WTAP = KG * BN, WPT = WTAP / 256;
+  extern __shared__ half8 smem[];                        // patch [KG][NP_] | weights [2][KG][BN]
+  half8* patch = smem;
+  half8* wbuf = smem + KG * NP_;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv & 1, wn = wv >> 1;
+  const int r = lane & 31, kgl = lane >> 5;
+  const int tx0 = (blockIdx.x % tiles_x) * TW;
+  const int g0 = (blockIdx.x / tiles_x) * TH_;            // first stacked row (img * H + y) of the tile
+  const int nb = blockIdx.y;
+  const int nchunk = C / KC;
+  const half8* wsrc = wpack + (size_t)nb * nchunk * 9 * WTAP;
+
+  int pb[4];
+  bool top[4], bot[4];                                    // this lane's pixel is on the first / last row of its image
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = wm * 128 + i * 32 + r;
+    const int ty = m / TW, tx = m % TW;
+    pb[i] = ty * PW_ + tx;
+    const int yy = (g0 + ty) % H;
+    top[i] = yy == 0;
+    bot[i] = yy == H - 1;
+  }
+
+  float16v acc[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.0f;
+
+  const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int ck = 0; ck < nchunk; ++ck) {
+    for (int it = tid; it < KG * NP_; it += 256) {
+      const int kg = it & (KG - 1), p = it / KG;
+      const int pr = p / PW_, pc = p - pr * PW_;
+      const int gv = g0 + pr - 1, gx = tx0 + pc - 1;      // stacked row: rows of neighbouring images are loaded as
+      half8 v = zero8;                                    // they are and masked per pixel below
+      if (gv >= 0 && gv < rows && gx >= 0 && gx < W)
+        v = *reinterpret_cast<const half8*>(x + ((size_t)gv * W + gx) * xs + ck * KC + kg * 8);
+      patch[kg * NP_ + p] = v;
+    }
+    const half8* wck = wsrc + (size_t)ck * 9 * WTAP;
+#pragma unroll
+    for (int q = 0; q < WPT; ++q) wbuf[tid + 256 * q] = wck[tid + 256 * q];
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      half8 nx[WPT];
+      if (tap < 8) {
+#pragma unroll
+        for (int q = 0; q < WPT; ++q) nx[q] = wck[(tap + 1) * WTAP + tid + 256 * q];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const half8* wb = wbuf + (tap & 1) * WTAP;
+      const int dy = tap / 3;
+      const int toff = dy * PW_ + (tap % 3);
+#pragma unroll
+      for (int grp = 0; grp < KC / 32; ++grp) {
+        half8 a[2][2], b[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int kg = 4 * grp + 2 * s + kgl;
+          a[s][0] = wb[kg * BN + wn * 64 + r];
+          a[s][1] = wb[kg * BN + wn * 64 + 32 + r];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            half8 v = patch[kg * NP_ + pb[i] + toff];
+            if (dy == 0 && top[i]) v = zero8;             // the row above belongs to the previous image
+            if (dy == 2 && bot[i]) v = zero8;             // the row below belongs to the next image
+            b[s][i] = v;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][0], b[s][i], acc[0][i], 0, 0, 0);
+            acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][1], b[s][i], acc[1][i], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (tap < 8) {
+        half8* wnext = wbuf + ((tap + 1) & 1) * WTAP;
+#pragma unroll
+        for (int q = 0; q < WPT; ++q) wnext[tid + 256 * q] = nx[q];
+      }
+      __syncthreads();
+    }
+  }
+
+  _Float16* tile = reinterpret_cast<_Float16*>(smem) + wv * 32 * TS;
+  _Float16* yb = y + nb * BN + wn * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc[j][i][4 * g + e];
+        *reinterpret_cast<half4*>(tile + r * TS + j * 32 + 8 * g + 4 * kgl) = o;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int pxr = it * 8 + (lane >> 3), piece = lane & 7;
+      const int m = wm * 128 + i * 32 + pxr;
+      const int gv = g0 + m / TW, gx = tx0 + m % TW;
+      if (gv < rows && gx < W) {
+        const half8 v = *reinterpret_cast<const half8*>(tile + pxr * TS + piece * 8);
+        *reinterpret_cast<half8*>(yb + ((size_t)gv * W + gx) * ys + piece * 8) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int KC, int TW>
+int launch3x3s(const void* x, int x_stride, int c_in, const void* wpack, void* y, int y_stride, int n_out, int n, int h,
+               int w, hipStream_t st) {
+  constexpr int NP_ = (256 / TW + 2) * (TW + 2);
+  constexpr size_t lds = (size_t)((KC / 8) * NP_ + 2 * (KC / 8) * BN) * sizeof(half8);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv3x3_stacked_kernel<KC, TW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+      gs_set_error("conv3x3_stacked: cannot raise the dynamic LDS limit to %zu bytes", lds);
+      return GS_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const long long rows = (long long)n * h;
+  GS_REQUIRE(rows * w < (1ll << 31), "conv3x3_stacked: too many pixels");
+  const int tiles_x = gs_cdiv(w, TW), tiles_y = gs_cdiv((int)rows, 256 / TW);
+  conv3x3_stacked_kernel<KC, TW><<<dim3((unsigned)(tiles_x * tiles_y), n_out / BN), 256, lds, st>>>(
+      (const _Float16*)x, x_stride, c_in, (const half8*)wpack, (_Float16*)y, y_stride, h, w, (int)rows, tiles_x);
+  GS_CHECK_LAUNCH("conv3x3_stacked");
+  return GS_OK;
+}
+
 template <int KC>
 int launch3x3(const void* x, int x_stride, int c_in, const void* wpack, void* y, int y_stride, int n_out, int n, int h,
               int w, hipStream_t st) {
@@ -198,4 +359,28 @@ extern "C" int gs_conv3x3(const void* x, int x_stride, int c_in, const void* wpa
   hipStream_t st = (hipStream_t)stream;
   if (kc == 32) return launch3x3<32>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, st);
   return launch3x3<64>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, st);
+}
+
+extern "C" int gs_conv3x3_stacked(const void* x, int x_stride, int c_in, const void* wpack, int kc, int tw, void* y,
+                                  int y_stride, int n_out, int n, int h, int w, gs_stream_t stream) {
+  GS_REQUIRE(x && wpack && y, "conv3x3_stacked: null pointer");
+  GS_REQUIRE(kc == 32 || kc == 64, "conv3x3_stacked: kc must be 32 or 64");
+  GS_REQUIRE(tw == 8 || tw == 16 || tw == 32, "conv3x3_stacked: tile width must be 8, 16 or 32");
+  GS_REQUIRE(c_in > 0 && c_in % kc == 0, "conv3x3_stacked: c_in must be a multiple of kc = %d", kc);
+  GS_REQUIRE(n_out > 0 && n_out % BN == 0, "conv3x3_stacked: n_out must be a multiple of %d", BN);
+  GS_REQUIRE(x_stride >= c_in && x_stride % 8 == 0, "conv3x3_stacked: x_stride must be >= c_in and a multiple of 8");
+  GS_REQUIRE(y_stride >= n_out && y_stride % 8 == 0, "conv3x3_stacked: y_stride must be >= n_out and a multiple of 8");
+  GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3_stacked: bad shape");
+  if (n == 0) return GS_OK;
+  hipStream_t st = (hipStream_t)stream;
+#define GS_S(KC_, TW_) return launch3x3s<KC_, TW_>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, st)
+  if (kc == 32) {
+    if (tw == 8) GS_S(32, 8);
+    if (tw == 16) GS_S(32, 16);
+    GS_S(32, 32);
+  }
+  if (tw == 8) GS_S(64, 8);
+  if (tw == 16) GS_S(64, 16);
+  GS_S(64, 32);
+#undef GS_S
 }

@@ -184,6 +184,9 @@ CONV3X3_IMPL = os.environ.get("GOSLAM_CONV3X3", "auto")
 # input channels per LDS chunk of gs_conv3x3: 32, 64 or "auto" = 64 except for the 320 -> 256 GRU z|r layer, where
 # 32 measured faster (885 vs 802 TFLOP/s; q / heads / corr_encoder[2]: 853 / 888 / 705 at 32, 896 / 917 / 859 at 64)
 CONV3X3_KC = "auto"
+# Row-stacked tiling (gs_conv3x3_stacked: no tile padding along the rows, tile width chosen per map width) -- opt-in
+# (GOSLAM_CONV3X3_STACKED=1) until it has been timed against the plain tiling; with it "auto" covers every map size.
+CONV3X3_STACKED = os.environ.get("GOSLAM_CONV3X3_STACKED", "0") == "1"
 _CONV3X3_PACKS = {}        # (data_ptr, version, shape, device, kc) -> (packed image, weight tensor kept alive)
 _CONV3X3_PACKS_MAX = 32
 
@@ -216,15 +219,22 @@ def conv3x3_tile_efficiency(h, w):
     return (h * w) / float(((h + 15) // 16 * 16) * ((w + 15) // 16 * 16))
 
 
+def conv3x3_stacked_tile_width(w):
+    """tile width in {16, 8, 32} with the least column padding (ties: 16 first)"""
+    return min((16, 8, 32), key=lambda tw: ((w + tw - 1) // tw * tw, tw != 16))
+
+
 def _use_own_conv3x3(x, w, stride, padding):
     if CONV3X3_IMPL == "miopen" or stride not in (1, (1, 1)) or padding not in (1, (1, 1)):
         return False
     if not conv3x3_hip_supported(x, w):
         return False
-    return CONV3X3_IMPL == "hip" or conv3x3_tile_efficiency(x.shape[2], x.shape[3]) >= 0.9
+    if CONV3X3_IMPL == "hip" or CONV3X3_STACKED:
+        return True
+    return conv3x3_tile_efficiency(x.shape[2], x.shape[3]) >= 0.9
 
 
-def conv3x3_hip(x, w, kc=None):
+def conv3x3_hip(x, w, kc=None, stacked=None, tw=None):
     """bias-free 3x3 / pad 1 convolution of an NHWC fp16 tensor through gs_conv3x3; `w` is the [O,C,3,3] weight.
     Its packed image is cached per (storage address, version, shape); the entry keeps the weight tensor alive, so the
     address cannot be recycled for different values while the entry exists."""
@@ -240,9 +250,15 @@ def conv3x3_hip(x, w, kc=None):
     n, c, h, wd = x.shape
     O = w.shape[0]
     y = torch.empty((n, O, h, wd), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    stacked = CONV3X3_STACKED if stacked is None else stacked
     with torch.cuda.device(x.device):
-        rc = _lib.lib().gs_conv3x3(_lib.ptr(x), c, c, _lib.ptr(hit[0]), kc, _lib.ptr(y), O, O, n, h, wd,
-                                   _lib.stream_ptr(x.device))
+        if stacked:
+            rc = _lib.lib().gs_conv3x3_stacked(_lib.ptr(x), c, c, _lib.ptr(hit[0]), kc,
+                                               tw or conv3x3_stacked_tile_width(wd), _lib.ptr(y), O, O, n, h, wd,
+                                               _lib.stream_ptr(x.device))
+        else:
+            rc = _lib.lib().gs_conv3x3(_lib.ptr(x), c, c, _lib.ptr(hit[0]), kc, _lib.ptr(y), O, O, n, h, wd,
+                                       _lib.stream_ptr(x.device))
     _lib.check(rc, "conv3x3")
     return y
 

@@ -179,6 +179,12 @@ int gs_conv1x1(const void* x, int x_stride, int k_in, const void* wpack, const f
 size_t gs_conv3x3_wpack_elems(int c_in, int n_out);
 int gs_conv3x3(const void* x, int x_stride, int c_in, const void* wpack, int kc, void* y, int y_stride, int n_out,
                int n, int h, int w, gs_stream_t stream);
+/* Same convolution with row-stacked tiles: the n images are tiled as one image of n*h rows (tiles of 256/tw rows x
+ * tw columns run across image boundaries; the vertical taps are masked per pixel at y == 0 / y == h-1), so no tile
+ * padding is spent on h.  tw in {8, 16, 32}: pick the width that divides w best (40 -> 8, 80 -> 16).  Same wpack.
+ * Requires the images to be contiguous (image stride = h * w * x_stride resp. y_stride).                    */
+int gs_conv3x3_stacked(const void* x, int x_stride, int c_in, const void* wpack, int kc, int tw, void* y,
+                       int y_stride, int n_out, int n, int h, int w, gs_stream_t stream);
 /* 3x3 convolution (padding 1) from 128 channels to n_out in {1,2} channels, NHWC fp16 in, fp32 out
  * [n,h,w,n_out]: the flow-revision / confidence heads delta[2], weight[2] (src/droid_net.py:83-92) and
  * GraphAgg's eta[0] (src/droid_net.py:43).  x rows are x_stride elements apart (a channel slice of a

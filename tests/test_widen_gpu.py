@@ -257,6 +257,28 @@ def test_conv3x3_implicit_gemm_matches_reference(built_lib, n, h, w, c, xs, o, k
     torch.testing.assert_close(y[..., :o].float(), ref, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("n,h,w,c,xs,o,kc,tw", [(5, 30, 40, 128, 128, 128, 64, 8), (3, 60, 80, 320, 320, 256, 32, 16),
+                                                 (4, 7, 37, 64, 72, 128, 32, 32), (6, 5, 19, 64, 64, 256, 64, 8),
+                                                 (1, 40, 80, 128, 128, 384, 64, 16)])
+def test_conv3x3_row_stacked_tiles_match_reference(built_lib, n, h, w, c, xs, o, kc, tw):
+    """gs_conv3x3_stacked: tiles run across image boundaries, so the vertical taps must be masked per pixel (y == 0 /
+    y == h-1) -- images shorter than a tile (several images per tile), h not a multiple of the tile height, all three
+    tile widths, both chunk sizes; vs F.conv2d in fp32 on the same fp16 operands."""
+    from go_slam_amd import _lib
+    from go_slam_amd.droid_net import pack_conv3x3_weight
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(n * 100 + h)
+    x = torch.randn(n, h, w, xs, generator=g).half().to(dev)
+    wt = (torch.randn(o, c, 3, 3, generator=g) / (3.0 * c ** 0.5)).half().to(dev)
+    wp = pack_conv3x3_weight(wt, kc)
+    y = torch.full((n, h, w, o), 7.0, dtype=torch.float16, device=dev)
+    rc = _lib.lib().gs_conv3x3_stacked(_lib.ptr(x), xs, c, _lib.ptr(wp), kc, tw, _lib.ptr(y), o, o, n, h, w,
+                                       _lib.stream_ptr(dev))
+    _lib.check(rc, "conv3x3_stacked")
+    ref = torch.nn.functional.conv2d(x[..., :c].permute(0, 3, 1, 2).float(), wt.float(), padding=1).permute(0, 2, 3, 1)
+    torch.testing.assert_close(y.float(), ref, rtol=2e-3, atol=2e-3)
+
+
 def test_update_operator_with_own_conv3x3_matches_miopen_path(built_lib):
     """UpdateModule's inference fast path with CONV3X3_IMPL = "hip" (all large 3x3 convolutions on gs_conv3x3) vs the
     same path on MIOpen: same outputs within fp16 accumulation-order noise."""
