@@ -1,5 +1,9 @@
-"""Micro-benchmark: the package's implicit-GEMM 3x3 convolution (gs_conv3x3) vs MIOpen on the update operator's layer
-shapes at the bench workload (75 edges, 60x80 maps).  Prints one JSON object."""
+"""Micro-benchmark: the package's implicit-GEMM 3x3 convolution (gs_conv3x3 plain tiling, gs_conv3x3_stacked row-stacked
+tiling; both chunk sizes) vs MIOpen on the update operator's layer shapes.  Prints one JSON object per map shape.
+
+    python tools/conv3x3_bench.py                 # bench workload: 75 edges, 60x80
+    python tools/conv3x3_bench.py all             # + Replica (40x80) and ScanNet (30x40, 13-keyframe update_lowmem chunk)
+"""
 import json
 import os
 import sys
@@ -11,6 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from go_slam_amd import droid_net as DN  # noqa: E402
 
 LAYERS = (("gru_zr", 320, 256), ("gru_q", 320, 128), ("heads", 128, 384), ("corr_enc2", 128, 128))
+SHAPES = {"S480": (75, 60, 80), "Rep": (75, 40, 80), "Scan": (78, 30, 40)}
 
 
 def time_op(fn, iters=10, warm=3):
@@ -26,10 +31,10 @@ def time_op(fn, iters=10, warm=3):
     return s.elapsed_time(e) / iters
 
 
-def main(E=75, h=60, w=80):
+def run(tag, E, h, w):
     dev = "cuda:0"
-    torch.backends.cudnn.benchmark = True
-    out = {"edges": E, "map": [h, w]}
+    out = {"shape": tag, "edges": E, "map": [h, w], "tile_efficiency_plain": round(DN.conv3x3_tile_efficiency(h, w), 4),
+           "stacked_tile_width": DN.conv3x3_stacked_tile_width(w)}
     for name, c, o in LAYERS:
         x = torch.randn(E, c, h, w, device=dev).half().contiguous(memory_format=torch.channels_last)
         wt = (torch.randn(o, c, 3, 3, device=dev) / (3 * c ** 0.5)).half().contiguous(memory_format=torch.channels_last)
@@ -37,14 +42,18 @@ def main(E=75, h=60, w=80):
         ms_m = time_op(lambda: F.conv2d(x, wt, None, padding=1))
         row = {"miopen_ms": round(ms_m, 4), "miopen_tflops": round(flops / ms_m / 1e9, 1)}
         ref = F.conv2d(x, wt, None, padding=1).float()
-        for kc in (32, 64):
-            ms_h = time_op(lambda: DN.conv3x3_hip(x, wt, kc))
-            row[f"hip_kc{kc}_ms"] = round(ms_h, 4)
-            row[f"hip_kc{kc}_tflops"] = round(flops / ms_h / 1e9, 1)
-            row[f"hip_kc{kc}_max_abs_diff"] = float((DN.conv3x3_hip(x, wt, kc).float() - ref).abs().max())
+        for stacked in (False, True):
+            for kc in (32, 64):
+                key = f"{'stacked' if stacked else 'plain'}_kc{kc}"
+                ms_h = time_op(lambda: DN.conv3x3_hip(x, wt, kc, stacked=stacked))
+                row[key + "_ms"] = round(ms_h, 4)
+                row[key + "_tflops"] = round(flops / ms_h / 1e9, 1)
+                row[key + "_max_abs_diff"] = float((DN.conv3x3_hip(x, wt, kc, stacked=stacked).float() - ref).abs().max())
         out[name] = row
     print(json.dumps(out))
 
 
 if __name__ == "__main__":
-    main()
+    torch.backends.cudnn.benchmark = True
+    for tag in (SHAPES if len(sys.argv) > 1 and sys.argv[1] == "all" else ("S480",)):
+        run(tag, *SHAPES[tag])
