@@ -225,3 +225,27 @@ def test_mapper_schedule_and_ray_batches_match_reference():
         Mapper(cfg, types.SimpleNamespace(device="cpu"), types.SimpleNamespace(
             bound=None, video=video, mapping_net=mapper.mapping_net, renderer=None, reload_map=torch.zeros(1).int(),
             H=32, W=48, fx=1, fy=1, cx=1, cy=1))
+
+
+def test_ate_rmse_recovers_known_similarity():
+    """ATE with Sim(3) alignment (src/slam.py:343-360 via evo; here Umeyama's closed form): a trajectory that differs
+    from the reference by a similarity transform has zero error and the transform is recovered; noise gives the
+    noise level; without scale correction a scaled trajectory keeps an error."""
+    from go_slam_amd.eval_ate import ate_rmse, umeyama_alignment
+    from go_slam_amd.lietorch_shim import SE3
+    g = torch.Generator().manual_seed(2)
+    ref = torch.cumsum(torch.randn(200, 3, generator=g, dtype=torch.float64) * 0.1, 0).numpy()
+    Rm = SE3.exp(torch.tensor([[0.0, 0, 0, 0.4, -0.7, 0.2]], dtype=torch.float64)).matrix()[0, :3, :3].numpy()
+    t, c = np.array([0.5, -1.0, 2.0]), 1.7
+    est = ((ref - t) @ Rm) / c                                  # ref = c R est + t
+    rmse, info = ate_rmse(est, ref)
+    assert rmse < 1e-9 and abs(info["scale"] - c) < 1e-9
+    assert np.allclose(info["rotation"], Rm, atol=1e-9) and np.allclose(info["translation"], t, atol=1e-9)
+    R2, t2, c2 = umeyama_alignment(est.T, ref.T, with_scale=False)
+    assert c2 == 1.0 and abs(np.linalg.det(R2) - 1.0) < 1e-9
+    assert ate_rmse(est, ref, correct_scale=False)[0] > 0.05
+    noisy = est + 0.01 * np.random.default_rng(0).standard_normal(est.shape)
+    r = ate_rmse(noisy, ref)[0]
+    assert 0.5 * 0.01 * c * 3 ** 0.5 < r < 1.5 * 0.01 * c * 3 ** 0.5
+    mirrored = ref * np.array([1.0, 1.0, -1.0])                 # a reflection must not be "aligned away"
+    assert ate_rmse(mirrored, ref)[0] > 0.05
