@@ -216,8 +216,14 @@ def gen_neus():
     z, dist = NO.render_sample(o, d, gt, P["bound"], 24, 48, torch.rand(24, generator=g))
     out = net(o, d, z, dist)
     sdf_err, sdf_front = net.compute_sdf_error(out["sdf"], out["z_vals"], gt)
+    sd = net.state_dict()
+    names = {id(p): k for k, p in net.named_parameters()}
+    train_names = [names[id(p)] for p in net.get_training_parameters()]
+    volume_names = [names[id(p)] for p in net.get_volume_parameters()]
     save("neus_forward.npz", seed=109, rt_bound=rt, rays_o=o, rays_d=d, gt_depth=gt, z_in=z, dists_in=dist,
-         sdf_error=sdf_err, sdf_front_error=sdf_front, **{k: v for k, v in out.items()})
+         sdf_error=sdf_err, sdf_front_error=sdf_front, **{k: v for k, v in out.items()},
+         state_keys=np.array(list(sd.keys())), state_shapes=np.array([str(tuple(v.shape)) for v in sd.values()]),
+         train_param_names=np.array(train_names), volume_param_names=np.array(volume_names))
 
 
 def gen_rays():

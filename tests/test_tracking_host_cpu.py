@@ -249,3 +249,33 @@ def test_ate_rmse_recovers_known_similarity():
     assert 0.5 * 0.01 * c * 3 ** 0.5 < r < 1.5 * 0.01 * c * 3 ** 0.5
     mirrored = ref * np.array([1.0, 1.0, -1.0])                 # a reflection must not be "aligned away"
     assert ate_rmse(mirrored, ref)[0] > 0.05
+
+
+def test_instant_neus_checkpoint_contract():
+    """InstantNeuS keeps the reference module's state-dict keys, order and shapes (so `go.ckpt` / `mapping_net`
+    checkpoints interchange, src/slam.py:296-301), the same split into network / volume parameter groups
+    (src/mapping.py:52-58), and survives what src/slam.py / src/mesher.py do to it: share_memory(), copy.deepcopy,
+    state_dict round trip (SURVEY 8b boundary 2)."""
+    import copy
+    from go_slam_amd.neus import InstantNeuS
+    gold = np.load(os.path.join(HERE, "golden", "neus_forward.npz"))
+    cfg = {"sdf_network": {"d_in": 3, "d_out": 32}, "color_network": {"d_in": 3, "d_feat": 31, "d_hidden": 64, "n_layers": 2},
+           "variance_network": {"init_val": 0.2, "scale_factor": 10.0}, "sdf_smooth_std": 0.005,
+           "sdf_sparse_factor": 5, "sdf_truncation": 0.16, "sdf_random_weight": 0.04}
+    net = InstantNeuS(cfg, [[-2.5, 2.5]] * 3, device="cpu")
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in gold["state_keys"]]
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in gold["state_shapes"]]
+    names = {id(p): k for k, p in net.named_parameters()}
+    assert [names[id(p)] for p in net.get_training_parameters()] == [str(k) for k in gold["train_param_names"]]
+    assert [names[id(p)] for p in net.get_volume_parameters()] == [str(k) for k in gold["volume_param_names"]]
+    net.share_memory()
+    twin = copy.deepcopy(net)
+    with torch.no_grad():
+        twin.sdf_network.sdf_layer.weight.add_(1.0)
+        twin.update_bound(torch.tensor([[-1.0, 1.0]] * 3))
+    assert not torch.equal(twin.sdf_network.sdf_layer.weight, net.sdf_network.sdf_layer.weight)
+    net.load_state_dict(twin.state_dict())
+    assert torch.equal(net.sdf_network.sdf_layer.weight, twin.sdf_network.sdf_layer.weight)
+    assert torch.equal(net.realtime_bound, torch.tensor([[-1.0, 1.0]] * 3))
+    assert (net.sdf_truncation, net.sdf_sparse_factor) == (0.16, 5)
