@@ -16,7 +16,7 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def _load(name):
     d = np.load(os.path.join(G, name))
-    return {k: torch.from_numpy(d[k]) for k in d.files}
+    return {k: torch.from_numpy(d[k]) for k in d.files if d[k].dtype.kind not in "USO"}     # string arrays: metadata
 
 
 # ------------------------------------------------------------------ tracking path ---------
