@@ -198,68 +198,3 @@ def test_proximity_proposal_corner_cases():
     es = FactorGraph.propose_proximity_edges(d2, [(3, 1)], 2, 0, 6, 1, 1, 16.0, 100, False)
     assert es[8:10] == [(5, 0), (0, 5)]
     assert all(e != (3, 1) and e != (2, 0) for e in es[8:])         # existing edge and its NMS neighbourhood
-
-
-def test_conv3x3_weight_image_layout():
-    """pack_conv3x3_weight produces the LDS images gs_conv3x3 documents (include/goslam_hip.h): contracting them
-    with the zero-padded input exactly the way the kernel indexes them reproduces F.conv2d."""
-    import torch.nn.functional as F
-    from go_slam_amd.droid_net import pack_conv3x3_weight
-    g = torch.Generator().manual_seed(9)
-    O, C, H, W = 256, 64, 5, 7
-    w = (torch.randn(O, C, 3, 3, generator=g) * 0.1).half()
-    x = torch.randn(1, C, H, W, generator=g).half()
-    xp = F.pad(x.float(), (1, 1, 1, 1))[0].permute(1, 2, 0)                     # [H+2, W+2, C]
-    ref = F.conv2d(x.float(), w.float(), padding=1)[0]
-    for kc in (32, 64):
-        wp = pack_conv3x3_weight(w, kc).float().view(O // 128, C // kc, 9, kc // 8, 128, 8)
-        out = torch.zeros(O, H, W)
-        for ck in range(C // kc):
-            for tap in range(9):
-                ky, kx = tap // 3, tap % 3
-                win = xp[ky:ky + H, kx:kx + W, kc * ck:kc * ck + kc].reshape(H, W, kc // 8, 8)   # [.., kg, e]
-                out += torch.einsum("nkre,hwke->nrhw", wp[:, ck, tap], win).reshape(O, H, W)
-        assert torch.allclose(out, ref, rtol=1e-4, atol=1e-4), kc
-
-
-def _conv_emulator():
-    import importlib.util
-    import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "emulate_conv3x3.py")
-    spec = importlib.util.spec_from_file_location("emulate_conv3x3", path)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    return mod
-
-
-def test_conv3x3_kernel_index_arithmetic_by_lane_level_emulation():
-    """tools/emulate_conv3x3.py replays conv3x3.hip's per-thread index arithmetic (patch staging, weight images,
-    MFMA operand / accumulator layout, row-stacked masking, LDS-transposed epilogue) in NumPy: plain and row-stacked
-    tilings, all tile widths, both chunk sizes, with and without the lane permutation, on shapes with partial tiles,
-    channel slices and several images per tile -- each must equal F.conv2d and write every output exactly once."""
-    emu = _conv_emulator()
-    cases = [  # n  H  W   C   O   xs  KC  TW  LP     stacked
-        (1, 5, 9, 32, 128, 40, 32, 16, False, False), (1, 5, 9, 32, 128, 32, 32, 16, True, False),
-        (1, 3, 17, 64, 128, 64, 64, 16, True, False), (2, 5, 9, 32, 128, 32, 32, 16, False, True),
-        (2, 5, 9, 32, 128, 32, 32, 16, True, True), (3, 7, 5, 32, 128, 40, 32, 8, False, True),
-        (3, 7, 5, 32, 128, 32, 32, 8, True, True), (2, 3, 33, 32, 128, 32, 32, 32, False, True),
-        (2, 9, 10, 64, 128, 64, 64, 8, True, True)]
-    for case in cases:
-        diff, unwritten = emu.check(*case)
-        assert unwritten == 0 and diff < 5e-5, (case, diff, unwritten)
-
-
-def test_conv3x3_lane_permutation_removes_the_bank_conflicts():
-    """ds_read_b128 service groups (MI355X_MICROARCH.md, LDS): the plain column -> pixel mapping is 2-way (16-wide
-    tiles) / 3-way (8-wide) conflicted on the pixel-fragment reads, the permuted one conflict-free; 32-wide tiles need
-    no permutation; the permutation is a bijection onto the tile."""
-    from collections import Counter
-    emu = _conv_emulator()
-    bm = emu.bank_model()
-    assert bm[(16, False)] == 2 and bm[(8, False)] == 3 and bm[(32, False)] == 1
-    assert bm[(16, True)] == bm[(8, True)] == bm[(32, True)] == 1
-    for tw in (8, 16, 32):
-        for lp in (False, True):
-            seen = Counter(emu.tile_pixel(tw, lp, wm, i, r) for wm in range(2) for i in range(4) for r in range(32))
-            assert len(seen) == 256 and set(seen.values()) == {1}
-            assert {t for t, _ in seen} == set(range(256 // tw)) and {x for _, x in seen} == set(range(tw))
