@@ -28,6 +28,7 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
   * multiview_filter.py  MultiviewFilter.forward host logic (masks, bound, priority) -> multiview_filter.npz
   * trajectory_filler.py PoseTrajectoryFiller: bracketing, interpolation, parked items, edges -> trajectory_filler.npz
   * mapping.py + depth_video.get_mapping_item  Mapper keyframe schedule and ray batches -> mapper.npz
+  * factor_graph.py      update_lowmem chunking and call arguments (mocked kernels) -> update_lowmem.npz
   * InstantNeuS.py       normalisation, masking, sdf gradient by autograd.grad, get_alpha,
                          compositing, compute_sdf_error                       -> neus_forward.npz
 The stand-ins themselves (tcnn / lietorch / CUDA kernels) stay "parity unpinned" (DESIGN.md 4).
@@ -926,6 +927,106 @@ def gen_mapper():
     save("mapper.npz", **arrays)
 
 
+class FakeAltCorr:
+    """stands in for AltCorrBlock under update_lowmem (both sides): a deterministic function of its arguments"""
+    log = None
+
+    def __init__(self, fmaps, num_levels=4, radius=3):
+        FakeAltCorr.log.append(("altcorr_init", tuple(fmaps.shape)))
+
+    def __call__(self, coords, ii, jj):
+        FakeAltCorr.log.append(("altcorr", ii.tolist(), jj.tolist(), digest(coords)))
+        b, n, h, w, _ = coords.shape
+        base = (ii.float() * 0.01 + jj.float() * 0.001).view(1, n, 1, 1, 1)
+        return (base + 0.01 * coords.mean(dim=-1, keepdim=True).permute(0, 1, 4, 2, 3)).expand(b, n, 196, h, w).contiguous()
+
+
+def run_lowmem(graph_cls, scale, value_counter=True):
+    """Drives FactorGraph.update_lowmem (the reference's or ours) on a 30-keyframe graph with mocked kernels: a
+    deterministic reprojection, FakeAltCorr, a scripted update operator, recording BA / upsample calls.  `scale` = 8 for
+    the reference (its graph divides video.ht by 8), 1 for ours.  Returns (log, graph, video)."""
+    import contextlib
+    log = []
+    FakeAltCorr.log = log
+    T, h, w = 30, 4, 6
+    g = torch.Generator().manual_seed(199)
+
+    def reproject(ii, jj):
+        ii, jj = torch.as_tensor(ii), torch.as_tensor(jj)
+        yy, xx = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+        base = torch.stack([xx, yy], -1)[None, None]
+        shift = (0.1 * (jj - ii).float() + 0.003 * video.poses[jj, 0] - 0.002 * video.poses[ii, 0]).view(1, -1, 1, 1, 1)
+        return base + shift, torch.ones(1, len(ii), h, w, 1)
+
+    def ba(target, weight, damping, ii, jj, t0=1, t1=None, iters=2, lm=1e-4, ep=0.1, motion_only=False, ba_type=None):
+        log.append(("ba", digest(target), digest(weight), digest(damping), ii.tolist(), jj.tolist(), t0, t1, iters, lm, ep,
+                    bool(motion_only), ba_type, tuple(target.shape), tuple(damping.shape)))
+        video.poses[t0:t1, 0] += 0.05 * float(weight.mean())          # the next step's reprojection must see the update
+
+    def upsample(ix, mask):
+        log.append(("upsample", ix.tolist(), digest(mask)))
+
+    def update_op(net, inp, corr, flow=None, ii=None, jj=None, **kw):
+        log.append(("update_op", ii.tolist(), jj.tolist(), digest(net), digest(inp), digest(corr), digest(flow)))
+        n = net.shape[1]
+        uniq = torch.unique(ii)
+        delta = 0.1 * flow[:, :, :2].permute(0, 1, 3, 4, 2) + 0.01
+        weight = torch.sigmoid(corr[:, :, :2].permute(0, 1, 3, 4, 2))
+        eta = 0.01 * uniq.float().view(1, -1, 1, 1).expand(1, len(uniq), h, w) + 0.001 * float(net.mean())
+        upmask = torch.ones(1, len(uniq), 576, h, w) * uniq.float().view(1, -1, 1, 1, 1)
+        return net * 0.9 + 0.01 * inp.float(), delta, weight, eta, upmask
+    video = types.SimpleNamespace(
+        ht=h * scale, wd=w * scale, stereo=False, counter=types.SimpleNamespace(value=T) if value_counter else T,
+        disps=torch.ones(T + 4, h, w), poses=torch.zeros(T + 4, 7), dirty=torch.zeros(T + 4, dtype=torch.bool),
+        fmaps=torch.rand(T + 4, 1, 8, h, w, generator=g), nets=torch.rand(T + 4, 8, h, w, generator=g),
+        inps=torch.rand(T + 4, 8, h, w, generator=g), reproject=reproject, ba=ba, upsample=upsample,
+        get_lock=contextlib.nullcontext)
+    video.poses[:, 6] = 1.0
+    graph = graph_cls(video, update_op, device="cpu", corr_impl="alt", max_factors=-1, upsample=True)
+    # edges: bands |i - j| <= 2 around keyframes 2..11 and 28..29 (three 13-keyframe chunks, the middle one without
+    # sources) + three long-range edges
+    ii, jj = [], []
+    for i in list(range(2, 12)) + list(range(28, 30)):
+        for j in range(max(0, i - 2), min(T, i + 3)):
+            if i != j:
+                ii.append(i); jj.append(j)
+    ii += [28, 3, 29]; jj += [3, 28, 5]
+    graph.add_factors(torch.tensor(ii), torch.tensor(jj))
+    log.append(("edges", graph.ii.tolist(), graph.jj.tolist()))
+    graph.update_lowmem(t0=3, t1=T, iters=2, steps=2, max_t=T - 1, ba_type="dense", motion_only=False)
+    graph.update_lowmem(steps=1, ba_type="loop", motion_only=True)
+    return log, graph, video
+
+
+def flatten_log(log):
+    struct, nums = [], []
+    for r in log:
+        struct.append(tuple(x for x in r if not torch.is_tensor(x)))
+        nums += [x for x in r if torch.is_tensor(x)]
+    return repr(struct), nums
+
+
+def gen_lowmem():
+    """The reference's FactorGraph.update_lowmem (src/factor_graph.py:253-321) on CPU with mocked kernels: chunking by
+    13 source keyframes, the arguments of every alt-corr / update-operator / upsample / BA call, and the state left."""
+    mods = sys.modules["refsrc.modules"]
+    corr = importlib.import_module("refsrc.modules.corr")
+    mods.CorrBlock, mods.AltCorrBlock = corr.CorrBlock, corr.AltCorrBlock
+    fg = importlib.import_module("refsrc.factor_graph")
+    keep = fg.AltCorrBlock
+    fg.AltCorrBlock = FakeAltCorr
+    try:
+        log, graph, video = run_lowmem(fg.FactorGraph, 8)
+    finally:
+        fg.AltCorrBlock = keep
+    struct, nums = flatten_log(log)
+    arrays = {"struct": np.array(struct), "n": np.array(len(nums)), "net": graph.net, "target": graph.target,
+              "weight": graph.weight, "damping": graph.damping, "dirty": video.dirty, "poses": video.poses}
+    for k, x in enumerate(nums):
+        arrays[f"d{k}"] = x
+    save("update_lowmem.npz", **arrays)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate the fixtures"
     install_stubs()
@@ -940,6 +1041,7 @@ if __name__ == "__main__":
         gen_multiview_filter()
         gen_filler()
         gen_mapper()
+        gen_lowmem()
         gen_corr()
         gen_proj()
         gen_render()

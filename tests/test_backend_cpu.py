@@ -98,3 +98,27 @@ def test_frontend_call_sequence_matches_reference_golden(monkeypatch):
             assert video.ready.value == int(gold[f"{tag}_ready"]) == 1
     assert "loop_ba" in str(gold["loop_trace"]) and "loop_ba" not in str(gold["noloop_trace"])
     assert "rmkf" in str(gold["loop_trace"])
+
+
+def test_update_lowmem_matches_reference_golden(monkeypatch):
+    """FactorGraph.update_lowmem vs the reference's (src/factor_graph.py:253-321; fixture update_lowmem.npz), kernels
+    mocked on both sides: chunks of 13 source keyframes (incl. a chunk without sources), rig / stereo index arithmetic
+    of the alt-corr call, per-chunk update-operator inputs, upsampling of the chunk's source keyframes, damping rows,
+    BA operands and its lm / ep per ba_type, default t0 / t1, dirty flags, and the graph state left behind."""
+    import go_slam_amd.factor_graph as FG
+    gen = _gen()
+    gold = np.load(os.path.join(HERE, "golden", "update_lowmem.npz"))
+    monkeypatch.setattr(FG, "AltCorrBlock", gen.FakeAltCorr)
+    for value_counter in (True, False):
+        with torch.no_grad():
+            log, graph, video = gen.run_lowmem(
+                lambda *a, **k: FG.FactorGraph(*a, channels_last=False, **k), 1, value_counter)
+        struct, nums = gen.flatten_log(log)
+        assert struct == str(gold["struct"])
+        assert len(nums) == int(gold["n"])
+        for k, x in enumerate(nums):
+            assert np.allclose(x.numpy(), gold[f"d{k}"], rtol=1e-5, atol=1e-6), k
+        for name, mine in (("net", graph.net), ("target", graph.target), ("weight", graph.weight),
+                           ("damping", graph.damping), ("poses", video.poses)):
+            assert np.allclose(mine.float().numpy(), gold[name], rtol=1e-5, atol=1e-6), name
+        assert np.array_equal(video.dirty.numpy(), gold["dirty"])
