@@ -355,6 +355,50 @@ class FactorGraph:
             self.video.upsample(seg["uniq"], upmask[0])
         self.age += 1
 
+    def _select_edges(self, x5, sel):
+        """x5[:, sel] for a [1,E,C,h,w] state tensor, keeping the graph's memory format (index_select on the NHWC view:
+        rows of h*w*C contiguous halves, no layout conversion afterwards)."""
+        x4 = x5[0]
+        if self.channels_last and x4.is_contiguous(memory_format=torch.channels_last):
+            return x4.permute(0, 2, 3, 1).index_select(0, sel).permute(0, 3, 1, 2).unsqueeze(0)
+        return x4.index_select(0, sel).unsqueeze(0)
+
+    def _lowmem_index(self, t0, t1, rig):
+        """What update_lowmem derives from the edge lists alone, computed once per topology on a host copy and cached
+        (the reference recomputes it per step and per chunk with boolean masks, `.sum()` / `.min()` / `.max()` reads
+        and torch.unique -- two to four host syncs per 13-keyframe chunk, src/factor_graph.py:266-299): the BA window,
+        the damping rows, and per chunk the edge selection, the alt-corr pyramid indices (`rig`-strided, right view for
+        stereo pairs), the source keyframes to upsample and the GraphAgg segments."""
+        from .droid_net import build_segments
+        tens = (self.ii, self.jj)
+        key = tuple(x._version for x in tens) + (t0, t1, rig)
+        c = getattr(self, "_lidx", None)
+        if c is not None and c["key"] == key and all(a is b for a, b in zip(c["tens"], tens)):
+            return c
+        dev = self.device
+        ii_c, jj_c = self.ii.cpu(), self.jj.cpu()
+        a0 = max(1, int(ii_c.min()) + 1) if t0 is None else t0
+        a0 = max(1, a0)
+        a1 = (max(int(ii_c.max()), int(jj_c.max())) + 1) if t1 is None else t1
+        chunks = []
+        s = 13
+        for i in range(int(ii_c.min()), int(ii_c.max()) + 1, s):
+            sel = torch.nonzero((ii_c >= i) & (ii_c < i + s)).reshape(-1)
+            if sel.numel() < 1:
+                continue
+            iis, jjs = ii_c[sel], jj_c[sel]
+            ck = {"sel": sel.to(dev), "ii": iis.to(dev), "jj": jjs.to(dev), "corr_ii": (rig * iis).to(dev),
+                  "corr_jj": (rig * jjs + (iis == jjs).long()).to(dev), "uniq": torch.unique(iis, sorted=True).to(dev)}
+            seg = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in build_segments(iis).items()}
+            ck["seg_kw"] = {"seg": seg} if getattr(self.update_op, "_forward_fast", None) is not None else {}
+            ck["inp"] = (lambda ix=ck["ii"]: self._fmt(self.video.inps[ix]).unsqueeze(0))
+            chunks.append(ck)
+        c = {"key": key, "tens": tens, "t0": a0, "t1": a1, "chunks": chunks, "ii": self.ii.contiguous(),
+             "jj": self.jj.contiguous(),
+             "damping_index": torch.unique(torch.cat([torch.arange(a0, a1), ii_c]), sorted=True).to(dev)}
+        self._lidx = c
+        return c
+
     @torch.no_grad()
     def update_lowmem(self, t0=None, t1=None, iters=2, use_inactive=False, EPS=1e-7, steps=8, max_t=None,
                       ba_type="dense", motion_only=False):
@@ -366,37 +410,31 @@ class FactorGraph:
         fm = self.video.fmaps[:cur_t + 2]
         num, rig, ch, ht, wd = fm.shape
         corr_op = AltCorrBlock(fm.reshape(1, num * rig, ch, ht, wd))
-        if t0 is None:
-            t0 = max(1, int(self.ii.min()) + 1)
-        t0 = max(1, t0)
-        if t1 is None:
-            t1 = max(int(self.ii.max()), int(self.jj.max())) + 1
+        idx = self._lowmem_index(t0, t1, rig)
+        t0, t1 = idx["t0"], idx["t1"]
+        ii_all, jj_all = idx["ii"], idx["jj"]
         for _ in range(steps):
-            coords1, mask = self.video.reproject(self.ii, self.jj)
+            coords1, mask = self.video.reproject(ii_all, jj_all)
             motion = torch.cat([coords1 - self.coords0, self.target - coords1], dim=-1)
             motion = motion.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
-            s = 13
-            lo, hi = int(self.ii.min()), int(self.ii.max())
-            for i in range(lo, hi + 1, s):
-                v = (self.ii >= i) & (self.ii < i + s)
-                if int(v.sum()) < 1:
-                    continue
-                iis, jjs = self.ii[v], self.jj[v]
-                corr1 = corr_op(coords1[:, v], rig * iis, rig * jjs + (iis == jjs).long())
+            for ck in idx["chunks"]:                    # 13 source keyframes at a time
+                sel, iis, jjs = ck["sel"], ck["ii"], ck["jj"]
+                c1 = coords1.index_select(1, sel)
+                corr1 = corr_op(c1, ck["corr_ii"], ck["corr_jj"])
                 with torch.autocast("cuda", dtype=torch.float16):
                     net, delta, weight, damping, upmask = self.update_op(
-                        self.net[:, v], self._fmt(self.video.inps[iis]).unsqueeze(0), corr1, motion[:, v], iis, jjs)
+                        self._select_edges(self.net, sel), ck["inp"](), corr1, motion.index_select(1, sel), iis, jjs,
+                        **ck["seg_kw"])
                     if self.upsample:
-                        self.video.upsample(torch.unique(iis, sorted=True), upmask[0])
-                self.net[:, v] = net.to(self.net.dtype)
-                self.target[:, v] = coords1[:, v] + delta.float()
-                self.weight[:, v] = weight.float()
-                self.damping[torch.unique(iis, sorted=True)] = damping.float()
-            damping_index = torch.unique(torch.cat([torch.arange(t0, t1, device=self.ii.device), self.ii]), sorted=True)
-            damping = 0.2 * self.damping[damping_index].contiguous() + EPS
+                        self.video.upsample(ck["uniq"], upmask[0])
+                self.net[:, sel] = net.to(self.net.dtype)
+                self.target[:, sel] = c1 + delta.float()
+                self.weight[:, sel] = weight.float()
+                self.damping[ck["uniq"]] = damping.float()
+            damping = 0.2 * self.damping[idx["damping_index"]].contiguous() + EPS
             target = self.target.view(-1, self.ht, self.wd, 2).permute(0, 3, 1, 2).contiguous()
             weight = self.weight.view(-1, self.ht, self.wd, 2).permute(0, 3, 1, 2).contiguous()
             lm, ep = (1e-4, 1e-1) if ba_type == "loop" else (1e-5, 1e-2)
-            self.video.ba(target, weight, damping, self.ii.contiguous(), self.jj.contiguous(), t0=t0, t1=t1,
+            self.video.ba(target, weight, damping, ii_all, jj_all, t0=t0, t1=t1,
                           iters=iters, lm=lm, ep=ep, motion_only=motion_only, ba_type=ba_type)
             self.video.dirty[:t] = True
