@@ -361,7 +361,10 @@ def main():
         line["breakdown_ms"] = {k: round(v, 4) for k, v in br.items() if k.endswith("_ms")}
         line["ba_gn_iters_per_s"] = 2.0 / (br["ba_2iter_ms"] * 1e-3)
         if world == 1:      # single-GPU measurement (tracking does not shard); keeps the N > 1 runs short
-            line["global_ba_stress"] = global_ba_stress(device)
+            try:
+                line["global_ba_stress"] = global_ba_stress(device)
+            except Exception as exc:                   # an auxiliary leg must not cost the bench line
+                line["global_ba_stress"] = {"error": repr(exc)}
         ht, wd = graph.ht, graph.wd
         algo_bytes = 912.0 * ht * wd * br["edges"]            # 912*HW B per edge per lookup
         t_s = br["corr_lookup_ms"] * 1e-3
