@@ -66,11 +66,32 @@ __device__ __forceinline__ void tile_pixel(int wm, int i, int r, int& ty, int& t
   }
 }
 
+// Workgroup id -> (tile, output-channel block).  Workgroups are handed to the 8 XCDs round-robin by linear id, and each
+// XCD has its own L2; the default 2-D grid puts the channel blocks of one tile gridDim.x ids apart, i.e. on unrelated
+// XCDs, so every block re-fetches the tile's input patch into another L2.  With `xcd` the 1-D id is decoded so that
+// ids L, L + 8, L + 16 ... (same XCD, adjacent in time) are the NB channel blocks of the same tile: groups of 8 * NB ids
+// cover 8 consecutive tiles; id l of a group -> tile (l % 8), block (l / 8); a last partial group of m < 8 tiles
+// uses m instead of 8.  (Only reachable in the LP instantiations, which take a 1-D grid.)
+__device__ __forceinline__ void decode_block(int L, int ntiles, int NB, int xcd, int& tile, int& nb) {
+  if (!xcd) {
+    tile = L % ntiles;
+    nb = L / ntiles;
+    return;
+  }
+  const int G = 8 * NB;
+  const int s = L / G, l = L - s * G;
+  const int left = ntiles - s * 8;
+  const int m = left < 8 ? left : 8;
+  tile = s * 8 + l % m;
+  nb = l / m;
+}
+
 // KC = input channels per chunk (32: 37 KB of LDS, a barrier every 16 MFMAs per wave; 64: 74 KB, every 32 MFMAs)
 template <int KC, bool LP>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restrict__ x, int xs, int C,
                                                          const half8* __restrict__ wpack, _Float16* __restrict__ y,
-                                                         int ys, int H, int W, int tiles_x, int tiles_y) {
+                                                         int ys, int H, int W, int tiles_x, int tiles_y, int NB,
+                                                         int xcd) {
   constexpr int KG = KC / 8;                             // 8-channel groups per chunk
   constexpr int WTAP = KG * BN;                          // 16-byte vectors of one tap's weight image
   constexpr int WPT = WTAP / 256;                        // ... per thread
@@ -81,12 +102,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restr
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv & 1, wn = wv >> 1;                    // pixel half (tile rows 8 wm ..), channel half (64 wn ..)
   const int r = lane & 31, kgl = lane >> 5;
-  int t = blockIdx.x;
+  int t = blockIdx.x, nb_ = blockIdx.y;
+  if constexpr (LP) decode_block(blockIdx.x, gridDim.x / NB, NB, xcd, t, nb_);   // LP: 1-D grid of tiles * NB ids
   const int tx0 = (t % tiles_x) * TW;
   t /= tiles_x;
   const int ty0 = (t % tiles_y) * TH;
   const int img = t / tiles_y;
-  const int nb = blockIdx.y;
+  const int nb = nb_;
   const int nchunk = C / KC;
   const _Float16* ximg = x + (size_t)img * H * W * xs;
   const half8* wsrc = wpack + (size_t)nb * nchunk * 9 * WTAP;
@@ -222,7 +244,7 @@ template <int KC, int TW, bool LP>
 __global__ __launch_bounds__(256, 2) void conv3x3_stacked_kernel(const _Float16* __restrict__ x, int xs, int C,
                                                                  const half8* __restrict__ wpack,
                                                                  _Float16* __restrict__ y, int ys, int H, int W,
-                                                                 int rows, int tiles_x) {
+                                                                 int rows, int tiles_x, int NB, int xcd) {
   constexpr int TH_ = 256 / TW, PW_ = TW + 2, NP_ = (TH_ + 2) * PW_;
   constexpr int NPP = LP ? NP_ + 1 : NP_;
   constexpr int KG = KC / 8, WTAP = KG * BN, WPT = WTAP / 256;
@@ -232,9 +254,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stacked_kernel(const _Float16*
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv & 1, wn = wv >> 1;
   const int r = lane & 31, kgl = lane >> 5;
-  const int tx0 = (blockIdx.x % tiles_x) * TW;
-  const int g0 = (blockIdx.x / tiles_x) * TH_;            // first stacked row (img * H + y) of the tile
-  const int nb = blockIdx.y;
+  int tx0, g0, nb;                                        // g0: first stacked row (img * H + y) of the tile
+  if constexpr (LP) {
+    int tix;
+    decode_block(blockIdx.x, gridDim.x / NB, NB, xcd, tix, nb);
+    tx0 = (tix % tiles_x) * TW;
+    g0 = (tix / tiles_x) * TH_;
+  } else {
+    tx0 = (blockIdx.x % tiles_x) * TW;
+    g0 = (blockIdx.x / tiles_x) * TH_;
+    nb = blockIdx.y;
+  }
   const int nchunk = C / KC;
   const half8* wsrc = wpack + (size_t)nb * nchunk * 9 * WTAP;
 
@@ -365,6 +395,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_stacked_kernel(const _Float16*
   }
 }
 
+// Opt-in tuning switches, read once.  The lane permutation (bank-conflict-free B reads; see frag_lane) and the
+// XCD-aware workgroup order (see decode_block; only with the lane permutation) are parity-checked by emulation but had
+// not run on hardware at the end of round 1, so both are OFF unless GOSLAM_CONV3X3_LANEPERM=1 / GOSLAM_CONV3X3_XCD=1.
+static bool env_flag(const char* name) {
+  const char* e = getenv(name);
+  return e && e[0] == '1';
+}
+static bool lane_perm_enabled() {
+  static const bool on = env_flag("GOSLAM_CONV3X3_LANEPERM");
+  return on;
+}
+static int xcd_remap_enabled() {
+  static const int on = env_flag("GOSLAM_CONV3X3_XCD") ? 1 : 0;
+  return on;
+}
+
 template <int KC, int TW, bool LP>
 int launch3x3s(const void* x, int x_stride, int c_in, const void* wpack, void* y, int y_stride, int n_out, int n, int h,
                int w, hipStream_t st) {
@@ -382,8 +428,11 @@ int launch3x3s(const void* x, int x_stride, int c_in, const void* wpack, void* y
   const long long rows = (long long)n * h;
   GS_REQUIRE(rows * w < (1ll << 31), "conv3x3_stacked: too many pixels");
   const int tiles_x = gs_cdiv(w, TW), tiles_y = gs_cdiv((int)rows, 256 / TW);
-  conv3x3_stacked_kernel<KC, TW, LP><<<dim3((unsigned)(tiles_x * tiles_y), n_out / BN), 256, lds, st>>>(
-      (const _Float16*)x, x_stride, c_in, (const half8*)wpack, (_Float16*)y, y_stride, h, w, (int)rows, tiles_x);
+  const int NB = n_out / BN;
+  const dim3 grid = LP ? dim3((unsigned)(tiles_x * tiles_y * NB)) : dim3((unsigned)(tiles_x * tiles_y), NB);
+  conv3x3_stacked_kernel<KC, TW, LP><<<grid, 256, lds, st>>>((const _Float16*)x, x_stride, c_in, (const half8*)wpack,
+                                                             (_Float16*)y, y_stride, h, w, (int)rows, tiles_x, NB,
+                                                             xcd_remap_enabled());
   GS_CHECK_LAUNCH("conv3x3_stacked");
   return GS_OK;
 }
@@ -404,23 +453,16 @@ int launch3x3(const void* x, int x_stride, int c_in, const void* wpack, void* y,
   const int tiles_x = gs_cdiv(w, TW), tiles_y = gs_cdiv(h, TH);
   const long long blocks = (long long)n * tiles_x * tiles_y;
   GS_REQUIRE(blocks < (1ll << 31), "conv3x3: too many tiles");
-  conv3x3_kernel<KC, LP><<<dim3((unsigned)blocks, n_out / BN), 256, lds, st>>>(
-      (const _Float16*)x, x_stride, c_in, (const half8*)wpack, (_Float16*)y, y_stride, h, w, tiles_x, tiles_y);
+  const int NB = n_out / BN;
+  GS_REQUIRE(blocks * NB < (1ll << 31), "conv3x3: too many workgroups");
+  const dim3 grid = LP ? dim3((unsigned)(blocks * NB)) : dim3((unsigned)blocks, NB);
+  conv3x3_kernel<KC, LP><<<grid, 256, lds, st>>>((const _Float16*)x, x_stride, c_in, (const half8*)wpack, (_Float16*)y,
+                                                 y_stride, h, w, tiles_x, tiles_y, NB, xcd_remap_enabled());
   GS_CHECK_LAUNCH("conv3x3");
   return GS_OK;
 }
 
 }  // namespace
-
-// Lane permutation of the pixel fragments (bank-conflict-free B reads; see frag_lane): parity-checked by emulation,
-// not yet run on hardware at the end of round 1, so it is OFF unless GOSLAM_CONV3X3_LANEPERM=1 is set.
-static bool lane_perm_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("GOSLAM_CONV3X3_LANEPERM");
-    return e && e[0] == '1';
-  }();
-  return on;
-}
 
 extern "C" size_t gs_conv3x3_wpack_elems(int c_in, int n_out) { return (size_t)9 * c_in * n_out; }
 

@@ -67,3 +67,23 @@ def test_conv3x3_lane_permutation_removes_the_bank_conflicts():
             seen = Counter(emu.tile_pixel(tw, lp, wm, i, r) for wm in range(2) for i in range(4) for r in range(32))
             assert len(seen) == 256 and set(seen.values()) == {1}
             assert {t for t, _ in seen} == set(range(256 // tw)) and {x for _, x in seen} == set(range(tw))
+
+
+def test_conv3x3_xcd_aware_block_order_is_a_bijection_and_colocates_channel_blocks():
+    """decode_block (conv3x3.hip, LP instantiations): every (tile, channel block) pair is produced exactly once for
+    any tile count, and with the XCD-aware order the channel blocks of a tile get workgroup ids that are equal modulo 8
+    (same XCD, hence one L2 for the tile's input patch) and at most 8 * (NB - 1) apart."""
+    emu = _conv_emulator()
+    for ntiles in list(range(1, 20)) + [1500, 1501, 1507]:
+        for NB in (1, 2, 3):
+            for xcd in (0, 1):
+                got = [emu.decode_block(L, ntiles, NB, xcd) for L in range(ntiles * NB)]
+                assert sorted(got) == [(t, b) for t in range(ntiles) for b in range(NB)], (ntiles, NB, xcd)
+                if xcd:
+                    ids = {}
+                    for L, (t, b) in enumerate(got):
+                        ids.setdefault(t, []).append(L)
+                    full = (ntiles // 8) * 8
+                    for t, ls in ids.items():
+                        if t < full:
+                            assert len({L % 8 for L in ls}) == 1 and max(ls) - min(ls) == 8 * (NB - 1), (ntiles, NB, t)

@@ -105,6 +105,16 @@ def run(x, xs, C, wpack, O, n, H, W, KC, TW, LP, stacked):
     return y
 
 
+def decode_block(L, ntiles, NB, xcd):
+    """conv3x3.hip decode_block: workgroup id -> (tile, output-channel block)"""
+    if not xcd:
+        return L % ntiles, L // ntiles
+    G = 8 * NB
+    s, l = L // G, L % G
+    m = min(8, ntiles - s * 8)
+    return s * 8 + l % m, l // m
+
+
 def bank_model():
     """worst n-way conflict of a B-fragment ds_read_b128 per service group, for each tile width / lane mapping"""
     groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
