@@ -86,12 +86,33 @@ __device__ __forceinline__ void decode_block(int L, int ntiles, int NB, int xcd,
   nb = l / m;
 }
 
+// Fused ConvGRU epilogues (EPI != 0): the gate arithmetic of gru_gates.hip applied to the convolution's fp16-rounded
+// pre-activations while they pass through the LDS tile -- same formulas, same rounding points, so the results equal
+// conv + gs_gru_gate_zr / gs_gru_gate_q bit for bit, but zr_pre / q_pre never travel to HBM and back.
+//   EPI 1 (z|r, 256 outputs): block 0 -> z = sigm(pre + inp_pre[:, 0:128] + b + glo) -> out0;
+//                             block 1 -> r likewise from channels 128:256, out1 = r * net (net = x[:, 0:128]).
+//   EPI 2 (q, 128 outputs):   q = tanh(pre + inp_pre[:, 256:384] + b + glo), out0 = (1 - z) net + z q with z = aux0,
+//                             net = aux1; the input is [xa (first `split` channels, stride xs) | xb (stride xsb)].
+struct EpiArgs {
+  const float* bias;           // [256] (EPI 1) / [128] (EPI 2)
+  const float* glo;            // [n, 256] / [n, 128] global-context terms
+  const _Float16* inp_pre;     // [n*h*w, 384] hoisted context-feature convolutions, or nullptr
+  const _Float16* aux0;        // EPI 2: z [n*h*w, 128]
+  const _Float16* aux1;        // EPI 2: net [n*h*w, 128]
+  _Float16* out0;              // EPI 1: z, EPI 2: new net   [n*h*w, 128]
+  _Float16* out1;              // EPI 1: r * net             [n*h*w, 128]
+  const _Float16* xb;          // EPI 2: second input source (channels >= split)
+  int xsb, split;
+};
+
+__device__ __forceinline__ float sigm_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
 // KC = input channels per chunk (32: 37 KB of LDS, a barrier every 16 MFMAs per wave; 64: 74 KB, every 32 MFMAs)
-template <int KC, bool LP>
+template <int KC, bool LP, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restrict__ x, int xs, int C,
                                                          const half8* __restrict__ wpack, _Float16* __restrict__ y,
                                                          int ys, int H, int W, int tiles_x, int tiles_y, int NB,
-                                                         int xcd) {
+                                                         int xcd, EpiArgs ep = EpiArgs()) {
   constexpr int KG = KC / 8;                             // 8-channel groups per chunk
   constexpr int WTAP = KG * BN;                          // 16-byte vectors of one tap's weight image
   constexpr int WPT = WTAP / 256;                        // ... per thread
@@ -142,8 +163,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restr
       const int py = p / PW, px = p - py * PW;
       const int gy = ty0 + py - 1, gx = tx0 + px - 1;
       half8 v = zero8;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-        v = *reinterpret_cast<const half8*>(ximg + ((size_t)gy * W + gx) * xs + ck * KC + kg * 8);
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        if constexpr (EPI == 2) {
+          const size_t pix = ((size_t)img * H + gy) * W + gx;
+          const int c0 = ck * KC + kg * 8;
+          v = c0 < ep.split ? *reinterpret_cast<const half8*>(x + pix * xs + c0)
+                            : *reinterpret_cast<const half8*>(ep.xb + pix * ep.xsb + (c0 - ep.split));
+        } else {
+          v = *reinterpret_cast<const half8*>(ximg + ((size_t)gy * W + gx) * xs + ck * KC + kg * 8);
+        }
+      }
       patch[kg * NPP + p] = v;
     }
     // ---- and the first tap's weights
@@ -225,7 +254,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restr
       }
       if (gy < H && gx < W) {
         const half8 v = *reinterpret_cast<const half8*>(tile + pxr * TS + piece * 8);
-        *reinterpret_cast<half8*>(yimg + ((size_t)gy * W + gx) * ys + piece * 8) = v;
+        if constexpr (EPI == 0) {
+          *reinterpret_cast<half8*>(yimg + ((size_t)gy * W + gx) * ys + piece * 8) = v;
+        } else {
+          const size_t pix = ((size_t)img * H + gy) * W + gx;
+          const int c8 = wn * 64 + piece * 8;               // first of this lane's 8 channels inside the 128-block
+          half8 o;
+          if constexpr (EPI == 1) {
+            half8 pi = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ep.inp_pre) pi = *reinterpret_cast<const half8*>(ep.inp_pre + pix * 384 + nb * 128 + c8);
+            const float* bb = ep.bias + nb * 128 + c8;
+            const float* gg = ep.glo + (size_t)img * 256 + nb * 128 + c8;
+            if (nb == 0) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) o[k] = (_Float16)sigm_((float)v[k] + (float)pi[k] + bb[k] + gg[k]);
+              *reinterpret_cast<half8*>(ep.out0 + pix * 128 + c8) = o;
+            } else {
+              const half8 net = *reinterpret_cast<const half8*>(x + pix * xs + c8);
+#pragma unroll
+              for (int k = 0; k < 8; ++k)
+                o[k] = (_Float16)(sigm_((float)v[k] + (float)pi[k] + bb[k] + gg[k]) * (float)net[k]);
+              *reinterpret_cast<half8*>(ep.out1 + pix * 128 + c8) = o;
+            }
+          } else {
+            half8 pi = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ep.inp_pre) pi = *reinterpret_cast<const half8*>(ep.inp_pre + pix * 384 + 256 + c8);
+            const half8 zz = *reinterpret_cast<const half8*>(ep.aux0 + pix * 128 + c8);
+            const half8 nn = *reinterpret_cast<const half8*>(ep.aux1 + pix * 128 + c8);
+            const float* bb = ep.bias + c8;
+            const float* gg = ep.glo + (size_t)img * 128 + c8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float a = (float)v[k] + (float)pi[k] + bb[k] + gg[k];
+              const float q = 1.0f - 2.0f / (1.0f + __expf(2.0f * a));
+              const float zf = (float)zz[k];
+              o[k] = (_Float16)((1.0f - zf) * (float)nn[k] + zf * q);
+            }
+            *reinterpret_cast<half8*>(ep.out0 + pix * 128 + c8) = o;
+          }
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -437,14 +504,14 @@ int launch3x3s(const void* x, int x_stride, int c_in, const void* wpack, void* y
   return GS_OK;
 }
 
-template <int KC, bool LP>
+template <int KC, bool LP, int EPI = 0>
 int launch3x3(const void* x, int x_stride, int c_in, const void* wpack, void* y, int y_stride, int n_out, int n, int h,
-              int w, hipStream_t st) {
+              int w, hipStream_t st, EpiArgs ep = EpiArgs()) {
   constexpr size_t lds = (size_t)((KC / 8) * (NP + (LP ? 1 : 0)) + 2 * (KC / 8) * BN) * sizeof(half8);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3x3_kernel<KC, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess) {
+    if (hipFuncSetAttribute((const void*)conv3x3_kernel<KC, LP, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
       gs_set_error("conv3x3: cannot raise the dynamic LDS limit to %zu bytes", lds);
       return GS_ERR_LAUNCH;
     }
@@ -456,8 +523,9 @@ int launch3x3(const void* x, int x_stride, int c_in, const void* wpack, void* y,
   const int NB = n_out / BN;
   GS_REQUIRE(blocks * NB < (1ll << 31), "conv3x3: too many workgroups");
   const dim3 grid = LP ? dim3((unsigned)(blocks * NB)) : dim3((unsigned)blocks, NB);
-  conv3x3_kernel<KC, LP><<<grid, 256, lds, st>>>((const _Float16*)x, x_stride, c_in, (const half8*)wpack, (_Float16*)y,
-                                                 y_stride, h, w, tiles_x, tiles_y, NB, xcd_remap_enabled());
+  conv3x3_kernel<KC, LP, EPI><<<grid, 256, lds, st>>>((const _Float16*)x, x_stride, c_in, (const half8*)wpack,
+                                                      (_Float16*)y, y_stride, h, w, tiles_x, tiles_y, NB,
+                                                      xcd_remap_enabled(), ep);
   GS_CHECK_LAUNCH("conv3x3");
   return GS_OK;
 }
@@ -517,4 +585,49 @@ extern "C" int gs_conv3x3_stacked(const void* x, int x_stride, int c_in, const v
   if (tw == 16) GS_S(64, 16, false);
   GS_S(64, 32, false);
 #undef GS_S
+}
+
+// ---- ConvGRU with the gate arithmetic fused into the convolutions' epilogues (EXPERIMENTAL, see EpiArgs) ----------
+extern "C" int gs_conv3x3_gru_zr(const void* hx, int hx_stride, int c_in, const void* wpack, const float* bias_zr,
+                                 const float* glo_zr, const void* inp_pre, void* z_out, void* rnet_out, int n, int h,
+                                 int w, gs_stream_t stream) {
+  GS_REQUIRE(hx && wpack && bias_zr && glo_zr && z_out && rnet_out, "conv3x3_gru_zr: null pointer");
+  GS_REQUIRE(c_in >= 128 && c_in % 32 == 0, "conv3x3_gru_zr: c_in must be >= 128 and a multiple of 32");
+  GS_REQUIRE(hx_stride >= c_in && hx_stride % 8 == 0, "conv3x3_gru_zr: bad hx_stride");
+  GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3_gru_zr: bad shape");
+  if (n == 0) return GS_OK;
+  EpiArgs ep = EpiArgs();
+  ep.bias = bias_zr;
+  ep.glo = glo_zr;
+  ep.inp_pre = (const _Float16*)inp_pre;
+  ep.out0 = (_Float16*)z_out;
+  ep.out1 = (_Float16*)rnet_out;
+  hipStream_t st = (hipStream_t)stream;
+  if (lane_perm_enabled()) return launch3x3<32, true, 1>(hx, hx_stride, c_in, wpack, nullptr, 0, 256, n, h, w, st, ep);
+  return launch3x3<32, false, 1>(hx, hx_stride, c_in, wpack, nullptr, 0, 256, n, h, w, st, ep);
+}
+
+extern "C" int gs_conv3x3_gru_q(const void* rnet, const void* x_rest, int x_rest_stride, int c_rest, const void* wpack,
+                                const float* bias_q, const float* glo_q, const void* inp_pre, const void* z,
+                                const void* net, void* net_out, int n, int h, int w, gs_stream_t stream) {
+  GS_REQUIRE(rnet && x_rest && wpack && bias_q && glo_q && z && net && net_out, "conv3x3_gru_q: null pointer");
+  GS_REQUIRE(c_rest > 0 && c_rest % 64 == 0, "conv3x3_gru_q: c_rest must be a multiple of 64");
+  GS_REQUIRE(x_rest_stride >= c_rest && x_rest_stride % 8 == 0, "conv3x3_gru_q: bad x_rest_stride");
+  GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3_gru_q: bad shape");
+  if (n == 0) return GS_OK;
+  EpiArgs ep = EpiArgs();
+  ep.bias = bias_q;
+  ep.glo = glo_q;
+  ep.inp_pre = (const _Float16*)inp_pre;
+  ep.aux0 = (const _Float16*)z;
+  ep.aux1 = (const _Float16*)net;
+  ep.out0 = (_Float16*)net_out;
+  ep.xb = (const _Float16*)x_rest;
+  ep.xsb = x_rest_stride;
+  ep.split = 128;
+  hipStream_t st = (hipStream_t)stream;
+  const int c_in = 128 + c_rest;
+  if (lane_perm_enabled())
+    return launch3x3<64, true, 2>(rnet, 128, c_in, wpack, nullptr, 0, 128, n, h, w, st, ep);
+  return launch3x3<64, false, 2>(rnet, 128, c_in, wpack, nullptr, 0, 128, n, h, w, st, ep);
 }

@@ -187,6 +187,9 @@ CONV3X3_KC = "auto"
 # Row-stacked tiling (gs_conv3x3_stacked: no tile padding along the rows, tile width chosen per map width) -- opt-in
 # (GOSLAM_CONV3X3_STACKED=1) until it has been timed against the plain tiling; with it "auto" covers every map size.
 CONV3X3_STACKED = os.environ.get("GOSLAM_CONV3X3_STACKED", "0") == "1"
+# ConvGRU gate arithmetic fused into the z|r and q convolutions' epilogues (gs_conv3x3_gru_zr / _q): bit-identical to
+# conv + gate kernels by construction, parity-checked by emulation, not yet run on hardware -> opt-in.
+GRU_FUSED_EPILOGUE = os.environ.get("GOSLAM_GRU_FUSED", "0") == "1"
 _CONV3X3_PACKS = {}        # (data_ptr, version, shape, device, kc) -> (packed image, weight tensor kept alive)
 _CONV3X3_PACKS_MAX = 32
 
@@ -234,12 +237,8 @@ def _use_own_conv3x3(x, w, stride, padding):
     return conv3x3_tile_efficiency(x.shape[2], x.shape[3]) >= 0.9
 
 
-def conv3x3_hip(x, w, kc=None, stacked=None, tw=None):
-    """bias-free 3x3 / pad 1 convolution of an NHWC fp16 tensor through gs_conv3x3; `w` is the [O,C,3,3] weight.
-    Its packed image is cached per (storage address, version, shape); the entry keeps the weight tensor alive, so the
-    address cannot be recycled for different values while the entry exists."""
-    from . import _lib
-    kc = kc or conv3x3_chunk(w.shape[1], w.shape[0])
+def conv3x3_weight_image(w, kc):
+    """cached gs_conv3x3 weight image of `w` (see conv3x3_hip)"""
     key = (w.data_ptr(), w._version, tuple(w.shape), w.device, kc)
     hit = _CONV3X3_PACKS.pop(key, None)
     if hit is None:
@@ -247,17 +246,27 @@ def conv3x3_hip(x, w, kc=None, stacked=None, tw=None):
         while len(_CONV3X3_PACKS) >= _CONV3X3_PACKS_MAX:
             _CONV3X3_PACKS.pop(next(iter(_CONV3X3_PACKS)))
     _CONV3X3_PACKS[key] = hit                                # re-inserted last: least recently used goes first
+    return hit[0]
+
+
+def conv3x3_hip(x, w, kc=None, stacked=None, tw=None):
+    """bias-free 3x3 / pad 1 convolution of an NHWC fp16 tensor through gs_conv3x3; `w` is the [O,C,3,3] weight.
+    Its packed image is cached per (storage address, version, shape); the entry keeps the weight tensor alive, so the
+    address cannot be recycled for different values while the entry exists."""
+    from . import _lib
+    kc = kc or conv3x3_chunk(w.shape[1], w.shape[0])
+    image = conv3x3_weight_image(w, kc)
     n, c, h, wd = x.shape
     O = w.shape[0]
     y = torch.empty((n, O, h, wd), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
     stacked = CONV3X3_STACKED if stacked is None else stacked
     with torch.cuda.device(x.device):
         if stacked:
-            rc = _lib.lib().gs_conv3x3_stacked(_lib.ptr(x), c, c, _lib.ptr(hit[0]), kc,
+            rc = _lib.lib().gs_conv3x3_stacked(_lib.ptr(x), c, c, _lib.ptr(image), kc,
                                                tw or conv3x3_stacked_tile_width(wd), _lib.ptr(y), O, O, n, h, wd,
                                                _lib.stream_ptr(x.device))
         else:
-            rc = _lib.lib().gs_conv3x3(_lib.ptr(x), c, c, _lib.ptr(hit[0]), kc, _lib.ptr(y), O, O, n, h, wd,
+            rc = _lib.lib().gs_conv3x3(_lib.ptr(x), c, c, _lib.ptr(image), kc, _lib.ptr(y), O, O, n, h, wd,
                                        _lib.stream_ptr(x.device))
     _lib.check(rc, "conv3x3")
     return y
@@ -372,6 +381,20 @@ class ConvGRU(nn.Module):
             _lib.check(L.gs_gru_glo(_lib.ptr(w_pre), _lib.ptr(bw), _lib.ptr(net), _lib.ptr(gw[0]), _lib.ptr(gw[1]),
                                     _lib.ptr(gw[2]), _lib.ptr(gw[3]), _lib.ptr(gw[4]), _lib.ptr(gw[5]),
                                     _lib.ptr(gzr), _lib.ptr(gq), b, hw, _lib.ptr(ws), ws.numel(), st), "gru_glo")
+            cin = hx.shape[1]
+            if GRU_FUSED_EPILOGUE and _use_own_conv3x3(hx, wzr, 1, 1) and cin % 64 == 0 and h * w > 0:
+                # gate arithmetic in the convolutions' epilogues: zr_pre / q_pre never reach HBM; hx stays intact
+                z = torch.empty_like(net)
+                rnet = torch.empty_like(net)
+                out = torch.empty_like(net)
+                _lib.check(L.gs_conv3x3_gru_zr(_lib.ptr(hx), cin, cin, _lib.ptr(conv3x3_weight_image(wzr, 32)),
+                                               _lib.ptr(bzr), _lib.ptr(gzr), _lib.ptr(inp_pre), _lib.ptr(z),
+                                               _lib.ptr(rnet), b, h, w, st), "conv3x3_gru_zr")
+                _lib.check(L.gs_conv3x3_gru_q(_lib.ptr(rnet), hx.data_ptr() + 2 * 128, cin, cin - 128,
+                                              _lib.ptr(conv3x3_weight_image(wq, 64)), _lib.ptr(bq), _lib.ptr(gq),
+                                              _lib.ptr(inp_pre), _lib.ptr(z), _lib.ptr(net), _lib.ptr(out), b, h, w,
+                                              st), "conv3x3_gru_q")
+                return out
             zr_pre = conv_nobias(hx, wzr, padding=1)
             z = torch.empty_like(net)
             _lib.check(L.gs_gru_gate_zr(_lib.ptr(zr_pre), _lib.ptr(bzr), _lib.ptr(gzr), _lib.ptr(inp_pre), _lib.ptr(hx),

@@ -185,6 +185,20 @@ int gs_conv3x3(const void* x, int x_stride, int c_in, const void* wpack, int kc,
  * Requires the images to be contiguous (image stride = h * w * x_stride resp. y_stride).                    */
 int gs_conv3x3_stacked(const void* x, int x_stride, int c_in, const void* wpack, int kc, int tw, void* y,
                        int y_stride, int n_out, int n, int h, int w, gs_stream_t stream);
+/* ConvGRU (src/modules/gru.py:20-33) with the gate arithmetic fused into the 3x3 convolutions' epilogues
+ * (EXPERIMENTAL: opt-in from the host mirror; results equal gs_conv3x3 + gs_gru_gate_zr / gs_gru_gate_q bit for bit,
+ * but the 256 + 128 channels of pre-activations never travel to HBM and back).
+ *   gs_conv3x3_gru_zr: hx [n,h,w,hx_stride] fp16, first c_in channels = [net(128) | rest]; wpack = gs_conv3x3 image of
+ *     the fused convz|convr weight [256, c_in, 3, 3] at kc = 32; bias_zr f32 [256]; glo_zr f32 [n,256]; inp_pre fp16
+ *     [n,h,w,384] or NULL.  Writes z_out = sigmoid(.) [n,h,w,128] and rnet_out = r * net [n,h,w,128]; hx is not modified.
+ *   gs_conv3x3_gru_q: input [rnet (128 ch, dense) | x_rest (c_rest channels, pixels x_rest_stride apart)]; wpack = image
+ *     of convq [128, 128 + c_rest, 3, 3] at kc = 64 (c_rest % 64 == 0); writes net_out = (1 - z) net + z tanh(.).   */
+int gs_conv3x3_gru_zr(const void* hx, int hx_stride, int c_in, const void* wpack, const float* bias_zr,
+                      const float* glo_zr, const void* inp_pre, void* z_out, void* rnet_out, int n, int h, int w,
+                      gs_stream_t stream);
+int gs_conv3x3_gru_q(const void* rnet, const void* x_rest, int x_rest_stride, int c_rest, const void* wpack,
+                     const float* bias_q, const float* glo_q, const void* inp_pre, const void* z, const void* net,
+                     void* net_out, int n, int h, int w, gs_stream_t stream);
 /* 3x3 convolution (padding 1) from 128 channels to n_out in {1,2} channels, NHWC fp16 in, fp32 out
  * [n,h,w,n_out]: the flow-revision / confidence heads delta[2], weight[2] (src/droid_net.py:83-92) and
  * GraphAgg's eta[0] (src/droid_net.py:43).  x rows are x_stride elements apart (a channel slice of a

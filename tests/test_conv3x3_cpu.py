@@ -87,3 +87,15 @@ def test_conv3x3_xcd_aware_block_order_is_a_bijection_and_colocates_channel_bloc
                     for t, ls in ids.items():
                         if t < full:
                             assert len({L % 8 for L in ls}) == 1 and max(ls) - min(ls) == 8 * (NB - 1), (ntiles, NB, t)
+
+
+def test_fused_gru_epilogues_by_emulation():
+    """gs_conv3x3_gru_zr / gs_conv3x3_gru_q (EPI 1 / 2 of conv3x3_kernel: gate arithmetic on the fp16 pre-activations in
+    the LDS-tile stage, two-source input [r*net | rest] for the q convolution) replayed thread by thread vs the dense
+    formulation conv -> fp16 -> gru_gates.hip formulas: z, r*net and the new hidden state agree to one fp16 ulp (the
+    emulated and the dense convolution sum in different orders), every output is written once; with and without the
+    hoisted context term, with and without the lane permutation."""
+    emu = _conv_emulator()
+    for args in ((2, 5, 9, 64, False, True), (1, 3, 17, 64, True, False)):
+        dz, dr, dout, unwritten = emu.gru_fused(*args[:5], hoisted=args[5])
+        assert unwritten == 0 and max(dz, dr, dout) <= 5e-4, (args, dz, dr, dout, unwritten)

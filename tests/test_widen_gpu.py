@@ -306,3 +306,39 @@ def test_update_operator_with_own_conv3x3_matches_miopen_path(built_lib):
         DN.CONV3X3_IMPL = keep
     for a, b, name in zip(out["hip"], out["miopen"], ("net", "delta", "weight", "eta", "upmask")):
         torch.testing.assert_close(a, b, rtol=5e-3, atol=3e-3, msg=lambda m, nm=name: f"{nm}: {m}")
+
+
+@pytest.mark.skipif(os.environ.get("GOSLAM_TEST_EXPERIMENTAL") != "1",
+                    reason="opt-in variant that has not run on hardware yet (tools/conv3x3_variants.sh sets the flag)")
+@pytest.mark.parametrize("hoisted", [True, False])
+def test_fused_gru_epilogues_equal_conv_plus_gate_kernels(built_lib, hoisted):
+    """ConvGRU.forward_hx with the gate arithmetic fused into the convolutions' epilogues (gs_conv3x3_gru_zr / _q) vs the
+    same convolutions followed by gs_gru_gate_zr / gs_gru_gate_q: same kernels' accumulation order, same rounding
+    points -> the new hidden state must be EQUAL, with and without the hoisted context-feature term."""
+    import go_slam_amd.droid_net as DN
+    dev = "cuda:0"
+    torch.manual_seed(21)
+    gru = DN.ConvGRU(128, 320).to(dev).eval()
+    n, h, w = 5, 32, 48
+    g = torch.Generator().manual_seed(22)
+    cl = lambda t: t.half().to(dev).contiguous(memory_format=torch.channels_last)
+    net = cl(torch.tanh(torch.randn(n, 128, h, w, generator=g)))
+    inp = cl(torch.relu(torch.randn(n, 128, h, w, generator=g)))
+    rest = cl(torch.relu(torch.randn(n, 192, h, w, generator=g)))
+    keep = (DN.CONV3X3_IMPL, DN.GRU_FUSED_EPILOGUE)
+    out = {}
+    try:
+        DN.CONV3X3_IMPL = "hip"
+        for fused in (False, True):
+            DN.GRU_FUSED_EPILOGUE = fused
+            with torch.no_grad():
+                if hoisted:
+                    hx = cl(torch.cat([net, rest], 1).float())
+                    out[fused] = gru.forward_hx(net.clone(), hx, gru.inp_gates(inp))
+                else:
+                    hx = cl(torch.cat([net, inp, rest], 1).float())
+                    out[fused] = gru.forward_hx(net.clone(), hx, None)
+    finally:
+        DN.CONV3X3_IMPL, DN.GRU_FUSED_EPILOGUE = keep
+    assert torch.isfinite(out[True].float()).all()
+    assert torch.equal(out[True], out[False])

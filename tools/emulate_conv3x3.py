@@ -21,7 +21,7 @@ def tile_pixel(TW, LP, wm, i, r):
     grp,pos=frag_lane(r)
     if TW==16: return wm*8+2*i+grp, pos
     return wm*16+i+8*grp+4*(pos>>3), pos&7
-def run(x, xs, C, wpack, O, n, H, W, KC, TW, LP, stacked):
+def run(x, xs, C, wpack, O, n, H, W, KC, TW, LP, stacked, xb=None, xsb=0, split=0, epi=None):
     TH=256//TW; PW=TW+2; NP=(TH+2)*PW; NPP=NP+1 if LP else NP; KG=KC//8; WTAP=KG*BN
     rows=n*H
     if stacked:
@@ -50,7 +50,11 @@ def run(x, xs, C, wpack, O, n, H, W, KC, TW, LP, stacked):
                 else:
                     gy=ty0+pr-1; gx=tx0+pc-1
                     if 0<=gy<H and 0<=gx<W:
-                        base=((img*H+gy)*W+gx)*xs+ck*KC+kg*8; v=x[base:base+8]
+                        pix=(img*H+gy)*W+gx; c0=ck*KC+kg*8
+                        if xb is not None and c0>=split:        # EPI 2: second input source
+                            base=pix*xsb+(c0-split); v=xb[base:base+8]
+                        else:
+                            base=pix*xs+c0; v=x[base:base+8]
                 patch[kg*NPP+p]=v
             wck=wsrc+ck*9*WTAP
             for tap in range(9):
@@ -101,7 +105,11 @@ def run(x, xs, C, wpack, O, n, H, W, KC, TW, LP, stacked):
                             gy=ty0+ty; gx=tx0+tx; ok=gy<H and gx<W; gv=img*H+gy
                         if ok:
                             c0=nb*BN+wn*64+piece*8
-                            y[gv*W+gx, c0:c0+8]=tile[pxr*TS+piece*8:pxr*TS+piece*8+8]
+                            v8=tile[pxr*TS+piece*8:pxr*TS+piece*8+8]
+                            if epi is None:                      # kept in fp32 here so that index errors cannot hide
+                                y[gv*W+gx, c0:c0+8]=v8           # behind the fp16 rounding of the real LDS tile
+                            else:
+                                epi(gv*W+gx, gv//H, nb, wn*64+piece*8, v8.astype(np.float16).astype(np.float32))
     return y
 
 
@@ -113,6 +121,60 @@ def decode_block(L, ntiles, NB, xcd):
     s, l = L // G, L % G
     m = min(8, ntiles - s * 8)
     return s * 8 + l % m, l // m
+
+
+def gru_fused(n, H, W, c_rest, LP, hoisted=True, seed=3):
+    """Emulates gs_conv3x3_gru_zr + gs_conv3x3_gru_q (EPI 1 / 2 of conv3x3_kernel) on random data and returns the max
+    difference to conv (fp16-rounded) + the gate formulas of gru_gates.hip evaluated densely in torch, for z, r * net
+    and the new hidden state, plus the count of outputs never written."""
+    g = torch.Generator().manual_seed(seed)
+    cin = 128 + c_rest
+    P = n * H * W
+    hx = (torch.randn(P, cin, generator=g) * 0.5).half()
+    net = hx[:, :128].clone()
+    wzr = (torch.randn(256, cin, 3, 3, generator=g) * 0.03).half()
+    wq = (torch.randn(128, cin, 3, 3, generator=g) * 0.03).half()
+    bzr, bq = torch.randn(256, generator=g) * 0.1, torch.randn(128, generator=g) * 0.1
+    gzr, gq = torch.randn(n, 256, generator=g) * 0.1, torch.randn(n, 128, generator=g) * 0.1
+    inp_pre = (torch.randn(P, 384, generator=g) * 0.3).half() if hoisted else None
+    f32 = lambda t: t.float().numpy()
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v, dtype=np.float32))
+    z_o = np.full((P, 128), np.nan, np.float32); rn_o = z_o.copy(); out_o = z_o.copy()
+    ip = f32(inp_pre) if hoisted else None
+
+    def epi1(pix, img, nb, c8, v8):
+        pi = ip[pix, nb * 128 + c8: nb * 128 + c8 + 8] if hoisted else np.zeros(8, np.float32)
+        a = sig((v8 + pi + f32(bzr)[nb * 128 + c8: nb * 128 + c8 + 8] + f32(gzr)[img, nb * 128 + c8: nb * 128 + c8 + 8]).astype(np.float32))
+        if nb == 0:
+            z_o[pix, c8:c8 + 8] = a.astype(np.float16)
+        else:
+            rn_o[pix, c8:c8 + 8] = (a * f32(hx)[pix, c8:c8 + 8]).astype(np.float16)
+    run(f32(hx).reshape(-1), cin, cin, pack_conv3x3_weight(wzr, 32).float().numpy(), 256, n, H, W, 32, 16, LP, False, epi=epi1)
+    z16, rn16 = z_o.copy(), rn_o.copy()
+
+    def epi2(pix, img, nb, c8, v8):
+        pi = ip[pix, 256 + c8: 256 + c8 + 8] if hoisted else np.zeros(8, np.float32)
+        a = (v8 + pi + f32(bq)[c8:c8 + 8] + f32(gq)[img, c8:c8 + 8]).astype(np.float32)
+        q = (1.0 - 2.0 / (1.0 + np.exp(2.0 * a, dtype=np.float32))).astype(np.float32)
+        zf = z16[pix, c8:c8 + 8]
+        out_o[pix, c8:c8 + 8] = ((1.0 - zf) * f32(net)[pix, c8:c8 + 8] + zf * q).astype(np.float16)
+    rest = hx[:, 128:].contiguous()
+    run(rn16.reshape(-1), 128, cin, pack_conv3x3_weight(wq, 64).float().numpy(), 128, n, H, W, 64, 16, LP, False,
+        xb=f32(rest).reshape(-1), xsb=c_rest, split=128, epi=epi2)
+    # dense reference: conv in fp32 on the fp16 operands, rounded to fp16, then the gate formulas
+    to_img = lambda t: t.float().view(n, H, W, -1).permute(0, 3, 1, 2)
+    zr_pre = F.conv2d(to_img(hx), wzr.float(), padding=1).permute(0, 2, 3, 1).reshape(P, 256).half().float()
+    addz = zr_pre + (inp_pre[:, :256].float() if hoisted else 0) + bzr + gzr.repeat_interleave(H * W, 0)
+    zr = torch.sigmoid(addz)
+    z_ref = zr[:, :128].half()
+    rn_ref = (zr[:, 128:] * net.float()).half()
+    hq = torch.cat([rn_ref, hx[:, 128:]], 1)
+    q_pre = F.conv2d(to_img(hq), wq.float(), padding=1).permute(0, 2, 3, 1).reshape(P, 128).half().float()
+    a = q_pre + (inp_pre[:, 256:].float() if hoisted else 0) + bq + gq.repeat_interleave(H * W, 0)
+    out_ref = ((1 - z_ref.float()) * net.float() + z_ref.float() * torch.tanh(a)).half()
+    d = lambda e, r: float(np.abs(np.nan_to_num(e) - r.float().numpy()).max())
+    unwritten = int(np.isnan(z_o).sum() + np.isnan(rn_o).sum() + np.isnan(out_o).sum())
+    return d(z_o, z_ref), d(rn_o, rn_ref), d(out_o, out_ref), unwritten
 
 
 def bank_model():
