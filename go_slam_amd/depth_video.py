@@ -22,29 +22,26 @@ class DepthVideo:
         c = 2 if stereo else 1
         self.counter = 0                     # int here; a multiprocessing.Value (`.value`) is accepted too
         self.stereo = stereo
-        self.timestamp = torch.zeros(buffer, device=d, dtype=torch.float32)
-        self.poses = torch.zeros(buffer, 7, device=d, dtype=torch.float32)
-        self.poses[:, 6] = 1.0
-        self.disps = torch.ones(buffer, ht, wd, device=d, dtype=torch.float32)
-        self.disps_sens = torch.zeros(buffer, ht, wd, device=d, dtype=torch.float32)
-        self.disps_up = torch.zeros(buffer, 8 * ht, 8 * wd, device=d, dtype=torch.float32)
-        self.intrinsics = torch.zeros(buffer, 4, device=d, dtype=torch.float32)
-        self.fmaps = torch.zeros(buffer, c, 128, ht, wd, device=d, dtype=torch.half)
-        self.nets = torch.zeros(buffer, 128, ht, wd, device=d, dtype=torch.half)
-        self.inps = torch.zeros(buffer, 128, ht, wd, device=d, dtype=torch.half)
-        self.dirty = torch.zeros(buffer, device=d, dtype=torch.bool)
+        H, W = 8 * ht, 8 * wd
+        f32, f16 = torch.float32, torch.half
+        # name -> (per-keyframe shape, dtype, fill): the 1/8-resolution state the hot path reads and writes ...
+        table = {"timestamp": ((), f32, 0), "poses": ((7,), f32, 0), "disps": ((ht, wd), f32, 1),
+                 "disps_sens": ((ht, wd), f32, 0), "disps_up": ((H, W), f32, 0), "intrinsics": ((4,), f32, 0),
+                 "fmaps": ((c, 128, ht, wd), f16, 0), "nets": ((128, ht, wd), f16, 0), "inps": ((128, ht, wd), f16, 0),
+                 "dirty": ((), torch.bool, 0)}
+        if full_res:   # ... and the full-resolution / tracker -> mapper hand-off buffers (src/depth_video.py:41-69)
+            table.update({"images": ((3, H, W), f32, 0), "depths_gt": ((H, W), f32, 0), "poses_gt": ((4, 4), f32, 0),
+                          "poses_filtered": ((7,), f32, 0), "disps_filtered": ((H, W), f32, 0),
+                          "mask_filtered": ((H, W), f32, 0), "update_priority": ((), f32, 0)})
+        for name, (shape, dtype, fill) in table.items():
+            setattr(self, name, torch.full((buffer,) + shape, fill, device=d, dtype=dtype))
+        self.poses[:, 6] = 1.0               # identity: t = 0, q = (0, 0, 0, 1)
         if full_res:
-            self.images = torch.zeros(buffer, 3, 8 * ht, 8 * wd, device=d, dtype=torch.float32)
-            self.depths_gt = torch.zeros(buffer, 8 * ht, 8 * wd, device=d, dtype=torch.float32)
-            self.poses_gt = torch.eye(4, device=d, dtype=torch.float32).repeat(buffer, 1, 1)
-            # tracker -> mapper hand-off, written by MultiviewFilter (src/depth_video.py:57-69)
+            self.poses_gt[:] = torch.eye(4, device=d)
+            self.poses_filtered[:, 6] = 1.0
             self.scale_factor = 8
-            self.poses_filtered = self.poses.clone()
-            self.disps_filtered = torch.zeros(buffer, 8 * ht, 8 * wd, device=d, dtype=torch.float32)
-            self.mask_filtered = torch.zeros(buffer, 8 * ht, 8 * wd, device=d, dtype=torch.float32)
-            self.filtered_id = torch.tensor([-1], dtype=torch.int32, device=d)
-            self.update_priority = torch.zeros(buffer, device=d, dtype=torch.float32)
-            self.bound = torch.zeros(1, 3, 2, device=d, dtype=torch.float32)
+            self.filtered_id = torch.tensor([-1], dtype=torch.int32, device=d)      # written by MultiviewFilter
+            self.bound = torch.zeros(1, 3, 2, device=d, dtype=f32)
             self.pose_compensate = torch.tensor([[0, 0, 0, 0, 0, 0, 1.0]], device=d)
 
     @classmethod
@@ -79,24 +76,20 @@ class DepthVideo:
         self.timestamp[index] = item[0]
         if hasattr(self, "images"):
             self.images[index] = item[1]
-        if item[2] is not None:
-            self.poses[index] = item[2]
-        if item[3] is not None:
-            self.disps[index] = item[3]
-        if item[4] is not None:
+        pose, disp, depth = item[2], item[3], item[4]
+        if pose is not None:
+            self.poses[index] = pose
+        if disp is not None:
+            self.disps[index] = disp
+        if depth is not None:                      # sensor depth: prior AND initial value (overrides `disp`)
             if hasattr(self, "depths_gt"):
-                self.depths_gt[index] = item[4]
-            depth = item[4][..., 3::8, 3::8].to(self.device)
-            self.disps_sens[index] = torch.where(depth > 0, 1.0 / depth, depth)
+                self.depths_gt[index] = depth
+            sub = depth[..., 3::8, 3::8].to(self.device)
+            self.disps_sens[index] = torch.where(sub > 0, 1.0 / sub, sub)
             self.disps[index] = self.disps_sens[index].clone()
-        if item[5] is not None:
-            self.intrinsics[index] = item[5]
-        if len(item) > 6:
-            self.fmaps[index] = item[6]
-        if len(item) > 7:
-            self.nets[index] = item[7]
-        if len(item) > 8:
-            self.inps[index] = item[8]
+        for slot, name in ((5, "intrinsics"), (6, "fmaps"), (7, "nets"), (8, "inps")):
+            if len(item) > slot and (slot > 5 or item[slot] is not None):
+                getattr(self, name)[index] = item[slot]
         if len(item) > 9 and item[9] is not None and hasattr(self, "poses_gt"):
             self.poses_gt[index] = item[9].to(self.poses_gt.device)
 

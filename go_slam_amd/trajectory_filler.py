@@ -13,6 +13,10 @@ from .factor_graph import FactorGraph
 from .frontend import keyframe_count, set_keyframe_count
 from .lietorch_shim import SE3
 
+BATCH = 16                 # frames refined together (trajectory_filler.py:99)
+REFINE_UPDATES = 6         # motion-only updates per batch (:71)
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
 
 class PoseTrajectoryFiller:
     """fills in the poses of non-keyframe images"""
@@ -22,64 +26,75 @@ class PoseTrajectoryFiller:
         self.count = 0
         self.video = video
         self.device = device
-        self.MEAN = torch.tensor([0.485, 0.456, 0.406], device=device)[:, None, None]
-        self.STDV = torch.tensor([0.229, 0.224, 0.225], device=device)[:, None, None]
+        self.MEAN = torch.tensor(IMAGENET_MEAN, device=device)[:, None, None]
+        self.STDV = torch.tensor(IMAGENET_STD, device=device)[:, None, None]
 
-    def _feature_encoder(self, image):
+    # ---- pieces of one batch ---------------------------------------------------------------------------------------
+    def _bracket(self, tt, ts):
+        """(t0, t1): last keyframe at or before each timestamp (-1 -> wraps to the newest, as the reference's
+        `ts[ts <= t].shape[0] - 1` does) and its successor, clamped at the newest keyframe"""
+        before = (ts.unsqueeze(0) <= tt.unsqueeze(1)).sum(dim=1) - 1
+        after = torch.where(before < ts.shape[0] - 1, before + 1, before)
+        return before, after
+
+    def _interpolate(self, tt, ts, Ps, t0, t1):
+        """constant-velocity pose between the bracketing keyframes: exp(log(P1 P0^-1) (t - t0)/(dt + 1e-3)) P0"""
+        span = ts[t1] - ts[t0] + 1e-3
+        twist = (Ps[t1] * Ps[t0].inv()).log() / span.unsqueeze(-1)
+        return SE3.exp(twist * (tt - ts[t0]).unsqueeze(-1)) * Ps[t0]
+
+    def _features(self, frames):
+        """feature maps only -- no context network needed for motion-only refinement.  Normalises in place."""
+        frames = frames.sub_(self.MEAN).div_(self.STDV)
         with torch.autocast("cuda", enabled=torch.device(self.device).type == "cuda"):
-            return self.fnet(image)
+            return self.fnet(frames)
+
+    def _refine(self, t0, t1, first, count):
+        graph = FactorGraph(self.video, self.update, device=self.device)
+        parked = torch.arange(first, first + count, device=self.device)
+        for anchor in (t0, t1):                                   # one edge to each bracketing keyframe
+            graph.add_factors(anchor.to(self.device), parked)
+        for _ in range(REFINE_UPDATES):
+            graph.update(first, first + count, motion_only=True)
 
     def _fill(self, timestamps, images, depths, intrinsics):
         v = self.video
+        N, M = keyframe_count(v), len(timestamps)
         tt = torch.as_tensor(timestamps, device=self.device, dtype=v.timestamp.dtype)
         images = torch.stack(images, dim=0)                       # [M, b, 3, H, W]
-        depths = torch.stack(depths, dim=0) if depths is not None else None
+        depths = None if depths is None else torch.stack(depths, dim=0)
         intrinsics = torch.stack(intrinsics, 0)
-        inputs = images.to(self.device)
-        N, M = keyframe_count(v), len(timestamps)
-        ts = v.timestamp[:N]
-        Ps = SE3(v.poses[:N])
-        # last keyframe at or before each timestamp, and its successor (clamped at the end)
-        t0 = (ts[None, :] <= tt[:, None]).sum(dim=1) - 1
-        t1 = torch.where(t0 < N - 1, t0 + 1, t0)
-        dt = ts[t1] - ts[t0] + 1e-3
-        dP = Ps[t1] * Ps[t0].inv()
-        vel = dP.log() / dt.unsqueeze(-1)
-        Gs = SE3.exp(vel * (tt - ts[t0]).unsqueeze(-1)) * Ps[t0]
-        inputs = inputs.sub_(self.MEAN).div_(self.STDV)
-        fmap = self._feature_encoder(inputs)                      # no context features needed
-        # park the non-keyframes behind the keyframes
-        set_keyframe_count(v, N + M)
-        v[N:N + M] = (tt, images[:, 0], Gs.data, 1, depths, intrinsics / 8.0, fmap)
-        graph = FactorGraph(v, self.update, device=self.device)
-        new = torch.arange(N, N + M, device=self.device)
-        graph.add_factors(t0.to(self.device), new)
-        graph.add_factors(t1.to(self.device), new)
-        for _ in range(6):
-            graph.update(N, N + M, motion_only=True)
-        Gs = SE3(v.poses[N:N + M].clone())
-        set_keyframe_count(v, N)
-        return [Gs]
+        frames = images.to(self.device)
+        ts, Ps = v.timestamp[:N], SE3(v.poses[:N])
+        t0, t1 = self._bracket(tt, ts)
+        guess = self._interpolate(tt, ts, Ps, t0, t1)
+        fmap = self._features(frames)
+        set_keyframe_count(v, N + M)                              # park the batch behind the keyframes ...
+        v[N:N + M] = (tt, images[:, 0], guess.data, 1, depths, intrinsics / 8.0, fmap)
+        self._refine(t0, t1, N, M)
+        refined = SE3(v.poses[N:N + M].clone())
+        set_keyframe_count(v, N)                                  # ... and un-park it
+        return [refined]
 
     @torch.no_grad()
     def __call__(self, image_stream):
         """image_stream yields (timestamp, image [b,3,H,W], depth | None, intrinsic [4], gt_pose); returns one SE3
         holding a world-to-camera pose per frame."""
-        pose_list = []
-        timestamps, images, depths, intrinsics = [], [], [], []
+        poses, batch = [], ([], [], [], [])
 
         def flush():
-            nonlocal timestamps, images, depths, intrinsics
-            pose_list.extend(self._fill(timestamps, images, depths if len(depths) > 0 else None, intrinsics))
-            timestamps, images, depths, intrinsics = [], [], [], []
-        for (timestamp, image, depth, intrinsic, gt_pose) in image_stream:
-            timestamps.append(timestamp)
-            images.append(image)
+            stamps, imgs, deps, intr = batch
+            poses.extend(self._fill(list(stamps), list(imgs), list(deps) if deps else None, list(intr)))
+            for part in batch:
+                part.clear()
+        for timestamp, image, depth, intrinsic, _gt in image_stream:
+            batch[0].append(timestamp)
+            batch[1].append(image)
             if depth is not None:
-                depths.append(depth)
-            intrinsics.append(intrinsic)
-            if len(timestamps) == 16:
+                batch[2].append(depth)
+            batch[3].append(intrinsic)
+            if len(batch[0]) == BATCH:
                 flush()
-        if len(timestamps) > 0:
+        if batch[0]:
             flush()
-        return lietorch.cat(pose_list, dim=0)
+        return lietorch.cat(poses, dim=0)
