@@ -93,6 +93,8 @@ __device__ __forceinline__ void decode_block(int L, int ntiles, int NB, int xcd,
 //                             block 1 -> r likewise from channels 128:256, out1 = r * net (net = x[:, 0:128]).
 //   EPI 2 (q, 128 outputs):   q = tanh(pre + inp_pre[:, 256:384] + b + glo), out0 = (1 - z) net + z q with z = aux0,
 //                             net = aux1; the input is [xa (first `split` channels, stride xs) | xb (stride xsb)].
+//   EPI 3 (any width):        y = relu(pre + b) -- gs_bias_act's arithmetic (fp16 pre-activation, fp32 add, fp16 result)
+//                             in the store stage; y / y_stride may address a channel slice of a wider tensor.
 struct EpiArgs {
   const float* bias;           // [256] (EPI 1) / [128] (EPI 2)
   const float* glo;            // [n, 256] / [n, 128] global-context terms
@@ -256,6 +258,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restr
         const half8 v = *reinterpret_cast<const half8*>(tile + pxr * TS + piece * 8);
         if constexpr (EPI == 0) {
           *reinterpret_cast<half8*>(yimg + ((size_t)gy * W + gx) * ys + piece * 8) = v;
+        } else if constexpr (EPI == 3) {
+          const float* bb = ep.bias + nb * BN + wn * 64 + piece * 8;
+          half8 o;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] = (_Float16)fmaxf((float)v[k] + bb[k], 0.0f);
+          *reinterpret_cast<half8*>(yimg + ((size_t)gy * W + gx) * ys + piece * 8) = o;
         } else {
           const size_t pix = ((size_t)img * H + gy) * W + gx;
           const int c8 = wn * 64 + piece * 8;               // first of this lane's 8 channels inside the 128-block
@@ -630,4 +638,22 @@ extern "C" int gs_conv3x3_gru_q(const void* rnet, const void* x_rest, int x_rest
   if (lane_perm_enabled())
     return launch3x3<64, true, 2>(rnet, 128, c_in, wpack, nullptr, 0, 128, n, h, w, st, ep);
   return launch3x3<64, false, 2>(rnet, 128, c_in, wpack, nullptr, 0, 128, n, h, w, st, ep);
+}
+
+// 3x3 convolution + bias + ReLU in one kernel (EPI 3): corr_encoder[2] writing straight into its slice of the GRU input,
+// agg.conv2.  Same arithmetic as gs_conv3x3 followed by gs_bias_act(relu).  EXPERIMENTAL (opt-in from the host mirror).
+extern "C" int gs_conv3x3_bias_relu(const void* x, int x_stride, int c_in, const void* wpack, const float* bias, void* y,
+                                    int y_stride, int n_out, int n, int h, int w, gs_stream_t stream) {
+  GS_REQUIRE(x && wpack && bias && y, "conv3x3_bias_relu: null pointer");
+  GS_REQUIRE(c_in > 0 && c_in % 64 == 0, "conv3x3_bias_relu: c_in must be a multiple of 64");
+  GS_REQUIRE(n_out > 0 && n_out % BN == 0, "conv3x3_bias_relu: n_out must be a multiple of %d", BN);
+  GS_REQUIRE(x_stride >= c_in && x_stride % 8 == 0, "conv3x3_bias_relu: bad x_stride");
+  GS_REQUIRE(y_stride >= n_out && y_stride % 8 == 0, "conv3x3_bias_relu: bad y_stride");
+  GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3_bias_relu: bad shape");
+  if (n == 0) return GS_OK;
+  EpiArgs ep = EpiArgs();
+  ep.bias = bias;
+  hipStream_t st = (hipStream_t)stream;
+  if (lane_perm_enabled()) return launch3x3<64, true, 3>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, st, ep);
+  return launch3x3<64, false, 3>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, st, ep);
 }

@@ -187,8 +187,9 @@ CONV3X3_KC = "auto"
 # Row-stacked tiling (gs_conv3x3_stacked: no tile padding along the rows, tile width chosen per map width) -- opt-in
 # (GOSLAM_CONV3X3_STACKED=1) until it has been timed against the plain tiling; with it "auto" covers every map size.
 CONV3X3_STACKED = os.environ.get("GOSLAM_CONV3X3_STACKED", "0") == "1"
-# ConvGRU gate arithmetic fused into the z|r and q convolutions' epilogues (gs_conv3x3_gru_zr / _q): bit-identical to
-# conv + gate kernels by construction, parity-checked by emulation, not yet run on hardware -> opt-in.
+# Epilogues fused into the own 3x3 convolutions: the ConvGRU gate arithmetic (gs_conv3x3_gru_zr / _q) and bias + ReLU
+# (gs_conv3x3_bias_relu).  Bit-identical to conv + gate / bias_act kernels by construction, parity-checked by
+# emulation, not yet run on hardware -> opt-in.
 GRU_FUSED_EPILOGUE = os.environ.get("GOSLAM_GRU_FUSED", "0") == "1"
 _CONV3X3_PACKS = {}        # (data_ptr, version, shape, device, kc) -> (packed image, weight tensor kept alive)
 _CONV3X3_PACKS_MAX = 32
@@ -287,6 +288,19 @@ def conv_bias_act(cache, conv, x, act, out=None, out_channel=0):
     (PyTorch issues conv, add_(bias) and relu_ as three passes).  With `out` (an NHWC fp16 tensor
     with more channels) the result lands in out[:, out_channel:out_channel+C] -- no torch.cat."""
     w, b = cache.get(conv)
+    if GRU_FUSED_EPILOGUE and act == "relu" and w.shape[1] % 64 == 0 and _use_own_conv3x3(x, w, conv.stride, conv.padding):
+        from . import _lib
+        n, c, h, wd = x.shape
+        O = w.shape[0]
+        if out is None:
+            out, out_channel = torch.empty((n, O, h, wd), dtype=torch.float16, device=x.device,
+                                           memory_format=torch.channels_last), 0
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().gs_conv3x3_bias_relu(_lib.ptr(x), c, c, _lib.ptr(conv3x3_weight_image(w, 64)), _lib.ptr(b),
+                                                 out.data_ptr() + 2 * out_channel, out.shape[1], O, n, h, wd,
+                                                 _lib.stream_ptr(x.device))
+        _lib.check(rc, "conv3x3_bias_relu")
+        return out
     y = conv_nobias(x, w, conv.stride, conv.padding)
     return bias_act(y, b, act, out, out_channel)
 

@@ -193,6 +193,10 @@ int gs_conv3x3_stacked(const void* x, int x_stride, int c_in, const void* wpack,
  *     [n,h,w,384] or NULL.  Writes z_out = sigmoid(.) [n,h,w,128] and rnet_out = r * net [n,h,w,128]; hx is not modified.
  *   gs_conv3x3_gru_q: input [rnet (128 ch, dense) | x_rest (c_rest channels, pixels x_rest_stride apart)]; wpack = image
  *     of convq [128, 128 + c_rest, 3, 3] at kc = 64 (c_rest % 64 == 0); writes net_out = (1 - z) net + z tanh(.).   */
+/* gs_conv3x3 (kc = 64 image) + bias + ReLU in one kernel; y / y_stride may address a channel slice of a wider NHWC
+ * tensor (corr_encoder[2] -> the GRU input buffer, src/droid_net.py:76; agg.conv2, :41).  EXPERIMENTAL, opt-in.      */
+int gs_conv3x3_bias_relu(const void* x, int x_stride, int c_in, const void* wpack, const float* bias, void* y,
+                         int y_stride, int n_out, int n, int h, int w, gs_stream_t stream);
 int gs_conv3x3_gru_zr(const void* hx, int hx_stride, int c_in, const void* wpack, const float* bias_zr,
                       const float* glo_zr, const void* inp_pre, void* z_out, void* rnet_out, int n, int h, int w,
                       gs_stream_t stream);

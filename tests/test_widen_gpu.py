@@ -342,3 +342,31 @@ def test_fused_gru_epilogues_equal_conv_plus_gate_kernels(built_lib, hoisted):
         DN.CONV3X3_IMPL, DN.GRU_FUSED_EPILOGUE = keep
     assert torch.isfinite(out[True].float()).all()
     assert torch.equal(out[True], out[False])
+
+
+@pytest.mark.skipif(os.environ.get("GOSLAM_TEST_EXPERIMENTAL") != "1",
+                    reason="opt-in variant that has not run on hardware yet (tools/conv3x3_variants.sh sets the flag)")
+def test_fused_bias_relu_convolution_equals_conv_plus_bias_act(built_lib):
+    """gs_conv3x3_bias_relu (bias + ReLU in the convolution's store stage, output into a channel slice of a wider
+    tensor) vs gs_conv3x3 followed by gs_bias_act: EQUAL, and the other channels of the destination are untouched."""
+    import go_slam_amd.droid_net as DN
+    dev = "cuda:0"
+    torch.manual_seed(31)
+    conv = torch.nn.Conv2d(128, 128, 3, padding=1).to(dev)
+    cache = DN._HalfWeights()
+    x = torch.randn(6, 128, 32, 48, device=dev).half().contiguous(memory_format=torch.channels_last)
+    keep = (DN.CONV3X3_IMPL, DN.GRU_FUSED_EPILOGUE)
+    res = {}
+    try:
+        DN.CONV3X3_IMPL = "hip"
+        for fused in (False, True):
+            DN.GRU_FUSED_EPILOGUE = fused
+            hx = torch.full((6, 320, 32, 48), 3.0, device=dev, dtype=torch.float16).contiguous(
+                memory_format=torch.channels_last)
+            DN.conv_bias_act(cache, conv, x, "relu", out=hx, out_channel=128)
+            res[fused] = (hx, DN.conv_bias_act(cache, conv, x, "relu"))
+    finally:
+        DN.CONV3X3_IMPL, DN.GRU_FUSED_EPILOGUE = keep
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert bool((res[True][0][:, :128] == 3.0).all()) and bool((res[True][0][:, 256:] == 3.0).all())
+    assert float(res[True][1].min()) == 0.0 and float(res[True][1].max()) > 0.0

@@ -12,7 +12,7 @@ mkdir -p "$out"
 run() {   # name, env assignments...
   local name=$1; shift
   echo "== $name ($*)"
-  env "$@" timeout 90 python -m pytest tests/test_widen_gpu.py -q -x -k "conv3x3 or fused_gru" 2>&1 | tail -2 | tee "$out/$name.tests.txt"
+  env "$@" timeout 90 python -m pytest tests/test_widen_gpu.py -q -x -k "conv3x3 or fused_gru or fused_bias" 2>&1 | tail -2 | tee "$out/$name.tests.txt"
   env "$@" timeout 120 python tools/conv3x3_bench.py all 2>/dev/null | tee "$out/$name.bench.json"
   env "$@" timeout 60 python tools/update_ab.py 2>/dev/null | tail -1 | tee "$out/$name.update_ab.json"
 }
