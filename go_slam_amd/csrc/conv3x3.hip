@@ -3,8 +3,13 @@
 // corr_encoder[2] 128->128, the hoisted context gates 128->384; reference src/modules/gru.py:10-12,
 // src/droid_net.py:76,83-92,40) -- 1.27 TFLOP of an update's 1.6.
 //
-// Organisation (EXPERIMENTAL in round 1: opt-in through GOSLAM_CONV3X3=hip; MIOpen stays the default until this
-// kernel has been profiled):
+// Measured on MI355X (75 edges, 60x80 maps): 885 / 896 / 917 / 859 TFLOP/s on the four layers against MIOpen's 795 / 706 /
+// 792 / 658; the host mirror uses it wherever the 16x16 tiles fit the map (go_slam_amd/droid_net.py, CONV3X3_IMPL).
+// This file holds the verified kernels (conv3x3_kernel<KC, false>, conv3x3_stacked_kernel<KC, TW, false>) and, as
+// further template instantiations that leave those untouched instruction for instruction, the opt-in variants that
+// round 2 has to time: lane-permuted fragments (LP), XCD-aware block order, fused ConvGRU / bias+ReLU epilogues (EPI).
+//
+// Organisation:
 //  * a workgroup (4 waves) owns a 16x16-pixel tile x 128 output channels; K = 9 taps x C runs in chunks of 32
 //    input channels;
 //  * per chunk the 18x18-pixel input patch (20.7 KB) is staged in LDS ONCE and serves all 9 taps -- a generic
@@ -17,7 +22,7 @@
 //  * patch and weight planes are laid out [8-channel group][pixel | channel][8] so that 32 consecutive lanes read 32
 //    consecutive 16-byte vectors (bank-conflict free);
 //  * the epilogue goes through a wave-private LDS tile so that global stores are 128 B per pixel (8 lanes x 16 B).
-// LDS: 37 KB per workgroup; 2 workgroups per CU at <= 256 VGPRs.
+// LDS: 37 KB (KC = 32) / 74 KB (KC = 64) per workgroup; 2 workgroups per CU at 210-234 VGPRs, no spills.
 #include "common.h"
 #include <stdlib.h>
 
