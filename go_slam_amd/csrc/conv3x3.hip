@@ -19,8 +19,9 @@
 //  * weights are the MFMA A operand (rows = output channels), pixels the B operand: a wave's 64-channel x 128-pixel
 //    register tile needs 2 + 4 LDS fragment reads per 8 MFMAs (24 B/clk/wave), and the accumulator layout gives each
 //    lane 4 consecutive channels of one pixel -- packed 8-byte LDS writes in the epilogue;
-//  * patch and weight planes are laid out [8-channel group][pixel | channel][8] so that 32 consecutive lanes read 32
-//    consecutive 16-byte vectors (bank-conflict free);
+//  * patch and weight planes are laid out [8-channel group][pixel | channel][8]: a weight-fragment read is 32
+//    consecutive 16-byte vectors per half-wave (conflict-free); a pixel-fragment read is two 16-pixel rows 18 slots
+//    apart, which ds_read_b128's service groups turn into a 2-way conflict -- removed by the LP instantiations;
 //  * the epilogue goes through a wave-private LDS tile so that global stores are 128 B per pixel (8 lanes x 16 B).
 // LDS: 37 KB (KC = 32) / 74 KB (KC = 64) per workgroup; 2 workgroups per CU at 210-234 VGPRs, no spills.
 #include "common.h"
