@@ -198,3 +198,27 @@ def test_proximity_proposal_corner_cases():
     es = FactorGraph.propose_proximity_edges(d2, [(3, 1)], 2, 0, 6, 1, 1, 16.0, 100, False)
     assert es[8:10] == [(5, 0), (0, 5)]
     assert all(e != (3, 1) and e != (2, 0) for e in es[8:])         # existing edge and its NMS neighbourhood
+
+
+def test_lowmem_index_chunks_and_cache():
+    """_lowmem_index: 13-keyframe chunks by source keyframe (empty chunks skipped), rig-strided alt-corr indices with
+    the right view for stereo pairs, per-chunk unique sources, BA window / damping rows as the reference derives them
+    (src/factor_graph.py:262-300), cached per edge-list version."""
+    g = _graph()
+    g.ii = torch.tensor([2, 2, 3, 16, 16, 40, 40, 67])                 # no source keyframe in [41, 54) and [54, 67)
+    g.jj = torch.tensor([3, 2, 2, 15, 17, 39, 40, 40])
+    c = g._lowmem_index(None, None, 2)
+    assert (c["t0"], c["t1"]) == (3, 68)
+    sels = [ck["sel"].tolist() for ck in c["chunks"]]
+    assert sels == [[0, 1, 2], [3, 4], [5, 6], [7]]                     # sources in [2,15) [15,28) [28,41) [41,54)
+    first = c["chunks"][0]
+    assert first["corr_ii"].tolist() == [4, 4, 6] and first["corr_jj"].tolist() == [6, 5, 4]    # (2,2) is a stereo pair
+    assert [ck["uniq"].tolist() for ck in c["chunks"]] == [[2, 3], [16], [40], [67]]
+    want = torch.unique(torch.cat([torch.arange(3, 68), g.ii]))
+    assert torch.equal(c["damping_index"], want)
+    assert g._lowmem_index(None, None, 2) is c
+    assert g._lowmem_index(None, None, 1) is not c                     # different rig
+    d = g._lowmem_index(5, 30, 2)
+    assert (d["t0"], d["t1"]) == (5, 30)
+    g.ii = g.ii.clone()                                                # replaced tensor -> new index
+    assert g._lowmem_index(5, 30, 2) is not d
