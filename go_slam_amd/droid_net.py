@@ -1,9 +1,10 @@
-"""Update operator of the tracker (host side, PyTorch-ROCm / MIOpen convolutions).
+"""Update operator of the tracker (host side: PyTorch-ROCm module tree over the package's HIP kernels).
 
 Mirrors the module tree of the reference's `DroidNet.update` (src/droid_net.py:70-140,
 src/modules/gru.py:5-33, src/droid_net.py:34-67) so that a `droid.pth` state dict loads with
 the same keys: update.{corr_encoder,flow_encoder,weight,delta,gru,agg}.  SURVEY.md 8(a5): these
-convolutions stay ATen/MIOpen; the hand-written HIP kernels are the ops around them.
+convolutions were to stay ATen/MIOpen; since the end of round 1 the large 3x3 ones run on the package's own
+implicit-GEMM kernel (gs_conv3x3, see CONV3X3_IMPL below) and MIOpen keeps the rest.
 
 `torch_scatter.scatter_mean` (absent in this image) is replaced by an index_add segment mean.
 """
@@ -284,7 +285,7 @@ def conv_nobias(x, w, stride=1, padding=0):
 
 
 def conv_bias_act(cache, conv, x, act, out=None, out_channel=0):
-    """act(conv(x) + bias) for NHWC fp16 x: bias-free MIOpen convolution + one fused HIP epilogue
+    """act(conv(x) + bias) for NHWC fp16 x: bias-free convolution (gs_conv3x3 or MIOpen) + one fused HIP epilogue
     (PyTorch issues conv, add_(bias) and relu_ as three passes).  With `out` (an NHWC fp16 tensor
     with more channels) the result lands in out[:, out_channel:out_channel+C] -- no torch.cat."""
     w, b = cache.get(conv)
@@ -359,7 +360,7 @@ class ConvGRU(nn.Module):
         return self._hw
 
     def _forward_fused(self, net, inputs):
-        """Same mathematics as forward(); the 3x3 convolutions stay MIOpen, everything between them is
+        """Same mathematics as forward(); the 3x3 convolutions go through conv_nobias, everything between them is
         HIP (gs_gru_glo, gs_gru_gate_zr, gs_gru_gate_q) and ONE 448-channel cat."""
         hx = torch.cat([net, *inputs], dim=1)
         if not hx.is_contiguous(memory_format=torch.channels_last):
@@ -517,7 +518,7 @@ class UpdateModule(nn.Module):
         return self._heads
 
     def _forward_fast(self, net, inp, corr, flow, ii, jj, seg=None):
-        """forward() on the inference path: bias-free MIOpen convolutions, each followed by one HIP
+        """forward() on the inference path: bias-free convolutions (gs_conv3x3 / MIOpen), each followed by one HIP
         epilogue (bias + activation, written straight into the next consumer's buffer -- no torch.cat),
         the context-feature part of the GRU convolutions hoisted out of the update loop, the three
         128->128 head convolutions merged into one; same mathematics, fp16 NHWC throughout."""

@@ -2,7 +2,8 @@
 (mirrors src/factor_graph.py:24-252 for the volume-correlation frontend path).
 
 update() = reproject (HIP) -> motion features -> 4-level corr lookup (HIP, one launch) ->
-UpdateModule (MIOpen convs) -> dense BA (HIP, no host round trips) -> convex upsampling.
+UpdateModule (gs_conv3x3 / MIOpen convolutions + HIP epilogues) -> dense BA (HIP, no host round trips) -> convex
+upsampling.
 """
 import torch
 
