@@ -58,6 +58,7 @@ SIGNATURES = {
     "gs_grid_meta_default": (c_int, [_P]),
     "gs_render_sample": (c_int, [_P] * 7 + [c_float, _P, _P, _P] + [c_int] * 3 + [_P]),
     "gs_grid_encode": (c_int, [_P] * 4 + [c_int, _P]),
+    "gs_grid_backward": (c_int, [_P, _P, _P, c_int, c_float, _P, _P, c_int, c_float, _P, _P, c_int, _P]),
     "gs_mlp_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gs_mlp_forward": (c_int, [_P] * 3 + [c_int] * 3 + [_P, c_size_t, _P]),
     "gs_neus_forward_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -187,18 +187,6 @@ __global__ __launch_bounds__(256) void render_sample_wave_kernel(
 // ---------------------------------------------------------------------------------------
 // hash grid
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t grid_index(const gs_grid_meta& m, int l, uint32_t cx, uint32_t cy, uint32_t cz) {
-  const uint32_t size = m.size[l];
-  uint32_t idx;
-  if (m.hashed[l]) {
-    idx = (cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u);
-  } else {
-    const uint32_t res = m.resolution[l];
-    idx = cx + cy * res + cz * res * res;
-  }
-  return idx % size;
-}
-
 // One level: value (2 features) and d value / d x (3 x 2), tcnn accumulation order.
 __device__ __forceinline__ void grid_level(const gs_grid_meta& m, int l, const _Float16* __restrict__ grid,
                                            const float x[3], float val[2], float dv[3][2], bool want_grad) {

@@ -114,18 +114,6 @@ __global__ __launch_bounds__(256) void neus_ray_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t grid_index(const gs_grid_meta& m, int l, uint32_t cx, uint32_t cy, uint32_t cz) {
-  const uint32_t size = m.size[l];
-  uint32_t idx;
-  if (m.hashed[l]) {
-    idx = (cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u);
-  } else {
-    const uint32_t res = m.resolution[l];
-    idx = cx + cy * res + cz * res * res;
-  }
-  return idx % size;
-}
-
 struct BwdArgs {
   const float* rays_o; const float* rays_d; const float* z_vals; const float* dists;
   const _Float16* grid; const float* sdf_w; const float* color_B;
@@ -137,85 +125,6 @@ struct BwdArgs {
   int rows16; float row_scale; int dx16; float dx_inv_scale; int row_stride16;
   int n, s;
 };
-
-// Scatter one level's 8 corners x 2 features.  Lanes are consecutive samples of a ray, so
-// neighbours often sit in the SAME cell (always at the coarse levels): runs of equal cells are
-// pre-reduced inside the wave with a segmented scan and only the run's last lane issues atomics --
-// at the coarse levels this removes ~10x of the (memory-side, heavily contended) atomic traffic.
-// `tab16` != nullptr: tiny-cuda-nn's own accumulation mode -- the table gradient is fp16, both features
-// of an entry go out as ONE packed atomic (global_atomic_pk_add_f16), pre-multiplied by the loss scale
-// (tcnn: 128) so that small contributions stay above fp16's subnormal range; half the atomic count.
-typedef _Float16 half2a __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void lvl_scatter(float* __restrict__ tab, _Float16* __restrict__ tab16, float scale16,
-                                            const uint32_t (&cidx)[8], float (&gacc)[8][2],
-                                            const uint32_t (&gi)[3], bool on, int lane) {
-  const uint32_t p0 = __shfl_up(gi[0], 1, 64), p1 = __shfl_up(gi[1], 1, 64), p2 = __shfl_up(gi[2], 1, 64);
-  const int on_prev = __shfl_up((int)on, 1, 64);
-  const bool same = (lane > 0) && on && on_prev && p0 == gi[0] && p1 == gi[1] && p2 == gi[2];
-  const unsigned long long same_mask = __ballot(same);
-  bool tail = true;
-  if (same_mask != 0ull) {                            // wave-uniform
-    const unsigned long long starts = ~same_mask;     // bit set where a run begins
-    const unsigned long long below = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-    const int run_start = 63 - __builtin_clzll(below);
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const bool take = (lane - off) >= run_start;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float u0 = __shfl_up(gacc[c][0], off, 64), u1 = __shfl_up(gacc[c][1], off, 64);
-        if (take) { gacc[c][0] += u0; gacc[c][1] += u1; }
-      }
-    }
-    tail = (lane == 63) || (((starts >> (lane + 1)) & 1ull) != 0ull);
-  }
-  if (tab16) {
-    // The atomics are executed memory-side: every (lane, address) pair that is not merged in the TA costs a
-    // fabric transaction, and 128 of them per point are what bound this kernel.  The two x-neighbours of a
-    // cell (corners c, c^1) are ADJACENT table entries whenever the level is dense or x is even (the hash
-    // multiplies x by 1), so lanes 2i / 2i+1 issue them in the SAME instruction -- first for point 2i, then
-    // for point 2i+1 -- which lets the hardware merge the pair into one 64-byte request.
-    const bool act = on && tail;
-#pragma unroll
-    for (int cp = 0; cp < 4; ++cp) {
-      const int c0 = 2 * cp, c1 = 2 * cp + 1;
-      const half2a v0 = {(_Float16)(gacc[c0][0] * scale16), (_Float16)(gacc[c0][1] * scale16)};
-      const half2a v1 = {(_Float16)(gacc[c1][0] * scale16), (_Float16)(gacc[c1][1] * scale16)};
-      const int u0 = __builtin_bit_cast(int, v0), u1 = __builtin_bit_cast(int, v1);
-      const int a0 = (act && (gacc[c0][0] != 0.0f || gacc[c0][1] != 0.0f)) ? 1 : 0;
-      const int a1 = (act && (gacc[c1][0] != 0.0f || gacc[c1][1] != 0.0f)) ? 1 : 0;
-      const int i0 = (int)cidx[c0], i1 = (int)cidx[c1];
-      const bool odd = lane & 1;
-      // round A: point 2i -- even lane its own c0, odd lane the even neighbour's c1
-      {
-        const int ni = __builtin_amdgcn_mov_dpp(i1, 0xA0, 0xf, 0xf, true);     // quad_perm [0,0,2,2]
-        const int nu = __builtin_amdgcn_mov_dpp(u1, 0xA0, 0xf, 0xf, true);
-        const int na = __builtin_amdgcn_mov_dpp(a1, 0xA0, 0xf, 0xf, true);
-        const int idx = odd ? ni : i0, uu = odd ? nu : u0, aa = odd ? na : a0;
-        if (aa)
-          __builtin_amdgcn_global_atomic_fadd_v2f16(
-              (__attribute__((address_space(1))) half2a*)(tab16 + (size_t)(uint32_t)idx * 2), __builtin_bit_cast(half2a, uu));
-      }
-      // round B: point 2i+1 -- odd lane its own c1, even lane the odd neighbour's c0
-      {
-        const int ni = __builtin_amdgcn_mov_dpp(i0, 0xF5, 0xf, 0xf, true);     // quad_perm [1,1,3,3]
-        const int nu = __builtin_amdgcn_mov_dpp(u0, 0xF5, 0xf, 0xf, true);
-        const int na = __builtin_amdgcn_mov_dpp(a0, 0xF5, 0xf, 0xf, true);
-        const int idx = odd ? i1 : ni, uu = odd ? u1 : nu, aa = odd ? a1 : na;
-        if (aa)
-          __builtin_amdgcn_global_atomic_fadd_v2f16(
-              (__attribute__((address_space(1))) half2a*)(tab16 + (size_t)(uint32_t)idx * 2), __builtin_bit_cast(half2a, uu));
-      }
-    }
-  } else if (on && tail) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float* gp = tab + (size_t)cidx[c] * 2;
-      if (gacc[c][0] != 0.0f) atomicAdd(gp, gacc[c][0]);
-      if (gacc[c][1] != 0.0f) atomicAdd(gp + 1, gacc[c][1]);
-    }
-  }
-}
 
 // 8 consecutive entries of row i of dX (fp32, or loss-scaled fp16 straight from the MLP-backward GEMM)
 __device__ __forceinline__ void load_dx8(const BwdArgs& A, int i, int c, float* out) {

@@ -142,8 +142,9 @@ void neus_mlp_bwd_kernel(const _Float16* __restrict__ X, const _Float16* __restr
     if (hf == 0) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float y = (float)rgb[pc * 3 + k];
-        const float v = valid ? d_rgb[pc * 3 + k] * y * (1.0f - y) * loss_scale : 0.0f;
+        const float y = rgb ? (float)rgb[pc * 3 + k] : 0.0f;
+        const float dact = rgb ? y * (1.0f - y) : 1.0f;     // rgb == NULL: d_rgb is w.r.t. the raw outputs
+        const float v = valid ? d_rgb[pc * 3 + k] * dact * loss_scale : 0.0f;
         bdp[k] = (_Float16)v;
         DP[k * TS + r] = bdp[k];
       }
@@ -294,7 +295,7 @@ extern "C" int gs_mlp_backward_blocks(int n) {
 
 extern "C" int gs_mlp_backward(const void* x, const void* wpack, const float* d_rgb, const void* rgb, float loss_scale,
                                void* dx, float* partial, int n, gs_stream_t stream) {
-  GS_REQUIRE(x && wpack && d_rgb && rgb && dx && partial, "mlp_backward: null pointer");
+  GS_REQUIRE(x && wpack && d_rgb && dx && partial, "mlp_backward: null pointer");
   GS_REQUIRE(n >= 0 && loss_scale > 0.0f, "mlp_backward: bad arguments");
   if (n == 0) return GS_OK;
   const int nblk = (n + 31) / 32;

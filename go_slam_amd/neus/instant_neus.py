@@ -15,7 +15,8 @@ import torch.nn as nn
 
 from .. import _lib
 from ..droid_backends import _workspace
-from .tcnn_compat import Encoding as TcnnEncoding, Network as TcnnNetwork, _require_inference
+from .tcnn_compat import (Encoding as TcnnEncoding, Network as TcnnNetwork, _mlp_fragment_index,  # noqa: F401
+                          _pack_mlp_fragments)
 
 
 class Encoding(nn.Module):
@@ -339,43 +340,6 @@ def _colsum(A, chunk=8192):
     """Column sums of a tall matrix via the same split (a strided torch.sum(0) takes 18 ms here)."""
     ones = torch.ones(A.shape[0], 8 if A.dtype == torch.float16 else 1, dtype=A.dtype, device=A.device)
     return _tn(ones, A, chunk)[0].reshape(-1)
-
-
-_FRAG_INDEX = {}
-
-
-def _mlp_fragment_index(device):
-    """Gather indices that turn tcnn's parameter vector (+ one trailing zero) into the 40 MFMA A-fragments of
-    gs_mlp_backward ([40,64,8], see include/goslam_neus.h); built once per device."""
-    idx = _FRAG_INDEX.get(device)
-    if idx is not None:
-        return idx
-    import numpy as np
-    ZERO = 10240
-    l = np.arange(64)[:, None]
-    e = np.arange(8)[None, :]
-    r, kk = (l & 31), 8 * (l >> 5) + e                       # row within the 32-row block, k within the 16-wide step
-    frags = []
-
-    def add(n_mt, n_ks, fn):
-        for mt in range(n_mt):
-            for ks in range(n_ks):
-                frags.append(fn(32 * mt + r + 0 * kk, 16 * ks + kk + 0 * r))
-    add(2, 5, lambda row, k: row * 80 + k)                                     # W1
-    add(2, 4, lambda row, k: 5120 + row * 64 + k)                               # W2
-    add(2, 1, lambda row, k: 9216 + k * 64 + row)                               # W3^T
-    add(2, 4, lambda row, k: 5120 + k * 64 + row)                               # W2^T
-    add(3, 4, lambda row, k: np.where(row < 80, k * 80 + row, ZERO))            # W1^T, rows padded to 96
-    idx = torch.from_numpy(np.stack(frags).astype(np.int64).reshape(-1)).to(device)
-    assert idx.numel() == 40 * 64 * 8
-    _FRAG_INDEX[device] = idx
-    return idx
-
-
-def _pack_mlp_fragments(W):
-    """One gather: [10240] fp16 parameters -> [40,64,8] fp16 fragments."""
-    ext = torch.cat([W.reshape(-1), W.new_zeros(1)])
-    return ext[_mlp_fragment_index(W.device)].view(40, 64, 8)
 
 
 class _NeusRenderFn(torch.autograd.Function):

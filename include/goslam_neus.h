@@ -50,6 +50,23 @@ int gs_render_sample(const float* rays_o, const float* rays_d, const float* gt_d
 int gs_grid_encode(const float* x, const void* grid, void* out, float* dy_dx, int n,
                    gs_stream_t stream);
 
+/* Backward passes of tcnn.Encoding (the autograd the reference drives at src/InstantNeuS.py:134-148: the encoding is
+ * differentiated w.r.t. x with create_graph=True on EVERY forward, and that gradient is differentiated again by
+ * loss.backward()).  x f32 [n,3] in [0,1]; dy [n,32] f16 or f32 (dy_dtype), read as dy * dy_scale; grid f16
+ * [total*2] (may be NULL when neither dx nor ddy is requested).
+ *   v == NULL -- first order (tcnn kernel_grid_backward / kernel_grid_backward_input):
+ *       grid_grad += sum_points w_corner(x) * dy     (atomically accumulated; zero it first; NULL = skip)
+ *       dx f32 [n,3] = sum_c dy_c * d y_c / d x      (NULL = skip)
+ *   v f32 [n,3] = d L / d (dx) -- second order (tcnn kernel_grid_backward_input_backward_*):
+ *       ddy f32 [n,32] = (d y / d x) . v             (d L / d dy; NULL = skip)
+ *       grid_grad += dy * sum_d v_d * d w_corner / d x_d
+ *       dx f32 [n,3] = sum_c dy_c * (d^2 y_c / dx dx) v   (trilinear interpolation: mixed terms only)
+ * grid_grad dtype GS_F32, or GS_F16 = tcnn's own mode (one packed fp16 atomic per table entry); every
+ * contribution is multiplied by grid_grad_scale (tcnn's loss scale; the caller divides it out).       */
+int gs_grid_backward(const float* x, const void* grid, const void* dy, int dy_dtype, float dy_scale,
+                     const float* v, void* grid_grad, int grid_grad_dtype, float grid_grad_scale,
+                     float* dx, float* ddy, int n, gs_stream_t stream);
+
 /* tcnn.Network.__call__ (src/InstantNeuS.py:192,201): FullyFusedMLP n_in(->80, padded with
  * ones)->64->64->n_out(->16), ReLU, no bias; mlp f16 [64*80+64*64+16*64] row-major [out,in] per
  * layer; x f16 [n,n_in] -> out f16 [n,n_out].  Workspace only needed when n_in != 80.         */
@@ -91,7 +108,8 @@ int gs_neus_backward_rays(const float* alpha, const void* rgb, const float* z_mi
 /* Backward of the fused colour MLP (tcnn FullyFusedMLP 67(->80)->64->64->3(->16), ReLU, sigmoid output) in ONE
  * kernel: recomputes H1, H2 as gs_mlp_forward does, then dX and the three weight gradients on MFMA.
  *   x f16 [n,80] (the saved MLP input rows), d_rgb f32 [n,3] (gradient w.r.t. the sigmoid outputs), rgb f16
- *   [n,3] (the saved outputs), loss_scale (tcnn: 128) multiplies every gradient that travels in fp16.
+ *   [n,3] (the saved outputs; NULL = no output activation, d_rgb is the gradient w.r.t. the raw network outputs,
+ *   which is tcnn.Network's own contract: `output_activation: none`, src/InstantNeuS.py:184-192), loss_scale (tcnn: 128) multiplies every gradient that travels in fp16.
  *   wpack f16 [40][64][8]: MFMA A-fragments A[l][e] = M[32 mt + (l&31)][16 ks + 8 (l>>5) + e] of, in this
  *   order, M = W1 (mt<2, ks<5), W2 (mt<2, ks<4), W3^T (mt<2, ks=0), W2^T (mt<2, ks<4), W1^T zero-padded to 96
  *   rows (mt<3, ks<4), each block mt-major.

@@ -32,9 +32,11 @@ def _index(meta, l, c):
     return idx % size
 
 
-def grid_encode_diff(x, grid, meta):
-    """x [n,3] in [0,1] (treated as constant), grid f32 [total*2] (differentiable, used as its fp16
-    rounding).  Returns enc [n,32] (fp16-rounded, STE) and dydx [n,32,3] (differentiable in grid)."""
+def grid_encode_diff(x, grid, meta, x_differentiable=False):
+    """x [n,3] in [0,1] (treated as constant unless x_differentiable), grid f32 [total*2] (differentiable,
+    used as its fp16 rounding).  Returns enc [n,32] (fp16-rounded, STE) and dydx [n,32,3] (differentiable
+    in grid; with x_differentiable also in x: the mixed second derivatives of the trilinear interpolation,
+    tiny-cuda-nn's kernel_grid_backward_input_backward_input)."""
     n = x.shape[0]
     g16 = _ste_half(grid).view(-1, 2)
     encs, dys = [], []
@@ -45,6 +47,8 @@ def grid_encode_diff(x, grid, meta):
         pos = (xd.double() * scale + 0.5).float()
         gfl = torch.floor(pos)
         f = pos - gfl
+        if x_differentiable:      # same values; d f / d x = scale inside a cell (tcnn's input gradients)
+            f = f + (x - xd) * scale
         gi = gfl.to(torch.int64)
         vals = []
         for corner in range(8):
