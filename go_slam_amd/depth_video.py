@@ -1,34 +1,58 @@
-"""Keyframe state buffers + the three hot-path methods of the reference's DepthVideo
-(src/depth_video.py:207-269): `reproject`, `distance`, `ba` keep their signatures and
-semantics; the native callees are the HIP kernels behind `go_slam_amd.droid_backends`.
+"""Keyframe state buffers + the hot-path methods of the reference's DepthVideo (src/depth_video.py): `reproject`,
+`distance`, `ba`, `upsample` keep their signatures and semantics; the native callees are the HIP kernels behind
+`go_slam_amd.droid_backends`.
 
-This host mirror holds only what the hot path touches (poses, disps, disps_sens, intrinsics,
-fmaps/nets/inps, disps_up); process-sharing flags and the mapping hand-off of the reference's
-class are orchestration (out of scope).
+Construction follows the reference: `DepthVideo(cfg, args)` (src/depth_video.py:12-71) allocates every state /
+feature / hand-off buffer on `args.device`, marks them `share_memory_()` (HIP IPC once the object crosses a
+`torch.multiprocessing` spawn), and carries the `multiprocessing.Value` counter and lock flags (`counter`, `ready`,
+`mapping`, `ba_lock['dense'|'loop']`, `global_ba_lock`) that `src/slam.py` and the workers read.  `ht` / `wd` are the
+FULL-resolution size as there; the 1/8-resolution map size the kernels work on is `map_ht` / `map_wd`
+(= `disps.shape[-2:]`).  `DepthVideo(h8, w8, buffer=..., device=...)` is a light single-process form for benches and
+kernel tests: same attributes, counter still a `Value`, only the 1/8-resolution buffers unless `full_res=True`.
 """
 import torch
+import torch.multiprocessing as _mp
 
 from . import droid_backends
 from .droid_net import cvx_upsample
 
 
 class DepthVideo:
-    def __init__(self, ht, wd, buffer=512, device="cuda:0", stereo=False, full_res=False):
-        """`full_res`: also keep the per-keyframe full-resolution buffers of the reference (images, depths_gt,
-        poses_gt; src/depth_video.py:41-49) that MotionFilter.track fills -- 8h x 8w, allocated only on request."""
+    def __init__(self, cfg_or_ht, args_or_wd, buffer=512, device="cuda:0", stereo=False, full_res=False):
+        if isinstance(cfg_or_ht, int):       # light form: 1/8-resolution map size given directly
+            self.cfg, self.args = None, None
+            mh, mw = int(cfg_or_ht), int(args_or_wd)
+            shared = False
+        else:                                 # the reference's constructor: DepthVideo(cfg, args)
+            cfg, args = cfg_or_ht, args_or_wd
+            self.cfg, self.args = cfg, args
+            mh, mw = cfg["cam"]["H_out"] // 8, cfg["cam"]["W_out"] // 8
+            buffer, device = cfg["tracking"]["buffer"], args.device
+            stereo = (cfg["mode"] == "stereo")
+            full_res, shared = True, True
         self.device = torch.device(device)
-        self.ht, self.wd = ht, wd            # 1/8-resolution map size
+        self.scale_factor = 8
+        self.map_ht, self.map_wd = mh, mw
+        self.ht, self.wd = (cfg["cam"]["H_out"], cfg["cam"]["W_out"]) if self.cfg is not None else (8 * mh, 8 * mw)
+        self.stereo = stereo
+        # keyframe count and the cross-process flags (src/depth_video.py:17-25).  The reference creates them after
+        # run.py:57 set the start method to "spawn" (HIP / CUDA tensors cannot cross a fork); taking them from the
+        # spawn context here makes the object picklable into spawned workers whatever the global default is.
+        Value = _mp.get_context("spawn").Value
+        self._counter = Value("i", 0)
+        self.ready = Value("i", 0)
+        self.mapping = Value("i", 0)
+        self.ba_lock = {"dense": Value("i", 0), "loop": Value("i", 0)}
+        self.global_ba_lock = Value("i", 0)
         d = self.device
         c = 2 if stereo else 1
-        self.counter = 0                     # int here; a multiprocessing.Value (`.value`) is accepted too
-        self.stereo = stereo
-        H, W = 8 * ht, 8 * wd
+        H, W = self.ht, self.wd
         f32, f16 = torch.float32, torch.half
         # name -> (per-keyframe shape, dtype, fill): the 1/8-resolution state the hot path reads and writes ...
-        table = {"timestamp": ((), f32, 0), "poses": ((7,), f32, 0), "disps": ((ht, wd), f32, 1),
-                 "disps_sens": ((ht, wd), f32, 0), "disps_up": ((H, W), f32, 0), "intrinsics": ((4,), f32, 0),
-                 "fmaps": ((c, 128, ht, wd), f16, 0), "nets": ((128, ht, wd), f16, 0), "inps": ((128, ht, wd), f16, 0),
-                 "dirty": ((), torch.bool, 0)}
+        table = {"timestamp": ((), f32, 0), "poses": ((7,), f32, 0), "disps": ((mh, mw), f32, 1),
+                 "disps_sens": ((mh, mw), f32, 0), "disps_up": ((H, W), f32, 0), "intrinsics": ((4,), f32, 0),
+                 "fmaps": ((c, 128, mh, mw), f16, 0), "nets": ((128, mh, mw), f16, 0), "inps": ((128, mh, mw), f16, 0),
+                 "dirty": ((), torch.bool, 0), "red": ((), torch.bool, 0)}
         if full_res:   # ... and the full-resolution / tracker -> mapper hand-off buffers (src/depth_video.py:41-69)
             table.update({"images": ((3, H, W), f32, 0), "depths_gt": ((H, W), f32, 0), "poses_gt": ((4, 4), f32, 0),
                           "poses_filtered": ((7,), f32, 0), "disps_filtered": ((H, W), f32, 0),
@@ -36,33 +60,47 @@ class DepthVideo:
         for name, (shape, dtype, fill) in table.items():
             setattr(self, name, torch.full((buffer,) + shape, fill, device=d, dtype=dtype))
         self.poses[:, 6] = 1.0               # identity: t = 0, q = (0, 0, 0, 1)
+        extra = []
         if full_res:
             self.poses_gt[:] = torch.eye(4, device=d)
             self.poses_filtered[:, 6] = 1.0
-            self.scale_factor = 8
             self.filtered_id = torch.tensor([-1], dtype=torch.int32, device=d)      # written by MultiviewFilter
             self.bound = torch.zeros(1, 3, 2, device=d, dtype=f32)
             self.pose_compensate = torch.tensor([[0, 0, 0, 0, 0, 0, 1.0]], device=d)
+            extra = ["filtered_id", "bound", "pose_compensate"]
+        if shared:     # every buffer but `images` is shared with the other workers (src/depth_video.py:39-71)
+            for name in list(table) + extra:
+                if name != "images":
+                    getattr(self, name).share_memory_()
 
     @classmethod
     def from_config(cls, cfg, args):
         """the reference's constructor form DepthVideo(cfg, args) (src/depth_video.py:13-36)."""
-        return cls(cfg["cam"]["H_out"] // 8, cfg["cam"]["W_out"] // 8, buffer=cfg["tracking"]["buffer"],
-                   device=args.device, stereo=(cfg["mode"] == "stereo"), full_res=True)
+        return cls(cfg, args)
 
     def get_lock(self):
-        """single-process host mirror: nothing to lock (the reference guards IPC-shared buffers)."""
-        import contextlib
-        return contextlib.nullcontext()
+        return self.counter.get_lock()
+
+    def get_ba_lock(self, ba_type):
+        return self.ba_lock[ba_type].get_lock()
+
+    def get_mapping_lock(self):
+        return self.mapping.get_lock()
+
+    @property
+    def counter(self):
+        """keyframe count: a `multiprocessing.Value` (`.value`, `.get_lock()`), as src/depth_video.py:17."""
+        return self._counter
+
+    @counter.setter
+    def counter(self, n):       # `video.counter = n` (benches, tests) writes through to the shared value
+        self._counter.value = int(getattr(n, "value", n))
 
     def _count(self):
-        return int(getattr(self.counter, "value", self.counter))
+        return int(self._counter.value)
 
     def _set_count(self, n):
-        if hasattr(self.counter, "value"):
-            self.counter.value = int(n)
-        else:
-            self.counter = int(n)
+        self._counter.value = int(n)
 
     def __setitem__(self, index, item):
         """item = (timestamp, image, pose | None, disp | None, depth | None, intrinsics | None[, fmap, net, inp,
@@ -140,7 +178,7 @@ class DepthVideo:
     def upsample(self, ix, mask):
         """disps_up[ix] = cvx_upsample(disps[ix], mask) (src/depth_video.py:194-196).  fp16 masks go
         through the fused HIP kernel (no gather / unfold / softmax / index_put passes)."""
-        m = mask.reshape(-1, 576, self.ht, self.wd)
+        m = mask.reshape(-1, 576, self.map_ht, self.map_wd)
         if m.dtype == torch.float16 and m.is_cuda:
             cl = m.is_contiguous(memory_format=torch.channels_last)
             if not cl:
@@ -149,7 +187,7 @@ class DepthVideo:
             from . import _lib
             with torch.cuda.device(self.device):
                 rc = _lib.lib().gs_cvx_upsample(_lib.ptr(self.disps), _lib.ptr(m), _lib.ptr(ix),
-                                                _lib.ptr(self.disps_up), ix.numel(), self.ht, self.wd, int(cl),
+                                                _lib.ptr(self.disps_up), ix.numel(), self.map_ht, self.map_wd, int(cl),
                                                 _lib.stream_ptr(self.device))
             _lib.check(rc, "DepthVideo.upsample")
             return
@@ -163,7 +201,7 @@ class DepthVideo:
 
     def distance(self, ii=None, jj=None, beta=0.3, bidirectional=True):
         return_matrix = False
-        N = int(getattr(self.counter, "value", self.counter))
+        N = self._count()
         if ii is None:
             return_matrix = True
             ii, jj = torch.meshgrid(torch.arange(N), torch.arange(N), indexing="ij")

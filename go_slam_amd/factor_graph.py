@@ -30,7 +30,9 @@ class FactorGraph:
         self.max_factors = max_factors
         self.corr_impl = corr_impl
         self.upsample = upsample
-        self.ht, self.wd = video.ht, video.wd
+        # 1/8-resolution map size, read off the buffers: unambiguous for this package's DepthVideo and for a
+        # reference-style video object alike (whose .ht is the full-resolution height, src/factor_graph.py:19-20)
+        self.ht, self.wd = (int(x) for x in video.disps.shape[-2:])
         self.coords0 = coords_grid(self.ht, self.wd, self.device)
         z = lambda *s: torch.zeros(*s, device=self.device)
         self.ii = torch.zeros(0, dtype=torch.long, device=self.device)

@@ -61,6 +61,11 @@ def test_encoding_autograd_first_and_second_order(T, O, dev, grad_dtype):
     A = torch.randn(n, 32, generator=g)            # weights of the value path
     c = torch.randn(32, generator=g)               # upstream of the autograd.grad call (the reference: W[0,3:])
     B = torch.randn(n, 3, generator=g)             # weights of the gradient path
+    if grad_dtype == torch.float16:
+        # tcnn's own accumulation mode: fp16 table gradient under a loss scale of 128.  d w / d x reaches the level
+        # scale (4096 at the finest level), so O(1) upstream gradients overflow fp16 there exactly as they do in
+        # tiny-cuda-nn; realistic loss gradients (per-ray means) are orders of magnitude smaller.
+        A, B = A * 0.05, B * 1e-3
 
     # ---- oracle: everything through torch.autograd on the differentiable restatement
     go = grid.clone().requires_grad_(True)

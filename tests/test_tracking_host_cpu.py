@@ -102,7 +102,7 @@ def test_depth_video_item_setter_and_normalize():
     intr = torch.tensor([10.0, 11.0, 3.0, 2.0])
     ident = torch.tensor([0, 0, 0, 0, 0, 0, 1.0])
     v.append(0.5, img, ident, 1.0, depth, intr, fmap, net_, inp_, torch.eye(4) * 2)
-    assert v.counter == 1 and float(v.timestamp[0]) == 0.5
+    assert v.counter.value == 1 and float(v.timestamp[0]) == 0.5
     sub = depth[3::8, 3::8]
     want = torch.where(sub > 0, 1.0 / sub, sub)
     assert torch.equal(v.disps_sens[0], want) and torch.equal(v.disps[0], want)      # sensor depth overrides 1.0
@@ -110,9 +110,9 @@ def test_depth_video_item_setter_and_normalize():
     assert torch.equal(v.fmaps[0], fmap.half()) and torch.equal(v.nets[0], net_.half())
     assert torch.equal(v.poses_gt[0], torch.eye(4) * 2)
     v.append(1.5, img, None, None, None, intr, fmap, net_, inp_, None)
-    assert v.counter == 2 and torch.equal(v.poses[1], ident) and torch.all(v.disps[1] == 1.0)
+    assert v.counter.value == 2 and torch.equal(v.poses[1], ident) and torch.all(v.disps[1] == 1.0)
     v[5] = (9.0, img, None, 0.25, None, None)                         # sparse write moves the counter
-    assert v.counter == 6 and torch.all(v.disps[5] == 0.25)
+    assert v.counter.value == 6 and torch.all(v.disps[5] == 0.25)
     poses, disps, intrinsics, fmaps, nets, inps = v[0]
     assert torch.equal(disps, v.disps[0]) and torch.equal(intrinsics, intr)
     v.counter = 2
@@ -129,14 +129,14 @@ def test_depth_video_item_setter_and_normalize():
     Gs[:, 0] = torch.tensor([0.5, 0.6])
     v[2:4] = (tt, torch.stack([img, img]), Gs, 1, torch.stack([depth, depth]), intr.repeat(2, 1) / 8.0,
               torch.stack([fmap, fmap]))
-    assert v.counter == 2 and torch.equal(v.timestamp[2:4], tt) and torch.equal(v.poses[2:4], Gs)
+    assert v.counter.value == 2 and torch.equal(v.timestamp[2:4], tt) and torch.equal(v.poses[2:4], Gs)
     assert torch.equal(v.disps[2], want) and torch.equal(v.fmaps[3], fmap.half())
     lean = DepthVideo(4, 6, buffer=4, device="cpu")                   # hot-path-only mirror: no full-res buffers
     lean.append(0.0, img, ident, 1.0, depth, intr, fmap[:1], net_, inp_, None)
-    assert lean.counter == 1 and not hasattr(lean, "images")
+    assert lean.counter.value == 1 and not hasattr(lean, "images")
     cfg = {"cam": {"H_out": 32, "W_out": 48}, "tracking": {"buffer": 5}, "mode": "rgbd"}
     fc = DepthVideo.from_config(cfg, types.SimpleNamespace(device="cpu"))
-    assert (fc.ht, fc.wd) == (4, 6) and fc.images.shape == (5, 3, 32, 48) and not fc.stereo
+    assert (fc.ht, fc.wd) == (32, 48) and (fc.map_ht, fc.map_wd) == (4, 6) and fc.images.shape == (5, 3, 32, 48) and not fc.stereo
 
 
 def test_multiview_filter_matches_reference(monkeypatch):

@@ -46,7 +46,7 @@ def test_tracker_callers_end_to_end(built_lib):
         net.update.delta[2].weight.mul_(0.05)
         net.update.delta[2].bias.zero_()
     video = DepthVideo.from_config(cfg, args)
-    assert (video.ht, video.wd) == (16, 16)
+    assert (video.map_ht, video.map_wd) == (16, 16)
     mf = MotionFilter(net, video, thresh=0.0, device=dev)  # every frame with any predicted motion is a keyframe
     fe = Frontend(net, video, args, cfg)
     intr = torch.tensor([120.0, 120.0, 64.0, 64.0])
@@ -57,7 +57,7 @@ def test_tracker_callers_end_to_end(built_lib):
         mf.track(float(t), img, depth, intr, gt_pose=torch.eye(4))
         fe()
     assert fe.is_initialized and fe.count >= 1
-    n = video.counter
+    n = video.counter.value
     assert 8 <= n <= n_frames and fe.t1 == n
     assert torch.allclose(video.intrinsics[0].cpu(), intr / 8.0)
     assert float(video.disps_sens[:n].min()) > 0               # sensor depth reached the prior
@@ -88,7 +88,7 @@ def test_tracker_callers_end_to_end(built_lib):
             yield 0.5 + 2.0 * k, img, depth, intr, None
     traj = PoseTrajectoryFiller(net, video, device=dev)(stream())
     assert tuple(traj.data.shape) == (5, 7) and bool(torch.isfinite(traj.data).all())
-    assert video.counter == n and torch.equal(video.poses[:n], kf_poses)      # keyframes untouched (motion-only)
+    assert video.counter.value == n and torch.equal(video.poses[:n], kf_poses)      # keyframes untouched (motion-only)
     assert torch.allclose(traj.data[:, 3:].norm(dim=-1), torch.ones(5, device=dev), atol=1e-4)
 
 
