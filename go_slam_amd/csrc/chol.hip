@@ -501,16 +501,9 @@ int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float*
                          int32_t* fail_count, hipStream_t st) {
   if (n <= SMALL_N && n % CB == 0) {
     const size_t lds = ((size_t)(n + 1) * (n + 2) / 2 + (size_t)n) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-      const size_t cap = ((size_t)(SMALL_N + 1) * (SMALL_N + 2) / 2 + SMALL_N) * sizeof(double);
-      if (hipFuncSetAttribute((const void*)chol_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)cap) != hipSuccess) {
-        gs_set_error("chol: cannot raise the dynamic LDS limit to %zu bytes", cap);
-        return GS_ERR_LAUNCH;
-      }
-      attr_set = true;
-    }
+    static GsLdsLimit limit;
+    const size_t cap = ((size_t)(SMALL_N + 1) * (SMALL_N + 2) / 2 + SMALL_N) * sizeof(double);
+    if (int rc = limit.raise((const void*)chol_small_kernel, cap, "chol")) return rc;
     chol_small_kernel<<<1, SMALL_NT, lds, st>>>(H, b, n, (double)lm, (double)ep, dx_out, fail_flag, fail_count);
     GS_CHECK_LAUNCH("chol_small");
     return GS_OK;

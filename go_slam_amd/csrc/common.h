@@ -30,6 +30,26 @@ void gs_set_error(const char* fmt, ...);
     }                                                                           \
   } while (0)
 
+// Raises a kernel's dynamic-LDS limit the first time it is launched on EACH device of the process (the attribute is
+// per device; tracking on cuda:0 and mapping on cuda:1 in one process is a supported configuration).  Idempotent, so
+// two threads racing on the first launch are harmless.
+#include <atomic>
+struct GsLdsLimit {
+  std::atomic<unsigned long long> done{0ull};            // bit d: raised on device d
+  int raise(const void* fn, size_t bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return GS_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+      gs_set_error("%s: cannot raise the dynamic LDS limit to %zu bytes", what, bytes);
+      return GS_ERR_LAUNCH;
+    }
+    done.fetch_or(bit, std::memory_order_release);
+    return GS_OK;
+  }
+};
+
 static inline int gs_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t gs_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 

@@ -131,15 +131,8 @@ int launch1x1(const void* x, int ldx, int K, const void* wpack, const float* bia
   const int nslice = (NBT + NBS - 1) / NBS;
   const size_t lds = (size_t)NBS * KS * 1024 + 4 * 32 * 72 * sizeof(_Float16);
   GS_REQUIRE(lds <= 152 * 1024, "conv1x1: %d x %d weights need %zu bytes of LDS", N, K, lds);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv1x1_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            152 * 1024) != hipSuccess) {
-      gs_set_error("conv1x1: cannot raise the dynamic LDS limit");
-      return GS_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
+  static GsLdsLimit limit;
+  if (int rc = limit.raise((const void*)conv1x1_kernel<KS>, 152 * 1024, "conv1x1")) return rc;
   const size_t nblk = (rows + 31) / 32;
   size_t grid = (size_t)256 * 2 / nslice;
   if (grid < 64) grid = 64;

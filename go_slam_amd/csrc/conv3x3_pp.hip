@@ -1,0 +1,282 @@
+// 3x3 / pad 1 / stride 1 convolution, NHWC fp16 -> NHWC fp16 (fp32 accumulation): the update operator's large
+// convolutions (reference src/modules/gru.py:10-12, src/droid_net.py:76,83-92,40) as an implicit GEMM on MFMA with a
+// TWO-GROUP PING-PONG schedule -- the production kernel of round 2.
+//
+// Why a second kernel: rocprofv3 on conv3x3_kernel (profiles/r02_pmc_conv3x3.md) shows the matrix pipes busy 46 % and
+// the LDS 40 % of the kernel's cycles, waves parked at barriers / waitcnt 35 % of theirs: its four waves read all their
+// fragments together, then compute together (the LDS pipe idles while the MFMAs run and vice versa), and the second
+// workgroup of the CU only overlaps with it by chance.  Here the overlap is built in:
+//
+//  * 512 threads = 8 waves = two groups of four; waves w and w + 4 share a SIMD.  Every wave alternates a READ phase
+//    (12 ds_read_b128: its A/B fragments of one tap) and a MATH phase (16 v_mfma_f32_32x32x16_f16), separated by
+//    workgroup barriers; group 1 runs one phase behind group 0 (one extra barrier up front), so on every SIMD one wave
+//    is on the matrix pipe while its partner is on the LDS pipe.  One instruction stream, no role branches.
+//  * the workgroup owns 512 pixels (row-stacked tiling: the n images are one image of n*H rows, tiles of 512 / TW rows x
+//    TW columns run across image boundaries; vertical taps that would cross an image boundary read a zero slot) x 128
+//    output channels; K = 9 taps x C in chunks of 32 channels; the (TH+2) x (TW+2) input patch of a chunk is staged ONCE
+//    and serves all 9 taps.
+//  * ALL staging is LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.  The pre-packed weight image
+//    of a tap (8 KB, exactly one 16-byte piece per thread) goes into a ring of 4 buffers, issued 3 taps ahead; the next
+//    chunk's patch goes into the second patch buffer, one 512-slot round per tap.  Out-of-image pixels load from a
+//    16-byte zero page, so there is no masking or zero-fill code.  Loads stay in flight across the barriers (raw
+//    s_barrier, counted s_waitcnt vmcnt(N), never 0 in the loop); a buffer is read only in the phase AFTER the
+//    barrier that follows the wait which retires it (both groups' pieces).
+//  * patch layout [pixel][4 x 16-byte channel groups] with the group index XOR-swizzled by (pixel >> 2) & 3: the four
+//    DMA lanes of a pixel still read its 64 contiguous bytes, and with the lane-permuted fragment mapping (a
+//    ds_read_b128 service group = 16 consecutive pixels of one patch row, conv3x3_common.h) every B-fragment read is
+//    bank-conflict-free; weight planes [8-channel group][128 channels][8] are conflict-free as they are.
+//  * LDS: 2 x 40 KB patch + 4 x 8 KB weights = 112 KB (TW = 16); one workgroup per CU, 2 waves per SIMD.
+#include "common.h"
+#include "conv3x3_common.h"
+
+namespace {
+
+constexpr int PP_BN = 128;          // output channels per workgroup
+constexpr int PP_KG = 4;            // 8-channel groups per 32-channel chunk
+constexpr int PP_WTAP = PP_KG * PP_BN;   // 16-byte slots of one tap's weight image (= 512 = one per thread)
+constexpr int PP_TS = 72;           // epilogue tile row stride in halves
+
+__device__ __attribute__((aligned(16))) const uint32_t pp_zero_page[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void pp_glds16(const void* src, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+#define PP_BAR()                              \
+  do {                                        \
+    asm volatile("" ::: "memory");            \
+    __builtin_amdgcn_s_barrier();             \
+    asm volatile("" ::: "memory");            \
+    __builtin_amdgcn_sched_barrier(0);        \
+  } while (0)
+
+#define PP_LGKM0()                                        \
+  do {                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                    \
+  } while (0)
+
+template <int TW>
+__global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __restrict__ x, int xs, int C,
+                                                            const half8* __restrict__ wpack, _Float16* __restrict__ y,
+                                                            int ys, int H, int W, int rows, int tiles_x, int NB,
+                                                            int xcd) {
+  constexpr int TH_ = 512 / TW, PW_ = TW + 2, NPX = (TH_ + 2) * PW_;
+  constexpr int NROUND = (NPX * PP_KG + 511) / 512;       // DMA rounds (512 slots each) per patch
+  constexpr int PSLOTS = NROUND * 512;                    // slots of a patch buffer; [NPX * 4, PSLOTS) hold zeros
+  constexpr int ZSLOT = NPX * PP_KG;                      // a slot that always reads as zero
+  static_assert(PSLOTS > NPX * PP_KG, "the patch buffer needs at least one padding (zero) slot");
+  static_assert(NROUND <= 9, "one DMA round per tap");
+  extern __shared__ half8 smem[];                         // patch [2][PSLOTS] | weights [4][PP_WTAP]
+  half8* const pbuf = smem;
+  half8* const wbuf = smem + 2 * PSLOTS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp2 = wv >> 2;                               // 0: leading group, 1: one phase behind
+  const int wm = (wv & 1) + 2 * grp2;                     // pixel quarter of the 512-pixel tile
+  const int wn = (wv >> 1) & 1;                           // channel half (64 of 128)
+  const int r = lane & 31, kgl = lane >> 5;
+  int tix, nb;
+  decode_block(blockIdx.x, gridDim.x / NB, NB, xcd, tix, nb);
+  const int tx0 = (tix % tiles_x) * TW;
+  const int g0 = (tix / tiles_x) * TH_;                   // first stacked row (img * H + y) of the tile
+  const int nchunk = C / 32;
+  const int T = nchunk * 9;                               // taps in all
+  const half8* wsrc = wpack + (size_t)nb * T * PP_WTAP;
+
+  // this lane's pixel in the 4 pixel fragments of its wave, and whether it sits on the first / last row of its image
+  int pb[4];
+  bool top[4], bot[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int ty, tx;
+    tile_pixel<TW, true>(wm, i, r, ty, tx);
+    pb[i] = ty * PW_ + tx;
+    const int yy = (g0 + ty) % H;
+    top[i] = yy == 0;
+    bot[i] = yy == H - 1;
+  }
+  // DMA sources of this thread's patch slots (element offsets into x for chunk 0; < 0: zero page)
+  int poff[NROUND];
+#pragma unroll
+  for (int q = 0; q < NROUND; ++q) {
+    const int s = q * 512 + tid, p = s >> 2, ks = s & 3;
+    int off = -1;
+    if (p < NPX) {
+      const int kg = ks ^ ((p >> 2) & 3);
+      const int pr = p / PW_, pc = p - pr * PW_;
+      const int gv = g0 + pr - 1, gx = tx0 + pc - 1;
+      if (gv >= 0 && gv < rows && gx >= 0 && gx < W) off = (gv * W + gx) * xs + kg * 8;
+    }
+    poff[q] = off;
+  }
+
+  float16v acc[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.0f;
+  half8 a[2][2], b[2][4];
+
+  // ---- the three building blocks --------------------------------------------------------------------------------
+  auto issue_patch = [&](int src_chunk, int buf, int q, int off) {        // one 512-slot round of a patch
+    const void* src = off >= 0 ? (const void*)(x + off + src_chunk * 32) : (const void*)pp_zero_page;
+    pp_glds16(src, pbuf + buf * PSLOTS + q * 512 + wv * 64);
+  };
+  auto issue_w = [&](int src_tap, int buf) {                              // one tap's weight image
+    pp_glds16(wsrc + (size_t)src_tap * PP_WTAP + tid, wbuf + buf * PP_WTAP + wv * 64);
+  };
+  auto read_frags = [&](int pbuf_ix, int wbuf_ix, int tap) {              // READ phase body: 4 A + 8 B fragments
+    const half8* wb = wbuf + wbuf_ix * PP_WTAP;
+    const half8* pp = pbuf + pbuf_ix * PSLOTS;
+    const int dy = tap / 3, toff = dy * PW_ + (tap % 3);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int kg = 2 * s + kgl;
+      a[s][0] = wb[kg * PP_BN + wn * 64 + r];
+      a[s][1] = wb[kg * PP_BN + wn * 64 + 32 + r];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int pbi = pb[i];
+      asm volatile("" : "+v"(pbi));                       // opaque: keeps the 9 x 4 x 2 slot addresses from being hoisted
+      const int p = pbi + toff;                           // out of the chunk loop (72 VGPRs, spills at the 256 cap)
+      int s0 = p * 4 + (kgl ^ ((p >> 2) & 3));            // channel group kgl (s = 0); group 2 + kgl is s0 ^ 2
+      int s1 = s0 ^ 2;
+      if ((dy == 0 && top[i]) || (dy == 2 && bot[i])) {   // the row above / below belongs to another image
+        s0 = ZSLOT;
+        s1 = ZSLOT;
+      }
+      b[0][i] = pp[s0];
+      b[1][i] = pp[s1];
+    }
+  };
+  auto math = [&]() {                                                     // MATH phase body: 16 MFMAs
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][0], b[s][i], acc[0][i], 0, 0, 0);
+        acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][1], b[s][i], acc[1][i], 0, 0, 0);
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: patch of chunk 0, weights of taps 0..2 ------------------------------------------------------------
+#pragma unroll
+  for (int q = 0; q < NROUND; ++q) issue_patch(0, 0, q, poff[q]);
+  issue_w(0, 0);
+  issue_w(1, 1);
+  issue_w(2, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PP_BAR();
+  if (grp2 == 1) PP_BAR();                                // group 1 runs one phase behind from here on
+  read_frags(0, 0, 0);
+  PP_LGKM0();
+  PP_BAR();
+
+  for (int ck = 0; ck < nchunk; ++ck) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int tg = ck * 9 + tap;
+      // ---- MATH phase of tap tg; first put the loads for 3 taps ahead (and a round of the next patch) in flight.
+      // Past the end the same number of loads is issued from clamped sources into buffers nobody reads any more, so
+      // that the counted waits below stay compile-time constants.
+      {
+        const int tw = tg + 3 < T ? tg + 3 : T - 1;
+        issue_w(tw, (tg + 3) & 3);
+        if (tap < NROUND) issue_patch(ck + 1 < nchunk ? ck + 1 : nchunk - 1, (ck + 1) & 1, tap, poff[tap]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      math();
+      __builtin_amdgcn_sched_barrier(0);
+      // everything issued before this tap has landed (this wave's pieces); the barrier publishes it.  Tap tg + 2's
+      // weights are first read two phases from now, the next patch at the earliest four taps from now.
+      if (tap < NROUND) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      PP_BAR();
+      // ---- READ phase: fragments of tap tg + 1
+      if (tap < 8) read_frags(ck & 1, (tg + 1) & 3, tap + 1);
+      else if (ck + 1 < nchunk) read_frags((ck + 1) & 1, (tg + 1) & 3, 0);
+      PP_LGKM0();
+      PP_BAR();
+    }
+  }
+  if (grp2 == 0) PP_BAR();                                // pairs with group 1's last barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped tail loads: they target LDS the epilogue reuses
+  PP_BAR();
+
+  // ---- epilogue: [32 pixels][64 channels] at a time through a wave-private LDS tile (aliases patch buffer 0)
+  _Float16* tile = reinterpret_cast<_Float16*>(smem) + wv * 32 * PP_TS;
+  _Float16* yb = y + nb * PP_BN + wn * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {                       // C layout: row (channel) = 8 g + 4 (lane >> 5) + e, col = pixel
+        half4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc[j][i][4 * g + e];
+        *reinterpret_cast<half4*>(tile + r * PP_TS + j * 32 + 8 * g + 4 * kgl) = o;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int pxr = it * 8 + (lane >> 3), piece = lane & 7;
+      int ty, tx;
+      tile_pixel<TW, true>(wm, i, pxr, ty, tx);
+      const int gv = g0 + ty, gx = tx0 + tx;
+      if (gv < rows && gx < W) {
+        const half8 v = *reinterpret_cast<const half8*>(tile + pxr * PP_TS + piece * 8);
+        *reinterpret_cast<half8*>(yb + ((size_t)gv * W + gx) * ys + piece * 8) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int TW>
+int launch_pp(const void* x, int x_stride, int c_in, const void* wpack, void* y, int y_stride, int n_out, int n, int h,
+              int w, int xcd, hipStream_t st) {
+  constexpr int NPX = (512 / TW + 2) * (TW + 2);
+  constexpr int PSLOTS = ((NPX * PP_KG + 511) / 512) * 512;
+  constexpr size_t lds = (size_t)(2 * PSLOTS + 4 * PP_WTAP) * sizeof(half8);
+  static GsLdsLimit limit;
+  if (int rc = limit.raise((const void*)conv3x3_pp_kernel<TW>, lds, "conv3x3_pp")) return rc;
+  const long long rows = (long long)n * h;
+  GS_REQUIRE(rows * w * (long long)x_stride < (1ll << 31), "conv3x3_pp: input too large for 32-bit element offsets");
+  const int tiles_x = gs_cdiv(w, TW), tiles_y = gs_cdiv((int)rows, 512 / TW);
+  const int NB = n_out / PP_BN;
+  const long long blocks = (long long)tiles_x * tiles_y * NB;
+  GS_REQUIRE(blocks < (1ll << 31), "conv3x3_pp: too many workgroups");
+  conv3x3_pp_kernel<TW><<<dim3((unsigned)blocks), 512, lds, st>>>((const _Float16*)x, x_stride, c_in, (const half8*)wpack,
+                                                                  (_Float16*)y, y_stride, h, w, (int)rows, tiles_x, NB,
+                                                                  xcd);
+  GS_CHECK_LAUNCH("conv3x3_pp");
+  return GS_OK;
+}
+
+}  // namespace
+
+extern "C" int gs_conv3x3_pp(const void* x, int x_stride, int c_in, const void* wpack, int tw, void* y, int y_stride,
+                             int n_out, int n, int h, int w, int xcd_order, gs_stream_t stream) {
+  GS_REQUIRE(x && wpack && y, "conv3x3_pp: null pointer");
+  GS_REQUIRE(tw == 8 || tw == 16, "conv3x3_pp: tile width must be 8 or 16");
+  GS_REQUIRE(c_in > 0 && c_in % 32 == 0, "conv3x3_pp: c_in must be a multiple of 32 (weights packed with kc = 32)");
+  GS_REQUIRE(n_out > 0 && n_out % PP_BN == 0, "conv3x3_pp: n_out must be a multiple of %d", PP_BN);
+  GS_REQUIRE(x_stride >= c_in && x_stride % 8 == 0, "conv3x3_pp: x_stride must be >= c_in and a multiple of 8");
+  GS_REQUIRE(y_stride >= n_out && y_stride % 8 == 0, "conv3x3_pp: y_stride must be >= n_out and a multiple of 8");
+  GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3_pp: bad shape");
+  if (n == 0) return GS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (tw == 8) return launch_pp<8>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, xcd_order ? 1 : 0, st);
+  return launch_pp<16>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, xcd_order ? 1 : 0, st);
+}

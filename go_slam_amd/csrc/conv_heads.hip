@@ -110,15 +110,8 @@ int launch_head(const void* x, int ldx, const float* in_bias, int in_relu, const
   constexpr int S = (9 * O) | 1;
   const size_t lds = (size_t)(HEAD_ROWS + 2) * w * S * sizeof(float);
   GS_REQUIRE(lds <= 160 * 1024, "conv3x3_head: image width %d needs %zu bytes of LDS", w, lds);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3x3_head_kernel<O>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) {
-      gs_set_error("conv3x3_head: cannot raise the dynamic LDS limit");
-      return GS_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
+  static GsLdsLimit limit;
+  if (int rc = limit.raise((const void*)conv3x3_head_kernel<O>, 160 * 1024, "conv3x3_head")) return rc;
   conv3x3_head_kernel<O><<<dim3(gs_cdiv(h, HEAD_ROWS), n), 256, lds, st>>>(
       (const _Float16*)x, ldx, in_bias, in_relu, (const _Float16*)wpack, bias, epilogue, out_scale, out, h, w);
   GS_CHECK_LAUNCH("conv3x3_head");

@@ -275,11 +275,8 @@ extern "C" int gs_corr_volume_pyramid(const void* fmap1, const void* fmap2, void
   GS_CHECK_LAUNCH("corr_prep");
   const int BN = ROWS * w;
   const size_t lds = (size_t)(BM * (BN + 8) + BM * ((ROWS / 2) * (w / 2) + 8) + BM * ((ROWS / 4) * (w / 4) + 2)) * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)corr_volume_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static GsLdsLimit limit;
+  if (int rc = limit.raise((const void*)corr_volume_kernel, 160 * 1024, "corr_volume")) return rc;
   dim3 grid(gs_cdiv(hw, BM), gs_cdiv(h, ROWS), n);
   corr_volume_kernel<<<grid, 256, lds, st>>>(f1t, f2t, (_Float16*)vol0, (_Float16*)vol1, (_Float16*)vol2,
                                              (_Float16*)vol3, h, w, layout == GS_CORR_TILE8);

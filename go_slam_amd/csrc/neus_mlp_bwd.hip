@@ -301,15 +301,8 @@ extern "C" int gs_mlp_backward(const void* x, const void* wpack, const float* d_
   const int nblk = (n + 31) / 32;
   const int grid = gs_mlp_backward_blocks(n);
   const size_t lds = (size_t)(NFRAG * 512 + 4 * WAVE_LDS) * sizeof(_Float16);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)neus_mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess) {
-      gs_set_error("mlp_backward: cannot raise the dynamic LDS limit to %zu bytes", lds);
-      return GS_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
+  static GsLdsLimit limit;
+  if (int rc = limit.raise((const void*)neus_mlp_bwd_kernel, lds, "mlp_backward")) return rc;
   neus_mlp_bwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const _Float16*)x, (const _Float16*)wpack, d_rgb,
                                                               (const _Float16*)rgb, loss_scale, (_Float16*)dx, partial,
                                                               n, nblk);

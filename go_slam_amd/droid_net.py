@@ -191,6 +191,8 @@ CONV3X3_STACKED = os.environ.get("GOSLAM_CONV3X3_STACKED", "0") == "1"
 # Epilogues fused into the own 3x3 convolutions: the ConvGRU gate arithmetic (gs_conv3x3_gru_zr / _q) and bias + ReLU
 # (gs_conv3x3_bias_relu).  Bit-identical to conv + gate / bias_act kernels by construction, parity-checked by
 # emulation, not yet run on hardware -> opt-in.
+# The two-group ping-pong kernel (csrc/conv3x3_pp.hip); GOSLAM_CONV3X3_PP=0 falls back to the round-1 kernels.
+CONV3X3_PP = os.environ.get("GOSLAM_CONV3X3_PP", "1") == "1"
 GRU_FUSED_EPILOGUE = os.environ.get("GOSLAM_GRU_FUSED", "0") == "1"
 _CONV3X3_PACKS = {}        # (data_ptr, version, shape, device, kc) -> (packed image, weight tensor kept alive)
 _CONV3X3_PACKS_MAX = 32
@@ -234,7 +236,7 @@ def _use_own_conv3x3(x, w, stride, padding):
         return False
     if not conv3x3_hip_supported(x, w):
         return False
-    if CONV3X3_IMPL == "hip" or CONV3X3_STACKED:
+    if CONV3X3_IMPL == "hip" or CONV3X3_STACKED or CONV3X3_PP:      # row-stacked tilings cover every map size
         return True
     return conv3x3_tile_efficiency(x.shape[2], x.shape[3]) >= 0.9
 
@@ -251,19 +253,29 @@ def conv3x3_weight_image(w, kc):
     return hit[0]
 
 
-def conv3x3_hip(x, w, kc=None, stacked=None, tw=None):
-    """bias-free 3x3 / pad 1 convolution of an NHWC fp16 tensor through gs_conv3x3; `w` is the [O,C,3,3] weight.
+def conv3x3_pp_tile_width(w):
+    """tile width of the ping-pong kernel, 16 or 8: least column padding (ties: 16)"""
+    return min((16, 8), key=lambda tw: ((w + tw - 1) // tw * tw, tw != 16))
+
+
+def conv3x3_hip(x, w, kc=None, stacked=None, tw=None, pp=None):
+    """bias-free 3x3 / pad 1 convolution of an NHWC fp16 tensor through gs_conv3x3_pp (the ping-pong kernel, default) or
+    gs_conv3x3 / gs_conv3x3_stacked (round-1 kernels, `pp=False`); `w` is the [O,C,3,3] weight.
     Its packed image is cached per (storage address, version, shape); the entry keeps the weight tensor alive, so the
     address cannot be recycled for different values while the entry exists."""
     from . import _lib
-    kc = kc or conv3x3_chunk(w.shape[1], w.shape[0])
+    pp = CONV3X3_PP if pp is None else pp
+    kc = 32 if pp else (kc or conv3x3_chunk(w.shape[1], w.shape[0]))
     image = conv3x3_weight_image(w, kc)
     n, c, h, wd = x.shape
     O = w.shape[0]
     y = torch.empty((n, O, h, wd), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
     stacked = CONV3X3_STACKED if stacked is None else stacked
     with torch.cuda.device(x.device):
-        if stacked:
+        if pp:
+            rc = _lib.lib().gs_conv3x3_pp(_lib.ptr(x), c, c, _lib.ptr(image), tw or conv3x3_pp_tile_width(wd),
+                                          _lib.ptr(y), O, O, n, h, wd, 1, _lib.stream_ptr(x.device))
+        elif stacked:
             rc = _lib.lib().gs_conv3x3_stacked(_lib.ptr(x), c, c, _lib.ptr(image), kc,
                                                tw or conv3x3_stacked_tile_width(wd), _lib.ptr(y), O, O, n, h, wd,
                                                _lib.stream_ptr(x.device))

@@ -185,6 +185,13 @@ int gs_conv3x3(const void* x, int x_stride, int c_in, const void* wpack, int kc,
  * Requires the images to be contiguous (image stride = h * w * x_stride resp. y_stride).                    */
 int gs_conv3x3_stacked(const void* x, int x_stride, int c_in, const void* wpack, int kc, int tw, void* y,
                        int y_stride, int n_out, int n, int h, int w, gs_stream_t stream);
+/* The same convolution (row-stacked tiles of 512 / tw rows x tw columns, tw in {8, 16}; weights packed with kc = 32)
+ * on the two-group ping-pong kernel: 512-thread workgroups whose two wave groups alternate a fragment-read phase and
+ * an MFMA phase one phase apart, all staging by LDS-DMA (global_load_lds) with counted waits across raw barriers, an
+ * XOR-swizzled bank-conflict-free patch layout.  xcd_order != 0: workgroup ids are decoded so that the output-channel
+ * blocks of a tile run on one XCD (shared L2).  The production path of the update operator.                  */
+int gs_conv3x3_pp(const void* x, int x_stride, int c_in, const void* wpack, int tw, void* y, int y_stride, int n_out,
+                  int n, int h, int w, int xcd_order, gs_stream_t stream);
 /* ConvGRU (src/modules/gru.py:20-33) with the gate arithmetic fused into the 3x3 convolutions' epilogues
  * (EXPERIMENTAL: opt-in from the host mirror; results equal gs_conv3x3 + gs_gru_gate_zr / gs_gru_gate_q bit for bit,
  * but the 256 + 128 channels of pre-activations never travel to HBM and back).

@@ -60,7 +60,8 @@ def _worker(rank, video, prob, lock_kind, barrier, out_q):
                 torch.cuda.synchronize()
         with video.get_lock():
             video.counter.value += HALF
-        out_q.put((rank, "ok", dx.cpu()))
+        out_q.put((rank, "ok", dx.cpu().numpy()))    # a NumPy array: a torch tensor would travel as a file
+                                                      # descriptor owned by this (soon finished) process
     except Exception as exc:                       # surface the failure in the parent instead of hanging it
         import traceback
         out_q.put((rank, "error", traceback.format_exc() + repr(exc)))
@@ -108,4 +109,4 @@ def test_two_processes_run_ba_on_one_shared_video(built_lib):
     torch.testing.assert_close(video.poses.cpu(), po, rtol=0, atol=2e-5)
     torch.testing.assert_close(video.disps.cpu(), do, rtol=0, atol=2e-5)
     for k in range(2):
-        torch.testing.assert_close(results[k], last[k], rtol=2e-3, atol=2e-6)
+        torch.testing.assert_close(torch.from_numpy(results[k]), last[k], rtol=2e-3, atol=2e-6)

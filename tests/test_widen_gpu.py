@@ -257,6 +257,38 @@ def test_conv3x3_implicit_gemm_matches_reference(built_lib, n, h, w, c, xs, o, k
     torch.testing.assert_close(y[..., :o].float(), ref, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("n,h,w,c,xs,o,tw", [(5, 30, 40, 128, 128, 128, 8), (3, 60, 80, 320, 320, 256, 16),
+                                              (4, 7, 37, 64, 72, 128, 16), (6, 5, 19, 64, 64, 256, 8),
+                                              (1, 40, 80, 128, 128, 384, 16), (75, 40, 80, 128, 128, 128, 16),
+                                              (2, 33, 16, 32, 40, 128, 16), (40, 30, 40, 320, 320, 128, 8)])
+def test_conv3x3_pingpong_kernel_matches_reference(built_lib, n, h, w, c, xs, o, tw):
+    """gs_conv3x3_pp (two-group ping-pong schedule, LDS-DMA staging, swizzled patch) vs F.conv2d in fp32 on the same
+    fp16 operands: images shorter than a 512-pixel tile (tiles spanning several images), partial tiles in x and at the
+    end of the batch, channel slices (xs > c), 1-3 output blocks, one and many chunks, both tile widths, both
+    workgroup orders.  The kernel keeps LDS-DMA loads in flight across barriers, so it is also run repeatedly and
+    required to reproduce itself bit for bit (a staging race shows up as run-to-run differences)."""
+    from go_slam_amd import _lib
+    from go_slam_amd.droid_net import pack_conv3x3_weight
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(n * 1000 + c + w)
+    x = torch.randn(n, h, w, xs, generator=g).half().to(dev)
+    wt = (torch.randn(o, c, 3, 3, generator=g) / (3.0 * c ** 0.5)).half().to(dev)
+    wp = pack_conv3x3_weight(wt, 32)
+    ref = torch.nn.functional.conv2d(x[..., :c].permute(0, 3, 1, 2).float(), wt.float(), padding=1).permute(0, 2, 3, 1)
+    first = None
+    for rep in range(4):
+        y = torch.full((n, h, w, o + 8), 7.0, dtype=torch.float16, device=dev)
+        rc = _lib.lib().gs_conv3x3_pp(_lib.ptr(x), xs, c, _lib.ptr(wp), tw, _lib.ptr(y), o + 8, o, n, h, w, rep & 1,
+                                      _lib.stream_ptr(dev))
+        _lib.check(rc, "conv3x3_pp")
+        assert bool((y[..., o:] == 7.0).all())
+        torch.testing.assert_close(y[..., :o].float(), ref, rtol=2e-3, atol=2e-3)
+        if first is None:
+            first = y.clone()
+        else:
+            assert torch.equal(y, first), f"run {rep} differs from run 0"
+
+
 @pytest.mark.parametrize("n,h,w,c,xs,o,kc,tw", [(5, 30, 40, 128, 128, 128, 64, 8), (3, 60, 80, 320, 320, 256, 32, 16),
                                                  (4, 7, 37, 64, 72, 128, 32, 32), (6, 5, 19, 64, 64, 256, 64, 8),
                                                  (1, 40, 80, 128, 128, 384, 64, 16)])

@@ -45,10 +45,14 @@ def run(tag, E, h, w):
         for stacked in (False, True):
             for kc in (32, 64):
                 key = f"{'stacked' if stacked else 'plain'}_kc{kc}"
-                ms_h = time_op(lambda: DN.conv3x3_hip(x, wt, kc, stacked=stacked))
+                ms_h = time_op(lambda: DN.conv3x3_hip(x, wt, kc, stacked=stacked, pp=False))
                 row[key + "_ms"] = round(ms_h, 4)
                 row[key + "_tflops"] = round(flops / ms_h / 1e9, 1)
-                row[key + "_max_abs_diff"] = float((DN.conv3x3_hip(x, wt, kc, stacked=stacked).float() - ref).abs().max())
+                row[key + "_max_abs_diff"] = float((DN.conv3x3_hip(x, wt, kc, stacked=stacked, pp=False).float() - ref).abs().max())
+        ms_p = time_op(lambda: DN.conv3x3_hip(x, wt, pp=True))
+        row["pp_ms"] = round(ms_p, 4)
+        row["pp_tflops"] = round(flops / ms_p / 1e9, 1)
+        row["pp_max_abs_diff"] = float((DN.conv3x3_hip(x, wt, pp=True).float() - ref).abs().max())
         out[name] = row
     print(json.dumps(out))
 

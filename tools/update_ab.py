@@ -1,5 +1,5 @@
 """A/B of the update operator's 3x3-convolution implementation on the bench workload: ms per keyframe
-(bench.UPDATES_PER_KF x FactorGraph.update, as bench.py times it) with CONV3X3_IMPL = miopen / hip (both chunk sizes).  Prints one JSON line."""
+(bench.UPDATES_PER_KF x FactorGraph.update, as bench.py times it) with CONV3X3_IMPL = miopen / round-1 own kernel (kc 32) / ping-pong kernel.  Prints one JSON line."""
 import json
 import os
 import sys
@@ -17,8 +17,9 @@ def main():
     video, op, graph, _ = bench.build_state(dev, seed=43)
     poses0, disps0 = video.poses.clone(), video.disps.clone()
     out = {}
-    for impl in ("miopen", "hip32", "hip64", "miopen", "hip32", "hip64"):
-        DN.CONV3X3_IMPL = "hip" if impl.startswith("hip") else "miopen"
+    for impl in ("miopen", "hip32", "pp", "miopen", "hip32", "pp"):
+        DN.CONV3X3_IMPL = "miopen" if impl == "miopen" else "hip"
+        DN.CONV3X3_PP = impl == "pp"
         DN.CONV3X3_KC = int(impl[3:]) if impl.startswith("hip") else 32
         video.poses.copy_(poses0)
         video.disps.copy_(disps0)
