@@ -9,9 +9,9 @@ the 1/8-resolution map size 60x80: reproject + 4-level corr lookup + UpdateModul
 timed region.  Tracking does not shard ("replicas only"), so --gpus N runs N
 independent replicas, one process per GPU, and `value` is their aggregate.
 
-Extra objects on the line: `roofline` for the dominant hand-written kernel (the fused
-correlation-pyramid lookup: 912*HW algorithmic bytes per edge, measured with events on the
-launch stream) and `cpu_baseline` (the CPU oracle + the same UpdateModule on the host cores,
+Extra objects on the line: `roofline` for the time-dominant hand-written kernel (the update
+operator's implicit-GEMM 3x3 convolution, MFMA-bound: algorithmic FLOPs / launch time measured with
+events on the launch stream; the HBM-bound lookup / volume kernels are in `roofline_other`) and `cpu_baseline` (the CPU oracle + the same UpdateModule on the host cores,
 on a bounded 1-update sample, rank 0 at N=1 only).
 """
 import argparse
@@ -291,6 +291,42 @@ def cpu_baseline(sample_updates=1):
                       f"(oracle reproject+lookup+BA, UpdateModule fp32 on CPU torch {torch.__version__})"}
 
 
+CONV_LAYERS = (("gru_zr", 320, 256), ("gru_q", 320, 128), ("heads", 128, 384), ("corr_enc2", 128, 128))
+
+
+def pmc_traffic(name):
+    """HBM bytes per launch from a COMMITTED rocprofv3 --pmc pass of the same launch shape (FETCH_SIZE / WRITE_SIZE in
+    separate passes, corrected as MI355X_MICROARCH.md prescribes).  Not measured in this run: the source is named."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return {"traffic": None}
+    return {"traffic": json.load(open(path)).get("traffic_bytes_per_launch"),
+            "traffic_source": f"profiles/{name} (committed PMC passes, not re-measured by this run)"}
+
+
+def conv_roofline(device, E, ht, wd):
+    from go_slam_amd import droid_net as DN
+    layers, flops_sum, ms_sum = [], 0.0, 0.0
+    for name, c, o in CONV_LAYERS:
+        x = torch.randn(E, c, ht, wd, device=device).half().contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(o, c, 3, 3, device=device) / (3.0 * c ** 0.5)).half()
+        assert DN._use_own_conv3x3(x, w, 1, 1), "the update operator must be on the package's own 3x3 convolution"
+        ms = time_op(lambda: DN.conv3x3_hip(x, w), iters=10, warm=3)
+        fl = 2.0 * E * ht * wd * 9 * c * o
+        layers.append({"layer": name, "c_in": c, "c_out": o, "us": ms * 1e3, "tflops": fl / (ms * 1e-3) / 1e12})
+        flops_sum += fl
+        ms_sum += ms
+        del x, w
+    tf = flops_sum / (ms_sum * 1e-3) / 1e12
+    kern = "conv3x3_pp_kernel (two-group ping-pong implicit GEMM, LDS-DMA staging)" if DN.CONV3X3_PP else "conv3x3_kernel"
+    out = {"kernel": kern + ", fp16 MFMA 32x32x16 / fp32 accumulate; the update operator's four 3x3 layer shapes",
+           "bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": tf / MFMA_F16_PEAK_TFLOPS, "algorithmic_flops_per_update": flops_sum,
+           "kernel_us_per_update": ms_sum * 1e3, "layers": layers}
+    out.update(pmc_traffic("r02_pmc_conv3x3_pp.json"))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -366,39 +402,23 @@ def main():
             except Exception as exc:                   # an auxiliary leg must not cost the bench line
                 line["global_ba_stress"] = {"error": repr(exc)}
         ht, wd = graph.ht, graph.wd
+        # ---- roofline: the time-dominant hand-written kernel = the update operator's 3x3 convolutions (about half of
+        # an update's GPU time, profiles/r02_tracking_kernel_stats.md).  MFMA-bound; achieved = algorithmic FLOPs
+        # (2 * E * h * w * 9 * C_in * C_out, no tile padding counted) / launch time, measured here with events on the
+        # launch stream for each of the four layer shapes an update issues, and aggregated over them.
+        line["roofline"] = conv_roofline(device, int(br["edges"]), ht, wd)
         algo_bytes = 912.0 * ht * wd * br["edges"]            # 912*HW B per edge per lookup
         t_s = br["corr_lookup_ms"] * 1e-3
         achieved = algo_bytes / t_s / 1e9
-        traffic = None      # HBM bytes per launch from the committed PMC passes (same workload)
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_corr_lookup.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-        line["roofline"] = {"kernel": "corr_pyramid_coop_kernel<tile8> (fp16 NHWC, wave-cooperative fused 4-level lookup)", "bound": "hbm",
-                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                            "algorithmic_bytes_per_launch": algo_bytes,
-                            "kernel_avg_us": br["corr_lookup_ms"] * 1e3}
         bgb = br["corr_build_bytes"] / (br["corr_build_8edges_ms"] * 1e-3) / 1e9
         line["roofline_other"] = [
+            dict({"kernel": "corr_pyramid_coop_kernel<tile8> (fp16 NHWC, wave-cooperative fused 4-level lookup)",
+                  "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
+                  "kernel_avg_us": br["corr_lookup_ms"] * 1e3}, **pmc_traffic("r01_pmc_corr_lookup.json")),
             {"kernel": "corr_volume_kernel (MFMA all-pairs volume + 3 pooled levels, written once)", "bound": "hbm",
              "achieved": bgb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bgb / HBM_PEAK_GBS,
              "bytes_per_launch": br["corr_build_bytes"], "note": "8 edges per launch (one keyframe's new factors)"}]
-        try:    # the update operator's largest convolution (GRU z|r, 320 -> 256) on the package's implicit-GEMM kernel
-            from go_slam_amd import droid_net as DN
-            E = int(br["edges"])
-            xz = torch.randn(E, 320, ht, wd, device=device).half().contiguous(memory_format=torch.channels_last)
-            wz = (torch.randn(256, 320, 3, 3, device=device) / 160.0).half()
-            if DN.conv3x3_hip_supported(xz, wz):
-                ms = time_op(lambda: DN.conv3x3_hip(xz, wz), iters=10, warm=3)
-                tf = 2.0 * E * ht * wd * 9 * 320 * 256 / (ms * 1e-3) / 1e12
-                line["roofline_other"].append(
-                    {"kernel": "conv3x3_kernel (implicit-GEMM 3x3 conv, GRU z|r 320->256, fp16 MFMA / fp32 accumulate)",
-                     "bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": tf / MFMA_F16_PEAK_TFLOPS, "kernel_avg_us": ms * 1e3,
-                     "in_use": DN._use_own_conv3x3(xz, wz, 1, 1), "impl": DN.CONV3X3_IMPL})
-            del xz, wz
-        except Exception as exc:                       # never lose the bench line over an auxiliary measurement
-            line["roofline_other"].append({"kernel": "conv3x3_kernel", "error": repr(exc)})
         line["neus_render"] = neus_render_bench(device)
         line["roofline_other"].append(dict(line["neus_render"]["mlp_mfma"], bound="mfma"))
         if world == 1 and not args.no_cpu_baseline:

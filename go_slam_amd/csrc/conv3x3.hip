@@ -5,9 +5,10 @@
 //
 // Measured on MI355X (75 edges, 60x80 maps): 885 / 896 / 917 / 859 TFLOP/s on the four layers against MIOpen's 795 / 706 /
 // 792 / 658; the host mirror uses it wherever the 16x16 tiles fit the map (go_slam_amd/droid_net.py, CONV3X3_IMPL).
-// This file holds the verified kernels (conv3x3_kernel<KC, false>, conv3x3_stacked_kernel<KC, TW, false>) and, as
-// further template instantiations that leave those untouched instruction for instruction, the opt-in variants that
-// round 2 has to time: lane-permuted fragments (LP), XCD-aware block order, fused ConvGRU / bias+ReLU epilogues (EPI).
+// ROUND-1 KERNELS, kept as the A/B reference of the production kernel (conv3x3_pp.hip, which is 1.2-1.3x faster:
+// tools/conv3x3_bench.py, profiles/r02_conv3x3_bench.json): conv3x3_kernel<KC, LP>, conv3x3_stacked_kernel<KC, TW, LP>;
+// LP = lane-permuted (bank-conflict-free) fragments, with them optionally the XCD-aware block order
+// (GOSLAM_CONV3X3_LANEPERM / _XCD; both hardware-verified in round 2, worth 1-4 %).
 //
 // Organisation:
 //  * a workgroup (4 waves) owns a 16x16-pixel tile x 128 output channels; K = 9 taps x C runs in chunks of 32
@@ -36,35 +37,12 @@ constexpr int NP = PH * PW;                // 324 patch pixels
 constexpr int BN = 128;                    // output channels per workgroup
 constexpr int TS = 72;                     // epilogue tile row stride in halves (144 B, staggers the banks)
 
-// Fused ConvGRU epilogues (EPI != 0): the gate arithmetic of gru_gates.hip applied to the convolution's fp16-rounded
-// pre-activations while they pass through the LDS tile -- same formulas, same rounding points, so the results equal
-// conv + gs_gru_gate_zr / gs_gru_gate_q bit for bit, but zr_pre / q_pre never travel to HBM and back.
-//   EPI 1 (z|r, 256 outputs): block 0 -> z = sigm(pre + inp_pre[:, 0:128] + b + glo) -> out0;
-//                             block 1 -> r likewise from channels 128:256, out1 = r * net (net = x[:, 0:128]).
-//   EPI 2 (q, 128 outputs):   q = tanh(pre + inp_pre[:, 256:384] + b + glo), out0 = (1 - z) net + z q with z = aux0,
-//                             net = aux1; the input is [xa (first `split` channels, stride xs) | xb (stride xsb)].
-//   EPI 3 (any width):        y = relu(pre + b) -- gs_bias_act's arithmetic (fp16 pre-activation, fp32 add, fp16 result)
-//                             in the store stage; y / y_stride may address a channel slice of a wider tensor.
-struct EpiArgs {
-  const float* bias;           // [256] (EPI 1) / [128] (EPI 2)
-  const float* glo;            // [n, 256] / [n, 128] global-context terms
-  const _Float16* inp_pre;     // [n*h*w, 384] hoisted context-feature convolutions, or nullptr
-  const _Float16* aux0;        // EPI 2: z [n*h*w, 128]
-  const _Float16* aux1;        // EPI 2: net [n*h*w, 128]
-  _Float16* out0;              // EPI 1: z, EPI 2: new net   [n*h*w, 128]
-  _Float16* out1;              // EPI 1: r * net             [n*h*w, 128]
-  const _Float16* xb;          // EPI 2: second input source (channels >= split)
-  int xsb, split;
-};
-
-__device__ __forceinline__ float sigm_(float v) { return 1.0f / (1.0f + __expf(-v)); }
-
 // KC = input channels per chunk (32: 37 KB of LDS, a barrier every 16 MFMAs per wave; 64: 74 KB, every 32 MFMAs)
-template <int KC, bool LP, int EPI = 0>
+template <int KC, bool LP>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restrict__ x, int xs, int C,
                                                          const half8* __restrict__ wpack, _Float16* __restrict__ y,
                                                          int ys, int H, int W, int tiles_x, int tiles_y, int NB,
-                                                         int xcd, EpiArgs ep = EpiArgs()) {
+                                                         int xcd) {
   constexpr int KG = KC / 8;                             // 8-channel groups per chunk
   constexpr int WTAP = KG * BN;                          // 16-byte vectors of one tap's weight image
   constexpr int WPT = WTAP / 256;                        // ... per thread
@@ -115,16 +93,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restr
       const int py = p / PW, px = p - py * PW;
       const int gy = ty0 + py - 1, gx = tx0 + px - 1;
       half8 v = zero8;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-        if constexpr (EPI == 2) {
-          const size_t pix = ((size_t)img * H + gy) * W + gx;
-          const int c0 = ck * KC + kg * 8;
-          v = c0 < ep.split ? *reinterpret_cast<const half8*>(x + pix * xs + c0)
-                            : *reinterpret_cast<const half8*>(ep.xb + pix * ep.xsb + (c0 - ep.split));
-        } else {
-          v = *reinterpret_cast<const half8*>(ximg + ((size_t)gy * W + gx) * xs + ck * KC + kg * 8);
-        }
-      }
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+        v = *reinterpret_cast<const half8*>(ximg + ((size_t)gy * W + gx) * xs + ck * KC + kg * 8);
       patch[kg * NPP + p] = v;
     }
     // ---- and the first tap's weights
@@ -206,51 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const _Float16* __restr
       }
       if (gy < H && gx < W) {
         const half8 v = *reinterpret_cast<const half8*>(tile + pxr * TS + piece * 8);
-        if constexpr (EPI == 0) {
-          *reinterpret_cast<half8*>(yimg + ((size_t)gy * W + gx) * ys + piece * 8) = v;
-        } else if constexpr (EPI == 3) {
-          const float* bb = ep.bias + nb * BN + wn * 64 + piece * 8;
-          half8 o;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) o[k] = (_Float16)fmaxf((float)v[k] + bb[k], 0.0f);
-          *reinterpret_cast<half8*>(yimg + ((size_t)gy * W + gx) * ys + piece * 8) = o;
-        } else {
-          const size_t pix = ((size_t)img * H + gy) * W + gx;
-          const int c8 = wn * 64 + piece * 8;               // first of this lane's 8 channels inside the 128-block
-          half8 o;
-          if constexpr (EPI == 1) {
-            half8 pi = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ep.inp_pre) pi = *reinterpret_cast<const half8*>(ep.inp_pre + pix * 384 + nb * 128 + c8);
-            const float* bb = ep.bias + nb * 128 + c8;
-            const float* gg = ep.glo + (size_t)img * 256 + nb * 128 + c8;
-            if (nb == 0) {
-#pragma unroll
-              for (int k = 0; k < 8; ++k) o[k] = (_Float16)sigm_((float)v[k] + (float)pi[k] + bb[k] + gg[k]);
-              *reinterpret_cast<half8*>(ep.out0 + pix * 128 + c8) = o;
-            } else {
-              const half8 net = *reinterpret_cast<const half8*>(x + pix * xs + c8);
-#pragma unroll
-              for (int k = 0; k < 8; ++k)
-                o[k] = (_Float16)(sigm_((float)v[k] + (float)pi[k] + bb[k] + gg[k]) * (float)net[k]);
-              *reinterpret_cast<half8*>(ep.out1 + pix * 128 + c8) = o;
-            }
-          } else {
-            half8 pi = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ep.inp_pre) pi = *reinterpret_cast<const half8*>(ep.inp_pre + pix * 384 + 256 + c8);
-            const half8 zz = *reinterpret_cast<const half8*>(ep.aux0 + pix * 128 + c8);
-            const half8 nn = *reinterpret_cast<const half8*>(ep.aux1 + pix * 128 + c8);
-            const float* bb = ep.bias + c8;
-            const float* gg = ep.glo + (size_t)img * 128 + c8;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const float a = (float)v[k] + (float)pi[k] + bb[k] + gg[k];
-              const float q = 1.0f - 2.0f / (1.0f + __expf(2.0f * a));
-              const float zf = (float)zz[k];
-              o[k] = (_Float16)((1.0f - zf) * (float)nn[k] + zf * q);
-            }
-            *reinterpret_cast<half8*>(ep.out0 + pix * 128 + c8) = o;
-          }
-        }
+        *reinterpret_cast<half8*>(yimg + ((size_t)gy * W + gx) * ys + piece * 8) = v;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -455,21 +381,21 @@ int launch3x3s(const void* x, int x_stride, int c_in, const void* wpack, void* y
   return GS_OK;
 }
 
-template <int KC, bool LP, int EPI = 0>
+template <int KC, bool LP>
 int launch3x3(const void* x, int x_stride, int c_in, const void* wpack, void* y, int y_stride, int n_out, int n, int h,
-              int w, hipStream_t st, EpiArgs ep = EpiArgs()) {
+              int w, hipStream_t st) {
   constexpr size_t lds = (size_t)((KC / 8) * (NP + (LP ? 1 : 0)) + 2 * (KC / 8) * BN) * sizeof(half8);
   static GsLdsLimit limit;
-  if (int rc = limit.raise((const void*)conv3x3_kernel<KC, LP, EPI>, lds, "conv3x3")) return rc;
+  if (int rc = limit.raise((const void*)conv3x3_kernel<KC, LP>, lds, "conv3x3")) return rc;
   const int tiles_x = gs_cdiv(w, TW), tiles_y = gs_cdiv(h, TH);
   const long long blocks = (long long)n * tiles_x * tiles_y;
   GS_REQUIRE(blocks < (1ll << 31), "conv3x3: too many tiles");
   const int NB = n_out / BN;
   GS_REQUIRE(blocks * NB < (1ll << 31), "conv3x3: too many workgroups");
   const dim3 grid = LP ? dim3((unsigned)(blocks * NB)) : dim3((unsigned)blocks, NB);
-  conv3x3_kernel<KC, LP, EPI><<<grid, 256, lds, st>>>((const _Float16*)x, x_stride, c_in, (const half8*)wpack,
+  conv3x3_kernel<KC, LP><<<grid, 256, lds, st>>>((const _Float16*)x, x_stride, c_in, (const half8*)wpack,
                                                       (_Float16*)y, y_stride, h, w, tiles_x, tiles_y, NB,
-                                                      xcd_remap_enabled(), ep);
+                                                      xcd_remap_enabled());
   GS_CHECK_LAUNCH("conv3x3");
   return GS_OK;
 }
@@ -529,67 +455,4 @@ extern "C" int gs_conv3x3_stacked(const void* x, int x_stride, int c_in, const v
   if (tw == 16) GS_S(64, 16, false);
   GS_S(64, 32, false);
 #undef GS_S
-}
-
-// ---- ConvGRU with the gate arithmetic fused into the convolutions' epilogues (EXPERIMENTAL, see EpiArgs) ----------
-extern "C" int gs_conv3x3_gru_zr(const void* hx, int hx_stride, int c_in, const void* wpack, const float* bias_zr,
-                                 const float* glo_zr, const void* inp_pre, void* z_out, void* rnet_out, int n, int h,
-                                 int w, gs_stream_t stream) {
-  GS_REQUIRE(hx && wpack && bias_zr && glo_zr && z_out && rnet_out, "conv3x3_gru_zr: null pointer");
-  GS_REQUIRE(c_in >= 128 && c_in % 32 == 0, "conv3x3_gru_zr: c_in must be >= 128 and a multiple of 32");
-  GS_REQUIRE(hx_stride >= c_in && hx_stride % 8 == 0, "conv3x3_gru_zr: bad hx_stride");
-  GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3_gru_zr: bad shape");
-  if (n == 0) return GS_OK;
-  EpiArgs ep = EpiArgs();
-  ep.bias = bias_zr;
-  ep.glo = glo_zr;
-  ep.inp_pre = (const _Float16*)inp_pre;
-  ep.out0 = (_Float16*)z_out;
-  ep.out1 = (_Float16*)rnet_out;
-  hipStream_t st = (hipStream_t)stream;
-  if (lane_perm_enabled()) return launch3x3<32, true, 1>(hx, hx_stride, c_in, wpack, nullptr, 0, 256, n, h, w, st, ep);
-  return launch3x3<32, false, 1>(hx, hx_stride, c_in, wpack, nullptr, 0, 256, n, h, w, st, ep);
-}
-
-extern "C" int gs_conv3x3_gru_q(const void* rnet, const void* x_rest, int x_rest_stride, int c_rest, const void* wpack,
-                                const float* bias_q, const float* glo_q, const void* inp_pre, const void* z,
-                                const void* net, void* net_out, int n, int h, int w, gs_stream_t stream) {
-  GS_REQUIRE(rnet && x_rest && wpack && bias_q && glo_q && z && net && net_out, "conv3x3_gru_q: null pointer");
-  GS_REQUIRE(c_rest > 0 && c_rest % 64 == 0, "conv3x3_gru_q: c_rest must be a multiple of 64");
-  GS_REQUIRE(x_rest_stride >= c_rest && x_rest_stride % 8 == 0, "conv3x3_gru_q: bad x_rest_stride");
-  GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3_gru_q: bad shape");
-  if (n == 0) return GS_OK;
-  EpiArgs ep = EpiArgs();
-  ep.bias = bias_q;
-  ep.glo = glo_q;
-  ep.inp_pre = (const _Float16*)inp_pre;
-  ep.aux0 = (const _Float16*)z;
-  ep.aux1 = (const _Float16*)net;
-  ep.out0 = (_Float16*)net_out;
-  ep.xb = (const _Float16*)x_rest;
-  ep.xsb = x_rest_stride;
-  ep.split = 128;
-  hipStream_t st = (hipStream_t)stream;
-  const int c_in = 128 + c_rest;
-  if (lane_perm_enabled())
-    return launch3x3<64, true, 2>(rnet, 128, c_in, wpack, nullptr, 0, 128, n, h, w, st, ep);
-  return launch3x3<64, false, 2>(rnet, 128, c_in, wpack, nullptr, 0, 128, n, h, w, st, ep);
-}
-
-// 3x3 convolution + bias + ReLU in one kernel (EPI 3): corr_encoder[2] writing straight into its slice of the GRU input,
-// agg.conv2.  Same arithmetic as gs_conv3x3 followed by gs_bias_act(relu).  EXPERIMENTAL (opt-in from the host mirror).
-extern "C" int gs_conv3x3_bias_relu(const void* x, int x_stride, int c_in, const void* wpack, const float* bias, void* y,
-                                    int y_stride, int n_out, int n, int h, int w, gs_stream_t stream) {
-  GS_REQUIRE(x && wpack && bias && y, "conv3x3_bias_relu: null pointer");
-  GS_REQUIRE(c_in > 0 && c_in % 64 == 0, "conv3x3_bias_relu: c_in must be a multiple of 64");
-  GS_REQUIRE(n_out > 0 && n_out % BN == 0, "conv3x3_bias_relu: n_out must be a multiple of %d", BN);
-  GS_REQUIRE(x_stride >= c_in && x_stride % 8 == 0, "conv3x3_bias_relu: bad x_stride");
-  GS_REQUIRE(y_stride >= n_out && y_stride % 8 == 0, "conv3x3_bias_relu: bad y_stride");
-  GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3_bias_relu: bad shape");
-  if (n == 0) return GS_OK;
-  EpiArgs ep = EpiArgs();
-  ep.bias = bias;
-  hipStream_t st = (hipStream_t)stream;
-  if (lane_perm_enabled()) return launch3x3<64, true, 3>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, st, ep);
-  return launch3x3<64, false, 3>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, st, ep);
 }

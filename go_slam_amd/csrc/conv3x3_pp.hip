@@ -57,11 +57,35 @@ __device__ __forceinline__ void pp_glds16(const void* src, void* lds_wave_base) 
     __builtin_amdgcn_sched_barrier(0);                    \
   } while (0)
 
-template <int TW>
+// Fused epilogues (EPI != 0): arithmetic applied to the convolution's fp16-rounded pre-activations while they pass
+// through the epilogue's LDS tile -- the formulas and rounding points of gru_gates.hip (gs_gru_gate_zr / gs_gru_gate_q /
+// gs_bias_act), so the results equal convolution + gate kernel bit for bit, but the pre-activations never travel to HBM
+// and back.
+//   EPI 1 (ConvGRU z|r, 256 outputs): block 0 -> z = sigm(pre + inp_pre[:, 0:128] + b + glo) -> out0;
+//                                     block 1 -> r likewise from channels 128:256, out1 = r * net (net = x[:, 0:128]).
+//   EPI 2 (ConvGRU q, 128 outputs):   q = tanh(pre + inp_pre[:, 256:384] + b + glo), out0 = (1 - z) net + z q with
+//                                     z = aux0, net = aux1; the convolution's input is [x (first `split` channels,
+//                                     stride xs) | xb (stride xsb)], i.e. [r * net | corr, flow features] without a cat.
+//   EPI 3 (any width):                y = relu(pre + b); y / ys may address a channel slice of a wider tensor.
+struct PpEpi {
+  const float* bias;           // [256] (EPI 1) / [128] (EPI 2) / [n_out] (EPI 3)
+  const float* glo;            // [n, 256] / [n, 128] global-context terms
+  const _Float16* inp_pre;     // [n*h*w, 384] hoisted context-feature convolutions, or nullptr
+  const _Float16* aux0;        // EPI 2: z [n*h*w, 128]
+  const _Float16* aux1;        // EPI 2: net [n*h*w, 128]
+  _Float16* out0;              // EPI 1: z, EPI 2: new net   [n*h*w, 128]
+  _Float16* out1;              // EPI 1: r * net             [n*h*w, 128]
+  const _Float16* xb;          // EPI 2: second input source (channels >= split)
+  int xsb, split;
+};
+
+__device__ __forceinline__ float pp_sigm(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+template <int TW, int EPI>
 __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __restrict__ x, int xs, int C,
                                                             const half8* __restrict__ wpack, _Float16* __restrict__ y,
                                                             int ys, int H, int W, int rows, int tiles_x, int NB,
-                                                            int xcd) {
+                                                            int xcd, PpEpi ep) {
   constexpr int TH_ = 512 / TW, PW_ = TW + 2, NPX = (TH_ + 2) * PW_;
   constexpr int NROUND = (NPX * PP_KG + 511) / 512;       // DMA rounds (512 slots each) per patch
   constexpr int PSLOTS = NROUND * 512;                    // slots of a patch buffer; [NPX * 4, PSLOTS) hold zeros
@@ -97,7 +121,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
     top[i] = yy == 0;
     bot[i] = yy == H - 1;
   }
-  // DMA sources of this thread's patch slots (element offsets into x for chunk 0; < 0: zero page)
+  // DMA sources of this thread's patch slots: 4 * (pixel index) + channel group, or < 0 for the zero page
   int poff[NROUND];
 #pragma unroll
   for (int q = 0; q < NROUND; ++q) {
@@ -107,7 +131,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
       const int kg = ks ^ ((p >> 2) & 3);
       const int pr = p / PW_, pc = p - pr * PW_;
       const int gv = g0 + pr - 1, gx = tx0 + pc - 1;
-      if (gv >= 0 && gv < rows && gx >= 0 && gx < W) off = (gv * W + gx) * xs + kg * 8;
+      if (gv >= 0 && gv < rows && gx >= 0 && gx < W) off = (gv * W + gx) * 4 + kg;
     }
     poff[q] = off;
   }
@@ -123,7 +147,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
 
   // ---- the three building blocks --------------------------------------------------------------------------------
   auto issue_patch = [&](int src_chunk, int buf, int q, int off) {        // one 512-slot round of a patch
-    const void* src = off >= 0 ? (const void*)(x + off + src_chunk * 32) : (const void*)pp_zero_page;
+    const void* src = (const void*)pp_zero_page;
+    if (off >= 0) {
+      const size_t pix = (size_t)(off >> 2);
+      const int c0 = src_chunk * 32 + (off & 3) * 8;
+      if constexpr (EPI == 2)
+        src = c0 < ep.split ? (const void*)(x + pix * xs + c0) : (const void*)(ep.xb + pix * ep.xsb + (c0 - ep.split));
+      else
+        src = (const void*)(x + pix * xs + c0);
+    }
     pp_glds16(src, pbuf + buf * PSLOTS + q * 512 + wv * 64);
   };
   auto issue_w = [&](int src_tap, int buf) {                              // one tap's weight image
@@ -154,15 +186,28 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
       b[1][i] = pp[s1];
     }
   };
-  auto math = [&]() {                                                     // MATH phase body: 16 MFMAs
+  // MATH phase body: 16 MFMAs; `between` (the LDS-DMA issue of this tap) is placed after the first four, so that its
+  // address arithmetic issues in the shadow of running MFMAs instead of delaying the first one after the barrier
+  auto math = [&](auto&& between) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int i = 0; i < 2; ++i) {
+      acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b[0][i], acc[0][i], 0, 0, 0);
+      acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][1], b[0][i], acc[1][i], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    between();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][0], b[s][i], acc[0][i], 0, 0, 0);
-        acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][1], b[s][i], acc[1][i], 0, 0, 0);
-      }
+    for (int i = 2; i < 4; ++i) {
+      acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b[0][i], acc[0][i], 0, 0, 0);
+      acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][1], b[0][i], acc[1][i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], b[1][i], acc[0][i], 0, 0, 0);
+      acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][1], b[1][i], acc[1][i], 0, 0, 0);
+    }
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -186,13 +231,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
       // ---- MATH phase of tap tg; first put the loads for 3 taps ahead (and a round of the next patch) in flight.
       // Past the end the same number of loads is issued from clamped sources into buffers nobody reads any more, so
       // that the counted waits below stay compile-time constants.
-      {
+      __builtin_amdgcn_sched_barrier(0);
+      math([&]() {
         const int tw = tg + 3 < T ? tg + 3 : T - 1;
         issue_w(tw, (tg + 3) & 3);
         if (tap < NROUND) issue_patch(ck + 1 < nchunk ? ck + 1 : nchunk - 1, (ck + 1) & 1, tap, poff[tap]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      math();
+      });
       __builtin_amdgcn_sched_barrier(0);
       // everything issued before this tap has landed (this wave's pieces); the barrier publishes it.  Tap tg + 2's
       // weights are first read two phases from now, the next patch at the earliest four taps from now.
@@ -235,7 +279,52 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
       const int gv = g0 + ty, gx = tx0 + tx;
       if (gv < rows && gx < W) {
         const half8 v = *reinterpret_cast<const half8*>(tile + pxr * PP_TS + piece * 8);
-        *reinterpret_cast<half8*>(yb + ((size_t)gv * W + gx) * ys + piece * 8) = v;
+        const size_t pix = (size_t)gv * W + gx;
+        const int c8 = wn * 64 + piece * 8;                 // first of this lane's 8 channels inside the 128-block
+        if constexpr (EPI == 0) {
+          *reinterpret_cast<half8*>(yb + pix * ys + piece * 8) = v;
+        } else if constexpr (EPI == 3) {
+          const float* bb = ep.bias + nb * PP_BN + c8;
+          half8 o;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] = (_Float16)fmaxf((float)v[k] + bb[k], 0.0f);
+          *reinterpret_cast<half8*>(yb + pix * ys + piece * 8) = o;
+        } else if constexpr (EPI == 1) {
+          const int img = gv / H;
+          half8 pi = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (ep.inp_pre) pi = *reinterpret_cast<const half8*>(ep.inp_pre + pix * 384 + nb * 128 + c8);
+          const float* bb = ep.bias + nb * 128 + c8;
+          const float* gg = ep.glo + (size_t)img * 256 + nb * 128 + c8;
+          half8 o;
+          if (nb == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (_Float16)pp_sigm((float)v[k] + (float)pi[k] + bb[k] + gg[k]);
+            *reinterpret_cast<half8*>(ep.out0 + pix * 128 + c8) = o;
+          } else {
+            const half8 net = *reinterpret_cast<const half8*>(x + pix * xs + c8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              o[k] = (_Float16)(pp_sigm((float)v[k] + (float)pi[k] + bb[k] + gg[k]) * (float)net[k]);
+            *reinterpret_cast<half8*>(ep.out1 + pix * 128 + c8) = o;
+          }
+        } else {
+          const int img = gv / H;
+          half8 pi = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (ep.inp_pre) pi = *reinterpret_cast<const half8*>(ep.inp_pre + pix * 384 + 256 + c8);
+          const half8 zz = *reinterpret_cast<const half8*>(ep.aux0 + pix * 128 + c8);
+          const half8 nn = *reinterpret_cast<const half8*>(ep.aux1 + pix * 128 + c8);
+          const float* bb = ep.bias + c8;
+          const float* gg = ep.glo + (size_t)img * 128 + c8;
+          half8 o;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float a_ = (float)v[k] + (float)pi[k] + bb[k] + gg[k];
+            const float q = 1.0f - 2.0f / (1.0f + __expf(2.0f * a_));
+            const float zf = (float)zz[k];
+            o[k] = (_Float16)((1.0f - zf) * (float)nn[k] + zf * q);
+          }
+          *reinterpret_cast<half8*>(ep.out0 + pix * 128 + c8) = o;
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -243,26 +332,35 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
   }
 }
 
-template <int TW>
+template <int TW, int EPI>
 int launch_pp(const void* x, int x_stride, int c_in, const void* wpack, void* y, int y_stride, int n_out, int n, int h,
-              int w, int xcd, hipStream_t st) {
+              int w, int xcd, hipStream_t st, PpEpi ep = PpEpi()) {
   constexpr int NPX = (512 / TW + 2) * (TW + 2);
   constexpr int PSLOTS = ((NPX * PP_KG + 511) / 512) * 512;
   constexpr size_t lds = (size_t)(2 * PSLOTS + 4 * PP_WTAP) * sizeof(half8);
   static GsLdsLimit limit;
-  if (int rc = limit.raise((const void*)conv3x3_pp_kernel<TW>, lds, "conv3x3_pp")) return rc;
+  if (int rc = limit.raise((const void*)conv3x3_pp_kernel<TW, EPI>, lds, "conv3x3_pp")) return rc;
   const long long rows = (long long)n * h;
-  GS_REQUIRE(rows * w * (long long)x_stride < (1ll << 31), "conv3x3_pp: input too large for 32-bit element offsets");
+  GS_REQUIRE(rows * w < (1ll << 29), "conv3x3_pp: too many pixels");
   const int tiles_x = gs_cdiv(w, TW), tiles_y = gs_cdiv((int)rows, 512 / TW);
   const int NB = n_out / PP_BN;
   const long long blocks = (long long)tiles_x * tiles_y * NB;
   GS_REQUIRE(blocks < (1ll << 31), "conv3x3_pp: too many workgroups");
-  conv3x3_pp_kernel<TW><<<dim3((unsigned)blocks), 512, lds, st>>>((const _Float16*)x, x_stride, c_in, (const half8*)wpack,
-                                                                  (_Float16*)y, y_stride, h, w, (int)rows, tiles_x, NB,
-                                                                  xcd);
+  conv3x3_pp_kernel<TW, EPI><<<dim3((unsigned)blocks), 512, lds, st>>>(
+      (const _Float16*)x, x_stride, c_in, (const half8*)wpack, (_Float16*)y, y_stride, h, w, (int)rows, tiles_x, NB, xcd,
+      ep);
   GS_CHECK_LAUNCH("conv3x3_pp");
   return GS_OK;
 }
+
+template <int EPI>
+int dispatch_pp(const void* x, int x_stride, int c_in, const void* wpack, int tw, void* y, int y_stride, int n_out, int n,
+                int h, int w, int xcd, hipStream_t st, PpEpi ep = PpEpi()) {
+  if (tw == 8) return launch_pp<8, EPI>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, xcd, st, ep);
+  return launch_pp<16, EPI>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, xcd, st, ep);
+}
+
+int pp_tile_width(int w) { return gs_cdiv(w, 8) * 8 < gs_cdiv(w, 16) * 16 ? 8 : 16; }   // least column padding
 
 }  // namespace
 
@@ -276,7 +374,63 @@ extern "C" int gs_conv3x3_pp(const void* x, int x_stride, int c_in, const void* 
   GS_REQUIRE(y_stride >= n_out && y_stride % 8 == 0, "conv3x3_pp: y_stride must be >= n_out and a multiple of 8");
   GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3_pp: bad shape");
   if (n == 0) return GS_OK;
-  hipStream_t st = (hipStream_t)stream;
-  if (tw == 8) return launch_pp<8>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, xcd_order ? 1 : 0, st);
-  return launch_pp<16>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, xcd_order ? 1 : 0, st);
+  return dispatch_pp<0>(x, x_stride, c_in, wpack, tw, y, y_stride, n_out, n, h, w, xcd_order ? 1 : 0,
+                        (hipStream_t)stream);
+}
+
+// ---- ConvGRU with the gate arithmetic fused into the convolutions' epilogues (see PpEpi) -----------------------------
+extern "C" int gs_conv3x3_gru_zr(const void* hx, int hx_stride, int c_in, const void* wpack, const float* bias_zr,
+                                 const float* glo_zr, const void* inp_pre, void* z_out, void* rnet_out, int n, int h,
+                                 int w, gs_stream_t stream) {
+  GS_REQUIRE(hx && wpack && bias_zr && glo_zr && z_out && rnet_out, "conv3x3_gru_zr: null pointer");
+  GS_REQUIRE(c_in >= 128 && c_in % 32 == 0, "conv3x3_gru_zr: c_in must be >= 128 and a multiple of 32");
+  GS_REQUIRE(hx_stride >= c_in && hx_stride % 8 == 0, "conv3x3_gru_zr: bad hx_stride");
+  GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3_gru_zr: bad shape");
+  if (n == 0) return GS_OK;
+  PpEpi ep = PpEpi();
+  ep.bias = bias_zr;
+  ep.glo = glo_zr;
+  ep.inp_pre = (const _Float16*)inp_pre;
+  ep.out0 = (_Float16*)z_out;
+  ep.out1 = (_Float16*)rnet_out;
+  return dispatch_pp<1>(hx, hx_stride, c_in, wpack, pp_tile_width(w), nullptr, 0, 256, n, h, w, 1, (hipStream_t)stream, ep);
+}
+
+extern "C" int gs_conv3x3_gru_q(const void* rnet, const void* x_rest, int x_rest_stride, int c_rest, const void* wpack,
+                                const float* bias_q, const float* glo_q, const void* inp_pre, const void* z,
+                                const void* net, void* net_out, int n, int h, int w, gs_stream_t stream) {
+  GS_REQUIRE(rnet && x_rest && wpack && bias_q && glo_q && z && net && net_out, "conv3x3_gru_q: null pointer");
+  GS_REQUIRE(c_rest > 0 && c_rest % 32 == 0, "conv3x3_gru_q: c_rest must be a multiple of 32");
+  GS_REQUIRE(x_rest_stride >= c_rest && x_rest_stride % 8 == 0, "conv3x3_gru_q: bad x_rest_stride");
+  GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3_gru_q: bad shape");
+  if (n == 0) return GS_OK;
+  PpEpi ep = PpEpi();
+  ep.bias = bias_q;
+  ep.glo = glo_q;
+  ep.inp_pre = (const _Float16*)inp_pre;
+  ep.aux0 = (const _Float16*)z;
+  ep.aux1 = (const _Float16*)net;
+  ep.out0 = (_Float16*)net_out;
+  ep.xb = (const _Float16*)x_rest;
+  ep.xsb = x_rest_stride;
+  ep.split = 128;
+  return dispatch_pp<2>(rnet, 128, 128 + c_rest, wpack, pp_tile_width(w), nullptr, 0, 128, n, h, w, 1,
+                        (hipStream_t)stream, ep);
+}
+
+// 3x3 convolution + bias + ReLU in one kernel (EPI 3): corr_encoder[2] writing straight into its slice of the GRU input,
+// agg.conv2.  Same arithmetic as gs_conv3x3_pp followed by gs_bias_act(relu).
+extern "C" int gs_conv3x3_bias_relu(const void* x, int x_stride, int c_in, const void* wpack, const float* bias, void* y,
+                                    int y_stride, int n_out, int n, int h, int w, gs_stream_t stream) {
+  GS_REQUIRE(x && wpack && bias && y, "conv3x3_bias_relu: null pointer");
+  GS_REQUIRE(c_in > 0 && c_in % 32 == 0, "conv3x3_bias_relu: c_in must be a multiple of 32");
+  GS_REQUIRE(n_out > 0 && n_out % PP_BN == 0, "conv3x3_bias_relu: n_out must be a multiple of %d", PP_BN);
+  GS_REQUIRE(x_stride >= c_in && x_stride % 8 == 0, "conv3x3_bias_relu: bad x_stride");
+  GS_REQUIRE(y_stride >= n_out && y_stride % 8 == 0, "conv3x3_bias_relu: bad y_stride");
+  GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3_bias_relu: bad shape");
+  if (n == 0) return GS_OK;
+  PpEpi ep = PpEpi();
+  ep.bias = bias;
+  return dispatch_pp<3>(x, x_stride, c_in, wpack, pp_tile_width(w), y, y_stride, n_out, n, h, w, 1, (hipStream_t)stream,
+                        ep);
 }

@@ -188,12 +188,12 @@ CONV3X3_KC = "auto"
 # Row-stacked tiling (gs_conv3x3_stacked: no tile padding along the rows, tile width chosen per map width) -- opt-in
 # (GOSLAM_CONV3X3_STACKED=1) until it has been timed against the plain tiling; with it "auto" covers every map size.
 CONV3X3_STACKED = os.environ.get("GOSLAM_CONV3X3_STACKED", "0") == "1"
-# Epilogues fused into the own 3x3 convolutions: the ConvGRU gate arithmetic (gs_conv3x3_gru_zr / _q) and bias + ReLU
-# (gs_conv3x3_bias_relu).  Bit-identical to conv + gate / bias_act kernels by construction, parity-checked by
-# emulation, not yet run on hardware -> opt-in.
 # The two-group ping-pong kernel (csrc/conv3x3_pp.hip); GOSLAM_CONV3X3_PP=0 falls back to the round-1 kernels.
 CONV3X3_PP = os.environ.get("GOSLAM_CONV3X3_PP", "1") == "1"
-GRU_FUSED_EPILOGUE = os.environ.get("GOSLAM_GRU_FUSED", "0") == "1"
+# Epilogues fused into the ping-pong kernel: the ConvGRU gate arithmetic (gs_conv3x3_gru_zr / _q) and bias + ReLU
+# (gs_conv3x3_bias_relu).  Bit-identical to conv + gate / bias_act kernels (same formulas and rounding points; GPU test
+# test_fused_gru_epilogues_equal_conv_plus_gate_kernels); zr_pre / q_pre never travel to HBM and back.
+GRU_FUSED_EPILOGUE = os.environ.get("GOSLAM_GRU_FUSED", "1") == "1"
 _CONV3X3_PACKS = {}        # (data_ptr, version, shape, device, kc) -> (packed image, weight tensor kept alive)
 _CONV3X3_PACKS_MAX = 32
 
@@ -301,7 +301,7 @@ def conv_bias_act(cache, conv, x, act, out=None, out_channel=0):
     (PyTorch issues conv, add_(bias) and relu_ as three passes).  With `out` (an NHWC fp16 tensor
     with more channels) the result lands in out[:, out_channel:out_channel+C] -- no torch.cat."""
     w, b = cache.get(conv)
-    if GRU_FUSED_EPILOGUE and act == "relu" and w.shape[1] % 64 == 0 and _use_own_conv3x3(x, w, conv.stride, conv.padding):
+    if GRU_FUSED_EPILOGUE and CONV3X3_PP and act == "relu" and _use_own_conv3x3(x, w, conv.stride, conv.padding):
         from . import _lib
         n, c, h, wd = x.shape
         O = w.shape[0]
@@ -309,7 +309,7 @@ def conv_bias_act(cache, conv, x, act, out=None, out_channel=0):
             out, out_channel = torch.empty((n, O, h, wd), dtype=torch.float16, device=x.device,
                                            memory_format=torch.channels_last), 0
         with torch.cuda.device(x.device):
-            rc = _lib.lib().gs_conv3x3_bias_relu(_lib.ptr(x), c, c, _lib.ptr(conv3x3_weight_image(w, 64)), _lib.ptr(b),
+            rc = _lib.lib().gs_conv3x3_bias_relu(_lib.ptr(x), c, c, _lib.ptr(conv3x3_weight_image(w, 32)), _lib.ptr(b),
                                                  out.data_ptr() + 2 * out_channel, out.shape[1], O, n, h, wd,
                                                  _lib.stream_ptr(x.device))
         _lib.check(rc, "conv3x3_bias_relu")
@@ -409,7 +409,7 @@ class ConvGRU(nn.Module):
                                     _lib.ptr(gw[2]), _lib.ptr(gw[3]), _lib.ptr(gw[4]), _lib.ptr(gw[5]),
                                     _lib.ptr(gzr), _lib.ptr(gq), b, hw, _lib.ptr(ws), ws.numel(), st), "gru_glo")
             cin = hx.shape[1]
-            if GRU_FUSED_EPILOGUE and _use_own_conv3x3(hx, wzr, 1, 1) and cin % 64 == 0 and h * w > 0:
+            if GRU_FUSED_EPILOGUE and CONV3X3_PP and _use_own_conv3x3(hx, wzr, 1, 1) and h * w > 0:
                 # gate arithmetic in the convolutions' epilogues: zr_pre / q_pre never reach HBM; hx stays intact
                 z = torch.empty_like(net)
                 rnet = torch.empty_like(net)
@@ -418,7 +418,7 @@ class ConvGRU(nn.Module):
                                                _lib.ptr(bzr), _lib.ptr(gzr), _lib.ptr(inp_pre), _lib.ptr(z),
                                                _lib.ptr(rnet), b, h, w, st), "conv3x3_gru_zr")
                 _lib.check(L.gs_conv3x3_gru_q(_lib.ptr(rnet), hx.data_ptr() + 2 * 128, cin, cin - 128,
-                                              _lib.ptr(conv3x3_weight_image(wq, 64)), _lib.ptr(bq), _lib.ptr(gq),
+                                              _lib.ptr(conv3x3_weight_image(wq, 32)), _lib.ptr(bq), _lib.ptr(gq),
                                               _lib.ptr(inp_pre), _lib.ptr(z), _lib.ptr(net), _lib.ptr(out), b, h, w,
                                               st), "conv3x3_gru_q")
                 return out

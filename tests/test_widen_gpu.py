@@ -340,8 +340,6 @@ def test_update_operator_with_own_conv3x3_matches_miopen_path(built_lib):
         torch.testing.assert_close(a, b, rtol=5e-3, atol=3e-3, msg=lambda m, nm=name: f"{nm}: {m}")
 
 
-@pytest.mark.skipif(os.environ.get("GOSLAM_TEST_EXPERIMENTAL") != "1",
-                    reason="opt-in variant that has not run on hardware yet (tools/conv3x3_variants.sh sets the flag)")
 @pytest.mark.parametrize("hoisted", [True, False])
 def test_fused_gru_epilogues_equal_conv_plus_gate_kernels(built_lib, hoisted):
     """ConvGRU.forward_hx with the gate arithmetic fused into the convolutions' epilogues (gs_conv3x3_gru_zr / _q) vs the
@@ -376,8 +374,6 @@ def test_fused_gru_epilogues_equal_conv_plus_gate_kernels(built_lib, hoisted):
     assert torch.equal(out[True], out[False])
 
 
-@pytest.mark.skipif(os.environ.get("GOSLAM_TEST_EXPERIMENTAL") != "1",
-                    reason="opt-in variant that has not run on hardware yet (tools/conv3x3_variants.sh sets the flag)")
 def test_fused_bias_relu_convolution_equals_conv_plus_bias_act(built_lib):
     """gs_conv3x3_bias_relu (bias + ReLU in the convolution's store stage, output into a channel slice of a wider
     tensor) vs gs_conv3x3 followed by gs_bias_act: EQUAL, and the other channels of the destination are untouched."""
