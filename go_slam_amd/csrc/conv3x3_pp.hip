@@ -77,7 +77,13 @@ struct PpEpi {
   _Float16* out1;              // EPI 1: r * net             [n*h*w, 128]
   const _Float16* xb;          // EPI 2: second input source (channels >= split)
   int xsb, split;
+  long long* dbg;              // tools only (gs_conv3x3_pp_probe): per-workgroup s_memtime stamps, nullptr in production
+  int variant;                 // tools only: bit 0 = no s_setprio around the MFMAs, bit 1 = read phase without masks
 };
+
+__device__ __forceinline__ void pp_stamp(long long* dbg, int slot) {
+  if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 4 + slot] = (long long)__builtin_amdgcn_s_memtime();
+}
 
 __device__ __forceinline__ float pp_sigm(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
       const int p = pbi + toff;                           // out of the chunk loop (72 VGPRs, spills at the 256 cap)
       int s0 = p * 4 + (kgl ^ ((p >> 2) & 3));            // channel group kgl (s = 0); group 2 + kgl is s0 ^ 2
       int s1 = s0 ^ 2;
-      if ((dy == 0 && top[i]) || (dy == 2 && bot[i])) {   // the row above / below belongs to another image
+      if (!(ep.variant & 2) && ((dy == 0 && top[i]) || (dy == 2 && bot[i]))) {   // the row above / below belongs to another image
         s0 = ZSLOT;
         s1 = ZSLOT;
       }
@@ -188,8 +194,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
   };
   // MATH phase body: 16 MFMAs; `between` (the LDS-DMA issue of this tap) is placed after the first four, so that its
   // address arithmetic issues in the shadow of running MFMAs instead of delaying the first one after the barrier
+  const bool prio = !(ep.variant & 1);
   auto math = [&](auto&& between) {
-    __builtin_amdgcn_s_setprio(1);
+    if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b[0][i], acc[0][i], 0, 0, 0);
@@ -208,10 +215,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
       acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], b[1][i], acc[0][i], 0, 0, 0);
       acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][1], b[1][i], acc[1][i], 0, 0, 0);
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (prio) __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- prologue: patch of chunk 0, weights of taps 0..2 ------------------------------------------------------------
+  pp_stamp(ep.dbg, 0);
 #pragma unroll
   for (int q = 0; q < NROUND; ++q) issue_patch(0, 0, q, poff[q]);
   issue_w(0, 0);
@@ -219,6 +227,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
   issue_w(2, 2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PP_BAR();
+  pp_stamp(ep.dbg, 1);
   if (grp2 == 1) PP_BAR();                                // group 1 runs one phase behind from here on
   read_frags(0, 0, 0);
   PP_LGKM0();
@@ -250,6 +259,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
       PP_BAR();
     }
   }
+  pp_stamp(ep.dbg, 2);
   if (grp2 == 0) PP_BAR();                                // pairs with group 1's last barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped tail loads: they target LDS the epilogue reuses
   PP_BAR();
@@ -259,6 +269,37 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
   _Float16* yb = y + nb * PP_BN + wn * 64;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    // (1) where this lane's four output pieces go, and -- for the gate epilogues -- their operands, requested NOW so
+    //     that the loads are in flight while the accumulators are transposed through LDS
+    size_t pix4[4];
+    bool ok4[4];
+    half8 pi4[4], u4[4], v4[4];
+    const int piece = lane & 7;
+    const int c8 = wn * 64 + piece * 8;                     // first of this lane's 8 channels inside the 128-block
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int pxr = it * 8 + (lane >> 3);
+      int ty, tx;
+      tile_pixel<TW, true>(wm, i, pxr, ty, tx);
+      const int gv = g0 + ty, gx = tx0 + tx;
+      ok4[it] = gv < rows && gx < W;
+      pix4[it] = (size_t)gv * W + gx;
+      if constexpr (EPI == 1 || EPI == 2) {
+        const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        pi4[it] = z8; u4[it] = z8; v4[it] = z8;
+        if (ok4[it]) {
+          if constexpr (EPI == 1) {
+            if (ep.inp_pre) pi4[it] = *reinterpret_cast<const half8*>(ep.inp_pre + pix4[it] * 384 + nb * 128 + c8);
+            if (nb == 1) u4[it] = *reinterpret_cast<const half8*>(x + pix4[it] * xs + c8);          // net
+          } else {
+            if (ep.inp_pre) pi4[it] = *reinterpret_cast<const half8*>(ep.inp_pre + pix4[it] * 384 + 256 + c8);
+            u4[it] = *reinterpret_cast<const half8*>(ep.aux0 + pix4[it] * 128 + c8);               // z
+            v4[it] = *reinterpret_cast<const half8*>(ep.aux1 + pix4[it] * 128 + c8);               // net
+          }
+        }
+      }
+    }
+    // (2) accumulators -> [32 pixels][64 channels] fp16 tile
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -271,16 +312,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // (3) rows of 64 channels leave as 128 contiguous bytes per pixel
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int pxr = it * 8 + (lane >> 3), piece = lane & 7;
-      int ty, tx;
-      tile_pixel<TW, true>(wm, i, pxr, ty, tx);
-      const int gv = g0 + ty, gx = tx0 + tx;
-      if (gv < rows && gx < W) {
+      const int pxr = it * 8 + (lane >> 3);
+      if (ok4[it]) {
         const half8 v = *reinterpret_cast<const half8*>(tile + pxr * PP_TS + piece * 8);
-        const size_t pix = (size_t)gv * W + gx;
-        const int c8 = wn * 64 + piece * 8;                 // first of this lane's 8 channels inside the 128-block
+        const size_t pix = pix4[it];
         if constexpr (EPI == 0) {
           *reinterpret_cast<half8*>(yb + pix * ys + piece * 8) = v;
         } else if constexpr (EPI == 3) {
@@ -290,9 +328,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
           for (int k = 0; k < 8; ++k) o[k] = (_Float16)fmaxf((float)v[k] + bb[k], 0.0f);
           *reinterpret_cast<half8*>(yb + pix * ys + piece * 8) = o;
         } else if constexpr (EPI == 1) {
-          const int img = gv / H;
-          half8 pi = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (ep.inp_pre) pi = *reinterpret_cast<const half8*>(ep.inp_pre + pix * 384 + nb * 128 + c8);
+          const int img = (int)(pix / ((size_t)H * W));
+          const half8 pi = pi4[it];
           const float* bb = ep.bias + nb * 128 + c8;
           const float* gg = ep.glo + (size_t)img * 256 + nb * 128 + c8;
           half8 o;
@@ -301,18 +338,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
             for (int k = 0; k < 8; ++k) o[k] = (_Float16)pp_sigm((float)v[k] + (float)pi[k] + bb[k] + gg[k]);
             *reinterpret_cast<half8*>(ep.out0 + pix * 128 + c8) = o;
           } else {
-            const half8 net = *reinterpret_cast<const half8*>(x + pix * xs + c8);
+            const half8 net = u4[it];
 #pragma unroll
             for (int k = 0; k < 8; ++k)
               o[k] = (_Float16)(pp_sigm((float)v[k] + (float)pi[k] + bb[k] + gg[k]) * (float)net[k]);
             *reinterpret_cast<half8*>(ep.out1 + pix * 128 + c8) = o;
           }
         } else {
-          const int img = gv / H;
-          half8 pi = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (ep.inp_pre) pi = *reinterpret_cast<const half8*>(ep.inp_pre + pix * 384 + 256 + c8);
-          const half8 zz = *reinterpret_cast<const half8*>(ep.aux0 + pix * 128 + c8);
-          const half8 nn = *reinterpret_cast<const half8*>(ep.aux1 + pix * 128 + c8);
+          const int img = (int)(pix / ((size_t)H * W));
+          const half8 pi = pi4[it], zz = u4[it], nn = v4[it];
           const float* bb = ep.bias + c8;
           const float* gg = ep.glo + (size_t)img * 128 + c8;
           half8 o;
@@ -330,6 +364,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+  pp_stamp(ep.dbg, 3);
 }
 
 template <int TW, int EPI>
@@ -433,4 +468,17 @@ extern "C" int gs_conv3x3_bias_relu(const void* x, int x_stride, int c_in, const
   ep.bias = bias;
   return dispatch_pp<3>(x, x_stride, c_in, wpack, pp_tile_width(w), y, y_stride, n_out, n, h, w, 1, (hipStream_t)stream,
                         ep);
+}
+
+// Tools only (tools/conv3x3_pp_probe.py): gs_conv3x3_pp with per-workgroup s_memtime stamps (dbg: int64 [workgroups][4] =
+// start, prologue done, main loop done, end; wave 0 of each workgroup) and A/B variant bits (see PpEpi).
+extern "C" int gs_conv3x3_pp_probe(const void* x, int x_stride, int c_in, const void* wpack, int tw, void* y, int y_stride,
+                                   int n_out, int n, int h, int w, int variant, long long* dbg, gs_stream_t stream) {
+  GS_REQUIRE(x && wpack && y, "conv3x3_pp_probe: null pointer");
+  GS_REQUIRE((tw == 8 || tw == 16) && c_in > 0 && c_in % 32 == 0 && n_out > 0 && n_out % PP_BN == 0 && n > 0,
+             "conv3x3_pp_probe: bad arguments");
+  PpEpi ep = PpEpi();
+  ep.dbg = dbg;
+  ep.variant = variant;
+  return dispatch_pp<0>(x, x_stride, c_in, wpack, tw, y, y_stride, n_out, n, h, w, 1, (hipStream_t)stream, ep);
 }

@@ -192,6 +192,12 @@ int gs_conv3x3_stacked(const void* x, int x_stride, int c_in, const void* wpack,
  * blocks of a tile run on one XCD (shared L2).  The production path of the update operator.                  */
 int gs_conv3x3_pp(const void* x, int x_stride, int c_in, const void* wpack, int tw, void* y, int y_stride, int n_out,
                   int n, int h, int w, int xcd_order, gs_stream_t stream);
+/* Measurement hook of the kernel above (tools/conv3x3_pp_probe.py; not used by the product path): same convolution,
+ * plus per-workgroup s_memtime stamps dbg[workgroup][4] = {start, prologue done, main loop done, end} (NULL: none) and
+ * A/B variant bits (1: no s_setprio around the MFMA phase, 2: read phase without the image-boundary masks -- wrong
+ * results at image borders, timing only).                                                                      */
+int gs_conv3x3_pp_probe(const void* x, int x_stride, int c_in, const void* wpack, int tw, void* y, int y_stride,
+                        int n_out, int n, int h, int w, int variant, long long* dbg, gs_stream_t stream);
 /* ConvGRU (src/modules/gru.py:20-33) with the gate arithmetic fused into the 3x3 convolutions' epilogues
  * (EXPERIMENTAL: opt-in from the host mirror; results equal gs_conv3x3 + gs_gru_gate_zr / gs_gru_gate_q bit for bit,
  * but the 256 + 128 channels of pre-activations never travel to HBM and back).
