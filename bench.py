@@ -242,7 +242,9 @@ def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768, s
     ms = 1e3 * dt / steps
     return {"metric": "NeuS mapping train step rays/s (render + loss + backward + all-reduce + clip + AdamW)",
             "value": n / (ms * 1e-3), "unit": "rays/s", "global_rays": n, "rays_per_gpu": n // world, "ms_per_step": ms,
-            "scaling": scaling, "allreduce_bytes": 4 * sum(p.numel() for p in tr.train_params) if world > 1 else 0,
+            "scaling": scaling, "fused_step": bool(getattr(tr, "fused", False)),
+            "allreduce_bytes": 0 if world == 1 else (2 * tr.flat.n16 + 4 * (tr.flat.n - tr.flat.n16) if tr.fused
+                                                     else 4 * sum(p.numel() for p in tr.train_params)),
             "final_loss": float(loss)}
 
 

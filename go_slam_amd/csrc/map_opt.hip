@@ -1,0 +1,152 @@
+// The mapper's optimiser step on ONE flat parameter buffer (reference src/mapping.py:55-58,135-137:
+// clip_grad_norm_(35) over all trained parameters, then AdamW with two learning rates) in two launches:
+//
+//   map_grad_sqnorm_kernel   sum of squared gradients over [hash-table gradient | dense-parameter gradients] into a
+//                            device scalar (the table gradient may stay in tiny-cuda-nn's loss-scaled fp16 form -- it is
+//                            unscaled on the fly, never converted in a pass of its own);
+//   map_adamw_kernel         clip coefficient from that scalar, unscale, AdamW (decoupled weight decay, bias-corrected
+//                            moments, torch.optim.AdamW's formulas), and the fp16 working copy of the parameters that
+//                            the next forward reads -- instead of foreach-norm + stack + norm + clamp + foreach-mul +
+//                            fused AdamW (x2 groups) + a 12.6 M-entry fp32 -> fp16 cast + zero_grad.
+//
+// Traffic per step: table 12.6 M entries x (2 B grad + 4 B p + 4 B m + 4 B v read, 4 + 4 + 4 + 2 written) = 28 B
+// -> 353 MB, one pass; HBM-bound (~60 us on MI355X).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// grads: element i < n16 comes from g16 (fp16, value * inv_scale16), element i >= n16 from g32[i - n16]
+__global__ __launch_bounds__(256) void map_grad_sqnorm_kernel(const _Float16* __restrict__ g16, size_t n16,
+                                                              float inv_scale16, const float* __restrict__ g32,
+                                                              size_t n32, float* __restrict__ out) {
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  float acc = 0.0f;
+  const size_t n8 = n16 / 8;
+  for (size_t i = tid; i < n8; i += stride) {
+    const half8 v = reinterpret_cast<const half8*>(g16)[i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float f = (float)v[k] * inv_scale16;
+      acc = fmaf(f, f, acc);
+    }
+  }
+  for (size_t i = n8 * 8 + tid; i < n16; i += stride) {
+    const float f = (float)g16[i] * inv_scale16;
+    acc = fmaf(f, f, acc);
+  }
+  for (size_t i = tid; i < n32; i += stride) {
+    const float f = g32[i];
+    acc = fmaf(f, f, acc);
+  }
+  acc = gs_wave_sum(acc);
+  __shared__ float part[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) part[wv] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+struct AdamArgs {
+  float* p; float* m; float* v; _Float16* p16;
+  const _Float16* g16; const float* g32;
+  size_t n16, n;                 // elements [0, n16) take their gradient from g16, [n16, n) from g32
+  float inv_scale16;
+  float lr16, lr32;              // learning rates of the two ranges (volume / network parameters)
+  float beta1, beta2, eps, wd, bc1, bc2_sqrt;
+  const float* sqnorm; float max_norm;
+};
+
+__device__ __forceinline__ void adam_one(float& p, float& m, float& v, float g, float lr, const AdamArgs& A) {
+  p = p * (1.0f - lr * A.wd);                          // decoupled weight decay
+  m = A.beta1 * m + (1.0f - A.beta1) * g;              // = m.lerp(g, 1 - beta1)
+  v = A.beta2 * v + (1.0f - A.beta2) * g * g;
+  const float denom = sqrtf(v) / A.bc2_sqrt + A.eps;
+  p = p - (lr / A.bc1) * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void map_adamw_kernel(AdamArgs A) {
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
+  float coef = 1.0f;
+  if (A.sqnorm) {
+    const float c = A.max_norm / (sqrtf(*A.sqnorm) + 1e-6f);
+    coef = c < 1.0f ? c : 1.0f;
+  }
+  const float s16 = A.inv_scale16 * coef;
+  const size_t n8 = A.n16 / 8;
+  for (size_t i = tid; i < n8; i += stride) {
+    const half8 g = reinterpret_cast<const half8*>(A.g16)[i];
+    float4 p0 = reinterpret_cast<float4*>(A.p)[2 * i], p1 = reinterpret_cast<float4*>(A.p)[2 * i + 1];
+    float4 m0 = reinterpret_cast<float4*>(A.m)[2 * i], m1 = reinterpret_cast<float4*>(A.m)[2 * i + 1];
+    float4 v0 = reinterpret_cast<float4*>(A.v)[2 * i], v1 = reinterpret_cast<float4*>(A.v)[2 * i + 1];
+    float pp[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+    float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    half8 h;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      adam_one(pp[k], mm[k], vv[k], (float)g[k] * s16, A.lr16, A);
+      h[k] = (_Float16)pp[k];
+    }
+    reinterpret_cast<float4*>(A.p)[2 * i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    reinterpret_cast<float4*>(A.p)[2 * i + 1] = make_float4(pp[4], pp[5], pp[6], pp[7]);
+    reinterpret_cast<float4*>(A.m)[2 * i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    reinterpret_cast<float4*>(A.m)[2 * i + 1] = make_float4(mm[4], mm[5], mm[6], mm[7]);
+    reinterpret_cast<float4*>(A.v)[2 * i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    reinterpret_cast<float4*>(A.v)[2 * i + 1] = make_float4(vv[4], vv[5], vv[6], vv[7]);
+    if (A.p16) reinterpret_cast<half8*>(A.p16)[i] = h;
+  }
+  for (size_t i = n8 * 8 + tid; i < A.n; i += stride) {
+    const bool lo = i < A.n16;
+    const float g = lo ? (float)A.g16[i] * s16 : A.g32[i - A.n16] * coef;
+    float p = A.p[i], m = A.m[i], v = A.v[i];
+    adam_one(p, m, v, g, lo ? A.lr16 : A.lr32, A);
+    A.p[i] = p; A.m[i] = m; A.v[i] = v;
+    if (A.p16) A.p16[i] = (_Float16)p;
+  }
+}
+
+}  // namespace
+
+extern "C" int gs_map_grad_sqnorm(const void* g16, size_t n16, float inv_scale16, const float* g32, size_t n32,
+                                  float* sqnorm_out, gs_stream_t stream) {
+  GS_REQUIRE(sqnorm_out && (g16 || n16 == 0) && (g32 || n32 == 0), "map_grad_sqnorm: null pointer");
+  GS_REQUIRE(((size_t)g16 & 15) == 0, "map_grad_sqnorm: g16 must be 16-byte aligned");
+  if (n16 + n32 == 0) return GS_OK;
+  const size_t work = n16 / 8 + n32;
+  unsigned blocks = (unsigned)((work + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks == 0) blocks = 1;
+  map_grad_sqnorm_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const _Float16*)g16, n16, inv_scale16, g32, n32,
+                                                                   sqnorm_out);
+  GS_CHECK_LAUNCH("map_grad_sqnorm");
+  return GS_OK;
+}
+
+extern "C" int gs_map_adamw(float* p, float* m, float* v, void* p16, const void* g16, size_t n16, float inv_scale16,
+                            const float* g32, size_t n, float lr16, float lr32, float beta1, float beta2, float eps,
+                            float weight_decay, int step, const float* sqnorm, float max_norm, gs_stream_t stream) {
+  GS_REQUIRE(p && m && v && (g16 || n16 == 0) && (g32 || n == n16), "map_adamw: null pointer");
+  GS_REQUIRE(n16 <= n && n16 % 8 == 0 && step >= 1, "map_adamw: bad sizes (n16 must be a multiple of 8) or step");
+  GS_REQUIRE((((size_t)p | (size_t)m | (size_t)v | (size_t)g16 | (size_t)p16) & 15) == 0,
+             "map_adamw: buffers must be 16-byte aligned");
+  if (n == 0) return GS_OK;
+  AdamArgs A;
+  A.p = p; A.m = m; A.v = v; A.p16 = (_Float16*)p16; A.g16 = (const _Float16*)g16; A.g32 = g32;
+  A.n16 = n16; A.n = n; A.inv_scale16 = inv_scale16; A.lr16 = lr16; A.lr32 = lr32;
+  A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.wd = weight_decay;
+  A.bc1 = 1.0f - powf(beta1, (float)step);
+  A.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+  A.sqnorm = sqnorm; A.max_norm = max_norm;
+  const size_t work = n16 / 8 + (n - n16);
+  unsigned blocks = (unsigned)((work + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  map_adamw_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(A);
+  GS_CHECK_LAUNCH("map_adamw");
+  return GS_OK;
+}

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void grid_encode_kernel(const float* __restric
 struct NeusArgs {
   const float* rays_o; const float* rays_d; const float* z_vals; const float* dists;
   const _Float16* grid; const float* sdf_w; const float* sdf_b; const float* color_B;
-  float inv_s;
+  float inv_s; const float* inv_s_dev;     // inv_s_dev != nullptr: read the scalar from device memory instead
   float bound[6]; float rt_bound[6];
   int n, s;
 };
@@ -361,8 +361,9 @@ __global__ __launch_bounds__(256) void neus_point_kernel(NeusArgs A, gs_grid_met
   const float iter_cos = -(fmaxf(-true_cos * 0.5f + 0.5f, 0.0f) * 0.0f + fmaxf(-true_cos, 0.0f) * 1.0f);
   const float est_next = sdf + iter_cos * dist / 2.0f;
   const float est_prev = sdf - iter_cos * dist / 2.0f;
-  const float prev_cdf = 1.0f / (1.0f + expf(-(est_prev * A.inv_s)));
-  const float next_cdf = 1.0f / (1.0f + expf(-(est_next * A.inv_s)));
+  const float inv_s_ = A.inv_s_dev ? *A.inv_s_dev : A.inv_s;
+  const float prev_cdf = 1.0f / (1.0f + expf(-(est_prev * inv_s_)));
+  const float next_cdf = 1.0f / (1.0f + expf(-(est_next * inv_s_)));
   float alpha = (prev_cdf - next_cdf + 1e-5f) / (prev_cdf + 1e-5f);
   alpha = fminf(fmaxf(alpha, 0.0f), 1.0f);
   sdf_out[idx] = sdf;
@@ -736,7 +737,8 @@ extern "C" size_t gs_neus_forward_workspace_bytes(int n, int s) {
 
 extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const float* z_vals, const float* dists,
                                const void* grid, const float* sdf_w, const float* sdf_b, const float* color_B,
-                               const void* mlp, float inv_s, const float* bound_host, const float* rt_bound_host,
+                               const void* mlp, float inv_s, const float* inv_s_dev, const float* bound_host,
+                               const float* rt_bound_host,
                                float* color, float* depth, float* depth_var, float* normal, float* weight_sum,
                                float* sdf, float* z_mid, float* grad_err_ray, float* alpha_out, void* rgb_out,
                                float* grad_out, uint8_t* mask_out, void* mlp_in_out, int n, int s, void* workspace,
@@ -758,6 +760,7 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
   A.rays_o = rays_o; A.rays_d = rays_d; A.z_vals = z_vals; A.dists = dists;
   A.grid = (const _Float16*)grid; A.sdf_w = sdf_w; A.sdf_b = sdf_b; A.color_B = color_B;
   A.inv_s = inv_s;
+  A.inv_s_dev = inv_s_dev;
   for (int k = 0; k < 6; ++k) { A.bound[k] = bound_host[k]; A.rt_bound[k] = rt_bound_host[k]; }
   A.n = n; A.s = s;
   const int np = n * s;

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void neus_ray_bwd_kernel(
 struct BwdArgs {
   const float* rays_o; const float* rays_d; const float* z_vals; const float* dists;
   const _Float16* grid; const float* sdf_w; const float* color_B;
-  float inv_s; float bound[6];
+  float inv_s; const float* inv_s_dev; float bound[6];
   const float* sdf; const float* grad; const uint8_t* mask;
   const float* d_alpha; const float* d_sdf; const float* d_grad; const void* dX;
   const float* d_gerr_ray;
@@ -223,16 +223,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
     const float cosv = (dir[0] * g[0] + dir[1] * g[1]) + dir[2] * g[2];
     const float c = -fmaxf(-cosv, 0.0f);
     const float est_next = sdf + c * dist / 2.0f, est_prev = sdf - c * dist / 2.0f;
-    const float p = 1.0f / (1.0f + expf(-(est_prev * A.inv_s)));
-    const float q = 1.0f / (1.0f + expf(-(est_next * A.inv_s)));
+    const float inv_s_ = A.inv_s_dev ? *A.inv_s_dev : A.inv_s;
+    const float p = 1.0f / (1.0f + expf(-(est_prev * inv_s_)));
+    const float q = 1.0f / (1.0f + expf(-(est_next * inv_s_)));
     const float raw = (p - q + 1e-5f) / (p + 1e-5f);
     if (da != 0.0f && raw >= 0.0f && raw <= 1.0f) {    // torch.clip passes the gradient on [min, max]
       const float dp = da * q / ((p + 1e-5f) * (p + 1e-5f));
       const float dq = -da / (p + 1e-5f);
       const float dprev = dp * p * (1.0f - p), dnext = dq * q * (1.0f - q);
       d_invs_local = dprev * est_prev + dnext * est_next;
-      d_sdf += (dprev + dnext) * A.inv_s;
-      const float dc = (dnext - dprev) * A.inv_s * dist / 2.0f;
+      d_sdf += (dprev + dnext) * inv_s_;
+      const float dc = (dnext - dprev) * inv_s_ * dist / 2.0f;
       if (cosv < 0.0f) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) dg[d] += dc * dir[d];
@@ -425,7 +426,8 @@ extern "C" int gs_neus_backward_rays(const float* alpha, const void* rgb, const 
 
 extern "C" int gs_neus_backward_points(const float* rays_o, const float* rays_d, const float* z_vals,
                                        const float* dists, const void* grid, const float* sdf_w,
-                                       const float* color_B, float inv_s, const float* bound_host, const float* sdf,
+                                       const float* color_B, float inv_s, const float* inv_s_dev, const float* bound_host,
+                                       const float* sdf,
                                        const float* grad, const uint8_t* mask, const float* d_alpha,
                                        const float* d_sdf, const float* d_grad, const void* dX, int dx_dtype,
                                        float dx_scale, const float* d_gerr_ray,
@@ -446,7 +448,7 @@ extern "C" int gs_neus_backward_points(const float* rays_o, const float* rays_d,
   if (n == 0) return GS_OK;
   BwdArgs A;
   A.rays_o = rays_o; A.rays_d = rays_d; A.z_vals = z_vals; A.dists = dists;
-  A.grid = (const _Float16*)grid; A.sdf_w = sdf_w; A.color_B = color_B; A.inv_s = inv_s;
+  A.grid = (const _Float16*)grid; A.sdf_w = sdf_w; A.color_B = color_B; A.inv_s = inv_s; A.inv_s_dev = inv_s_dev;
   for (int k = 0; k < 6; ++k) A.bound[k] = bound_host[k];
   A.sdf = sdf; A.grad = grad; A.mask = mask; A.d_alpha = d_alpha; A.d_sdf = d_sdf; A.d_grad = d_grad; A.dX = dX;
   A.d_gerr_ray = d_gerr_ray;

@@ -271,7 +271,8 @@ class InstantNeuS(nn.Module):
 # fused forward / backward plumbing
 # ------------------------------------------------------------------------------------------
 
-def _neus_forward_raw(model, rays_o, rays_d, z_vals, dists, inv_s, save):
+def _neus_forward_raw(model, rays_o, rays_d, z_vals, dists, inv_s, save, inv_s_dev=None):
+    """`inv_s_dev` (optional fp32 device scalar) overrides the host value `inv_s` inside the kernels."""
     net = model.sdf_network
     dev = rays_o.device
     n, s = z_vals.shape
@@ -294,7 +295,8 @@ def _neus_forward_raw(model, rays_o, rays_d, z_vals, dists, inv_s, save):
     cB = model.color_network._B.detach().float().contiguous()
     with torch.cuda.device(dev):
         rc = L.gs_neus_forward(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z_vals), _lib.ptr(dists), _lib.ptr(grid),
-                               _lib.ptr(sdf_w), _lib.ptr(sdf_b), _lib.ptr(cB), _lib.ptr(mlp), float(inv_s), bh, rh,
+                               _lib.ptr(sdf_w), _lib.ptr(sdf_b), _lib.ptr(cB), _lib.ptr(mlp), float(inv_s),
+                               _lib.ptr(inv_s_dev), bh, rh,
                                _lib.ptr(color), _lib.ptr(depth), _lib.ptr(dvar), _lib.ptr(normal), _lib.ptr(wsum),
                                _lib.ptr(sdf), _lib.ptr(zmid), _lib.ptr(gerr),
                                _lib.ptr(saved.get("alpha")), _lib.ptr(saved.get("rgb")), _lib.ptr(saved.get("grad")),
@@ -359,88 +361,105 @@ class _NeusRenderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_color, d_depth, d_dvar, d_normal, d_wsum, d_sdf, d_gerr, _d_zmid):
-        model, S = ctx.model, ctx.saved
-        rays_o, rays_d, z_vals, dists, sdf, zmid = ctx.inputs
-        dev = rays_o.device
-        n, s = z_vals.shape
-        np_ = n * s
-        f32 = dict(dtype=torch.float32, device=dev)
-        z = lambda t, shape: (torch.zeros(shape, **f32) if t is None else t.float().contiguous())
-        d_color, d_normal = z(d_color, (n, 3)), z(d_normal, (n, 3))
-        d_depth, d_dvar, d_wsum, d_gerr = z(d_depth, (n, 1)), z(d_dvar, (n, 1)), z(d_wsum, (n, 1)), z(d_gerr, (n, 1))
-        d_sdf = z(d_sdf, (n, s))
-        L = _lib.lib()
-        st = _lib.stream_ptr(dev)
-        d_alpha = torch.empty(n, s, **f32)
-        d_rgb = torch.empty(np_, 3, **f32)
-        d_grad = torch.empty(np_, 3, **f32)
+        g = _neus_backward_raw(ctx.model, ctx.saved, ctx.inputs, ctx.inv_s, ctx.var,
+                               d_color, d_depth, d_dvar, d_normal, d_wsum, d_sdf, d_gerr)
+        grid_acc, gscale = g["grid_acc"], g["grid_scale"]
+        grid_grad = grid_acc.float().mul_(1.0 / gscale) if grid_acc.dtype == torch.float16 else grid_acc
+        return (None, None, None, None, None, grid_grad, g["sdf_w"], g["sdf_b"], g["cB"], g["mlp"], g["var"].reshape(()))
+
+
+def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d_normal, d_wsum, d_sdf, d_gerr,
+                       inv_s_dev=None, var_dev=None):
+    """The HIP backward of the fused renderer: upstream gradients of the ray outputs -> gradients of every trained
+    parameter.  Returns a dict: grid_acc (the raw table gradient: fp32, or tiny-cuda-nn's loss-scaled fp16 form with
+    `grid_scale`), sdf_w, sdf_b, cB, mlp, var (fp32).  Used by the autograd Function above and, without any autograd
+    graph, by the fused mapper step (neus/mapper.py)."""
+    rays_o, rays_d, z_vals, dists, sdf, zmid = inputs
+    dev = rays_o.device
+    n, s = z_vals.shape
+    np_ = n * s
+    f32 = dict(dtype=torch.float32, device=dev)
+    z = lambda t, shape: (torch.zeros(shape, **f32) if t is None else t.float().contiguous())
+    d_color, d_normal = z(d_color, (n, 3)), z(d_normal, (n, 3))
+    d_depth, d_dvar, d_wsum, d_gerr = z(d_depth, (n, 1)), z(d_dvar, (n, 1)), z(d_wsum, (n, 1)), z(d_gerr, (n, 1))
+    d_sdf = z(d_sdf, (n, s))
+    L = _lib.lib()
+    st = _lib.stream_ptr(dev)
+    d_alpha = torch.empty(n, s, **f32)
+    d_rgb = torch.empty(np_, 3, **f32)
+    d_grad = torch.empty(np_, 3, **f32)
+    with torch.cuda.device(dev):
+        rc = L.gs_neus_backward_rays(_lib.ptr(S["alpha"]), _lib.ptr(S["rgb"]), _lib.ptr(zmid), _lib.ptr(S["grad"]),
+                                     _lib.ptr(S["mask"]), _lib.ptr(d_color), _lib.ptr(d_depth), _lib.ptr(d_dvar),
+                                     _lib.ptr(d_normal), _lib.ptr(d_wsum), _lib.ptr(d_alpha), _lib.ptr(d_rgb),
+                                     _lib.ptr(d_grad), n, s, st)
+    _lib.check(rc, "InstantNeuS.backward(rays)")
+    # ---- colour MLP backward in fp16 with fp32 accumulation and tiny-cuda-nn's loss scale (128) on every
+    # gradient that lives in fp16 -- the reference's network trains exactly like this (tcnn FullyFusedMLP
+    # backward).  Default: the fused MFMA kernel; fallback: the same maths as hipBLASLt GEMMs.
+    LS = float(model.grid_grad_scale)
+    X = S["mlp_in"]                                     # [np,80] f16
+    W = S["mlp"]
+    if model.fused_mlp_backward:
+        # one MFMA kernel: forward recompute + dX + the three weight gradients (gs_mlp_backward)
+        wpack = _pack_mlp_fragments(W)
+        nb = L.gs_mlp_backward_blocks(np_)
+        partial = torch.empty(nb, 10240, **f32)
+        dX = torch.empty(np_, 80, dtype=torch.float16, device=dev)
         with torch.cuda.device(dev):
-            rc = L.gs_neus_backward_rays(_lib.ptr(S["alpha"]), _lib.ptr(S["rgb"]), _lib.ptr(zmid), _lib.ptr(S["grad"]),
-                                         _lib.ptr(S["mask"]), _lib.ptr(d_color), _lib.ptr(d_depth), _lib.ptr(d_dvar),
-                                         _lib.ptr(d_normal), _lib.ptr(d_wsum), _lib.ptr(d_alpha), _lib.ptr(d_rgb),
-                                         _lib.ptr(d_grad), n, s, st)
-        _lib.check(rc, "InstantNeuS.backward(rays)")
-        # ---- colour MLP backward in fp16 with fp32 accumulation and tiny-cuda-nn's loss scale (128) on every
-        # gradient that lives in fp16 -- the reference's network trains exactly like this (tcnn FullyFusedMLP
-        # backward).  Default: the fused MFMA kernel; fallback: the same maths as hipBLASLt GEMMs.
-        LS = float(model.grid_grad_scale)
-        X = S["mlp_in"]                                     # [np,80] f16
-        W = S["mlp"]
-        if model.fused_mlp_backward:
-            # one MFMA kernel: forward recompute + dX + the three weight gradients (gs_mlp_backward)
-            wpack = _pack_mlp_fragments(W)
-            nb = L.gs_mlp_backward_blocks(np_)
-            partial = torch.empty(nb, 10240, **f32)
-            dX = torch.empty(np_, 80, dtype=torch.float16, device=dev)
-            with torch.cuda.device(dev):
-                rc = L.gs_mlp_backward(_lib.ptr(X), _lib.ptr(wpack), _lib.ptr(d_rgb), _lib.ptr(S["rgb"]), LS,
-                                       _lib.ptr(dX), _lib.ptr(partial), np_, st)
-            _lib.check(rc, "InstantNeuS.backward(mlp)")
-            g_mlp = partial.sum(0) / LS
-        else:
-            W1, W2, W3 = W[:5120].view(64, 80), W[5120:9216].view(64, 64), W[9216:].view(16, 64)
-            H1 = torch.relu(X @ W1.t())
-            H2 = torch.relu(H1 @ W2.t())
-            y = S["rgb"].view(np_, 3).float()
-            dpre = torch.zeros(np_, 16, dtype=torch.float16, device=dev)
-            dpre[:, :3] = (d_rgb * y * (1.0 - y)) * LS      # sigmoid', scaled, padded to the 16 output rows
-            dW3 = _tn(dpre, H2) / LS                        # [16,64]; rows 3.. are zero
-            dH2 = (dpre @ W3) * (H2 > 0)
-            dW2 = _tn(dH2, H1) / LS
-            dH1 = (dH2 @ W2) * (H1 > 0)
-            dW1 = _tn(dH1, X) / LS
-            dX = (dH1 @ W1).contiguous()                    # [np,80] f16, loss-scaled; unscaled inside the per-point kernel
-            g_mlp = torch.cat([dW1.reshape(-1), dW2.reshape(-1), dW3.reshape(-1)])
-        # ---- per-point backward: alpha chain, SDF linear, hash grid (value + second-order paths)
-        # hash-table gradient: tcnn's mode (fp16, packed atomics, loss scale 128) or fp32 atomics
-        half_grads = model.grid_grad_dtype == torch.float16
-        gscale = float(model.grid_grad_scale) if half_grads else 1.0
-        grid_acc = torch.zeros(S["grid"].numel(), dtype=model.grid_grad_dtype, device=dev)
-        # per-point rows: fp16, gradient rows loss-scaled, all five as column blocks of ONE [np,160] matrix
-        # d_out 0:32 | lin_in 32:72 | dw0 72:112 | d_arg 112:152 | pts,1 152:160 -- its Gram matrix (one split-K
-        # GEMM) contains every dense-parameter gradient: d_out^T lin_in, the column sums (via the ones column)
-        # and pts^T d_arg
-        rows = torch.empty(np_, 160, dtype=torch.float16, device=dev)
-        d_out, lin_in, dw0, d_arg, pts = (rows[:, a:b] for a, b in ((0, 32), (32, 72), (72, 112), (112, 152), (152, 160)))
-        d_invs = torch.zeros(1, **f32)
-        bh, _ = model._bounds_host()
-        with torch.cuda.device(dev):
-            rc = L.gs_neus_backward_points(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z_vals), _lib.ptr(dists),
-                                           _lib.ptr(S["grid"]), _lib.ptr(S["sdf_w"]), _lib.ptr(S["cB"]),
-                                           float(ctx.inv_s), bh, _lib.ptr(sdf.contiguous()), _lib.ptr(S["grad"]),
-                                           _lib.ptr(S["mask"]), _lib.ptr(d_alpha), _lib.ptr(d_sdf), _lib.ptr(d_grad),
-                                           _lib.ptr(dX), 0, LS, _lib.ptr(d_gerr.reshape(-1).contiguous()),
-                                           _lib.ptr(grid_acc), 0 if half_grads else 1, gscale,
-                                           d_out.data_ptr(), lin_in.data_ptr(), dw0.data_ptr(),
-                                           d_arg.data_ptr(), pts.data_ptr(), 0, LS, 160, _lib.ptr(d_invs), n, s, st)
-        _lib.check(rc, "InstantNeuS.backward(points)")
-        grid_grad = grid_acc.float().mul_(1.0 / gscale) if half_grads else grid_acc
-        G = _tn(rows, rows) / LS                            # [160,160] Gram matrix, fp32
-        g_sdf_w = G[0:32, 32:67].clone()
-        g_sdf_w[0] += G[155, 72:107]                        # column sums of dw0 (row 155 = the ones column)
-        g_sdf_b = G[155, 0:32].clone()
-        g_cB = G[152:155, 112:145].clone()
-        sf = model.variance_network.scale_factor
-        raw = math.exp(ctx.var * sf)
-        g_var = (d_invs[0] * sf * ctx.inv_s) if 1e-6 <= raw <= 1e6 else torch.zeros((), **f32)
-        return (None, None, None, None, None, grid_grad, g_sdf_w, g_sdf_b, g_cB, g_mlp, g_var.reshape(()))
+            rc = L.gs_mlp_backward(_lib.ptr(X), _lib.ptr(wpack), _lib.ptr(d_rgb), _lib.ptr(S["rgb"]), LS,
+                                   _lib.ptr(dX), _lib.ptr(partial), np_, st)
+        _lib.check(rc, "InstantNeuS.backward(mlp)")
+        g_mlp = partial.sum(0) / LS
+    else:
+        W1, W2, W3 = W[:5120].view(64, 80), W[5120:9216].view(64, 64), W[9216:].view(16, 64)
+        H1 = torch.relu(X @ W1.t())
+        H2 = torch.relu(H1 @ W2.t())
+        y = S["rgb"].view(np_, 3).float()
+        dpre = torch.zeros(np_, 16, dtype=torch.float16, device=dev)
+        dpre[:, :3] = (d_rgb * y * (1.0 - y)) * LS      # sigmoid', scaled, padded to the 16 output rows
+        dW3 = _tn(dpre, H2) / LS                        # [16,64]; rows 3.. are zero
+        dH2 = (dpre @ W3) * (H2 > 0)
+        dW2 = _tn(dH2, H1) / LS
+        dH1 = (dH2 @ W2) * (H1 > 0)
+        dW1 = _tn(dH1, X) / LS
+        dX = (dH1 @ W1).contiguous()                    # [np,80] f16, loss-scaled; unscaled inside the per-point kernel
+        g_mlp = torch.cat([dW1.reshape(-1), dW2.reshape(-1), dW3.reshape(-1)])
+    # ---- per-point backward: alpha chain, SDF linear, hash grid (value + second-order paths)
+    # hash-table gradient: tcnn's mode (fp16, packed atomics, loss scale 128) or fp32 atomics
+    half_grads = model.grid_grad_dtype == torch.float16
+    gscale = float(model.grid_grad_scale) if half_grads else 1.0
+    grid_acc = torch.zeros(S["grid"].numel(), dtype=model.grid_grad_dtype, device=dev)
+    # per-point rows: fp16, gradient rows loss-scaled, all five as column blocks of ONE [np,160] matrix
+    # d_out 0:32 | lin_in 32:72 | dw0 72:112 | d_arg 112:152 | pts,1 152:160 -- its Gram matrix (one split-K
+    # GEMM) contains every dense-parameter gradient: d_out^T lin_in, the column sums (via the ones column)
+    # and pts^T d_arg
+    rows = torch.empty(np_, 160, dtype=torch.float16, device=dev)
+    d_out, lin_in, dw0, d_arg, pts = (rows[:, a:b] for a, b in ((0, 32), (32, 72), (72, 112), (112, 152), (152, 160)))
+    d_invs = torch.zeros(1, **f32)
+    bh, _ = model._bounds_host()
+    with torch.cuda.device(dev):
+        rc = L.gs_neus_backward_points(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z_vals), _lib.ptr(dists),
+                                       _lib.ptr(S["grid"]), _lib.ptr(S["sdf_w"]), _lib.ptr(S["cB"]),
+                                       float(inv_s), _lib.ptr(inv_s_dev), bh, _lib.ptr(sdf.contiguous()),
+                                       _lib.ptr(S["grad"]),
+                                       _lib.ptr(S["mask"]), _lib.ptr(d_alpha), _lib.ptr(d_sdf), _lib.ptr(d_grad),
+                                       _lib.ptr(dX), 0, LS, _lib.ptr(d_gerr.reshape(-1).contiguous()),
+                                       _lib.ptr(grid_acc), 0 if half_grads else 1, gscale,
+                                       d_out.data_ptr(), lin_in.data_ptr(), dw0.data_ptr(),
+                                       d_arg.data_ptr(), pts.data_ptr(), 0, LS, 160, _lib.ptr(d_invs), n, s, st)
+    _lib.check(rc, "InstantNeuS.backward(points)")
+    G = _tn(rows, rows) / LS                            # [160,160] Gram matrix, fp32
+    g_sdf_w = G[0:32, 32:67].clone()
+    g_sdf_w[0] += G[155, 72:107]                        # column sums of dw0 (row 155 = the ones column)
+    g_sdf_b = G[155, 0:32].clone()
+    g_cB = G[152:155, 112:145].clone()
+    sf = model.variance_network.scale_factor
+    if inv_s_dev is not None:       # device-scalar form: no host value of the variance exists in this step
+        raw_d = torch.exp(var_dev.detach().float() * sf)
+        g_var = d_invs[0] * sf * inv_s_dev.reshape(()) * ((raw_d >= 1e-6) & (raw_d <= 1e6)).float()
+    else:
+        raw = math.exp(var * sf)
+        g_var = (d_invs[0] * sf * inv_s) if 1e-6 <= raw <= 1e6 else torch.zeros((), **f32)
+    return {"grid_acc": grid_acc, "grid_scale": gscale, "sdf_w": g_sdf_w, "sdf_b": g_sdf_b, "cB": g_cB, "mlp": g_mlp,
+            "var": g_var}

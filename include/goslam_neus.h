@@ -77,7 +77,8 @@ int gs_mlp_forward(const void* x, const void* mlp, void* out, int n, int n_in, i
 /* InstantNeuS.forward (src/InstantNeuS.py:295-370) for one chunk of rays, forward only:
  * hash-grid encode + SDF linear + analytic SDF gradient + NeuS alpha + colour MLP + compositing.
  *   grid f16 [total*2], sdf_w f32 [32,35], sdf_b f32 [32], color_B f32 [3,33], mlp f16 [10240];
- *   inv_s = clip(exp(10*variance), 1e-6, 1e6) (host scalar);
+ *   inv_s = clip(exp(10*variance), 1e-6, 1e6) as a host scalar, or -- when inv_s_dev != NULL -- read from that device
+ *   scalar instead (a training loop then never reads the variance parameter back to the host);
  *   bound_host / rt_bound_host: HOST f32 [3,2] (static bound for normalisation, realtime bound
  *   for the in-bound mask; 6 floats each, passed by value to the kernels).
  * Outputs f32: color [n,3], depth [n], depth_var [n], normal [n,3], weight_sum [n], sdf [n,s],
@@ -88,7 +89,7 @@ int gs_mlp_forward(const void* x, const void* mlp, void* out, int n, int n_in, i
 size_t gs_neus_forward_workspace_bytes(int n, int s);
 int gs_neus_forward(const float* rays_o, const float* rays_d, const float* z_vals,
                     const float* dists, const void* grid, const float* sdf_w, const float* sdf_b,
-                    const float* color_B, const void* mlp, float inv_s,
+                    const float* color_B, const void* mlp, float inv_s, const float* inv_s_dev,
                     const float* bound_host, const float* rt_bound_host,
                     float* color, float* depth, float* depth_var, float* normal,
                     float* weight_sum, float* sdf, float* z_mid, float* grad_err_ray,
@@ -142,7 +143,7 @@ int gs_mlp_backward(const void* x, const void* wpack, const float* d_rgb, const 
  * d_arg f32 [n*s,33] (d color_B = pts^T @ d_arg), pts f32 [n*s,3], d_inv_s f32 [1] (atomic; zero it). */
 int gs_neus_backward_points(const float* rays_o, const float* rays_d, const float* z_vals,
                             const float* dists, const void* grid, const float* sdf_w,
-                            const float* color_B, float inv_s, const float* bound_host,
+                            const float* color_B, float inv_s, const float* inv_s_dev, const float* bound_host,
                             const float* sdf, const float* grad, const uint8_t* mask,
                             const float* d_alpha, const float* d_sdf, const float* d_grad,
                             const void* dX, int dx_dtype, float dx_scale, const float* d_gerr_ray,
@@ -163,6 +164,22 @@ int gs_mapping_loss(const float* color, const float* depth, const float* depth_v
                     float truncation, float sparse_factor, float w_color, float w_sdf, int uncertainty,
                     float* d_color, float* d_depth, float* d_sdf, float* loss_rays, int n, int s,
                     gs_stream_t stream);
+
+/* The mapper's optimiser step (src/mapping.py:55-58,135-137: clip_grad_norm_(35) over all trained parameters, then
+ * AdamW with lr 1e-2 for the hash table and 1e-3 for the networks) on ONE flat fp32 parameter buffer laid out
+ * [hash table (n16 entries) | dense parameters (n - n16)], in two launches.
+ *   gs_map_grad_sqnorm: sqnorm_out[0] += sum g^2 (zero it first) over the table gradient g16 (fp16 holding
+ *     gradient / inv_scale16, tiny-cuda-nn's loss-scaled form; n16 elements) and the dense gradients g32 (fp32).
+ *   gs_map_adamw: coef = min(1, max_norm / (sqrt(sqnorm[0]) + 1e-6)) (sqnorm == NULL: no clipping), then for every
+ *     element g' = g * coef, p *= 1 - lr wd, m = b1 m + (1 - b1) g', v = b2 v + (1 - b2) g'^2,
+ *     p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps)   (torch.optim.AdamW), lr = lr16 on the table
+ *     and lr32 on the dense range; p16 (optional, fp16 [n]) receives the fp16 working copy of the new parameters.
+ *   All buffers 16-byte aligned, n16 % 8 == 0, step >= 1.                                                      */
+int gs_map_grad_sqnorm(const void* g16, size_t n16, float inv_scale16, const float* g32, size_t n32,
+                       float* sqnorm_out, gs_stream_t stream);
+int gs_map_adamw(float* p, float* m, float* v, void* p16, const void* g16, size_t n16, float inv_scale16,
+                 const float* g32, size_t n, float lr16, float lr32, float beta1, float beta2, float eps,
+                 float weight_decay, int step, const float* sqnorm, float max_norm, gs_stream_t stream);
 
 #ifdef __cplusplus
 }

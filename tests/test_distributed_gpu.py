@@ -1,0 +1,75 @@
+"""RCCL path of the sharded mapper step -- needs >= 2 GPUs, skipped on the 1-GPU test box.  Two ranks
+(one process per GPU, backend "nccl" = RCCL) each render half of a ray batch; after the fp16 table all-reduce + fp32
+dense all-reduce + identical flat AdamW the parameters of both ranks must be equal, and equal to a single-GPU step on
+the whole batch (same tolerance as the gloo test of the autograd path, tests/test_distributed_cpu.py)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2,
+                                 reason="needs >= 2 GPUs (RCCL)")]
+
+
+def _make(dev, n_rays=1024, seed=61):
+    import go_slam_amd.neus as neus
+    from go_slam_amd.neus.mapper import MapTrainer
+    from oracle import neus_oracle as O
+    P = O.make_params(seed, grid_init=0.05, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    g = torch.Generator().manual_seed(seed + 1)
+    o = torch.rand(n_rays, 3, generator=g) * 4 - 2
+    d = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=1)
+    gt = torch.rand(n_rays, generator=g) * 3.5 + 0.5
+    gt[torch.rand(n_rays, generator=g) < 0.1] = 0
+    col = torch.rand(n_rays, 3, generator=g)
+    pr = torch.rand(24, generator=g)
+    model = neus.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    with torch.no_grad():
+        model.sdf_network.encoding.encoding.params.copy_(P["grid"])
+        model.sdf_network.sdf_layer.weight.copy_(P["sdf_w"])
+        model.sdf_network.sdf_layer.bias.copy_(P["sdf_b"])
+        model.color_network._B.copy_(P["color_B"])
+        model.color_network.network.params.copy_(P["mlp"])
+    return model, neus.Renderer(N_samples=24, N_surface=48), [t.to(dev) for t in (o, d, col, gt, pr)], MapTrainer
+
+
+def _rank(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        model, R, args, MapTrainer = _make(dev)
+        tr = MapTrainer(model, R, rank=rank, world=world)
+        for _ in range(2):
+            loss = tr.step(*args)
+        torch.cuda.synchronize()
+        out_q.put((rank, float(loss), tr.flat.P.detach().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_rccl_step_equals_single_gpu_step(built_lib):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank, args=(r, 2, 29531, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, loss, flat = q.get(timeout=500)
+        res[r] = (loss, torch.from_numpy(flat))
+    for p in procs:
+        p.join(timeout=60)
+    dev = torch.device("cuda", 0)
+    model, R, args, MapTrainer = _make(dev)
+    tr = MapTrainer(model, R)
+    for _ in range(2):
+        loss = tr.step(*args)
+    assert torch.equal(res[0][1], res[1][1]), "ranks diverged"
+    assert abs(res[0][0] - float(loss)) < 2e-4 * max(1.0, abs(float(loss)))
+    torch.testing.assert_close(res[0][1], tr.flat.P.detach().cpu(), rtol=2e-3, atol=2e-5)

@@ -322,3 +322,77 @@ def test_fused_mapping_loss_matches_torch_formulation(N, dev):
     for i, name in ((1, "d_color"), (2, "d_depth"), (3, "d_sdf"), (4, "d_gerr")):
         torch.testing.assert_close(a[i], b[i], rtol=1e-4, atol=1e-8, msg=lambda m, nm=name: f"{nm}: {m}")
     assert a[5] is None or not bool(a[5].any())          # the uncertainty weight is detached in both
+
+
+def _trainer_pair(N, O, dev, n_rays, seed):
+    P = O.make_params(seed, grid_init=0.05, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    o, d, gt = _rays(n_rays, seed=seed + 1)
+    g = torch.Generator().manual_seed(seed + 2)
+    col = torch.rand(n_rays, 3, generator=g)
+    pr = torch.rand(24, generator=g)
+    out = []
+    from go_slam_amd.neus.mapper import MapTrainer
+    for fused in (False, True):
+        model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+        _load(model, P)
+        out.append((model, MapTrainer(model, N.Renderer(N_samples=24, N_surface=48), fused=fused)))
+    return out, [t.to(dev) for t in (o, d, col, gt, pr)]
+
+
+def test_fused_mapper_step_matches_autograd_step(N, O, dev):
+    """MapTrainer.step_fused (no autograd graph: loss kernel's analytic output gradients -> HIP backward -> flat-buffer
+    clip + AdamW in two launches, fp16 table gradient consumed as is) vs the autograd path + clip_grad_norm_ +
+    torch.optim.AdamW on two identical models: same loss and, after 4 steps, the same parameters."""
+    pair, args = _trainer_pair(N, O, dev, 512, 51)
+    (m_ref, t_ref), (m_fus, t_fus) = pair
+    assert t_fus.fused and not t_ref.fused
+    for it in range(4):
+        l_ref = t_ref.step(*args)
+        l_fus = t_fus.step(*args)
+        torch.testing.assert_close(l_fus.float().cpu(), l_ref.float().cpu(), rtol=2e-4, atol=1e-5)
+    names = ["sdf_network.encoding.encoding.params", "sdf_network.sdf_layer.weight", "sdf_network.sdf_layer.bias",
+             "color_network._B", "color_network.network.params", "variance_network.variance"]
+    pr, pf = dict(m_ref.named_parameters()), dict(m_fus.named_parameters())
+    for k in names:
+        a, b = pf[k].detach().float().cpu(), pr[k].detach().float().cpu()
+        torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-5, msg=lambda m: f"{k}: {m}")
+    # the fused step keeps the modules usable: state_dict, inference forward with the refreshed fp16 copies
+    sd = m_fus.state_dict()
+    assert sd["sdf_network.encoding.encoding.params"].data_ptr() == t_fus.flat.P.data_ptr()
+    with torch.no_grad():
+        z, dd = N.Renderer(N_samples=24, N_surface=48).sample(args[0], args[1], m_fus.bound, args[3], args[4])
+        a = m_fus(args[0], args[1], z, dd)
+        b = m_ref(args[0], args[1], z, dd)
+    torch.testing.assert_close(a["sdf"], b["sdf"], rtol=5e-3, atol=5e-4)
+
+
+def test_flat_adamw_kernels_match_torch_adamw(N, dev, built_lib):
+    """gs_map_grad_sqnorm + gs_map_adamw on synthetic gradients vs clip_grad_norm_ + torch.optim.AdamW (two groups)."""
+    from go_slam_amd import _lib
+    g = torch.Generator().manual_seed(77)
+    n16, n32 = 4096 * 8, 1003
+    p = torch.randn(n16 + n32, generator=g).to(dev)
+    g16 = (torch.randn(n16, generator=g) * 40).half().to(dev)           # loss-scaled by 128
+    g32 = torch.randn(n32, generator=g).to(dev) * 30
+    pa, pb = torch.nn.Parameter(p[:n16].clone()), torch.nn.Parameter(p[n16:].clone())
+    opt = torch.optim.AdamW([{"params": [pb], "lr": 1e-3}, {"params": [pa], "lr": 1e-2}], betas=(0.9, 0.999), eps=1e-8,
+                            weight_decay=0.01)
+    P, M, V = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
+    P16 = torch.zeros(n16 + n32, dtype=torch.float16, device=dev)
+    sq = torch.zeros(1, device=dev)
+    L = _lib.lib()
+    for step in range(1, 4):
+        pa.grad, pb.grad = g16.float() / 128.0, g32.clone()
+        torch.nn.utils.clip_grad_norm_([pa, pb], 35.0)
+        opt.step()
+        sq.zero_()
+        _lib.check(L.gs_map_grad_sqnorm(_lib.ptr(g16), n16, 1 / 128.0, _lib.ptr(g32), n32, _lib.ptr(sq),
+                                        _lib.stream_ptr(dev)), "sqnorm")
+        _lib.check(L.gs_map_adamw(_lib.ptr(P), _lib.ptr(M), _lib.ptr(V), _lib.ptr(P16), _lib.ptr(g16), n16, 1 / 128.0,
+                                  _lib.ptr(g32), n16 + n32, 1e-2, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, _lib.ptr(sq), 35.0,
+                                  _lib.stream_ptr(dev)), "adamw")
+        ref = torch.cat([pa.detach(), pb.detach()])
+        torch.testing.assert_close(P, ref, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(P16.float(), ref.half().float(), rtol=0, atol=1e-3)
+    want = float(torch.cat([g16.float() / 128.0, g32]).pow(2).sum())
+    assert abs(float(sq) - want) / want < 1e-4 and want ** 0.5 > 35.0, "the clip must be active in this test"
