@@ -368,6 +368,7 @@ class ConvGRU(nn.Module):
             self._hw_hoist = (w_all[:, 128:256].half().contiguous(memory_format=cl),
                               w_all[:256][:, keep].half().contiguous(memory_format=cl),
                               w_all[256:][:, keep].half().contiguous(memory_format=cl))
+            self._ww_pack = pack_1x1_weight(self.w.weight)
             self._hw, self._hw_key = (wzr, wq, bzr, bq, ww, bw, glo), key
         return self._hw
 
@@ -401,7 +402,11 @@ class ConvGRU(nn.Module):
         st = _lib.stream_ptr(net.device)
         dev = net.device
         with torch.autocast("cuda", enabled=False):
-            w_pre = F.conv2d(net, ww, None)
+            # gs_conv1x1 (own MFMA kernel; deterministic, one launch) instead of an MIOpen 1x1 convolution, whose
+            # solver choice -- and with it the fp16 rounding of the global-context gate -- can change between calls
+            w_pre = torch.empty_like(net)
+            _lib.check(L.gs_conv1x1(_lib.ptr(net), 128, 128, _lib.ptr(self._ww_pack), None, 0, _lib.ptr(w_pre), 128, 128,
+                                    b * hw, st), "conv1x1(gru.w)")
             gzr = torch.empty(b, 256, dtype=torch.float32, device=dev)
             gq = torch.empty(b, 128, dtype=torch.float32, device=dev)
             ws = torch.empty(L.gs_gru_glo_workspace_bytes(b), dtype=torch.uint8, device=dev)

@@ -15,12 +15,27 @@ def make_optimizer(model, net_lr=1e-3, grid_lr=1e-2, fused=None):
     if fused is None:
         fused = all(p.is_cuda for g in groups for p in g["params"])
     kw = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    opt = None
     if fused:
         try:
-            return torch.optim.AdamW(groups, fused=True, **kw)
+            opt = torch.optim.AdamW(groups, fused=True, **kw)
         except (RuntimeError, TypeError, ValueError):
-            pass
-    return torch.optim.AdamW(groups, **kw)
+            opt = None
+    if opt is None:
+        opt = torch.optim.AdamW(groups, **kw)
+    opt.register_step_post_hook(_bump_versions)
+    return opt
+
+
+def _bump_versions(optimizer, args=None, kwargs=None):
+    """torch's single-kernel (`fused=True`) AdamW updates the parameters WITHOUT advancing their version counters
+    (measured on torch 2.10 / ROCm: version 0 -> 0, foreach: 0 -> 2).  Everything this package caches per parameter
+    version -- the fp16 working copies of the hash table and the colour MLP (tcnn_compat._HalfCache), the host copy of
+    the NeuS variance -- would silently keep serving the pre-step values, so optimisers made here advance the
+    counters themselves after every step."""
+    for g in optimizer.param_groups:
+        for p in g["params"]:
+            torch.autograd.graph.increment_version(p)
 
 
 class FlatAdamW:
@@ -117,6 +132,13 @@ class MapTrainer:
             self.reducer = FlatGradReducer(self.train_params) if world > 1 else None
 
     def step_fused(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand=None):
+        loss, grid16, inv_scale = self.fused_gradients(rays_o, rays_d, rays_color, rays_depth, perturb_rand)
+        self.flat.step(grid16, inv_scale)
+        return loss
+
+    def fused_gradients(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand=None):
+        """forward + loss + HIP backward (+ all-reduce) without an autograd graph.  Returns (global loss, table gradient
+        in loss-scaled fp16, its inverse scale); the dense gradients are left in self.flat.g32."""
         from .instant_neus import _neus_backward_raw, _neus_forward_raw
         model, L = self.model, _lib.lib()
         dev = rays_o.device
@@ -161,11 +183,10 @@ class MapTrainer:
         if self.world > 1:          # one fp16 collective for the table (25 MB), one small fp32 one for the rest
             all_reduce_sum_(grid16, self.group)
             all_reduce_sum_(flat.g32, self.group)
-        flat.step(grid16, 1.0 / float(g["grid_scale"]))
         loss = loss_rays.sum() + w["w_eikonal"] * gerr.sum() / (counts[1] * float(s))
         if self.world > 1:
             loss = all_reduce_sum_(loss.clone(), self.group)
-        return loss
+        return loss, grid16, 1.0 / float(g["grid_scale"])
 
     def step(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand=None):
         """One joint iteration on the GLOBAL batch (every rank passes the same tensors; each renders

@@ -37,7 +37,11 @@ def _have_lib():
 
 class _HalfCache:
     """fp16 working copy of an fp32 master parameter, re-cast only when the parameter changes (tcnn keeps a
-    persistent fp16 copy; re-casting the 12.6 M-entry grid on every call costs more than the encode itself)."""
+    persistent fp16 copy; re-casting the 12.6 M-entry grid on every call costs more than the encode itself).
+    "Changes" = its storage address or autograd version counter: every in-place torch op, load_state_dict and the
+    foreach optimisers advance the counter; `torch.optim.*(fused=True)` does NOT -- an optimiser of that kind must be
+    followed by `torch.autograd.graph.increment_version(p)` (go_slam_amd.neus.mapper.make_optimizer registers a step
+    hook that does it), or by `invalidate()`."""
 
     _key = None
     _val = None
@@ -48,6 +52,10 @@ class _HalfCache:
             self._val = p.detach().to(torch.float16).contiguous()
             self._key = key
         return self._val
+
+    def invalidate(self):
+        self._key = None
+        self._val = None
 
     def __deepcopy__(self, memo):        # a copied module re-derives its cache
         return _HalfCache()

@@ -346,16 +346,44 @@ def test_fused_mapper_step_matches_autograd_step(N, O, dev):
     pair, args = _trainer_pair(N, O, dev, 512, 51)
     (m_ref, t_ref), (m_fus, t_fus) = pair
     assert t_fus.fused and not t_ref.fused
+    # gradients first: autograd on the reference-style loss vs the no-autograd pipeline, same parameters
+    R = N.Renderer(N_samples=24, N_surface=48)
+    z, dd = R.sample(args[0], args[1], m_ref.bound, args[3], args[4])
+    from go_slam_amd.neus.distributed import mapping_loss_sharded
+    loss_a, _ = mapping_loss_sharded(R.eval_points(args[0], args[1], z, dd, m_ref, None), args[2], args[3],
+                                     m_ref.compute_sdf_error)
+    loss_a.backward()
+    loss_f, grid16, inv_scale = t_fus.fused_gradients(*args)
+    torch.testing.assert_close(loss_f.float().cpu(), loss_a.detach().float().cpu(), rtol=2e-4, atol=1e-5)
+    ref_g = {"grid": m_ref.sdf_network.encoding.encoding.params.grad, "mlp": m_ref.color_network.network.params.grad,
+             "sdf_w": m_ref.sdf_network.sdf_layer.weight.grad, "sdf_b": m_ref.sdf_network.sdf_layer.bias.grad,
+             "cB": m_ref.color_network._B.grad, "var": m_ref.variance_network.variance.grad}
+    rep = {"grid": _rel(grid16.float().cpu() * inv_scale, ref_g["grid"].cpu())}
+    for k in ("mlp", "sdf_w", "sdf_b", "cB", "var"):
+        rep[k] = _rel(t_fus.flat.dense_grad(k).cpu(), ref_g[k].reshape(-1).cpu())
+    assert all(v < 1e-4 for v in rep.values()), rep
+    for p_ in m_ref.parameters():
+        p_.grad = None
     for it in range(4):
         l_ref = t_ref.step(*args)
         l_fus = t_fus.step(*args)
-        torch.testing.assert_close(l_fus.float().cpu(), l_ref.float().cpu(), rtol=2e-4, atol=1e-5)
+        torch.testing.assert_close(l_fus.float().cpu(), l_ref.float().cpu(), rtol=2e-4, atol=1e-5,
+                                   msg=lambda m: f"iteration {it}: {m}")
     names = ["sdf_network.encoding.encoding.params", "sdf_network.sdf_layer.weight", "sdf_network.sdf_layer.bias",
              "color_network._B", "color_network.network.params", "variance_network.variance"]
     pr, pf = dict(m_ref.named_parameters()), dict(m_fus.named_parameters())
     for k in names:
         a, b = pf[k].detach().float().cpu(), pr[k].detach().float().cpu()
-        torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-5, msg=lambda m: f"{k}: {m}")
+        if k.endswith("encoding.params"):
+            # The table gradient is accumulated with fp16 atomics, whose order is not reproducible: two runs of the SAME
+            # path differ in ~1 % of the non-zero entries by one fp16 ulp (tools/debug_fused_mapper.py).  Adam normalises
+            # every gradient to a step of +-lr, so an entry whose contributions cancel to rounding noise can take
+            # opposite steps in two runs.  Measured: 0.04 % of the entries after 4 steps, each within 4 steps x lr.
+            d = (a - b).abs()
+            off = d > (2e-5 + 2e-3 * b.abs())
+            assert float(off.float().mean()) < 2e-3 and float(d.max()) <= 4 * 1e-2 * 1.01, (float(off.float().mean()), float(d.max()))
+        else:
+            torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-5, msg=lambda m: f"{k}: {m}")
     # the fused step keeps the modules usable: state_dict, inference forward with the refreshed fp16 copies
     sd = m_fus.state_dict()
     assert sd["sdf_network.encoding.encoding.params"].data_ptr() == t_fus.flat.P.data_ptr()

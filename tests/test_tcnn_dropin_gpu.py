@@ -332,3 +332,27 @@ def test_dropin_module_contract(T, dev):
         y2 = enc(x)
     assert not torch.equal(y1, y2)
     torch.testing.assert_close(twin(x), y1)       # the copy kept its own parameters
+
+
+def test_fused_adamw_needs_the_version_hook(T, dev):
+    """torch.optim.AdamW(fused=True) leaves `_version` untouched (so a version-keyed fp16 cache would go stale);
+    optimisers from go_slam_amd.neus.mapper.make_optimizer advance it in a step hook."""
+    import go_slam_amd.neus as neus
+    from go_slam_amd.neus.mapper import make_optimizer
+    model = neus.InstantNeuS({}, [[-1.0, 1.0]] * 3).to(dev)
+    enc = model.sdf_network.encoding.encoding
+    x = torch.rand(64, 3, device=dev)
+    with torch.no_grad():
+        enc.params.uniform_(-0.5, 0.5)
+        y1 = enc(x)
+    opt = make_optimizer(model)
+    v0 = enc.params._version
+    enc(x).float().sum().backward()
+    for p in model.parameters():
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    opt.step()
+    assert enc.params._version > v0
+    with torch.no_grad():
+        y2 = enc(x)
+    assert not torch.equal(y1, y2), "the encoding still serves the pre-step fp16 table"

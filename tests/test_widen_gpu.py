@@ -404,3 +404,63 @@ def test_fused_bias_relu_convolution_equals_conv_plus_bias_act(built_lib):
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
     assert bool((res[True][0][:, :128] == 3.0).all()) and bool((res[True][0][:, 256:] == 3.0).all())
     assert float(res[True][1].min()) == 0.0 and float(res[True][1].max()) > 0.0
+
+
+def _golden(name):
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+    return {k: (torch.from_numpy(g[k]) if g[k].dtype.kind in "fiub" else g[k]) for k in g.files}
+
+
+def test_build_rays_on_device_matches_reference_golden(built_lib):
+    """SURVEY a11 (src/nerf_func.py:115-181) on the GPU.  Without sub-sampling the rays of all masked pixels must equal
+    the reference's (fixture build_rays.npz holds a 50-ray draw of the CPU generator, which the device generator cannot
+    reproduce, so the full set is compared against the CPU run of the same function, itself pinned to the fixture in
+    test_oracle_pinned.py); with sub-sampling every drawn ray must be one of those rays, carrying its pixel's depth and
+    colour."""
+    from go_slam_amd.neus.rays import build_rays
+    g = _golden("build_rays.npz")
+    dev = "cuda:0"
+    args = (2, 22, 3, 29)
+    cam = (24, 32, 30.0, 31.0, 15.5, 11.5)
+    full_c = build_rays(*args, 0, *cam, g["c2w"], g["depth"], g["color"], "cpu", mask=g["mask"])
+    full_g = build_rays(*args, 0, *cam, g["c2w"].to(dev), g["depth"].to(dev), g["color"].to(dev), dev,
+                        mask=g["mask"].to(dev))
+    for a, b in zip(full_g, full_c):
+        torch.testing.assert_close(a.cpu(), b, rtol=1e-6, atol=1e-6)
+    torch.manual_seed(5)
+    o, d, dep, col = build_rays(*args, 50, *cam, g["c2w"].to(dev), g["depth"].to(dev), g["color"].to(dev), dev,
+                                mask=g["mask"].to(dev))
+    assert tuple(d.shape) == (50, 3) and torch.equal(o.cpu(), full_c[0][:50])
+    dist = torch.cdist(d.cpu().double(), full_c[1].double())
+    hit = dist.argmin(1)
+    assert float(dist.min(1).values.max()) < 1e-5, "a sampled ray is not one of the masked pixels' rays"
+    torch.testing.assert_close(dep.cpu(), full_c[2][hit])
+    torch.testing.assert_close(col.cpu(), full_c[3][hit])
+
+
+def test_encoders_on_device_match_reference_golden(built_lib):
+    """fnet / cnet (src/modules/extractor.py:61-126; MIOpen NHWC convolutions here) on the GPU against the outputs of
+    the reference's own BasicEncoder (fixture encoders.npz): fp32 within 1e-3, and under the tracker's fp16 autocast
+    (src/motion_filter.py:26-39) within fp16 accuracy of the 10-layer stack."""
+    import importlib.util
+    from go_slam_amd.droid_net import DroidNet
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(os.path.dirname(__file__), "golden",
+                                                                             "gen_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    g = _golden("encoders.npz")
+    dev = "cuda:0"
+    net = DroidNet().eval()
+    net.load_state_dict(gen.named_weights(net.state_dict(), seed=173))
+    net = net.to(dev)
+    x = g["x"].to(dev)
+    with torch.no_grad():
+        f, c = net.fnet(x), net.cnet(x)
+        with torch.autocast("cuda", dtype=torch.float16):
+            fh, ch = net.fnet(x), net.cnet(x)
+    torch.testing.assert_close(f.cpu(), g["fnet"], rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(c.cpu(), g["cnet"], rtol=1e-3, atol=1e-3)
+    sf, sc = float(g["fnet"].abs().max()), float(g["cnet"].abs().max())
+    assert float((fh.float().cpu() - g["fnet"]).abs().max()) < 3e-2 * sf
+    assert float((ch.float().cpu() - g["cnet"]).abs().max()) < 3e-2 * sc
