@@ -4,8 +4,8 @@
 Metric (BASELINE.json): BA keyframes/s on synthetic 640x480 RGB-D.  One *step* = the
 frontend's per-keyframe work unit = 6 x FactorGraph.update(iters=2, use_inactive=True)
 (reference src/frontend.py:66-67,90-91) on a window graph of P=25 keyframes / E=75 edges at
-the 1/8-resolution map size 60x80: reproject + 4-level corr lookup + UpdateModule (MIOpen) +
-2 Gauss-Newton dense-BA iterations + convex upsampling.  Inputs are resident in HBM before the
+the 1/8-resolution map size 60x80: reproject + 4-level corr lookup + UpdateModule (own implicit-GEMM
+3x3 convolutions with fused ConvGRU epilogues) + 2 Gauss-Newton dense-BA iterations + convex upsampling.  Inputs are resident in HBM before the
 timed region.  Tracking does not shard ("replicas only"), so --gpus N runs N
 independent replicas, one process per GPU, and `value` is their aggregate.
 
@@ -366,6 +366,13 @@ def main():
 
     for _ in range(args.warmup):
         keyframe_step(graph)
+    # What a long-running tracker process does once after start-up: move the module / tensor object graph built so
+    # far out of the cyclic collector's reach.  Without it CPython's first full collection lands around the 10th
+    # keyframe and stalls the launch thread for ~23 ms (tools/debug_bench_gap.py: 15.2 ms per keyframe before and
+    # after, one 38.5 ms keyframe in between); garbage created from here on is still collected.
+    import gc
+    gc.collect()
+    gc.freeze()
     barrier()
     tic = time.perf_counter()
     for _ in range(args.steps):

@@ -54,6 +54,8 @@ SIGNATURES = {
     "gs_gru_glo": (c_int, [_P] * 11 + [c_int, c_int, _P, c_size_t, _P]),
     "gs_gru_gate_zr": (c_int, [_P] * 6 + [c_int] * 3 + [_P]),
     "gs_gru_gate_q": (c_int, [_P] * 7 + [c_int] * 2 + [_P]),
+    "gs_edge_prep": (c_int, [_P] * 4 + [c_int, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P]),
+    "gs_edge_greedy": (c_int, [_P] * 5 + [c_int] * 5 + [c_float, c_int, c_int, _P]),
     "gs_ba_workspace_bytes": (c_size_t, [c_int] * 5),
     "gs_ba": (c_int, [_P] * 9 + [c_int] * 3 + [c_float, c_float] + [c_int] * 6 + [_P, _P, _P, _P, c_size_t, _P]),
     # include/goslam_neus.h

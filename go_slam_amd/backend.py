@@ -94,12 +94,20 @@ class Backend:
         assert t_start_loop >= t_start, f"short: {t_start_loop}, long: {t_start}."
         ii, jj = torch.meshgrid(torch.arange(t_start_loop, t_end), torch.arange(t_start, t_end), indexing="ij")
         d = self.video.distance(ii.reshape(-1), jj.reshape(-1), beta=self.beta)
-        d = d.detach().float().cpu().numpy().reshape(t_end - t_start_loop, t_end - t_start)   # the one D2H copy
-        es = propose_backend_edges(d, t_start, t_start_loop, t_end, radius, nms, thresh, max_factors,
-                                   stereo=bool(getattr(self.video, "stereo", False)), loop=loop)
-        if len(es) < 3:
-            return 0
-        e = torch.tensor(es, dtype=torch.long, device=self.device)
+        stereo = bool(getattr(self.video, "stereo", False))
+        if d.is_cuda and (t_end - t_start_loop) * (t_end - t_start) <= 512 * 512:
+            # proposal on the GPU (csrc/edge_nms.hip): the matrix stays in HBM, one int is read back
+            e = FactorGraph.propose_edges_on_device(d, None, t_start_loop, t_start, t_end, radius, nms, thresh, thresh,
+                                                    max_factors, stereo and not loop, t_start_loop, loop)
+            if e.shape[0] < 3:
+                return 0
+        else:
+            d = d.detach().float().cpu().numpy().reshape(t_end - t_start_loop, t_end - t_start)   # one D2H copy
+            es = propose_backend_edges(d, t_start, t_start_loop, t_end, radius, nms, thresh, max_factors, stereo=stereo,
+                                       loop=loop)
+            if len(es) < 3:
+                return 0
+            e = torch.tensor(es, dtype=torch.long, device=self.device)
         graph.add_factors(e[:, 0], e[:, 1], remove=True)
         edge_num = len(graph.ii)
         # the start pose is fixed to avoid drift: t_start_loop, not t_start (src/backend.py:100-109)

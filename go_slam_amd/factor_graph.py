@@ -279,18 +279,53 @@ class FactorGraph:
             suppress(di, dj)
         return es
 
+    @staticmethod
+    def propose_edges_on_device(raw, existing, i0, j0, t, rad, nms, cut, thresh, max_factors, stereo, jmin, loop):
+        """The same greedy proposal on the GPU (csrc/edge_nms.hip: gs_edge_prep -> stable device sort -> gs_edge_greedy):
+        `raw` f32 [(t - i0) * (t - j0)] stays in HBM, `existing` = (ii, jj) device tensors or None.  ONE int comes back
+        to the host (the edge count sizes the edge tensors).  Returns an int64 [n, 2] device tensor in the reference's
+        order -- the order and content of propose_proximity_edges / backend.propose_backend_edges (GPU test)."""
+        from . import _lib
+        dev = raw.device
+        n_local = sum((1 if stereo else 0) + 2 * max(i - max(i - rad, jmin), 0) for i in range(i0, t))
+        cap = n_local + max(int(max_factors), 0) + 16
+        raw = raw.detach().float().contiguous()
+        d_work = torch.empty_like(raw)
+        es = torch.zeros(cap, 2, dtype=torch.long, device=dev)
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        ex_i, ex_j = (None, None) if existing is None else (existing[0].long().contiguous(), existing[1].long().contiguous())
+        n_ex = 0 if existing is None else int(ex_i.numel())
+        L, st = _lib.lib(), _lib.stream_ptr(dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.gs_edge_prep(_lib.ptr(raw), _lib.ptr(d_work), _lib.ptr(ex_i), _lib.ptr(ex_j), n_ex, _lib.ptr(es),
+                                      _lib.ptr(count), cap, i0, j0, t, rad, nms, float(cut), int(bool(stereo)), jmin, st),
+                       "edge_prep")
+            vals, order = torch.sort(d_work, stable=True)
+            _lib.check(L.gs_edge_greedy(_lib.ptr(raw), _lib.ptr(vals), _lib.ptr(order), _lib.ptr(es), _lib.ptr(count), cap,
+                                        i0, j0, t, nms, float(thresh), int(max_factors), int(bool(loop)), st),
+                       "edge_greedy")
+        return es[:int(count)]
+
     @torch.no_grad()
     def add_proximity_factors(self, t0=0, t1=0, rad=2, nms=2, beta=0.25, thresh=16.0, remove=False, max_t=None):
-        """add edges based on frame distance (src/factor_graph.py:383-450): one frame_distance launch pair,
-        ONE device-to-host copy of the distance matrix, then the greedy NMS on the host (the reference keeps
-        d on the GPU and syncs once per candidate)."""
+        """add edges based on frame distance (src/factor_graph.py:383-450): one frame_distance launch pair, then the
+        greedy NMS -- on the GPU for a CUDA video (the distance matrix stays in HBM, one int is read back); on the CPU
+        one copy of the matrix and a NumPy loop (the reference keeps d on the GPU and syncs once per candidate)."""
         cnt = self.video.counter
         t = max_t if max_t is not None else int(getattr(cnt, "value", cnt))
         if t <= t0 or t <= t1:
             return
         ii, jj = torch.meshgrid(torch.arange(t0, t), torch.arange(t1, t), indexing="ij")
         ii, jj = ii.reshape(-1), jj.reshape(-1)
-        d = self.video.distance(ii, jj, beta=beta).detach().float().cpu()
+        d_dev = self.video.distance(ii, jj, beta=beta)
+        if d_dev.is_cuda and (t - t0) * (t - t1) <= 512 * 512:
+            existing = (torch.cat([self.ii, self.ii_bad, self.ii_inac]), torch.cat([self.jj, self.jj_bad, self.jj_inac]))
+            e = FactorGraph.propose_edges_on_device(d_dev, existing, t0, t1, t, rad, nms, 100.0, thresh, self.max_factors,
+                                                    bool(getattr(self.video, "stereo", False)), 0, False)
+            if e.shape[0]:
+                self.add_factors(e[:, 0].contiguous(), e[:, 1].contiguous(), remove)
+            return
+        d = d_dev.detach().float().cpu()
         d[ii - rad < jj] = float("inf")
         d[d > 100] = float("inf")
         d = d.reshape(t - t0, t - t1).numpy().copy()

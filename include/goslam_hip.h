@@ -274,6 +274,25 @@ int gs_ba(float* poses, float* disps, const float* intrinsics, const float* disp
           float* dx, float* dz, int32_t* status_out,
           void* workspace, size_t workspace_bytes, gs_stream_t stream);
 
+/* Edge proposal with greedy non-maximum suppression on the device: FactorGraph.add_proximity_factors
+ * (src/factor_graph.py:384-450) and Backend.ba's selection incl. the loop-closure rule (src/backend.py:31-94), in two
+ * launches around a device-side stable sort; the frame-distance matrix never leaves HBM.
+ *   raw f32 [(t-i0) x (t-j0)]: frame distances of keyframe pairs (i0 + row, j0 + col).
+ *   gs_edge_prep: d_work = raw with the non-candidates (i - rad < j, raw > cut) at +inf, +inf in the (2 nms + 1)^2
+ *     windows of the existing edges ex_i / ex_j (i64, n_existing; pairs outside the window are ignored) and of the
+ *     local-window edges (i, j), (j, i) for j in [max(i - rad, jmin), i) -- which are written to es (i64 [cap,2], with
+ *     (i, i) first per keyframe if `stereo`) in the reference's order; count[0] = number of edges written.
+ *   (the caller sorts d_work ascending, stable: sorted_vals f32, order i64)
+ *   gs_edge_greedy: visits the candidates with sorted value <= thresh in order; a candidate that an earlier pick has
+ *     not suppressed appends (i, j), (j, i) -- in `loop` mode instead the members (si != sj) of its 3x3 neighbourhood
+ *     with raw <= thresh, and only if more than 4 of the 9 are -- and suppresses its window; stops as soon as
+ *     count > max_factors.  count[0] is updated.  At most 512 x 512 candidate pairs.                       */
+int gs_edge_prep(const float* raw, float* d_work, const long long* ex_i, const long long* ex_j, int n_existing,
+                 long long* es, int* count, int cap, int i0, int j0, int t, int rad, int nms, float cut, int stereo,
+                 int jmin, gs_stream_t stream);
+int gs_edge_greedy(const float* raw, const float* sorted_vals, const long long* order, long long* es, int* count,
+                   int cap, int i0, int j0, int t, int nms, float thresh, int max_factors, int loop, gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

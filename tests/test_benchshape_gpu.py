@@ -139,7 +139,7 @@ def test_global_ba_step_matches_oracle_pipeline(built_lib, O, dev):
     from go_slam_amd.depth_video import DepthVideo
     from go_slam_amd.droid_net import UpdateModule
     from go_slam_amd.factor_graph import FactorGraph
-    shape, num_kf, num_edges = "Scan", 40, 200
+    shape, num_kf, num_edges = "Scan", 40, 140
     ht, wd, _ = synth.SHAPES[shape]
     torch.manual_seed(5)
     vid = synth.make_video(num_kf, shape, seed=5, buffer=num_kf + 4)

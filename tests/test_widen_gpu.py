@@ -464,3 +464,54 @@ def test_encoders_on_device_match_reference_golden(built_lib):
     sf, sc = float(g["fnet"].abs().max()), float(g["cnet"].abs().max())
     assert float((fh.float().cpu() - g["fnet"]).abs().max()) < 3e-2 * sf
     assert float((ch.float().cpu() - g["cnet"]).abs().max()) < 3e-2 * sc
+
+
+def _rand_dist(ilen, jlen, seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    d = torch.rand(ilen, jlen, generator=g) * scale
+    d[torch.rand(ilen, jlen, generator=g) < 0.05] = 1000.0          # frame_distance's "too few valid pixels" value
+    return d
+
+
+@pytest.mark.parametrize("t0,t1,t,rad,nms,thresh,max_factors,stereo,n_ex,seed", [
+    (0, 0, 12, 2, 2, 16.0, 48, False, 0, 1), (5, 0, 30, 2, 2, 16.0, 75, False, 25, 2), (20, 5, 45, 3, 1, 12.0, 100, True, 40, 3),
+    (3, 0, 25, 2, 2, 16.0, -1, False, 10, 4), (0, 0, 200, 2, 2, 20.0, 1500, False, 300, 5), (8, 10, 40, 2, 3, 16.0, 60, False, 5, 6)])
+def test_edge_proposal_on_device_equals_host_frontend(built_lib, t0, t1, t, rad, nms, thresh, max_factors, stereo, n_ex, seed):
+    """gs_edge_prep + device sort + gs_edge_greedy vs FactorGraph.propose_proximity_edges (the NumPy loop that is pinned
+    to the reference's own edge lists on CPU goldens): same edges in the same order -- windows clipped at the borders,
+    existing edges inside and outside the window, the stereo self-edges, the max_factors = -1 quirk, t1 > t0 (negative
+    column indices wrap as in the reference), 200 keyframes."""
+    import numpy as np
+    from go_slam_amd.factor_graph import FactorGraph
+    dev = "cuda:0"
+    raw = _rand_dist(t - t0, t - t1, seed, 30.0)
+    g = torch.Generator().manual_seed(seed + 100)
+    ex_i = torch.randint(0, t + 2, (n_ex,), generator=g)
+    ex_j = torch.randint(0, t + 2, (n_ex,), generator=g)
+    ii, jj = torch.meshgrid(torch.arange(t0, t), torch.arange(t1, t), indexing="ij")
+    d = raw.clone()
+    d[(ii - rad) < jj] = float("inf")
+    d[d > 100] = float("inf")
+    want = FactorGraph.propose_proximity_edges(d.numpy().copy(), list(zip(ex_i.tolist(), ex_j.tolist())), t0, t1, t, rad, nms,
+                                               thresh, max_factors, stereo)
+    got = FactorGraph.propose_edges_on_device(raw.reshape(-1).to(dev), (ex_i.to(dev), ex_j.to(dev)), t0, t1, t, rad, nms,
+                                              100.0, thresh, max_factors, stereo, 0, False)
+    assert got.cpu().tolist() == [list(e) for e in want]
+
+
+@pytest.mark.parametrize("t_start,t_loop,t_end,radius,nms,thresh,max_factors,stereo,loop,seed", [
+    (0, 0, 40, 2, 2, 16.0, 320, False, False, 11), (0, 0, 200, 2, 2, 20.0, 1600, False, False, 12),
+    (10, 35, 60, 1, 12, 25.0, 400, False, True, 13), (0, 20, 50, 1, 3, 25.0, 200, True, True, 14),
+    (0, 0, 30, 2, 2, 1.0, 240, True, False, 15)])
+def test_edge_proposal_on_device_equals_host_backend(built_lib, t_start, t_loop, t_end, radius, nms, thresh, max_factors,
+                                                     stereo, loop, seed):
+    """Backend.ba's selection (src/backend.py:31-94) incl. the loop-closure rule (3x3 neighbourhood vote in the raw
+    matrix) on the device vs backend.propose_backend_edges."""
+    from go_slam_amd.backend import propose_backend_edges
+    from go_slam_amd.factor_graph import FactorGraph
+    dev = "cuda:0"
+    raw = _rand_dist(t_end - t_loop, t_end - t_start, seed, 40.0)
+    want = propose_backend_edges(raw.numpy(), t_start, t_loop, t_end, radius, nms, thresh, max_factors, stereo=stereo, loop=loop)
+    got = FactorGraph.propose_edges_on_device(raw.reshape(-1).to(dev), None, t_loop, t_start, t_end, radius, nms, thresh, thresh,
+                                              max_factors, stereo and not loop, t_loop, loop)
+    assert got.cpu().tolist() == [list(e) for e in want]
