@@ -40,6 +40,7 @@ SIGNATURES = {
     "gs_motion_features": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "gs_ba_inputs": (c_int, [_P] * 6 + [c_int, c_int, c_int, _P]),
     "gs_conv1x1": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, c_int, c_int, ctypes.c_longlong, _P]),
+    "gs_conv7x7_c4": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gs_conv3x3_wpack_elems": (c_size_t, [c_int, c_int]),
     "gs_conv3x3": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "gs_conv3x3_stacked": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),

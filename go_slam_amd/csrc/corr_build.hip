@@ -5,7 +5,7 @@
 // The op is HBM-WRITE bound (2.656*HW^2 bytes vs 256*HW^2 flops per edge, AI ~ 96 flop/B), so the
 // kernel is organised around writing every byte exactly once:
 //   corr_prep_kernel   : [n,128,HW] -> channels-last [n,HW,128] fp16, scaled by 1/4 (corr.py:71-72),
-//                        so both MFMA operands are K-contiguous 16-byte fragments
+//                        so both MFMA operands are K-contiguous 16-byte fragments (both maps, one launch)
 //   corr_volume_kernel : one workgroup = 32 source pixels (p1) x 8 full rows of the target map
 //                        (p2 = 8*w columns).  v_mfma_f32_32x32x16_f16 with A = f2 rows, B = f1 rows
 //                        (so each lane ends up holding 4 consecutive p2 of one p1 -> 8-byte LDS
@@ -28,26 +28,44 @@ constexpr int MT = BM / 32;     // 32-pixel MFMA column blocks per workgroup
 constexpr int ROWS = 8;         // target rows per workgroup (covers one 8x8 pooling block row)
 constexpr int MAXT = 5;         // n-tiles (32 columns) per wave: 8*w/32/4 <= 5  <=>  w <= 80
 
-__global__ __launch_bounds__(256) void corr_prep_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out,
-                                                        int hw) {
-  __shared__ _Float16 t[32][34];
-  const int e = blockIdx.z;
-  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-  for (int k = ty; k < 32; k += 8) {
-    const int p = p0 + tx;
-    t[k][tx] = (p < hw) ? in[((size_t)e * KDIM + c0 + k) * hw + p] : (_Float16)0;
+// [n,128,HW] -> [n,HW,128], x 1/4, for both feature maps in one launch (blockIdx.z = map * n + edge).  A workgroup
+// transposes 64 pixels x 128 channels: 128-byte row segments in (4 B per lane), whole 256-byte pixel rows out (16 B per lane).
+__global__ __launch_bounds__(256) void corr_prep_kernel(const _Float16* __restrict__ in1, const _Float16* __restrict__ in2,
+                                                        _Float16* __restrict__ out1, _Float16* __restrict__ out2,
+                                                        int n, int hw) {
+  typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+  __shared__ _Float16 t[KDIM][64 + 2];
+  const int which = blockIdx.z / n, e = blockIdx.z - which * n;
+  const _Float16* in = (which ? in2 : in1) + (size_t)e * KDIM * hw;
+  _Float16* out = (which ? out2 : out1) + (size_t)e * hw * KDIM;
+  const int p0 = blockIdx.x * 64;
+  const int pp = (threadIdx.x & 31) * 2, cr = threadIdx.x >> 5;
+  const bool pair_ok = ((hw & 1) == 0) && (p0 + pp + 1 < hw);
+#pragma unroll 4
+  for (int c = cr; c < KDIM; c += 8) {
+    const _Float16* src = in + (size_t)c * hw + p0 + pp;
+    half2v v = {0, 0};
+    if (pair_ok) v = *reinterpret_cast<const half2v*>(src);
+    else {
+      if (p0 + pp < hw) v[0] = src[0];
+      if (p0 + pp + 1 < hw) v[1] = src[1];
+    }
+    *reinterpret_cast<half2v*>(&t[c][pp]) = v;
   }
   __syncthreads();
-  for (int k = ty; k < 32; k += 8) {
-    const int p = p0 + k;
-    if (p < hw) out[((size_t)e * hw + p) * KDIM + c0 + tx] = t[tx][k] / (_Float16)4.0f;
+  const int c8 = (threadIdx.x & 15) * 8;
+  for (int px = threadIdx.x >> 4; px < 64; px += 16) {
+    if (p0 + px >= hw) break;
+    half8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = t[c8 + k][px] / (_Float16)4.0f;
+    *reinterpret_cast<half8*>(out + (size_t)(p0 + px) * KDIM + c8) = o;
   }
 }
 
 __device__ __forceinline__ half8 ld8(const _Float16* p) { return *reinterpret_cast<const half8*>(p); }
 
-__global__ __launch_bounds__(256) void corr_volume_kernel(
+__global__ __launch_bounds__(256, 3) void corr_volume_kernel(
     const _Float16* __restrict__ f1t, const _Float16* __restrict__ f2t, _Float16* __restrict__ v0,
     _Float16* __restrict__ v1, _Float16* __restrict__ v2, _Float16* __restrict__ v3, int h, int w, int tiled) {
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
@@ -58,23 +76,42 @@ __global__ __launch_bounds__(256) void corr_volume_kernel(
   const int LD2 = (ROWS / 4) * (w / 4) + 2;
   _Float16* c0 = lds;                      // [BM][LD0]
   _Float16* c1 = c0 + BM * LD0;            // [BM][LD1]
-  _Float16* c2 = c1 + BM * LD1;            // [BM][LD2]
+  _Float16* c2 = c0;                       // [BM][LD2]: level 2 is produced after the last read of c0 (barrier below)
   const int e = blockIdx.z;
-  const int p1_0 = blockIdx.x * BM;
-  const int y2_0 = blockIdx.y * ROWS;
+  // target-row block fastest: workgroups that run together then write the SAME 32 source pixels' planes side by side
+  // (32 x 9.6 KB contiguous per 8 workgroups at 60 x 80) instead of 1.3 KB pieces 9.6 KB apart across the whole volume
+  const int p1_0 = blockIdx.y * BM;
+  const int y2_0 = blockIdx.x * ROWS;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r = lane & 31, kh = 8 * (lane >> 5);
+  const int r = lane & 31;
   const int ntile = BN / 32;
   const _Float16* A = f2t + (size_t)e * hw * KDIM;   // rows p2
   const _Float16* B = f1t + (size_t)e * hw * KDIM;   // rows p1
 
-  // B fragments (source pixels) for the two 32-wide p1 tiles, all 8 k-steps
-  half8 bf[MT][8];
+  // A operand, first tile: issued before anything else so that its round trip overlaps the B tile's (see below)
+  const int srow = lane >> 4, schunk = lane & 15;
+  half8 areg[8];
+  auto issue_tile = [&](int t) {
+    const int nt = wave + 4 * t;
+    if (nt < ntile) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int p1 = min(p1_0 + 32 * mt + r, hw - 1);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) bf[mt][ks] = ld8(B + (size_t)p1 * KDIM + 16 * ks + kh);
+      for (int i = 0; i < 8; ++i) {
+        const int p2 = min(y2_0 * w + 32 * nt + 4 * i + srow, hw - 1);
+        areg[i] = ld8(A + (size_t)p2 * KDIM + 8 * schunk);
+      }
+    }
+  };
+  issue_tile(0);
+  // B operand (source pixels): the workgroup's BM x 128 tile through LDS as well (coalesced loads, one copy for the 4
+  // waves; see the A operand below).  Its fragments are re-read from LDS per tile rather than held in 32 VGPRs.
+  _Float16* bstage = lds + 4 * (32 * KDIM);
+  {
+    for (int idx = threadIdx.x; idx < BM * 16; idx += 256) {
+      const int row = idx >> 4, chunk = idx & 15;
+      const int p1 = min(p1_0 + row, hw - 1);
+      *reinterpret_cast<half8*>(bstage + row * KDIM + 8 * (chunk ^ (row & 15))) = ld8(B + (size_t)p1 * KDIM + 8 * chunk);
+    }
+    __syncthreads();
   }
   float16v acc[MAXT][MT];
 #pragma unroll
@@ -83,21 +120,44 @@ __global__ __launch_bounds__(256) void corr_volume_kernel(
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][mt][i] = 0.f;
+  // A operand (target pixels): a fragment lane wants 16 bytes of ITS row, so loading fragments straight from memory
+  // makes every load instruction touch 32 rows x 32 B (32 cache lines for 1 KB; the texture path, not HBM, bounded the
+  // kernel at 0.17 of the write roofline).  Instead a wave fetches its 32 x 128 tile as 8 fully coalesced 1 KB loads
+  // (lane -> row 4 i + lane / 16, 16-byte chunk lane % 16), parks it in a wave-private 8 KB LDS stage (chunk XOR row:
+  // conflict-free both ways; the stage aliases the output tile c0, which is only written after the MFMA phase) and
+  // reads the fragments back with ds_read_b128.  Tile t + 1 is in flight while tile t is multiplied.  (One register
+  // buffer: with 3 workgroups per CU -- 168 VGPRs, 52 KB of LDS -- the other workgroups cover what is left of the latency.)
+  _Float16* stage = lds + wave * (32 * KDIM);
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
     const int nt = wave + 4 * t;
     if (nt < ntile) {
-      const int p2 = min(y2_0 * w + 32 * nt + r, hw - 1);
-      const _Float16* ar = A + (size_t)p2 * KDIM + kh;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const half8 af = ld8(ar + 16 * ks);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[mt][ks], acc[t][mt], 0, 0, 0);
+      for (int i = 0; i < 8; ++i) {
+        const int R = 4 * i + srow;
+        *reinterpret_cast<half8*>(stage + R * KDIM + 8 * (schunk ^ (R & 15))) = areg[i];
       }
     }
+    if (t + 1 < MAXT) issue_tile(t + 1);               // the registers are free again: next tile flies during the MFMAs
+    if (nt < ntile) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int sw = 8 * ((2 * ks + (lane >> 5)) ^ (r & 15));
+        const half8 af = *reinterpret_cast<const half8*>(stage + r * KDIM + sw);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const half8 bfr = *reinterpret_cast<const half8*>(bstage + (32 * mt + r) * KDIM + sw);
+          acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfr, acc[t][mt], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
   }
+  __syncthreads();                                     // every wave is done with its stage before c0 is written
   // D[p2][p1]: lane -> p1 = 32*mt + (lane&31); reg q*4+k -> p2 = 32*nt + 8*q + 4*(lane>>5) + k
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
@@ -259,7 +319,7 @@ extern "C" int gs_corr_volume_pyramid(const void* fmap1, const void* fmap2, void
   GS_REQUIRE(w % 8 == 0 && w <= 16 * MAXT, "corr_volume_pyramid: map width %d must be a multiple of 8 and <= %d",
              w, 16 * MAXT);
   if (n == 0) return GS_OK;
-  GS_REQUIRE(n <= 65535, "corr_volume_pyramid: n=%d exceeds grid.z limit", n);
+  GS_REQUIRE(n <= 32767, "corr_volume_pyramid: n=%d exceeds the grid.z limit", n);
   const size_t need = gs_corr_volume_workspace_bytes(n, dim, h, w);
   if (!workspace || workspace_bytes < need) {
     gs_set_error("corr_volume_pyramid: workspace too small (%zu < %zu)", workspace_bytes, need);
@@ -269,15 +329,17 @@ extern "C" int gs_corr_volume_pyramid(const void* fmap1, const void* fmap2, void
   const int hw = h * w;
   _Float16* f1t = (_Float16*)gs_align((size_t)workspace);
   _Float16* f2t = f1t + gs_align((size_t)n * hw * KDIM * 2) / 2;
-  dim3 pg(gs_cdiv(hw, 32), KDIM / 32, n);
-  corr_prep_kernel<<<pg, 256, 0, st>>>((const _Float16*)fmap1, f1t, hw);
-  corr_prep_kernel<<<pg, 256, 0, st>>>((const _Float16*)fmap2, f2t, hw);
+  corr_prep_kernel<<<dim3(gs_cdiv(hw, 64), 1, 2 * n), 256, 0, st>>>((const _Float16*)fmap1, (const _Float16*)fmap2, f1t,
+                                                                    f2t, n, hw);
   GS_CHECK_LAUNCH("corr_prep");
   const int BN = ROWS * w;
-  const size_t lds = (size_t)(BM * (BN + 8) + BM * ((ROWS / 2) * (w / 2) + 8) + BM * ((ROWS / 4) * (w / 4) + 2)) * 2;
+  size_t lds = (size_t)(BM * (BN + 8) + BM * ((ROWS / 2) * (w / 2) + 8)) * 2;     // c0 (+ c2 inside it) and c1
+  const size_t stages = (size_t)(4 * 32 + BM) * KDIM * 2;                   // operand stages (alias the output tile)
+  if (lds < stages) lds = stages;
   static GsLdsLimit limit;
   if (int rc = limit.raise((const void*)corr_volume_kernel, 160 * 1024, "corr_volume")) return rc;
-  dim3 grid(gs_cdiv(hw, BM), gs_cdiv(h, ROWS), n);
+  GS_REQUIRE(gs_cdiv(hw, BM) <= 65535, "corr_volume_pyramid: map too large");
+  dim3 grid(gs_cdiv(h, ROWS), gs_cdiv(hw, BM), n);
   corr_volume_kernel<<<grid, 256, lds, st>>>(f1t, f2t, (_Float16*)vol0, (_Float16*)vol1, (_Float16*)vol2,
                                              (_Float16*)vol3, h, w, layout == GS_CORR_TILE8);
   GS_CHECK_LAUNCH("corr_volume");

@@ -108,6 +108,40 @@ def conv1x1_bias_act(cache, conv, x, act):
     return y
 
 
+def pack_conv7x7_c4_weight(weight):
+    """[128, 4, 7, 7] -> gs_conv7x7_c4's fp16 A-fragment image [2][2][14][64][8] (include/goslam_hip.h): K index
+    k = 32 ky + 4 kx + c with an all-zero 8th tap per kernel row."""
+    O, C, kh, kw = weight.shape
+    assert (O, C, kh, kw) == (128, 4, 7, 7)
+    wk = torch.zeros(O, 7, 8, 4, dtype=torch.float16, device=weight.device)
+    wk[:, :, :7, :] = weight.detach().half().permute(0, 2, 3, 1)               # o ky kx c
+    wk = wk.reshape(2, 2, 32, 14, 2, 8)                                        # nh t row s kg e
+    return wk.permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)               # nh t s (kg row) e
+
+
+def conv7x7_c4_supported(conv, x):
+    return (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and x.shape[1] == 4 and x.shape[3] <= 1024
+            and tuple(conv.weight.shape) == (128, 4, 7, 7) and conv.stride in (1, (1, 1))
+            and conv.padding in (3, (3, 3)) and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def conv7x7_c4_bias_act(cache, conv, x, act, rt=0):
+    """act(conv7x7(x) + bias) for a 4-channel NHWC fp16 x in one HIP launch (gs_conv7x7_c4); act: none / relu."""
+    from . import _lib
+    key = (conv.weight._version, conv.bias._version, conv.weight.device, conv.weight.data_ptr())
+    hit = cache.get(id(conv))
+    if hit is None or hit[0] != key:
+        hit = (key, pack_conv7x7_c4_weight(conv.weight), conv.bias.detach().float().contiguous())
+        cache[id(conv)] = hit
+    n, _, h, w = x.shape
+    y = torch.empty((n, 128, h, w), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().gs_conv7x7_c4(_lib.ptr(x), _lib.ptr(hit[1]), _lib.ptr(hit[2]), _lib.ptr(y), 128, n, h, w,
+                                      int(act == "relu"), int(rt), _lib.stream_ptr(x.device))
+    _lib.check(rc, "conv7x7_c4")
+    return y
+
+
 def conv3x3_head(x, conv, cache, epilogue="none", out_scale=1.0, in_channel=0, in_bias=None, in_relu=False):
     """epi(conv(relu?(x[:, in_channel:in_channel+128] + in_bias)) + bias) * out_scale -> fp32 [n,h,w,O]
     (values are the reference's fp16 results), one HIP launch (gs_conv3x3_head)."""
@@ -194,6 +228,8 @@ CONV3X3_PP = os.environ.get("GOSLAM_CONV3X3_PP", "1") == "1"
 # (gs_conv3x3_bias_relu).  Same formulas and rounding points as conv + gate / bias_act kernels (GPU tests: bias + ReLU
 # bit-identical; ConvGRU within one fp16 ulp on < 1e-4 of the elements); zr_pre / q_pre never travel to HBM and back.
 GRU_FUSED_EPILOGUE = os.environ.get("GOSLAM_GRU_FUSED", "1") == "1"
+# flow_encoder[0] (7x7, 4 -> 128) through gs_conv7x7_c4 (bias + ReLU fused); GOSLAM_CONV7X7=0: MIOpen + bias_act pass
+CONV7X7_OWN = os.environ.get("GOSLAM_CONV7X7", "1") == "1"
 _CONV3X3_PACKS = {}        # (data_ptr, version, shape, device, kc) -> (packed image, weight tensor kept alive)
 _CONV3X3_PACKS_MAX = 32
 
@@ -553,7 +589,10 @@ class UpdateModule(nn.Module):
         copy_channels(net4, hx, 0)
         c4 = conv1x1_bias_act(self._head_cache, self.corr_encoder[0], c4, "relu")
         conv_bias_act(hwc, self.corr_encoder[2], c4, "relu", out=hx, out_channel=128)
-        f4 = conv_bias_act(hwc, self.flow_encoder[0], f4, "relu")
+        if CONV7X7_OWN and conv7x7_c4_supported(self.flow_encoder[0], f4):
+            f4 = conv7x7_c4_bias_act(self._head_cache, self.flow_encoder[0], f4, "relu")
+        else:
+            f4 = conv_bias_act(hwc, self.flow_encoder[0], f4, "relu")
         conv_bias_act(hwc, self.flow_encoder[2], f4, "relu", out=hx, out_channel=256)
         net4 = self.gru.forward_hx(net4, hx, inp_pre)
         net = net4.view(*out_dim)

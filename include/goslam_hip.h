@@ -168,6 +168,15 @@ int gs_ba_inputs(const float* coords1, const float* delta, const float* weight, 
  * bias may be NULL; act: 0 none, 1 ReLU.                                                            */
 int gs_conv1x1(const void* x, int x_stride, int k_in, const void* wpack, const float* bias, int act, void* y,
                int y_stride, int n_out, long long rows, gs_stream_t stream);
+/* act(conv7x7(x) + bias), padding 3, stride 1, for a FOUR-channel NHWC fp16 map [n,h,w,4] -> 128 channels (pixels of
+ * y `ys` halves apart, 128 written): the flow encoder's first layer over the motion features (reference
+ * src/droid_net.py:79 `Conv2d(4, 128, 7, padding=3)` + ReLU).  fp32 accumulation starting from the bias, one rounding to
+ * fp16, then ReLU if `relu`.  K is laid out as 7 kernel rows x 8 taps x 4 channels (the 8th tap is zero) = 14 MFMA
+ * k-steps; wpack: fp16 [2][2][14][64][8],
+ * wpack[nh][t][s][l][e] = Wk[64 nh + 32 t + (l & 31)][16 s + 8 (l >> 5) + e] with Wk[o][32 ky + 4 kx + c] = W[o][c][ky][kx]
+ * (0 for kx = 7).  rt = image rows per workgroup (0: chosen from the map size); w <= 1024.              */
+int gs_conv7x7_c4(const void* x, const void* wpack, const float* bias, void* y, int ys, int n, int h, int w, int relu,
+                  int rt, gs_stream_t stream);
 /* 3x3 convolution, padding 1, stride 1, no bias: NHWC fp16 [n,h,w,c_in] (pixels x_stride elements apart) ->
  * NHWC fp16 [n,h,w,n_out] (y_stride apart), fp32 accumulation, as an implicit GEMM on MFMA with the 18x18 input
  * patch of a 16x16-pixel tile staged once in LDS for all 9 taps.  Covers the large convolutions of the update

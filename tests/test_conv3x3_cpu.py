@@ -99,3 +99,34 @@ def test_fused_gru_epilogues_by_emulation():
     for args in ((2, 5, 9, 64, False, True), (1, 3, 17, 64, True, False)):
         dz, dr, dout, unwritten = emu.gru_fused(*args[:5], hoisted=args[5])
         assert unwritten == 0 and max(dz, dr, dout) <= 5e-4, (args, dz, dr, dout, unwritten)
+
+
+def test_conv7x7_c4_weight_image_by_lane_level_emulation():
+    """pack_conv7x7_c4_weight vs conv7x7.hip's indexing, lane by lane: A fragment (nh, t, s) lane l = 8 halves of channel
+    64 nh + 32 t + (l & 31) at K = 16 s + 8 (l >> 5) ..; the pixel operand of lane l at k-step s = the 2 patch pixels
+    (py + s // 2, px + 4 (s & 1) + 2 (l >> 5) + {0, 1}) x 4 channels of the zero-padded NHWC patch (origin -3, -3).
+    Contracting the two the way the MFMA does reproduces F.conv2d; the 8th tap never contributes."""
+    import torch.nn.functional as F
+    from go_slam_amd.droid_net import pack_conv7x7_c4_weight
+    g = torch.Generator().manual_seed(4)
+    H, W = 5, 9
+    w = (torch.randn(128, 4, 7, 7, generator=g) * 0.1).half()
+    x = torch.randn(1, 4, H, W, generator=g).half()
+    ref = F.conv2d(x.float(), w.float(), padding=3)[0]                          # [128, H, W]
+    img = pack_conv7x7_c4_weight(w).float().view(2, 2, 14, 64, 8)
+    patch = torch.full((H + 6, W + 8, 4), float("nan"))                         # kernel: zero-filled incl. columns W+3..W+4
+    patch[:] = 0.0
+    patch[3:3 + H, 3:3 + W] = x[0].permute(1, 2, 0).float()
+    out = torch.zeros(128, H, W)
+    for py in range(H):
+        for px in range(W):
+            for s in range(14):
+                for kg in range(2):
+                    pix = patch[py + s // 2, px + 4 * (s & 1) + 2 * kg: px + 4 * (s & 1) + 2 * kg + 2].reshape(8)
+                    lanes = torch.arange(32) + 32 * kg
+                    a = img[:, :, s, lanes]                                     # [nh, t, 32 rows, 8]
+                    out[:, py, px] += (a @ pix).reshape(128)
+    assert torch.allclose(out, ref, rtol=1e-4, atol=1e-4)
+    wk = img.permute(0, 1, 3, 2, 4)                                              # nh t lane s e
+    # tap 7 of every kernel row (K = 32 ky + 28 .. 31 -> k-step 2 ky + 1, k-group 1, e = 4..7) is zero
+    assert float(img[:, :, 1::2, 32:, 4:].abs().max()) == 0.0 and wk.shape[-2] == 14

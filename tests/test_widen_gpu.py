@@ -406,6 +406,63 @@ def test_fused_bias_relu_convolution_equals_conv_plus_bias_act(built_lib):
     assert float(res[True][1].min()) == 0.0 and float(res[True][1].max()) > 0.0
 
 
+@pytest.mark.parametrize("n,h,w,rt", [(3, 60, 80, 0), (2, 30, 40, 0), (1, 85, 150, 0), (2, 23, 37, 5), (1, 7, 9, 3),
+                                      (1, 60, 80, 60)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv7x7_c4_kernel_matches_reference(built_lib, n, h, w, rt, relu):
+    """gs_conv7x7_c4 (flow_encoder[0]: 7x7, 4 -> 128, bias + ReLU fused) vs an fp32 torch convolution of the same fp16
+    operands, rounded once to fp16: within one fp16 ulp of the fp32 result (accumulation order differs), every map size
+    incl. widths that are no multiple of anything and a last strip with fewer rows."""
+    import torch.nn.functional as F
+    import go_slam_amd.droid_net as DN
+    dev = "cuda:0"
+    torch.manual_seed(100 * h + w)
+    conv = torch.nn.Conv2d(4, 128, 7, padding=3).to(dev)
+    x = (4.0 * torch.randn(n, 4, h, w, device=dev)).half().contiguous(memory_format=torch.channels_last)
+    assert DN.conv7x7_c4_supported(conv, x)
+    y = DN.conv7x7_c4_bias_act({}, conv, x, "relu" if relu else "none", rt=rt)
+    with torch.autocast("cuda", enabled=False):
+        ref = F.conv2d(x.float(), conv.weight.half().float(), conv.bias.float(), padding=3)
+    if relu:
+        ref = ref.relu()
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    err = (y.float() - ref).abs()
+    tol = 2.0 ** -10 * ref.abs().clamp_min(1.0)                      # one fp16 ulp at the value's binade (>= 2^-10)
+    assert bool((err <= tol).all()), float((err / tol).max())
+    if relu:
+        assert float(y.min()) == 0.0
+
+
+def test_update_operator_with_own_conv7x7_matches_library_path(built_lib):
+    """UpdateModule fast path with flow_encoder[0] through gs_conv7x7_c4 vs MIOpen + bias_act: the library path rounds
+    twice (conv -> fp16, + bias -> fp16), the own kernel once, so outputs agree to fp16 resolution of the activations."""
+    import go_slam_amd.droid_net as DN
+    dev = "cuda:0"
+    torch.manual_seed(5)
+    op = DN.UpdateModule().to(dev).eval()
+    E, ht, wd = 6, 30, 40
+    net = (0.5 * torch.randn(1, E, 128, ht, wd, device=dev)).half().contiguous()
+    net = net.view(E, 128, ht, wd).contiguous(memory_format=torch.channels_last).view(1, E, 128, ht, wd)
+    inp = (0.5 * torch.randn(1, E, 128, ht, wd, device=dev)).half()
+    corr = torch.randn(1, E, 196, ht, wd, device=dev).half()
+    flow = (3.0 * torch.randn(1, E, 4, ht, wd, device=dev))
+    ii = torch.tensor([0, 0, 1, 1, 2, 2], device=dev)
+    jj = torch.tensor([1, 2, 0, 2, 0, 1], device=dev)
+    keep = DN.CONV7X7_OWN
+    res = {}
+    try:
+        for own in (True, False):
+            DN.CONV7X7_OWN = own
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                res[own] = op(net.clone(), inp, corr, flow, ii, jj)
+    finally:
+        DN.CONV7X7_OWN = keep
+    for a, b in zip(res[True], res[False]):
+        assert torch.isfinite(a.float()).all()
+        d = (a.float() - b.float()).abs().max()
+        assert float(d) <= 2e-2 * max(1.0, float(b.float().abs().max())), float(d)
+
+
 def _golden(name):
     import numpy as np
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
