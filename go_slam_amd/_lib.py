@@ -53,6 +53,8 @@ SIGNATURES = {
     "gs_segment_mean": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gs_gru_glo_workspace_bytes": (c_size_t, [c_int]),
     "gs_gru_glo": (c_int, [_P] * 11 + [c_int, c_int, _P, c_size_t, _P]),
+    "gs_gru_glo_fused_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "gs_gru_glo_fused": (c_int, [_P, c_int] + [_P] * 10 + [c_int, c_int, _P, c_size_t, _P]),
     "gs_gru_gate_zr": (c_int, [_P] * 6 + [c_int] * 3 + [_P]),
     "gs_gru_gate_q": (c_int, [_P] * 7 + [c_int] * 2 + [_P]),
     "gs_edge_prep": (c_int, [_P] * 4 + [c_int, _P, _P] + [c_int] * 6 + [c_float, c_int, c_int, _P]),

@@ -8,8 +8,13 @@
 // the accumulator registers (MIOpen's CK kernel + a separate bias/ReLU pass moved the output twice
 // more).  W^T is the MFMA A operand: pre-packed per (32-channel block, 16-wide k-step) into 1 KB
 // fragments, copied to LDS once per workgroup (53 KB for 196->128, 147 KB for 128->576) and read back
-// conflict-free; pixels are the B operand, loaded straight from their rows.  Workgroups are
-// persistent and stride over 32-pixel blocks.
+// conflict-free; pixels are the B operand.  A fragment lane wants 16 bytes of ITS pixel row, so loading
+// fragments straight from memory makes every load instruction touch 32 rows (32 cache lines per KB:
+// the texture path, not HBM, was the bound).  When the rows are dense (x_stride == k_in) a wave's 32
+// pixels are ONE contiguous chunk: it is fetched with fully coalesced 16-byte loads, parked in a
+// wave-private LDS stage (rows padded to a stride of 4 banks mod 64: conflict-free ds_read_b128) and
+// the fragments are read from there; the stage doubles as the epilogue's transpose tile.  Strided
+// inputs keep the direct loads.  Workgroups (8 waves) are persistent and stride over 32-pixel blocks.
 #include "common.h"
 
 namespace {
@@ -19,12 +24,30 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 struct __attribute__((packed, aligned(8))) half8_a8 { half8 v; };   // pixel rows of 196 halves are 8-B aligned
 
+// 16-byte piece `c` of a dense chunk of `avail` halves; the last piece of a chunk whose length is 4 mod 8 is 8 bytes
+__device__ __forceinline__ half8 ld_piece(const _Float16* base, int c, size_t avail) {
+  if ((size_t)c * 8 + 8 <= avail) return *reinterpret_cast<const half8*>(base + (size_t)c * 8);
+  const half4 t = *reinterpret_cast<const half4*>(base + (size_t)c * 8);
+  half8 v = {t[0], t[1], t[2], t[3], 0, 0, 0, 0};
+  return v;
+}
+
+constexpr int C1_WAVES = 8;
+constexpr int C1_THREADS = 64 * C1_WAVES;
+
+// halves per row of the wave stage: an ODD number of 16-byte pieces >= the row, so that rows r, r + 1, ... r + 15 start
+// in 16 different 16-byte slots modulo 256 B (conflict-free ds_read_b128 service groups)
+__host__ __device__ inline int c1_stage_stride(int K) {
+  const int pieces = (K + 7) / 8;
+  return 8 * (pieces | 1);
+}
+
 template <int KS>   // k-steps of 16 input channels
-__global__ __launch_bounds__(256) void conv1x1_kernel(const _Float16* __restrict__ x, int ldx, int K,
+__global__ __launch_bounds__(C1_THREADS) void conv1x1_kernel(const _Float16* __restrict__ x, int ldx, int K,
                                                       const _Float16* __restrict__ wpack,
                                                       const float* __restrict__ bias, int act,
                                                       _Float16* __restrict__ y, int ldy, int NBT, int NBS,
-                                                      size_t rows) {
+                                                      size_t rows, int staged) {
   // blockIdx.y picks a slice of NBS 32-channel blocks: wide outputs (576) are split so that a slice's
   // weights (<= 52 KB) leave room for 3 workgroups per CU; the pixel rows are re-read per slice from L2
   extern __shared__ _Float16 wl[];            // [NB][KS][64][8]
@@ -34,30 +57,91 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const _Float16* __restrict
   {
     const int nfrag16 = NB * KS * 64;         // 16-byte pieces
     const half8* src = reinterpret_cast<const half8*>(wpack) + (size_t)nbase * KS * 64;
-    for (int i = tid; i < nfrag16; i += 256) reinterpret_cast<half8*>(wl)[i] = src[i];
+    for (int i = tid; i < nfrag16; i += C1_THREADS) reinterpret_cast<half8*>(wl)[i] = src[i];
   }
   __syncthreads();
   constexpr int TS = 72;                      // tile row stride in halves (144 B: 16-B aligned, staggered banks)
-  _Float16* tile = wl + (size_t)NBS * KS * 512 + (size_t)wv * 32 * TS;
+  const int SS = c1_stage_stride(K);          // stage row stride in halves
+  const int wave_lds = staged ? (32 * SS > 32 * TS ? 32 * SS : 32 * TS) : 32 * TS;
+  _Float16* tile = wl + (size_t)NBS * KS * 512 + (size_t)wv * wave_lds;     // stage and transpose tile share it
   const int kh = 8 * (lane >> 5);
   const size_t nblk = (rows + 31) / 32;
-  for (size_t blk = (size_t)blockIdx.x * 4 + wv; blk < nblk; blk += (size_t)gridDim.x * 4) {
+  const int U = K >> 2;                       // 8-byte units per row
+  const float invU = 1.0f / (float)U;
+  // the wave's 32 rows = one contiguous chunk of 32 * K halves (fewer at the tail): 16-byte pieces, coalesced.
+  // (Requesting the NEXT block's pieces before this block's MFMAs -- 52 more VGPRs -- measured no faster.)
+  constexpr int NLOAD = (KS * 16 * 32 / 8 + 63) / 64;                     // >= ceil(32 K / 8 / 64)
+  half8 pc[NLOAD];
+  auto issue = [&](size_t blk) {
+    const size_t first = blk * 32 * (size_t)K;                            // in halves; 16-byte aligned (32 K * 2 B)
+    const size_t avail = (rows - blk * 32 < 32 ? rows - blk * 32 : 32) * (size_t)K;
+    const int npiece = (int)((avail + 7) >> 3);
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int c = i * 64 + lane;
+      pc[i] = ld_piece(x + first, c < npiece ? c : npiece - 1, avail);
+    }
+  };
+  const size_t blk_first = (size_t)blockIdx.x * C1_WAVES + wv, blk_step = (size_t)gridDim.x * C1_WAVES;
+  for (size_t blk = blk_first; blk < nblk; blk += blk_step) {
     const size_t px = blk * 32 + (lane & 31);
     const bool valid = px < rows;
-    const _Float16* xr = x + (valid ? px : 0) * (size_t)ldx + kh;
     half8 b[KS];
+    if (staged) {
+      issue(blk);
+      const size_t avail = (rows - blk * 32 < 32 ? rows - blk * 32 : 32) * (size_t)K;
+      const int npiece = (int)((avail + 7) >> 3);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int k0 = 16 * ks + kh;
-      half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (valid) {
-        if (k0 + 8 <= K) v = reinterpret_cast<const half8_a8*>(xr + 16 * ks)->v;
-        else if (k0 + 4 <= K) {               // K % 8 == 4 (196): the last 4 channels
-          const half4 t = *reinterpret_cast<const half4*>(xr + 16 * ks);
-          v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+      for (int i = 0; i < NLOAD; ++i) {
+        const int c = i * 64 + lane;
+        if (c < npiece) {
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {                                // two 8-byte units; K % 4 == 0: none straddles a row
+            const int u = 2 * c + hh;
+            const int r = (int)(((float)u + 0.5f) * invU);
+            const int cu = u - r * U;
+            if (r < 32) {
+              half4 t4;
+              t4[0] = pc[i][4 * hh]; t4[1] = pc[i][4 * hh + 1]; t4[2] = pc[i][4 * hh + 2]; t4[3] = pc[i][4 * hh + 3];
+              *reinterpret_cast<half4*>(tile + r * SS + 4 * cu) = t4;
+            }
+          }
         }
       }
-      b[ks] = v;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const _Float16* sr = tile + (lane & 31) * SS + kh;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k0 = 16 * ks + kh;
+        half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (valid) {
+          if (k0 + 8 <= K) v = *reinterpret_cast<const half8*>(sr + 16 * ks);
+          else if (k0 + 4 <= K) {
+            const half4 t = *reinterpret_cast<const half4*>(sr + 16 * ks);
+            v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+          }
+        }
+        b[ks] = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                                    // fragments are in registers: the tile is free
+    } else {
+      const _Float16* xr = x + (valid ? px : 0) * (size_t)ldx + kh;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k0 = 16 * ks + kh;
+        half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (valid) {
+          if (k0 + 8 <= K) v = reinterpret_cast<const half8_a8*>(xr + 16 * ks)->v;
+          else if (k0 + 4 <= K) {               // K % 8 == 4 (196): the last 4 channels
+            const half4 t = *reinterpret_cast<const half4*>(xr + 16 * ks);
+            v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+          }
+        }
+        b[ks] = v;
+      }
     }
     for (int nb0 = 0; nb0 < NB; nb0 += 4) {
       float16v c[4];
@@ -129,16 +213,24 @@ int launch1x1(const void* x, int ldx, int K, const void* wpack, const float* bia
   NBS = (NBS + 3) / 4 * 4 > NBT ? NBT : (NBS + 3) / 4 * 4;       // whole groups of 4 blocks (one accumulator pass)
   if ((size_t)NBS * KS * 1024 > 60 * 1024) NBS = NBS > 4 ? NBS - 4 : NBS;
   const int nslice = (NBT + NBS - 1) / NBS;
-  const size_t lds = (size_t)NBS * KS * 1024 + 4 * 32 * 72 * sizeof(_Float16);
-  GS_REQUIRE(lds <= 152 * 1024, "conv1x1: %d x %d weights need %zu bytes of LDS", N, K, lds);
+  // dense, 16-byte aligned rows: coalesced loads through the wave stages (see the kernel)
+  int staged = (ldx == K && ((size_t)x & 15) == 0) ? 1 : 0;
+  size_t wave_lds = 32 * 72;
+  if (staged && (size_t)32 * c1_stage_stride(K) > wave_lds) wave_lds = (size_t)32 * c1_stage_stride(K);
+  size_t lds = (size_t)NBS * KS * 1024 + C1_WAVES * wave_lds * sizeof(_Float16);
+  if (lds > 160 * 1024) {                       // cannot happen for the update operator's layers; keep the direct loads
+    staged = 0;
+    lds = (size_t)NBS * KS * 1024 + C1_WAVES * 32 * 72 * sizeof(_Float16);
+  }
+  GS_REQUIRE(lds <= 160 * 1024, "conv1x1: %d x %d weights need %zu bytes of LDS", N, K, lds);
   static GsLdsLimit limit;
-  if (int rc = limit.raise((const void*)conv1x1_kernel<KS>, 152 * 1024, "conv1x1")) return rc;
+  if (int rc = limit.raise((const void*)conv1x1_kernel<KS>, 160 * 1024, "conv1x1")) return rc;
   const size_t nblk = (rows + 31) / 32;
-  size_t grid = (size_t)256 * 2 / nslice;
-  if (grid < 64) grid = 64;
-  if (grid > (nblk + 3) / 4) grid = (nblk + 3) / 4;
-  conv1x1_kernel<KS><<<dim3((unsigned)grid, nslice), 256, lds, st>>>((const _Float16*)x, ldx, K, (const _Float16*)wpack,
-                                                                    bias, act, (_Float16*)y, ldy, NBT, NBS, rows);
+  size_t grid = (size_t)256 / nslice;           // one 8-wave workgroup per CU and slice
+  if (grid < 32) grid = 32;
+  if (grid > (nblk + C1_WAVES - 1) / C1_WAVES) grid = (nblk + C1_WAVES - 1) / C1_WAVES;
+  conv1x1_kernel<KS><<<dim3((unsigned)grid, nslice), C1_THREADS, lds, st>>>(
+      (const _Float16*)x, ldx, K, (const _Float16*)wpack, bias, act, (_Float16*)y, ldy, NBT, NBS, rows, staged);
   GS_CHECK_LAUNCH("conv1x1");
   return GS_OK;
 }

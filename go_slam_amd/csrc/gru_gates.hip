@@ -215,6 +215,91 @@ __global__ __launch_bounds__(256) void glo_pool_kernel(const _Float16* __restric
   }
 }
 
+// The same partial sums WITHOUT the w_pre round trip: the 1x1 convolution w(net) (128 -> 128) runs on MFMA inside this
+// kernel (weights = A operand, 32 KB of fragments in LDS; pixels = B operand straight from their rows, as in conv1x1.hip)
+// and sigmoid(. + bias) * net is pooled in its epilogue -- net is read once from HBM (the second read, in row layout,
+// hits L1/L2), nothing but 512 B of partial sums per 32 pixels is written: 23 MB instead of 92 + 92 + 92 + 92 MB moved
+// at 75 edges x 60 x 80.  A wave owns 32 consecutive pixels of ONE edge (blocks never straddle edges);
+// partial[(edge, block), 128] in a fixed order -> deterministic.  Rounding: fp16(conv + bias) once (as autocast's
+// conv2d does), fp16 sigmoid, fp16 product, fp32 sums.
+typedef _Float16 half4g __attribute__((ext_vector_type(4)));
+typedef float float16g __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void glo_conv_pool_kernel(const _Float16* __restrict__ net, int ldx,
+                                                            const _Float16* __restrict__ wpack,
+                                                            const float* __restrict__ bias, float* __restrict__ partial,
+                                                            int hw, int bpi, size_t nblk) {
+  extern __shared__ _Float16 wl[];            // [4][8][64][8] weight fragments, then 4 x [32][72] wave tiles
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int i = tid; i < 4 * 8 * 64; i += 256) reinterpret_cast<half8*>(wl)[i] = reinterpret_cast<const half8*>(wpack)[i];
+  __syncthreads();
+  constexpr int TS = 72;
+  _Float16* tile = wl + 4 * 8 * 512 + wv * 32 * TS;
+  const int kh = 8 * (lane >> 5);
+  for (size_t blk = (size_t)blockIdx.x * 4 + wv; blk < nblk; blk += (size_t)gridDim.x * 4) {
+    const size_t img = blk / bpi;
+    const int b0 = (int)(blk - img * bpi) * 32;
+    const int pin = b0 + (lane & 31);
+    const _Float16* xr = net + (img * hw + (pin < hw ? pin : hw - 1)) * (size_t)ldx + kh;
+    half8 bfr[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) bfr[ks] = *reinterpret_cast<const half8*>(xr + 16 * ks);
+    float16g c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) c[q][e] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const half8 a = *reinterpret_cast<const half8*>(wl + ((size_t)(q * 8 + ks) * 64 + lane) * 8);
+        c[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfr[ks], c[q], 0, 0, 0);
+      }
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int chl = qq * 32 + 8 * g + 4 * (lane >> 5);
+          half4g o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            o[e] = (_Float16)sigm((float)(_Float16)(c[2 * pr + qq][4 * g + e] + bias[pr * 64 + chl + e]));
+          *reinterpret_cast<half4g*>(tile + (lane & 31) * TS + chl) = o;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const int piece = lane & 7;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int pxr = it * 8 + (lane >> 3);
+        if (b0 + pxr < hw) {
+          const half8 g8 = *reinterpret_cast<const half8*>(tile + pxr * TS + piece * 8);
+          const half8 h8 = *reinterpret_cast<const half8*>(net + (img * hw + b0 + pxr) * (size_t)ldx + pr * 64 + piece * 8);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[k] += (float)(_Float16)((float)g8[k] * (float)h8[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        acc[k] += __shfl_xor(acc[k], 8);
+        acc[k] += __shfl_xor(acc[k], 16);
+        acc[k] += __shfl_xor(acc[k], 32);
+      }
+      if (lane < 8) {
+        float* dst = partial + blk * 128 + pr * 64 + lane * 8;
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 // glo = mean -> the three 1x1 "global context" convolutions (128x128 mat-vecs) of the ConvGRU
 __global__ __launch_bounds__(384) void glo_heads_kernel(const float* __restrict__ partial, int nchunk, float inv_hw,
                                                         const _Float16* __restrict__ wz, const _Float16* __restrict__ wr,
@@ -297,6 +382,38 @@ extern "C" int gs_gru_glo(const void* w_pre, const float* w_bias, const void* ne
   glo_heads_kernel<<<n, 384, 0, st>>>((const float*)workspace, nchunk, 1.0f / (float)hw, (const _Float16*)wz,
                                       (const _Float16*)wr, (const _Float16*)wq, bz, br, bq, gzr, gq);
   GS_CHECK_LAUNCH("gru_glo heads");
+  return GS_OK;
+}
+
+extern "C" size_t gs_gru_glo_fused_workspace_bytes(int n, int hw) {
+  if (n <= 0 || hw <= 0) return 0;
+  return (size_t)n * ((hw + 31) / 32) * 128 * sizeof(float);
+}
+
+// gs_gru_glo with the w convolution inside: w_pack = gs_conv1x1's weight image of gru.w ([4][8][64][8] halves)
+extern "C" int gs_gru_glo_fused(const void* net, int net_stride, const void* w_pack, const float* w_bias, const void* wz,
+                                const void* wr, const void* wq, const float* bz, const float* br, const float* bq,
+                                float* gzr, float* gq, int n, int hw, void* workspace, size_t workspace_bytes,
+                                gs_stream_t stream) {
+  GS_REQUIRE(net && w_pack && w_bias && wz && wr && wq && bz && br && bq && gzr && gq, "gru_glo_fused: null pointer");
+  GS_REQUIRE(n >= 0 && hw > 0 && net_stride >= 128 && net_stride % 8 == 0, "gru_glo_fused: bad shape");
+  GS_REQUIRE((((size_t)net | (size_t)w_pack) & 15) == 0, "gru_glo_fused: net / w_pack must be 16-byte aligned");
+  if (n == 0) return GS_OK;
+  GS_REQUIRE(workspace && workspace_bytes >= gs_gru_glo_fused_workspace_bytes(n, hw), "gru_glo_fused: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int bpi = (hw + 31) / 32;
+  const size_t nblk = (size_t)n * bpi;
+  const size_t lds = (size_t)(4 * 8 * 512 + 4 * 32 * 72) * sizeof(_Float16);      // 32 KB + 18 KB
+  static GsLdsLimit limit;
+  if (int rc = limit.raise((const void*)glo_conv_pool_kernel, lds, "gru_glo_fused")) return rc;
+  size_t grid = 256 * 3;
+  if (grid > (nblk + 3) / 4) grid = (nblk + 3) / 4;
+  glo_conv_pool_kernel<<<(unsigned)grid, 256, lds, st>>>((const _Float16*)net, net_stride, (const _Float16*)w_pack, w_bias,
+                                                         (float*)workspace, hw, bpi, nblk);
+  GS_CHECK_LAUNCH("gru_glo_fused pool");
+  glo_heads_kernel<<<n, 384, 0, st>>>((const float*)workspace, bpi, 1.0f / (float)hw, (const _Float16*)wz,
+                                      (const _Float16*)wr, (const _Float16*)wq, bz, br, bq, gzr, gq);
+  GS_CHECK_LAUNCH("gru_glo_fused heads");
   return GS_OK;
 }
 

@@ -230,6 +230,8 @@ CONV3X3_PP = os.environ.get("GOSLAM_CONV3X3_PP", "1") == "1"
 GRU_FUSED_EPILOGUE = os.environ.get("GOSLAM_GRU_FUSED", "1") == "1"
 # flow_encoder[0] (7x7, 4 -> 128) through gs_conv7x7_c4 (bias + ReLU fused); GOSLAM_CONV7X7=0: MIOpen + bias_act pass
 CONV7X7_OWN = os.environ.get("GOSLAM_CONV7X7", "1") == "1"
+# ConvGRU global context: w(net) + sigmoid + pooling in one kernel (gs_gru_glo_fused); 0: gs_conv1x1 + gs_gru_glo
+GRU_GLO_FUSED = os.environ.get("GOSLAM_GRU_GLO_FUSED", "1") == "1"
 _CONV3X3_PACKS = {}        # (data_ptr, version, shape, device, kc) -> (packed image, weight tensor kept alive)
 _CONV3X3_PACKS_MAX = 32
 
@@ -440,15 +442,23 @@ class ConvGRU(nn.Module):
         with torch.autocast("cuda", enabled=False):
             # gs_conv1x1 (own MFMA kernel; deterministic, one launch) instead of an MIOpen 1x1 convolution, whose
             # solver choice -- and with it the fp16 rounding of the global-context gate -- can change between calls
-            w_pre = torch.empty_like(net)
-            _lib.check(L.gs_conv1x1(_lib.ptr(net), 128, 128, _lib.ptr(self._ww_pack), None, 0, _lib.ptr(w_pre), 128, 128,
-                                    b * hw, st), "conv1x1(gru.w)")
             gzr = torch.empty(b, 256, dtype=torch.float32, device=dev)
             gq = torch.empty(b, 128, dtype=torch.float32, device=dev)
-            ws = torch.empty(L.gs_gru_glo_workspace_bytes(b), dtype=torch.uint8, device=dev)
-            _lib.check(L.gs_gru_glo(_lib.ptr(w_pre), _lib.ptr(bw), _lib.ptr(net), _lib.ptr(gw[0]), _lib.ptr(gw[1]),
-                                    _lib.ptr(gw[2]), _lib.ptr(gw[3]), _lib.ptr(gw[4]), _lib.ptr(gw[5]),
-                                    _lib.ptr(gzr), _lib.ptr(gq), b, hw, _lib.ptr(ws), ws.numel(), st), "gru_glo")
+            if GRU_GLO_FUSED:
+                # w(net), sigmoid, * net and the pooling in one kernel: w_pre never reaches memory
+                ws = torch.empty(L.gs_gru_glo_fused_workspace_bytes(b, hw), dtype=torch.uint8, device=dev)
+                _lib.check(L.gs_gru_glo_fused(_lib.ptr(net), 128, _lib.ptr(self._ww_pack), _lib.ptr(bw), _lib.ptr(gw[0]),
+                                              _lib.ptr(gw[1]), _lib.ptr(gw[2]), _lib.ptr(gw[3]), _lib.ptr(gw[4]),
+                                              _lib.ptr(gw[5]), _lib.ptr(gzr), _lib.ptr(gq), b, hw, _lib.ptr(ws),
+                                              ws.numel(), st), "gru_glo_fused")
+            else:
+                w_pre = torch.empty_like(net)
+                _lib.check(L.gs_conv1x1(_lib.ptr(net), 128, 128, _lib.ptr(self._ww_pack), None, 0, _lib.ptr(w_pre), 128,
+                                        128, b * hw, st), "conv1x1(gru.w)")
+                ws = torch.empty(L.gs_gru_glo_workspace_bytes(b), dtype=torch.uint8, device=dev)
+                _lib.check(L.gs_gru_glo(_lib.ptr(w_pre), _lib.ptr(bw), _lib.ptr(net), _lib.ptr(gw[0]), _lib.ptr(gw[1]),
+                                        _lib.ptr(gw[2]), _lib.ptr(gw[3]), _lib.ptr(gw[4]), _lib.ptr(gw[5]),
+                                        _lib.ptr(gzr), _lib.ptr(gq), b, hw, _lib.ptr(ws), ws.numel(), st), "gru_glo")
             cin = hx.shape[1]
             if GRU_FUSED_EPILOGUE and CONV3X3_PP and _use_own_conv3x3(hx, wzr, 1, 1) and h * w > 0:
                 # gate arithmetic in the convolutions' epilogues: zr_pre / q_pre never reach HBM; hx stays intact

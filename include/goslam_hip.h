@@ -252,6 +252,14 @@ int gs_gru_glo(const void* w_pre, const float* w_bias, const void* net, const vo
                const void* wq, const float* bz, const float* br, const float* bq, float* gzr, float* gq,
                int n, int hw, void* workspace, size_t workspace_bytes, gs_stream_t stream);
 
+/* The same with the 1x1 convolution w(net) inside (MFMA; gru.py:22 `self.w`): w_pre never exists in memory, net is
+ * read once.  net: NHWC fp16 [n,hw,*] with pixels net_stride halves apart (first 128 channels used); w_pack = gs_conv1x1's
+ * weight image of w ([4][8][64][8] halves); the pre-activation is rounded once, fp16(conv + w_bias).  Deterministic.  */
+size_t gs_gru_glo_fused_workspace_bytes(int n, int hw);
+int gs_gru_glo_fused(const void* net, int net_stride, const void* w_pack, const float* w_bias, const void* wz,
+                     const void* wr, const void* wq, const float* bz, const float* br, const float* bq, float* gzr,
+                     float* gq, int n, int hw, void* workspace, size_t workspace_bytes, gs_stream_t stream);
+
 /* DepthVideo.upsample -> cvx_upsample (src/depth_video.py:194-196, src/droid_net.py:9-23):
  * out[ix[n]] (f32 [*,8h,8w]) = convex 8x upsampling of disps[ix[n]] (f32 [*,h,w]) with the softmax
  * of mask f16 [m,576,h,w] (logical NCHW; mask_channels_last != 0: NHWC strides).  ix i64 [m] or

@@ -252,6 +252,26 @@ def test_conv3x3_head_kernel(built_lib, n_out, epi):
     torch.testing.assert_close(got2, ref2.permute(0, 2, 3, 1), rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("k_in,n_out,stride", [(196, 128, 196), (196, 128, 208), (128, 576, 128), (128, 128, 320)])
+def test_conv1x1_kernel_dense_and_strided_rows_many_blocks(built_lib, k_in, n_out, stride):
+    """gs_conv1x1 through the C ABI on 20 x 30 x 40 maps (several 32-pixel blocks per wave of the persistent grid) with
+    dense rows (x_stride == k_in: coalesced loads through the wave stages) and with rows inside a wider tensor
+    (x_stride > k_in: direct fragment loads): same result as an fp32 matmul of the fp16 operands."""
+    from go_slam_amd import _lib
+    from go_slam_amd.droid_net import pack_1x1_weight
+    dev = torch.device("cuda:0")
+    torch.manual_seed(k_in + stride)
+    rows = 20 * 30 * 40 + 13
+    xw = torch.randn(rows, stride, device=dev).half()
+    w = (0.1 * torch.randn(n_out, k_in, 1, 1, device=dev))
+    bias = torch.randn(n_out, device=dev)
+    y = torch.full((rows, n_out), 7.0, device=dev, dtype=torch.float16)
+    _lib.check(_lib.lib().gs_conv1x1(_lib.ptr(xw), stride, k_in, _lib.ptr(pack_1x1_weight(w)), _lib.ptr(bias), 1,
+                                     _lib.ptr(y), n_out, n_out, rows, _lib.stream_ptr(dev)), "conv1x1")
+    ref = torch.relu(xw[:, :k_in].float() @ w.half().float().view(n_out, k_in).t() + bias)
+    torch.testing.assert_close(y.float(), ref, rtol=2e-3, atol=2e-3)
+
+
 @pytest.mark.parametrize("k_in,n_out,act", [(196, 128, "relu"), (128, 576, "none"), (64, 32, "relu")])
 def test_conv1x1_kernel(built_lib, k_in, n_out, act):
     """gs_conv1x1 (MFMA GEMM + fused bias/activation) vs F.conv2d; 196 exercises the ragged last k-step,

@@ -463,6 +463,55 @@ def test_update_operator_with_own_conv7x7_matches_library_path(built_lib):
         assert float(d) <= 2e-2 * max(1.0, float(b.float().abs().max())), float(d)
 
 
+@pytest.mark.parametrize("n,h,w", [(5, 60, 80), (3, 23, 37), (2, 8, 12)])
+def test_gru_global_context_fused_kernel_matches_reference(built_lib, n, h, w):
+    """gs_gru_glo_fused (w(net) on MFMA + sigmoid + * net + pooling in one kernel, then the three glo mat-vecs) vs the
+    same arithmetic in torch with autocast's rounding points (fp16 conv output, fp16 sigmoid, fp16 product, fp32 mean
+    rounded to fp16, fp16 1x1 outputs), and vs the two-kernel path gs_conv1x1 + gs_gru_glo (which rounds the
+    pre-activation twice).  Map sizes incl. one whose pixel count is no multiple of 32; run twice: deterministic."""
+    import go_slam_amd.droid_net as DN
+    from go_slam_amd import _lib
+    dev = "cuda:0"
+    torch.manual_seed(7 * h + w)
+    gru = DN.ConvGRU(128, 320).to(dev).eval()
+    net = (0.7 * torch.randn(n, 128, h, w, device=dev)).half().contiguous(memory_format=torch.channels_last)
+    wzr, wq, bzr, bq, ww, bw, gw = gru._half_weights()
+    L, st = _lib.lib(), _lib.stream_ptr(torch.device(dev))
+    hw = h * w
+
+    def run_fused():
+        gzr = torch.empty(n, 256, dtype=torch.float32, device=dev)
+        gq = torch.empty(n, 128, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.gs_gru_glo_fused_workspace_bytes(n, hw), dtype=torch.uint8, device=dev)
+        _lib.check(L.gs_gru_glo_fused(_lib.ptr(net), 128, _lib.ptr(gru._ww_pack), _lib.ptr(bw), _lib.ptr(gw[0]),
+                                      _lib.ptr(gw[1]), _lib.ptr(gw[2]), _lib.ptr(gw[3]), _lib.ptr(gw[4]), _lib.ptr(gw[5]),
+                                      _lib.ptr(gzr), _lib.ptr(gq), n, hw, _lib.ptr(ws), ws.numel(), st), "glo_fused")
+        return gzr, gq
+
+    gzr, gq = run_fused()
+    gzr2, gq2 = run_fused()
+    assert torch.equal(gzr, gzr2) and torch.equal(gq, gq2)
+    # two-kernel path
+    w_pre = torch.empty_like(net)
+    _lib.check(L.gs_conv1x1(_lib.ptr(net), 128, 128, _lib.ptr(gru._ww_pack), None, 0, _lib.ptr(w_pre), 128, 128, n * hw, st), "c")
+    gzr_b = torch.empty_like(gzr); gq_b = torch.empty_like(gq)
+    ws = torch.empty(L.gs_gru_glo_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    _lib.check(L.gs_gru_glo(_lib.ptr(w_pre), _lib.ptr(bw), _lib.ptr(net), _lib.ptr(gw[0]), _lib.ptr(gw[1]), _lib.ptr(gw[2]),
+                            _lib.ptr(gw[3]), _lib.ptr(gw[4]), _lib.ptr(gw[5]), _lib.ptr(gzr_b), _lib.ptr(gq_b), n, hw,
+                            _lib.ptr(ws), ws.numel(), st), "glo")
+    # torch, autocast's rounding points
+    x = net.float().permute(0, 2, 3, 1).reshape(n, hw, 128)
+    pre = (x @ gru.w.weight.detach().half().float().view(128, 128).t() + gru.w.bias.detach().float()).half()
+    g = torch.sigmoid(pre.float()).half()
+    glo = (g.float() * x).half().float().mean(1).half().float()                         # [n,128]
+    def head(conv):
+        return (glo @ conv.weight.detach().half().float().view(128, 128).t() + conv.bias.detach().float()).half().float()
+    ref_zr = torch.cat([head(gru.convz_glo), head(gru.convr_glo)], 1)
+    ref_q = head(gru.convq_glo)
+    for got, ref in ((gzr, ref_zr), (gq, ref_q), (gzr_b, ref_zr), (gq_b, ref_q)):
+        assert float((got - ref).abs().max()) <= 2e-3, float((got - ref).abs().max())
+
+
 def _golden(name):
     import numpy as np
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
