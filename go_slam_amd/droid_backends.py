@@ -9,6 +9,8 @@ Error behaviour mirrors `CHECK_CONTIGUOUS` (droid.cpp:84-85): a non-contiguous t
 RuntimeError("<name> must be contiguous").  Unlike the reference (legacy default stream) the
 kernels are enqueued on torch's *current* stream of the tensors' device.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -16,6 +18,10 @@ from . import _lib
 _DT = {torch.float16: 0, torch.float32: 1, torch.float64: 2}
 
 _ws_cache = {}
+_ba_status = {}            # device index -> int32[4] status of the last ba() enqueued there (still on the device)
+# GOSLAM_BA_CHECK=1: read the status word back after every ba() (one host sync per call) and raise on a depth-row
+# mismatch, as the reference's shape errors would; off by default -- ba_status() reads it on demand.
+BA_CHECK = os.environ.get("GOSLAM_BA_CHECK", "0") == "1"
 
 
 def _chk(name, t, dtype=None):
@@ -63,15 +69,37 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
     need = L.gs_ba_workspace_bytes(E, P, M, nbuf, hw)
     ws = _workspace(dev, need + 256)
     dx = torch.empty(P, 6, dtype=torch.float32, device=dev)
-    dz = None if motion_only else torch.empty(M, hw, dtype=torch.float32, device=dev)
+    # zeros: depth rows the kernels skip (only when `eta` has more rows than the graph has depth keyframes, status [1])
+    # must not hand uninitialised memory to the caller
+    dz = None if motion_only else torch.zeros(M, hw, dtype=torch.float32, device=dev)
+    status = _ba_status.get(dev.index)
+    if status is None:
+        status = _ba_status[dev.index] = torch.zeros(4, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         rc = L.gs_ba(_lib.ptr(poses), _lib.ptr(disps), _lib.ptr(intrinsics), _lib.ptr(disps_sens),
                      _lib.ptr(targets), _lib.ptr(weights), _lib.ptr(eta), _lib.ptr(ii), _lib.ptr(jj),
                      int(t0), int(t1), int(iterations), float(lm), float(ep), int(bool(motion_only)),
-                     E, M, nbuf, ht, wd, _lib.ptr(dx), _lib.ptr(dz), None,
+                     E, M, nbuf, ht, wd, _lib.ptr(dx), _lib.ptr(dz), _lib.ptr(status),
                      _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "droid_backends.ba")
+    if BA_CHECK:
+        st = ba_status(dev)
+        if st["depth_rows_mismatch"]:
+            raise RuntimeError(f"droid_backends.ba: eta has {M} rows but the graph has {st['depth_keyframes']} depth "
+                               "keyframes (unique(arange(t0, t1) U ii))")
     return [dx, dz]
+
+
+def ba_status(device=None):
+    """Status of the last ba() enqueued on `device` (synchronises): number of depth keyframes the kernels found, whether
+    that differed from eta's row count (rows beyond it were skipped / dz left zero), Cholesky failures (dx = 0 for those
+    iterations, as the reference does).  None if ba() has not run there."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    status = _ba_status.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    if status is None:
+        return None
+    s = status.tolist()
+    return {"depth_keyframes": s[0], "depth_rows_mismatch": bool(s[1]), "cholesky_failures": s[2]}
 
 
 def frame_distance(poses, disps, intrinsics, ii, jj, beta):

@@ -264,6 +264,34 @@ def test_ba_cholesky_failure_gives_zero_update(db, dev):
     assert torch.equal(pg.cpu(), prob["poses"])
 
 
+def test_ba_status_word_reports_failures_and_depth_row_mismatch(db, dev):
+    """droid_backends.ba_status(): Cholesky failures are counted; an `eta` with more rows than the graph has depth
+    keyframes is flagged and the surplus rows of dz come back ZERO (not uninitialised); GOSLAM_BA_CHECK raises."""
+    from oracle import droid_oracle as O
+    prob = _ba_problem(O, 6, 14, "tiny", seed=29)
+    K = prob["intrinsics"][0].contiguous().to(dev)
+    args = lambda eta: (prob["poses"].clone().to(dev), prob["disps"].clone().to(dev), K, prob["disps_sens"].to(dev),
+                        prob["target"].to(dev), prob["weight"].to(dev), eta.to(dev), prob["ii"].to(dev),
+                        prob["jj"].to(dev), 1, 6)
+    db.ba(*args(prob["eta"]), 2, 1e-4, 0.1, False)
+    st = db.ba_status(dev)
+    assert st == {"depth_keyframes": prob["eta"].shape[0], "depth_rows_mismatch": False, "cholesky_failures": 0}
+    db.ba(*args(prob["eta"]), 1, -2.0, -1.0, True)                     # indefinite system
+    assert db.ba_status(dev)["cholesky_failures"] == 1
+    eta_big = torch.cat([prob["eta"], prob["eta"][:2]], 0).contiguous()
+    dx, dz = db.ba(*args(eta_big), 1, 1e-4, 0.1, False)
+    st = db.ba_status(dev)
+    assert st["depth_rows_mismatch"] and st["depth_keyframes"] == prob["eta"].shape[0]
+    assert torch.count_nonzero(dz[prob["eta"].shape[0]:]) == 0 and torch.isfinite(dz).all()
+    keep = db.BA_CHECK
+    try:
+        db.BA_CHECK = True
+        with pytest.raises(RuntimeError, match="depth keyframes"):
+            db.ba(*args(eta_big), 1, 1e-4, 0.1, False)
+    finally:
+        db.BA_CHECK = keep
+
+
 def test_ba_rejects_non_contiguous(db, dev):
     from oracle import droid_oracle as O
     prob = _ba_problem(O, 6, 14, "tiny", seed=31)
