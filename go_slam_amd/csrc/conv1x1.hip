@@ -64,6 +64,10 @@ __global__ __launch_bounds__(C1_THREADS) void conv1x1_kernel(const _Float16* __r
   const int SS = c1_stage_stride(K);          // stage row stride in halves
   const int wave_lds = staged ? (32 * SS > 32 * TS ? 32 * SS : 32 * TS) : 32 * TS;
   _Float16* tile = wl + (size_t)NBS * KS * 512 + (size_t)wv * wave_lds;     // stage and transpose tile share it
+  // this slice's bias in LDS (per-lane global loads of it inside the block loop cost a memory round trip per use)
+  float* sbias = reinterpret_cast<float*>(wl + (size_t)NBS * KS * 512 + (size_t)C1_WAVES * wave_lds);
+  for (int i = tid; i < NB * 32; i += C1_THREADS) sbias[i] = bias ? bias[nbase * 32 + i] : 0.0f;
+  __syncthreads();
   const int kh = 8 * (lane >> 5);
   const size_t nblk = (rows + 31) / 32;
   const int U = K >> 2;                       // 8-byte units per row
@@ -174,11 +178,10 @@ __global__ __launch_bounds__(C1_THREADS) void conv1x1_kernel(const _Float16* __r
 #pragma unroll
           for (int g = 0; g < 4; ++g) {               // 4 consecutive channels per register group
             const int chl = qq * 32 + 8 * g + 4 * (lane >> 5);
-            const int ch = (nbase + nbp) * 32 + chl;
             half4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              float f = c[q][4 * g + e] + (bias ? bias[ch + e] : 0.0f);
+              float f = c[q][4 * g + e] + sbias[nbp * 32 + chl + e];
               if (act == 1) f = fmaxf(f, 0.0f);
               o[e] = (_Float16)f;
             }
@@ -217,10 +220,10 @@ int launch1x1(const void* x, int ldx, int K, const void* wpack, const float* bia
   int staged = (ldx == K && ((size_t)x & 15) == 0) ? 1 : 0;
   size_t wave_lds = 32 * 72;
   if (staged && (size_t)32 * c1_stage_stride(K) > wave_lds) wave_lds = (size_t)32 * c1_stage_stride(K);
-  size_t lds = (size_t)NBS * KS * 1024 + C1_WAVES * wave_lds * sizeof(_Float16);
+  size_t lds = (size_t)NBS * KS * 1024 + C1_WAVES * wave_lds * sizeof(_Float16) + (size_t)NBS * 32 * sizeof(float);
   if (lds > 160 * 1024) {                       // cannot happen for the update operator's layers; keep the direct loads
     staged = 0;
-    lds = (size_t)NBS * KS * 1024 + C1_WAVES * 32 * 72 * sizeof(_Float16);
+    lds = (size_t)NBS * KS * 1024 + C1_WAVES * 32 * 72 * sizeof(_Float16) + (size_t)NBS * 32 * sizeof(float);
   }
   GS_REQUIRE(lds <= 160 * 1024, "conv1x1: %d x %d weights need %zu bytes of LDS", N, K, lds);
   static GsLdsLimit limit;

@@ -163,17 +163,15 @@ extern "C" int gs_conv7x7_c4(const void* x, const void* wpack, const float* bias
   GS_REQUIRE(ys >= 128 && ys % 8 == 0 && ((size_t)y & 15) == 0 && ((size_t)x & 7) == 0 && ((size_t)wpack & 15) == 0,
              "conv7x7_c4: output rows must be 16-byte aligned, >= 128 halves");
   if (rt <= 0) {
-    // rows per strip: ~512 pixels of work per workgroup, least row padding among the candidates around that
-    int want = (512 + w - 1) / w;
-    if (want < 1) want = 1;
-    if (want > h) want = h;
-    int best = want; long long best_cost = -1;
-    for (int c = want > 2 ? want - 2 : 1; c <= want + 2 && c <= h; ++c) {
-      const long long padded = (long long)((h + c - 1) / c) * c;          // rows computed incl. the last strip's padding
-      const long long cost = padded * 1000 / h * (c + 6) / c;              // x patch-halo overhead
-      if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = c; }
-    }
-    rt = best;
+    // rows per strip: one round of workgroups (2 per CU x 256 CUs) covers the launch when it can -- measured best at
+    // all three map sizes (75 edges: 60 x 80 -> 10 rows, 85 x 150 -> 15, 48 x 64 -> 8) -- with at least ~256 pixels each
+    const int slots = 512;
+    const int per_image = n >= slots ? 1 : slots / n;
+    rt = (h + per_image - 1) / per_image;
+    const int min_rows = (256 + w - 1) / w;
+    if (rt < min_rows) rt = min_rows;
+    if (rt > h) rt = h;
+    while (rt > 1 && (size_t)(rt + 6) * (w + 8) * 8 > 96 * 1024) rt = (rt + 1) / 2;
   }
   if (rt > h) rt = h;
   const size_t lds = (size_t)(rt + 6) * (w + 8) * 8 + 128 * 4 + (size_t)4 * 32 * kScratchRow * 2;

@@ -234,7 +234,11 @@ __global__ __launch_bounds__(256) void glo_conv_pool_kernel(const _Float16* __re
   __syncthreads();
   constexpr int TS = 72;
   _Float16* tile = wl + 4 * 8 * 512 + wv * 32 * TS;
+  float* sbias = reinterpret_cast<float*>(wl + 4 * 8 * 512 + 4 * 32 * TS);      // [128]: per-lane global loads of the
+  if (tid < 128) sbias[tid] = bias[tid];                                        // bias inside the block loop cost a
+  __syncthreads();                                                              // memory round trip per use
   const int kh = 8 * (lane >> 5);
+  const int piece = lane & 7;
   for (size_t blk = (size_t)blockIdx.x * 4 + wv; blk < nblk; blk += (size_t)gridDim.x * 4) {
     const size_t img = blk / bpi;
     const int b0 = (int)(blk - img * bpi) * 32;
@@ -243,6 +247,15 @@ __global__ __launch_bounds__(256) void glo_conv_pool_kernel(const _Float16* __re
     half8 bfr[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) bfr[ks] = *reinterpret_cast<const half8*>(xr + 16 * ks);
+    // the same rows again in row layout for the epilogue's product (L1 / L2 hits), requested now, used after the MFMAs
+    half8 hrow[2][4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int pxr = b0 + it * 8 + (lane >> 3);
+      const _Float16* hr = net + (img * hw + (pxr < hw ? pxr : hw - 1)) * (size_t)ldx + piece * 8;
+      hrow[0][it] = *reinterpret_cast<const half8*>(hr);
+      hrow[1][it] = *reinterpret_cast<const half8*>(hr + 64);
+    }
     float16g c[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -265,23 +278,21 @@ __global__ __launch_bounds__(256) void glo_conv_pool_kernel(const _Float16* __re
           half4g o;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            o[e] = (_Float16)sigm((float)(_Float16)(c[2 * pr + qq][4 * g + e] + bias[pr * 64 + chl + e]));
+            o[e] = (_Float16)sigm((float)(_Float16)(c[2 * pr + qq][4 * g + e] + sbias[pr * 64 + chl + e]));
           *reinterpret_cast<half4g*>(tile + (lane & 31) * TS + chl) = o;
         }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const int piece = lane & 7;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int pxr = it * 8 + (lane >> 3);
-        if (b0 + pxr < hw) {
-          const half8 g8 = *reinterpret_cast<const half8*>(tile + pxr * TS + piece * 8);
-          const half8 h8 = *reinterpret_cast<const half8*>(net + (img * hw + b0 + pxr) * (size_t)ldx + pr * 64 + piece * 8);
+        const half8 g8 = *reinterpret_cast<const half8*>(tile + pxr * TS + piece * 8);
+        const half8 h8 = hrow[pr][it];
+        const float live = (b0 + pxr < hw) ? 1.0f : 0.0f;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) acc[k] += (float)(_Float16)((float)g8[k] * (float)h8[k]);
-        }
+        for (int k = 0; k < 8; ++k) acc[k] += live * (float)(_Float16)((float)g8[k] * (float)h8[k]);
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -308,11 +319,16 @@ __global__ __launch_bounds__(384) void glo_heads_kernel(const float* __restrict_
                                                         float* __restrict__ gzr, float* __restrict__ gq) {
   const int n = blockIdx.x, t = threadIdx.x;
   __shared__ float g[128];
-  if (t < 128) {
+  __shared__ float part3[3][128];
+  {
+    // 384 threads: thread (third, channel) sums every third chunk; thirds combined in a fixed order
+    const int third = t >> 7, ch = t & 127;
     float s = 0.0f;
-    for (int c = 0; c < nchunk; ++c) s += partial[((size_t)n * nchunk + c) * 128 + t];
-    g[t] = (float)(_Float16)(s * inv_hw);
+    for (int c = third; c < nchunk; c += 3) s += partial[((size_t)n * nchunk + c) * 128 + ch];
+    part3[third][ch] = s;
   }
+  __syncthreads();
+  if (t < 128) g[t] = (float)(_Float16)(((part3[0][t] + part3[1][t]) + part3[2][t]) * inv_hw);
   __syncthreads();
   const int head = t >> 7, o = t & 127;
   const _Float16* w = (head == 0 ? wz : head == 1 ? wr : wq) + (size_t)o * 128;
@@ -403,7 +419,7 @@ extern "C" int gs_gru_glo_fused(const void* net, int net_stride, const void* w_p
   hipStream_t st = (hipStream_t)stream;
   const int bpi = (hw + 31) / 32;
   const size_t nblk = (size_t)n * bpi;
-  const size_t lds = (size_t)(4 * 8 * 512 + 4 * 32 * 72) * sizeof(_Float16);      // 32 KB + 18 KB
+  const size_t lds = (size_t)(4 * 8 * 512 + 4 * 32 * 72) * sizeof(_Float16) + 128 * sizeof(float);   // 32 + 18 + 0.5 KB
   static GsLdsLimit limit;
   if (int rc = limit.raise((const void*)glo_conv_pool_kernel, lds, "gru_glo_fused")) return rc;
   size_t grid = 256 * 3;

@@ -265,24 +265,31 @@ def test_ba_cholesky_failure_gives_zero_update(db, dev):
 
 
 def test_ba_status_word_reports_failures_and_depth_row_mismatch(db, dev):
-    """droid_backends.ba_status(): Cholesky failures are counted; an `eta` with more rows than the graph has depth
-    keyframes is flagged and the surplus rows of dz come back ZERO (not uninitialised); GOSLAM_BA_CHECK raises."""
+    """droid_backends.ba_status(): Cholesky failures are counted; an `eta` whose row count differs from the number of
+    depth keyframes of the graph is flagged -- surplus rows of dz come back ZERO (not uninitialised), missing rows are
+    dropped -- and GOSLAM_BA_CHECK turns the flag into the shape error the reference would raise."""
     from oracle import droid_oracle as O
     prob = _ba_problem(O, 6, 14, "tiny", seed=29)
     K = prob["intrinsics"][0].contiguous().to(dev)
-    args = lambda eta: (prob["poses"].clone().to(dev), prob["disps"].clone().to(dev), K, prob["disps_sens"].to(dev),
-                        prob["target"].to(dev), prob["weight"].to(dev), eta.to(dev), prob["ii"].to(dev),
-                        prob["jj"].to(dev), 1, 6)
+    pad = lambda x: torch.cat([x, x[-2:]], 0).contiguous()              # two frames no edge refers to (nbuf = 8)
+
+    def args(eta):
+        return (pad(prob["poses"]).to(dev), pad(prob["disps"]).to(dev), K, pad(prob["disps_sens"]).to(dev),
+                prob["target"].to(dev), prob["weight"].to(dev), eta.to(dev), prob["ii"].to(dev), prob["jj"].to(dev), 1, 6)
+
+    M = prob["eta"].shape[0]
     db.ba(*args(prob["eta"]), 2, 1e-4, 0.1, False)
-    st = db.ba_status(dev)
-    assert st == {"depth_keyframes": prob["eta"].shape[0], "depth_rows_mismatch": False, "cholesky_failures": 0}
-    db.ba(*args(prob["eta"]), 1, -2.0, -1.0, True)                     # indefinite system
+    assert db.ba_status(dev) == {"depth_keyframes": M, "depth_rows_mismatch": False, "cholesky_failures": 0}
+    db.ba(*args(prob["eta"]), 1, -2.0, -1.0, True)                      # indefinite system
     assert db.ba_status(dev)["cholesky_failures"] == 1
     eta_big = torch.cat([prob["eta"], prob["eta"][:2]], 0).contiguous()
     dx, dz = db.ba(*args(eta_big), 1, 1e-4, 0.1, False)
     st = db.ba_status(dev)
-    assert st["depth_rows_mismatch"] and st["depth_keyframes"] == prob["eta"].shape[0]
-    assert torch.count_nonzero(dz[prob["eta"].shape[0]:]) == 0 and torch.isfinite(dz).all()
+    assert st["depth_rows_mismatch"] and st["depth_keyframes"] == M
+    assert dz.shape[0] == M + 2 and torch.count_nonzero(dz[M:]) == 0 and torch.isfinite(dz).all()
+    assert torch.count_nonzero(dz[:M]) > 0
+    db.ba(*args(prob["eta"][:-1].contiguous()), 1, 1e-4, 0.1, False)    # too few rows
+    assert db.ba_status(dev)["depth_rows_mismatch"]
     keep = db.BA_CHECK
     try:
         db.BA_CHECK = True
