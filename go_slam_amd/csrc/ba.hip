@@ -333,17 +333,16 @@ __global__ __launch_bounds__(256) void ba_accum_kernel(
     const bool j_in = (pj_ >= 0) && (pj_ < P);
     if (i_in || j_in) {   // uniform across the workgroup
       const int wave = tid >> 6, lane = tid & 63;
+      // 78 + 6 + 6 sums per wave: one reduce-scatter (~90 lane exchanges) instead of 90 butterflies (~1000 instructions)
+      float rs[90];
 #pragma unroll
-      for (int l = 0; l < 78; ++l) {
-        const float s = gs_wave_sum(hij[l]);
-        if (lane == 0) red[wave][l] = s;
-      }
+      for (int l = 0; l < 78; ++l) rs[l] = hij[l];
 #pragma unroll
-      for (int n = 0; n < 6; ++n) {
-        const float s0 = gs_wave_sum(vi[n]);
-        const float s1 = gs_wave_sum(vj[n]);
-        if (lane == 0) { red[wave][78 + n] = s0; red[wave][84 + n] = s1; }
-      }
+      for (int n = 0; n < 6; ++n) { rs[78 + n] = vi[n]; rs[84 + n] = vj[n]; }
+      gs_wave_reduce_scatter<90>(rs, lane);
+      const int ix = gs_bitrev6(lane);
+      red[wave][ix] = rs[0];
+      if (64 + ix < 90) red[wave][64 + ix] = rs[1];
       __syncthreads();
       if (tid < 90) {
         const double s = (double)((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
@@ -439,17 +438,15 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(int M, int hw, int P, BaW
         for (int n = 0; n < 6; ++n) vv[n] = fmaf(ea[n], ww, vv[n]);
       }
     }
+    {
+      float rs[42];                                     // 36 + 6 sums: one reduce-scatter per wave
 #pragma unroll
-    for (int i = 0; i < 36; ++i) {
-      const float s = gs_wave_sum(S[i]);
-      if (lane == 0) red[wave][i] = s;
-    }
-    if (diag) {
+      for (int i = 0; i < 36; ++i) rs[i] = S[i];
 #pragma unroll
-      for (int n = 0; n < 6; ++n) {
-        const float s = gs_wave_sum(vv[n]);
-        if (lane == 0) red[wave][36 + n] = s;
-      }
+      for (int n = 0; n < 6; ++n) rs[36 + n] = vv[n];
+      gs_wave_reduce_scatter<42>(rs, lane);
+      const int ix = gs_bitrev6(lane);
+      if (ix < 42) red[wave][ix] = rs[0];
     }
     __syncthreads();
     if (tid < 36) {

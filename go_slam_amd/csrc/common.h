@@ -191,6 +191,36 @@ __device__ __forceinline__ float gs_wave_sum(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// Sums of N per-lane values over the wave, "reduce-scatter" form: instead of N full butterflies (gs_wave_sum: 11
+// instructions per value) the value array is halved at every lane-bit step -- a lane keeps the even or the odd element of
+// each pair and sends the other one to its partner -- so N values cost ~N exchanges in all.  On return lane L holds, in
+// v[j], the wave total of value index 64 j + bitrev6(L) (j < ceil(N / 64); indices >= N are padding).  Fixed order =>
+// deterministic.
+template <int N, int MASK>
+__device__ __forceinline__ void gs_rs_step(float* v, int lane) {
+  constexpr int NN = (N + 1) / 2;
+  const bool up = (lane & MASK) != 0;
+#pragma unroll
+  for (int i = 0; i < NN; ++i) {
+    const float a = v[2 * i];
+    const float b = (2 * i + 1 < N) ? v[2 * i + 1] : 0.0f;
+    const float send = up ? a : b;
+    const float keep = up ? b : a;
+    v[i] = keep + __shfl_xor(send, MASK, 64);
+  }
+}
+template <int N>
+__device__ __forceinline__ void gs_wave_reduce_scatter(float (&v)[N], int lane) {
+  constexpr int n1 = (N + 1) / 2, n2 = (n1 + 1) / 2, n3 = (n2 + 1) / 2, n4 = (n3 + 1) / 2, n5 = (n4 + 1) / 2;
+  gs_rs_step<N, 32>(v, lane);
+  gs_rs_step<n1, 16>(v, lane);
+  gs_rs_step<n2, 8>(v, lane);
+  gs_rs_step<n3, 4>(v, lane);
+  gs_rs_step<n4, 2>(v, lane);
+  gs_rs_step<n5, 1>(v, lane);
+}
+__device__ __forceinline__ int gs_bitrev6(int lane) { return (int)(__brev((unsigned)lane) >> 26); }
+
 __device__ __forceinline__ double gs_wave_sum_f64(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
