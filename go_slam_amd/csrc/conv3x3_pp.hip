@@ -26,15 +26,16 @@
 //    ds_read_b128 service group = 16 consecutive pixels of one patch row, conv3x3_common.h) every B-fragment read is
 //    bank-conflict-free; weight planes [8-channel group][128 channels][8] are conflict-free as they are.
 //  * LDS: 2 x 40 KB patch + 4 x 8 KB weights = 112 KB (TW = 16); one workgroup per CU, 2 waves per SIMD.
+//  * BN = 64 instantiation (flow_encoder[2], 128 -> 64 channels): the same schedule with ONE 32-channel fragment per wave
+//    (a wave owns 128 pixels x 32 channels: 8 MFMAs per phase against 10 fragment reads, so it is bound by the READ
+//    phase, not the matrix pipe); a tap's weight image is 4 KB = one piece per thread of waves 0-3, waves 4-7 issue a
+//    dummy 16-byte DMA from the zero page so that every wave's vmcnt arithmetic stays the same.
 #include "common.h"
 #include "conv3x3_common.h"
 
 namespace {
 
-constexpr int PP_BN = 128;          // output channels per workgroup
 constexpr int PP_KG = 4;            // 8-channel groups per 32-channel chunk
-constexpr int PP_WTAP = PP_KG * PP_BN;   // 16-byte slots of one tap's weight image (= 512 = one per thread)
-constexpr int PP_TS = 72;           // epilogue tile row stride in halves
 
 __device__ __attribute__((aligned(16))) const uint32_t pp_zero_page[4] = {0u, 0u, 0u, 0u};
 
@@ -87,25 +88,31 @@ __device__ __forceinline__ void pp_stamp(long long* dbg, int slot) {
 
 __device__ __forceinline__ float pp_sigm(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
-template <int TW, int EPI>
+template <int TW, int EPI, int BN = 128>
 __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __restrict__ x, int xs, int C,
                                                             const half8* __restrict__ wpack, _Float16* __restrict__ y,
                                                             int ys, int H, int W, int rows, int tiles_x, int NB,
                                                             int xcd, PpEpi ep) {
+  static_assert(BN == 128 || (BN == 64 && (EPI == 0 || EPI == 3)), "64-channel workgroups: plain / bias + ReLU only");
+  constexpr int PP_BN = BN;                               // output channels per workgroup
+  constexpr int PP_WTAP = PP_KG * PP_BN;                  // 16-byte slots of one tap's weight image (512 or 256)
+  constexpr int NJ = BN / 64;                             // 32-channel fragments per wave
+  constexpr int PP_TS = NJ == 2 ? 72 : 40;                // epilogue tile row stride in halves (16-byte aligned rows)
   constexpr int TH_ = 512 / TW, PW_ = TW + 2, NPX = (TH_ + 2) * PW_;
   constexpr int NROUND = (NPX * PP_KG + 511) / 512;       // DMA rounds (512 slots each) per patch
   constexpr int PSLOTS = NROUND * 512;                    // slots of a patch buffer; [NPX * 4, PSLOTS) hold zeros
   constexpr int ZSLOT = NPX * PP_KG;                      // a slot that always reads as zero
   static_assert(PSLOTS > NPX * PP_KG, "the patch buffer needs at least one padding (zero) slot");
   static_assert(NROUND <= 9, "one DMA round per tap");
-  extern __shared__ half8 smem[];                         // patch [2][PSLOTS] | weights [4][PP_WTAP]
+  extern __shared__ half8 smem[];                         // patch [2][PSLOTS] | weights [4][PP_WTAP] (| 256 dummy slots)
   half8* const pbuf = smem;
   half8* const wbuf = smem + 2 * PSLOTS;
+  half8* const wjunk = wbuf + 4 * PP_WTAP;                // BN = 64 only: target of waves 4-7's dummy weight DMA
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp2 = wv >> 2;                               // 0: leading group, 1: one phase behind
   const int wm = (wv & 1) + 2 * grp2;                     // pixel quarter of the 512-pixel tile
-  const int wn = (wv >> 1) & 1;                           // channel half (64 of 128)
+  const int wn = (wv >> 1) & 1;                           // channel half (64 of 128, or 32 of 64)
   const int r = lane & 31, kgl = lane >> 5;
   int tix, nb;
   decode_block(blockIdx.x, gridDim.x / NB, NB, xcd, tix, nb);
@@ -142,14 +149,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
     poff[q] = off;
   }
 
-  float16v acc[2][4];
+  float16v acc[NJ][4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.0f;
-  half8 a[2][2], b[2][4];
+  half8 a[2][NJ], b[2][4];
 
   // ---- the three building blocks --------------------------------------------------------------------------------
   auto issue_patch = [&](int src_chunk, int buf, int q, int off) {        // one 512-slot round of a patch
@@ -165,7 +172,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
     pp_glds16(src, pbuf + buf * PSLOTS + q * 512 + wv * 64);
   };
   auto issue_w = [&](int src_tap, int buf) {                              // one tap's weight image
-    pp_glds16(wsrc + (size_t)src_tap * PP_WTAP + tid, wbuf + buf * PP_WTAP + wv * 64);
+    if constexpr (BN == 128) {
+      pp_glds16(wsrc + (size_t)src_tap * PP_WTAP + tid, wbuf + buf * PP_WTAP + wv * 64);
+    } else {                                                              // 256 pieces: waves 0-3; 4-7 keep vmcnt in step
+      if (wv < 4) pp_glds16(wsrc + (size_t)src_tap * PP_WTAP + tid, wbuf + buf * PP_WTAP + wv * 64);
+      else pp_glds16((const void*)pp_zero_page, wjunk + (wv - 4) * 64);
+    }
   };
   auto read_frags = [&](int pbuf_ix, int wbuf_ix, int tap) {              // READ phase body: 4 A + 8 B fragments
     const half8* wb = wbuf + wbuf_ix * PP_WTAP;
@@ -174,8 +186,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int kg = 2 * s + kgl;
-      a[s][0] = wb[kg * PP_BN + wn * 64 + r];
-      a[s][1] = wb[kg * PP_BN + wn * 64 + 32 + r];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) a[s][j] = wb[kg * PP_BN + wn * (PP_BN / 2) + 32 * j + r];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -198,23 +210,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
   auto math = [&](auto&& between) {
     if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b[0][i], acc[0][i], 0, 0, 0);
-      acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][1], b[0][i], acc[1][i], 0, 0, 0);
-    }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][j], b[0][i], acc[j][i], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     between();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 2; i < 4; ++i) {
-      acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b[0][i], acc[0][i], 0, 0, 0);
-      acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][1], b[0][i], acc[1][i], 0, 0, 0);
-    }
+    for (int i = 2; i < 4; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], b[1][i], acc[0][i], 0, 0, 0);
-      acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][1], b[1][i], acc[1][i], 0, 0, 0);
-    }
+      for (int j = 0; j < NJ; ++j)
+        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][j], b[0][i], acc[j][i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][j], b[1][i], acc[j][i], 0, 0, 0);
     if (prio) __builtin_amdgcn_s_setprio(0);
   };
 
@@ -266,19 +278,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
 
   // ---- epilogue: [32 pixels][64 channels] at a time through a wave-private LDS tile (aliases patch buffer 0)
   _Float16* tile = reinterpret_cast<_Float16*>(smem) + wv * 32 * PP_TS;
-  _Float16* yb = y + nb * PP_BN + wn * 64;
+  _Float16* yb = y + nb * PP_BN + wn * (PP_BN / 2);
+  constexpr int PIECES = NJ * 4;                          // 16-byte pieces per pixel row of this wave's channels (8 / 4)
+  constexpr int PXIT = 64 / PIECES;                       // pixels covered per store round (8 / 16)
+  constexpr int NIT = 32 / PXIT;                          // store rounds per 32-pixel fragment (4 / 2)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     // (1) where this lane's four output pieces go, and -- for the gate epilogues -- their operands, requested NOW so
     //     that the loads are in flight while the accumulators are transposed through LDS
-    size_t pix4[4];
-    bool ok4[4];
-    half8 pi4[4], u4[4], v4[4];
-    const int piece = lane & 7;
-    const int c8 = wn * 64 + piece * 8;                     // first of this lane's 8 channels inside the 128-block
+    size_t pix4[NIT];
+    bool ok4[NIT];
+    half8 pi4[NIT], u4[NIT], v4[NIT];
+    const int piece = lane & (PIECES - 1);
+    const int c8 = wn * (PP_BN / 2) + piece * 8;            // first of this lane's 8 channels inside the channel block
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int pxr = it * 8 + (lane >> 3);
+    for (int it = 0; it < NIT; ++it) {
+      const int pxr = it * PXIT + lane / PIECES;
       int ty, tx;
       tile_pixel<TW, true>(wm, i, pxr, ty, tx);
       const int gv = g0 + ty, gx = tx0 + tx;
@@ -299,9 +314,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
         }
       }
     }
-    // (2) accumulators -> [32 pixels][64 channels] fp16 tile
+    // (2) accumulators -> [32 pixels][64 (32) channels] fp16 tile
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {                       // C layout: row (channel) = 8 g + 4 (lane >> 5) + e, col = pixel
         half4 o;
@@ -312,10 +327,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // (3) rows of 64 channels leave as 128 contiguous bytes per pixel
+    // (3) rows of 64 (32) channels leave as 128 (64) contiguous bytes per pixel
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int pxr = it * 8 + (lane >> 3);
+    for (int it = 0; it < NIT; ++it) {
+      const int pxr = it * PXIT + lane / PIECES;
       if (ok4[it]) {
         const half8 v = *reinterpret_cast<const half8*>(tile + pxr * PP_TS + piece * 8);
         const size_t pix = pix4[it];
@@ -367,33 +382,37 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
   pp_stamp(ep.dbg, 3);
 }
 
-template <int TW, int EPI>
+template <int TW, int EPI, int BN = 128>
 int launch_pp(const void* x, int x_stride, int c_in, const void* wpack, void* y, int y_stride, int n_out, int n, int h,
               int w, int xcd, hipStream_t st, PpEpi ep = PpEpi()) {
+  constexpr int PP_BN = BN, PP_WTAP = PP_KG * BN;
   constexpr int NPX = (512 / TW + 2) * (TW + 2);
   constexpr int PSLOTS = ((NPX * PP_KG + 511) / 512) * 512;
-  constexpr size_t lds = (size_t)(2 * PSLOTS + 4 * PP_WTAP) * sizeof(half8);
+  constexpr size_t lds = (size_t)(2 * PSLOTS + 4 * PP_WTAP + (BN == 64 ? 256 : 0)) * sizeof(half8);
   static GsLdsLimit limit;
-  if (int rc = limit.raise((const void*)conv3x3_pp_kernel<TW, EPI>, lds, "conv3x3_pp")) return rc;
+  if (int rc = limit.raise((const void*)conv3x3_pp_kernel<TW, EPI, BN>, lds, "conv3x3_pp")) return rc;
   const long long rows = (long long)n * h;
   GS_REQUIRE(rows * w < (1ll << 29), "conv3x3_pp: too many pixels");
   const int tiles_x = gs_cdiv(w, TW), tiles_y = gs_cdiv((int)rows, 512 / TW);
   const int NB = n_out / PP_BN;
   const long long blocks = (long long)tiles_x * tiles_y * NB;
   GS_REQUIRE(blocks < (1ll << 31), "conv3x3_pp: too many workgroups");
-  conv3x3_pp_kernel<TW, EPI><<<dim3((unsigned)blocks), 512, lds, st>>>(
+  conv3x3_pp_kernel<TW, EPI, BN><<<dim3((unsigned)blocks), 512, lds, st>>>(
       (const _Float16*)x, x_stride, c_in, (const half8*)wpack, (_Float16*)y, y_stride, h, w, (int)rows, tiles_x, NB, xcd,
       ep);
   GS_CHECK_LAUNCH("conv3x3_pp");
   return GS_OK;
 }
 
-template <int EPI>
+template <int EPI, int BN = 128>
 int dispatch_pp(const void* x, int x_stride, int c_in, const void* wpack, int tw, void* y, int y_stride, int n_out, int n,
                 int h, int w, int xcd, hipStream_t st, PpEpi ep = PpEpi()) {
-  if (tw == 8) return launch_pp<8, EPI>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, xcd, st, ep);
-  return launch_pp<16, EPI>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, xcd, st, ep);
+  if (tw == 8) return launch_pp<8, EPI, BN>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, xcd, st, ep);
+  return launch_pp<16, EPI, BN>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, xcd, st, ep);
 }
+
+// output channels per workgroup for a layer: 128, or 64 when n_out is only a multiple of 64 (the weight image follows)
+int pp_block_channels(int n_out) { return n_out % 128 == 0 ? 128 : 64; }
 
 int pp_tile_width(int w) { return gs_cdiv(w, 8) * 8 < gs_cdiv(w, 16) * 16 ? 8 : 16; }   // least column padding
 
@@ -404,11 +423,14 @@ extern "C" int gs_conv3x3_pp(const void* x, int x_stride, int c_in, const void* 
   GS_REQUIRE(x && wpack && y, "conv3x3_pp: null pointer");
   GS_REQUIRE(tw == 8 || tw == 16, "conv3x3_pp: tile width must be 8 or 16");
   GS_REQUIRE(c_in > 0 && c_in % 32 == 0, "conv3x3_pp: c_in must be a multiple of 32 (weights packed with kc = 32)");
-  GS_REQUIRE(n_out > 0 && n_out % PP_BN == 0, "conv3x3_pp: n_out must be a multiple of %d", PP_BN);
+  GS_REQUIRE(n_out > 0 && n_out % 64 == 0, "conv3x3_pp: n_out must be a multiple of 64");
   GS_REQUIRE(x_stride >= c_in && x_stride % 8 == 0, "conv3x3_pp: x_stride must be >= c_in and a multiple of 8");
   GS_REQUIRE(y_stride >= n_out && y_stride % 8 == 0, "conv3x3_pp: y_stride must be >= n_out and a multiple of 8");
   GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3_pp: bad shape");
   if (n == 0) return GS_OK;
+  if (pp_block_channels(n_out) == 64)
+    return dispatch_pp<0, 64>(x, x_stride, c_in, wpack, tw, y, y_stride, n_out, n, h, w, xcd_order ? 1 : 0,
+                              (hipStream_t)stream);
   return dispatch_pp<0>(x, x_stride, c_in, wpack, tw, y, y_stride, n_out, n, h, w, xcd_order ? 1 : 0,
                         (hipStream_t)stream);
 }
@@ -459,13 +481,16 @@ extern "C" int gs_conv3x3_bias_relu(const void* x, int x_stride, int c_in, const
                                     int y_stride, int n_out, int n, int h, int w, gs_stream_t stream) {
   GS_REQUIRE(x && wpack && bias && y, "conv3x3_bias_relu: null pointer");
   GS_REQUIRE(c_in > 0 && c_in % 32 == 0, "conv3x3_bias_relu: c_in must be a multiple of 32");
-  GS_REQUIRE(n_out > 0 && n_out % PP_BN == 0, "conv3x3_bias_relu: n_out must be a multiple of %d", PP_BN);
+  GS_REQUIRE(n_out > 0 && n_out % 64 == 0, "conv3x3_bias_relu: n_out must be a multiple of 64");
   GS_REQUIRE(x_stride >= c_in && x_stride % 8 == 0, "conv3x3_bias_relu: bad x_stride");
   GS_REQUIRE(y_stride >= n_out && y_stride % 8 == 0, "conv3x3_bias_relu: bad y_stride");
   GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3_bias_relu: bad shape");
   if (n == 0) return GS_OK;
   PpEpi ep = PpEpi();
   ep.bias = bias;
+  if (pp_block_channels(n_out) == 64)
+    return dispatch_pp<3, 64>(x, x_stride, c_in, wpack, pp_tile_width(w), y, y_stride, n_out, n, h, w, 1,
+                              (hipStream_t)stream, ep);
   return dispatch_pp<3>(x, x_stride, c_in, wpack, pp_tile_width(w), y, y_stride, n_out, n, h, w, 1, (hipStream_t)stream,
                         ep);
 }
@@ -475,7 +500,7 @@ extern "C" int gs_conv3x3_bias_relu(const void* x, int x_stride, int c_in, const
 extern "C" int gs_conv3x3_pp_probe(const void* x, int x_stride, int c_in, const void* wpack, int tw, void* y, int y_stride,
                                    int n_out, int n, int h, int w, int variant, long long* dbg, gs_stream_t stream) {
   GS_REQUIRE(x && wpack && y, "conv3x3_pp_probe: null pointer");
-  GS_REQUIRE((tw == 8 || tw == 16) && c_in > 0 && c_in % 32 == 0 && n_out > 0 && n_out % PP_BN == 0 && n > 0,
+  GS_REQUIRE((tw == 8 || tw == 16) && c_in > 0 && c_in % 32 == 0 && n_out > 0 && n_out % 128 == 0 && n > 0,
              "conv3x3_pp_probe: bad arguments");
   PpEpi ep = PpEpi();
   ep.dbg = dbg;

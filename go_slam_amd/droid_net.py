@@ -237,17 +237,21 @@ _CONV3X3_PACKS_MAX = 32
 
 
 def pack_conv3x3_weight(weight, kc=32):
-    """[O, C, 3, 3] -> gs_conv3x3's fp16 LDS images [O/128][C/kc][9][kc/8][128][8] (include/goslam_hip.h):
-    wpack[nb][ck][3 ky + kx][kg][r][e] = W[128 nb + r][kc ck + 8 kg + e][ky][kx]."""
+    """[O, C, 3, 3] -> gs_conv3x3's fp16 LDS images [O/BN][C/kc][9][kc/8][BN][8] (include/goslam_hip.h):
+    wpack[nb][ck][3 ky + kx][kg][r][e] = W[BN nb + r][kc ck + 8 kg + e][ky][kx]; BN = 128 output channels per workgroup,
+    or 64 when O is only a multiple of 64 (ping-pong kernel, kc = 32)."""
     O, C, kh, kw = weight.shape
-    assert (kh, kw) == (3, 3) and O % 128 == 0 and C % kc == 0 and kc in (32, 64)
-    w = weight.detach().half().reshape(O // 128, 128, C // kc, kc // 8, 8, 3, 3)   # nb r ck kg e ky kx
+    bn = 128 if O % 128 == 0 else 64
+    assert (kh, kw) == (3, 3) and O % bn == 0 and C % kc == 0 and kc in (32, 64) and (bn == 128 or kc == 32)
+    w = weight.detach().half().reshape(O // bn, bn, C // kc, kc // 8, 8, 3, 3)     # nb r ck kg e ky kx
     return w.permute(0, 2, 5, 6, 3, 1, 4).contiguous().reshape(-1)                # nb ck ky kx kg r e
 
 
 def conv3x3_hip_supported(x, w):
+    """the own kernels cover n_out % 128 == 0; the ping-pong kernel also n_out % 64 == 0 (flow_encoder[2])"""
+    mult = 64 if CONV3X3_PP else 128
     return (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
-            and w.shape[0] % 128 == 0 and w.shape[1] % 32 == 0 and x.shape[1] == w.shape[1]
+            and w.shape[0] % mult == 0 and w.shape[1] % 32 == 0 and x.shape[1] == w.shape[1]
             and x.is_contiguous(memory_format=torch.channels_last))
 
 

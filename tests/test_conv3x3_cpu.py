@@ -24,6 +24,16 @@ def test_conv3x3_weight_image_layout():
                 win = xp[ky:ky + H, kx:kx + W, kc * ck:kc * ck + kc].reshape(H, W, kc // 8, 8)   # [.., kg, e]
                 out += torch.einsum("nkre,hwke->nrhw", wp[:, ck, tap], win).reshape(O, H, W)
         assert torch.allclose(out, ref, rtol=1e-4, atol=1e-4), kc
+    # 64 output channels (flow_encoder[2]): images of 64-channel blocks, [1][C/32][9][4][64][8]
+    w64 = w[:64].contiguous()
+    wp = pack_conv3x3_weight(w64, 32).float().view(1, C // 32, 9, 4, 64, 8)
+    out = torch.zeros(64, H, W)
+    for ck in range(C // 32):
+        for tap in range(9):
+            ky, kx = tap // 3, tap % 3
+            win = xp[ky:ky + H, kx:kx + W, 32 * ck:32 * ck + 32].reshape(H, W, 4, 8)
+            out += torch.einsum("nkre,hwke->nrhw", wp[:, ck, tap], win).reshape(64, H, W)
+    assert torch.allclose(out, ref[:64], rtol=1e-4, atol=1e-4)
 
 
 def _conv_emulator():

@@ -512,6 +512,32 @@ def test_gru_global_context_fused_kernel_matches_reference(built_lib, n, h, w):
         assert float((got - ref).abs().max()) <= 2e-3, float((got - ref).abs().max())
 
 
+@pytest.mark.parametrize("n,h,w", [(5, 60, 80), (3, 30, 40), (2, 23, 37)])
+def test_conv3x3_pingpong_64_output_channels(built_lib, n, h, w):
+    """the BN = 64 instantiation of the ping-pong kernel (flow_encoder[2]: 128 -> 64, bias + ReLU into channels 256:320 of
+    the GRU input): vs an fp32 convolution of the same fp16 operands (one fp16 ulp), plain and with the fused
+    epilogue writing a channel slice; the other channels of the destination stay untouched."""
+    import torch.nn.functional as F
+    import go_slam_amd.droid_net as DN
+    dev = "cuda:0"
+    torch.manual_seed(64 + h)
+    conv = torch.nn.Conv2d(128, 64, 3, padding=1).to(dev)
+    x = torch.randn(n, 128, h, w, device=dev).half().contiguous(memory_format=torch.channels_last)
+    wt = conv.weight.detach().half().contiguous(memory_format=torch.channels_last)
+    assert DN.conv3x3_hip_supported(x, wt)
+    y = DN.conv3x3_hip(x, wt, pp=True)
+    ref = F.conv2d(x.float(), wt.float(), padding=1)
+    err = (y.float() - ref).abs()
+    assert bool((err <= 2.0 ** -10 * ref.abs().clamp_min(1.0)).all()), float(err.max())
+    hx = torch.full((n, 320, h, w), 3.0, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    cache = DN._HalfWeights()
+    DN.conv_bias_act(cache, conv, x, "relu", out=hx, out_channel=256)
+    ref2 = torch.relu(ref + conv.bias.detach().float().view(1, -1, 1, 1))
+    err2 = (hx[:, 256:].float() - ref2).abs()
+    assert bool((err2 <= 2.0 ** -9 * ref2.abs().clamp_min(1.0)).all()), float(err2.max())
+    assert bool((hx[:, :256] == 3.0).all())
+
+
 def _golden(name):
     import numpy as np
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
