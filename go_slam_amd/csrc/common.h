@@ -191,6 +191,13 @@ __device__ __forceinline__ float gs_wave_sum(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// sigmoid / tanh of an fp32 value whose result is rounded to fp16 by the caller: v_exp_f32 + v_rcp_f32 (1 ulp) instead
+// of the IEEE division sequence (v_div_scale / v_div_fmas / v_div_fixup + Newton steps: ~10 instructions per value,
+// measured 17 us of the 53 us global-context kernel and a tenth of the GRU convolutions' epilogues).  After the fp16
+// rounding the result differs from the exactly divided one for ~1 element in 10^4 (by one fp16 ulp).
+__device__ __forceinline__ float gs_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float gs_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
 // Sums of N per-lane values over the wave, "reduce-scatter" form: instead of N full butterflies (gs_wave_sum: 11
 // instructions per value) the value array is halved at every lane-bit step -- a lane keeps the even or the odd element of
 // each pair and sends the other one to its partner -- so N values cost ~N exchanges in all.  On return lane L holds, in

@@ -86,7 +86,7 @@ __device__ __forceinline__ void pp_stamp(long long* dbg, int slot) {
   if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 4 + slot] = (long long)__builtin_amdgcn_s_memtime();
 }
 
-__device__ __forceinline__ float pp_sigm(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float pp_sigm(float v) { return gs_sigmoid(v); }
 
 template <int TW, int EPI, int BN = 128>
 __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __restrict__ x, int xs, int C,
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             const float a_ = (float)v[k] + (float)pi[k] + bb[k] + gg[k];
-            const float q = 1.0f - 2.0f / (1.0f + __expf(2.0f * a_));
+            const float q = gs_tanh(a_);
             const float zf = (float)zz[k];
             o[k] = (_Float16)((1.0f - zf) * (float)nn[k] + zf * q);
           }

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void conv3x3_head_kernel(
 #pragma unroll
     for (int o = 0; o < O; ++o) {
       float v = (float)(_Float16)(acc[o] + bias[o]);                 // the convolution's fp16 output
-      if (epilogue == 1) v = (float)(_Float16)(1.0f / (1.0f + __expf(-v)));          // sigmoid (fp16 op)
+      if (epilogue == 1) v = (float)(_Float16)gs_sigmoid(v);                          // sigmoid (fp16 op)
       else if (epilogue == 2) v = (v > 20.0f) ? v : log1pf(__expf(v));                // softplus (fp32 op)
       op[o] = v * out_scale;
     }

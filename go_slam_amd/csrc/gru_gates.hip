@@ -14,7 +14,7 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigm(float x) { return gs_sigmoid(x); }
 
 // zr_pre [n,hw,256]; bias [256] f32; glo [n,256] f32; hx [n,hw,ldx] (first 128 ch = net, in/out); z [n,hw,128]
 __global__ __launch_bounds__(256) void gru_gate_zr_kernel(const _Float16* __restrict__ zr_pre,
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void gru_gate_q_kernel(const _Float16* __restr
   for (int k = 0; k < 8; ++k) {
     const int c = c8 * 8 + k;
     const float a = (float)qp[k] + (float)qi[k] + bias[c] + glo[(size_t)n * 128 + c];
-    const float q = 1.0f - 2.0f / (1.0f + __expf(2.0f * a));      // tanh (|err| ~1e-7, result goes to fp16)
+    const float q = gs_tanh(a);                                    // tanh (|err| ~1e-7, result goes to fp16)
     const float zf = (float)zz[k];
     out[k] = (_Float16)((1.0f - zf) * (float)nn[k] + zf * q);
   }

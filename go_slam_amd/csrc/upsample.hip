@@ -33,12 +33,13 @@ __global__ __launch_bounds__(256) void cvx_upsample_kernel(const float* __restri
 #pragma unroll
   for (int k = 0; k < 9; ++k) { lg[k] = __expf(lg[k] - mx); den += lg[k]; }
   const float* d = disps + frame * hw;
+  const float inv_den = __builtin_amdgcn_rcpf(den);
   float acc = 0.f;
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
     const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;              // F.unfold(3x3, padding 1): zero padded
     const float nb = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? d[yy * w + xx] : 0.0f;
-    const float wk = (float)(_Float16)(lg[k] / den);               // softmax output is fp16
+    const float wk = (float)(_Float16)(lg[k] * inv_den);           // softmax output is fp16
     acc += wk * nb;
   }
   const int i = lane >> 3, j = lane & 7;
@@ -80,8 +81,9 @@ __global__ __launch_bounds__(256) void cvx_upsample_nhwc_kernel(const float* __r
     for (int k = 0; k < 9; ++k) { e[k] = (float)lg[k][j]; mx = fmaxf(mx, e[k]); }
 #pragma unroll
     for (int k = 0; k < 9; ++k) { e[k] = __expf(e[k] - mx); den += e[k]; }
+    const float inv_den = __builtin_amdgcn_rcpf(den);             // one v_rcp instead of nine IEEE division sequences
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc += (float)(_Float16)(e[k] / den) * nb[k];     // softmax output is fp16
+    for (int k = 0; k < 9; ++k) acc += (float)(_Float16)(e[k] * inv_den) * nb[k];   // softmax output is fp16
     res[j] = acc;
   }
   float4* o = reinterpret_cast<float4*>(out + frame * (long)hw * 64 + (long)(8 * y + c) * (8 * w) + 8 * x);
