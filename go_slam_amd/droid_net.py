@@ -430,7 +430,37 @@ class ConvGRU(nn.Module):
         self._half_weights()
         return conv_nobias(inp, self._hw_hoist[0], padding=1)
 
-    def forward_hx(self, net, hx, inp_pre=None):
+    def global_context(self, net):
+        """(gzr [b,256], gq [b,128]) fp32: the global-context terms of the three gates (modules/gru.py:22-27)"""
+        from . import _lib
+        b, c, h, w = net.shape
+        hw = h * w
+        wzr, wq, bzr, bq, ww, bw, gw = self._half_weights()
+        L = _lib.lib()
+        st = _lib.stream_ptr(net.device)
+        dev = net.device
+        gzr = torch.empty(b, 256, dtype=torch.float32, device=dev)
+        gq = torch.empty(b, 128, dtype=torch.float32, device=dev)
+        if GRU_GLO_FUSED:
+            # w(net), sigmoid, * net and the pooling in one kernel: w_pre never reaches memory
+            ws = torch.empty(L.gs_gru_glo_fused_workspace_bytes(b, hw), dtype=torch.uint8, device=dev)
+            _lib.check(L.gs_gru_glo_fused(_lib.ptr(net), 128, _lib.ptr(self._ww_pack), _lib.ptr(bw), _lib.ptr(gw[0]),
+                                          _lib.ptr(gw[1]), _lib.ptr(gw[2]), _lib.ptr(gw[3]), _lib.ptr(gw[4]),
+                                          _lib.ptr(gw[5]), _lib.ptr(gzr), _lib.ptr(gq), b, hw, _lib.ptr(ws),
+                                          ws.numel(), st), "gru_glo_fused")
+        else:
+            # gs_conv1x1 (own MFMA kernel; deterministic, one launch) instead of an MIOpen 1x1 convolution, whose
+            # solver choice -- and with it the fp16 rounding of the global-context gate -- can change between calls
+            w_pre = torch.empty_like(net)
+            _lib.check(L.gs_conv1x1(_lib.ptr(net), 128, 128, _lib.ptr(self._ww_pack), None, 0, _lib.ptr(w_pre), 128,
+                                    128, b * hw, st), "conv1x1(gru.w)")
+            ws = torch.empty(L.gs_gru_glo_workspace_bytes(b), dtype=torch.uint8, device=dev)
+            _lib.check(L.gs_gru_glo(_lib.ptr(w_pre), _lib.ptr(bw), _lib.ptr(net), _lib.ptr(gw[0]), _lib.ptr(gw[1]),
+                                    _lib.ptr(gw[2]), _lib.ptr(gw[3]), _lib.ptr(gw[4]), _lib.ptr(gw[5]),
+                                    _lib.ptr(gzr), _lib.ptr(gq), b, hw, _lib.ptr(ws), ws.numel(), st), "gru_glo")
+        return gzr, gq
+
+    def forward_hx(self, net, hx, inp_pre=None, glo=None):
         """GRU step given hx = [net | inputs] already laid out as one NHWC fp16 tensor.  hx[:, :128] is
         overwritten with r*net (the q-convolution's input).  With `inp_pre` (= inp_gates(inp)) hx is
         [net | corr | flow] and the context-feature term is added inside the gate kernels."""
@@ -444,25 +474,7 @@ class ConvGRU(nn.Module):
         st = _lib.stream_ptr(net.device)
         dev = net.device
         with torch.autocast("cuda", enabled=False):
-            # gs_conv1x1 (own MFMA kernel; deterministic, one launch) instead of an MIOpen 1x1 convolution, whose
-            # solver choice -- and with it the fp16 rounding of the global-context gate -- can change between calls
-            gzr = torch.empty(b, 256, dtype=torch.float32, device=dev)
-            gq = torch.empty(b, 128, dtype=torch.float32, device=dev)
-            if GRU_GLO_FUSED:
-                # w(net), sigmoid, * net and the pooling in one kernel: w_pre never reaches memory
-                ws = torch.empty(L.gs_gru_glo_fused_workspace_bytes(b, hw), dtype=torch.uint8, device=dev)
-                _lib.check(L.gs_gru_glo_fused(_lib.ptr(net), 128, _lib.ptr(self._ww_pack), _lib.ptr(bw), _lib.ptr(gw[0]),
-                                              _lib.ptr(gw[1]), _lib.ptr(gw[2]), _lib.ptr(gw[3]), _lib.ptr(gw[4]),
-                                              _lib.ptr(gw[5]), _lib.ptr(gzr), _lib.ptr(gq), b, hw, _lib.ptr(ws),
-                                              ws.numel(), st), "gru_glo_fused")
-            else:
-                w_pre = torch.empty_like(net)
-                _lib.check(L.gs_conv1x1(_lib.ptr(net), 128, 128, _lib.ptr(self._ww_pack), None, 0, _lib.ptr(w_pre), 128,
-                                        128, b * hw, st), "conv1x1(gru.w)")
-                ws = torch.empty(L.gs_gru_glo_workspace_bytes(b), dtype=torch.uint8, device=dev)
-                _lib.check(L.gs_gru_glo(_lib.ptr(w_pre), _lib.ptr(bw), _lib.ptr(net), _lib.ptr(gw[0]), _lib.ptr(gw[1]),
-                                        _lib.ptr(gw[2]), _lib.ptr(gw[3]), _lib.ptr(gw[4]), _lib.ptr(gw[5]),
-                                        _lib.ptr(gzr), _lib.ptr(gq), b, hw, _lib.ptr(ws), ws.numel(), st), "gru_glo")
+            gzr, gq = glo if glo is not None else self.global_context(net)
             cin = hx.shape[1]
             if GRU_FUSED_EPILOGUE and CONV3X3_PP and _use_own_conv3x3(hx, wzr, 1, 1) and h * w > 0:
                 # gate arithmetic in the convolutions' epilogues: zr_pre / q_pre never reach HBM; hx stays intact
@@ -584,6 +596,20 @@ class UpdateModule(nn.Module):
             self._heads, self._heads_key = (w, b), key
         return self._heads
 
+    def _corr_independent_part(self, net4, inp, f4, n, ht, wd):
+        """everything of the fast path that does not need the correlation features: the GRU input buffer with net and the
+        flow-encoder features in place, the hoisted context term, the GRU's global-context terms"""
+        hx, inp_pre = self._edge_state(inp, n, ht, wd)
+        copy_channels(net4, hx, 0)
+        if CONV7X7_OWN and conv7x7_c4_supported(self.flow_encoder[0], f4):
+            f4 = conv7x7_c4_bias_act(self._head_cache, self.flow_encoder[0], f4, "relu")
+        else:
+            f4 = conv_bias_act(self._hw, self.flow_encoder[0], f4, "relu")
+        conv_bias_act(self._hw, self.flow_encoder[2], f4, "relu", out=hx, out_channel=256)
+        with torch.autocast("cuda", enabled=False):
+            glo = self.gru.global_context(net4)
+        return hx, inp_pre, glo
+
     def _forward_fast(self, net, inp, corr, flow, ii, jj, seg=None):
         """forward() on the inference path: bias-free convolutions (gs_conv3x3 / MIOpen), each followed by one HIP
         epilogue (bias + activation, written straight into the next consumer's buffer -- no torch.cat),
@@ -599,16 +625,12 @@ class UpdateModule(nn.Module):
         if flow is None:
             flow = torch.zeros(batch, num, 4, ht, wd, device=net.device)
         f4 = flow.view(n, -1, ht, wd).half().contiguous(memory_format=cl)
-        hx, inp_pre = self._edge_state(inp, n, ht, wd)
-        copy_channels(net4, hx, 0)
+        # (running this part on a side stream next to the correlation lookup -- a light, memory-bound kernel -- was
+        # measured: bit-identical, 2 % slower per keyframe; the kernels do not share the CUs to any advantage)
+        hx, inp_pre, glo = self._corr_independent_part(net4, inp, f4, n, ht, wd)
         c4 = conv1x1_bias_act(self._head_cache, self.corr_encoder[0], c4, "relu")
         conv_bias_act(hwc, self.corr_encoder[2], c4, "relu", out=hx, out_channel=128)
-        if CONV7X7_OWN and conv7x7_c4_supported(self.flow_encoder[0], f4):
-            f4 = conv7x7_c4_bias_act(self._head_cache, self.flow_encoder[0], f4, "relu")
-        else:
-            f4 = conv_bias_act(hwc, self.flow_encoder[0], f4, "relu")
-        conv_bias_act(hwc, self.flow_encoder[2], f4, "relu", out=hx, out_channel=256)
-        net4 = self.gru.forward_hx(net4, hx, inp_pre)
+        net4 = self.gru.forward_hx(net4, hx, inp_pre, glo=glo)
         net = net4.view(*out_dim)
         hw_, hb = self._head_weights()
         heads = conv_nobias(net4, hw_ if ii is not None else hw_[:256], padding=1)
