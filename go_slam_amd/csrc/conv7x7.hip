@@ -158,8 +158,9 @@ GsLdsLimit g_c7_lds;
 // y: [n, h, w] pixels of `ys` halves, 128 written per pixel.  rt = rows per workgroup (0 = choose).
 extern "C" int gs_conv7x7_c4(const void* x, const void* wpack, const float* bias, void* y, int ys, int n, int h, int w,
                              int relu, int rt, gs_stream_t stream) {
+  GS_REQUIRE(n >= 0 && h > 0 && w > 0 && w <= 1024, "conv7x7_c4: bad shape (w <= 1024)");
+  if (n == 0) return GS_OK;
   GS_REQUIRE(x && wpack && bias && y, "conv7x7_c4: null pointer");
-  GS_REQUIRE(n > 0 && h > 0 && w > 0 && w <= 1024, "conv7x7_c4: bad shape (w <= 1024)");
   GS_REQUIRE(ys >= 128 && ys % 8 == 0 && ((size_t)y & 15) == 0 && ((size_t)x & 7) == 0 && ((size_t)wpack & 15) == 0,
              "conv7x7_c4: output rows must be 16-byte aligned, >= 128 halves");
   if (rt <= 0) {
