@@ -61,6 +61,7 @@ SIGNATURES = {
     "gs_edge_greedy": (c_int, [_P] * 5 + [c_int] * 5 + [c_float, c_int, c_int, _P]),
     "gs_ba_workspace_bytes": (c_size_t, [c_int] * 5),
     "gs_ba": (c_int, [_P] * 9 + [c_int] * 3 + [c_float, c_float] + [c_int] * 6 + [_P, _P, _P, _P, c_size_t, _P]),
+    "gs_ba_ex": (c_int, [_P] * 9 + [c_int] * 3 + [c_float, c_float] + [c_int] * 6 + [_P, _P, _P, _P, c_size_t, c_int, _P]),
     # include/goslam_neus.h
     "gs_grid_meta_default": (c_int, [_P]),
     "gs_render_sample": (c_int, [_P] * 7 + [c_float, _P, _P, _P] + [c_int] * 3 + [_P]),

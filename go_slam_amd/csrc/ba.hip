@@ -198,8 +198,10 @@ __global__ __launch_bounds__(256) void ba_accum_kernel(
     const float* __restrict__ poses, const float* __restrict__ disps, const float* __restrict__ intr,
     const float* __restrict__ disps_sens, const float* __restrict__ targets, const float* __restrict__ weights,
     const float* __restrict__ eta, const int64_t* __restrict__ jj, int t0, int t1, int hw, int wd,
-    int motion_only, BaWs w) {
+    int motion_only, int reset_fail, BaWs w) {
   __shared__ float red[4][92];
+  // (a call that reuses an earlier call's tables skips ba_prep_kernel, which is where the failure counters are cleared)
+  if (reset_fail && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { w.hdr[2] = 0; w.hdr[3] = 0; }
   const int m = blockIdx.y;
   if (m >= w.hdr[0]) return;   // only when n_depth over-states the graph (status word 1)
   const int tid = threadIdx.x;
@@ -519,11 +521,11 @@ extern "C" size_t gs_ba_workspace_bytes(int n_edges, int n_poses, int n_depth, i
   return carve(nullptr, n_edges, n_poses, n_depth, nbuf, hw).total + 256;
 }
 
-extern "C" int gs_ba(float* poses, float* disps, const float* intrinsics, const float* disps_sens,
-                     const float* targets, const float* weights, const float* eta, const int64_t* ii,
-                     const int64_t* jj, int t0, int t1, int iterations, float lm, float ep, int motion_only,
-                     int n_edges, int n_depth, int nbuf, int h, int w, float* dx, float* dz,
-                     int32_t* status_out, void* workspace, size_t workspace_bytes, gs_stream_t stream) {
+extern "C" int gs_ba_ex(float* poses, float* disps, const float* intrinsics, const float* disps_sens,
+                        const float* targets, const float* weights, const float* eta, const int64_t* ii,
+                        const int64_t* jj, int t0, int t1, int iterations, float lm, float ep, int motion_only,
+                        int n_edges, int n_depth, int nbuf, int h, int w, float* dx, float* dz,
+                        int32_t* status_out, void* workspace, size_t workspace_bytes, int flags, gs_stream_t stream) {
   GS_REQUIRE(poses && disps && intrinsics && disps_sens && targets && weights && ii && jj && dx && workspace,
              "ba: null pointer");
   GS_REQUIRE(motion_only || (eta && dz), "ba: eta/dz required unless motion_only");
@@ -542,8 +544,13 @@ extern "C" int gs_ba(float* poses, float* disps, const float* intrinsics, const 
   hipStream_t st = (hipStream_t)stream;
   const int n6 = 6 * P;
 
-  ba_prep_kernel<<<1, kPrepThreads, 0, st>>>(ii, jj, n_edges, nbuf, t0, t1, M, ws);
-  GS_CHECK_LAUNCH("ba_prep");
+  // GS_BA_REUSE_TABLES: the index tables in `workspace` are those of an earlier call with the same ii / jj / t0 / t1 /
+  // n_depth / nbuf / map size (the caller's promise): they depend on nothing else, so ba_prep_kernel is skipped
+  const bool reuse = (flags & 1) != 0;
+  if (!reuse) {
+    ba_prep_kernel<<<1, kPrepThreads, 0, st>>>(ii, jj, n_edges, nbuf, t0, t1, M, ws);
+    GS_CHECK_LAUNCH("ba_prep");
+  }
   const int chunks = gs_cdiv(hw, 256);
   for (int it = 0; it < iterations; ++it) {
     if (hipMemsetAsync(ws.H, 0, ((size_t)n6 * n6 + n6) * sizeof(double), st) != hipSuccess) {
@@ -551,7 +558,7 @@ extern "C" int gs_ba(float* poses, float* disps, const float* intrinsics, const 
       return GS_ERR_LAUNCH;
     }
     ba_accum_kernel<<<dim3(chunks, M), 256, 0, st>>>(poses, disps, intrinsics, disps_sens, targets, weights,
-                                                     eta, jj, t0, t1, hw, w, motion_only, ws);
+                                                     eta, jj, t0, t1, hw, w, motion_only, (reuse && it == 0) ? 1 : 0, ws);
     GS_CHECK_LAUNCH("ba_accum");
     if (!motion_only) {
       ba_schur_kernel<<<2048, 256, 0, st>>>(M, hw, P, ws);
@@ -570,4 +577,13 @@ extern "C" int gs_ba(float* poses, float* disps, const float* intrinsics, const 
     GS_CHECK_LAUNCH("ba_status");
   }
   return GS_OK;
+}
+
+extern "C" int gs_ba(float* poses, float* disps, const float* intrinsics, const float* disps_sens,
+                     const float* targets, const float* weights, const float* eta, const int64_t* ii,
+                     const int64_t* jj, int t0, int t1, int iterations, float lm, float ep, int motion_only,
+                     int n_edges, int n_depth, int nbuf, int h, int w, float* dx, float* dz,
+                     int32_t* status_out, void* workspace, size_t workspace_bytes, gs_stream_t stream) {
+  return gs_ba_ex(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep,
+                  motion_only, n_edges, n_depth, nbuf, h, w, dx, dz, status_out, workspace, workspace_bytes, 0, stream);
 }

@@ -216,12 +216,14 @@ class DepthVideo:
             d = droid_backends.frame_distance(self.poses, self.disps, intr, ii, jj, beta)
         return d.reshape(N, N) if return_matrix else d
 
+    ba_accepts_tables = True            # FactorGraph.update passes its per-edge-set table cache (not in the reference)
+
     def ba(self, target, weight, eta, ii, jj, t0=1, t1=None, iters=2, lm=1e-4, ep=0.1,
-           motion_only=False, ba_type=None):
-        """dense bundle adjustment (src/depth_video.py:257-269)."""
+           motion_only=False, ba_type=None, tables=None):
+        """dense bundle adjustment (src/depth_video.py:257-269).  `tables`: see droid_backends.ba."""
         if t1 is None:
             t1 = max(int(ii.max()), int(jj.max())) + 1
         out = droid_backends.ba(self.poses, self.disps, self.intrinsics[0].contiguous(), self.disps_sens,
-                                target, weight, eta, ii, jj, t0, t1, iters, lm, ep, motion_only)
+                                target, weight, eta, ii, jj, t0, t1, iters, lm, ep, motion_only, tables=tables)
         self.disps.clamp_(min=0.001)
         return out

@@ -47,8 +47,12 @@ def _workspace(device, nbytes):
 
 
 def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
-       t0, t1, iterations, lm, ep, motion_only):
-    """droid.cpp:88-117.  Mutates `poses`/`disps`; returns [dx, dz] (dz None if motion_only)."""
+       t0, t1, iterations, lm, ep, motion_only, tables=None):
+    """droid.cpp:88-117.  Mutates `poses`/`disps`; returns [dx, dz] (dz None if motion_only).
+
+    `tables` (optional, not in the reference): a dict the caller keeps per EDGE SET.  It then owns the call's workspace,
+    and a second call with the same ii / jj tensors, window and depth-row count skips the index-table kernel
+    (GS_BA_REUSE_TABLES) -- FactorGraph.update runs six calls per keyframe on one edge set."""
     _chk("targets", targets, torch.float32)
     _chk("weights", weights, torch.float32)
     _chk("poses", poses, torch.float32)
@@ -67,7 +71,18 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
     M = eta.reshape(-1, hw).shape[0]
     L = _lib.lib()
     need = L.gs_ba_workspace_bytes(E, P, M, nbuf, hw)
-    ws = _workspace(dev, need + 256)
+    flags = 0
+    if tables is None:
+        ws = _workspace(dev, need + 256)
+    else:
+        key = (ii.data_ptr(), ii._version, jj.data_ptr(), jj._version, E, int(t0), int(t1), M, nbuf, ht, wd, dev)
+        ws = tables.get("workspace")
+        if ws is not None and tables.get("key") == key and ws.numel() >= need + 256:
+            flags = 1                                        # GS_BA_REUSE_TABLES
+        else:
+            ws = tables["workspace"] = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+            tables["key"] = key
+            tables["ii"], tables["jj"] = ii, jj              # keep the addresses in the key alive
     dx = torch.empty(P, 6, dtype=torch.float32, device=dev)
     # zeros: depth rows the kernels skip (only when `eta` has more rows than the graph has depth keyframes, status [1])
     # must not hand uninitialised memory to the caller
@@ -76,11 +91,11 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
     if status is None:
         status = _ba_status[dev.index] = torch.zeros(4, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        rc = L.gs_ba(_lib.ptr(poses), _lib.ptr(disps), _lib.ptr(intrinsics), _lib.ptr(disps_sens),
-                     _lib.ptr(targets), _lib.ptr(weights), _lib.ptr(eta), _lib.ptr(ii), _lib.ptr(jj),
-                     int(t0), int(t1), int(iterations), float(lm), float(ep), int(bool(motion_only)),
-                     E, M, nbuf, ht, wd, _lib.ptr(dx), _lib.ptr(dz), _lib.ptr(status),
-                     _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        rc = L.gs_ba_ex(_lib.ptr(poses), _lib.ptr(disps), _lib.ptr(intrinsics), _lib.ptr(disps_sens),
+                        _lib.ptr(targets), _lib.ptr(weights), _lib.ptr(eta), _lib.ptr(ii), _lib.ptr(jj),
+                        int(t0), int(t1), int(iterations), float(lm), float(ep), int(bool(motion_only)),
+                        E, M, nbuf, ht, wd, _lib.ptr(dx), _lib.ptr(dz), _lib.ptr(status),
+                        _lib.ptr(ws), ws.numel(), flags, _lib.stream_ptr(dev))
     _lib.check(rc, "droid_backends.ba")
     if BA_CHECK:
         st = ba_status(dev)

@@ -5,9 +5,14 @@ update() = reproject (HIP) -> motion features -> 4-level corr lookup (HIP, one l
 UpdateModule (gs_conv3x3 / MIOpen convolutions + HIP epilogues) -> dense BA (HIP, no host round trips) -> convex
 upsampling.
 """
+import os
+
 import torch
 
 from .corr import AltCorrBlock, CorrBlock
+
+# FactorGraph.update: keep the BA's index tables per edge set (GS_BA_REUSE_TABLES); 0 = rebuild them in every call
+BA_TABLES = os.environ.get("GOSLAM_BA_TABLES", "1") == "1"
 
 
 def coords_grid(ht, wd, device):
@@ -387,8 +392,14 @@ class FactorGraph:
 
         damping = 0.2 * self.damping[idx["damping_index"]].contiguous() + EPS
 
-        self.video.ba(target, weight, damping, idx["ii"], idx["jj"], t0=t0, t1=t1, iters=iters,
-                      lm=1e-4, ep=0.1, motion_only=motion_only)
+        # (the cached edge index also keeps the BA's index tables: built by the first call on this edge set, reused after)
+        tables = idx.setdefault("ba_tables", {}) if (BA_TABLES and getattr(self.video, "ba_accepts_tables", False)) else None
+        if tables is None:
+            self.video.ba(target, weight, damping, idx["ii"], idx["jj"], t0=t0, t1=t1, iters=iters,
+                          lm=1e-4, ep=0.1, motion_only=motion_only)
+        else:
+            self.video.ba(target, weight, damping, idx["ii"], idx["jj"], t0=t0, t1=t1, iters=iters,
+                          lm=1e-4, ep=0.1, motion_only=motion_only, tables=tables)
         if self.upsample:
             self.video.upsample(seg["uniq"], upmask[0])
         self.age += 1

@@ -291,6 +291,19 @@ int gs_ba(float* poses, float* disps, const float* intrinsics, const float* disp
           float* dx, float* dz, int32_t* status_out,
           void* workspace, size_t workspace_bytes, gs_stream_t stream);
 
+/* gs_ba with flags.  GS_BA_REUSE_TABLES (1): `workspace` still holds the index tables (unique keyframes, CSR of
+ * out-edges, Schur entry lists) an earlier call built for the SAME ii / jj / t0 / t1 / n_depth / nbuf / map size and
+ * nothing has written to it since -- they depend on nothing else, so the one-workgroup table kernel (26 us, once per
+ * call) is skipped.  FactorGraph.update issues 6 calls per keyframe on one edge set.                       */
+#define GS_BA_REUSE_TABLES 1
+int gs_ba_ex(float* poses, float* disps, const float* intrinsics, const float* disps_sens,
+             const float* targets, const float* weights, const float* eta,
+             const int64_t* ii, const int64_t* jj,
+             int t0, int t1, int iterations, float lm, float ep, int motion_only,
+             int n_edges, int n_depth, int nbuf, int h, int w,
+             float* dx, float* dz, int32_t* status_out,
+             void* workspace, size_t workspace_bytes, int flags, gs_stream_t stream);
+
 /* Edge proposal with greedy non-maximum suppression on the device: FactorGraph.add_proximity_factors
  * (src/factor_graph.py:384-450) and Backend.ba's selection incl. the loop-closure rule (src/backend.py:31-94), in two
  * launches around a device-side stable sort; the frame-distance matrix never leaves HBM.

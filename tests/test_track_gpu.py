@@ -299,6 +299,44 @@ def test_ba_status_word_reports_failures_and_depth_row_mismatch(db, dev):
         db.BA_CHECK = keep
 
 
+def test_ba_reuses_index_tables_on_one_edge_set(db, dev):
+    """droid_backends.ba(..., tables=dict): the second and third call on the same edge tensors skip the table kernel
+    (GS_BA_REUSE_TABLES) and must produce exactly what three plain calls produce -- poses / disparities move between the
+    calls, the tables depend on the edge set and window only; a different window rebuilds them."""
+    from oracle import droid_oracle as O
+    prob = _ba_problem(O, 8, 22, "tiny", seed=37)
+    K = prob["intrinsics"][0].contiguous().to(dev)
+    fixed = [prob["disps_sens"].to(dev), prob["target"].to(dev), prob["weight"].to(dev), prob["eta"].to(dev),
+             prob["ii"].to(dev), prob["jj"].to(dev)]
+
+    def run(tables_of):
+        pg, dg = prob["poses"].clone().to(dev), prob["disps"].clone().to(dev)
+        outs = []
+        for it in range(3):
+            outs.append(db.ba(pg, dg, K, *fixed, prob["t0"], prob["t1"], 2, 1e-4, 0.1, False, **tables_of(it)))
+        return pg, dg, outs
+
+    pa, da, oa = run(lambda it: {})
+    cache = {}
+    pb, dbb, ob = run(lambda it: {"tables": cache})
+    assert "workspace" in cache and cache["key"][4] == prob["ii"].numel()
+    assert torch.equal(pa, pb) and torch.equal(da, dbb)
+    for (dxa, dza), (dxb, dzb) in zip(oa, ob):
+        assert torch.equal(dxa, dxb) and torch.equal(dza, dzb)
+    assert db.ba_status(dev)["cholesky_failures"] == 0
+    # another window on the same cache object: tables are rebuilt (key mismatch), result = plain call
+    pg, dg = prob["poses"].clone().to(dev), prob["disps"].clone().to(dev)
+    ws_before = cache["workspace"].data_ptr()
+    kx = torch.unique(torch.cat([torch.arange(2, prob["t1"]), prob["ii"]]))
+    eta2 = prob["eta"][: len(kx)].contiguous().to(dev) if len(kx) <= prob["eta"].shape[0] else fixed[3]
+    f2 = [fixed[0], fixed[1], fixed[2], eta2, fixed[4], fixed[5]]
+    r1 = db.ba(pg, dg, K, *f2, 2, prob["t1"], 1, 1e-4, 0.1, False, tables=cache)
+    pg2, dg2 = prob["poses"].clone().to(dev), prob["disps"].clone().to(dev)
+    r2 = db.ba(pg2, dg2, K, *f2, 2, prob["t1"], 1, 1e-4, 0.1, False)
+    assert cache["key"][5] == 2 and torch.equal(r1[0], r2[0]) and torch.equal(pg, pg2)
+    del ws_before
+
+
 def test_ba_rejects_non_contiguous(db, dev):
     from oracle import droid_oracle as O
     prob = _ba_problem(O, 6, 14, "tiny", seed=31)
