@@ -48,6 +48,7 @@ SIGNATURES = {
     "gs_conv3x3_pp_probe": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "gs_conv3x3_bias_relu": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "gs_conv3x3_gru_zr": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "gs_conv3x3_gru_zr2": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gs_conv3x3_gru_q": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gs_conv3x3_head": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_float, _P, c_int, c_int, c_int, _P]),
     "gs_segment_mean": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),

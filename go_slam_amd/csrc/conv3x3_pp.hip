@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
     if (off >= 0) {
       const size_t pix = (size_t)(off >> 2);
       const int c0 = src_chunk * 32 + (off & 3) * 8;
-      if constexpr (EPI == 2)
+      if constexpr (EPI == 1 || EPI == 2)                  // two input tensors: [x (first `split` channels) | xb]
         src = c0 < ep.split ? (const void*)(x + pix * xs + c0) : (const void*)(ep.xb + pix * ep.xsb + (c0 - ep.split));
       else
         src = (const void*)(x + pix * xs + c0);
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_v3_kernel(const _Float16* __re
       if (off >= 0) {
         const size_t pix = (size_t)(off >> 2);
         const int c0 = src_chunk * 32 + (off & 3) * 8;
-        if constexpr (EPI == 2)
+        if constexpr (EPI == 1 || EPI == 2)
           src = c0 < ep.split ? (const void*)(x + pix * xs + c0) : (const void*)(ep.xb + pix * ep.xsb + (c0 - ep.split));
         else
           src = (const void*)(x + pix * xs + c0);
@@ -768,7 +768,34 @@ extern "C" int gs_conv3x3_gru_zr(const void* hx, int hx_stride, int c_in, const 
   ep.inp_pre = (const _Float16*)inp_pre;
   ep.out0 = (_Float16*)z_out;
   ep.out1 = (_Float16*)rnet_out;
+  ep.xb = (const _Float16*)hx;                              // one tensor: every channel comes from `hx`
+  ep.xsb = hx_stride;
+  ep.split = 1 << 30;
   return dispatch_pp<1>(hx, hx_stride, c_in, wpack, pp_tile_width(w), nullptr, 0, 256, n, h, w, 1, (hipStream_t)stream, ep);
+}
+
+// The same with the GRU input given as two tensors, [net (128 channels, dense) | x_rest (c_rest channels, pixels
+// x_rest_stride apart)], as gs_conv3x3_gru_q takes it: the caller no longer copies net into the first 128 channels of the
+// input buffer before every step.
+extern "C" int gs_conv3x3_gru_zr2(const void* net, const void* x_rest, int x_rest_stride, int c_rest, const void* wpack,
+                                  const float* bias_zr, const float* glo_zr, const void* inp_pre, void* z_out,
+                                  void* rnet_out, int n, int h, int w, gs_stream_t stream) {
+  GS_REQUIRE(net && x_rest && wpack && bias_zr && glo_zr && z_out && rnet_out, "conv3x3_gru_zr2: null pointer");
+  GS_REQUIRE(c_rest > 0 && c_rest % 32 == 0, "conv3x3_gru_zr2: c_rest must be a multiple of 32");
+  GS_REQUIRE(x_rest_stride >= c_rest && x_rest_stride % 8 == 0, "conv3x3_gru_zr2: bad x_rest_stride");
+  GS_REQUIRE(n >= 0 && h > 0 && w > 0, "conv3x3_gru_zr2: bad shape");
+  if (n == 0) return GS_OK;
+  PpEpi ep = PpEpi();
+  ep.bias = bias_zr;
+  ep.glo = glo_zr;
+  ep.inp_pre = (const _Float16*)inp_pre;
+  ep.out0 = (_Float16*)z_out;
+  ep.out1 = (_Float16*)rnet_out;
+  ep.xb = (const _Float16*)x_rest;
+  ep.xsb = x_rest_stride;
+  ep.split = 128;
+  return dispatch_pp<1>(net, 128, 128 + c_rest, wpack, pp_tile_width(w), nullptr, 0, 256, n, h, w, 1,
+                        (hipStream_t)stream, ep);
 }
 
 extern "C" int gs_conv3x3_gru_q(const void* rnet, const void* x_rest, int x_rest_stride, int c_rest, const void* wpack,

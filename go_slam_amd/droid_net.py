@@ -481,14 +481,17 @@ class ConvGRU(nn.Module):
                 z = torch.empty_like(net)
                 rnet = torch.empty_like(net)
                 out = torch.empty_like(net)
-                _lib.check(L.gs_conv3x3_gru_zr(_lib.ptr(hx), cin, cin, _lib.ptr(conv3x3_weight_image(wzr, 32)),
-                                               _lib.ptr(bzr), _lib.ptr(gzr), _lib.ptr(inp_pre), _lib.ptr(z),
-                                               _lib.ptr(rnet), b, h, w, st), "conv3x3_gru_zr")
+                # (both convolutions take [net | hx[:, 128:]] as two tensors: net is never copied into hx[:, :128])
+                _lib.check(L.gs_conv3x3_gru_zr2(_lib.ptr(net), hx.data_ptr() + 2 * 128, cin, cin - 128,
+                                                _lib.ptr(conv3x3_weight_image(wzr, 32)), _lib.ptr(bzr), _lib.ptr(gzr),
+                                                _lib.ptr(inp_pre), _lib.ptr(z), _lib.ptr(rnet), b, h, w, st),
+                           "conv3x3_gru_zr2")
                 _lib.check(L.gs_conv3x3_gru_q(_lib.ptr(rnet), hx.data_ptr() + 2 * 128, cin, cin - 128,
                                               _lib.ptr(conv3x3_weight_image(wq, 32)), _lib.ptr(bq), _lib.ptr(gq),
                                               _lib.ptr(inp_pre), _lib.ptr(z), _lib.ptr(net), _lib.ptr(out), b, h, w,
                                               st), "conv3x3_gru_q")
                 return out
+            copy_channels(net, hx, 0)                         # the unfused kernels read net from hx[:, :128]
             zr_pre = conv_nobias(hx, wzr, padding=1)
             z = torch.empty_like(net)
             _lib.check(L.gs_gru_gate_zr(_lib.ptr(zr_pre), _lib.ptr(bzr), _lib.ptr(gzr), _lib.ptr(inp_pre), _lib.ptr(hx),
@@ -600,7 +603,6 @@ class UpdateModule(nn.Module):
         """everything of the fast path that does not need the correlation features: the GRU input buffer with net and the
         flow-encoder features in place, the hoisted context term, the GRU's global-context terms"""
         hx, inp_pre = self._edge_state(inp, n, ht, wd)
-        copy_channels(net4, hx, 0)
         if CONV7X7_OWN and conv7x7_c4_supported(self.flow_encoder[0], f4):
             f4 = conv7x7_c4_bias_act(self._head_cache, self.flow_encoder[0], f4, "relu")
         else:

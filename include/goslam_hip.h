@@ -219,6 +219,11 @@ int gs_conv3x3_pp_probe(const void* x, int x_stride, int c_in, const void* wpack
  * tensor (corr_encoder[2] -> the GRU input buffer, src/droid_net.py:76; agg.conv2, :41).  EXPERIMENTAL, opt-in.      */
 int gs_conv3x3_bias_relu(const void* x, int x_stride, int c_in, const void* wpack, const float* bias, void* y,
                          int y_stride, int n_out, int n, int h, int w, gs_stream_t stream);
+/* gs_conv3x3_gru_zr2: the same with the input given as [net (128 channels, dense rows) | x_rest (c_rest channels, pixels
+ * x_rest_stride apart)] -- no copy of net into the input buffer before the step (as gs_conv3x3_gru_q).          */
+int gs_conv3x3_gru_zr2(const void* net, const void* x_rest, int x_rest_stride, int c_rest, const void* wpack,
+                       const float* bias_zr, const float* glo_zr, const void* inp_pre, void* z_out, void* rnet_out,
+                       int n, int h, int w, gs_stream_t stream);
 int gs_conv3x3_gru_zr(const void* hx, int hx_stride, int c_in, const void* wpack, const float* bias_zr,
                       const float* glo_zr, const void* inp_pre, void* z_out, void* rnet_out, int n, int h, int w,
                       gs_stream_t stream);
