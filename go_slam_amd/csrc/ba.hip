@@ -490,7 +490,11 @@ __global__ __launch_bounds__(256) void ba_update_kernel(
   }
   const int m = blockIdx.y;
   const int p = blockIdx.x * 256 + tid;
-  if (p >= hw || m >= w.hdr[0]) return;
+  if (p >= hw) return;
+  if (m >= w.hdr[0]) {                     // eta had more rows than the graph has depth keyframes (status word 1):
+    dz[(size_t)m * hw + p] = 0.0f;         // the surplus rows of dz are defined (zero), not left as allocated
+    return;
+  }
   const int eb = w.ent_ptr[m], ee = w.ent_ptr[m + 1];
   float dw = 0.f;
   for (int idx = eb; idx < ee; ++idx) {

@@ -454,6 +454,24 @@ __global__ __launch_bounds__(256) void motion_features_kernel(const float2* __re
   reinterpret_cast<half4m*>(out)[t] = o;
 }
 
+// damping rows of a BA call (reference src/factor_graph.py:228,244): damping_buf[uniq] = eta, then
+// out = scale * damping_buf[index] + eps -- index_put + gather + mul + add in one pass.  inv[k] = the row of `eta` that
+// belongs to frame index[k], or -1 if the operator produced none for it this update (its buffered value is used).
+__global__ __launch_bounds__(256) void damping_rows_kernel(const float* __restrict__ eta, const int* __restrict__ inv,
+                                                           const int64_t* __restrict__ index,
+                                                           float* __restrict__ damping_buf, float* __restrict__ out,
+                                                           int hw, float scale, float eps, size_t total) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int k = (int)(t / hw), p = (int)(t - (size_t)k * hw);
+  const int m = inv[k];
+  float* slot = damping_buf + (size_t)index[k] * hw + p;
+  float v;
+  if (m >= 0) { v = eta[(size_t)m * hw + p]; *slot = v; }
+  else v = *slot;
+  out[t] = scale * v + eps;
+}
+
 // target = coords1 + delta (kept as [E,h,w,2] state) and the BA-layout copies target/weight [E,2,h,w]
 __global__ __launch_bounds__(256) void ba_inputs_kernel(const float2* __restrict__ coords1, const float2* __restrict__ delta,
                                                         const float2* __restrict__ weight, float2* __restrict__ target,
@@ -495,5 +513,17 @@ extern "C" int gs_ba_inputs(const float* coords1, const float* delta, const floa
       (const float2*)coords1, (const float2*)delta, (const float2*)weight, (float2*)target, ba_target, ba_weight,
       h * w, total);
   GS_CHECK_LAUNCH("ba_inputs");
+  return GS_OK;
+}
+
+extern "C" int gs_damping_rows(const float* eta, const int* inv, const int64_t* index, float* damping_buf, float* out,
+                               int n_rows, int hw, float scale, float eps, gs_stream_t stream) {
+  GS_REQUIRE(inv && index && damping_buf && out, "damping_rows: null pointer");
+  GS_REQUIRE(n_rows >= 0 && hw > 0, "damping_rows: bad shape");
+  if (n_rows == 0) return GS_OK;
+  const size_t total = (size_t)n_rows * hw;
+  damping_rows_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(eta, inv, index, damping_buf, out,
+                                                                                       hw, scale, eps, total);
+  GS_CHECK_LAUNCH("damping_rows");
   return GS_OK;
 }

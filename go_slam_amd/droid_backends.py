@@ -84,9 +84,10 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
             tables["key"] = key
             tables["ii"], tables["jj"] = ii, jj              # keep the addresses in the key alive
     dx = torch.empty(P, 6, dtype=torch.float32, device=dev)
-    # zeros: depth rows the kernels skip (only when `eta` has more rows than the graph has depth keyframes, status [1])
-    # must not hand uninitialised memory to the caller
-    dz = None if motion_only else torch.zeros(M, hw, dtype=torch.float32, device=dev)
+    # (depth rows the kernels skip -- only when `eta` has more rows than the graph has depth keyframes, status [1] -- are
+    # zeroed by ba_update_kernel itself; with zero iterations nothing runs, hence the explicit zeros then)
+    dz = None if motion_only else (torch.empty if int(iterations) > 0 else torch.zeros)(M, hw, dtype=torch.float32,
+                                                                                      device=dev)
     status = _ba_status.get(dev.index)
     if status is None:
         status = _ba_status[dev.index] = torch.zeros(4, dtype=torch.int32, device=dev)

@@ -83,7 +83,14 @@ class FactorGraph:
             c["jj"] = torch.cat([jin[m], jj_c]).to(dev)
         else:
             c["ii"], c["jj"] = self.ii.contiguous(), self.jj.contiguous()
-        c["damping_index"] = torch.unique(torch.cat([torch.arange(a0, a1), ii_all]), sorted=True).to(dev)
+        dindex = torch.unique(torch.cat([torch.arange(a0, a1), ii_all]), sorted=True)
+        c["damping_index"] = dindex.to(dev)
+        # row of the operator's eta output (one per unique source keyframe of the ACTIVE edges) for every damping row
+        uniq = torch.unique(ii_c, sorted=True)
+        pos = torch.searchsorted(uniq, dindex).clamp_(max=max(uniq.numel() - 1, 0))
+        inv = torch.where(uniq[pos] == dindex, pos, torch.full_like(pos, -1)) if uniq.numel() else torch.full_like(dindex, -1)
+        c["damping_inv"] = inv.to(torch.int32).to(dev)
+        c["uniq_host"] = uniq
         self._eidx = c
         return c
 
@@ -367,7 +374,11 @@ class FactorGraph:
             self.net, delta, weight, damping, upmask = self.update_op(
                 self.net, self.inp, corr, motion, self.ii, self.jj, seg=seg)
 
-        self.damping[seg["uniq"]] = damping.float()
+        fuse_damping = fused and damping.dtype == torch.float32 and damping.is_contiguous() and \
+            self.damping.is_contiguous() and damping.shape[1] == idx["uniq_host"].numel()
+        if not fuse_damping:
+            self.damping[seg["uniq"]] = damping.float()
+        eta_rows = damping
         if fused and delta.dtype == torch.float32 and weight.dtype == torch.float32:
             # one pass: target = coords1 + delta, and the [E,2,h,w] BA operands written behind the
             # (cached, already transposed) inactive edges
@@ -390,7 +401,14 @@ class FactorGraph:
             target = target.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
             weight = weight.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
 
-        damping = 0.2 * self.damping[idx["damping_index"]].contiguous() + EPS
+        if fuse_damping:
+            # self.damping[uniq] = eta and 0.2 * self.damping[index] + EPS in one launch
+            damping = torch.empty(idx["damping_index"].numel(), ht, wd, device=self.device)
+            _lib.check(L.gs_damping_rows(_lib.ptr(eta_rows), _lib.ptr(idx["damping_inv"]), _lib.ptr(idx["damping_index"]),
+                                         _lib.ptr(self.damping), _lib.ptr(damping), damping.shape[0], ht * wd, 0.2,
+                                         float(EPS), st), "damping_rows")
+        else:
+            damping = 0.2 * self.damping[idx["damping_index"]].contiguous() + EPS
 
         # (the cached edge index also keeps the BA's index tables: built by the first call on this edge set, reused after)
         tables = idx.setdefault("ba_tables", {}) if (BA_TABLES and getattr(self.video, "ba_accepts_tables", False)) else None

@@ -265,6 +265,12 @@ int gs_gru_glo_fused(const void* net, int net_stride, const void* w_pack, const 
                      const void* wr, const void* wq, const float* bz, const float* br, const float* bq, float* gzr,
                      float* gq, int n, int hw, void* workspace, size_t workspace_bytes, gs_stream_t stream);
 
+/* FactorGraph.update's damping rows (src/factor_graph.py:228,244): damping_buf[index[k]] = eta[inv[k]] where
+ * inv[k] >= 0, then out[k] = scale * damping_buf[index[k]] + eps, rows of hw floats; eta [*,hw] (may be NULL when no
+ * inv[k] >= 0), inv int32 [n_rows], index int64 [n_rows] (distinct frames), out [n_rows,hw].                  */
+int gs_damping_rows(const float* eta, const int* inv, const int64_t* index, float* damping_buf, float* out,
+                    int n_rows, int hw, float scale, float eps, gs_stream_t stream);
+
 /* DepthVideo.upsample -> cvx_upsample (src/depth_video.py:194-196, src/droid_net.py:9-23):
  * out[ix[n]] (f32 [*,8h,8w]) = convex 8x upsampling of disps[ix[n]] (f32 [*,h,w]) with the softmax
  * of mask f16 [m,576,h,w] (logical NCHW; mask_channels_last != 0: NHWC strides).  ix i64 [m] or

@@ -252,6 +252,28 @@ def test_conv3x3_head_kernel(built_lib, n_out, epi):
     torch.testing.assert_close(got2, ref2.permute(0, 2, 3, 1), rtol=2e-3, atol=2e-3)
 
 
+def test_damping_rows_kernel_equals_index_put_gather(built_lib):
+    """gs_damping_rows = `damping[uniq] = eta; out = 0.2 * damping[index] + EPS` (src/factor_graph.py:228,244), bit for
+    bit, incl. index rows the operator produced no eta for (they keep their buffered value)."""
+    from go_slam_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    hw, nbuf = 35 * 13, 20
+    buf = torch.rand(nbuf, hw, generator=g).to(dev)
+    uniq = torch.tensor([2, 3, 5, 9])
+    index = torch.tensor([1, 2, 3, 4, 5, 6, 9, 11])
+    eta = torch.rand(len(uniq), hw, generator=g).to(dev)
+    ref_buf = buf.clone()
+    ref_buf[uniq.to(dev)] = eta
+    ref = 0.2 * ref_buf[index.to(dev)] + 1e-7
+    pos = torch.searchsorted(uniq, index).clamp_(max=len(uniq) - 1)
+    inv = torch.where(uniq[pos] == index, pos, torch.full_like(pos, -1)).to(torch.int32).to(dev)
+    out = torch.empty(len(index), hw, device=dev)
+    _lib.check(_lib.lib().gs_damping_rows(_lib.ptr(eta), _lib.ptr(inv), _lib.ptr(index.to(dev)), _lib.ptr(buf), _lib.ptr(out),
+                                          len(index), hw, 0.2, 1e-7, _lib.stream_ptr(dev)), "damping_rows")
+    assert torch.equal(out, ref) and torch.equal(buf, ref_buf)
+
+
 @pytest.mark.parametrize("k_in,n_out,stride", [(196, 128, 196), (196, 128, 208), (128, 576, 128), (128, 128, 320)])
 def test_conv1x1_kernel_dense_and_strided_rows_many_blocks(built_lib, k_in, n_out, stride):
     """gs_conv1x1 through the C ABI on 20 x 30 x 40 maps (several 32-pixel blocks per wave of the persistent grid) with
