@@ -44,6 +44,13 @@ def test_edge_index_matches_reference_logic():
         if inac:
             assert torch.equal(c["sel"], torch.nonzero(m).reshape(-1))
         uniq, ix = torch.unique(g.ii, sorted=True, return_inverse=True)
+        # damping rows (gs_damping_rows): inv[k] = the operator's eta row for frame damping_index[k], -1 if it has none
+        inv = c["damping_inv"]
+        assert inv.dtype == torch.int32 and inv.numel() == dix.numel()
+        for k, f in enumerate(dix.tolist()):
+            hit = torch.nonzero(uniq == f).reshape(-1)
+            assert int(inv[k]) == (int(hit[0]) if hit.numel() else -1)
+        assert set(uniq.tolist()) <= set(dix.tolist())         # every eta row lands in the buffer through some k
         seg = c["seg"]
         assert torch.equal(seg["uniq"], uniq) and torch.equal(seg["ix"], ix)
         for s in range(seg["n"]):
