@@ -81,7 +81,9 @@ struct PpEpi {
   const _Float16* xb;          // EPI 2: second input source (channels >= split)
   int xsb, split;
   long long* dbg;              // tools only (gs_conv3x3_pp_probe): per-workgroup s_memtime stamps, nullptr in production
-  int variant;                 // tools only: bit 0 = no s_setprio around the MFMAs, bit 1 = read phase without masks
+  int variant;                 // tools only: bit 0 = no s_setprio around the MFMAs, bit 1 = read phase without masks,
+                               // bit 2 = no LDS-DMA in the main loop (stale operands), bit 3 = no fragment reads in the
+                               // main loop (stale fragments): what the schedule costs without that traffic (results wrong)
 };
 
 __device__ __forceinline__ void pp_stamp(long long* dbg, int slot) {
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
       // that the counted waits below stay compile-time constants.
       __builtin_amdgcn_sched_barrier(0);
       math([&]() {
+        if (ep.variant & 4) return;
         const int tw = tg + 3 < T ? tg + 3 : T - 1;
         issue_w(tw, (tg + 3) & 3);
         if (tap < NROUND) issue_patch(ck + 1 < nchunk ? ck + 1 : nchunk - 1, (ck + 1) & 1, tap, poff[tap]);
@@ -267,8 +270,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
       else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       PP_BAR();
       // ---- READ phase: fragments of tap tg + 1
-      if (tap < 8) read_frags(ck & 1, (tg + 1) & 3, tap + 1);
-      else if (ck + 1 < nchunk) read_frags((ck + 1) & 1, (tg + 1) & 3, 0);
+      if (!(ep.variant & 8)) {
+        if (tap < 8) read_frags(ck & 1, (tg + 1) & 3, tap + 1);
+        else if (ck + 1 < nchunk) read_frags((ck + 1) & 1, (tg + 1) & 3, 0);
+      }
       PP_LGKM0();
       PP_BAR();
     }

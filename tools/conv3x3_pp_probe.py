@@ -34,7 +34,7 @@ for name, (c, o) in LAYERS.items():
            "loop_ticks_per_phase": float(loop.mean()) / (2 * 9 * (c // 32)),
            "wg_ticks_mean": float((d[:, 3] - d[:, 0]).mean()), "wg_ticks_sum_over_span_x256": float((d[:, 3] - d[:, 0]).sum()) / span / 256}
     times = {}
-    for variant in (0, 1, 2, 3, 0, 1, 2, 3):
+    for variant in (0, 1, 2, 4, 8, 12, 0, 1, 2, 4, 8, 12):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(2):
             run(c, o, variant, None, x, wp, y, n, h, w)
@@ -43,5 +43,5 @@ for name, (c, o) in LAYERS.items():
             run(c, o, variant, None, x, wp, y, n, h, w)
         e.record(); torch.cuda.synchronize()
         times.setdefault(variant, []).append(round(s.elapsed_time(e) / 10 * 1e3, 1))
-    out["us_by_variant(0 base,1 noprio,2 nomask,3 both)"] = times
+    out["us_by_variant(0 base,1 noprio,2 nomask,4 no DMA in loop,8 no fragment reads in loop,12 neither)"] = times
     print(json.dumps(out))
