@@ -140,3 +140,31 @@ def test_conv7x7_c4_weight_image_by_lane_level_emulation():
     wk = img.permute(0, 1, 3, 2, 4)                                              # nh t lane s e
     # tap 7 of every kernel row (K = 32 ky + 28 .. 31 -> k-step 2 ky + 1, k-group 1, e = 4..7) is zero
     assert float(img[:, :, 1::2, 32:, 4:].abs().max()) == 0.0 and wk.shape[-2] == 14
+
+
+def _pp_emulator():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "emulate_conv3x3_pp.py")
+    spec = importlib.util.spec_from_file_location("emulate_conv3x3_pp", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_pingpong_kernel_schedule_and_data_path_by_emulation():
+    """tools/emulate_conv3x3_pp.py restates conv3x3_pp_kernel (the production convolution): (1) the LDS-DMA / counted-wait /
+    barrier schedule of both wave groups -- every fragment read must find its tap's weights and its chunk's patch
+    published by BOTH groups, no buffer refilled before its last reader -- for 1, 2, 4 and 10 channel chunks and both
+    tile widths; (2) every thread's index arithmetic (DMA sources incl. zero page and swizzle, fragment slots incl. the
+    image-boundary masks, MFMA operand layout, lane permutation, epilogue transpose) against F.conv2d on ragged shapes;
+    (3) the ds_read_b128 bank model: every pixel-fragment read conflict-free."""
+    E = _pp_emulator()
+    for tw in (16, 8):
+        assert set(E.bank_model(tw)) == {1}, "pixel-fragment reads must be conflict-free"
+        for nchunk in (1, 2, 4, 10):
+            problems = E.schedule(nchunk, tw)
+            assert not problems, problems[:4]
+    for args in ((2, 5, 19, 32, 40, 128, 16, 0), (3, 7, 10, 64, 64, 128, 8, 1)):
+        nan, err = E.check(*args)
+        assert nan == 0 and err < 1e-4, (args, nan, err)
