@@ -279,3 +279,43 @@ def test_instant_neus_checkpoint_contract():
     assert torch.equal(net.sdf_network.sdf_layer.weight, twin.sdf_network.sdf_layer.weight)
     assert torch.equal(net.realtime_bound, torch.tensor([[-1.0, 1.0]] * 3))
     assert (net.sdf_truncation, net.sdf_sparse_factor) == (0.16, 5)
+
+
+def test_wave_reduce_scatter_mapping_by_emulation():
+    """common.h gs_wave_reduce_scatter (the BA kernels' block sums): emulate the six lane-bit steps on a 64-lane wave --
+    a lane keeps the even or the odd element of each pair according to its lane bit and adds what its partner sends --
+    and check the documented result: lane L ends with the wave total of value index 64 j + bitrev6(L) in v[j], for the
+    two sizes the kernels use (90 and 42) and an odd one."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+
+    def bitrev6(x):
+        return int(f"{x:06b}"[::-1], 2)
+
+    for N in (90, 42, 7):
+        vals = rng.standard_normal((64, N))                 # vals[lane][index]
+        v = [list(vals[l]) for l in range(64)]
+        n = N
+        for mask in (32, 16, 8, 4, 2, 1):
+            nn = (n + 1) // 2
+            new = [[0.0] * nn for _ in range(64)]
+            for lane in range(64):
+                up = (lane & mask) != 0
+                partner = lane ^ mask
+                pup = (partner & mask) != 0
+                for i in range(nn):
+                    a = v[lane][2 * i]
+                    b = v[lane][2 * i + 1] if 2 * i + 1 < n else 0.0
+                    pa = v[partner][2 * i]
+                    pb = v[partner][2 * i + 1] if 2 * i + 1 < n else 0.0
+                    keep = b if up else a
+                    recv = pa if pup else pb                 # the partner sends what IT does not keep
+                    new[lane][i] = keep + recv
+            v, n = new, nn
+        total = vals.sum(0)
+        for lane in range(64):
+            for j in range(n):
+                idx = 64 * j + bitrev6(lane)
+                if idx < N:
+                    assert abs(v[lane][j] - total[idx]) < 1e-9, (N, lane, j)
+        assert n == (N + 63) // 64
