@@ -165,6 +165,7 @@ def test_pingpong_kernel_schedule_and_data_path_by_emulation():
         for nchunk in (1, 2, 4, 10):
             problems = E.schedule(nchunk, tw)
             assert not problems, problems[:4]
-    for args in ((2, 5, 19, 32, 40, 128, 16, 0), (3, 7, 10, 64, 64, 128, 8, 1)):
+    # (the last case is the 64-output-channel instantiation: 4 KB weight images, one 32-channel fragment per wave)
+    for args in ((2, 5, 19, 32, 40, 128, 16, 0), (3, 7, 10, 64, 64, 128, 8, 1), (2, 9, 21, 64, 64, 64, 16, 1)):
         nan, err = E.check(*args)
         assert nan == 0 and err < 1e-4, (args, nan, err)

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from go_slam_amd.droid_net import pack_conv3x3_weight  # noqa: E402
 
-BN, KG, WTAP, TS = 128, 4, 512, 72
+BN, KG, WTAP, TS = 128, 4, 512, 72      # the 128-channel instantiation (schedule / bank model); data_path derives its own
 
 
 def frag_lane(r):
@@ -173,6 +173,11 @@ def bank_model(TW):
 def data_path(x, xs, C, wt, n, H, W, TW, xcd=0):
     """x: flat float32 array [n*H*W*xs] (fp16 values); wt torch [O,C,3,3] half.  Returns y [n*H*W, O] float32."""
     O = wt.shape[0]
+    BN = 128 if O % 128 == 0 else 64          # pp_block_channels: the 64-channel instantiation for O % 128 != 0
+    WTAP, NJ = KG * BN, BN // 64
+    TS = 72 if NJ == 2 else 40
+    PIECES = NJ * 4
+    PXIT, NIT = 64 // PIECES, 32 // (64 // PIECES)
     TH, PW, NPX, NROUND, PSLOTS, ZSLOT = geometry(TW)
     wp = pack_conv3x3_weight(wt, 32).float().numpy().reshape(-1, 8)
     rows = n * H
@@ -218,7 +223,7 @@ def data_path(x, xs, C, wt, n, H, W, TW, xcd=0):
         def dma_w(tap_g, buf):
             wbuf[buf] = wp[wsrc + tap_g * WTAP: wsrc + (tap_g + 1) * WTAP]
 
-        acc = np.zeros((8, 64, 2, 4, 16), np.float32)
+        acc = np.zeros((8, 64, NJ, 4, 16), np.float32)
         dma_patch(0, 0)
         for t in range(3):
             dma_w(t, t)
@@ -239,12 +244,12 @@ def data_path(x, xs, C, wt, n, H, W, TW, xcd=0):
                     wm = (wv & 1) + 2 * grp2
                     wn = (wv >> 1) & 1
                     for s in range(2):
-                        A = np.zeros((2, 32, 16), np.float32)
+                        A = np.zeros((NJ, 32, 16), np.float32)
                         for lane in range(64):
                             r, kgl = lane & 31, lane >> 5
                             kg = 2 * s + kgl
-                            for j in range(2):
-                                A[j, r, 8 * kgl:8 * kgl + 8] = wb[kg * BN + wn * 64 + j * 32 + r]
+                            for j in range(NJ):
+                                A[j, r, 8 * kgl:8 * kgl + 8] = wb[kg * BN + wn * (BN // 2) + j * 32 + r]
                         for i in range(4):
                             B = np.zeros((32, 16), np.float32)
                             for lane in range(64):
@@ -257,7 +262,7 @@ def data_path(x, xs, C, wt, n, H, W, TW, xcd=0):
                                 if (dy == 0 and yy == 0) or (dy == 2 and yy == H - 1):
                                     s0 = s1 = ZSLOT
                                 B[r, 8 * kgl:8 * kgl + 8] = pp[s1 if s else s0]
-                            for j in range(2):
+                            for j in range(NJ):
                                 Cm = A[j] @ B.T
                                 for lane in range(64):
                                     col = lane & 31
@@ -272,17 +277,17 @@ def data_path(x, xs, C, wt, n, H, W, TW, xcd=0):
                 tile = np.zeros((32 * TS,), np.float32)
                 for lane in range(64):
                     r, kgl = lane & 31, lane >> 5
-                    for j in range(2):
+                    for j in range(NJ):
                         for g in range(4):
                             for e in range(4):
                                 tile[r * TS + j * 32 + 8 * g + 4 * kgl + e] = acc[wv, lane, j, i, 4 * g + e]
-                for it in range(4):
+                for it in range(NIT):
                     for lane in range(64):
-                        pxr, piece = it * 8 + (lane >> 3), lane & 7
+                        pxr, piece = it * PXIT + lane // PIECES, lane & (PIECES - 1)
                         ty, tx = tile_pixel(TW, wm, i, pxr)
                         gv, gx = g0 + ty, tx0 + tx
                         if gv < rows and gx < W:
-                            c0 = nb * BN + wn * 64 + piece * 8
+                            c0 = nb * BN + wn * (BN // 2) + piece * 8
                             y[gv * W + gx, c0:c0 + 8] = tile[pxr * TS + piece * 8: pxr * TS + piece * 8 + 8]
     return y
 
@@ -304,5 +309,6 @@ if __name__ == "__main__":
         for nchunk in (1, 2, 4, 10):
             pr = schedule(nchunk, TW)
             print(f"schedule TW={TW} nchunk={nchunk}:", "OK" if not pr else pr[:6])
-    for args in ((2, 5, 19, 32, 40, 128, 16, 0), (3, 7, 10, 64, 64, 128, 8, 1), (1, 33, 16, 32, 32, 256, 16, 1)):
+    for args in ((2, 5, 19, 32, 40, 128, 16, 0), (3, 7, 10, 64, 64, 128, 8, 1), (1, 33, 16, 32, 32, 256, 16, 1),
+                 (2, 9, 21, 64, 64, 64, 16, 1)):
         print("data path", args, check(*args))
