@@ -319,3 +319,20 @@ def test_wave_reduce_scatter_mapping_by_emulation():
                 if idx < N:
                     assert abs(v[lane][j] - total[idx]) < 1e-9, (N, lane, j)
         assert n == (N + 63) // 64
+
+
+def test_conv1x1_stage_row_arithmetic_is_exact():
+    """conv1x1.hip stages a wave's 32 dense pixel rows through LDS and finds the row of an 8-byte unit u with
+    (int)((u + 0.5f) * (1.0f / U)) instead of an integer division (U = K / 4 units per row): that must equal u // U for
+    every supported K and every unit of the 32-row chunk; and the stage's row stride (an odd number of 16-byte pieces)
+    must hold a row."""
+    import numpy as np
+    for K in range(4, 212, 4):
+        U = K // 4
+        u = np.arange(32 * U, dtype=np.int64)
+        inv = np.float32(1.0) / np.float32(U)
+        r = ((u.astype(np.float32) + np.float32(0.5)) * inv).astype(np.int64)
+        assert np.array_equal(r, u // U), K
+        pieces = (K + 7) // 8
+        stride_halves = 8 * (pieces | 1)
+        assert stride_halves >= K and (stride_halves // 8) % 2 == 1
