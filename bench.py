@@ -7,7 +7,14 @@ frontend's per-keyframe work unit = 6 x FactorGraph.update(iters=2, use_inactive
 the 1/8-resolution map size 60x80: reproject + 4-level corr lookup + UpdateModule (own implicit-GEMM
 3x3 convolutions with fused ConvGRU epilogues) + 2 Gauss-Newton dense-BA iterations + convex upsampling.  Inputs are resident in HBM before the
 timed region.  Tracking does not shard ("replicas only"), so --gpus N runs N
-independent replicas, one process per GPU, and `value` is their aggregate.
+independent replicas, one process per GPU, and `value` is their aggregate; the mapping legs
+(`neus_train`, `neus_train_weak`) shard their ray batch over the N ranks with RCCL collectives.
+
+Launching: under an external launcher (`python -m torch.distributed.run ... bench.py --gpus N`, WORLD_SIZE / RANK /
+LOCAL_RANK in the environment) every process is one rank.  Called plainly as `python bench.py --gpus N` with N > 1 and
+no WORLD_SIZE, the script re-executes itself under `torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1` and passes rank 0's JSON line through; `n_gpus` is the RCCL world size either way and
+`rccl_ranks` is the sum of ones the ranks all-reduced on their devices.
 
 Extra objects on the line: `roofline` for the time-dominant hand-written kernel (the update
 operator's implicit-GEMM 3x3 convolution, MFMA-bound: algorithmic FLOPs / launch time measured with
@@ -293,6 +300,47 @@ def cpu_baseline(sample_updates=1):
                       f"(oracle reproject+lookup+BA, UpdateModule fp32 on CPU torch {torch.__version__})"}
 
 
+def cpu_baseline_neus(n_rays=4096):
+    """Path M on the host cores, same ray distribution and sizes as the `neus_render` / `neus_train_weak` legs: the CPU
+    oracle's Renderer.render_batch_ray + InstantNeuS.forward (oracle/neus_oracle.py) for one 4096-ray x 72-sample
+    batch, and ONE mapper iteration (forward + losses + torch.autograd backward + clip + AdamW on the differentiable
+    restatement, oracle/neus_autograd.py) on the same batch.  kind "port": tiny-cuda-nn has no CPU path."""
+    from oracle import neus_autograd as NA, neus_oracle as NO
+    g = torch.Generator().manual_seed(43)
+    P = NO.make_params(43, grid_init=0.05)
+    o = torch.rand(n_rays, 3, generator=g) * 6 - 3
+    d = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=1)
+    gt = torch.rand(n_rays, generator=g) * 3.5 + 0.5
+    gt[torch.rand(n_rays, generator=g) < 0.1] = 0
+    col = torch.rand(n_rays, 3, generator=g)
+    pr = torch.rand(24, generator=g)
+    with torch.no_grad():
+        tic = time.perf_counter()
+        z, dist = NO.render_sample(o, d, gt, P["bound"], 24, 48, pr)
+        NO.neus_forward(o, d, z, dist, P)
+        t_render = time.perf_counter() - tic
+    names = ("grid", "sdf_w", "sdf_b", "color_B", "mlp")
+    Pd = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in P.items()}
+    Pd["variance"] = torch.tensor(float(P["variance"]), requires_grad=True)
+    params = [Pd[k] for k in names] + [Pd["variance"]]
+    opt = torch.optim.AdamW([{"params": params[1:], "lr": 1e-3}, {"params": params[:1], "lr": 1e-2}],
+                            betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    tic = time.perf_counter()
+    z, dist = NO.render_sample(o, d, gt, P["bound"], 24, 48, pr)
+    loss = NA.mapping_loss(NA.neus_forward_diff(o, d, z, dist, Pd), col, gt)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(params, 35.0)
+    opt.step()
+    t_train = time.perf_counter() - tic
+    cores = torch.get_num_threads()
+    return {"neus_render": {"value": n_rays / t_render, "unit": "rays/s", "cores": cores, "kind": "port",
+                            "sample": f"1 batch of {n_rays} rays x 72 samples, {t_render:.1f} s of CPU work (oracle "
+                                      "render_sample + neus_forward, fp32 torch on the host)"},
+            "neus_train": {"value": n_rays / t_train, "unit": "rays/s", "cores": cores, "kind": "port",
+                           "sample": f"1 mapper iteration on {n_rays} rays x 72 samples, {t_train:.1f} s of CPU work "
+                                     "(oracle forward + losses + torch.autograd backward + clip + AdamW)"}}
+
+
 CONV_LAYERS = (("gru_zr", 320, 256), ("gru_q", 320, 128), ("heads", 128, 384), ("corr_enc2", 128, 128))
 
 
@@ -329,6 +377,41 @@ def conv_roofline(device, E, ht, wd):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: one rank per GPU under torch.distributed.run on this node."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_only(world, rank):
+    """GS_BENCH_LAUNCH_ONLY=1: rendezvous check of the N > 1 launch path without touching a GPU (CPU test): every rank
+    joins a gloo group, all-reduces a one, rank 0 prints what the real run would put in n_gpus / rccl_ranks."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        ranks = int(t.item())
+        dist.destroy_process_group()
+    else:
+        ranks = 1
+    if rank == 0:
+        print(json.dumps({"launch_only": True, "n_gpus": world, "rccl_ranks": ranks}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -337,10 +420,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus reports the ranks that "
+              "actually run", file=sys.stderr)
     distributed = world > 1
+    if os.environ.get("GS_BENCH_LAUNCH_ONLY") == "1":
+        return launch_only(world, rank)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path)"
     # GS_BENCH_SMOKE_ONE_GPU=1: functional smoke test of the N>1 code path on a 1-GPU box (all ranks
     # on cuda:0, gloo instead of RCCL -- RCCL refuses two ranks on one device).  Never used for numbers.
@@ -356,6 +446,12 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+
+    rccl_ranks, backend = 1, "none"
+    if distributed:         # evidence that N ranks really exchange data on their devices
+        t = torch.ones(1, device=device)
+        dist.all_reduce(t)
+        rccl_ranks, backend = int(t.item()), dist.get_backend()
 
     video, update_op, graph, _ = build_state(device)
 
@@ -396,6 +492,7 @@ def main():
                                "E=75 edges, 6 updates/keyframe, iters=2, RGB-D depth prior, upsample on",
                    "parallelism": f"replicas x{world} (tracking does not shard)"},
         "updates_per_s": value * UPDATES_PER_KF, "state_finite": finite,
+        "rccl_ranks": rccl_ranks, "collective_backend": backend,
     }
     train = neus_train_bench(device, rank, world)      # collective: every rank takes part
     train_weak = neus_train_bench(device, rank, world, global_rays=4096 * world, scaling="weak")
@@ -434,7 +531,11 @@ def main():
         line["neus_render"] = neus_render_bench(device)
         line["roofline_other"].append(dict(line["neus_render"]["mlp_mfma"], bound="mfma"))
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(3)
+            line["cpu_baseline"] = cpu_baseline(2)
+            try:        # path M on the host cores (north_star: the render batches "alongside the reference's CPU path")
+                line["cpu_baseline"].update(cpu_baseline_neus())
+            except Exception as exc:
+                line["cpu_baseline"]["neus_error"] = repr(exc)
         print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()

@@ -51,12 +51,16 @@ __global__ __launch_bounds__(256) void map_grad_sqnorm_kernel(const _Float16* __
 }
 
 struct AdamArgs {
+  // segment 16: parameters whose gradient arrives as loss-scaled fp16 (the hash table, or ONE RANK'S SLICE of it)
   float* p; float* m; float* v; _Float16* p16;
-  const _Float16* g16; const float* g32;
-  size_t n16, n;                 // elements [0, n16) take their gradient from g16, [n16, n) from g32
+  const _Float16* g16; size_t n16;
+  // segment 32: parameters with fp32 gradients (colour MLP, SDF layer, colour embedding, variance)
+  float* pd; float* md; float* vd; _Float16* p16d;
+  const float* g32; size_t n32;
   float inv_scale16;
-  float lr16, lr32;              // learning rates of the two ranges (volume / network parameters)
+  float lr16, lr32;              // learning rates of the two segments (volume / network parameters)
   float beta1, beta2, eps, wd, bc1, bc2_sqrt;
+  const int* step_dev;           // != NULL: the step count lives on the device (graph replays), bc1 / bc2_sqrt from it
   const float* sqnorm; float max_norm;
 };
 
@@ -71,6 +75,11 @@ __device__ __forceinline__ void adam_one(float& p, float& m, float& v, float g, 
 __global__ __launch_bounds__(256) void map_adamw_kernel(AdamArgs A) {
   const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * 256;
+  if (A.step_dev) {
+    const float t = (float)*A.step_dev;
+    A.bc1 = 1.0f - powf(A.beta1, t);
+    A.bc2_sqrt = sqrtf(1.0f - powf(A.beta2, t));
+  }
   // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
   float coef = 1.0f;
   if (A.sqnorm) {
@@ -101,13 +110,17 @@ __global__ __launch_bounds__(256) void map_adamw_kernel(AdamArgs A) {
     reinterpret_cast<float4*>(A.v)[2 * i + 1] = make_float4(vv[4], vv[5], vv[6], vv[7]);
     if (A.p16) reinterpret_cast<half8*>(A.p16)[i] = h;
   }
-  for (size_t i = n8 * 8 + tid; i < A.n; i += stride) {
-    const bool lo = i < A.n16;
-    const float g = lo ? (float)A.g16[i] * s16 : A.g32[i - A.n16] * coef;
+  for (size_t i = n8 * 8 + tid; i < A.n16; i += stride) {      // (tail of a segment that is not a multiple of 8)
     float p = A.p[i], m = A.m[i], v = A.v[i];
-    adam_one(p, m, v, g, lo ? A.lr16 : A.lr32, A);
+    adam_one(p, m, v, (float)A.g16[i] * s16, A.lr16, A);
     A.p[i] = p; A.m[i] = m; A.v[i] = v;
     if (A.p16) A.p16[i] = (_Float16)p;
+  }
+  for (size_t i = tid; i < A.n32; i += stride) {
+    float p = A.pd[i], m = A.md[i], v = A.vd[i];
+    adam_one(p, m, v, A.g32[i] * coef, A.lr32, A);
+    A.pd[i] = p; A.md[i] = m; A.vd[i] = v;
+    if (A.p16d) A.p16d[i] = (_Float16)p;
   }
 }
 
@@ -128,6 +141,23 @@ extern "C" int gs_map_grad_sqnorm(const void* g16, size_t n16, float inv_scale16
   return GS_OK;
 }
 
+static int launch_adamw(AdamArgs A, int step, gs_stream_t stream) {
+  if (A.n16 + A.n32 == 0) return GS_OK;
+  if (!A.step_dev) {
+    A.bc1 = 1.0f - powf(A.beta1, (float)step);
+    A.bc2_sqrt = sqrtf(1.0f - powf(A.beta2, (float)step));
+  } else {
+    A.bc1 = A.bc2_sqrt = 1.0f;
+  }
+  const size_t work = A.n16 / 8 + A.n32;
+  unsigned blocks = (unsigned)((work + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks == 0) blocks = 1;
+  map_adamw_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(A);
+  GS_CHECK_LAUNCH("map_adamw");
+  return GS_OK;
+}
+
 extern "C" int gs_map_adamw(float* p, float* m, float* v, void* p16, const void* g16, size_t n16, float inv_scale16,
                             const float* g32, size_t n, float lr16, float lr32, float beta1, float beta2, float eps,
                             float weight_decay, int step, const float* sqnorm, float max_norm, gs_stream_t stream) {
@@ -135,18 +165,33 @@ extern "C" int gs_map_adamw(float* p, float* m, float* v, void* p16, const void*
   GS_REQUIRE(n16 <= n && n16 % 8 == 0 && step >= 1, "map_adamw: bad sizes (n16 must be a multiple of 8) or step");
   GS_REQUIRE((((size_t)p | (size_t)m | (size_t)v | (size_t)g16 | (size_t)p16) & 15) == 0,
              "map_adamw: buffers must be 16-byte aligned");
-  if (n == 0) return GS_OK;
   AdamArgs A;
-  A.p = p; A.m = m; A.v = v; A.p16 = (_Float16*)p16; A.g16 = (const _Float16*)g16; A.g32 = g32;
-  A.n16 = n16; A.n = n; A.inv_scale16 = inv_scale16; A.lr16 = lr16; A.lr32 = lr32;
+  A.p = p; A.m = m; A.v = v; A.p16 = (_Float16*)p16; A.g16 = (const _Float16*)g16; A.n16 = n16;
+  A.pd = p + n16; A.md = m + n16; A.vd = v + n16; A.p16d = p16 ? (_Float16*)p16 + n16 : nullptr;
+  A.g32 = g32; A.n32 = n - n16;
+  A.inv_scale16 = inv_scale16; A.lr16 = lr16; A.lr32 = lr32;
   A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.wd = weight_decay;
-  A.bc1 = 1.0f - powf(beta1, (float)step);
-  A.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
-  A.sqnorm = sqnorm; A.max_norm = max_norm;
-  const size_t work = n16 / 8 + (n - n16);
-  unsigned blocks = (unsigned)((work + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  map_adamw_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(A);
-  GS_CHECK_LAUNCH("map_adamw");
-  return GS_OK;
+  A.step_dev = nullptr; A.sqnorm = sqnorm; A.max_norm = max_norm;
+  return launch_adamw(A, step, stream);
+}
+
+// The two segments given separately: `*16` = one contiguous run of table entries (the whole table, or the slice a rank
+// owns when the optimiser state is sharded over the ranks of a node), `*d` = the dense parameters.  `step_dev` (device
+// int32, >= 1) replaces `step` when non-NULL, so a captured graph replays with the right bias corrections.
+extern "C" int gs_map_adamw_seg(float* p, float* m, float* v, void* p16, const void* g16, size_t n16,
+                                float inv_scale16, float* pd, float* md, float* vd, void* p16d, const float* g32,
+                                size_t n32, float lr16, float lr32, float beta1, float beta2, float eps,
+                                float weight_decay, int step, const int* step_dev, const float* sqnorm, float max_norm,
+                                gs_stream_t stream) {
+  GS_REQUIRE((n16 == 0 || (p && m && v && g16)) && (n32 == 0 || (pd && md && vd && g32)), "map_adamw_seg: null pointer");
+  GS_REQUIRE(step_dev || step >= 1, "map_adamw_seg: step must be >= 1");
+  GS_REQUIRE((((size_t)p | (size_t)m | (size_t)v | (size_t)g16 | (size_t)p16) & 15) == 0,
+             "map_adamw_seg: table-segment buffers must be 16-byte aligned");
+  AdamArgs A;
+  A.p = p; A.m = m; A.v = v; A.p16 = (_Float16*)p16; A.g16 = (const _Float16*)g16; A.n16 = n16;
+  A.pd = pd; A.md = md; A.vd = vd; A.p16d = (_Float16*)p16d; A.g32 = g32; A.n32 = n32;
+  A.inv_scale16 = inv_scale16; A.lr16 = lr16; A.lr32 = lr32;
+  A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.wd = weight_decay;
+  A.step_dev = step_dev; A.sqnorm = sqnorm; A.max_norm = max_norm;
+  return launch_adamw(A, step, stream);
 }

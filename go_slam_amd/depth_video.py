@@ -35,6 +35,7 @@ class DepthVideo:
         self.map_ht, self.map_wd = mh, mw
         self.ht, self.wd = (cfg["cam"]["H_out"], cfg["cam"]["W_out"]) if self.cfg is not None else (8 * mh, 8 * mw)
         self.stereo = stereo
+        self._shared = shared                 # buffers visible to other processes: locked sections end with a stream sync
         # keyframe count and the cross-process flags (src/depth_video.py:17-25).  The reference creates them after
         # run.py:57 set the start method to "spawn" (HIP / CUDA tensors cannot cross a fork); taking them from the
         # spawn context here makes the object picklable into spawned workers whatever the global default is.
@@ -160,11 +161,22 @@ class DepthVideo:
 
     def normalize(self):
         """unit mean disparity over the keyframes so far; translations scale with it (src/depth_video.py:198-205)"""
-        n = self._count()
-        s = self.disps[:n].mean()
-        self.disps[:n] /= s
-        self.poses[:n, :3] *= s
-        self.dirty[:n] = True
+        with self.get_lock():
+            n = self._count()
+            s = self.disps[:n].mean()
+            self.disps[:n] /= s
+            self.poses[:n, :3] *= s
+            self.dirty[:n] = True
+            self._finish_locked_section()
+
+    def _finish_locked_section(self):
+        """The kernels are asynchronous: when the buffers are shared with other processes (the reference's tracking /
+        BA / mapping workers), the work enqueued under a lock has to be COMPLETE before the lock is released, or the
+        next holder reads poses / disparities that are still being written.  The reference gets this implicitly from
+        the blocking host round trips inside its `ba`; here the section ends with one stream synchronisation.  The
+        single-process form (benches, kernel tests) stays fully asynchronous."""
+        if self._shared:
+            torch.cuda.current_stream(self.device).synchronize()
 
     @staticmethod
     def format_indices(ii, jj, device="cuda"):
@@ -220,10 +232,14 @@ class DepthVideo:
 
     def ba(self, target, weight, eta, ii, jj, t0=1, t1=None, iters=2, lm=1e-4, ep=0.1,
            motion_only=False, ba_type=None, tables=None):
-        """dense bundle adjustment (src/depth_video.py:257-269).  `tables`: see droid_backends.ba."""
-        if t1 is None:
-            t1 = max(int(ii.max()), int(jj.max())) + 1
-        out = droid_backends.ba(self.poses, self.disps, self.intrinsics[0].contiguous(), self.disps_sens,
-                                target, weight, eta, ii, jj, t0, t1, iters, lm, ep, motion_only, tables=tables)
-        self.disps.clamp_(min=0.001)
+        """dense bundle adjustment (src/depth_video.py:257-269), under the reference's lock: the keyframe lock, or the
+        'dense' / 'loop' BA lock when `ba_type` names one (`:259-260`).  `tables`: see droid_backends.ba."""
+        lock = self.get_lock() if ba_type is None else self.get_ba_lock(ba_type)
+        with lock:
+            if t1 is None:
+                t1 = max(int(ii.max()), int(jj.max())) + 1
+            out = droid_backends.ba(self.poses, self.disps, self.intrinsics[0].contiguous(), self.disps_sens,
+                                    target, weight, eta, ii, jj, t0, t1, iters, lm, ep, motion_only, tables=tables)
+            self.disps.clamp_(min=0.001)
+            self._finish_locked_section()
         return out

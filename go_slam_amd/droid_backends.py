@@ -72,6 +72,7 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
     L = _lib.lib()
     need = L.gs_ba_workspace_bytes(E, P, M, nbuf, hw)
     flags = 0
+    new_key = None
     if tables is None:
         ws = _workspace(dev, need + 256)
     else:
@@ -81,8 +82,8 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
             flags = 1                                        # GS_BA_REUSE_TABLES
         else:
             ws = tables["workspace"] = torch.empty(need + 256, dtype=torch.uint8, device=dev)
-            tables["key"] = key
-            tables["ii"], tables["jj"] = ii, jj              # keep the addresses in the key alive
+            tables.pop("key", None)                          # set only once the tables have actually been built
+            new_key = key
     dx = torch.empty(P, 6, dtype=torch.float32, device=dev)
     # (depth rows the kernels skip -- only when `eta` has more rows than the graph has depth keyframes, status [1] -- are
     # zeroed by ba_update_kernel itself; with zero iterations nothing runs, hence the explicit zeros then)
@@ -98,6 +99,9 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
                         E, M, nbuf, ht, wd, _lib.ptr(dx), _lib.ptr(dz), _lib.ptr(status),
                         _lib.ptr(ws), ws.numel(), flags, _lib.stream_ptr(dev))
     _lib.check(rc, "droid_backends.ba")
+    if new_key is not None:                                  # only a call that went through owns valid tables
+        tables["key"] = new_key
+        tables["ii"], tables["jj"] = ii, jj                  # keep the addresses in the key alive
     if BA_CHECK:
         st = ba_status(dev)
         if st["depth_rows_mismatch"]:

@@ -180,6 +180,15 @@ int gs_map_grad_sqnorm(const void* g16, size_t n16, float inv_scale16, const flo
 int gs_map_adamw(float* p, float* m, float* v, void* p16, const void* g16, size_t n16, float inv_scale16,
                  const float* g32, size_t n, float lr16, float lr32, float beta1, float beta2, float eps,
                  float weight_decay, int step, const float* sqnorm, float max_norm, gs_stream_t stream);
+/* gs_map_adamw_seg: the same update with the two ranges given separately -- (p, m, v, p16, g16, n16) one contiguous
+ * run of table entries: the whole table, or the 1/G slice a rank owns when the optimiser state is sharded over the G
+ * ranks of a node (reduce-scatter of the table gradient -> this call on the slice -> all-gather of p16); (pd, md, vd,
+ * p16d, g32, n32) the dense parameters.  `step_dev` (device int32 >= 1; may be NULL) overrides `step`, so a captured
+ * hipGraph replays with the right bias corrections.  n16 need not be a multiple of 8; table pointers 16-byte aligned. */
+int gs_map_adamw_seg(float* p, float* m, float* v, void* p16, const void* g16, size_t n16, float inv_scale16,
+                     float* pd, float* md, float* vd, void* p16d, const float* g32, size_t n32, float lr16, float lr32,
+                     float beta1, float beta2, float eps, float weight_decay, int step, const int* step_dev,
+                     const float* sqnorm, float max_norm, gs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -50,13 +50,16 @@ def test_ba_at_benchmark_shapes_matches_oracle(db, O, dev, shape, rgbd, motion_o
                 motion_only)
     torch.cuda.synchronize()
     assert float(ref[0].abs().max()) > 1e-4, "degenerate problem"
-    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=1e-3, atol=2e-6)
-    torch.testing.assert_close(pg.cpu(), po, rtol=0, atol=1e-5)
+    # dx rtol 1e-4 / atol 1e-6 vs the fp64-accumulated oracle.  Measured at these shapes
+    # (tools/ba_error_report.py, profiles/r03_ba_error.json): |dx error| <= 5.7e-7 on |dx| <= 4.5e-2 (relative L2
+    # 1.5e-5 ... 5e-5), |dz error| <= 2e-6 on |dz| <= 0.36 (relative L2 <= 3e-5) after two iterations.
+    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(pg.cpu(), po, rtol=0, atol=2e-6)
     if motion_only:
         assert out[1] is None and torch.equal(dg.cpu(), prob["disps"])
     else:
-        torch.testing.assert_close(out[1].cpu(), ref[1], rtol=2e-3, atol=1e-5)
-        torch.testing.assert_close(dg.cpu(), do, rtol=0, atol=1e-5)
+        torch.testing.assert_close(out[1].cpu(), ref[1], rtol=1e-4, atol=4e-6)
+        torch.testing.assert_close(dg.cpu(), do, rtol=0, atol=4e-6)
 
 
 @pytest.mark.parametrize("shape,n", [("S480", 3), ("Rep", 4)])
@@ -203,3 +206,233 @@ def test_global_ba_step_matches_oracle_pipeline(built_lib, O, dev):
     assert float((po[1:num_kf] - poses0[1:num_kf]).abs().max()) > 1e-4, "the step must move the poses"
     torch.testing.assert_close(video.poses.cpu(), po, rtol=0, atol=5e-5)
     torch.testing.assert_close(video.disps.cpu(), do, rtol=0, atol=5e-5)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Path M (mapping) at the BASELINE batch sizes: 4096 rays x 72 samples per render batch (configs[2]; the reference's
+# own mapper batch is 4400 pixels, configs/go_slam.yaml:20) and 32768 rays per mapper step (configs[4]).  This is
+# where the small-batch tests of tests/test_neus_gpu.py cannot reach: ~480 fp16 packed-atomic contributions per
+# coarse-level table entry under loss scale 128, long runs of equal cells in the wave-level pre-reduction of the
+# table gradient, the split-K reductions of the dense gradients, the fused loss kernel on 32768 rays.
+# --------------------------------------------------------------------------------------------------------------------
+import json
+import os
+
+
+def _record(name, payload):
+    """Measured parity numbers go to gpurun_out/ (scratch; the summaries judged are copied to profiles/)."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "r03_pathM_parity.json")
+        cur = json.load(open(path)) if os.path.exists(path) else {}
+        cur[name] = payload
+        json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _bench_rays(n, seed):
+    """the ray distribution of bench.py's NeuS legs: origins inside the bound, 10 % rays without depth"""
+    g = torch.Generator().manual_seed(seed)
+    o = torch.rand(n, 3, generator=g) * 6 - 3
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+    gt = torch.rand(n, generator=g) * 3.5 + 0.5
+    gt[torch.rand(n, generator=g) < 0.1] = 0
+    col = torch.rand(n, 3, generator=g)
+    pr = torch.rand(24, generator=g)
+    return o, d, gt, col, pr
+
+
+def _load_neus(model, P):
+    with torch.no_grad():
+        model.sdf_network.encoding.encoding.params.copy_(P["grid"])
+        model.sdf_network.sdf_layer.weight.copy_(P["sdf_w"])
+        model.sdf_network.sdf_layer.bias.copy_(P["sdf_b"])
+        model.color_network._B.copy_(P["color_B"])
+        model.color_network.network.params.copy_(P["mlp"])
+        model.variance_network.variance.fill_(float(P["variance"]))
+
+
+def _rel(a, b):
+    return float((a - b).norm() / b.norm().clamp(min=1e-12))
+
+
+@pytest.fixture(scope="module")
+def NO():
+    from oracle import neus_oracle
+    return neus_oracle
+
+
+@pytest.fixture(scope="module")
+def N(built_lib):
+    import go_slam_amd.neus as neus
+    return neus
+
+
+@pytest.mark.parametrize("grid_init", [0.3, 1e-4])
+def test_neus_forward_at_4096_rays_matches_oracle(N, NO, dev, grid_init):
+    """Renderer.sample + InstantNeuS.forward (src/render.py:99-171, src/InstantNeuS.py:295-370) on ONE 4096-ray x 72
+    sample batch -- 294,912 points -- against the CPU oracle: all 9 outputs, in-bound masks exact."""
+    P = NO.make_params(71, grid_init=grid_init)                         # bound [-5, 5]^3 (room0.yaml:4)
+    P["rt_bound"] = torch.tensor([[-4.2, 4.6], [-4.4, 4.1], [-3.9, 4.4]])
+    o, d, gt, _, pr = _bench_rays(4096, seed=72)
+    zr, dr = NO.render_sample(o, d, gt, P["bound"], 24, 48, pr)
+    ref = NO.neus_forward(o, d, zr, dr, P)
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load_neus(model, P)
+    model.update_bound(P["rt_bound"])
+    R = N.Renderer(N_samples=24, N_surface=48)
+    with torch.no_grad():
+        z, dd = R.sample(o.to(dev), d.to(dev), P["bound"].to(dev), gt.to(dev), pr.to(dev))
+        assert torch.equal(z.cpu(), zr), "sample placement must be bit-exact"
+        out = model(o.to(dev), d.to(dev), z, dd)
+    c = {k: v.cpu() for k, v in out.items()}
+    assert set(c) == {"color", "depth", "depth_variance", "normal", "weight_sum", "sdf_variance", "sdf", "z_vals",
+                      "gradient_error"}
+    assert torch.equal(c["z_vals"], ref["z_vals"])
+    assert torch.equal(c["sdf"] == 100.0, ref["sdf"] == 100.0), "in-bound masks must agree exactly"
+    n_in = int((ref["sdf"] != 100.0).sum())
+    assert 0.3 * 4096 * 72 < n_in < 4096 * 72, n_in                     # both branches populated
+    torch.testing.assert_close(c["sdf"], ref["sdf"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(c["weight_sum"], ref["weight_sum"], rtol=0, atol=5e-4)
+    torch.testing.assert_close(c["depth"], ref["depth"], rtol=0, atol=2e-3)
+    torch.testing.assert_close(c["depth_variance"], ref["depth_variance"], rtol=1e-2, atol=2e-3)
+    torch.testing.assert_close(c["color"], ref["color"], rtol=0, atol=4e-3)
+    torch.testing.assert_close(c["normal"], ref["normal"], rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(c["gradient_error"], ref["gradient_error"], rtol=2e-3, atol=1e-5)
+    torch.testing.assert_close(c["sdf_variance"], ref["sdf_variance"])
+    _record(f"forward_4096_grid{grid_init:g}", {
+        "points_in_bound": n_in,
+        "max_abs": {k: float((c[k] - ref[k]).abs().max()) for k in ("sdf", "color", "depth", "normal", "weight_sum")}})
+
+
+@pytest.mark.parametrize("grad_dtype", [torch.float16, torch.float32])
+def test_training_gradients_at_4096_rays_match_autograd_oracle(N, NO, dev, grad_dtype):
+    """Mapper loss (src/mapping.py:96-132) -> gradient of every trained parameter at the reference's batch size,
+    HIP backward vs torch.autograd on the differentiable CPU restatement; both table-gradient modes (tiny-cuda-nn's
+    loss-scaled fp16 packed atomics -- the production mode -- and fp32 atomics).  The measured relative L2 error per
+    parameter group is recorded (gpurun_out/r03_pathM_parity.json -> profiles/)."""
+    from oracle import neus_autograd as NA
+    P = NO.make_params(81, grid_init=0.3)
+    P["rt_bound"] = torch.tensor([[-4.2, 4.6], [-4.4, 4.1], [-3.9, 4.4]])
+    o, d, gt, col, pr = _bench_rays(4096, seed=82)
+    z, dist = NO.render_sample(o, d, gt, P["bound"], 24, 48, pr)
+    Pd = {k: (v.clone().requires_grad_(True) if k in ("grid", "sdf_w", "sdf_b", "color_B", "mlp") else v)
+          for k, v in P.items()}
+    Pd["variance"] = torch.tensor(0.2, requires_grad=True)
+    ref_loss = NA.mapping_loss(NA.neus_forward_diff(o, d, z, dist, Pd), col, gt)
+    ref_loss.backward()
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load_neus(model, P)
+    model.update_bound(P["rt_bound"])
+    model.grid_grad_dtype = grad_dtype
+    out = model(o.to(dev), d.to(dev), z.to(dev), dist.to(dev))
+    loss = NA.mapping_loss({k: v for k, v in out.items()}, col.to(dev), gt.to(dev))
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), ref_loss.detach(), rtol=2e-3, atol=1e-4)
+    pairs = {
+        "grid": (model.sdf_network.encoding.encoding.params.grad, Pd["grid"].grad),
+        "sdf_w": (model.sdf_network.sdf_layer.weight.grad, Pd["sdf_w"].grad),
+        "sdf_b": (model.sdf_network.sdf_layer.bias.grad, Pd["sdf_b"].grad),
+        "color_B": (model.color_network._B.grad, Pd["color_B"].grad),
+        "mlp": (model.color_network.network.params.grad, Pd["mlp"].grad),
+        "variance": (model.variance_network.variance.grad.reshape(1), Pd["variance"].grad.reshape(1)),
+    }
+    report = {k: _rel(a.cpu().float(), b) for k, (a, b) in pairs.items()}
+    # the coarse levels are where the fp16 atomics pile up: level 0 has 17^3 entries for ~200 k in-bound points
+    gm = NO.grid_meta()
+    gg, gr = pairs["grid"][0].cpu().float().reshape(-1, 2), pairs["grid"][1].reshape(-1, 2)
+    per_level = []
+    for l in range(16):
+        a, b = int(gm["offset"][l]), int(gm["offset"][l]) + int(gm["size"][l])
+        per_level.append(_rel(gg[a:b], gr[a:b]))
+    _record(f"grad_4096_{str(grad_dtype).split('.')[-1]}", {"rel_l2": report, "grid_rel_l2_per_level": per_level,
+                                                           "loss": float(loss.detach()), "ref_loss": float(ref_loss.detach())})
+    for k, r in report.items():
+        assert r < 5e-3, (report, per_level)
+    assert max(per_level) < 2e-2, per_level
+
+
+def test_fused_mapper_step_at_32768_rays_matches_autograd_path(N, NO, dev):
+    """One mapper iteration on configs[4]'s 32768-ray batch (2.36 M points): MapTrainer.step_fused (loss kernel ->
+    HIP backward -> flat clip + AdamW) vs the autograd path (reference-style loss, torch clip_grad_norm_ + AdamW) on
+    identical models: same loss, same gradients, and the same parameters after the step."""
+    from go_slam_amd.neus.distributed import mapping_loss_sharded
+    from go_slam_amd.neus.mapper import MapTrainer
+    P = NO.make_params(91, grid_init=0.05)
+    o, d, gt, col, pr = _bench_rays(32768, seed=92)
+    args = [t.to(dev) for t in (o, d, col, gt, pr)]
+    pair = []
+    for fused in (False, True):
+        model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+        _load_neus(model, P)
+        if not fused:       # the referee accumulates the table gradient with fp32 atomics (exact to ~1e-5); the fused
+            model.grid_grad_dtype = torch.float32       # step uses tiny-cuda-nn's loss-scaled fp16 packed atomics
+        pair.append((model, MapTrainer(model, N.Renderer(N_samples=24, N_surface=48), fused=fused)))
+    (m_ref, t_ref), (m_fus, t_fus) = pair
+    assert t_fus.fused and not t_ref.fused
+    R = N.Renderer(N_samples=24, N_surface=48)
+    z, dd = R.sample(args[0], args[1], m_ref.bound, args[3], args[4])
+    loss_a, _ = mapping_loss_sharded(R.eval_points(args[0], args[1], z, dd, m_ref, None), args[2], args[3],
+                                     m_ref.compute_sdf_error)
+    loss_a.backward()
+    loss_f, grid16, inv_scale = t_fus.fused_gradients(*args)
+    torch.testing.assert_close(loss_f.float().cpu(), loss_a.detach().float().cpu(), rtol=2e-4, atol=1e-5)
+    ref_g = {"grid": m_ref.sdf_network.encoding.encoding.params.grad, "mlp": m_ref.color_network.network.params.grad,
+             "sdf_w": m_ref.sdf_network.sdf_layer.weight.grad, "sdf_b": m_ref.sdf_network.sdf_layer.bias.grad,
+             "cB": m_ref.color_network._B.grad, "var": m_ref.variance_network.variance.grad}
+    rep = {"grid": _rel(grid16.float().cpu() * inv_scale, ref_g["grid"].cpu())}
+    for k in ("mlp", "sdf_w", "sdf_b", "cB", "var"):
+        rep[k] = _rel(t_fus.flat.dense_grad(k).cpu(), ref_g[k].reshape(-1).cpu())
+    gm = NO.grid_meta()
+    gf, gr = (grid16.float().cpu() * inv_scale).reshape(-1, 2), ref_g["grid"].cpu().reshape(-1, 2)
+    per_level = [_rel(gf[int(gm["offset"][l]):int(gm["offset"][l]) + int(gm["size"][l])],
+                      gr[int(gm["offset"][l]):int(gm["offset"][l]) + int(gm["size"][l])]) for l in range(16)]
+    _record("fused_step_32768", {"rel_l2_vs_autograd_path_fp32_atomics": rep, "grid_rel_l2_per_level": per_level,
+                                 "loss": float(loss_f)})
+    # ~3800 fp16 additions per coarse-level entry: the packed-atomic sum carries fp16 accumulation error (as
+    # tiny-cuda-nn's does); same bar as the oracle-gradient tests: 0.5 % relative L2 per parameter group
+    assert all(v < 5e-3 for v in rep.values()), (rep, per_level)
+    for p_ in m_ref.parameters():
+        p_.grad = None
+    l_ref = t_ref.step(*args)
+    l_fus = t_fus.step(*args)
+    torch.testing.assert_close(l_fus.float().cpu(), l_ref.float().cpu(), rtol=2e-4, atol=1e-5)
+    pr_, pf_ = dict(m_ref.named_parameters()), dict(m_fus.named_parameters())
+    lr = {"sdf_network.encoding.encoding.params": 1e-2}
+    for k in ["sdf_network.encoding.encoding.params", "sdf_network.sdf_layer.weight", "sdf_network.sdf_layer.bias",
+              "color_network._B", "color_network.network.params", "variance_network.variance"]:
+        a, b = pf_[k].detach().float().cpu(), pr_[k].detach().float().cpu()
+        step = lr.get(k, 1e-3)
+        dlt = (a - b).abs()
+        # Adam's first step is +-lr per entry: an entry whose fp16-atomic sum lands on the other side of zero flips
+        off = dlt > (2e-5 + 2e-3 * b.abs())
+        assert float(off.float().mean()) < 2e-3 and float(dlt.max()) <= 2 * step * 1.01, \
+            (k, float(off.float().mean()), float(dlt.max()))
+
+
+def test_corr_volume_pyramid_at_S480_matches_oracle(db, O, dev):
+    """corr_volume_kernel + pooled levels at the bench map size (4800 x 4800 x 128 per edge) vs CorrBlock.corr /
+    avg_pool2d restated on the CPU (src/modules/corr.py:26-41,67-76), row-major AND tile8 layouts."""
+    import torch.nn.functional as F
+    ht, wd, _ = synth.SHAPES["S480"]
+    n = 2
+    f1 = synth.make_features(n, "S480", seed=121)
+    f2 = synth.make_features(n, "S480", seed=122)
+    ref = O.corr_pyramid(f1[None], f2[None])
+    for layout in (db.CORR_ROWMAJOR, db.CORR_TILE8):
+        out = db.corr_volume_pyramid(f1.to(dev), f2.to(dev), layout=layout)
+        if layout == db.CORR_TILE8:
+            out = [db.corr_untile8(out[l], ht >> l, wd >> l) if l < 2 else out[l] for l in range(4)]
+        o0, r0 = out[0].cpu().float(), ref[0].float()
+        assert o0.shape == r0.shape
+        diff = (o0 - r0).abs()
+        assert float(diff.max()) <= 2 ** -10 * max(1.0, float(r0.abs().max())) * 1.01
+        assert float((diff == 0).float().mean()) > 0.97
+        for l in range(1, 4):
+            low = out[l - 1].cpu()
+            hl, wl = low.shape[-2:]
+            pooled = F.avg_pool2d(low.reshape(-1, 1, hl, wl).float(), 2, 2).to(torch.float16)
+            assert torch.equal(out[l].cpu().reshape(-1, 1, hl // 2, wl // 2), pooled), f"level {l}"
+            torch.testing.assert_close(out[l].cpu().float(), ref[l].float().reshape(out[l].shape), rtol=0, atol=2e-3)

@@ -76,3 +76,28 @@ def test_two_rank_gradient_equals_single_process(tmp_path):
     assert abs(got["loss"] - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
     for a, b in zip(got["grads"], ref_grads):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment must start 2 ranks itself (the driver's N > 1
+    command shape is `torch.distributed.run ... bench.py --gpus N`, but a plain call must not silently measure one
+    GPU).  GS_BENCH_LAUNCH_ONLY=1 stops after the rendezvous, so this runs without a GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["GS_BENCH_LAUNCH_ONLY"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+    # and under an external launcher the script must NOT nest another one
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
