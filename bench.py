@@ -250,8 +250,11 @@ def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768, s
     return {"metric": "NeuS mapping train step rays/s (render + loss + backward + all-reduce + clip + AdamW)",
             "value": n / (ms * 1e-3), "unit": "rays/s", "global_rays": n, "rays_per_gpu": n // world, "ms_per_step": ms,
             "scaling": scaling, "fused_step": bool(getattr(tr, "fused", False)),
-            "allreduce_bytes": 0 if world == 1 else (2 * tr.flat.n16 + 4 * (tr.flat.n - tr.flat.n16) if tr.fused
-                                                     else 4 * sum(p.numel() for p in tr.train_params)),
+            "graph_replay": bool(getattr(tr, "graph", False)),
+            "collective_bytes_sent_per_rank": (tr.flat.collective_bytes() if tr.fused
+                                               else (0 if world == 1 else 4 * sum(p.numel() for p in tr.train_params))),
+            "exchange": "none" if world == 1 else ("reduce-scatter(fp16 table grad) + sharded AdamW + all-gather(fp16 "
+                                                   "table)" if tr.fused else "all-reduce(fp32 flat grad)"),
             "final_loss": float(loss)}
 
 

@@ -43,10 +43,7 @@ SIGNATURES = {
     "gs_conv1x1": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, c_int, c_int, ctypes.c_longlong, _P]),
     "gs_conv7x7_c4": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "gs_conv3x3_wpack_elems": (c_size_t, [c_int, c_int]),
-    "gs_conv3x3": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "gs_conv3x3_stacked": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "gs_conv3x3_pp": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    "gs_conv3x3_pp_probe": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "gs_conv3x3_bias_relu": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "gs_conv3x3_gru_zr": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gs_conv3x3_gru_zr2": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),

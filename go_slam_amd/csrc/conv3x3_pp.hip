@@ -32,8 +32,6 @@
 //    dummy 16-byte DMA from the zero page so that every wave's vmcnt arithmetic stays the same.
 #include "common.h"
 #include "conv3x3_common.h"
-#include <atomic>
-#include <stdlib.h>
 
 namespace {
 
@@ -80,19 +78,24 @@ struct PpEpi {
   _Float16* out1;              // EPI 1: r * net             [n*h*w, 128]
   const _Float16* xb;          // EPI 2: second input source (channels >= split)
   int xsb, split;
-  long long* dbg;              // tools only (gs_conv3x3_pp_probe): per-workgroup s_memtime stamps, nullptr in production
-  int variant;                 // tools only: bit 0 = no s_setprio around the MFMAs, bit 1 = read phase without masks,
-                               // bit 2 = no LDS-DMA in the main loop (stale operands), bit 3 = no fragment reads in the
-                               // main loop (stale fragments): what the schedule costs without that traffic (results wrong)
+  // Read by the PROBE instantiation only (built with -DGS_BUILD_PROBES for tools/conv3x3_pp_probe.py; the production
+  // instantiations contain no trace of them): per-workgroup s_memtime stamps, and A/B bits -- 1 = no s_setprio around
+  // the MFMAs, 2 = read phase without masks, 4 = no LDS-DMA in the main loop (stale operands), 8 = no fragment reads in
+  // the main loop (stale fragments): what the schedule costs without that traffic (results wrong on purpose).
+  long long* dbg;
+  int variant;
 };
 
+template <bool PROBE>
 __device__ __forceinline__ void pp_stamp(long long* dbg, int slot) {
-  if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 4 + slot] = (long long)__builtin_amdgcn_s_memtime();
+  if constexpr (PROBE) {
+    if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 4 + slot] = (long long)__builtin_amdgcn_s_memtime();
+  }
 }
 
 __device__ __forceinline__ float pp_sigm(float v) { return gs_sigmoid(v); }
 
-template <int TW, int EPI, int BN = 128>
+template <int TW, int EPI, int BN = 128, bool PROBE = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __restrict__ x, int xs, int C,
                                                             const half8* __restrict__ wpack, _Float16* __restrict__ y,
                                                             int ys, int H, int W, int rows, int tiles_x, int NB,
@@ -200,7 +203,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
       const int p = pbi + toff;                           // out of the chunk loop (72 VGPRs, spills at the 256 cap)
       int s0 = p * 4 + (kgl ^ ((p >> 2) & 3));            // channel group kgl (s = 0); group 2 + kgl is s0 ^ 2
       int s1 = s0 ^ 2;
-      if (!(ep.variant & 2) && ((dy == 0 && top[i]) || (dy == 2 && bot[i]))) {   // the row above / below belongs to another image
+      bool masked = (dy == 0 && top[i]) || (dy == 2 && bot[i]);     // the row above / below belongs to another image
+      if constexpr (PROBE) masked = masked && !(ep.variant & 2);
+      if (masked) {
         s0 = ZSLOT;
         s1 = ZSLOT;
       }
@@ -210,7 +215,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
   };
   // MATH phase body: 16 MFMAs; `between` (the LDS-DMA issue of this tap) is placed after the first four, so that its
   // address arithmetic issues in the shadow of running MFMAs instead of delaying the first one after the barrier
-  const bool prio = !(ep.variant & 1);
+  bool prio = true;
+  if constexpr (PROBE) prio = !(ep.variant & 1);
   auto math = [&](auto&& between) {
     if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
   };
 
   // ---- prologue: patch of chunk 0, weights of taps 0..2 ------------------------------------------------------------
-  pp_stamp(ep.dbg, 0);
+  pp_stamp<PROBE>(ep.dbg, 0);
 #pragma unroll
   for (int q = 0; q < NROUND; ++q) issue_patch(0, 0, q, poff[q]);
   issue_w(0, 0);
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
   issue_w(2, 2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PP_BAR();
-  pp_stamp(ep.dbg, 1);
+  pp_stamp<PROBE>(ep.dbg, 1);
   if (grp2 == 1) PP_BAR();                                // group 1 runs one phase behind from here on
   read_frags(0, 0, 0);
   PP_LGKM0();
@@ -258,7 +264,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
       // that the counted waits below stay compile-time constants.
       __builtin_amdgcn_sched_barrier(0);
       math([&]() {
-        if (ep.variant & 4) return;
+        if constexpr (PROBE) {
+          if (ep.variant & 4) return;
+        }
         const int tw = tg + 3 < T ? tg + 3 : T - 1;
         issue_w(tw, (tg + 3) & 3);
         if (tap < NROUND) issue_patch(ck + 1 < nchunk ? ck + 1 : nchunk - 1, (ck + 1) & 1, tap, poff[tap]);
@@ -270,7 +278,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
       else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       PP_BAR();
       // ---- READ phase: fragments of tap tg + 1
-      if (!(ep.variant & 8)) {
+      bool reads = true;
+      if constexpr (PROBE) reads = !(ep.variant & 8);
+      if (reads) {
         if (tap < 8) read_frags(ck & 1, (tg + 1) & 3, tap + 1);
         else if (ck + 1 < nchunk) read_frags((ck + 1) & 1, (tg + 1) & 3, 0);
       }
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
       PP_BAR();
     }
   }
-  pp_stamp(ep.dbg, 2);
+  pp_stamp<PROBE>(ep.dbg, 2);
   if (grp2 == 0) PP_BAR();                                // pairs with group 1's last barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped tail loads: they target LDS the epilogue reuses
   PP_BAR();
@@ -386,315 +396,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  pp_stamp(ep.dbg, 3);
+  pp_stamp<PROBE>(ep.dbg, 3);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// conv3x3_v3_kernel: the same tile, LDS layout, DMA scheme and epilogues with FOUR waves of 512 registers (one per SIMD)
-// instead of eight of 256.  A wave owns 128 pixels x 128 channels: 256 accumulator registers (AccVGPRs), 8 fragment
-// reads per 16 MFMAs (0.5 per MFMA; the two-group kernel: 0.75), and it overlaps its own LDS reads with its own MFMAs:
-// the fragments of k-step u + 1 are requested a quarter into the MFMAs of k-step u (two register sets), the buffer
-// hand-over barrier sits behind the first four MFMAs of the second k-step of a tap, so the matrix pipe has work queued
-// while the wave waits.  Opt-in (GOSLAM_CONV3X3_V3=1) until it has been measured against the two-group kernel.
-template <int TW, int EPI>
-__global__ __launch_bounds__(256, 1) void conv3x3_v3_kernel(const _Float16* __restrict__ x, int xs, int C,
-                                                            const half8* __restrict__ wpack, _Float16* __restrict__ y,
-                                                            int ys, int H, int W, int rows, int tiles_x, int NB,
-                                                            int xcd, PpEpi ep) {
-  constexpr int PP_BN = 128, PP_WTAP = PP_KG * PP_BN, PP_TS = 72;
-  constexpr int TH_ = 512 / TW, PW_ = TW + 2, NPX = (TH_ + 2) * PW_;
-  constexpr int NROUND = (NPX * PP_KG + 511) / 512;       // DMA rounds of 512 slots (two per thread) per patch
-  constexpr int PSLOTS = NROUND * 512;
-  constexpr int ZSLOT = NPX * PP_KG;
-  static_assert(PSLOTS > NPX * PP_KG, "the patch buffer needs at least one padding (zero) slot");
-  static_assert(NROUND <= 9, "one DMA round per tap");
-  extern __shared__ half8 smem[];                         // patch [2][PSLOTS] | weights [4][PP_WTAP]
-  half8* const pbuf = smem;
-  half8* const wbuf = smem + 2 * PSLOTS;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wv;                                      // pixel quarter of the 512-pixel tile
-  const int r = lane & 31, kgl = lane >> 5;
-  int tix, nb;
-  decode_block(blockIdx.x, gridDim.x / NB, NB, xcd, tix, nb);
-  const int tx0 = (tix % tiles_x) * TW;
-  const int g0 = (tix / tiles_x) * TH_;
-  const int nchunk = C / 32;
-  const int T = nchunk * 9;
-  const half8* wsrc = wpack + (size_t)nb * T * PP_WTAP;
-
-  int pb[4];
-  bool top[4], bot[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int ty, tx;
-    tile_pixel<TW, true>(wm, i, r, ty, tx);
-    pb[i] = ty * PW_ + tx;
-    const int yy = (g0 + ty) % H;
-    top[i] = yy == 0;
-    bot[i] = yy == H - 1;
-  }
-  int poff[NROUND][2];                                    // this thread's two patch slots per round
-#pragma unroll
-  for (int q = 0; q < NROUND; ++q)
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int s_ = q * 512 + hh * 256 + tid, p = s_ >> 2, ks = s_ & 3;
-      int off = -1;
-      if (p < NPX) {
-        const int kg = ks ^ ((p >> 2) & 3);
-        const int pr = p / PW_, pc = p - pr * PW_;
-        const int gv = g0 + pr - 1, gx = tx0 + pc - 1;
-        if (gv >= 0 && gv < rows && gx >= 0 && gx < W) off = (gv * W + gx) * 4 + kg;
-      }
-      poff[q][hh] = off;
-    }
-
-  float16v acc[4][4];                                     // [channel fragment j][pixel fragment i]
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.0f;
-  half8 fa[2][4], fb[2][4];                               // two fragment sets (one k-step each): weights, pixels
-
-  auto issue_patch = [&](int src_chunk, int buf, int q) {  // one 512-slot round of a patch: two slots per thread
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int off = poff[q][hh];
-      const void* src = (const void*)pp_zero_page;
-      if (off >= 0) {
-        const size_t pix = (size_t)(off >> 2);
-        const int c0 = src_chunk * 32 + (off & 3) * 8;
-        if constexpr (EPI == 1 || EPI == 2)
-          src = c0 < ep.split ? (const void*)(x + pix * xs + c0) : (const void*)(ep.xb + pix * ep.xsb + (c0 - ep.split));
-        else
-          src = (const void*)(x + pix * xs + c0);
-      }
-      pp_glds16(src, pbuf + buf * PSLOTS + q * 512 + hh * 256 + wv * 64);
-    }
-  };
-  auto issue_w = [&](int src_tap, int buf) {               // one tap's weight image: two pieces per thread
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-      pp_glds16(wsrc + (size_t)src_tap * PP_WTAP + hh * 256 + tid, wbuf + buf * PP_WTAP + hh * 256 + wv * 64);
-  };
-  // fragments of k-step s (16 of the chunk's 32 channels) of tap `tap`: 4 weight + 4 pixel fragments into set `set`
-  auto read_kstep = [&](int set, int pbuf_ix, int wbuf_ix, int tap, int s) {
-    const half8* wb = wbuf + wbuf_ix * PP_WTAP;
-    const half8* pp = pbuf + pbuf_ix * PSLOTS;
-    const int dy = tap / 3, toff = dy * PW_ + (tap % 3);
-    const int kg = 2 * s + kgl;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fa[set][j] = wb[kg * PP_BN + 32 * j + r];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      // (unlike the two-group kernel, the 72 slot addresses MAY be hoisted out of the chunk loop here: the wave has 256
-      // architectural VGPRs next to its 256 accumulators, and every VALU instruction in the loop delays an MFMA issue)
-      const int p = pb[i] + toff;
-      int sl = p * 4 + (kg ^ ((p >> 2) & 3));
-      if ((dy == 0 && top[i]) || (dy == 2 && bot[i])) sl = ZSLOT;     // the row above / below belongs to another image
-      fb[set][i] = pp[sl];
-    }
-  };
-  auto mfma_cols = [&](int set, int i0, int i1) {          // pixel fragments [i0, i1) x all 4 channel fragments
-#pragma unroll
-    for (int i = i0; i < i1; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][j], fb[set][i], acc[j][i], 0, 0, 0);
-  };
-
-  // ---- prologue: patch of chunk 0, weights of taps 0..2, fragments of (tap 0, k-step 0)
-  pp_stamp(ep.dbg, 0);
-#pragma unroll
-  for (int q = 0; q < NROUND; ++q) issue_patch(0, 0, q);
-  issue_w(0, 0);
-  issue_w(1, 1);
-  issue_w(2, 2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  PP_BAR();
-  pp_stamp(ep.dbg, 1);
-  read_kstep(0, 0, 0, 0, 0);
-
-  for (int ck = 0; ck < nchunk; ++ck) {
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int tg = ck * 9 + tap;
-      // ---- k-step 0 of tap tg (set 0): 16 MFMAs; in their shadow the loads for 3 taps ahead are issued and the
-      // fragments of k-step 1 are read into set 1.  One instruction stream: the scheduler is told to alternate
-      // (sched_group_barrier: 0x008 MFMA, 0x100 DS read, 0x020 VMEM read), since every instruction that issues between
-      // two MFMAs must fit into the 32 cycles the matrix pipe is busy with the first.
-      PP_LGKM0();
-      {
-        const int tw = tg + 3 < T ? tg + 3 : T - 1;       // past the end: clamped sources, buffers nobody reads any more
-        issue_w(tw, (tg + 3) & 3);
-        if (tap < NROUND) issue_patch(ck + 1 < nchunk ? ck + 1 : nchunk - 1, (ck + 1) & 1, tap);
-      }
-      read_kstep(1, ck & 1, tg & 3, tap, 1);
-      mfma_cols(0, 0, 4);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- k-step 1 (set 1): four MFMAs, the hand-over barrier behind them, then the reads of the next tap's k-step 0
-      // under the remaining twelve
-      PP_LGKM0();
-      mfma_cols(1, 0, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      // everything issued before this tap has landed (this wave's pieces); the barrier publishes it
-      if (tap < NROUND) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      PP_BAR();
-      if (tap < 8) read_kstep(0, ck & 1, (tg + 1) & 3, tap + 1, 0);
-      else if (ck + 1 < nchunk) read_kstep(0, (ck + 1) & 1, (tg + 1) & 3, 0, 0);
-      mfma_cols(1, 1, 4);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  pp_stamp(ep.dbg, 2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped tail loads target LDS the epilogue reuses
-  PP_BAR();
-
-  // ---- epilogue: [32 pixels][64 channels] at a time through a wave-private LDS tile (aliases patch buffer 0)
-  _Float16* tile = reinterpret_cast<_Float16*>(smem) + wv * 32 * PP_TS;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    // where this lane's output pieces go, and -- for the gate epilogues -- their operands for BOTH channel halves,
-    // requested now (four waves per CU: twice the loads per wave keep as many in flight as the eight-wave kernel has)
-    size_t pix4[4];
-    bool ok4[4];
-    half8 pi8[2][4], u8[2][4], v8[2][4];
-    const int piece = lane & 7;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int pxr = it * 8 + (lane >> 3);
-      int ty, tx;
-      tile_pixel<TW, true>(wm, i, pxr, ty, tx);
-      const int gv = g0 + ty, gx = tx0 + tx;
-      ok4[it] = gv < rows && gx < W;
-      pix4[it] = (size_t)gv * W + gx;
-      if constexpr (EPI == 1 || EPI == 2) {
-        const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          const int c8 = h2 * 64 + piece * 8;
-          pi8[h2][it] = z8; u8[h2][it] = z8; v8[h2][it] = z8;
-          if (ok4[it]) {
-            if constexpr (EPI == 1) {
-              if (ep.inp_pre) pi8[h2][it] = *reinterpret_cast<const half8*>(ep.inp_pre + pix4[it] * 384 + nb * 128 + c8);
-              if (nb == 1) u8[h2][it] = *reinterpret_cast<const half8*>(x + pix4[it] * xs + c8);          // net
-            } else {
-              if (ep.inp_pre) pi8[h2][it] = *reinterpret_cast<const half8*>(ep.inp_pre + pix4[it] * 384 + 256 + c8);
-              u8[h2][it] = *reinterpret_cast<const half8*>(ep.aux0 + pix4[it] * 128 + c8);               // z
-              v8[h2][it] = *reinterpret_cast<const half8*>(ep.aux1 + pix4[it] * 128 + c8);               // net
-            }
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {                      // channel halves of the 128-block
-      _Float16* yb = y + nb * PP_BN + h2 * 64;
-      const int c8 = h2 * 64 + piece * 8;
-      half8 (&pi4)[4] = pi8[h2];
-      half8 (&u4)[4] = u8[h2];
-      half8 (&v4)[4] = v8[h2];
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          half4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc[2 * h2 + jj][i][4 * g + e];
-          *reinterpret_cast<half4*>(tile + r * PP_TS + jj * 32 + 8 * g + 4 * kgl) = o;
-        }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int pxr = it * 8 + (lane >> 3);
-        if (ok4[it]) {
-          const half8 v = *reinterpret_cast<const half8*>(tile + pxr * PP_TS + piece * 8);
-          const size_t pix = pix4[it];
-          if constexpr (EPI == 0) {
-            *reinterpret_cast<half8*>(yb + pix * ys + piece * 8) = v;
-          } else if constexpr (EPI == 3) {
-            const float* bb = ep.bias + nb * PP_BN + c8;
-            half8 o;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = (_Float16)fmaxf((float)v[k] + bb[k], 0.0f);
-            *reinterpret_cast<half8*>(yb + pix * ys + piece * 8) = o;
-          } else if constexpr (EPI == 1) {
-            const int img = (int)(pix / ((size_t)H * W));
-            const half8 pi = pi4[it];
-            const float* bb = ep.bias + nb * 128 + c8;
-            const float* gg = ep.glo + (size_t)img * 256 + nb * 128 + c8;
-            half8 o;
-            if (nb == 0) {
-#pragma unroll
-              for (int k = 0; k < 8; ++k) o[k] = (_Float16)pp_sigm((float)v[k] + (float)pi[k] + bb[k] + gg[k]);
-              *reinterpret_cast<half8*>(ep.out0 + pix * 128 + c8) = o;
-            } else {
-              const half8 net = u4[it];
-#pragma unroll
-              for (int k = 0; k < 8; ++k)
-                o[k] = (_Float16)(pp_sigm((float)v[k] + (float)pi[k] + bb[k] + gg[k]) * (float)net[k]);
-              *reinterpret_cast<half8*>(ep.out1 + pix * 128 + c8) = o;
-            }
-          } else {
-            const int img = (int)(pix / ((size_t)H * W));
-            const half8 pi = pi4[it], zz = u4[it], nn = v4[it];
-            const float* bb = ep.bias + c8;
-            const float* gg = ep.glo + (size_t)img * 128 + c8;
-            half8 o;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const float a_ = (float)v[k] + (float)pi[k] + bb[k] + gg[k];
-              const float q = gs_tanh(a_);
-              const float zf = (float)zz[k];
-              o[k] = (_Float16)((1.0f - zf) * (float)nn[k] + zf * q);
-            }
-            *reinterpret_cast<half8*>(ep.out0 + pix * 128 + c8) = o;
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  pp_stamp(ep.dbg, 3);
-}
-
-// GOSLAM_CONV3X3_V3=1: the four-wave kernel for the 128-channel-block layers
-int pp_use_v3() {
-  static std::atomic<int> cached{-1};
-  int v = cached.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = getenv("GOSLAM_CONV3X3_V3");
-    v = (e && atoi(e) != 0) ? 1 : 0;
-    cached.store(v, std::memory_order_relaxed);
-  }
-  return v;
-}
-
-template <int TW, int EPI, int BN = 128>
+template <int TW, int EPI, int BN = 128, bool PROBE = false>
 int launch_pp(const void* x, int x_stride, int c_in, const void* wpack, void* y, int y_stride, int n_out, int n, int h,
               int w, int xcd, hipStream_t st, PpEpi ep = PpEpi()) {
   constexpr int PP_BN = BN, PP_WTAP = PP_KG * BN;
@@ -702,25 +407,14 @@ int launch_pp(const void* x, int x_stride, int c_in, const void* wpack, void* y,
   constexpr int PSLOTS = ((NPX * PP_KG + 511) / 512) * 512;
   constexpr size_t lds = (size_t)(2 * PSLOTS + 4 * PP_WTAP + (BN == 64 ? 256 : 0)) * sizeof(half8);
   static GsLdsLimit limit;
-  if (int rc = limit.raise((const void*)conv3x3_pp_kernel<TW, EPI, BN>, lds, "conv3x3_pp")) return rc;
+  if (int rc = limit.raise((const void*)conv3x3_pp_kernel<TW, EPI, BN, PROBE>, lds, "conv3x3_pp")) return rc;
   const long long rows = (long long)n * h;
   GS_REQUIRE(rows * w < (1ll << 29), "conv3x3_pp: too many pixels");
   const int tiles_x = gs_cdiv(w, TW), tiles_y = gs_cdiv((int)rows, 512 / TW);
   const int NB = n_out / PP_BN;
   const long long blocks = (long long)tiles_x * tiles_y * NB;
   GS_REQUIRE(blocks < (1ll << 31), "conv3x3_pp: too many workgroups");
-  if constexpr (BN == 128) {
-    if (pp_use_v3()) {
-      static GsLdsLimit limit3;
-      if (int rc = limit3.raise((const void*)conv3x3_v3_kernel<TW, EPI>, lds, "conv3x3_v3")) return rc;
-      conv3x3_v3_kernel<TW, EPI><<<dim3((unsigned)blocks), 256, lds, st>>>(
-          (const _Float16*)x, x_stride, c_in, (const half8*)wpack, (_Float16*)y, y_stride, h, w, (int)rows, tiles_x, NB,
-          xcd, ep);
-      GS_CHECK_LAUNCH("conv3x3_v3");
-      return GS_OK;
-    }
-  }
-  conv3x3_pp_kernel<TW, EPI, BN><<<dim3((unsigned)blocks), 512, lds, st>>>(
+  conv3x3_pp_kernel<TW, EPI, BN, PROBE><<<dim3((unsigned)blocks), 512, lds, st>>>(
       (const _Float16*)x, x_stride, c_in, (const half8*)wpack, (_Float16*)y, y_stride, h, w, (int)rows, tiles_x, NB, xcd,
       ep);
   GS_CHECK_LAUNCH("conv3x3_pp");
@@ -845,15 +539,20 @@ extern "C" int gs_conv3x3_bias_relu(const void* x, int x_stride, int c_in, const
                         ep);
 }
 
-// Tools only (tools/conv3x3_pp_probe.py): gs_conv3x3_pp with per-workgroup s_memtime stamps (dbg: int64 [workgroups][4] =
-// start, prologue done, main loop done, end; wave 0 of each workgroup) and A/B variant bits (see PpEpi).
+extern "C" size_t gs_conv3x3_wpack_elems(int c_in, int n_out) { return (size_t)9 * c_in * n_out; }
+
+#ifdef GS_BUILD_PROBES
+// Tools only (tools/conv3x3_pp_probe.py; `make PROBES=1`, never part of the shipped library): gs_conv3x3_pp at tw = 16
+// with per-workgroup s_memtime stamps (dbg: int64 [workgroups][4] = start, prologue done, main loop done, end; wave 0 of
+// each workgroup) and A/B variant bits (see PpEpi).
 extern "C" int gs_conv3x3_pp_probe(const void* x, int x_stride, int c_in, const void* wpack, int tw, void* y, int y_stride,
                                    int n_out, int n, int h, int w, int variant, long long* dbg, gs_stream_t stream) {
   GS_REQUIRE(x && wpack && y, "conv3x3_pp_probe: null pointer");
-  GS_REQUIRE((tw == 8 || tw == 16) && c_in > 0 && c_in % 32 == 0 && n_out > 0 && n_out % 128 == 0 && n > 0,
-             "conv3x3_pp_probe: bad arguments");
+  GS_REQUIRE(tw == 16 && c_in > 0 && c_in % 32 == 0 && n_out > 0 && n_out % 128 == 0 && n > 0,
+             "conv3x3_pp_probe: bad arguments (tw must be 16)");
   PpEpi ep = PpEpi();
   ep.dbg = dbg;
   ep.variant = variant;
-  return dispatch_pp<0>(x, x_stride, c_in, wpack, tw, y, y_stride, n_out, n, h, w, 1, (hipStream_t)stream, ep);
+  return launch_pp<16, 0, 128, true>(x, x_stride, c_in, wpack, y, y_stride, n_out, n, h, w, 1, (hipStream_t)stream, ep);
 }
+#endif

@@ -4,7 +4,7 @@ Mirrors the module tree of the reference's `DroidNet.update` (src/droid_net.py:7
 src/modules/gru.py:5-33, src/droid_net.py:34-67) so that a `droid.pth` state dict loads with
 the same keys: update.{corr_encoder,flow_encoder,weight,delta,gru,agg}.  SURVEY.md 8(a5): these
 convolutions were to stay ATen/MIOpen; since the end of round 1 the large 3x3 ones run on the package's own
-implicit-GEMM kernel (gs_conv3x3, see CONV3X3_IMPL below) and MIOpen keeps the rest.
+implicit-GEMM kernel (gs_conv3x3_pp, see CONV3X3_IMPL below).
 
 `torch_scatter.scatter_mean` (absent in this image) is replaced by an index_add segment mean.
 """
@@ -206,81 +206,45 @@ def bias_act(y, b, act, out=None, out_channel=0, in_channel=0, channels=None):
     return dst
 
 
-# Implementation of the large 3x3 convolutions on the inference fast path:
-#   "hip"    the package's own implicit-GEMM MFMA kernel gs_conv3x3 (csrc/conv3x3.hip) wherever it applies,
-#   "miopen" always MIOpen,
-#   "auto"   (default) gs_conv3x3 when its 16x16-pixel tiles cover the map with <= 10 % padding waste (e.g. 60x80:
-#            6 %), MIOpen otherwise (30x40 and 40x80 maps waste 22 % / 17 % of the tile).
-# Measured on MI355X at the bench shape (75 edges, 60x80; tools/conv3x3_bench.py, profiles/r01_conv3x3_bench.json):
-# 885 / 896 / 917 / 859 TFLOP/s against MIOpen's 795 / 706 / 792 / 658 on the GRU z|r, GRU q, heads and
-# corr_encoder[2] layers; end to end 53.9 -> 59.7 keyframes/s (tools/update_ab.py, profiles/r01_update_ab.json).
-# Override with GOSLAM_CONV3X3 or by assigning this attribute.
-CONV3X3_IMPL = os.environ.get("GOSLAM_CONV3X3", "auto")
-# input channels per LDS chunk of gs_conv3x3: 32, 64 or "auto" = 64 except for the 320 -> 256 GRU z|r layer, where
-# 32 measured faster (885 vs 802 TFLOP/s; q / heads / corr_encoder[2]: 853 / 888 / 705 at 32, 896 / 917 / 859 at 64)
-CONV3X3_KC = "auto"
-# Row-stacked tiling (gs_conv3x3_stacked: no tile padding along the rows, tile width chosen per map width) -- opt-in
-# (GOSLAM_CONV3X3_STACKED=1) until it has been timed against the plain tiling; with it "auto" covers every map size.
-CONV3X3_STACKED = os.environ.get("GOSLAM_CONV3X3_STACKED", "0") == "1"
-# The two-group ping-pong kernel (csrc/conv3x3_pp.hip); GOSLAM_CONV3X3_PP=0 falls back to the round-1 kernels.
-CONV3X3_PP = os.environ.get("GOSLAM_CONV3X3_PP", "1") == "1"
-# Epilogues fused into the ping-pong kernel: the ConvGRU gate arithmetic (gs_conv3x3_gru_zr / _q) and bias + ReLU
-# (gs_conv3x3_bias_relu).  Same formulas and rounding points as conv + gate / bias_act kernels (GPU tests: bias + ReLU
-# bit-identical; ConvGRU within one fp16 ulp on < 1e-4 of the elements); zr_pre / q_pre never travel to HBM and back.
-GRU_FUSED_EPILOGUE = os.environ.get("GOSLAM_GRU_FUSED", "1") == "1"
-# flow_encoder[0] (7x7, 4 -> 128) through gs_conv7x7_c4 (bias + ReLU fused); GOSLAM_CONV7X7=0: MIOpen + bias_act pass
-CONV7X7_OWN = os.environ.get("GOSLAM_CONV7X7", "1") == "1"
-# ConvGRU global context: w(net) + sigmoid + pooling in one kernel (gs_gru_glo_fused); 0: gs_conv1x1 + gs_gru_glo
-GRU_GLO_FUSED = os.environ.get("GOSLAM_GRU_GLO_FUSED", "1") == "1"
+# The large 3x3 convolutions of the inference fast path run on the package's own implicit-GEMM MFMA kernel
+# (gs_conv3x3_pp, csrc/conv3x3_pp.hip: every layer, every map size).  CONV3X3_IMPL = "miopen" routes them through the
+# library instead -- the referee of the GPU tests (own kernel vs MIOpen on the same operands), not a product setting
+# and not read from the environment.  History of the A/B that retired the other variants (round-1 16x16-tile kernel,
+# row-stacked variant, four-wave schedule, persistent grid): DESIGN.md 3b.
+CONV3X3_IMPL = "own"
+# Epilogues fused into the convolution kernel: the ConvGRU gate arithmetic (gs_conv3x3_gru_zr2 / _q) and bias + ReLU
+# (gs_conv3x3_bias_relu); False = convolution + separate gate / bias kernels (the tests' referee for the fusion).
+GRU_FUSED_EPILOGUE = True
+# flow_encoder[0] (7x7, 4 -> 128) through gs_conv7x7_c4 (bias + ReLU fused); False: MIOpen + bias_act pass (referee)
+CONV7X7_OWN = True
+# ConvGRU global context: w(net) + sigmoid + pooling in one kernel (gs_gru_glo_fused); False: gs_conv1x1 + gs_gru_glo
+GRU_GLO_FUSED = True
 _CONV3X3_PACKS = {}        # (data_ptr, version, shape, device, kc) -> (packed image, weight tensor kept alive)
 _CONV3X3_PACKS_MAX = 32
 
 
 def pack_conv3x3_weight(weight, kc=32):
-    """[O, C, 3, 3] -> gs_conv3x3's fp16 LDS images [O/BN][C/kc][9][kc/8][BN][8] (include/goslam_hip.h):
-    wpack[nb][ck][3 ky + kx][kg][r][e] = W[BN nb + r][kc ck + 8 kg + e][ky][kx]; BN = 128 output channels per workgroup,
-    or 64 when O is only a multiple of 64 (ping-pong kernel, kc = 32)."""
+    """[O, C, 3, 3] -> gs_conv3x3_pp's fp16 LDS images [O/BN][C/32][9][4][BN][8] (include/goslam_hip.h):
+    wpack[nb][ck][3 ky + kx][kg][r][e] = W[BN nb + r][32 ck + 8 kg + e][ky][kx]; BN = 128 output channels per workgroup,
+    or 64 when O is only a multiple of 64."""
     O, C, kh, kw = weight.shape
     bn = 128 if O % 128 == 0 else 64
-    assert (kh, kw) == (3, 3) and O % bn == 0 and C % kc == 0 and kc in (32, 64) and (bn == 128 or kc == 32)
+    assert (kh, kw) == (3, 3) and O % bn == 0 and C % kc == 0 and kc == 32
     w = weight.detach().half().reshape(O // bn, bn, C // kc, kc // 8, 8, 3, 3)     # nb r ck kg e ky kx
     return w.permute(0, 2, 5, 6, 3, 1, 4).contiguous().reshape(-1)                # nb ck ky kx kg r e
 
 
 def conv3x3_hip_supported(x, w):
-    """the own kernels cover n_out % 128 == 0; the ping-pong kernel also n_out % 64 == 0 (flow_encoder[2])"""
-    mult = 64 if CONV3X3_PP else 128
+    """n_out % 64 == 0, c_in % 32 == 0, NHWC fp16"""
     return (x.is_cuda and x.dtype == torch.float16 and x.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
-            and w.shape[0] % mult == 0 and w.shape[1] % 32 == 0 and x.shape[1] == w.shape[1]
+            and w.shape[0] % 64 == 0 and w.shape[1] % 32 == 0 and x.shape[1] == w.shape[1]
             and x.is_contiguous(memory_format=torch.channels_last))
-
-
-def conv3x3_chunk(c_in, n_out):
-    """channels per LDS chunk for a layer (see CONV3X3_KC)"""
-    kc = CONV3X3_KC
-    if kc == "auto":
-        kc = 32 if (c_in >= 320 and n_out >= 256) else 64
-    return kc if c_in % kc == 0 else 32
-
-
-def conv3x3_tile_efficiency(h, w):
-    """fraction of gs_conv3x3's 16x16-pixel tiles that is real output"""
-    return (h * w) / float(((h + 15) // 16 * 16) * ((w + 15) // 16 * 16))
-
-
-def conv3x3_stacked_tile_width(w):
-    """tile width in {16, 8, 32} with the least column padding (ties: 16 first)"""
-    return min((16, 8, 32), key=lambda tw: ((w + tw - 1) // tw * tw, tw != 16))
 
 
 def _use_own_conv3x3(x, w, stride, padding):
     if CONV3X3_IMPL == "miopen" or stride not in (1, (1, 1)) or padding not in (1, (1, 1)):
         return False
-    if not conv3x3_hip_supported(x, w):
-        return False
-    if CONV3X3_IMPL == "hip" or CONV3X3_STACKED or CONV3X3_PP:      # row-stacked tilings cover every map size
-        return True
-    return conv3x3_tile_efficiency(x.shape[2], x.shape[3]) >= 0.9
+    return conv3x3_hip_supported(x, w)
 
 
 def conv3x3_weight_image(w, kc):
@@ -300,30 +264,18 @@ def conv3x3_pp_tile_width(w):
     return min((16, 8), key=lambda tw: ((w + tw - 1) // tw * tw, tw != 16))
 
 
-def conv3x3_hip(x, w, kc=None, stacked=None, tw=None, pp=None):
-    """bias-free 3x3 / pad 1 convolution of an NHWC fp16 tensor through gs_conv3x3_pp (the ping-pong kernel, default) or
-    gs_conv3x3 / gs_conv3x3_stacked (round-1 kernels, `pp=False`); `w` is the [O,C,3,3] weight.
+def conv3x3_hip(x, w, tw=None):
+    """bias-free 3x3 / pad 1 convolution of an NHWC fp16 tensor through gs_conv3x3_pp; `w` is the [O,C,3,3] weight.
     Its packed image is cached per (storage address, version, shape); the entry keeps the weight tensor alive, so the
     address cannot be recycled for different values while the entry exists."""
     from . import _lib
-    pp = CONV3X3_PP if pp is None else pp
-    kc = 32 if pp else (kc or conv3x3_chunk(w.shape[1], w.shape[0]))
-    image = conv3x3_weight_image(w, kc)
+    image = conv3x3_weight_image(w, 32)
     n, c, h, wd = x.shape
     O = w.shape[0]
     y = torch.empty((n, O, h, wd), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
-    stacked = CONV3X3_STACKED if stacked is None else stacked
     with torch.cuda.device(x.device):
-        if pp:
-            rc = _lib.lib().gs_conv3x3_pp(_lib.ptr(x), c, c, _lib.ptr(image), tw or conv3x3_pp_tile_width(wd),
-                                          _lib.ptr(y), O, O, n, h, wd, 1, _lib.stream_ptr(x.device))
-        elif stacked:
-            rc = _lib.lib().gs_conv3x3_stacked(_lib.ptr(x), c, c, _lib.ptr(image), kc,
-                                               tw or conv3x3_stacked_tile_width(wd), _lib.ptr(y), O, O, n, h, wd,
-                                               _lib.stream_ptr(x.device))
-        else:
-            rc = _lib.lib().gs_conv3x3(_lib.ptr(x), c, c, _lib.ptr(image), kc, _lib.ptr(y), O, O, n, h, wd,
-                                       _lib.stream_ptr(x.device))
+        rc = _lib.lib().gs_conv3x3_pp(_lib.ptr(x), c, c, _lib.ptr(image), tw or conv3x3_pp_tile_width(wd),
+                                      _lib.ptr(y), O, O, n, h, wd, 1, _lib.stream_ptr(x.device))
     _lib.check(rc, "conv3x3")
     return y
 
@@ -343,7 +295,7 @@ def conv_bias_act(cache, conv, x, act, out=None, out_channel=0):
     (PyTorch issues conv, add_(bias) and relu_ as three passes).  With `out` (an NHWC fp16 tensor
     with more channels) the result lands in out[:, out_channel:out_channel+C] -- no torch.cat."""
     w, b = cache.get(conv)
-    if GRU_FUSED_EPILOGUE and CONV3X3_PP and act == "relu" and _use_own_conv3x3(x, w, conv.stride, conv.padding):
+    if GRU_FUSED_EPILOGUE and act == "relu" and _use_own_conv3x3(x, w, conv.stride, conv.padding):
         from . import _lib
         n, c, h, wd = x.shape
         O = w.shape[0]
@@ -476,7 +428,7 @@ class ConvGRU(nn.Module):
         with torch.autocast("cuda", enabled=False):
             gzr, gq = glo if glo is not None else self.global_context(net)
             cin = hx.shape[1]
-            if GRU_FUSED_EPILOGUE and CONV3X3_PP and _use_own_conv3x3(hx, wzr, 1, 1) and h * w > 0:
+            if GRU_FUSED_EPILOGUE and _use_own_conv3x3(hx, wzr, 1, 1) and h * w > 0:
                 # gate arithmetic in the convolutions' epilogues: zr_pre / q_pre never reach HBM; hx stays intact
                 z = torch.empty_like(net)
                 rnet = torch.empty_like(net)

@@ -1,6 +1,8 @@
 """Data-parallel mapping across the GPUs of one node: the mapper's ray batch is
 sharded over ranks, every rank holds a full replica of the 12.6 M-entry grid and the MLPs, and one
-exchange step per iteration sums the gradients over RCCL / xGMI.
+exchange step per iteration sums the gradients over RCCL / xGMI.  The production (fused) trainer shards the OPTIMISER
+too: reduce-scatter of the fp16 table gradient, AdamW on the owned 1/G slice, all-gather of the fp16 working copy
+(neus/mapper.py: FlatAdamW); the all-reduce of one flat fp32 buffer described below serves the autograd path.
 
 The reference has no distributed code at all (its only multi-device knob is mapping.device); DDP
 cannot be used because the loss needs `autograd.grad` (InstantNeuS.py:139), so the exchange is an
@@ -29,6 +31,35 @@ def all_reduce_sum_(t, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def _gloo_on_device(t, group):
+    """functional smoke runs put several ranks on ONE GPU, where RCCL refuses to start; gloo then carries the
+    collectives, and its reduce-scatter / all-gather take host tensors only"""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def reduce_scatter_sum_(out, inp, group=None):
+    """out[i] = sum over ranks of inp[rank * len(out) + i] -- RCCL reduce-scatter over xGMI: every rank ends up with the
+    summed 1/G slice it owns (the sharded optimiser's input), moving (G-1)/G of the buffer once instead of twice."""
+    if _gloo_on_device(inp, group):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.reduce_scatter_tensor(h, inp.cpu(), op=dist.ReduceOp.SUM, group=group)
+        out.copy_(h)
+        return out
+    dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)
+    return out
+
+
+def all_gather_into_(full, part, group=None):
+    """full = concatenation over ranks of `part` (in place when `part` is this rank's slice of `full`)"""
+    if _gloo_on_device(full, group):
+        h = torch.empty(full.shape, dtype=full.dtype)
+        dist.all_gather_into_tensor(h, part.cpu(), group=group)
+        full.copy_(h)
+        return full
+    dist.all_gather_into_tensor(full, part, group=group)
+    return full
 
 
 class _MapLossFn(torch.autograd.Function):

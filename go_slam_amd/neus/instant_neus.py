@@ -369,7 +369,7 @@ class _NeusRenderFn(torch.autograd.Function):
 
 
 def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d_normal, d_wsum, d_sdf, d_gerr,
-                       inv_s_dev=None, var_dev=None):
+                       inv_s_dev=None, var_dev=None, grid_acc_out=None):
     """The HIP backward of the fused renderer: upstream gradients of the ray outputs -> gradients of every trained
     parameter.  Returns a dict: grid_acc (the raw table gradient: fp32, or tiny-cuda-nn's loss-scaled fp16 form with
     `grid_scale`), sdf_w, sdf_b, cB, mlp, var (fp32).  Used by the autograd Function above and, without any autograd
@@ -429,7 +429,11 @@ def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d
     # hash-table gradient: tcnn's mode (fp16, packed atomics, loss scale 128) or fp32 atomics
     half_grads = model.grid_grad_dtype == torch.float16
     gscale = float(model.grid_grad_scale) if half_grads else 1.0
-    grid_acc = torch.zeros(S["grid"].numel(), dtype=model.grid_grad_dtype, device=dev)
+    if grid_acc_out is not None:        # the caller's (zeroed) accumulation buffer, e.g. the sharded optimiser's padded one
+        assert grid_acc_out.dtype == model.grid_grad_dtype and grid_acc_out.numel() == S["grid"].numel()
+        grid_acc = grid_acc_out
+    else:
+        grid_acc = torch.zeros(S["grid"].numel(), dtype=model.grid_grad_dtype, device=dev)
     # per-point rows: fp16, gradient rows loss-scaled, all five as column blocks of ONE [np,160] matrix
     # d_out 0:32 | lin_in 32:72 | dw0 72:112 | d_arg 112:152 | pts,1 152:160 -- its Gram matrix (one split-K
     # GEMM) contains every dense-parameter gradient: d_out^T lin_in, the column sums (via the ones column)

@@ -6,6 +6,8 @@ import torch
 from .. import _lib
 from .distributed import FlatGradReducer, all_reduce_sum_, mapping_loss_sharded, shard_rays
 
+MAX_GRAPHS = 8          # captured batch shapes a trainer keeps (the mapper's batches come in a handful of sizes)
+
 
 def make_optimizer(model, net_lr=1e-3, grid_lr=1e-2, fused=None):
     """reference src/mapping.py:55-58 (same hyper-parameters).  On the GPU the single-kernel (`fused`) AdamW is
@@ -38,45 +40,106 @@ def _bump_versions(optimizer, args=None, kwargs=None):
             torch.autograd.graph.increment_version(p)
 
 
-class FlatAdamW:
-    """The trained parameters as views of ONE flat fp32 buffer [hash table | colour MLP | sdf_layer.weight | .bias |
-    colour _B | variance] with flat AdamW moments and a flat fp16 working copy, stepped by two HIP launches
-    (gs_map_grad_sqnorm + gs_map_adamw: global-norm clipping, unscaling of the loss-scaled fp16 table gradient, AdamW
-    with the two learning rates of src/mapping.py:55-58, and the fp16 copies the next forward reads).  Same update as
-    clip_grad_norm_(35) + torch.optim.AdamW(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01) on the same gradients.
-    `sdf_network.encoding._B` is in the reference's parameter list but never receives a gradient, so torch skips it
-    (no weight decay either) -- it stays outside the buffer."""
+class HipOptKernels:
+    """The optimiser's two HIP launches (csrc/map_opt.hip) behind tensor arguments.  ShardedFlatAdamW takes the object
+    as a parameter so that the world-size-2 gloo test can drive the SHARDING logic (slices, padding, collectives) on
+    CPU tensors with a torch restatement of the two kernels defined in the test; the product never passes another."""
 
-    def __init__(self, model, net_lr=1e-3, grid_lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=35.0):
+    def sqnorm(self, out, g16, inv_scale16, g32):
+        L = _lib.lib()
+        dev = out.device
+        n32 = 0 if g32 is None else g32.numel()
+        with torch.cuda.device(dev):
+            _lib.check(L.gs_map_grad_sqnorm(_lib.ptr(g16), g16.numel(), inv_scale16, _lib.ptr(g32), n32,
+                                            _lib.ptr(out), _lib.stream_ptr(dev)), "map_grad_sqnorm")
+
+    def adamw(self, p, m, v, p16, g16, inv_scale16, pd, md, vd, p16d, g32, h, step, step_dev, sqnorm):
+        L = _lib.lib()
+        dev = p.device
+        with torch.cuda.device(dev):
+            _lib.check(L.gs_map_adamw_seg(_lib.ptr(p), _lib.ptr(m), _lib.ptr(v), _lib.ptr(p16), _lib.ptr(g16),
+                                          g16.numel(), inv_scale16, _lib.ptr(pd), _lib.ptr(md), _lib.ptr(vd),
+                                          _lib.ptr(p16d), _lib.ptr(g32), g32.numel(), h["lr16"], h["lr32"], h["b1"],
+                                          h["b2"], h["eps"], h["wd"], int(step), _lib.ptr(step_dev), _lib.ptr(sqnorm),
+                                          h["max_norm"], _lib.stream_ptr(dev)), "map_adamw")
+
+
+class FlatAdamW:
+    """The trained parameters as views of ONE flat fp32 buffer [hash table (padded) | colour MLP | sdf_layer.weight |
+    .bias | colour _B | variance] with flat AdamW moments and a flat fp16 working copy, stepped by two HIP launches
+    (gs_map_grad_sqnorm + gs_map_adamw_seg: global-norm clipping, unscaling of the loss-scaled fp16 table gradient,
+    AdamW with the two learning rates of src/mapping.py:55-58, and the fp16 copies the next forward reads).  Same update
+    as clip_grad_norm_(35) + torch.optim.AdamW(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01) on the same gradients.
+    `sdf_network.encoding._B` is in the reference's parameter list but never receives a gradient, so torch skips it
+    (no weight decay either) -- it stays outside the buffer.
+
+    With `world` > 1 the optimiser state of the TABLE is sharded over the ranks (reduce-scatter /
+    all-gather over the xGMI mesh instead of all-reduce + a replicated optimiser):
+
+        reduce-scatter(fp16 table gradient)   each rank receives the sum of its 1/G slice        (25.2 MB / G per peer)
+        all-reduce(fp32 dense gradients)      46 KB; the global loss rides in a spare slot
+        gs_map_grad_sqnorm on the slice       (+ the dense part on rank 0) -> all-reduce of ONE scalar -> global norm
+        gs_map_adamw_seg on the slice         fp32 master, m, v of the slice only: the 353 MB pass becomes 353 / G MB;
+                                              the 11.5 K dense parameters are stepped identically on every rank
+        all-gather(fp16 working copy)         every rank gets the whole updated table for its next forward
+
+    The fp32 master of the slices a rank does not own goes stale between `sync_master()` calls (an all-gather of the
+    fp32 slices; call it before state_dict() / checkpoints -- MapTrainer.state_dict does)."""
+
+    def __init__(self, model, net_lr=1e-3, grid_lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=35.0,
+                 rank=0, world=1, group=None, kernels=None):
         net = model.sdf_network
         self.grid_module = net.encoding.encoding
         self.mlp_module = model.color_network.network
         self.grid_p = self.grid_module.params
         self.dense = [("mlp", self.mlp_module.params), ("sdf_w", net.sdf_layer.weight), ("sdf_b", net.sdf_layer.bias),
                       ("cB", model.color_network._B), ("var", model.variance_network.variance)]
+        self.rank, self.world, self.group = int(rank), int(world), group
+        self.kernels = kernels if kernels is not None else HipOptKernels()
         dev = self.grid_p.device
         self.n16 = self.grid_p.numel()
         assert self.n16 % 8 == 0
-        sizes = [p.numel() for _, p in self.dense]
-        self.n = self.n16 + sum(sizes)
-        self.P = torch.empty(self.n, dtype=torch.float32, device=dev)
-        off = 0
-        self.slices = {}
+        # entries per rank: a multiple of 8 (16-byte aligned fp16 slices); the table is padded to world * slice
+        self.slice = -(-self.n16 // (8 * self.world)) * 8
+        self.n16p = self.slice * self.world
+        self.lo, self.hi = self.rank * self.slice, (self.rank + 1) * self.slice
+        self.nd = sum(p.numel() for _, p in self.dense)
+        self.n = self.n16 + self.nd                       # trained parameters (without padding)
+        self.P = torch.zeros(self.n16p + self.nd, dtype=torch.float32, device=dev)
+        off = self.n16p
+        self.slices = {"grid": (0, self.n16)}
         with torch.no_grad():
-            for name, p in [("grid", self.grid_p)] + self.dense:
+            self.P[:self.n16].copy_(self.grid_p.detach().reshape(-1).float())
+            self.grid_p.data = self.P[:self.n16].view(self.grid_p.shape)
+            for name, p in self.dense:
                 k = p.numel()
                 self.P[off:off + k].copy_(p.detach().reshape(-1).float())
-                p.data = self.P[off:off + k].view(p.shape)        # the module now reads / state_dict()s the flat buffer
+                p.data = self.P[off:off + k].view(p.shape)      # the module now reads / state_dict()s the flat buffer
                 self.slices[name] = (off, off + k)
                 off += k
-        self.M = torch.zeros_like(self.P)
-        self.V = torch.zeros_like(self.P)
+        # moments: the own table slice + the dense parameters
+        self.M = torch.zeros(self.slice + self.nd, dtype=torch.float32, device=dev)
+        self.V = torch.zeros_like(self.M)
         self.P16 = self.P.to(torch.float16)
+        self.G16 = torch.zeros(self.n16p, dtype=torch.float16, device=dev)        # the backward's table-gradient buffer
+        self.g16s = torch.empty(self.slice, dtype=torch.float16, device=dev) if self.world > 1 else None
         self.sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.g32 = torch.zeros(self.n - self.n16, dtype=torch.float32, device=dev)
+        self.g32 = torch.zeros(self.nd + 2, dtype=torch.float32, device=dev)      # dense gradients | global loss | spare
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.hyper = dict(lr16=grid_lr, lr32=net_lr, b1=betas[0], b2=betas[1], eps=eps, wd=weight_decay, max_norm=max_norm)
         self.steps = 0
         self._publish()
+
+    # the reference's mapper scales its learning rates per iteration (src/mapping.py: lr_factor) through param_groups
+    @property
+    def param_groups(self):
+        return [{"name": "network", "lr": self.hyper["lr32"]}, {"name": "volume", "lr": self.hyper["lr16"]}]
+
+    def set_lr(self, net_lr=None, grid_lr=None):
+        if net_lr is not None:
+            self.hyper["lr32"] = float(net_lr)
+        if grid_lr is not None:
+            self.hyper["lr16"] = float(grid_lr)
 
     def _publish(self):
         """hand the fp16 working copies to the modules' caches and invalidate everything keyed on parameter versions"""
@@ -88,34 +151,70 @@ class FlatAdamW:
             mod._half._val = self.P16[a:b]
             mod._half._key = (p.data_ptr(), p._version, p.device, p.dtype)
 
+    def check_bindings(self):
+        """the modules' parameters must still be views of the flat buffer (a later `.half()`, `.to(device)`,
+        `share_memory()` or deepcopy rebinds `.data`: the step would then update memory nobody reads)"""
+        base = self.P.data_ptr()
+        for name, p in [("grid", self.grid_p)] + self.dense:
+            a, _ = self.slices[name]
+            if p.data_ptr() != base + 4 * a:
+                raise RuntimeError(f"FlatAdamW: parameter '{name}' no longer lives in the flat buffer (the model was "
+                                   "moved / converted / copied after the trainer was built); build a new MapTrainer")
+
     def dense_grad(self, name):
         a, b = self.slices[name]
-        return self.g32[a - self.n16:b - self.n16]
+        return self.g32[a - self.n16p:b - self.n16p]
 
-    def step(self, grid_grad16, inv_scale16):
-        """grid_grad16: fp16 [n16] = table gradient / inv_scale16; the dense gradients are in self.g32."""
-        L = _lib.lib()
-        dev = self.P.device
-        h = self.hyper
+    def grad_table(self):
+        """the (zeroed) loss-scaled fp16 table-gradient buffer the backward accumulates into"""
+        self.G16.zero_()
+        return self.G16[:self.n16]
+
+    def step(self, inv_scale16):
+        """table gradient / inv_scale16 is in self.G16 (fp16), the dense gradients (+ the loss in slot nd) in self.g32."""
+        from .distributed import all_gather_into_, all_reduce_sum_, reduce_scatter_sum_
+        K, h, nd = self.kernels, self.hyper, self.nd
         self.steps += 1
+        self.step_dev.add_(1)
         self.sqnorm.zero_()
-        st = _lib.stream_ptr(dev)
-        with torch.cuda.device(dev):
-            _lib.check(L.gs_map_grad_sqnorm(_lib.ptr(grid_grad16), self.n16, inv_scale16, _lib.ptr(self.g32),
-                                            self.g32.numel(), _lib.ptr(self.sqnorm), st), "map_grad_sqnorm")
-            _lib.check(L.gs_map_adamw(_lib.ptr(self.P), _lib.ptr(self.M), _lib.ptr(self.V), _lib.ptr(self.P16),
-                                      _lib.ptr(grid_grad16), self.n16, inv_scale16, _lib.ptr(self.g32), self.n,
-                                      h["lr16"], h["lr32"], h["b1"], h["b2"], h["eps"], h["wd"], self.steps,
-                                      _lib.ptr(self.sqnorm), h["max_norm"], st), "map_adamw")
+        dense = (self.P[self.n16p:], self.M[self.slice:], self.V[self.slice:], self.P16[self.n16p:], self.g32[:nd])
+        if self.world > 1:
+            reduce_scatter_sum_(self.g16s, self.G16, self.group)
+            all_reduce_sum_(self.g32, self.group)
+            K.sqnorm(self.sqnorm, self.g16s, inv_scale16, self.g32[:nd] if self.rank == 0 else None)
+            all_reduce_sum_(self.sqnorm, self.group)
+            K.adamw(self.P[self.lo:self.hi], self.M[:self.slice], self.V[:self.slice], self.P16[self.lo:self.hi],
+                    self.g16s, inv_scale16, *dense, h, self.steps, self.step_dev, self.sqnorm)
+            all_gather_into_(self.P16[:self.n16p], self.P16[self.lo:self.hi], self.group)
+        else:
+            K.sqnorm(self.sqnorm, self.G16, inv_scale16, self.g32[:nd])
+            K.adamw(self.P[:self.n16p], self.M[:self.slice], self.V[:self.slice], self.P16[:self.n16p], self.G16,
+                    inv_scale16, *dense, h, self.steps, self.step_dev, self.sqnorm)
         self._publish()
+
+    def sync_master(self):
+        """all-gather the fp32 master slices so that every rank's `P` (= the modules' parameters, state_dict()) is whole"""
+        if self.world > 1:
+            from .distributed import all_gather_into_
+            all_gather_into_(self.P[:self.n16p], self.P[self.lo:self.hi], self.group)
+
+    def collective_bytes(self):
+        """bytes a rank sends per step: reduce-scatter + all-gather of the fp16 table, the dense all-reduce, one scalar"""
+        if self.world == 1:
+            return 0
+        f = (self.world - 1) / self.world
+        return int(2 * f * 2 * self.n16p + 2 * f * 4 * self.g32.numel() + 8)
 
 
 class MapTrainer:
     def __init__(self, model, renderer, net_lr=1e-3, grid_lr=1e-2, w_color=2.0, w_sdf=2.0, w_eikonal=0.1,
-                 uncertainty=True, group=None, rank=0, world=1, fused=None):
+                 uncertainty=True, group=None, rank=0, world=1, fused=None, graph=None):
         """`fused` (default: on for a CUDA model with tiny-cuda-nn's fp16 table gradients): the whole step without an
         autograd graph -- forward, the loss kernel's analytic output gradients, the HIP backward, one flat-buffer
-        clip + AdamW -- ~25 launches instead of ~90, no parameter read-back to the host (`step_fused`)."""
+        clip + AdamW -- no parameter read-back to the host (`step_fused`).  `graph` (default: on with `fused`): the
+        step's launch sequence is captured once per batch size in a hipGraph and replayed (one graph launch instead of
+        ~65 kernel launches; with world > 1 the collectives stay outside: [sample + forward + loss + backward] is one
+        graph, the optimiser's two kernels sit between the collectives)."""
         self.model, self.renderer = model, renderer
         self.train_params = model.get_training_parameters() + model.get_volume_parameters()
         self.w = dict(w_color=w_color, w_sdf=w_sdf, w_eikonal=w_eikonal, uncertainty=uncertainty)
@@ -124,42 +223,39 @@ class MapTrainer:
             fused = (all(p.is_cuda for p in self.train_params) and model.grid_grad_dtype == torch.float16
                      and model.fused_mlp_backward)
         self.fused = bool(fused)
+        self.graph = bool(self.fused if graph is None else (graph and self.fused))
+        self._graphs = {}
         if self.fused:
-            self.flat = FlatAdamW(model, net_lr, grid_lr)
-            self.optimizer, self.reducer = None, None
+            self.flat = FlatAdamW(model, net_lr, grid_lr, rank=rank, world=world, group=group)
+            self.optimizer, self.reducer = self.flat, None        # `.param_groups` / `.set_lr` facade
         else:
             self.optimizer = make_optimizer(model, net_lr, grid_lr)
             self.reducer = FlatGradReducer(self.train_params) if world > 1 else None
 
-    def step_fused(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand=None):
-        loss, grid16, inv_scale = self.fused_gradients(rays_o, rays_d, rays_color, rays_depth, perturb_rand)
-        self.flat.step(grid16, inv_scale)
-        return loss
+    def state_dict(self):
+        """the model's state dict with whole fp32 masters on every rank (sharded optimiser: gathers the slices first)"""
+        if self.fused:
+            self.flat.sync_master()
+        return self.model.state_dict()
 
-    def fused_gradients(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand=None):
-        """forward + loss + HIP backward (+ all-reduce) without an autograd graph.  Returns (global loss, table gradient
-        in loss-scaled fp16, its inverse scale); the dense gradients are left in self.flat.g32."""
+    # ---- the fused step ------------------------------------------------------------------------------------------
+    def _local_gradients(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand, counts):
+        """THIS RANK's rays: sample + forward + loss kernel + HIP backward, no autograd graph, no collective, no host
+        sync.  `counts` = [valid rays, rays] over ALL ranks (device fp32[2]).  Leaves the loss-scaled fp16 table
+        gradient in flat.G16, the dense gradients in flat.g32[:nd] and this rank's share of the loss in flat.g32[nd]."""
         from .instant_neus import _neus_backward_raw, _neus_forward_raw
-        model, L = self.model, _lib.lib()
+        model, L, flat = self.model, _lib.lib(), self.flat
         dev = rays_o.device
         f32 = dict(dtype=torch.float32, device=dev)
-        if self.world > 1:
-            rays_o, rays_d, rays_color, rays_depth = shard_rays([rays_o, rays_d, rays_color, rays_depth],
-                                                                self.rank, self.world)
-        c = lambda t: t.detach().float().contiguous()
-        rays_o, rays_d, rays_color, rays_depth = c(rays_o), c(rays_d), c(rays_color), c(rays_depth).reshape(-1)
         n = rays_o.shape[0]
-        z_vals, dists = self.renderer.sample(rays_o, rays_d, model.bound, rays_depth, perturb_rand)
+        z_vals, dists = self.renderer.sample(rays_o, rays_d, model.bound, rays_depth, perturb_rand,
+                                             gt_max_dev=counts[2:3])
         s = z_vals.shape[1]
         sf = model.variance_network.scale_factor
         var_dev = model.variance_network.variance
         inv_s_dev = torch.exp(var_dev.detach().float() * sf).clamp(1e-6, 1e6).reshape(1)
         color, depth, dvar, normal, wsum, sdf, gerr, zmid, saved = _neus_forward_raw(
             model, rays_o, rays_d, z_vals, dists, 0.0, save=True, inv_s_dev=inv_s_dev)
-        # counts over ALL ranks: valid rays (loss normalisation) and rays (eikonal mean)
-        counts = torch.stack([(rays_depth > 0).sum().float(), torch.full((), float(n), **f32)])
-        if self.world > 1:
-            all_reduce_sum_(counts, self.group)
         d_color = torch.empty(n, 3, **f32)
         d_depth = torch.empty(n, 1, **f32)
         d_sdf = torch.empty(n, s, **f32)
@@ -175,18 +271,113 @@ class MapTrainer:
         # eikonal term: w_eik * mean over all points of all ranks -> the same constant for every ray
         d_gerr = (w["w_eikonal"] / (counts[1] * float(s))).expand(n, 1).contiguous()
         g = _neus_backward_raw(model, saved, (rays_o, rays_d, z_vals, dists, sdf, zmid), 0.0, 0.0,
-                               d_color, d_depth, None, None, None, d_sdf, d_gerr, inv_s_dev=inv_s_dev, var_dev=var_dev)
-        flat = self.flat
+                               d_color, d_depth, None, None, None, d_sdf, d_gerr, inv_s_dev=inv_s_dev, var_dev=var_dev,
+                               grid_acc_out=flat.grad_table())
         for name in ("mlp", "sdf_w", "sdf_b", "cB", "var"):
             flat.dense_grad(name).copy_(g[name].reshape(-1))
-        grid16 = g["grid_acc"]
-        if self.world > 1:          # one fp16 collective for the table (25 MB), one small fp32 one for the rest
-            all_reduce_sum_(grid16, self.group)
-            all_reduce_sum_(flat.g32, self.group)
-        loss = loss_rays.sum() + w["w_eikonal"] * gerr.sum() / (counts[1] * float(s))
+        flat.g32[flat.nd] = loss_rays.sum() + w["w_eikonal"] * gerr.sum() / (counts[1] * float(s))
+        return 1.0 / float(g["grid_scale"])
+
+    def _prepare(self, rays_o, rays_d, rays_color, rays_depth):
         if self.world > 1:
-            loss = all_reduce_sum_(loss.clone(), self.group)
-        return loss, grid16, 1.0 / float(g["grid_scale"])
+            rays_o, rays_d, rays_color, rays_depth = shard_rays([rays_o, rays_d, rays_color, rays_depth],
+                                                                self.rank, self.world)
+        c = lambda t: t.detach().float().contiguous()
+        return c(rays_o), c(rays_d), c(rays_color), c(rays_depth).reshape(-1)
+
+    def _counts(self, rays_depth):
+        """[valid rays, rays, max depth] over ALL ranks: the loss normalisers (means over VALID rays,
+        src/mapping.py:96-121) and the batch-wide depth maximum the sampler clamps with (src/render.py:121,140) -- one
+        small all-gather, reduced locally (sum, sum, max)."""
+        dev = rays_depth.device
+        n = rays_depth.shape[0]
+        mx = rays_depth.max() if n else torch.zeros((), dtype=torch.float32, device=dev)
+        counts = torch.stack([(rays_depth > 0).sum().float(), torch.full((), float(n), dtype=torch.float32, device=dev),
+                              mx.float()])
+        if self.world > 1:
+            from .distributed import all_gather_into_
+            allc = torch.empty(self.world * 3, dtype=torch.float32, device=dev)
+            all_gather_into_(allc, counts, self.group)
+            allc = allc.view(self.world, 3)
+            counts = torch.cat([allc[:, :2].sum(0), allc[:, 2:].max(0).values])
+        return counts
+
+    def fused_gradients(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand=None):
+        """forward + loss + HIP backward without an autograd graph and WITHOUT the optimiser's collectives.  Returns
+        (this rank's loss share, the rank-local table gradient in loss-scaled fp16, its inverse scale); the dense
+        gradients are left in self.flat.g32.  (Tests / tools; `step_fused` is the production entry.)"""
+        rays_o, rays_d, rays_color, rays_depth = self._prepare(rays_o, rays_d, rays_color, rays_depth)
+        inv_scale = self._local_gradients(rays_o, rays_d, rays_color, rays_depth, perturb_rand, self._counts(rays_depth))
+        return self.flat.g32[self.flat.nd].clone(), self.flat.G16[:self.flat.n16], inv_scale
+
+    def _graph_for(self, args, counts, perturb_rand):
+        """hipGraph of the step's local part for this batch shape: static input buffers + the captured launch sequence"""
+        h = self.flat.hyper
+        key = (tuple(args[0].shape), perturb_rand is None, self.world, h["lr16"], h["lr32"])   # (scalars are baked in)
+        ent = self._graphs.get(key)
+        if ent is not None:
+            return ent
+        if len(self._graphs) >= MAX_GRAPHS:
+            return None
+        static = [torch.empty_like(a) for a in args]
+        s_counts = torch.empty_like(counts)
+        s_pr = None if perturb_rand is None else torch.empty_like(perturb_rand.detach().float().contiguous())
+        ent = dict(static=static, counts=s_counts, pr=s_pr, graph=None, inv_scale=None, warm=0)
+        self._graphs[key] = ent
+        return ent
+
+    def step_fused(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand=None):
+        flat = self.flat
+        flat.check_bindings()
+        args = self._prepare(rays_o, rays_d, rays_color, rays_depth)
+        counts = self._counts(args[3])
+        if not self.graph or args[0].shape[0] == 0:
+            inv_scale = self._local_gradients(*args, perturb_rand, counts)
+            flat.step(inv_scale)
+            return self._global_loss()
+        if perturb_rand is None and self.renderer.perturb > 0:      # drawn OUTSIDE the graph: a replay must see new values
+            perturb_rand = torch.rand(self.renderer.N_samples, device=args[0].device)
+        ent = self._graph_for(args, counts, perturb_rand)
+        if ent is None:                     # more batch shapes than graphs worth keeping: run this one eagerly
+            inv_scale = self._local_gradients(*args, perturb_rand, counts)
+            flat.step(inv_scale)
+            return self._global_loss()
+        for dst, src in zip(ent["static"], args):
+            dst.copy_(src)
+        ent["counts"].copy_(counts)
+        if ent["pr"] is not None:
+            ent["pr"].copy_(perturb_rand)
+        whole = self.world == 1             # single GPU: the optimiser's two launches are part of the graph
+
+        def body():
+            inv = self._local_gradients(*ent["static"], ent["pr"], ent["counts"])
+            if whole:
+                flat.step(inv)
+            return inv
+        if ent["graph"] is None:
+            if ent["warm"] < 2:             # eager first (workspaces, fp16 caches, lazy library state), then capture
+                ent["warm"] += 1
+                inv = body()
+                if not whole:
+                    flat.step(inv)
+                return self._global_loss()
+            steps_before = flat.steps
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                ent["inv_scale"] = body()
+            ent["graph"] = graph
+            flat.steps = steps_before       # capture ran nothing: the replay below is the step
+        ent["graph"].replay()
+        if whole:
+            flat.steps += 1                 # (the device-side count was advanced inside the graph)
+            flat._publish()
+        else:
+            flat.step(ent["inv_scale"])
+        return self._global_loss()
+
+    def _global_loss(self):
+        """the step's loss over all ranks as a 0-dim tensor (with world > 1 it was summed by the dense all-reduce)"""
+        return self.flat.g32[self.flat.nd].clone()
 
     def step(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand=None):
         """One joint iteration on the GLOBAL batch (every rank passes the same tensors; each renders

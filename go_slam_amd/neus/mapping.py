@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .distributed import mapping_loss_sharded
-from .mapper import make_optimizer
+from .mapper import MapTrainer
 from .rays import build_rays
 
 
@@ -48,11 +48,23 @@ class Mapper:
         net_param = self.mapping_net.get_training_parameters(ignore_keys=())
         grid_param = self.mapping_net.get_volume_parameters()
         self.train_params = list(net_param) + list(grid_param)
-        self.optimizer = make_optimizer(self.mapping_net, m["net_lr"], m["grid_lr"])   # AdamW, fused on the GPU
+        # the joint iteration itself: MapTrainer (fused HIP step captured in a hipGraph when the model is on the GPU with
+        # tiny-cuda-nn's fp16 table gradients -- the default --, else autograd + torch AdamW); `self.optimizer` is what
+        # the reference's optimize_map is handed: torch's AdamW, or the fused step's param_groups facade
+        self.trainer = MapTrainer(self.mapping_net, self.renderer, m["net_lr"], m["grid_lr"], w_color=self.w_color_loss,
+                                  w_sdf=self.w_sdf_loss, w_eikonal=self.w_eikonal_loss,
+                                  uncertainty=self.uncertainty_based)
+        self.optimizer = self.trainer.optimizer
 
     def optimize_map(self, rays_o, rays_d, rays_color, rays_depth, optimizer, num_joint_iters):
         """mapping iterations on one ray batch (src/mapping.py:59-148)"""
         net = self.mapping_net
+        if self.trainer.fused and optimizer is self.trainer.optimizer:
+            for _ in range(num_joint_iters):            # forward + loss + backward + clip + AdamW without autograd
+                self.local_step += 1
+                self.global_step += 1
+                self.trainer.step(rays_o, rays_d, rays_color, rays_depth)
+            return
         for _ in range(num_joint_iters):
             self.local_step += 1
             self.global_step += 1

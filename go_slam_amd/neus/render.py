@@ -26,8 +26,11 @@ class Renderer:
             self._lin[key] = torch.linspace(0, 1, steps=steps, device=device).float().contiguous()
         return self._lin[key]
 
-    def sample(self, rays_o, rays_d, bound, gt_depth=None, perturb_rand=None):
-        """z_vals, dists [N, N_samples + N_surface] (render.py:99-171)."""
+    def sample(self, rays_o, rays_d, bound, gt_depth=None, perturb_rand=None, gt_max_dev=None):
+        """z_vals, dists [N, N_samples + N_surface] (render.py:99-171).  `gt_max_dev` (device fp32[1], optional): the
+        maximum depth measurement of the WHOLE batch when `gt_depth` is only one rank's shard of it -- the reference
+        clamps every ray's far bound with `gt_depth.max()` of the batch (:121,:140), so a sharded step must not take
+        the maximum over its own rays only."""
         dev = rays_o.device
         n = rays_o.shape[0]
         ns = self.N_samples
@@ -37,8 +40,9 @@ class Renderer:
             return z, z.clone()
         if gt_depth is not None:
             gt_depth = gt_depth.reshape(-1).float().contiguous()
-            gt_max_dev = gt_depth.max().reshape(1)  # stays on the device: the kernel reads it (the reference's
-            gt_max = 0.0                            # .max() at :121,:140 costs a host sync per batch)
+            if gt_max_dev is None:
+                gt_max_dev = gt_depth.max().reshape(1)  # stays on the device: the kernel reads it (the reference's
+            gt_max = 0.0                                # .max() at :121,:140 costs a host sync per batch)
         else:
             gt_max, gt_max_dev = 0.0, None
         if self.perturb > 0 and perturb_rand is None:

@@ -178,45 +178,32 @@ int gs_conv1x1(const void* x, int x_stride, int k_in, const void* wpack, const f
 int gs_conv7x7_c4(const void* x, const void* wpack, const float* bias, void* y, int ys, int n, int h, int w, int relu,
                   int rt, gs_stream_t stream);
 /* 3x3 convolution, padding 1, stride 1, no bias: NHWC fp16 [n,h,w,c_in] (pixels x_stride elements apart) ->
- * NHWC fp16 [n,h,w,n_out] (y_stride apart), fp32 accumulation, as an implicit GEMM on MFMA with the 18x18 input
- * patch of a 16x16-pixel tile staged once in LDS for all 9 taps.  Covers the large convolutions of the update
- * operator: ConvGRU convz|convr and convq (src/modules/gru.py:10-12), the first layers of the delta / weight / agg
- * heads (src/droid_net.py:83,88,40) and corr_encoder[2] (src/droid_net.py:76).  n_out % 128 == 0; kc in {32, 64}
- * is the number of input channels staged per LDS chunk (c_in % kc == 0) and fixes the weight image layout:
- * wpack: fp16 [n_out/128][c_in/kc][9][kc/8][128][8],
- * wpack[nb][ck][3 ky + kx][kg][r][e] = W[128 nb + r][kc ck + 8 kg + e][ky][kx] (gs_conv3x3_wpack_elems halves). */
+ * NHWC fp16 [n,h,w,n_out] (y_stride apart), fp32 accumulation, as an implicit GEMM on MFMA.  Covers the large
+ * convolutions of the update operator: ConvGRU convz|convr and convq (src/modules/gru.py:10-12), the first layers of
+ * the delta / weight / agg heads (src/droid_net.py:83,88,40), corr_encoder[2] and flow_encoder[2] (:76,:80).
+ * Row-stacked tiling: the n images are tiled as one image of n*h rows, tiles of 512 / tw rows x tw columns (tw in
+ * {8, 16}: pick the width that divides w best, 40 -> 8, 80 -> 16) run across image boundaries and the vertical taps
+ * are masked per pixel at y == 0 / y == h-1, so no tile padding is spent on h; the images must be contiguous (image
+ * stride = h * w * x_stride resp. y_stride).  512-thread workgroups whose two wave groups alternate a fragment-read
+ * phase and an MFMA phase one phase apart ("ping-pong"), all staging by LDS-DMA (global_load_lds) with counted waits
+ * across raw barriers, an XOR-swizzled bank-conflict-free patch layout.  xcd_order != 0: workgroup ids are decoded so
+ * that the output-channel blocks of a tile run on one XCD (shared L2).
+ * n_out % 64 == 0 (BN = 128 output channels per workgroup, or 64 when n_out is only a multiple of 64), c_in % 32 == 0.
+ * wpack: fp16 [n_out/BN][c_in/32][9][4][BN][8],
+ * wpack[nb][ck][3 ky + kx][kg][r][e] = W[BN nb + r][32 ck + 8 kg + e][ky][kx] (gs_conv3x3_wpack_elems halves). */
 size_t gs_conv3x3_wpack_elems(int c_in, int n_out);
-int gs_conv3x3(const void* x, int x_stride, int c_in, const void* wpack, int kc, void* y, int y_stride, int n_out,
-               int n, int h, int w, gs_stream_t stream);
-/* Same convolution with row-stacked tiles: the n images are tiled as one image of n*h rows (tiles of 256/tw rows x
- * tw columns run across image boundaries; the vertical taps are masked per pixel at y == 0 / y == h-1), so no tile
- * padding is spent on h.  tw in {8, 16, 32}: pick the width that divides w best (40 -> 8, 80 -> 16).  Same wpack.
- * Requires the images to be contiguous (image stride = h * w * x_stride resp. y_stride).                    */
-int gs_conv3x3_stacked(const void* x, int x_stride, int c_in, const void* wpack, int kc, int tw, void* y,
-                       int y_stride, int n_out, int n, int h, int w, gs_stream_t stream);
-/* The same convolution (row-stacked tiles of 512 / tw rows x tw columns, tw in {8, 16}; weights packed with kc = 32)
- * on the two-group ping-pong kernel: 512-thread workgroups whose two wave groups alternate a fragment-read phase and
- * an MFMA phase one phase apart, all staging by LDS-DMA (global_load_lds) with counted waits across raw barriers, an
- * XOR-swizzled bank-conflict-free patch layout.  xcd_order != 0: workgroup ids are decoded so that the output-channel
- * blocks of a tile run on one XCD (shared L2).  The production path of the update operator.                  */
 int gs_conv3x3_pp(const void* x, int x_stride, int c_in, const void* wpack, int tw, void* y, int y_stride, int n_out,
                   int n, int h, int w, int xcd_order, gs_stream_t stream);
-/* Measurement hook of the kernel above (tools/conv3x3_pp_probe.py; not used by the product path): same convolution,
- * plus per-workgroup s_memtime stamps dbg[workgroup][4] = {start, prologue done, main loop done, end} (NULL: none) and
- * A/B variant bits (1: no s_setprio around the MFMA phase, 2: read phase without the image-boundary masks -- wrong
- * results at image borders, timing only).                                                                      */
-int gs_conv3x3_pp_probe(const void* x, int x_stride, int c_in, const void* wpack, int tw, void* y, int y_stride,
-                        int n_out, int n, int h, int w, int variant, long long* dbg, gs_stream_t stream);
 /* ConvGRU (src/modules/gru.py:20-33) with the gate arithmetic fused into the 3x3 convolutions' epilogues
- * (EXPERIMENTAL: opt-in from the host mirror; results equal gs_conv3x3 + gs_gru_gate_zr / gs_gru_gate_q bit for bit,
- * but the 256 + 128 channels of pre-activations never travel to HBM and back).
- *   gs_conv3x3_gru_zr: hx [n,h,w,hx_stride] fp16, first c_in channels = [net(128) | rest]; wpack = gs_conv3x3 image of
- *     the fused convz|convr weight [256, c_in, 3, 3] at kc = 32; bias_zr f32 [256]; glo_zr f32 [n,256]; inp_pre fp16
+ * (results equal gs_conv3x3_pp + gs_gru_gate_zr / gs_gru_gate_q to one fp16 ulp on < 1e-4 of the elements; the 256 + 128
+ * channels of pre-activations never travel to HBM and back).
+ *   gs_conv3x3_gru_zr: hx [n,h,w,hx_stride] fp16, first c_in channels = [net(128) | rest]; wpack = gs_conv3x3_pp image of
+ *     the fused convz|convr weight [256, c_in, 3, 3]; bias_zr f32 [256]; glo_zr f32 [n,256]; inp_pre fp16
  *     [n,h,w,384] or NULL.  Writes z_out = sigmoid(.) [n,h,w,128] and rnet_out = r * net [n,h,w,128]; hx is not modified.
  *   gs_conv3x3_gru_q: input [rnet (128 ch, dense) | x_rest (c_rest channels, pixels x_rest_stride apart)]; wpack = image
- *     of convq [128, 128 + c_rest, 3, 3] at kc = 64 (c_rest % 64 == 0); writes net_out = (1 - z) net + z tanh(.).   */
-/* gs_conv3x3 (kc = 64 image) + bias + ReLU in one kernel; y / y_stride may address a channel slice of a wider NHWC
- * tensor (corr_encoder[2] -> the GRU input buffer, src/droid_net.py:76; agg.conv2, :41).  EXPERIMENTAL, opt-in.      */
+ *     of convq [128, 128 + c_rest, 3, 3] (c_rest % 32 == 0); writes net_out = (1 - z) net + z tanh(.).   */
+/* gs_conv3x3_pp + bias + ReLU in one kernel; y / y_stride may address a channel slice of a wider NHWC tensor
+ * (corr_encoder[2] / flow_encoder[2] -> the GRU input buffer, src/droid_net.py:76,80; agg.conv2, :41).             */
 int gs_conv3x3_bias_relu(const void* x, int x_stride, int c_in, const void* wpack, const float* bias, void* y,
                          int y_stride, int n_out, int n, int h, int w, gs_stream_t stream);
 /* gs_conv3x3_gru_zr2: the same with the input given as [net (128 channels, dense rows) | x_rest (c_rest channels, pixels

@@ -392,8 +392,10 @@ def test_fused_mapper_step_at_32768_rays_matches_autograd_path(N, NO, dev):
     _record("fused_step_32768", {"rel_l2_vs_autograd_path_fp32_atomics": rep, "grid_rel_l2_per_level": per_level,
                                  "loss": float(loss_f)})
     # ~3800 fp16 additions per coarse-level entry: the packed-atomic sum carries fp16 accumulation error (as
-    # tiny-cuda-nn's does); same bar as the oracle-gradient tests: 0.5 % relative L2 per parameter group
+    # tiny-cuda-nn's does).  Measured (profiles/r03_pathM_parity.json): 0.75 % relative L2 on level 0 (17^3 entries for
+    # 2 M points), 0.2 % on the hashed levels, 0.21 % over the whole table; the dense parameters 1e-7 ... 4e-5.
     assert all(v < 5e-3 for v in rep.values()), (rep, per_level)
+    assert max(per_level) < 1.5e-2, per_level
     for p_ in m_ref.parameters():
         p_.grad = None
     l_ref = t_ref.step(*args)
@@ -401,15 +403,25 @@ def test_fused_mapper_step_at_32768_rays_matches_autograd_path(N, NO, dev):
     torch.testing.assert_close(l_fus.float().cpu(), l_ref.float().cpu(), rtol=2e-4, atol=1e-5)
     pr_, pf_ = dict(m_ref.named_parameters()), dict(m_fus.named_parameters())
     lr = {"sdf_network.encoding.encoding.params": 1e-2}
+    gmax = float(ref_g["grid"].abs().max())
     for k in ["sdf_network.encoding.encoding.params", "sdf_network.sdf_layer.weight", "sdf_network.sdf_layer.bias",
               "color_network._B", "color_network.network.params", "variance_network.variance"]:
         a, b = pf_[k].detach().float().cpu(), pr_[k].detach().float().cpu()
         step = lr.get(k, 1e-3)
         dlt = (a - b).abs()
-        # Adam's first step is +-lr per entry: an entry whose fp16-atomic sum lands on the other side of zero flips
+        assert float(dlt.max()) <= 2 * step * 1.01, (k, float(dlt.max()))
         off = dlt > (2e-5 + 2e-3 * b.abs())
-        assert float(off.float().mean()) < 2e-3 and float(dlt.max()) <= 2 * step * 1.01, \
-            (k, float(off.float().mean()), float(dlt.max()))
+        if k.endswith("encoding.params"):
+            # Adam's first step is -lr * sign(g) on every entry: where the gradient is below what fp16 (loss scale 128)
+            # resolves, the fp16 sum underflows or lands on the other side of zero and the entry moves differently
+            # (measured: 3.2 % of ALL entries, every one of them with |g| < 1e-4 max|g|).  Entries with a gradient that
+            # fp16 resolves must move identically.
+            big = ref_g["grid"].cpu().abs() > 1e-3 * gmax
+            assert int(big.sum()) > 1000
+            assert float(off[big].float().mean()) < 1e-3, (float(off[big].float().mean()), float(off.float().mean()))
+            assert float(off.float().mean()) < 0.1
+        else:
+            assert float(off.float().mean()) < 2e-3, (k, float(off.float().mean()))
 
 
 def test_corr_volume_pyramid_at_S480_matches_oracle(db, O, dev):

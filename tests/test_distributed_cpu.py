@@ -101,3 +101,111 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
     assert json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+
+
+# ---- sharded optimiser (FlatAdamW with world > 1): reduce-scatter -> slice step -> all-gather -----------------------
+class _TorchOptKernels:
+    """torch restatement of csrc/map_opt.hip's two kernels (TEST infrastructure: lets the gloo test drive the sharding
+    logic -- slices, padding, collectives, master sync -- on CPU tensors; the product only ever passes HipOptKernels)."""
+
+    def sqnorm(self, out, g16, inv_scale16, g32):
+        out += (g16.float() * inv_scale16).double().pow(2).sum().float()
+        if g32 is not None:
+            out += g32.double().pow(2).sum().float()
+
+    def adamw(self, p, m, v, p16, g16, inv_scale16, pd, md, vd, p16d, g32, h, step, step_dev, sqnorm):
+        t = int(step_dev.item())
+        coef = min(1.0, h["max_norm"] / (float(sqnorm.sqrt()) + 1e-6))
+        for P, M, V, P16, g, lr in ((p, m, v, p16, g16.float() * (inv_scale16 * coef), h["lr16"]),
+                                    (pd, md, vd, p16d, g32 * coef, h["lr32"])):
+            P.mul_(1 - lr * h["wd"])
+            M.mul_(h["b1"]).add_(g, alpha=1 - h["b1"])
+            V.mul_(h["b2"]).addcmul_(g, g, value=1 - h["b2"])
+            denom = V.sqrt() / (1 - h["b2"] ** t) ** 0.5 + h["eps"]
+            P.addcdiv_(M, denom, value=-lr / (1 - h["b1"] ** t))
+            P16.copy_(P.half())
+
+
+class _TinyModel(torch.nn.Module):
+    """just the attribute tree FlatAdamW binds (table of 1000 entries: NOT divisible by 8 * world -> padded slices)"""
+
+    def __init__(self):
+        super().__init__()
+        from go_slam_amd.neus.tcnn_compat import _HalfCache
+        torch.manual_seed(4)                      # nn.Linear draws from the global generator
+        g = torch.Generator().manual_seed(5)
+        mk = lambda *s: torch.nn.Parameter(torch.randn(*s, generator=g) * 0.1)
+        enc = torch.nn.Module(); enc.params = mk(1000); enc._half = _HalfCache()
+        outer = torch.nn.Module(); outer.encoding = enc
+        self.sdf_network = torch.nn.Module()
+        self.sdf_network.encoding = outer
+        self.sdf_network.sdf_layer = torch.nn.Linear(35, 32)
+        self.color_network = torch.nn.Module()
+        net = torch.nn.Module(); net.params = mk(10240); net._half = _HalfCache()
+        self.color_network.network = net
+        self.color_network._B = mk(3, 33)
+        self.variance_network = torch.nn.Module()
+        self.variance_network.variance = torch.nn.Parameter(torch.tensor(0.2))
+
+
+def _opt_run(rank, world, steps=3):
+    """`steps` optimiser steps on synthetic gradients; rank r contributes share r of every gradient"""
+    from go_slam_amd.neus.mapper import FlatAdamW
+    model = _TinyModel()
+    flat = FlatAdamW(model, rank=rank, world=world, kernels=_TorchOptKernels())
+    g = torch.Generator().manual_seed(6)
+    for _ in range(steps):
+        # integer-valued fp16 shares: their fp16 sum is exact in any order, so sharded == single-process bit for bit
+        shares16 = [torch.randint(-40, 40, (1000,), generator=g).half() for _ in range(2)]
+        shares32 = [torch.randn(flat.nd, generator=g) for _ in range(2)]
+        tab = flat.grad_table()
+        if world == 1:
+            tab.copy_(shares16[0] + shares16[1])
+            flat.g32[:flat.nd] = shares32[0] + shares32[1]
+        else:
+            tab.copy_(shares16[rank])
+            flat.g32[:flat.nd] = shares32[rank]
+        flat.g32[flat.nd] = float(rank + 1)           # "loss" share: summed by the dense all-reduce
+        flat.step(1.0 / 128.0)
+    loss = float(flat.g32[flat.nd])
+    stale = flat.P[:flat.n16].clone()
+    flat.sync_master()
+    named = {k: flat.P[a:b].clone() for k, (a, b) in flat.slices.items()}
+    named16 = {k: flat.P16[a:b].clone() for k, (a, b) in flat.slices.items()}
+    assert model.sdf_network.encoding.encoding.params.data_ptr() == flat.P.data_ptr()
+    flat.check_bindings()
+    return dict(loss=loss, named=named, named16=named16, stale=stale, pad=(flat.n16p, flat.slice), steps=flat.steps,
+                sent=flat.collective_bytes())
+
+
+def _opt_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    res = _opt_run(rank, world)
+    torch.save(res, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_equals_single_process_step(tmp_path):
+    """FlatAdamW sharded over 2 gloo ranks (reduce-scatter of the fp16 table gradient, scalar all-reduce for the clip
+    norm, AdamW on the owned slice + the replicated dense part, all-gather of the fp16 working copy, fp32 master gathered
+    on demand) == the single-process optimiser on the summed gradients, for a table whose size is not a multiple of the
+    slice granularity (padding)."""
+    ref = _opt_run(0, 1)
+    out = str(tmp_path / "opt")
+    port = 29700 + (os.getpid() % 2000)
+    mp.start_processes(_opt_worker, args=(2, port, out), nprocs=2, join=True, start_method="spawn")
+    got = [torch.load(out + f".{r}") for r in range(2)]
+    assert got[0]["pad"] == (1008, 504) and ref["pad"] == (1000, 1000)
+    assert got[0]["loss"] == got[1]["loss"] == 3.0 and got[0]["sent"] > 0 and ref["sent"] == 0
+    for r in range(2):
+        for k in ref["named"]:
+            torch.testing.assert_close(got[r]["named"][k], ref["named"][k], rtol=1e-6, atol=1e-7, msg=lambda m: f"{k}: {m}")
+            assert torch.equal(got[r]["named16"][k], got[0]["named16"][k])
+            torch.testing.assert_close(got[r]["named16"][k].float(), ref["named16"][k].float(), rtol=1e-3, atol=1e-6)
+    # before sync_master a rank's fp32 master is current only on its own slice
+    assert not torch.equal(got[0]["stale"], ref["named"]["grid"]) and torch.equal(got[0]["stale"][:504], got[0]["named"]["grid"][:504])

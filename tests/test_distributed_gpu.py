@@ -1,6 +1,6 @@
 """RCCL path of the sharded mapper step -- needs >= 2 GPUs, skipped on the 1-GPU test box.  Two ranks
 (one process per GPU, backend "nccl" = RCCL) each render half of a ray batch; after the fp16 table all-reduce + fp32
-dense all-reduce + identical flat AdamW the parameters of both ranks must be equal, and equal to a single-GPU step on
+dense all-reduce + sharded AdamW (reduce-scatter -> slice step -> all-gather) the parameters of both ranks must be equal, and equal to a single-GPU step on
 the whole batch (same tolerance as the gloo test of the autograd path, tests/test_distributed_cpu.py)."""
 import os
 
@@ -46,6 +46,7 @@ def _rank(rank, world, port, out_q):
         tr = MapTrainer(model, R, rank=rank, world=world)
         for _ in range(2):
             loss = tr.step(*args)
+        tr.flat.sync_master()          # sharded optimiser: gather the fp32 master slices the other rank owns
         torch.cuda.synchronize()
         out_q.put((rank, float(loss), tr.flat.P.detach().cpu().numpy()))
     finally:

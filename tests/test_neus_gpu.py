@@ -6,6 +6,7 @@ hash indices bit-exact (checked through dense/hash KAT levels); grid features fp
 full forward: sdf rtol 1e-4, alpha atol 2e-4, colour/depth atol 3e-3 (fp16 rgb), grad rtol 1e-3.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -429,3 +430,105 @@ def test_flat_adamw_kernels_match_torch_adamw(N, dev, built_lib):
         torch.testing.assert_close(P16.float(), ref.half().float(), rtol=0, atol=1e-3)
     want = float(torch.cat([g16.float() / 128.0, g32]).pow(2).sum())
     assert abs(float(sq) - want) / want < 1e-4 and want ** 0.5 > 35.0, "the clip must be active in this test"
+
+
+def test_graph_replay_matches_eager_fused_step(N, O, dev):
+    """MapTrainer(graph=True): the fused step captured once per batch shape in a hipGraph and replayed (static input
+    buffers, device-side step count for Adam's bias corrections, perturbation vector drawn outside the graph) vs the
+    same step launched eagerly on an identical model: same loss every iteration and the same parameters afterwards --
+    with NEW rays in every iteration, so a replay that read stale inputs would show."""
+    from go_slam_amd.neus.mapper import MapTrainer
+    P = O.make_params(61, grid_init=0.05, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    trainers = []
+    for graph in (False, True):
+        model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+        _load(model, P)
+        trainers.append((model, MapTrainer(model, N.Renderer(N_samples=24, N_surface=48), graph=graph)))
+    (m_e, t_e), (m_g, t_g) = trainers
+    assert t_e.fused and t_g.fused and t_g.graph and not t_e.graph
+    g = torch.Generator().manual_seed(62)
+    for it in range(6):
+        o, d, gt = _rays(768, seed=100 + it)
+        col = torch.rand(768, 3, generator=g)
+        pr = torch.rand(24, generator=g)
+        args = [t.to(dev) for t in (o, d, col, gt, pr)]
+        l_e, l_g = t_e.step(*args), t_g.step(*args)
+        torch.testing.assert_close(l_g.float().cpu(), l_e.float().cpu(), rtol=3e-4, atol=1e-5,
+                                   msg=lambda m: f"iteration {it}: {m}")
+    ent = next(iter(t_g._graphs.values()))
+    assert ent["graph"] is not None, "the step was never captured"
+    assert t_g.flat.steps == t_e.flat.steps == 6 and int(t_g.flat.step_dev) == 6
+    pe, pg = t_e.flat.P, t_g.flat.P
+    d = (pe - pg).abs()
+    # fp16-atomic order noise -> +-lr flips of entries whose gradient is at rounding level (see the autograd-step test):
+    # ~0.06 % of the entries per step (measured 0.35 % after these 6), each by at most steps x lr
+    off = d > (2e-5 + 2e-3 * pe.abs())
+    assert float(off.float().mean()) < 1e-2 and float(d.max()) <= 6 * 1e-2 * 1.01, (float(off.float().mean()), float(d.max()))
+    # a second batch shape gets its own graph; changing the learning rate re-captures instead of replaying stale scalars
+    o, d, gt = _rays(256, seed=300)
+    args2 = [t.to(dev) for t in (o, d, torch.rand(256, 3), gt)]
+    for _ in range(4):
+        t_g.step(*args2)
+    assert len(t_g._graphs) == 2
+    t_g.optimizer.set_lr(grid_lr=5e-3)
+    for _ in range(3):
+        t_g.step(*args2)
+    assert len(t_g._graphs) == 3 and t_g.optimizer.param_groups[1]["lr"] == 5e-3
+
+
+def _one_gpu_rank(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    from go_slam_amd.neus.mapper import MapTrainer
+    import go_slam_amd.neus as neus
+    from oracle import neus_oracle as NO
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    P = NO.make_params(71, grid_init=0.05, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    model = neus.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    tr = MapTrainer(model, neus.Renderer(N_samples=24, N_surface=48), rank=rank, world=world)
+    o, d, gt = _rays(600, seed=72)
+    g = torch.Generator().manual_seed(73)
+    args = [t.to(dev) for t in (o, d, torch.rand(600, 3, generator=g), gt, torch.rand(24, generator=g))]
+    for _ in range(4):
+        loss = tr.step(*args)
+    sd = {k: v.detach().cpu() for k, v in tr.state_dict().items()}
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({"loss": float(loss), "sd": sd, "slice": tr.flat.slice, "graphs": len(tr._graphs)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_fused_step_two_ranks_on_one_gpu_equals_single_process(N, O, dev, tmp_path):
+    """The sharded mapper step with the real HIP kernels: 2 ranks (both on cuda:0, gloo carrying the collectives -- RCCL
+    needs one device per rank) render half the rays each, reduce-scatter the fp16 table gradient, step their slice,
+    all-gather the fp16 table; 4 iterations (2 eager + capture + replay) == the single-process trainer."""
+    import torch.multiprocessing as mp
+    from go_slam_amd.neus.mapper import MapTrainer
+    out = str(tmp_path / "two.pt")
+    mp.start_processes(_one_gpu_rank, args=(2, 29800 + (os.getpid() % 1000), out), nprocs=2, join=True, start_method="spawn")
+    got = torch.load(out)
+    P = O.make_params(71, grid_init=0.05, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    tr = MapTrainer(model, N.Renderer(N_samples=24, N_surface=48))
+    o, d, gt = _rays(600, seed=72)
+    g = torch.Generator().manual_seed(73)
+    args = [t.to(dev) for t in (o, d, torch.rand(600, 3, generator=g), gt, torch.rand(24, generator=g))]
+    for _ in range(4):
+        loss = tr.step(*args)
+    assert got["slice"] * 2 >= tr.flat.n16 and got["graphs"] == 1
+    assert abs(got["loss"] - float(loss)) < 3e-4 * max(1.0, abs(float(loss)))
+    trained = {"sdf_network.encoding.encoding.params", "sdf_network.sdf_layer.weight", "sdf_network.sdf_layer.bias",
+               "color_network._B", "color_network.network.params", "variance_network.variance"}
+    for k, v in tr.state_dict().items():
+        if k not in trained:            # (sdf_network.encoding._B is drawn at construction and never trained)
+            continue
+        a, b = got["sd"][k].float(), v.detach().cpu().float()
+        dlt = (a - b).abs()
+        lr = 1e-2 if k.endswith("encoding.params") else 1e-3
+        off = dlt > (2e-5 + 2e-3 * b.abs())
+        assert float(off.float().mean()) < 3e-3 and float(dlt.max()) <= 4 * lr * 1.01, (k, float(off.float().mean()), float(dlt.max()))

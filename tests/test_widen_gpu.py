@@ -233,30 +233,6 @@ def test_point_queries_and_extract_fields_match_oracle(built_lib):
     assert int(np.abs(cols.astype(np.int32) - (np.clip(rgb_r[:100].numpy(), 0, 1) * 255).astype(np.int32)).max()) <= 2
 
 
-@pytest.mark.parametrize("kc", [32, 64])
-@pytest.mark.parametrize("n,h,w,c,xs,o", [(3, 30, 40, 320, 320, 256), (2, 12, 16, 128, 128, 384), (1, 60, 80, 128, 128, 128),
-                                          (2, 17, 23, 64, 96, 128)])
-def test_conv3x3_implicit_gemm_matches_reference(built_lib, n, h, w, c, xs, o, kc):
-    """gs_conv3x3 (own implicit-GEMM MFMA convolution, experimental) vs F.conv2d in fp32 on the same fp16 operands:
-    partial tiles (h, w not multiples of 16), a channel slice of a wider tensor (xs > c), 1-3 output blocks.
-    Both chunk sizes (kc = 32 / 64 input channels staged per LDS chunk).  Tolerance: one fp16 rounding of the output (the products are exact in fp32, the sum order differs)."""
-    from go_slam_amd import _lib
-    from go_slam_amd.droid_net import pack_conv3x3_weight
-    dev = "cuda:0"
-    g = torch.Generator().manual_seed(n * 1000 + c)
-    x = torch.randn(n, h, w, xs, generator=g).half().to(dev)
-    wt = (torch.randn(o, c, 3, 3, generator=g) / (3.0 * c ** 0.5)).half().to(dev)
-    wp = pack_conv3x3_weight(wt, kc)
-    assert wp.numel() == _lib.lib().gs_conv3x3_wpack_elems(c, o)
-    y = torch.full((n, h, w, o + 8), 7.0, dtype=torch.float16, device=dev)          # y_stride > n_out: the tail stays
-    rc = _lib.lib().gs_conv3x3(_lib.ptr(x), xs, c, _lib.ptr(wp), kc, _lib.ptr(y), o + 8, o, n, h, w,
-                               _lib.stream_ptr(dev))
-    _lib.check(rc, "conv3x3")
-    ref = torch.nn.functional.conv2d(x[..., :c].permute(0, 3, 1, 2).float(), wt.float(), padding=1).permute(0, 2, 3, 1)
-    assert bool((y[..., o:] == 7.0).all())
-    torch.testing.assert_close(y[..., :o].float(), ref, rtol=2e-3, atol=2e-3)
-
-
 @pytest.mark.parametrize("n,h,w,c,xs,o,tw", [(5, 30, 40, 128, 128, 128, 8), (3, 60, 80, 320, 320, 256, 16),
                                               (4, 7, 37, 64, 72, 128, 16), (6, 5, 19, 64, 64, 256, 8),
                                               (1, 40, 80, 128, 128, 384, 16), (75, 40, 80, 128, 128, 128, 16),
@@ -274,6 +250,7 @@ def test_conv3x3_pingpong_kernel_matches_reference(built_lib, n, h, w, c, xs, o,
     x = torch.randn(n, h, w, xs, generator=g).half().to(dev)
     wt = (torch.randn(o, c, 3, 3, generator=g) / (3.0 * c ** 0.5)).half().to(dev)
     wp = pack_conv3x3_weight(wt, 32)
+    assert wp.numel() == _lib.lib().gs_conv3x3_wpack_elems(c, o)
     ref = torch.nn.functional.conv2d(x[..., :c].permute(0, 3, 1, 2).float(), wt.float(), padding=1).permute(0, 2, 3, 1)
     first = None
     for rep in range(4):
@@ -289,31 +266,10 @@ def test_conv3x3_pingpong_kernel_matches_reference(built_lib, n, h, w, c, xs, o,
             assert torch.equal(y, first), f"run {rep} differs from run 0"
 
 
-@pytest.mark.parametrize("n,h,w,c,xs,o,kc,tw", [(5, 30, 40, 128, 128, 128, 64, 8), (3, 60, 80, 320, 320, 256, 32, 16),
-                                                 (4, 7, 37, 64, 72, 128, 32, 32), (6, 5, 19, 64, 64, 256, 64, 8),
-                                                 (1, 40, 80, 128, 128, 384, 64, 16)])
-def test_conv3x3_row_stacked_tiles_match_reference(built_lib, n, h, w, c, xs, o, kc, tw):
-    """gs_conv3x3_stacked: tiles run across image boundaries, so the vertical taps must be masked per pixel (y == 0 /
-    y == h-1) -- images shorter than a tile (several images per tile), h not a multiple of the tile height, all three
-    tile widths, both chunk sizes; vs F.conv2d in fp32 on the same fp16 operands."""
-    from go_slam_amd import _lib
-    from go_slam_amd.droid_net import pack_conv3x3_weight
-    dev = "cuda:0"
-    g = torch.Generator().manual_seed(n * 100 + h)
-    x = torch.randn(n, h, w, xs, generator=g).half().to(dev)
-    wt = (torch.randn(o, c, 3, 3, generator=g) / (3.0 * c ** 0.5)).half().to(dev)
-    wp = pack_conv3x3_weight(wt, kc)
-    y = torch.full((n, h, w, o), 7.0, dtype=torch.float16, device=dev)
-    rc = _lib.lib().gs_conv3x3_stacked(_lib.ptr(x), xs, c, _lib.ptr(wp), kc, tw, _lib.ptr(y), o, o, n, h, w,
-                                       _lib.stream_ptr(dev))
-    _lib.check(rc, "conv3x3_stacked")
-    ref = torch.nn.functional.conv2d(x[..., :c].permute(0, 3, 1, 2).float(), wt.float(), padding=1).permute(0, 2, 3, 1)
-    torch.testing.assert_close(y.float(), ref, rtol=2e-3, atol=2e-3)
-
-
 def test_update_operator_with_own_conv3x3_matches_miopen_path(built_lib):
-    """UpdateModule's inference fast path with CONV3X3_IMPL = "hip" (all large 3x3 convolutions on gs_conv3x3) vs the
-    same path on MIOpen: same outputs within fp16 accumulation-order noise."""
+    """UpdateModule's inference fast path on the package's own 3x3 convolution (gs_conv3x3_pp and its fused epilogues)
+    vs the same path with the library convolution (CONV3X3_IMPL = "miopen", the tests' referee): same outputs within
+    fp16 accumulation-order noise."""
     import go_slam_amd.droid_net as DN
     dev = "cuda:0"
     torch.manual_seed(5)
@@ -329,14 +285,14 @@ def test_update_operator_with_own_conv3x3_matches_miopen_path(built_lib):
     out = {}
     keep = DN.CONV3X3_IMPL
     try:
-        for impl in ("miopen", "hip"):
+        for impl in ("miopen", "own"):
             DN.CONV3X3_IMPL = impl
             op.drop_edge_caches()
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
                 out[impl] = [t.float() for t in op(net.clone(), inp, corr, flow, ii, ii)]
     finally:
         DN.CONV3X3_IMPL = keep
-    for a, b, name in zip(out["hip"], out["miopen"], ("net", "delta", "weight", "eta", "upmask")):
+    for a, b, name in zip(out["own"], out["miopen"], ("net", "delta", "weight", "eta", "upmask")):
         torch.testing.assert_close(a, b, rtol=5e-3, atol=3e-3, msg=lambda m, nm=name: f"{nm}: {m}")
 
 
@@ -359,7 +315,7 @@ def test_fused_gru_epilogues_equal_conv_plus_gate_kernels(built_lib, hoisted):
     keep = (DN.CONV3X3_IMPL, DN.GRU_FUSED_EPILOGUE)
     out = {}
     try:
-        DN.CONV3X3_IMPL = "hip"
+        DN.CONV3X3_IMPL = "own"
         for fused in (False, True):
             DN.GRU_FUSED_EPILOGUE = fused
             with torch.no_grad():
@@ -382,7 +338,7 @@ def test_fused_gru_epilogues_equal_conv_plus_gate_kernels(built_lib, hoisted):
 
 def test_fused_bias_relu_convolution_equals_conv_plus_bias_act(built_lib):
     """gs_conv3x3_bias_relu (bias + ReLU in the convolution's store stage, output into a channel slice of a wider
-    tensor) vs gs_conv3x3 followed by gs_bias_act: EQUAL, and the other channels of the destination are untouched."""
+    tensor) vs gs_conv3x3_pp followed by gs_bias_act: EQUAL, and the other channels of the destination are untouched."""
     import go_slam_amd.droid_net as DN
     dev = "cuda:0"
     torch.manual_seed(31)
@@ -392,7 +348,7 @@ def test_fused_bias_relu_convolution_equals_conv_plus_bias_act(built_lib):
     keep = (DN.CONV3X3_IMPL, DN.GRU_FUSED_EPILOGUE)
     res = {}
     try:
-        DN.CONV3X3_IMPL = "hip"
+        DN.CONV3X3_IMPL = "own"
         for fused in (False, True):
             DN.GRU_FUSED_EPILOGUE = fused
             hx = torch.full((6, 320, 32, 48), 3.0, device=dev, dtype=torch.float16).contiguous(
@@ -525,7 +481,7 @@ def test_conv3x3_pingpong_64_output_channels(built_lib, n, h, w):
     x = torch.randn(n, 128, h, w, device=dev).half().contiguous(memory_format=torch.channels_last)
     wt = conv.weight.detach().half().contiguous(memory_format=torch.channels_last)
     assert DN.conv3x3_hip_supported(x, wt)
-    y = DN.conv3x3_hip(x, wt, pp=True)
+    y = DN.conv3x3_hip(x, wt)
     ref = F.conv2d(x.float(), wt.float(), padding=1)
     err = (y.float() - ref).abs()
     assert bool((err <= 2.0 ** -10 * ref.abs().clamp_min(1.0)).all()), float(err.max())

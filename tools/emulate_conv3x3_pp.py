@@ -38,6 +38,16 @@ def tile_pixel(TW, wm, i, r):
     return wm * 16 + i + 8 * grp + 4 * (pos >> 3), pos & 7
 
 
+def decode_block(L, ntiles, NB, xcd):
+    """conv3x3_common.h decode_block: workgroup id -> (tile, output-channel block)"""
+    if not xcd:
+        return L % ntiles, L // ntiles
+    G = 8 * NB
+    s, l = L // G, L % G
+    m = min(8, ntiles - s * 8)
+    return s * 8 + l % m, l // m
+
+
 def geometry(TW):
     TH = 512 // TW
     PW = TW + 2
