@@ -371,7 +371,7 @@ def conv_roofline(device, E, ht, wd):
         ms_sum += ms
         del x, w
     tf = flops_sum / (ms_sum * 1e-3) / 1e12
-    kern = "conv3x3_pp_kernel (two-group ping-pong implicit GEMM, LDS-DMA staging)" if DN.CONV3X3_PP else "conv3x3_kernel"
+    kern = "conv3x3_pp_kernel (two-group ping-pong implicit GEMM, LDS-DMA staging)"
     out = {"kernel": kern + ", fp16 MFMA 32x32x16 / fp32 accumulate; the update operator's four 3x3 layer shapes",
            "bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": tf / MFMA_F16_PEAK_TFLOPS, "algorithmic_flops_per_update": flops_sum,

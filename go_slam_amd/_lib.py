@@ -79,6 +79,9 @@ SIGNATURES = {
     "gs_mlp_backward_blocks": (c_int, [c_int]),
     "gs_mlp_backward": (c_int, [_P, _P, _P, _P, c_float, _P, _P, c_int, _P]),
     "gs_neus_backward_points": (c_int, [_P] * 7 + [c_float] + [_P] * 9 + [c_int, c_float, _P, _P, c_int, c_float] + [_P] * 5 + [c_int, c_float, c_int, _P, c_int, c_int, _P]),
+    "gs_neus_backward_points_binned": (c_int, [_P] * 7 + [c_float] + [_P] * 9 + [c_int, c_float, _P, _P, c_float] + [_P] * 5
+                                       + [c_int, c_float, c_int, _P, c_int, c_int, _P, c_size_t, _P]),
+    "gs_neus_bin_workspace_bytes": (c_size_t, [c_int]),
 }
 
 

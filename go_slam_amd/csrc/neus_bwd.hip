@@ -12,6 +12,28 @@
 //                          fp32 atomics into the table gradient; small dense parameter gradients
 //                          are emitted as per-point rows and reduced by GEMM / column sums on the
 //                          host side of the C ABI's caller.
+//
+// Table gradient WITHOUT global atomics (gs_neus_backward_points_binned; the production mode).  Every flavour of
+// global atomic on MI355X retires at 21 G requests/s however the addresses are spread (scratch/atomic_bench.hip,
+// profiles/r03_pmc_neus.json: pk_add_f16 / add_f32, sc1 or not, 0.5 ... 25 MB tables, XCD-private regions), and the PMC
+// counters show all of them forwarded to the memory side; the 95 M requests of a 32768-ray step cost 4.5 ms of this
+// kernel's 5.0.  The same read-modify-writes run 7x faster as plain L2 traffic and far faster still in LDS, so for the
+// 11 HASHED levels (93 % of the requests; 2^19 entries each) the scatter becomes bin-and-reduce:
+//   pass 1  neus_point_bwd_kernel<true>: each hashed level is cut into 64 bins of 8192 entries (bin = index >> 13).  A
+//           workgroup stages its (13-bit index, 2 x fp16 value) records per bin in LDS (double-buffered, so one barrier
+//           per level) and copies every staged bin out as ONE contiguous run into a segment of the bin's queue that
+//           belongs to this workgroup alone -- no reservation, no global atomic, no zeroing: the segment's fill count
+//           (one byte) is written with it.
+//   pass 2  grid_bin_reduce_kernel: one workgroup per bin sums the bin's records in LDS and writes the bin's 8192 entries
+//           of the table gradient ONCE with plain stores (adding what is already there: any overflow records' atomics).
+//           The sums are INTEGER: an fp16 value is a multiple of 2^-24, so every record is converted exactly to 64-bit
+//           fixed point (x 2^24) and added with ds_add_u64 -- the bin's sum is exact and independent of the order, and
+//           is rounded to fp16 once.  Why not float: scratch/lds_atomic_bench.hip measures ds_add_f32 / ds_pk_add_f16
+//           at 0.33 lanes per clock and CU against 5.3 for integer LDS atomics (the first version of this pass, with
+//           ds_add_f32: 2.2 ms; a barrier-synchronised non-atomic version: 5.3 ms).
+// The dense levels 0-4 (0.5 M entries, heavily pre-reduced inside the wave) stay on packed atomics.  Overflow of a
+// staging bin or of a queue falls back to the atomic, so every input is handled.  Side effect: the hashed levels'
+// gradient is summed in fp32 (each record rounded once to fp16) instead of through thousands of fp16 read-modify-writes.
 #include "common.h"
 #include "neus_common.h"
 #include <math.h>
@@ -124,7 +146,15 @@ struct BwdArgs {
   float* grid_grad; _Float16* grid_grad16; float grad_scale16; void* d_out; void* lin_in; void* dw0; void* d_arg; void* pts; float* d_inv_s;
   int rows16; float row_scale; int dx16; float dx_inv_scale; int row_stride16;
   int n, s;
+  // binned table gradient (BINNED instantiation): record queues [hashed level * 64 + bin][workgroup][ST_SLOTS] and the
+  // segments' fill counts [hashed level * 64 + bin][workgroup]
+  uint16_t* q_idx; uint32_t* q_val; uint8_t* q_cnt;
 };
+
+constexpr int BIN_SHIFT = 13, BIN_ENTRIES = 1 << BIN_SHIFT;   // 8192 entries per bin
+constexpr int BINS_PER_LEVEL = 64;                            // hashed levels hold 2^19 entries
+constexpr int ST_SLOTS = 48;                                  // records per (workgroup, level, bin): staging AND queue segment
+                                                              // (expected 256 x 8 / 64 = 32 at most; beyond: atomics)
 
 // 8 consecutive entries of row i of dX (fp32, or loss-scaled fp16 straight from the MLP-backward GEMM)
 __device__ __forceinline__ void load_dx8(const BwdArgs& A, int i, int c, float* out) {
@@ -175,9 +205,18 @@ __device__ __forceinline__ void st_row(void* base, bool h16, size_t idx, float v
   else reinterpret_cast<float*>(base)[idx] = v;
 }
 
+template <bool BINNED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void neus_point_bwd_kernel(BwdArgs A, gs_grid_meta m) {
   __shared__ float red[4];
   __shared__ uint32_t row_tiles[4][64 * ROW_TS];
+  __shared__ uint32_t st_val[BINNED ? 2 : 1][BINNED ? BINS_PER_LEVEL : 1][BINNED ? ST_SLOTS : 1];
+  __shared__ uint16_t st_idx[BINNED ? 2 : 1][BINNED ? BINS_PER_LEVEL : 1][BINNED ? ST_SLOTS : 1];
+  __shared__ uint32_t st_cnt[2][BINS_PER_LEVEL];
+  if (BINNED) {
+    if (threadIdx.x < 2 * BINS_PER_LEVEL) (&st_cnt[0][0])[threadIdx.x] = 0u;
+    __syncthreads();
+  }
+  int hord = 0;                                   // ordinal of the current level among the hashed ones
   uint32_t* tile = row_tiles[threadIdx.x >> 6];
   _Float16* tile_h = reinterpret_cast<_Float16*>(tile + (threadIdx.x & 63) * ROW_TS);    // this lane's row
   const size_t wave_p0 = (size_t)blockIdx.x * 256 + (threadIdx.x >> 6) * 64;
@@ -347,8 +386,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
         st_row(A.dw0, false, o35 + 3 + 2 * l + 1, v1);
       }
     }
-    lvl_scatter(A.grid_grad ? A.grid_grad + off * 2 : nullptr, A.grid_grad16 ? A.grid_grad16 + off * 2 : nullptr,
-                A.grad_scale16, cidx, gacc, gi, on, lane);
+    if (BINNED && m.hashed[l]) {
+      // ---- pass 1 of bin-and-reduce: stage this workgroup's records of level l per bin, then copy them to the queues
+      _Float16* tab16 = A.grid_grad16 + off * 2;
+      const int buf = hord & 1;
+      const bool act = lvl_prereduce(gacc, gi, on, lane) && on;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (act && (gacc[c][0] != 0.0f || gacc[c][1] != 0.0f)) {
+          const uint32_t e = cidx[c], bin = e >> BIN_SHIFT;
+          const uint32_t packed = pack2h(gacc[c][0] * A.grad_scale16, gacc[c][1] * A.grad_scale16);
+          const uint32_t slot = atomicAdd(&st_cnt[buf][bin], 1u);
+          if (slot < (uint32_t)ST_SLOTS) {
+            st_idx[buf][bin][slot] = (uint16_t)(e & (BIN_ENTRIES - 1));
+            st_val[buf][bin][slot] = packed;
+          } else {                                  // staging bin full: this record goes out as an atomic
+            __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2a*)(tab16 + (size_t)e * 2),
+                                                      __builtin_bit_cast(half2a, packed));
+          }
+        }
+      }
+      __syncthreads();
+      // wave w copies bins w, w + 4, ... to this workgroup's segments.  Staging buffer `buf` is appended to again two
+      // hashed levels from now, i.e. after the NEXT level's barrier, which every wave reaches only after this copy.
+      {
+        const int wv = threadIdx.x >> 6;
+        const size_t nblk = gridDim.x;
+#pragma unroll 1
+        for (int b = wv; b < BINS_PER_LEVEL; b += 4) {
+          const uint32_t cn = st_cnt[buf][b];
+          const uint32_t c = cn < (uint32_t)ST_SLOTS ? cn : (uint32_t)ST_SLOTS;
+          const size_t seg = (size_t)(hord * BINS_PER_LEVEL + b) * nblk + blockIdx.x;
+          if (lane < (int)c) {
+            A.q_idx[seg * ST_SLOTS + lane] = st_idx[buf][b][lane];
+            A.q_val[seg * ST_SLOTS + lane] = st_val[buf][b][lane];
+          }
+          if (lane == 0) {
+            A.q_cnt[seg] = (uint8_t)c;
+            st_cnt[buf][b] = 0u;
+          }
+        }
+      }
+      ++hord;
+    } else {
+      lvl_scatter(A.grid_grad ? A.grid_grad + off * 2 : nullptr, A.grid_grad16 ? A.grid_grad16 + off * 2 : nullptr,
+                  A.grad_scale16, cidx, gacc, gi, on, lane);
+    }
   }
   // ---- colour embedding sin(pts @ B): d arg = d emb * cos(arg)
   const size_t np_all = (size_t)np;
@@ -401,13 +484,88 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
   }
 }
 
+// pass 2 of bin-and-reduce: one workgroup per (hashed level, bin); see the file header
+__device__ __forceinline__ long long fix24(uint32_t h) {       // fp16 bits -> value * 2^24, exact (|v| <= 65504 < 2^16)
+  const float v = fminf(fmaxf((float)__builtin_bit_cast(_Float16, (uint16_t)h), -65504.0f), 65504.0f);   // (inf: saturate)
+  return (long long)(v * 16777216.0f);
+}
+
+__global__ __launch_bounds__(1024) void grid_bin_reduce_kernel(const uint16_t* __restrict__ q_idx,
+                                                               const uint32_t* __restrict__ q_val,
+                                                               const uint8_t* __restrict__ q_cnt, int nblk,
+                                                               _Float16* __restrict__ tab16, gs_grid_meta m) {
+  extern __shared__ unsigned long long acc[];          // [BIN_ENTRIES][2] 64-bit fixed point (two's complement)
+  const int q = blockIdx.x, h = q / BINS_PER_LEVEL, b = q - h * BINS_PER_LEVEL;
+  int l = 0;
+  for (int k = 0, seen = 0; k < GS_GRID_LEVELS; ++k)
+    if (m.hashed[k]) { if (seen == h) l = k; ++seen; }
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 2 * BIN_ENTRIES / 2; e += 1024) reinterpret_cast<uint4*>(acc)[e] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  const uint8_t* cnt = q_cnt + (size_t)q * nblk;
+  const uint16_t* qi = q_idx + (size_t)q * nblk * ST_SLOTS;
+  const uint32_t* qv = q_val + (size_t)q * nblk * ST_SLOTS;
+  // a segment (one pass-1 workgroup's records for this bin: ST_SLOTS = 48 slots, `cnt` of them filled) is read by 12
+  // threads, 4 records each: one 8-byte index load + one 16-byte value load
+  constexpr int TPS = ST_SLOTS / 4;                    // threads per segment
+  constexpr int SPB = 1020 / TPS;                      // segments per workgroup step (85)
+  const int sub = tid / TPS, part = tid - sub * TPS;
+  if (sub < SPB) {
+    for (int sg = sub; sg < nblk; sg += SPB) {
+      const int c = cnt[sg];
+      const int s0 = 4 * part;
+      if (s0 < c) {
+        const size_t at = (size_t)sg * ST_SLOTS + s0;
+        const uint2 ix = *reinterpret_cast<const uint2*>(qi + at);
+        const uint4 vv = *reinterpret_cast<const uint4*>(qv + at);
+        const uint32_t iw[4] = {ix.x & 0xffffu, ix.x >> 16, ix.y & 0xffffu, ix.y >> 16};
+        const uint32_t vw[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (s0 + k < c) {
+            atomicAdd(&acc[2 * iw[k]], (unsigned long long)fix24(vw[k] & 0xffffu));
+            atomicAdd(&acc[2 * iw[k] + 1], (unsigned long long)fix24(vw[k] >> 16));
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // the bin's entries: existing content (zero, or the atomics of overflow records) + the exact sums, rounded once
+  uint32_t* out = reinterpret_cast<uint32_t*>(tab16) + (size_t)m.offset[l] + (size_t)b * BIN_ENTRIES;
+  for (int e = tid; e < BIN_ENTRIES / 4; e += 1024) {
+    const uint4 old = reinterpret_cast<const uint4*>(out)[e];
+    const uint32_t ow[4] = {old.x, old.y, old.z, old.w};
+    uint32_t nw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float o0 = (float)__builtin_bit_cast(_Float16, (uint16_t)(ow[k] & 0xffffu));
+      const float o1 = (float)__builtin_bit_cast(_Float16, (uint16_t)(ow[k] >> 16));
+      const float a0 = (float)((double)(long long)acc[2 * (4 * e + k)] * (1.0 / 16777216.0));
+      const float a1 = (float)((double)(long long)acc[2 * (4 * e + k) + 1] * (1.0 / 16777216.0));
+      nw[k] = pack2h(o0 + a0, o1 + a1);
+    }
+    reinterpret_cast<uint4*>(out)[e] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
+  }
+}
+
 gs_grid_meta host_meta() {
   gs_grid_meta m;
   gs_grid_meta_default(&m);
   return m;
 }
 
+size_t bin_workgroups(size_t np) { return (np + 255) / 256; }
+
 }  // namespace
+
+extern "C" size_t gs_neus_bin_workspace_bytes(int n_points) {
+  const gs_grid_meta m = host_meta();
+  size_t nh = 0;
+  for (int l = 0; l < GS_GRID_LEVELS; ++l) nh += m.hashed[l] ? 1 : 0;
+  const size_t nq = nh * BINS_PER_LEVEL, nblk = bin_workgroups((size_t)(n_points > 0 ? n_points : 0));
+  return gs_align(nq * nblk) + nq * nblk * ST_SLOTS * 6 + 512;       // fill counts | values | indices
+}
 
 extern "C" int gs_neus_backward_rays(const float* alpha, const void* rgb, const float* z_mid, const float* grad,
                                      const uint8_t* mask, const float* d_color, const float* d_depth,
@@ -424,7 +582,7 @@ extern "C" int gs_neus_backward_rays(const float* alpha, const void* rgb, const 
   return GS_OK;
 }
 
-extern "C" int gs_neus_backward_points(const float* rays_o, const float* rays_d, const float* z_vals,
+static int backward_points_impl(const float* rays_o, const float* rays_d, const float* z_vals,
                                        const float* dists, const void* grid, const float* sdf_w,
                                        const float* color_B, float inv_s, const float* inv_s_dev, const float* bound_host,
                                        const float* sdf,
@@ -434,7 +592,7 @@ extern "C" int gs_neus_backward_points(const float* rays_o, const float* rays_d,
                                        void* grid_grad, int grid_grad_dtype, float grid_grad_scale, void* d_out,
                                        void* lin_in, void* dw0, void* d_arg, void* pts, int row_dtype,
                                        float row_scale, int row_stride, float* d_inv_s, int n, int s,
-                                       gs_stream_t stream) {
+                                       void* bin_ws, size_t bin_ws_bytes, gs_stream_t stream) {
   GS_REQUIRE(row_stride == 0 || (row_dtype == GS_F16 && row_stride >= 40 && row_stride % 8 == 0),
              "neus_backward_points: row_stride needs f16 rows, >= 40, a multiple of 8");
   GS_REQUIRE(dx_dtype == GS_F32 || dx_dtype == GS_F16, "neus_backward_points: dX dtype f32 or f16");
@@ -458,7 +616,73 @@ extern "C" int gs_neus_backward_points(const float* rays_o, const float* rays_d,
   A.d_out = d_out; A.lin_in = lin_in; A.dw0 = dw0; A.d_arg = d_arg; A.pts = pts;
   A.rows16 = row_dtype == GS_F16; A.row_scale = row_scale; A.row_stride16 = row_stride / 8; A.dx16 = dx_dtype == GS_F16; A.dx_inv_scale = 1.0f / dx_scale;
   A.d_inv_s = d_inv_s; A.n = n; A.s = s;
-  neus_point_bwd_kernel<<<gs_cdiv(n * s, 256), 256, 0, (hipStream_t)stream>>>(A, host_meta());
-  GS_CHECK_LAUNCH("neus_backward_points");
+  A.q_idx = nullptr; A.q_val = nullptr; A.q_cnt = nullptr;
+  const gs_grid_meta m = host_meta();
+  if (!bin_ws) {
+    neus_point_bwd_kernel<false><<<gs_cdiv(n * s, 256), 256, 0, (hipStream_t)stream>>>(A, m);
+    GS_CHECK_LAUNCH("neus_backward_points");
+    return GS_OK;
+  }
+  // ---- binned table gradient: queues carved from the caller's workspace
+  GS_REQUIRE(grid_grad_dtype == GS_F16, "neus_backward_points_binned: the table gradient must be f16 (loss-scaled)");
+  int nh = 0;
+  for (int l = 0; l < GS_GRID_LEVELS; ++l) {
+    if (!m.hashed[l]) continue;
+    GS_REQUIRE(m.size[l] == (uint32_t)BINS_PER_LEVEL * BIN_ENTRIES, "neus_backward_points_binned: hashed level %d has %u entries", l, m.size[l]);
+    ++nh;
+  }
+  const size_t nq = (size_t)nh * BINS_PER_LEVEL;
+  const size_t need = gs_neus_bin_workspace_bytes(n * s);
+  if (bin_ws_bytes < need) {
+    gs_set_error("neus_backward_points_binned: workspace too small (%zu < %zu bytes)", bin_ws_bytes, need);
+    return GS_ERR_WORKSPACE;
+  }
+  const size_t nblk = bin_workgroups((size_t)n * s);
+  char* base = (char*)gs_align((size_t)bin_ws);
+  A.q_cnt = (uint8_t*)base;                                       // [nq][nblk]
+  A.q_val = (uint32_t*)(base + gs_align(nq * nblk));              // [nq][nblk][ST_SLOTS]
+  A.q_idx = (uint16_t*)((char*)A.q_val + nq * nblk * ST_SLOTS * 4);
+  neus_point_bwd_kernel<true><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(A, m);
+  GS_CHECK_LAUNCH("neus_backward_points_binned");
+  static GsLdsLimit limit;
+  const size_t lds = (size_t)2 * BIN_ENTRIES * sizeof(unsigned long long);
+  if (int rc = limit.raise((const void*)grid_bin_reduce_kernel, lds, "grid_bin_reduce")) return rc;
+  grid_bin_reduce_kernel<<<(unsigned)nq, 1024, lds, (hipStream_t)stream>>>(A.q_idx, A.q_val, A.q_cnt, (int)nblk,
+                                                                           A.grid_grad16, m);
+  GS_CHECK_LAUNCH("grid_bin_reduce");
   return GS_OK;
+}
+
+extern "C" int gs_neus_backward_points(const float* rays_o, const float* rays_d, const float* z_vals,
+                                       const float* dists, const void* grid, const float* sdf_w,
+                                       const float* color_B, float inv_s, const float* inv_s_dev, const float* bound_host,
+                                       const float* sdf,
+                                       const float* grad, const uint8_t* mask, const float* d_alpha,
+                                       const float* d_sdf, const float* d_grad, const void* dX, int dx_dtype,
+                                       float dx_scale, const float* d_gerr_ray,
+                                       void* grid_grad, int grid_grad_dtype, float grid_grad_scale, void* d_out,
+                                       void* lin_in, void* dw0, void* d_arg, void* pts, int row_dtype,
+                                       float row_scale, int row_stride, float* d_inv_s, int n, int s,
+                                       gs_stream_t stream) {
+  return backward_points_impl(rays_o, rays_d, z_vals, dists, grid, sdf_w, color_B, inv_s, inv_s_dev, bound_host, sdf, grad,
+                              mask, d_alpha, d_sdf, d_grad, dX, dx_dtype, dx_scale, d_gerr_ray, grid_grad, grid_grad_dtype,
+                              grid_grad_scale, d_out, lin_in, dw0, d_arg, pts, row_dtype, row_scale, row_stride, d_inv_s, n,
+                              s, nullptr, 0, stream);
+}
+
+extern "C" int gs_neus_backward_points_binned(const float* rays_o, const float* rays_d, const float* z_vals,
+                                              const float* dists, const void* grid, const float* sdf_w,
+                                              const float* color_B, float inv_s, const float* inv_s_dev,
+                                              const float* bound_host, const float* sdf, const float* grad,
+                                              const uint8_t* mask, const float* d_alpha, const float* d_sdf,
+                                              const float* d_grad, const void* dX, int dx_dtype, float dx_scale,
+                                              const float* d_gerr_ray, void* grid_grad, float grid_grad_scale,
+                                              void* d_out, void* lin_in, void* dw0, void* d_arg, void* pts,
+                                              int row_dtype, float row_scale, int row_stride, float* d_inv_s, int n,
+                                              int s, void* bin_ws, size_t bin_ws_bytes, gs_stream_t stream) {
+  GS_REQUIRE(bin_ws, "neus_backward_points_binned: null workspace");
+  return backward_points_impl(rays_o, rays_d, z_vals, dists, grid, sdf_w, color_B, inv_s, inv_s_dev, bound_host, sdf, grad,
+                              mask, d_alpha, d_sdf, d_grad, dX, dx_dtype, dx_scale, d_gerr_ray, grid_grad, GS_F16,
+                              grid_grad_scale, d_out, lin_in, dw0, d_arg, pts, row_dtype, row_scale, row_stride, d_inv_s, n,
+                              s, bin_ws, bin_ws_bytes, stream);
 }

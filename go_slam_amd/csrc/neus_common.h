@@ -26,9 +26,9 @@ __device__ __forceinline__ uint32_t grid_index(const gs_grid_meta& m, int l, uin
 // of an entry go out as ONE packed atomic (global_atomic_pk_add_f16), pre-multiplied by the loss scale
 // (tcnn: 128) so that small contributions stay above fp16's subnormal range; half the atomic count.
 typedef _Float16 half2a __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void lvl_scatter(float* __restrict__ tab, _Float16* __restrict__ tab16, float scale16,
-                                            const uint32_t (&cidx)[8], float (&gacc)[8][2],
-                                            const uint32_t (&gi)[3], bool on, int lane) {
+// Runs of consecutive lanes in the same cell: inclusive segmented sum of the 8 x 2 corner contributions; returns
+// whether this lane is the LAST of its run (the one that holds the run's total and emits it).
+__device__ __forceinline__ bool lvl_prereduce(float (&gacc)[8][2], const uint32_t (&gi)[3], bool on, int lane) {
   const uint32_t p0 = __shfl_up(gi[0], 1, 64), p1 = __shfl_up(gi[1], 1, 64), p2 = __shfl_up(gi[2], 1, 64);
   const int on_prev = __shfl_up((int)on, 1, 64);
   const bool same = (lane > 0) && on && on_prev && p0 == gi[0] && p1 == gi[1] && p2 == gi[2];
@@ -49,6 +49,13 @@ __device__ __forceinline__ void lvl_scatter(float* __restrict__ tab, _Float16* _
     }
     tail = (lane == 63) || (((starts >> (lane + 1)) & 1ull) != 0ull);
   }
+  return tail;
+}
+
+__device__ __forceinline__ void lvl_scatter(float* __restrict__ tab, _Float16* __restrict__ tab16, float scale16,
+                                            const uint32_t (&cidx)[8], float (&gacc)[8][2],
+                                            const uint32_t (&gi)[3], bool on, int lane) {
+  const bool tail = lvl_prereduce(gacc, gi, on, lane);
   if (tab16) {
     // The atomics are executed memory-side: every (lane, address) pair that is not merged in the TA costs a
     // fabric transaction, and 128 of them per point are what bound this kernel.  The two x-neighbours of a

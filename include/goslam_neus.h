@@ -150,6 +150,21 @@ int gs_neus_backward_points(const float* rays_o, const float* rays_d, const floa
                             void* grid_grad, int grid_grad_dtype, float grid_grad_scale, void* d_out,
                             void* lin_in, void* dw0, void* d_arg, void* pts, int row_dtype, float row_scale,
                             int row_stride, float* d_inv_s, int n, int s, gs_stream_t stream);
+/* The same backward with the table gradient of the HASHED levels accumulated WITHOUT global atomics (bin-and-reduce:
+ * workgroups write (13-bit index, 2 x fp16) records to their own segments of per-(level, bin) queues in `bin_ws`, then
+ * one workgroup per bin sums its queue in fp32 LDS accumulators and writes its 8192 entries once; neus_bwd.hip).
+ * grid_grad is the loss-scaled f16 table gradient (zero it first; the dense levels and any overflow records still
+ * arrive as packed atomics).  `bin_ws`: gs_neus_bin_workspace_bytes(n * s) bytes of scratch (no initial state).     */
+size_t gs_neus_bin_workspace_bytes(int n_points);
+int gs_neus_backward_points_binned(const float* rays_o, const float* rays_d, const float* z_vals,
+                                   const float* dists, const void* grid, const float* sdf_w, const float* color_B,
+                                   float inv_s, const float* inv_s_dev, const float* bound_host, const float* sdf,
+                                   const float* grad, const uint8_t* mask, const float* d_alpha, const float* d_sdf,
+                                   const float* d_grad, const void* dX, int dx_dtype, float dx_scale,
+                                   const float* d_gerr_ray, void* grid_grad, float grid_grad_scale, void* d_out,
+                                   void* lin_in, void* dw0, void* d_arg, void* pts, int row_dtype, float row_scale,
+                                   int row_stride, float* d_inv_s, int n, int s, void* bin_ws, size_t bin_ws_bytes,
+                                   gs_stream_t stream);
 
 /* The mapper's loss without the eikonal term (src/mapping.py:96-132 + InstantNeuS.compute_sdf_error,
  * src/InstantNeuS.py:372-400) and its gradient, one launch.  Rays with rays_depth <= 0 are masked out.

@@ -532,3 +532,74 @@ def test_sharded_fused_step_two_ranks_on_one_gpu_equals_single_process(N, O, dev
         lr = 1e-2 if k.endswith("encoding.params") else 1e-3
         off = dlt > (2e-5 + 2e-3 * b.abs())
         assert float(off.float().mean()) < 3e-3 and float(dlt.max()) <= 4 * lr * 1.01, (k, float(off.float().mean()), float(dlt.max()))
+
+
+def _grid_grads(N, O, dev, P, rays, binned, grad_dtype):
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    model.grid_grad_dtype = grad_dtype
+    model.grid_grad_binned = binned
+    o, d, z, dist = rays
+    out = model(o.to(dev), d.to(dev), z.to(dev), dist.to(dev))
+    loss = (out["color"].sum() + 0.3 * out["depth"].sum() + out["sdf"][out["sdf"] != 100.0].sum()) / o.shape[0] \
+        + 0.1 * out["gradient_error"].sum()       # (a mean: the fp16 table gradient carries loss scale 128, max 65504)
+    loss.backward()
+    return model.sdf_network.encoding.encoding.params.grad.detach().float().cpu()
+
+
+def test_binned_table_gradient_equals_atomic_accumulation(N, O, dev):
+    """The hashed levels' table gradient by bin-and-reduce (no global atomics: per-bin record queues + fp32 LDS sums,
+    csrc/neus_bwd.hip) vs fp32 atomics on the same rays: equal to fp16 record rounding -- and CLOSER to the fp32 result
+    than tiny-cuda-nn's fp16 packed atomics are."""
+    P = O.make_params(81, grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    o, d, gt = _rays(3000, seed=82)
+    g = torch.Generator().manual_seed(83)
+    z, dist = O.render_sample(o, d, gt, P["bound"], 24, 48, torch.rand(24, generator=g))
+    rays = (o, d, z, dist)
+    ref = _grid_grads(N, O, dev, P, rays, False, torch.float32)
+    binned = _grid_grads(N, O, dev, P, rays, True, torch.float16)
+    atom16 = _grid_grads(N, O, dev, P, rays, False, torch.float16)
+    gm = O.grid_meta()
+    e_bin, e_atom = [], []
+    for l in range(16):
+        a, b = 2 * int(gm["offset"][l]), 2 * (int(gm["offset"][l]) + int(gm["size"][l]))
+        e_bin.append(_rel(binned[a:b], ref[a:b]))
+        e_atom.append(_rel(atom16[a:b], ref[a:b]))
+    hashed = [l for l in range(16) if int(gm["hashed"][l])]
+    assert len(hashed) == 11
+    assert max(e_bin) < 2e-3, e_bin
+    assert all(e_bin[l] <= e_atom[l] * 1.05 + 1e-6 for l in hashed), (e_bin, e_atom)
+    assert max(e_bin[l] for l in hashed) < 3e-4, e_bin          # one fp16 rounding per record, fp32 sums
+
+
+def test_binned_table_gradient_staging_overflow_falls_back_to_atomics(N, O, dev):
+    """Adversarial input for the record staging: 512 one-sample rays alternating between TWO positions, so that every
+    level receives all its records on 16 entries -- no run of equal cells for the wave to pre-reduce, and each
+    workgroup's staging bins (48 slots) see 128 records per entry.  The excess must continue as packed atomics: nothing
+    may be dropped.  (Kept small on purpose: an fp16 sum of n equal addends rounds at every step, with a bias that
+    grows with n -- tiny-cuda-nn's own accumulation, which the all-atomics mode shows on the same input.)"""
+    P = O.make_params(91, grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    n = 512
+    o = torch.zeros(n, 3)
+    o[0::2] = torch.tensor([0.31, -0.42, 0.17])
+    o[1::2] = torch.tensor([-1.13, 0.77, -0.58])
+    d = torch.nn.functional.normalize(torch.tensor([[0.2, 0.5, -0.3]]), dim=1).repeat(n, 1)
+    z = torch.full((n, 1), 0.05)
+    dist = torch.full((n, 1), 0.02)
+    rays = (o, d, z, dist)
+    ref = _grid_grads(N, O, dev, P, rays, False, torch.float32)
+    binned = _grid_grads(N, O, dev, P, rays, True, torch.float16)
+    atom16 = _grid_grads(N, O, dev, P, rays, False, torch.float16)
+    nz = ref.abs() > 1e-6 * ref.abs().max()
+    assert 16 * 2 * 8 // 2 <= int(nz.sum()) <= 16 * 2 * 16         # two points x 8 corners x 2 features x 16 levels
+    rel = ((binned - ref).abs() / ref.abs())[nz]
+    # 256 records per entry: 96 summed exactly through the queues, 160 by fp16 atomics.  A dropped overflow path would
+    # lose 60 % of every entry; fp16 accumulation alone (the all-atomics mode) explains a few per cent at most.
+    assert float(rel.max()) < 6e-2 and _rel(binned, ref) < 2e-2, (float(rel.max()), _rel(binned, ref))
+    assert _rel(binned, ref) <= 1.2 * _rel(atom16, ref) + 2e-3, (_rel(binned, ref), _rel(atom16, ref))
+    # an ordinary batch right after gives the ordinary result (no state left behind)
+    o2, d2, gt2 = _rays(500, seed=92)
+    z2, dist2 = O.render_sample(o2, d2, gt2, P["bound"], 24, 48, None)
+    a = _grid_grads(N, O, dev, P, (o2, d2, z2, dist2), True, torch.float16)
+    b = _grid_grads(N, O, dev, P, (o2, d2, z2, dist2), False, torch.float32)
+    assert _rel(a, b) < 2e-3

@@ -1,5 +1,6 @@
-"""Micro-benchmark: the package's implicit-GEMM 3x3 convolution (gs_conv3x3 plain tiling, gs_conv3x3_stacked row-stacked
-tiling; both chunk sizes) vs MIOpen on the update operator's layer shapes.  Prints one JSON object per map shape.
+"""Micro-benchmark: the package's implicit-GEMM 3x3 convolution (gs_conv3x3_pp) vs MIOpen on the update operator's layer
+shapes.  Prints one JSON object per map shape.  (The round-1 / round-2 A/B against the retired kernels:
+profiles/r01_conv3x3_bench.json, profiles/r02_conv3x3_bench.json.)
 
     python tools/conv3x3_bench.py                 # bench workload: 75 edges, 60x80
     python tools/conv3x3_bench.py all             # + Replica (40x80) and ScanNet (30x40, 13-keyframe update_lowmem chunk)
@@ -33,8 +34,7 @@ def time_op(fn, iters=10, warm=3):
 
 def run(tag, E, h, w):
     dev = "cuda:0"
-    out = {"shape": tag, "edges": E, "map": [h, w], "tile_efficiency_plain": round(DN.conv3x3_tile_efficiency(h, w), 4),
-           "stacked_tile_width": DN.conv3x3_stacked_tile_width(w)}
+    out = {"shape": tag, "edges": E, "map": [h, w], "tile_width": DN.conv3x3_pp_tile_width(w)}
     for name, c, o in LAYERS:
         x = torch.randn(E, c, h, w, device=dev).half().contiguous(memory_format=torch.channels_last)
         wt = (torch.randn(o, c, 3, 3, device=dev) / (3 * c ** 0.5)).half().contiguous(memory_format=torch.channels_last)
@@ -42,17 +42,10 @@ def run(tag, E, h, w):
         ms_m = time_op(lambda: F.conv2d(x, wt, None, padding=1))
         row = {"miopen_ms": round(ms_m, 4), "miopen_tflops": round(flops / ms_m / 1e9, 1)}
         ref = F.conv2d(x, wt, None, padding=1).float()
-        for stacked in (False, True):
-            for kc in (32, 64):
-                key = f"{'stacked' if stacked else 'plain'}_kc{kc}"
-                ms_h = time_op(lambda: DN.conv3x3_hip(x, wt, kc, stacked=stacked, pp=False))
-                row[key + "_ms"] = round(ms_h, 4)
-                row[key + "_tflops"] = round(flops / ms_h / 1e9, 1)
-                row[key + "_max_abs_diff"] = float((DN.conv3x3_hip(x, wt, kc, stacked=stacked, pp=False).float() - ref).abs().max())
-        ms_p = time_op(lambda: DN.conv3x3_hip(x, wt, pp=True))
+        ms_p = time_op(lambda: DN.conv3x3_hip(x, wt))
         row["pp_ms"] = round(ms_p, 4)
         row["pp_tflops"] = round(flops / ms_p / 1e9, 1)
-        row["pp_max_abs_diff"] = float((DN.conv3x3_hip(x, wt, pp=True).float() - ref).abs().max())
+        row["pp_max_abs_diff"] = float((DN.conv3x3_hip(x, wt).float() - ref).abs().max())
         out[name] = row
     print(json.dumps(out))
 

@@ -1,12 +1,19 @@
 """Where does a conv3x3_pp workgroup spend its time?  s_memtime stamps (start / prologue done / main loop done / end) of
-every workgroup + A/B of the variant bits, on the update operator's layer shapes.  Prints JSON lines."""
-import json, os, sys, torch
+every workgroup + A/B of the variant bits, on the update operator's layer shapes.  Prints JSON lines.
+Needs the probe build of the library: `make -C go_slam_amd/csrc clean all PROBES=1` (the shipped library has no probe
+instantiation and no probe symbol)."""
+import ctypes, json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from go_slam_amd import _lib, droid_net as DN
 
 LAYERS = {"gru_zr": (320, 256), "heads": (128, 384), "corr_enc2": (128, 128)}
 dev = torch.device("cuda:0")
 L = _lib.lib()
+if not hasattr(L, "gs_conv3x3_pp_probe"):
+    raise SystemExit("libgoslam_hip.so was built without PROBES=1")
+_P = ctypes.c_void_p
+L.gs_conv3x3_pp_probe.restype = ctypes.c_int
+L.gs_conv3x3_pp_probe.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P] + [ctypes.c_int] * 6 + [_P, _P]
 
 
 def run(c, o, variant, dbg, x, wp, y, n, h, w):

@@ -1,5 +1,5 @@
 """The update operator's convolution launches in their production form (fused epilogues), one by one, at the bench shape:
-us per call with bare C-ABI launches.  Run once per kernel variant (GOSLAM_CONV3X3_V3=0/1 is read at the first launch).
+us per call with bare C-ABI launches.  
 One JSON line."""
 import json
 import os

@@ -1,5 +1,5 @@
 """A/B of the update operator's 3x3-convolution implementation on the bench workload: ms per keyframe
-(bench.UPDATES_PER_KF x FactorGraph.update, as bench.py times it) with CONV3X3_IMPL = miopen / round-1 own kernel (kc 32) / ping-pong kernel.  Prints one JSON line."""
+(bench.UPDATES_PER_KF x FactorGraph.update, as bench.py times it) with CONV3X3_IMPL = "miopen" (library convolutions, the referee setting) / "own" (gs_conv3x3_pp).  Prints one JSON line."""
 import json
 import os
 import sys
@@ -17,10 +17,8 @@ def main():
     video, op, graph, _ = bench.build_state(dev, seed=43)
     poses0, disps0 = video.poses.clone(), video.disps.clone()
     out = {}
-    for impl in ("miopen", "hip32", "pp", "miopen", "hip32", "pp"):
-        DN.CONV3X3_IMPL = "miopen" if impl == "miopen" else "hip"
-        DN.CONV3X3_PP = impl == "pp"
-        DN.CONV3X3_KC = int(impl[3:]) if impl.startswith("hip") else 32
+    for impl in ("miopen", "own", "miopen", "own"):
+        DN.CONV3X3_IMPL = impl
         video.poses.copy_(poses0)
         video.disps.copy_(disps0)
         ms = bench.time_op(lambda: bench.keyframe_step(graph), iters=8, warm=3)
