@@ -60,6 +60,32 @@ class CorrBlock:
                                                  self.layout, self.map_size)
         return out.view(batch, num, -1, ht, wd)
 
+    def lazy(self, coords):
+        """A deferred lookup for the update operator's fast path: the operator asks it for the looked-up features
+        already passed through corr_encoder[0] (`encoded`: one fused launch, the 196-channel tensor never exists in HBM);
+        any other use materialises the ordinary lookup."""
+        return LazyLookup(self, coords)
+
+    def fused_encoder_supported(self):
+        p0 = self.corr_pyramid[0]
+        return p0.is_cuda and p0.dtype == torch.float16 and self.channels_last
+
+    def lookup_encoded(self, coords, wpad, bias):
+        """relu(conv1x1(lookup(coords)) + bias): [batch*num, 128, ht, wd] fp16 NHWC (gs_corr_lookup_enc)"""
+        from . import _lib
+        batch, num, ht, wd, _ = coords.shape
+        c = coords.reshape(batch * num, ht, wd, 2).float().contiguous()
+        n = batch * num
+        h2, w2 = self.map_size
+        y = torch.empty((n, 128, ht, wd), dtype=torch.float16, device=c.device, memory_format=torch.channels_last)
+        pyr = self.corr_pyramid
+        with torch.cuda.device(c.device):
+            rc = _lib.lib().gs_corr_lookup_enc(_lib.ptr(pyr[0]), _lib.ptr(pyr[1]), _lib.ptr(pyr[2]), _lib.ptr(pyr[3]),
+                                               _lib.ptr(c), _lib.ptr(wpad), _lib.ptr(bias), _lib.ptr(y), 128, n, ht, wd,
+                                               h2, w2, int(self.layout), _lib.stream_ptr(c.device))
+        _lib.check(rc, "corr_lookup_enc")
+        return y
+
     def cat(self, other):
         for i in range(self.num_levels):
             self.corr_pyramid[i] = torch.cat([self.corr_pyramid[i], other.corr_pyramid[i]], dim=0)
@@ -69,6 +95,26 @@ class CorrBlock:
         for i in range(self.num_levels):
             self.corr_pyramid[i] = self.corr_pyramid[i][index].contiguous()
         return self
+
+
+class LazyLookup:
+    """CorrBlock(coords), not evaluated yet.  `encoded(wpad, bias)` = the lookup fused with corr_encoder[0]; everything
+    else (`.view`, `.float()`, tensor attributes ...) goes to the materialised [batch, num, 196, ht, wd] tensor."""
+
+    def __init__(self, block, coords):
+        self.block, self.coords = block, coords
+        self._value = None
+
+    def materialize(self):
+        if self._value is None:
+            self._value = self.block(self.coords)
+        return self._value
+
+    def encoded(self, wpad, bias):
+        return self.block.lookup_encoded(self.coords, wpad, bias)
+
+    def __getattr__(self, name):            # only reached for attributes not defined above
+        return getattr(self.materialize(), name)
 
 
 class AltCorrBlock:

@@ -251,6 +251,90 @@ __global__ __launch_bounds__(256) void corr_pyramid_coop_kernel(
   }
 }
 
+// ---- lookup fused with corr_encoder[0] (src/droid_net.py:75-77: Conv2d(196, 128, 1) + ReLU on the looked-up features) --
+// The cooperative lookup already assembles the 196 channels of 8 pixels per wave in LDS; here the four waves of a
+// workgroup put their 4 x 8 pixels into ONE [32 pixels][208] tile (k padded to 13 MFMA steps, pad columns zero) and each
+// wave multiplies it by ITS 32 of the 128 output channels on the matrix cores (v_mfma_f32_32x32x16_f16, weights = A
+// operand, resident in 52 VGPRs for the whole workgroup: 8 passes = 256 pixels), adds the bias, applies ReLU and the
+// [32 pixels][128] fp16 result leaves through LDS as one contiguous 8 KB run.  The 196-channel features (141 MB per
+// update at the bench shape, written once and read once) never exist in HBM, and one launch is gone.
+// Arithmetic = lookup (bit-exact, as above) -> fp16 features -> fp32-accumulated dot products -> + bias -> ReLU -> fp16,
+// i.e. what gs_corr_lookup_pyramid + gs_conv1x1 compute, up to the summation order inside a dot product.
+constexpr int ENC_K = 208;            // 196 padded to 13 k-steps of 16
+constexpr int ENC_PASSES = 8;         // passes of 32 pixels per workgroup
+typedef _Float16 enc_h8 __attribute__((ext_vector_type(8)));
+typedef float enc_f16v __attribute__((ext_vector_type(16)));
+
+template <bool TILED>
+__global__ __launch_bounds__(256) void corr_lookup_enc_kernel(
+    const _Float16* __restrict__ v0, const _Float16* __restrict__ v1, const _Float16* __restrict__ v2,
+    const _Float16* __restrict__ v3, const float* __restrict__ coords, const _Float16* __restrict__ wpad,
+    const float* __restrict__ bias, _Float16* __restrict__ y, int ys, int hw1, int h2, int w2) {
+  __shared__ __attribute__((aligned(16))) _Float16 atile[32 * ENC_K];      // [pixel][k]
+  __shared__ __attribute__((aligned(16))) _Float16 otile[32 * 128];        // [pixel][out channel]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n = blockIdx.y;
+  const int p00 = blockIdx.x * 32 * ENC_PASSES;
+  const int pp = lane >> 3, j = lane & 7;
+  const int r = lane & 31, kgl = lane >> 5;
+  // this wave's weights: A[m = 32 wv + r][k = 16 s + 8 kgl + e]
+  enc_h8 wa[ENC_K / 16];
+#pragma unroll
+  for (int s = 0; s < ENC_K / 16; ++s)
+    wa[s] = *reinterpret_cast<const enc_h8*>(wpad + (size_t)(32 * wv + r) * ENC_K + 16 * s + 8 * kgl);
+  float bv[16];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[4 * g + e] = bias[32 * wv + 8 * g + 4 * kgl + e];
+  for (int i = threadIdx.x; i < 32 * (ENC_K - 196); i += 256)              // pad columns: zero, never written again
+    atile[(i / (ENC_K - 196)) * ENC_K + 196 + i % (ENC_K - 196)] = (_Float16)0.0f;
+  __syncthreads();
+#pragma unroll 1
+  for (int pass = 0; pass < ENC_PASSES; ++pass) {
+    const int pb = p00 + 32 * pass;
+    if (pb >= hw1) break;                                     // (workgroup-uniform)
+    {
+      const int p = pb + 8 * wv + pp;
+      const bool valid = p < hw1;
+      const size_t pix = (size_t)n * hw1 + (valid ? p : pb);
+      const float2 c = reinterpret_cast<const float2*>(coords)[pix];
+      _Float16* tp = atile + (8 * wv + pp) * ENC_K;
+      level_coop<0, TILED>(v0, pix, valid, h2, w2, c, j, tp);
+      level_coop<1, TILED>(v1, pix, valid, h2, w2, c, j, tp);
+      level_coop<2, TILED>(v2, pix, valid, h2, w2, c, j, tp);
+      level_coop<3, TILED>(v3, pix, valid, h2, w2, c, j, tp);
+    }
+    __syncthreads();
+    enc_f16v acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = bv[e];
+#pragma unroll
+    for (int s = 0; s < ENC_K / 16; ++s) {
+      const enc_h8 b = *reinterpret_cast<const enc_h8*>(atile + r * ENC_K + 16 * s + 8 * kgl);   // B[k][col = pixel r]
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[s], b, acc, 0, 0, 0);
+    }
+    // D[row = channel 8 g + 4 kgl + e][col = pixel r]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      h4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (_Float16)fmaxf(acc[4 * g + e], 0.0f);
+      *reinterpret_cast<h4*>(otile + r * 128 + 32 * wv + 8 * g + 4 * kgl) = o;
+    }
+    __syncthreads();
+    const int npx = min(32, hw1 - pb);
+    for (int i = threadIdx.x; i < npx * 16; i += 256) {       // 16-byte pieces: 16 per pixel
+      const int px = i >> 4, part = i & 15;
+      *reinterpret_cast<uint4*>(y + ((size_t)n * hw1 + pb + px) * ys + 8 * part) =
+          *reinterpret_cast<const uint4*>(otile + px * 128 + 8 * part);
+    }
+    // (the next pass writes atile only after this pass's reads -- ordered by the barrier above -- and otile only after
+    // its own first barrier, which every wave reaches after these stores' LDS reads)
+  }
+}
+
 // Sample one level for one pixel; writes 49 taps to out[(i*7+j)*plane] (plane == 0: `out` is a
 // 49-entry register array).
 template <typename T>
@@ -510,6 +594,30 @@ extern "C" int gs_corr_index_backward(const float* coords, const void* corr_grad
   }
   gs_set_error("corr_index_backward: unsupported dtype %d", dtype);
   return GS_ERR_UNSUPPORTED;
+}
+
+extern "C" int gs_corr_lookup_enc(const void* vol0, const void* vol1, const void* vol2, const void* vol3,
+                                  const float* coords, const void* wpad, const float* bias, void* y, int y_stride, int n,
+                                  int h1, int w1, int h2, int w2, int layout, gs_stream_t stream) {
+  GS_REQUIRE(layout == GS_CORR_ROWMAJOR || layout == GS_CORR_TILE8, "corr_lookup_enc: unknown layout %d", layout);
+  GS_REQUIRE(vol0 && vol1 && vol2 && vol3 && coords && wpad && bias && y, "corr_lookup_enc: null pointer");
+  GS_REQUIRE(n >= 0 && h1 > 0 && w1 > 0 && (h2 >> 3) > 0 && (w2 >> 3) > 0, "corr_lookup_enc: bad shape");
+  GS_REQUIRE(y_stride >= 128 && y_stride % 8 == 0, "corr_lookup_enc: y_stride must be >= 128 and a multiple of 8");
+  GS_REQUIRE(layout == GS_CORR_ROWMAJOR || (w2 % 16 == 0), "corr_lookup_enc: tile8 needs w2 %% 16 == 0");
+  if (n == 0) return GS_OK;
+  GS_REQUIRE(n <= 65535, "corr_lookup_enc: n=%d exceeds grid.y limit", n);
+  const int hw1 = h1 * w1;
+  dim3 grid(gs_cdiv(hw1, 32 * ENC_PASSES), n);
+  if (layout == GS_CORR_TILE8)
+    corr_lookup_enc_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(
+        (const _Float16*)vol0, (const _Float16*)vol1, (const _Float16*)vol2, (const _Float16*)vol3, coords,
+        (const _Float16*)wpad, bias, (_Float16*)y, y_stride, hw1, h2, w2);
+  else
+    corr_lookup_enc_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(
+        (const _Float16*)vol0, (const _Float16*)vol1, (const _Float16*)vol2, (const _Float16*)vol3, coords,
+        (const _Float16*)wpad, bias, (_Float16*)y, y_stride, hw1, h2, w2);
+  GS_CHECK_LAUNCH("corr_lookup_enc");
+  return GS_OK;
 }
 
 extern "C" int gs_corr_lookup_pyramid(const void* vol0, const void* vol1, const void* vol2, const void* vol3,

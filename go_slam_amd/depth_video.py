@@ -175,7 +175,7 @@ class DepthVideo:
         next holder reads poses / disparities that are still being written.  The reference gets this implicitly from
         the blocking host round trips inside its `ba`; here the section ends with one stream synchronisation.  The
         single-process form (benches, kernel tests) stays fully asynchronous."""
-        if self._shared:
+        if self._shared and self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
 
     @staticmethod

@@ -219,6 +219,9 @@ GRU_FUSED_EPILOGUE = True
 CONV7X7_OWN = True
 # ConvGRU global context: w(net) + sigmoid + pooling in one kernel (gs_gru_glo_fused); False: gs_conv1x1 + gs_gru_glo
 GRU_GLO_FUSED = True
+# correlation lookup fused with corr_encoder[0] (gs_corr_lookup_enc) when the caller hands a corr.LazyLookup; False:
+# gs_corr_lookup_pyramid + gs_conv1x1 (the tests' referee for the fusion)
+FUSE_LOOKUP_ENCODER = True
 _CONV3X3_PACKS = {}        # (data_ptr, version, shape, device, kc) -> (packed image, weight tensor kept alive)
 _CONV3X3_PACKS_MAX = 32
 
@@ -575,14 +578,23 @@ class UpdateModule(nn.Module):
         out_dim = (batch, num, -1, ht, wd)
         n = batch * num
         net4 = net.view(n, -1, ht, wd)
-        c4 = corr.view(n, -1, ht, wd).half().contiguous(memory_format=cl)
+        from .corr import LazyLookup
+        lazy = corr if isinstance(corr, LazyLookup) and FUSE_LOOKUP_ENCODER and corr.block.fused_encoder_supported() \
+            else None
+        if lazy is None:
+            if isinstance(corr, LazyLookup):
+                corr = corr.materialize()
+            c4 = corr.view(n, -1, ht, wd).half().contiguous(memory_format=cl)
         if flow is None:
             flow = torch.zeros(batch, num, 4, ht, wd, device=net.device)
         f4 = flow.view(n, -1, ht, wd).half().contiguous(memory_format=cl)
         # (running this part on a side stream next to the correlation lookup -- a light, memory-bound kernel -- was
         # measured: bit-identical, 2 % slower per keyframe; the kernels do not share the CUs to any advantage)
         hx, inp_pre, glo = self._corr_independent_part(net4, inp, f4, n, ht, wd)
-        c4 = conv1x1_bias_act(self._head_cache, self.corr_encoder[0], c4, "relu")
+        if lazy is not None:        # lookup + corr_encoder[0] in one launch: the 196-channel features never reach HBM
+            c4 = lazy.encoded(*self._corr_enc0_padded())
+        else:
+            c4 = conv1x1_bias_act(self._head_cache, self.corr_encoder[0], c4, "relu")
         conv_bias_act(hwc, self.corr_encoder[2], c4, "relu", out=hx, out_channel=128)
         net4 = self.gru.forward_hx(net4, hx, inp_pre, glo=glo)
         net = net4.view(*out_dim)
@@ -605,6 +617,18 @@ class UpdateModule(nn.Module):
         upmask = conv1x1_bias_act(hc, agg.upmask[0], x, "none").view(batch, -1, 8 * 8 * 9, ht, wd)
         return net, delta, weight, eta, upmask
 
+    def _corr_enc0_padded(self):
+        """(fp16 [128, 208] weight of corr_encoder[0] with zero-padded rows, fp32 bias) for gs_corr_lookup_enc; cached"""
+        conv = self.corr_encoder[0]
+        key = (conv.weight._version, conv.bias._version, conv.weight.device, conv.weight.data_ptr())
+        hit = self._head_cache.get("corr_enc0_pad")
+        if hit is None or hit[0] != key:
+            w = torch.zeros(128, 208, dtype=torch.float16, device=conv.weight.device)
+            w[:, :196] = conv.weight.detach().reshape(128, 196).half()
+            hit = (key, w.contiguous(), conv.bias.detach().float().contiguous())
+            self._head_cache["corr_enc0_pad"] = hit
+        return hit[1], hit[2]
+
     def _fast_ok(self, net, inp, corr):
         cl = torch.channels_last
         n4 = net.view(-1, *net.shape[2:])
@@ -613,10 +637,12 @@ class UpdateModule(nn.Module):
 
     def forward(self, net, inp, corr, flow=None, ii=None, jj=None, seg=None):
         """`seg` (optional, not in the reference): build_segments(ii) cached by the caller, which
-        saves the per-call torch.unique (a sort + host sync)."""
+        saves the per-call torch.unique (a sort + host sync).  `corr` may be a corr.LazyLookup."""
         batch, num, ch, ht, wd = net.shape
         if self._fast_ok(net, inp, corr):
             return self._forward_fast(net, inp, corr, flow, ii, jj, seg)
+        if hasattr(corr, "materialize"):
+            corr = corr.materialize()
         if flow is None:
             flow = torch.zeros(batch, num, 4, ht, wd, device=net.device)
         out_dim = (batch, num, -1, ht, wd)

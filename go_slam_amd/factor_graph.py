@@ -369,7 +369,8 @@ class FactorGraph:
             motion = torch.cat([coords1 - self.coords0, self.target - coords1], dim=-1)
             motion = motion.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
 
-        corr = self.corr(coords1)
+        # (a deferred lookup: the operator's fast path evaluates it fused with corr_encoder[0], anything else materialises it)
+        corr = self.corr.lazy(coords1) if hasattr(self.corr, "lazy") else self.corr(coords1)
         with torch.autocast("cuda", dtype=torch.float16):
             self.net, delta, weight, damping, upmask = self.update_op(
                 self.net, self.inp, corr, motion, self.ii, self.jj, seg=seg)

@@ -66,6 +66,13 @@ int gs_corr_lookup_pyramid(const void* vol0, const void* vol1, const void* vol2,
                            const float* coords, void* corr,
                            int n, int h1, int w1, int h2, int w2, int radius, int dtype,
                            int channels_last, int layout, gs_stream_t stream);
+/* The same lookup (fp16 volumes, radius 3) FUSED with corr_encoder[0] (src/droid_net.py:75-77: Conv2d(196, 128, 1) +
+ * ReLU): y[n,h1,w1, 0:128] (pixels y_stride elements apart, fp16) = relu(W @ lookup + bias) -- the 196-channel features
+ * never reach HBM.  wpad: fp16 [128][208] = the 1x1 weight [128][196] with rows zero-padded to 208; bias f32 [128].
+ * Equals gs_corr_lookup_pyramid (bit-exact features) followed by gs_conv1x1 up to the fp32 summation order.      */
+int gs_corr_lookup_enc(const void* vol0, const void* vol1, const void* vol2, const void* vol3, const float* coords,
+                       const void* wpad, const float* bias, void* y, int y_stride, int n, int h1, int w1, int h2,
+                       int w2, int layout, gs_stream_t stream);
 
 /* CorrBlock.__init__ + CorrBlock.corr (src/modules/corr.py:26-41,67-76): all-pairs volume of
  * fp16 feature maps fmap1[e], fmap2[e] ([n,128,h,w], both divided by 4) plus the 3 average-pooled
