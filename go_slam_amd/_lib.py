@@ -37,6 +37,7 @@ SIGNATURES = {
     "gs_iproj": (c_int, [_P] * 4 + [c_int] * 3 + [_P]),
     "gs_depth_filter": (c_int, [_P] * 6 + [c_int] * 4 + [_P]),
     "gs_cvx_upsample": (c_int, [_P] * 4 + [c_int] * 4 + [_P]),
+    "gs_upmask_upsample": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gs_bias_act": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "gs_motion_features": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "gs_ba_inputs": (c_int, [_P] * 6 + [c_int, c_int, c_int, _P]),
@@ -75,6 +76,8 @@ SIGNATURES = {
     "gs_mapping_loss": (c_int, [_P] * 8 + [c_float] * 4 + [c_int] + [_P] * 4 + [c_int, c_int, _P]),
     "gs_map_grad_sqnorm": (c_int, [_P, c_size_t, c_float, _P, c_size_t, _P, _P]),
     "gs_map_adamw": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, _P, c_size_t] + [c_float] * 6 + [c_int, _P, c_float, _P]),
+    "gs_map_step_prep": (c_int, [_P, c_int, _P, c_float, c_float, c_int] + [_P] * 8),
+    "gs_map_step_post": (c_int, [_P, c_int, c_float, _P, c_int, _P, _P, _P, c_float, _P, _P, c_int, c_float, c_int, _P, _P, _P]),
     "gs_map_adamw_seg": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, _P, _P, _P, _P, _P, c_size_t] + [c_float] * 6
                          + [c_int, _P, _P, c_float, _P]),
     "gs_mlp_backward_blocks": (c_int, [c_int]),

@@ -195,3 +195,156 @@ extern "C" int gs_map_adamw_seg(float* p, float* m, float* v, void* p16, const v
   A.step_dev = step_dev; A.sqnorm = sqnorm; A.max_norm = max_norm;
   return launch_adamw(A, step, stream);
 }
+
+// ---- the small arithmetic AROUND the mapper step's big kernels, two launches instead of ~45 ---------------------------------
+// A 4096-ray step is ~1.2 ms of GPU time, of which ~0.25 ms were ~50 one-block torch kernels (reductions over the ray
+// batch, scalar arithmetic on 1-element tensors, zero-fills, slices of the Gram matrix, copies into the flat gradient):
+//   map_step_prep_kernel   counts [valid rays, rays, max depth] (unless the caller provides all-rank counts), inv_s =
+//                          clamp(exp(variance * scale)), the per-ray eikonal upstream gradient w_eik / (rays * samples),
+//                          zeroed accumulators (d inv_s, squared gradient norm), step count + 1;
+//   map_step_post_kernel   Gram-matrix chunks -> d sdf_layer.weight / bias, d color_B; MLP-backward workgroup partials ->
+//                          d MLP; d variance; the step's loss (sum of the per-ray terms + eikonal mean) -- all written
+//                          into the flat dense-gradient buffer [mlp 10240 | sdf_w 1120 | sdf_b 32 | cB 99 | var 1 | loss].
+namespace {
+
+__global__ __launch_bounds__(1024) void map_step_prep_kernel(const float* __restrict__ rays_depth, int n,
+                                                             const float* __restrict__ variance, float scale_factor,
+                                                             float w_eik, int s, const float* __restrict__ counts_in,
+                                                             float* __restrict__ counts_out, float* __restrict__ inv_s_out,
+                                                             float* __restrict__ d_gerr_out, float* __restrict__ d_invs,
+                                                             float* __restrict__ sqnorm, int* __restrict__ step_dev) {
+  __shared__ float red_c[16], red_m[16], bc[3];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (counts_in) {
+    if (tid < 3) bc[tid] = counts_in[tid];
+  } else {
+    float c = 0.f, mx = -INFINITY;
+    for (int i = tid; i < n; i += 1024) {
+      const float d = rays_depth[i];
+      c += d > 0.f ? 1.0f : 0.0f;
+      mx = fmaxf(mx, d);
+    }
+    c = gs_wave_sum(c);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) { red_c[wv] = c; red_m[wv] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+      float cs = 0.f, ms = -INFINITY;
+      for (int k = 0; k < 16; ++k) { cs += red_c[k]; ms = fmaxf(ms, red_m[k]); }
+      bc[0] = cs; bc[1] = (float)n; bc[2] = n > 0 ? ms : 0.0f;
+    }
+  }
+  __syncthreads();
+  if (tid < 3) counts_out[tid] = bc[tid];
+  if (tid == 0) {
+    const float raw = expf(variance[0] * scale_factor);
+    inv_s_out[0] = fminf(fmaxf(raw, 1e-6f), 1e6f);
+    d_invs[0] = 0.0f;
+    sqnorm[0] = 0.0f;
+    step_dev[0] += 1;
+  }
+  const float dg = w_eik / (bc[1] * (float)s);
+  for (int i = tid; i < n; i += 1024) d_gerr_out[i] = dg;
+}
+
+struct PostArgs {
+  const float* gram; int nchunk;        // [nchunk][160][160] partial Gram matrices of the per-point rows
+  float inv_ls;                         // 1 / loss scale of the fp16 rows
+  const float* mlp_partial; int nb;     // [nb][10240] workgroup partials of the MLP weight gradient (loss-scaled)
+  const float* d_invs; const float* variance; const float* inv_s; float scale_factor;
+  const float* loss_rays; const float* gerr; int n; float w_eik; int s; const float* counts;
+  float* g32;                           // [10240 + 1120 + 32 + 99 + 1 + 1]
+};
+
+// workgroup = 32 outputs x 8 slices of the reduction axis (MLP workgroup partials, Gram chunks): the serial sums this
+// replaces took 98 us on 45 workgroups
+__global__ __launch_bounds__(256) void map_step_post_kernel(PostArgs A) {
+  constexpr int N_MLP = 10240, N_W = 32 * 35, N_B = 32, N_CB = 3 * 33;
+  constexpr int N_DENSE = N_W + N_B + N_CB;                 // outputs that come from the Gram matrix
+  constexpr int B_MLP = N_MLP / 32, B_DENSE = (N_DENSE + 31) / 32;
+  __shared__ float red[8][32];
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  if ((int)blockIdx.x == B_MLP + B_DENSE) {                 // last workgroup: the loss and d variance
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < A.n; i += 256) { a += A.loss_rays[i]; b += A.gerr[i]; }
+    a = gs_wave_sum(a);
+    b = gs_wave_sum(b);
+    const float v = a + A.w_eik * b / (A.counts[1] * (float)A.s);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      A.g32[N_MLP + N_DENSE + 1] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+      const float raw = expf(A.variance[0] * A.scale_factor);   // d variance through inv_s = clamp(exp(variance * scale))
+      A.g32[N_MLP + N_DENSE] = (raw >= 1e-6f && raw <= 1e6f) ? A.d_invs[0] * A.scale_factor * A.inv_s[0] : 0.0f;
+    }
+    return;
+  }
+  float t = 0.f;
+  int out = -1;
+  if ((int)blockIdx.x < B_MLP) {
+    out = blockIdx.x * 32 + o;
+    for (int k = sl; k < A.nb; k += 8) t += A.mlp_partial[(size_t)k * N_MLP + out];
+  } else {
+    const int e = ((int)blockIdx.x - B_MLP) * 32 + o;
+    if (e < N_DENSE) {
+      out = N_MLP + e;
+      int r0, c0, r1 = -1, c1 = 0;
+      if (e < N_W) {                                        // d sdf_layer.weight [32][35] = d_out^T lin_in; row 0 += colsum(dw0)
+        const int oo = e / 35, c = e - oo * 35;
+        r0 = oo; c0 = 32 + c;
+        if (oo == 0) { r1 = 155; c1 = 72 + c; }
+      } else if (e < N_W + N_B) {                           // d bias = colsum(d_out) (row 155 = the ones column)
+        r0 = 155; c0 = e - N_W;
+      } else {                                              // d color_B [3][33] = pts^T d_arg
+        const int q = e - N_W - N_B, d = q / 33, c = q - d * 33;
+        r0 = 152 + d; c0 = 112 + c;
+      }
+      for (int k = sl; k < A.nchunk; k += 8) {
+        const float* g = A.gram + (size_t)k * 160 * 160;
+        t += g[r0 * 160 + c0];
+        if (r1 >= 0) t += g[r1 * 160 + c1];
+      }
+    }
+  }
+  red[sl][o] = t;
+  __syncthreads();
+  if (sl == 0 && out >= 0) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += red[k][o];
+    A.g32[out] = v * A.inv_ls;
+  }
+}
+
+}  // namespace
+
+extern "C" int gs_map_step_prep(const float* rays_depth, int n, const float* variance, float scale_factor, float w_eikonal,
+                                int samples, const float* counts_in, float* counts_out, float* inv_s_out, float* d_gerr_out,
+                                float* d_invs, float* sqnorm, int* step_dev, gs_stream_t stream) {
+  GS_REQUIRE((rays_depth || counts_in) && variance && counts_out && inv_s_out && d_gerr_out && d_invs && sqnorm && step_dev,
+             "map_step_prep: null pointer");
+  GS_REQUIRE(n >= 0 && samples > 0, "map_step_prep: bad shape");
+  map_step_prep_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(rays_depth, n, variance, scale_factor, w_eikonal, samples,
+                                                           counts_in, counts_out, inv_s_out, d_gerr_out, d_invs, sqnorm,
+                                                           step_dev);
+  GS_CHECK_LAUNCH("map_step_prep");
+  return GS_OK;
+}
+
+extern "C" int gs_map_step_post(const float* gram_chunks, int nchunk, float inv_loss_scale, const float* mlp_partial,
+                                int nb, const float* d_invs, const float* variance, const float* inv_s, float scale_factor,
+                                const float* loss_rays, const float* gerr, int n, float w_eikonal, int samples,
+                                const float* counts, float* g32, gs_stream_t stream) {
+  GS_REQUIRE(gram_chunks && mlp_partial && d_invs && variance && inv_s && loss_rays && gerr && counts && g32,
+             "map_step_post: null pointer");
+  GS_REQUIRE(nchunk > 0 && nb > 0 && n >= 0 && samples > 0, "map_step_post: bad shape");
+  PostArgs A;
+  A.gram = gram_chunks; A.nchunk = nchunk; A.inv_ls = inv_loss_scale; A.mlp_partial = mlp_partial; A.nb = nb;
+  A.d_invs = d_invs; A.variance = variance; A.inv_s = inv_s; A.scale_factor = scale_factor; A.loss_rays = loss_rays;
+  A.gerr = gerr; A.n = n; A.w_eik = w_eikonal; A.s = samples; A.counts = counts; A.g32 = g32;
+  const int blocks = 10240 / 32 + (32 * 35 + 32 + 99 + 31) / 32 + 1;
+  map_step_post_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(A);
+  GS_CHECK_LAUNCH("map_step_post");
+  return GS_OK;
+}

@@ -91,6 +91,98 @@ __global__ __launch_bounds__(256) void cvx_upsample_nhwc_kernel(const float* __r
   o[1] = make_float4(res[4], res[5], res[6], res[7]);
 }
 
+// ---- GraphAgg's upmask 1x1 convolution (128 -> 576, src/droid_net.py:45,62) FUSED with the convex upsampling ------------
+// Unfused, the 576-channel mask is written (138 MB for 25 keyframes of 60x80) only to be read back by the kernel above.
+// Here a wave computes the logits of ITS 16 sub-pixels (two rows of the 8x8 block) x 9 taps = 144 mask channels for 32
+// coarse pixels at a time on the matrix cores -- its 144 x 128 weight slice stays in registers (160 VGPRs, one wave per
+// SIMD) -- and the MFMA accumulator layout hands every lane all 9 taps of 8 sub-pixels of one pixel: the softmax and the
+// 3x3 weighted sum are lane-local, and the 8 results leave as two 16-byte stores.  Same arithmetic and rounding points
+// as gs_conv1x1 -> fp16 mask -> gs_cvx_upsample (logits rounded to fp16, softmax weights rounded to fp16).
+typedef _Float16 up_h8 __attribute__((ext_vector_type(8)));
+typedef float up_f16v __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256, 1) void upmask_upsample_kernel(const _Float16* __restrict__ x, int xs,
+                                                                 const _Float16* __restrict__ wgt,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ disps,
+                                                                 const int64_t* __restrict__ ix, float* __restrict__ out,
+                                                                 int m, int h, int w) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = lane & 31, kgl = lane >> 5;
+  const int hw = h * w;
+  const long total = (long)m * hw;
+  // weights: rows row' = 16 k9 + i of this wave  <->  mask channel k9 * 64 + 16 wv + i; rows >= 144 are zero
+  up_h8 wa[5][8];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int rowp = 32 * t + r;
+    const int ch = (rowp >> 4) * 64 + 16 * wv + (rowp & 15);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const up_h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      wa[t][s] = rowp < 144 ? *reinterpret_cast<const up_h8*>(wgt + (size_t)ch * 128 + 16 * s + 8 * kgl) : z;
+    }
+  }
+  // this lane's sub-pixels: i = 8 ih + 4 kgl + e (ih = 0, 1; e = 0..3); bias of tap k: channel 64 k + 16 wv + i
+  float bv[9][2][4];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[k][ih][e] = bias[64 * k + 16 * wv + 8 * ih + 4 * kgl + e];
+  for (long g0 = (long)blockIdx.x * 32; g0 < total; g0 += (long)gridDim.x * 32) {
+    const long pix = g0 + r;
+    const bool valid = pix < total;
+    const long pq = valid ? pix : g0;
+    up_f16v acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+    const _Float16* xr = x + (size_t)pq * xs + 8 * kgl;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const up_h8 b = *reinterpret_cast<const up_h8*>(xr + 16 * s);
+#pragma unroll
+      for (int t = 0; t < 5; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[t][s], b, acc[t], 0, 0, 0);
+    }
+    const int n = (int)(pq / hw), p = (int)(pq - (long)n * hw);
+    const int y = p / w, xq = p - y * w;
+    const long frame = ix ? ix[n] : n;
+    const float* d = disps + frame * hw;
+    float nb[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int yy = y + k / 3 - 1, xx = xq + k % 3 - 1;          // F.unfold(3x3, padding 1): zero padded
+      nb[k] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? d[yy * w + xx] : 0.0f;
+    }
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+      float res[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float lg[9], mx = -INFINITY, den = 0.f, a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          // row' = 16 k + i -> tile k / 2, accumulator slot 4 (2 (k & 1) + ih) + e
+          lg[k] = (float)(_Float16)(acc[k >> 1][4 * (2 * (k & 1) + ih) + e] + bv[k][ih][e]);     // the fp16 mask value
+          mx = fmaxf(mx, lg[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { lg[k] = __expf(lg[k] - mx); den += lg[k]; }
+        const float inv_den = __builtin_amdgcn_rcpf(den);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a += (float)(_Float16)(lg[k] * inv_den) * nb[k];             // softmax output is fp16
+        res[e] = a;
+      }
+      if (valid)
+        *reinterpret_cast<float4*>(out + frame * (long)hw * 64 + (long)(8 * y + 2 * wv + ih) * (8 * w) + 8 * xq + 4 * kgl) =
+            make_float4(res[0], res[1], res[2], res[3]);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int gs_cvx_upsample(const float* disps, const void* mask, const int64_t* ix, float* out, int m, int h,
@@ -110,5 +202,20 @@ extern "C" int gs_cvx_upsample(const float* disps, const void* mask, const int64
   cvx_upsample_kernel<<<(unsigned)((total + 3) / 4), 256, 0, (hipStream_t)stream>>>(
       disps, (const _Float16*)mask, ix, out, m, h, w, cs, ps);
   GS_CHECK_LAUNCH("cvx_upsample");
+  return GS_OK;
+}
+
+extern "C" int gs_upmask_upsample(const void* x, int x_stride, const void* weight, const float* bias, const float* disps,
+                                  const int64_t* ix, float* out, int m, int h, int w, gs_stream_t stream) {
+  GS_REQUIRE(x && weight && bias && disps && out, "upmask_upsample: null pointer");
+  GS_REQUIRE(m >= 0 && h > 0 && w > 0 && x_stride >= 128 && x_stride % 8 == 0, "upmask_upsample: bad shape");
+  GS_REQUIRE((8 * w) % 4 == 0, "upmask_upsample: bad width");
+  if (m == 0) return GS_OK;
+  const long total = (long)m * h * w;
+  long blocks = (total + 31) / 32;
+  if (blocks > 512) blocks = 512;                     // weights are loaded once per workgroup: few, long-lived workgroups
+  upmask_upsample_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(
+      (const _Float16*)x, x_stride, (const _Float16*)weight, bias, disps, ix, out, m, h, w);
+  GS_CHECK_LAUNCH("upmask_upsample");
   return GS_OK;
 }

@@ -190,6 +190,12 @@ class DepthVideo:
     def upsample(self, ix, mask):
         """disps_up[ix] = cvx_upsample(disps[ix], mask) (src/depth_video.py:194-196).  fp16 masks go
         through the fused HIP kernel (no gather / unfold / softmax / index_put passes)."""
+        if hasattr(mask, "upsample_into"):       # droid_net.LazyUpmask: the 1x1 mask convolution fused with the upsampling
+            ix = ix.to(device=self.device, dtype=torch.long).contiguous()
+            if self.disps.is_cuda and self.disps.is_contiguous() and self.disps_up.is_contiguous():
+                mask.upsample_into(self.disps, ix, self.disps_up)
+                return
+            mask = mask.materialize()
         m = mask.reshape(-1, 576, self.map_ht, self.map_wd)
         if m.dtype == torch.float16 and m.is_cuda:
             cl = m.is_contiguous(memory_format=torch.channels_last)

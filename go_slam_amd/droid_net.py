@@ -219,6 +219,9 @@ GRU_FUSED_EPILOGUE = True
 CONV7X7_OWN = True
 # ConvGRU global context: w(net) + sigmoid + pooling in one kernel (gs_gru_glo_fused); False: gs_conv1x1 + gs_gru_glo
 GRU_GLO_FUSED = True
+# GraphAgg's upmask convolution (128 -> 576) fused with DepthVideo.upsample's convex upsampling (gs_upmask_upsample): the
+# update operator returns a LazyUpmask; False: gs_conv1x1 writes the mask, gs_cvx_upsample reads it (the tests' referee)
+FUSE_UPMASK_UPSAMPLE = True
 # correlation lookup fused with corr_encoder[0] (gs_corr_lookup_enc) when the caller hands a corr.LazyLookup; False:
 # gs_corr_lookup_pyramid + gs_conv1x1 (the tests' referee for the fusion)
 FUSE_LOOKUP_ENCODER = True
@@ -318,6 +321,47 @@ def conv_bias_act(cache, conv, x, act, out=None, out_channel=0):
 def copy_channels(x, out, out_channel):
     """out[:, out_channel:out_channel+C] = x for NHWC fp16 tensors (strided 16-byte copies)."""
     bias_act(x, None, "none", out, out_channel)
+
+
+class LazyUpmask:
+    """GraphAgg's upsampling mask [batch, M, 576, ht, wd], not evaluated yet: DepthVideo.upsample asks for
+    `upsample_into(disps, ix, disps_up)` (1x1 convolution + softmax + 3x3 weighted sum in one launch, the 138 MB mask
+    never exists); indexing ([0]) keeps it lazy; any other use materialises the ordinary fp16 mask."""
+
+    def __init__(self, module, x, shape):
+        self.module, self.x, self.shape_ = module, x, shape
+        self._value = None
+
+    def __getitem__(self, index):
+        if index == 0 and self.shape_[0] == 1:
+            return self
+        return self.materialize()[index]
+
+    def materialize(self):
+        if self._value is None:
+            m = self.module
+            self._value = conv1x1_bias_act(m._head_cache, m.agg.upmask[0], self.x, "none").view(*self.shape_)
+        return self._value
+
+    def upsample_into(self, disps, ix, disps_up):
+        from . import _lib
+        conv = self.module.agg.upmask[0]
+        cache = self.module._head_cache
+        key = (conv.weight._version, conv.bias._version, conv.weight.device, conv.weight.data_ptr())
+        hit = cache.get("upmask_plain")
+        if hit is None or hit[0] != key:
+            hit = (key, conv.weight.detach().reshape(576, 128).half().contiguous(), conv.bias.detach().float().contiguous())
+            cache["upmask_plain"] = hit
+        x = self.x
+        m, c, h, w = x.shape
+        assert c == 128 and x.is_contiguous(memory_format=torch.channels_last) and ix.numel() == m
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().gs_upmask_upsample(_lib.ptr(x), 128, _lib.ptr(hit[1]), _lib.ptr(hit[2]), _lib.ptr(disps),
+                                               _lib.ptr(ix), _lib.ptr(disps_up), m, h, w, _lib.stream_ptr(x.device))
+        _lib.check(rc, "upmask_upsample")
+
+    def __getattr__(self, name):            # only reached for attributes not defined above
+        return getattr(self.materialize(), name)
 
 
 class ConvGRU(nn.Module):
@@ -614,7 +658,10 @@ class UpdateModule(nn.Module):
         x = segment_mean_hip(heads, seg, in_channel=256, channels=128, in_bias=hb[2], in_relu=True)
         x = conv_bias_act(hwc, agg.conv2, x, "relu")
         eta = conv3x3_head(x, agg.eta[0], hc, "softplus", out_scale=0.01).view(batch, -1, ht, wd)
-        upmask = conv1x1_bias_act(hc, agg.upmask[0], x, "none").view(batch, -1, 8 * 8 * 9, ht, wd)
+        if FUSE_UPMASK_UPSAMPLE:    # deferred: DepthVideo.upsample evaluates it fused with the convex upsampling
+            upmask = LazyUpmask(self, x, (batch, -1, 8 * 8 * 9, ht, wd))
+        else:
+            upmask = conv1x1_bias_act(hc, agg.upmask[0], x, "none").view(batch, -1, 8 * 8 * 9, ht, wd)
         return net, delta, weight, eta, upmask
 
     def _corr_enc0_padded(self):

@@ -386,7 +386,7 @@ class _NeusRenderFn(torch.autograd.Function):
 
 
 def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d_normal, d_wsum, d_sdf, d_gerr,
-                       inv_s_dev=None, var_dev=None, grid_acc_out=None):
+                       inv_s_dev=None, var_dev=None, grid_acc_out=None, raw_dense=None):
     """The HIP backward of the fused renderer: upstream gradients of the ray outputs -> gradients of every trained
     parameter.  Returns a dict: grid_acc (the raw table gradient: fp32, or tiny-cuda-nn's loss-scaled fp16 form with
     `grid_scale`), sdf_w, sdf_b, cB, mlp, var (fp32).  Used by the autograd Function above and, without any autograd
@@ -396,7 +396,12 @@ def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d
     n, s = z_vals.shape
     np_ = n * s
     f32 = dict(dtype=torch.float32, device=dev)
-    z = lambda t, shape: (torch.zeros(shape, **f32) if t is None else t.float().contiguous())
+    # `raw_dense` (the fused mapper step): a dict with persistent buffers -- "zeros_n1", "zeros_n3" (upstream gradients
+    # that are identically zero there) and "d_invs" (zeroed by the caller) -- in which case the dense-parameter
+    # gradients are NOT assembled here: the chunked Gram matrix and the MLP partials are returned for gs_map_step_post
+    zb = raw_dense or {}
+    z = lambda t, shape: ((zb.get("zeros_n%d" % shape[1]) if zb.get("zeros_n%d" % shape[1]) is not None
+                           else torch.zeros(shape, **f32)) if t is None else t.float().contiguous())
     d_color, d_normal = z(d_color, (n, 3)), z(d_normal, (n, 3))
     d_depth, d_dvar, d_wsum, d_gerr = z(d_depth, (n, 1)), z(d_dvar, (n, 1)), z(d_wsum, (n, 1)), z(d_gerr, (n, 1))
     d_sdf = z(d_sdf, (n, s))
@@ -427,7 +432,7 @@ def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d
             rc = L.gs_mlp_backward(_lib.ptr(X), _lib.ptr(wpack), _lib.ptr(d_rgb), _lib.ptr(S["rgb"]), LS,
                                    _lib.ptr(dX), _lib.ptr(partial), np_, st)
         _lib.check(rc, "InstantNeuS.backward(mlp)")
-        g_mlp = partial.sum(0) / LS
+        g_mlp = None if raw_dense is not None else partial.sum(0) / LS
     else:
         W1, W2, W3 = W[:5120].view(64, 80), W[5120:9216].view(64, 64), W[9216:].view(16, 64)
         H1 = torch.relu(X @ W1.t())
@@ -455,9 +460,13 @@ def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d
     # d_out 0:32 | lin_in 32:72 | dw0 72:112 | d_arg 112:152 | pts,1 152:160 -- its Gram matrix (one split-K
     # GEMM) contains every dense-parameter gradient: d_out^T lin_in, the column sums (via the ones column)
     # and pts^T d_arg
-    rows = torch.empty(np_, 160, dtype=torch.float16, device=dev)
+    GC = 8192                                           # rows per Gram chunk (split-K of the tall-skinny product)
+    np_pad = -(-np_ // GC) * GC if raw_dense is not None else np_
+    rows = torch.empty(np_pad, 160, dtype=torch.float16, device=dev)
+    if np_pad > np_:
+        rows[np_:].zero_()                              # (padding rows add nothing to the Gram matrix)
     d_out, lin_in, dw0, d_arg, pts = (rows[:, a:b] for a, b in ((0, 32), (32, 72), (72, 112), (112, 152), (152, 160)))
-    d_invs = torch.zeros(1, **f32)
+    d_invs = zb["d_invs"] if raw_dense is not None else torch.zeros(1, **f32)
     bh, _ = model._bounds_host()
     binned = half_grads and bool(getattr(model, "grid_grad_binned", True))
     with torch.cuda.device(dev):
@@ -481,6 +490,10 @@ def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d
                                            d_out.data_ptr(), lin_in.data_ptr(), dw0.data_ptr(),
                                            d_arg.data_ptr(), pts.data_ptr(), 0, LS, 160, _lib.ptr(d_invs), n, s, st)
     _lib.check(rc, "InstantNeuS.backward(points)")
+    if raw_dense is not None:       # one batched GEMM; everything after it happens in gs_map_step_post
+        rc_ = rows.view(np_pad // GC, GC, 160)
+        return {"grid_acc": grid_acc, "grid_scale": gscale, "gram": _bmm_f32(rc_.transpose(1, 2), rc_),
+                "mlp_partial": partial, "loss_scale": LS}
     G = _tn(rows, rows) / LS                            # [160,160] Gram matrix, fp32
     g_sdf_w = G[0:32, 32:67].clone()
     g_sdf_w[0] += G[155, 72:107]                        # column sums of dw0 (row 155 = the ones column)

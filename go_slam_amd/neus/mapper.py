@@ -170,13 +170,15 @@ class FlatAdamW:
         self.G16.zero_()
         return self.G16[:self.n16]
 
-    def step(self, inv_scale16):
-        """table gradient / inv_scale16 is in self.G16 (fp16), the dense gradients (+ the loss in slot nd) in self.g32."""
+    def step(self, inv_scale16, prepped=False):
+        """table gradient / inv_scale16 is in self.G16 (fp16), the dense gradients (+ the loss in slot nd) in self.g32.
+        `prepped`: gs_map_step_prep already advanced the device-side step count and zeroed the norm accumulator."""
         from .distributed import all_gather_into_, all_reduce_sum_, reduce_scatter_sum_
         K, h, nd = self.kernels, self.hyper, self.nd
         self.steps += 1
-        self.step_dev.add_(1)
-        self.sqnorm.zero_()
+        if not prepped:
+            self.step_dev.add_(1)
+            self.sqnorm.zero_()
         dense = (self.P[self.n16p:], self.M[self.slice:], self.V[self.slice:], self.P16[self.n16p:], self.g32[:nd])
         if self.world > 1:
             reduce_scatter_sum_(self.g16s, self.G16, self.group)
@@ -224,7 +226,7 @@ class MapTrainer:
                      and model.fused_mlp_backward)
         self.fused = bool(fused)
         self.graph = bool(self.fused if graph is None else (graph and self.fused))
-        self._graphs = {}
+        self._graphs, self._bufs = {}, {}
         if self.fused:
             self.flat = FlatAdamW(model, net_lr, grid_lr, rank=rank, world=world, group=group)
             self.optimizer, self.reducer = self.flat, None        # `.param_groups` / `.set_lr` facade
@@ -239,43 +241,65 @@ class MapTrainer:
         return self.model.state_dict()
 
     # ---- the fused step ------------------------------------------------------------------------------------------
+    def _step_buffers(self, n, dev):
+        b = self._bufs.get(n)
+        if b is None:
+            f32 = dict(dtype=torch.float32, device=dev)
+            b = dict(counts=torch.zeros(3, **f32), inv_s=torch.zeros(1, **f32), d_gerr=torch.zeros(max(n, 1), 1, **f32),
+                     d_invs=torch.zeros(1, **f32), zeros_n1=torch.zeros(n, 1, **f32), zeros_n3=torch.zeros(n, 3, **f32))
+            if len(self._bufs) >= 2 * MAX_GRAPHS:
+                self._bufs.pop(next(iter(self._bufs)))
+            self._bufs[n] = b
+        return b
+
     def _local_gradients(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand, counts):
         """THIS RANK's rays: sample + forward + loss kernel + HIP backward, no autograd graph, no collective, no host
-        sync.  `counts` = [valid rays, rays] over ALL ranks (device fp32[2]).  Leaves the loss-scaled fp16 table
-        gradient in flat.G16, the dense gradients in flat.g32[:nd] and this rank's share of the loss in flat.g32[nd]."""
+        sync.  `counts` = [valid rays, rays, max depth] over ALL ranks (device fp32[3]) or None (single rank: computed
+        here).  Leaves the loss-scaled fp16 table gradient in flat.G16, the dense gradients in flat.g32[:nd] and this
+        rank's share of the loss in flat.g32[nd]; also zeroes the optimiser's norm accumulator and advances its
+        device-side step count (gs_map_step_prep), so flat.step must be called with prepped=True."""
         from .instant_neus import _neus_backward_raw, _neus_forward_raw
         model, L, flat = self.model, _lib.lib(), self.flat
         dev = rays_o.device
         f32 = dict(dtype=torch.float32, device=dev)
         n = rays_o.shape[0]
+        w = self.w
+        s = self.renderer.N_samples + self.renderer.N_surface
+        B = self._step_buffers(n, dev)
+        sf = float(model.variance_network.scale_factor)
+        var_dev = model.variance_network.variance
+        st = _lib.stream_ptr(dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.gs_map_step_prep(_lib.ptr(rays_depth), n, _lib.ptr(var_dev), sf, float(w["w_eikonal"]), s,
+                                          _lib.ptr(counts), _lib.ptr(B["counts"]), _lib.ptr(B["inv_s"]),
+                                          _lib.ptr(B["d_gerr"]), _lib.ptr(B["d_invs"]), _lib.ptr(flat.sqnorm),
+                                          _lib.ptr(flat.step_dev), st), "map_step_prep")
+        counts, inv_s_dev = B["counts"], B["inv_s"]
         z_vals, dists = self.renderer.sample(rays_o, rays_d, model.bound, rays_depth, perturb_rand,
                                              gt_max_dev=counts[2:3])
-        s = z_vals.shape[1]
-        sf = model.variance_network.scale_factor
-        var_dev = model.variance_network.variance
-        inv_s_dev = torch.exp(var_dev.detach().float() * sf).clamp(1e-6, 1e6).reshape(1)
+        assert z_vals.shape[1] == s
         color, depth, dvar, normal, wsum, sdf, gerr, zmid, saved = _neus_forward_raw(
             model, rays_o, rays_d, z_vals, dists, 0.0, save=True, inv_s_dev=inv_s_dev)
         d_color = torch.empty(n, 3, **f32)
         d_depth = torch.empty(n, 1, **f32)
         d_sdf = torch.empty(n, s, **f32)
         loss_rays = torch.empty(n, **f32)
-        w = self.w
         with torch.cuda.device(dev):
             rc = L.gs_mapping_loss(_lib.ptr(color), _lib.ptr(depth), _lib.ptr(dvar), _lib.ptr(sdf), _lib.ptr(zmid),
                                    _lib.ptr(rays_color), _lib.ptr(rays_depth), _lib.ptr(counts[:1]),
                                    float(model.sdf_truncation), float(model.sdf_sparse_factor), float(w["w_color"]),
                                    float(w["w_sdf"]), int(bool(w["uncertainty"])), _lib.ptr(d_color), _lib.ptr(d_depth),
-                                   _lib.ptr(d_sdf), _lib.ptr(loss_rays), n, s, _lib.stream_ptr(dev))
+                                   _lib.ptr(d_sdf), _lib.ptr(loss_rays), n, s, st)
         _lib.check(rc, "mapping_loss")
-        # eikonal term: w_eik * mean over all points of all ranks -> the same constant for every ray
-        d_gerr = (w["w_eikonal"] / (counts[1] * float(s))).expand(n, 1).contiguous()
         g = _neus_backward_raw(model, saved, (rays_o, rays_d, z_vals, dists, sdf, zmid), 0.0, 0.0,
-                               d_color, d_depth, None, None, None, d_sdf, d_gerr, inv_s_dev=inv_s_dev, var_dev=var_dev,
-                               grid_acc_out=flat.grad_table())
-        for name in ("mlp", "sdf_w", "sdf_b", "cB", "var"):
-            flat.dense_grad(name).copy_(g[name].reshape(-1))
-        flat.g32[flat.nd] = loss_rays.sum() + w["w_eikonal"] * gerr.sum() / (counts[1] * float(s))
+                               d_color, d_depth, None, None, None, d_sdf, B["d_gerr"][:n], inv_s_dev=inv_s_dev,
+                               var_dev=var_dev, grid_acc_out=flat.grad_table(), raw_dense=B)
+        gram, part = g["gram"], g["mlp_partial"]
+        with torch.cuda.device(dev):
+            _lib.check(L.gs_map_step_post(_lib.ptr(gram), gram.shape[0], 1.0 / float(g["loss_scale"]), _lib.ptr(part),
+                                          part.shape[0], _lib.ptr(B["d_invs"]), _lib.ptr(var_dev), _lib.ptr(inv_s_dev), sf,
+                                          _lib.ptr(loss_rays), _lib.ptr(gerr), n, float(w["w_eikonal"]), s,
+                                          _lib.ptr(counts), _lib.ptr(flat.g32), st), "map_step_post")
         return 1.0 / float(g["grid_scale"])
 
     def _prepare(self, rays_o, rays_d, rays_color, rays_depth):
@@ -286,9 +310,12 @@ class MapTrainer:
         return c(rays_o), c(rays_d), c(rays_color), c(rays_depth).reshape(-1)
 
     def _counts(self, rays_depth):
-        """[valid rays, rays, max depth] over ALL ranks: the loss normalisers (means over VALID rays,
+        """None on a single rank (gs_map_step_prep computes them inside the step); otherwise
+        [valid rays, rays, max depth] over ALL ranks: the loss normalisers (means over VALID rays,
         src/mapping.py:96-121) and the batch-wide depth maximum the sampler clamps with (src/render.py:121,140) -- one
         small all-gather, reduced locally (sum, sum, max)."""
+        if self.world == 1:
+            return None
         dev = rays_depth.device
         n = rays_depth.shape[0]
         mx = rays_depth.max() if n else torch.zeros((), dtype=torch.float32, device=dev)
@@ -308,6 +335,7 @@ class MapTrainer:
         gradients are left in self.flat.g32.  (Tests / tools; `step_fused` is the production entry.)"""
         rays_o, rays_d, rays_color, rays_depth = self._prepare(rays_o, rays_d, rays_color, rays_depth)
         inv_scale = self._local_gradients(rays_o, rays_d, rays_color, rays_depth, perturb_rand, self._counts(rays_depth))
+        self.flat.step_dev.sub_(1)          # (no optimiser step follows: undo gs_map_step_prep's step count)
         return self.flat.g32[self.flat.nd].clone(), self.flat.G16[:self.flat.n16], inv_scale
 
     def _graph_for(self, args, counts, perturb_rand):
@@ -319,8 +347,9 @@ class MapTrainer:
             return ent
         if len(self._graphs) >= MAX_GRAPHS:
             return None
+        dev = args[0].device
         static = [torch.empty_like(a) for a in args]
-        s_counts = torch.empty_like(counts)
+        s_counts = torch.zeros(3, dtype=torch.float32, device=dev) if counts is None else torch.empty_like(counts)
         s_pr = None if perturb_rand is None else torch.empty_like(perturb_rand.detach().float().contiguous())
         ent = dict(static=static, counts=s_counts, pr=s_pr, graph=None, inv_scale=None, warm=0)
         self._graphs[key] = ent
@@ -333,33 +362,34 @@ class MapTrainer:
         counts = self._counts(args[3])
         if not self.graph or args[0].shape[0] == 0:
             inv_scale = self._local_gradients(*args, perturb_rand, counts)
-            flat.step(inv_scale)
+            flat.step(inv_scale, prepped=True)
             return self._global_loss()
         if perturb_rand is None and self.renderer.perturb > 0:      # drawn OUTSIDE the graph: a replay must see new values
             perturb_rand = torch.rand(self.renderer.N_samples, device=args[0].device)
         ent = self._graph_for(args, counts, perturb_rand)
         if ent is None:                     # more batch shapes than graphs worth keeping: run this one eagerly
             inv_scale = self._local_gradients(*args, perturb_rand, counts)
-            flat.step(inv_scale)
+            flat.step(inv_scale, prepped=True)
             return self._global_loss()
         for dst, src in zip(ent["static"], args):
             dst.copy_(src)
-        ent["counts"].copy_(counts)
+        if counts is not None:
+            ent["counts"].copy_(counts)
         if ent["pr"] is not None:
             ent["pr"].copy_(perturb_rand)
         whole = self.world == 1             # single GPU: the optimiser's two launches are part of the graph
 
         def body():
-            inv = self._local_gradients(*ent["static"], ent["pr"], ent["counts"])
+            inv = self._local_gradients(*ent["static"], ent["pr"], None if whole else ent["counts"])
             if whole:
-                flat.step(inv)
+                flat.step(inv, prepped=True)
             return inv
         if ent["graph"] is None:
             if ent["warm"] < 2:             # eager first (workspaces, fp16 caches, lazy library state), then capture
                 ent["warm"] += 1
                 inv = body()
                 if not whole:
-                    flat.step(inv)
+                    flat.step(inv, prepped=True)
                 return self._global_loss()
             steps_before = flat.steps
             graph = torch.cuda.CUDAGraph()
@@ -372,7 +402,7 @@ class MapTrainer:
             flat.steps += 1                 # (the device-side count was advanced inside the graph)
             flat._publish()
         else:
-            flat.step(ent["inv_scale"])
+            flat.step(ent["inv_scale"], prepped=True)
         return self._global_loss()
 
     def _global_loss(self):

@@ -271,6 +271,11 @@ int gs_damping_rows(const float* eta, const int* inv, const int64_t* index, floa
  * NULL (identity).                                                                            */
 int gs_cvx_upsample(const float* disps, const void* mask, const int64_t* ix, float* out,
                     int m, int h, int w, int mask_channels_last, gs_stream_t stream);
+/* GraphAgg's upmask convolution (Conv2d(128, 576, 1), src/droid_net.py:45,62) fused with the convex upsampling above:
+ * x fp16 [m*h*w, x_stride] (NHWC agg features, first 128 channels), weight fp16 [576][128], bias f32 [576];
+ * out[ix[n]] = cvx_upsample(disps[ix[n]], half(W x + b)).  The 576-channel mask is never materialised.              */
+int gs_upmask_upsample(const void* x, int x_stride, const void* weight, const float* bias, const float* disps,
+                       const int64_t* ix, float* out, int m, int h, int w, gs_stream_t stream);
 
 /* ------------------------------------------------------ dense bundle adjustment ---- */
 

@@ -205,6 +205,22 @@ int gs_map_adamw_seg(float* p, float* m, float* v, void* p16, const void* g16, s
                      float beta1, float beta2, float eps, float weight_decay, int step, const int* step_dev,
                      const float* sqnorm, float max_norm, gs_stream_t stream);
 
+/* The scalar / reduction arithmetic around the mapper step's kernels in two launches (map_opt.hip):
+ *   gs_map_step_prep: counts_out = counts_in if given, else [#rays with depth > 0, n, max depth] of rays_depth [n];
+ *     inv_s_out[0] = clamp(exp(variance[0] * scale_factor), 1e-6, 1e6); d_gerr_out[0:n] = w_eikonal / (counts[1] * samples);
+ *     d_invs[0] = sqnorm[0] = 0; step_dev[0] += 1.
+ *   gs_map_step_post: g32 [mlp 10240 | sdf_w 32x35 | sdf_b 32 | color_B 3x33 | variance 1 | loss 1] from the chunked Gram
+ *     matrix of the per-point rows (gram_chunks f32 [nchunk,160,160], summed over chunks, x inv_loss_scale), the MLP
+ *     backward's workgroup partials (f32 [nb,10240]), d inv_s, and loss = sum(loss_rays) + w_eikonal * sum(gerr) /
+ *     (counts[1] * samples).                                                                                        */
+int gs_map_step_prep(const float* rays_depth, int n, const float* variance, float scale_factor, float w_eikonal,
+                     int samples, const float* counts_in, float* counts_out, float* inv_s_out, float* d_gerr_out,
+                     float* d_invs, float* sqnorm, int* step_dev, gs_stream_t stream);
+int gs_map_step_post(const float* gram_chunks, int nchunk, float inv_loss_scale, const float* mlp_partial, int nb,
+                     const float* d_invs, const float* variance, const float* inv_s, float scale_factor,
+                     const float* loss_rays, const float* gerr, int n, float w_eikonal, int samples, const float* counts,
+                     float* g32, gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -752,3 +752,36 @@ def test_update_operator_with_fused_lookup_matches_unfused(built_lib):
         DN.FUSE_LOOKUP_ENCODER = keep
     for a, b, name in zip(outs[True], outs[False], ("net", "target", "weight", "poses", "disps")):
         torch.testing.assert_close(a, b, rtol=5e-3, atol=3e-3, msg=lambda m, nm=name: f"{nm}: {m}")
+
+
+@pytest.mark.parametrize("m,h,w", [(25, 60, 80), (7, 30, 40), (3, 13, 17)])
+def test_upmask_convolution_fused_with_convex_upsampling(built_lib, m, h, w):
+    """gs_upmask_upsample (GraphAgg's 128 -> 576 mask convolution on MFMA + softmax + 3x3 weighted sum in one launch,
+    the mask never materialised) vs gs_conv1x1 -> fp16 mask -> gs_cvx_upsample, and vs the reference formulation
+    cvx_upsample (src/droid_net.py:9-23) on the same fp16 mask: every keyframe row written, others untouched."""
+    import go_slam_amd.droid_net as DN
+    from go_slam_amd.depth_video import DepthVideo
+    dev = "cuda:0"
+    torch.manual_seed(9 + m)
+    op = DN.UpdateModule().to(dev).eval()
+    x = torch.relu(torch.randn(m, 128, h, w, device=dev)).half().contiguous(memory_format=torch.channels_last)
+    buf = m + 3
+    ix = torch.randperm(buf, device=dev)[:m].sort().values
+    res = {}
+    for fused in (True, False):
+        video = DepthVideo(h, w, buffer=buf, device=dev)
+        g = torch.Generator().manual_seed(3)
+        video.disps.copy_((torch.rand(buf, h, w, generator=g) + 0.2).to(dev))
+        video.disps_up.fill_(-7.0)
+        lazy = DN.LazyUpmask(op, x, (1, -1, 576, h, w))
+        video.upsample(ix, lazy[0] if fused else lazy.materialize()[0])
+        res[fused] = video.disps_up.clone()
+        if not fused:
+            ref = DN.cvx_upsample(video.disps[ix].unsqueeze(-1), lazy.materialize()[0]).squeeze(-1).float()
+    other = torch.ones(buf, dtype=torch.bool, device=dev)
+    other[ix] = False
+    assert bool((res[True][other] == -7.0).all())
+    torch.testing.assert_close(res[True][ix], res[False][ix], rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(res[True][ix], ref, rtol=2e-3, atol=2e-4)
+    # a logit that lands on the other side of an fp16 rounding boundary moves one softmax weight by one fp16 ulp
+    assert float((res[True][ix] - res[False][ix]).abs().max()) < 2e-3
