@@ -375,13 +375,13 @@ def cpu_baseline_neus(n_rays=4096):
 CONV_LAYERS = (("gru_zr", 320, 256), ("gru_q", 320, 128), ("heads", 128, 384), ("corr_enc2", 128, 128))
 
 
-def pmc_traffic(name):
+def pmc_traffic(name, key="traffic_bytes_per_launch"):
     """HBM bytes per launch from a COMMITTED rocprofv3 --pmc pass of the same launch shape (FETCH_SIZE / WRITE_SIZE in
     separate passes, corrected as MI355X_MICROARCH.md prescribes).  Not measured in this run: the source is named."""
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return {"traffic": None}
-    return {"traffic": json.load(open(path)).get("traffic_bytes_per_launch"),
+    return {"traffic": json.load(open(path)).get(key),
             "traffic_source": f"profiles/{name} (committed PMC passes, not re-measured by this run)"}
 
 
@@ -556,14 +556,15 @@ def main():
                 {"kernel": "corr_lookup_enc_kernel<tile8> (cooperative 4-level lookup + corr_encoder[0] 196->128 on MFMA, "
                            "bias + ReLU; the 196-channel features never reach HBM)", "bound": "hbm", "achieved": fa,
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fa / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": fb,
-                 "kernel_avg_us": br["corr_lookup_enc0_ms"] * 1e3, "traffic": None,
-                 "replaces_us": (br["corr_lookup_ms"] * 1e3, "+ conv1x1 196->128")})
+                 "kernel_avg_us": br["corr_lookup_enc0_ms"] * 1e3,
+                 "replaces_us": (br["corr_lookup_ms"] * 1e3, "+ conv1x1 196->128"), **pmc_traffic("r03_pmc_corr_lookup.json")})
         line["roofline_other"] += [
             dict({"kernel": "corr_pyramid_coop_kernel<tile8> (fp16 NHWC, wave-cooperative fused 4-level lookup; the "
                             "unfused ABI entry)",
                   "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
-                  "kernel_avg_us": br["corr_lookup_ms"] * 1e3}, **pmc_traffic("r01_pmc_corr_lookup.json")),
+                  "kernel_avg_us": br["corr_lookup_ms"] * 1e3},
+                 **pmc_traffic("r03_pmc_corr_lookup.json", "traffic_bytes_per_launch_unfused")),
             dict({"kernel": "corr_volume_kernel (MFMA all-pairs volume + 3 pooled levels, written once)", "bound": "hbm",
                   "achieved": bgb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bgb / HBM_PEAK_GBS,
                   "bytes_per_launch": br["corr_build_bytes"],

@@ -35,17 +35,20 @@ void gs_set_error(const char* fmt, ...);
 // two threads racing on the first launch are harmless.
 #include <atomic>
 struct GsLdsLimit {
-  std::atomic<unsigned long long> done{0ull};            // bit d: raised on device d
+  // dynamic-LDS limit raised so far for one kernel, per device (devices 0-63; a later call that needs more raises again)
+  std::atomic<unsigned int> raised[64];
+  GsLdsLimit() { for (auto& r : raised) r.store(0u, std::memory_order_relaxed); }
   int raise(const void* fn, size_t bytes, const char* what) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (done.load(std::memory_order_acquire) & bit) return GS_OK;
+    std::atomic<unsigned int>& slot = raised[dev & 63];
+    if (dev < 64 && slot.load(std::memory_order_acquire) >= bytes) return GS_OK;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
       gs_set_error("%s: cannot raise the dynamic LDS limit to %zu bytes", what, bytes);
       return GS_ERR_LAUNCH;
     }
-    done.fetch_or(bit, std::memory_order_release);
+    unsigned int cur = slot.load(std::memory_order_relaxed);
+    while (cur < bytes && !slot.compare_exchange_weak(cur, (unsigned int)bytes, std::memory_order_release)) {}
     return GS_OK;
   }
 };

@@ -177,7 +177,7 @@ extern "C" int gs_conv7x7_c4(const void* x, const void* wpack, const float* bias
   if (rt > h) rt = h;
   const size_t lds = (size_t)(rt + 6) * (w + 8) * 8 + 128 * 4 + (size_t)4 * 32 * kScratchRow * 2;
   GS_REQUIRE(lds <= 160 * 1024, "conv7x7_c4: strip does not fit LDS (lower rt)");
-  if (int rc = g_c7_lds.raise((const void*)conv7x7_c4_kernel, 160 * 1024, "conv7x7_c4")) return rc;
+  if (int rc = g_c7_lds.raise((const void*)conv7x7_c4_kernel, lds, "conv7x7_c4")) return rc;
   C7Args A;
   A.x = (const half4*)x; A.wpack = (const half8*)wpack; A.bias = bias; A.y = (_Float16*)y; A.ys = ys;
   A.n = n; A.h = h; A.w = w; A.rt = rt; A.strips = (h + rt - 1) / rt; A.relu = relu;
