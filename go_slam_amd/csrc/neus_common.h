@@ -15,7 +15,11 @@ __device__ __forceinline__ uint32_t grid_index(const gs_grid_meta& m, int l, uin
     const uint32_t res = m.resolution[l];
     idx = cx + cy * res + cz * res * res;
   }
-  return idx % size;
+  // tcnn: `index % hashmap_size`.  A hashed level holds 2^19 entries (a mask), and a dense level's index is below its
+  // size except at the far corner of the box -- the generic 32-bit modulo (~30 VALU instructions, 8 per level and
+  // point, a third of a level's arithmetic) only runs when it has to.  Same result in every case.
+  if ((size & (size - 1u)) == 0u) return idx & (size - 1u);
+  return idx < size ? idx : idx % size;
 }
 
 // Scatter one level's 8 corners x 2 features.  Lanes are consecutive samples of a ray, so
