@@ -393,7 +393,9 @@ class MapTrainer:
                 return self._global_loss()
             steps_before = flat.steps
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread-local capture: with world > 1 RCCL's watchdog thread polls events while this thread captures, which a
+            # global-mode capture would treat as an illegal call
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 ent["inv_scale"] = body()
             ent["graph"] = graph
             flat.steps = steps_before       # capture ran nothing: the replay below is the step
