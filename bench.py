@@ -404,7 +404,7 @@ def conv_roofline(device, E, ht, wd):
            "bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": tf / MFMA_F16_PEAK_TFLOPS, "algorithmic_flops_per_update": flops_sum,
            "kernel_us_per_update": ms_sum * 1e3, "layers": layers}
-    out.update(pmc_traffic("r02_pmc_conv3x3_pp.json"))
+    out.update(pmc_traffic("r03_pmc_conv3x3_pp.json"))
     return out
 
 

@@ -2,7 +2,7 @@
 # rocprofv3 --pmc passes of one command, ONE counter group per pass (no trace domains alongside: MI355X_MICROARCH.md),
 # then a per-kernel table of the counter medians.   usage: tools/pmc_pass.sh <out_dir> <kernel-substring> -- <command...>
 set -u
-out=$1; pat=$2; shift 3
+out=$(realpath -m "$1"); pat=$2; shift 3        # (absolute: the passes run from /tmp; give the command absolute paths too)
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum" "TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum"; do
