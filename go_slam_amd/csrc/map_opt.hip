@@ -133,7 +133,7 @@ extern "C" int gs_map_grad_sqnorm(const void* g16, size_t n16, float inv_scale16
   if (n16 + n32 == 0) return GS_OK;
   const size_t work = n16 / 8 + n32;
   unsigned blocks = (unsigned)((work + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 512) blocks = 512;       // every workgroup ends with an atomic on ONE address: 2048 of them cost ~25 us
   if (blocks == 0) blocks = 1;
   map_grad_sqnorm_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const _Float16*)g16, n16, inv_scale16, g32, n32,
                                                                    sqnorm_out);
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(1024) void map_step_prep_kernel(const float* __rest
 }
 
 struct PostArgs {
-  const float* gram; int nchunk;        // [nchunk][160][160] partial Gram matrices of the per-point rows
+  const float* gram; int nchunk;        // [nchunk][40][160] partial products rows[:, :40]^T rows of the per-point rows
   float inv_ls;                         // 1 / loss scale of the fp16 rows
   const float* mlp_partial; int nb;     // [nb][10240] workgroup partials of the MLP weight gradient (loss-scaled)
   const float* d_invs; const float* variance; const float* inv_s; float scale_factor;
@@ -289,19 +289,21 @@ __global__ __launch_bounds__(256) void map_step_post_kernel(PostArgs A) {
     const int e = ((int)blockIdx.x - B_MLP) * 32 + o;
     if (e < N_DENSE) {
       out = N_MLP + e;
+      // per-point row layout [d_out 0:32 | x y z 1 32:36 (.. 40) | lin_in 40:80 | dw0 80:120 | d_arg 120:160]; the chunks
+      // hold rows[:, :40]^T rows: G[r][c], r < 40
       int r0, c0, r1 = -1, c1 = 0;
       if (e < N_W) {                                        // d sdf_layer.weight [32][35] = d_out^T lin_in; row 0 += colsum(dw0)
         const int oo = e / 35, c = e - oo * 35;
-        r0 = oo; c0 = 32 + c;
-        if (oo == 0) { r1 = 155; c1 = 72 + c; }
-      } else if (e < N_W + N_B) {                           // d bias = colsum(d_out) (row 155 = the ones column)
-        r0 = 155; c0 = e - N_W;
+        r0 = oo; c0 = 40 + c;
+        if (oo == 0) { r1 = 35; c1 = 80 + c; }
+      } else if (e < N_W + N_B) {                           // d bias = colsum(d_out) (row 35 = the ones column)
+        r0 = 35; c0 = e - N_W;
       } else {                                              // d color_B [3][33] = pts^T d_arg
         const int q = e - N_W - N_B, d = q / 33, c = q - d * 33;
-        r0 = 152 + d; c0 = 112 + c;
+        r0 = 32 + d; c0 = 120 + c;
       }
       for (int k = sl; k < A.nchunk; k += 8) {
-        const float* g = A.gram + (size_t)k * 160 * 160;
+        const float* g = A.gram + (size_t)k * 40 * 160;
         t += g[r0 * 160 + c0];
         if (r1 >= 0) t += g[r1 * 160 + c1];
       }

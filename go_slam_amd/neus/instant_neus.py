@@ -460,12 +460,19 @@ def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d
     # d_out 0:32 | lin_in 32:72 | dw0 72:112 | d_arg 112:152 | pts,1 152:160 -- its Gram matrix (one split-K
     # GEMM) contains every dense-parameter gradient: d_out^T lin_in, the column sums (via the ones column)
     # and pts^T d_arg
-    GC = 8192                                           # rows per Gram chunk (split-K of the tall-skinny product)
-    np_pad = -(-np_ // GC) * GC if raw_dense is not None else np_
-    rows = torch.empty(np_pad, 160, dtype=torch.float16, device=dev)
-    if np_pad > np_:
-        rows[np_:].zero_()                              # (padding rows add nothing to the Gram matrix)
-    d_out, lin_in, dw0, d_arg, pts = (rows[:, a:b] for a, b in ((0, 32), (32, 72), (72, 112), (112, 152), (152, 160)))
+    if raw_dense is not None:
+        # fused step: [d_out 0:32 | pts, 1 32:40 | lin_in 40:80 | dw0 80:120 | d_arg 120:160] -- every dense-parameter gradient
+        # is in rows[:, :40]^T @ rows, a [40,160] product per chunk of GC rows (gs_map_step_post knows this order).
+        # Chunk size measured on MI355X: 2048 rows at 295 k points (41 us; 8192: 73), 8192 at 2.4 M (224 us)
+        GC = 2048 if np_ <= (1 << 19) else 8192
+        np_pad = -(-np_ // GC) * GC
+        rows = torch.empty(np_pad, 160, dtype=torch.float16, device=dev)
+        if np_pad > np_:
+            rows[np_:].zero_()                          # (padding rows add nothing to the products)
+        d_out, pts, lin_in, dw0, d_arg = (rows[:, a:b] for a, b in ((0, 32), (32, 40), (40, 80), (80, 120), (120, 160)))
+    else:
+        rows = torch.empty(np_, 160, dtype=torch.float16, device=dev)
+        d_out, lin_in, dw0, d_arg, pts = (rows[:, a:b] for a, b in ((0, 32), (32, 72), (72, 112), (112, 152), (152, 160)))
     d_invs = zb["d_invs"] if raw_dense is not None else torch.zeros(1, **f32)
     bh, _ = model._bounds_host()
     binned = half_grads and bool(getattr(model, "grid_grad_binned", True))
@@ -492,7 +499,7 @@ def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d
     _lib.check(rc, "InstantNeuS.backward(points)")
     if raw_dense is not None:       # one batched GEMM; everything after it happens in gs_map_step_post
         rc_ = rows.view(np_pad // GC, GC, 160)
-        return {"grid_acc": grid_acc, "grid_scale": gscale, "gram": _bmm_f32(rc_.transpose(1, 2), rc_),
+        return {"grid_acc": grid_acc, "grid_scale": gscale, "gram": _bmm_f32(rc_[:, :, :40].transpose(1, 2), rc_),
                 "mlp_partial": partial, "loss_scale": LS}
     G = _tn(rows, rows) / LS                            # [160,160] Gram matrix, fp32
     g_sdf_w = G[0:32, 32:67].clone()

@@ -210,7 +210,8 @@ int gs_map_adamw_seg(float* p, float* m, float* v, void* p16, const void* g16, s
  *     inv_s_out[0] = clamp(exp(variance[0] * scale_factor), 1e-6, 1e6); d_gerr_out[0:n] = w_eikonal / (counts[1] * samples);
  *     d_invs[0] = sqnorm[0] = 0; step_dev[0] += 1.
  *   gs_map_step_post: g32 [mlp 10240 | sdf_w 32x35 | sdf_b 32 | color_B 3x33 | variance 1 | loss 1] from the chunked Gram
- *     matrix of the per-point rows (gram_chunks f32 [nchunk,160,160], summed over chunks, x inv_loss_scale), the MLP
+ *     product of the per-point rows laid out [d_out 32 | x y z 1 .. 8 | lin_in 40 | dw0 40 | d_arg 40] (gram_chunks f32
+ *     [nchunk,40,160] = rows[:, :40]^T rows per chunk, summed over chunks, x inv_loss_scale), the MLP
  *     backward's workgroup partials (f32 [nb,10240]), d inv_s, and loss = sum(loss_rays) + w_eikonal * sum(gerr) /
  *     (counts[1] * samples).                                                                                        */
 int gs_map_step_prep(const float* rays_depth, int n, const float* variance, float scale_factor, float w_eikonal,
