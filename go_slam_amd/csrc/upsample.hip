@@ -93,46 +93,43 @@ __global__ __launch_bounds__(256) void cvx_upsample_nhwc_kernel(const float* __r
 
 // ---- GraphAgg's upmask 1x1 convolution (128 -> 576, src/droid_net.py:45,62) FUSED with the convex upsampling ------------
 // Unfused, the 576-channel mask is written (138 MB for 25 keyframes of 60x80) only to be read back by the kernel above.
-// Here a wave computes the logits of ITS 16 sub-pixels (two rows of the 8x8 block) x 9 taps = 144 mask channels for 32
-// coarse pixels at a time on the matrix cores -- its 144 x 128 weight slice stays in registers (160 VGPRs, one wave per
-// SIMD) -- and the MFMA accumulator layout hands every lane all 9 taps of 8 sub-pixels of one pixel: the softmax and the
-// 3x3 weighted sum are lane-local, and the 8 results leave as two 16-byte stores.  Same arithmetic and rounding points
-// as gs_conv1x1 -> fp16 mask -> gs_cvx_upsample (logits rounded to fp16, softmax weights rounded to fp16).
+// Here wave w of an 8-wave workgroup computes the logits of sub-pixel ROW w of the 8x8 block: 8 sub-pixels x 9 taps = 72
+// mask channels (rows 8 k + i of its weight slice = channel 64 k + 8 w + i; 3 MFMA row tiles, the last one a quarter
+// full) for 32 coarse pixels per step on the matrix cores, weights resident in 96 VGPRs.  One tap = exactly one
+// 8-row group of the 32x32 accumulator layout, so lane (pixel r, half h) ends up with all 9 taps of sub-pixels 4 h .. 4 h + 3:
+// softmax and the 3x3 weighted sum are lane-local and the result is ONE 16-byte store.  Two waves per SIMD: one wave's
+// softmax arithmetic (the bulk: 36 exponentials per lane and step) overlaps the other's MFMAs -- the first version
+// (4 waves x 144 channels, one wave per SIMD) was bound by exactly that arithmetic, 74 us.
+// Same arithmetic and rounding points as gs_conv1x1 -> fp16 mask -> gs_cvx_upsample (logits and softmax weights in fp16).
 typedef _Float16 up_h8 __attribute__((ext_vector_type(8)));
 typedef float up_f16v __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256, 1) void upmask_upsample_kernel(const _Float16* __restrict__ x, int xs,
+__global__ __launch_bounds__(512, 1) void upmask_upsample_kernel(const _Float16* __restrict__ x, int xs,
                                                                  const _Float16* __restrict__ wgt,
                                                                  const float* __restrict__ bias,
                                                                  const float* __restrict__ disps,
                                                                  const int64_t* __restrict__ ix, float* __restrict__ out,
                                                                  int m, int h, int w) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;       // wv = sub-pixel row sy
   const int r = lane & 31, kgl = lane >> 5;
   const int hw = h * w;
   const long total = (long)m * hw;
-  // weights: rows row' = 16 k9 + i of this wave  <->  mask channel k9 * 64 + 16 wv + i; rows >= 144 are zero
-  up_h8 wa[5][8];
+  up_h8 wa[3][8];
 #pragma unroll
-  for (int t = 0; t < 5; ++t) {
-    const int rowp = 32 * t + r;
-    const int ch = (rowp >> 4) * 64 + 16 * wv + (rowp & 15);
+  for (int t = 0; t < 3; ++t) {
+    const int rowp = 32 * t + r;                                  // 8 k + i
+    const int ch = (rowp >> 3) * 64 + 8 * wv + (rowp & 7);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const up_h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      wa[t][s] = rowp < 144 ? *reinterpret_cast<const up_h8*>(wgt + (size_t)ch * 128 + 16 * s + 8 * kgl) : z;
+      wa[t][s] = rowp < 72 ? *reinterpret_cast<const up_h8*>(wgt + (size_t)ch * 128 + 16 * s + 8 * kgl) : z;
     }
   }
-  // this lane's sub-pixels: i = 8 ih + 4 kgl + e (ih = 0, 1; e = 0..3); bias of tap k: channel 64 k + 16 wv + i
-  float bv[9][2][4];
+  float bv[9][4];                                                 // bias of tap k, sub-pixel column 4 kgl + e
 #pragma unroll
   for (int k = 0; k < 9; ++k)
 #pragma unroll
-    for (int ih = 0; ih < 2; ++ih)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bv[k][ih][e] = bias[64 * k + 16 * wv + 8 * ih + 4 * kgl + e];
-  // software pipeline: the B fragments (the 32 pixels' 128 input channels) of the NEXT step are requested before this
-  // step's MFMAs and softmax, so their round trip is hidden (a step used to expose it: 74 us for 60 MB of traffic)
+    for (int e = 0; e < 4; ++e) bv[k][e] = bias[64 * k + 8 * wv + 4 * kgl + e];
   const long gstride = (long)gridDim.x * 32;
   up_h8 bnext[8];
   {
@@ -156,15 +153,15 @@ __global__ __launch_bounds__(256, 1) void upmask_upsample_kernel(const _Float16*
 #pragma unroll
       for (int s = 0; s < 8; ++s) bnext[s] = *reinterpret_cast<const up_h8*>(xr1 + 16 * s);
     }
-    up_f16v acc[5];
+    up_f16v acc[3];
 #pragma unroll
-    for (int t = 0; t < 5; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
 #pragma unroll
-      for (int t = 0; t < 5; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[t][s], bcur[s], acc[t], 0, 0, 0);
+      for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[t][s], bcur[s], acc[t], 0, 0, 0);
     }
     const int n = (int)(pq / hw), p = (int)(pq - (long)n * hw);
     const int y = p / w, xq = p - y * w;
@@ -176,29 +173,26 @@ __global__ __launch_bounds__(256, 1) void upmask_upsample_kernel(const _Float16*
       const int yy = y + k / 3 - 1, xx = xq + k % 3 - 1;          // F.unfold(3x3, padding 1): zero padded
       nb[k] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? d[yy * w + xx] : 0.0f;
     }
+    float res[4];
 #pragma unroll
-    for (int ih = 0; ih < 2; ++ih) {
-      float res[4];
+    for (int e = 0; e < 4; ++e) {
+      float lg[9], mx = -INFINITY, den = 0.f, a = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float lg[9], mx = -INFINITY, den = 0.f, a = 0.f;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          // row' = 16 k + i -> tile k / 2, accumulator slot 4 (2 (k & 1) + ih) + e
-          lg[k] = (float)(_Float16)(acc[k >> 1][4 * (2 * (k & 1) + ih) + e] + bv[k][ih][e]);     // the fp16 mask value
-          mx = fmaxf(mx, lg[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { lg[k] = __expf(lg[k] - mx); den += lg[k]; }
-        const float inv_den = __builtin_amdgcn_rcpf(den);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) a += (float)(_Float16)(lg[k] * inv_den) * nb[k];             // softmax output is fp16
-        res[e] = a;
+      for (int k = 0; k < 9; ++k) {
+        // row' = 8 k + i, i = 4 kgl + e -> tile k / 4, accumulator slot 4 (k % 4) + e
+        lg[k] = (float)(_Float16)(acc[k >> 2][4 * (k & 3) + e] + bv[k][e]);                     // the fp16 mask value
+        mx = fmaxf(mx, lg[k]);
       }
-      if (valid)
-        *reinterpret_cast<float4*>(out + frame * (long)hw * 64 + (long)(8 * y + 2 * wv + ih) * (8 * w) + 8 * xq + 4 * kgl) =
-            make_float4(res[0], res[1], res[2], res[3]);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { lg[k] = __expf(lg[k] - mx); den += lg[k]; }
+      const float inv_den = __builtin_amdgcn_rcpf(den);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a += (float)(_Float16)(lg[k] * inv_den) * nb[k];             // softmax output is fp16
+      res[e] = a;
     }
+    if (valid)
+      *reinterpret_cast<float4*>(out + frame * (long)hw * 64 + (long)(8 * y + wv) * (8 * w) + 8 * xq + 4 * kgl) =
+          make_float4(res[0], res[1], res[2], res[3]);
   }
 }
 
@@ -233,7 +227,7 @@ extern "C" int gs_upmask_upsample(const void* x, int x_stride, const void* weigh
   const long total = (long)m * h * w;
   long blocks = (total + 31) / 32;
   if (blocks > 256) blocks = 256;                     // one long-lived workgroup per CU: its 147 KB of weights are loaded once
-  upmask_upsample_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(
+  upmask_upsample_kernel<<<(unsigned)blocks, 512, 0, (hipStream_t)stream>>>(
       (const _Float16*)x, x_stride, (const _Float16*)weight, bias, disps, ix, out, m, h, w);
   GS_CHECK_LAUNCH("upmask_upsample");
   return GS_OK;
