@@ -448,3 +448,39 @@ def test_corr_volume_pyramid_at_S480_matches_oracle(db, O, dev):
             pooled = F.avg_pool2d(low.reshape(-1, 1, hl, wl).float(), 2, 2).to(torch.float16)
             assert torch.equal(out[l].cpu().reshape(-1, 1, hl // 2, wl // 2), pooled), f"level {l}"
             torch.testing.assert_close(out[l].cpu().float(), ref[l].float().reshape(out[l].shape), rtol=0, atol=2e-3)
+
+
+def test_update_operator_fast_path_at_bench_shape_matches_fp32_cpu_evaluation(built_lib, dev):
+    """The production update operator (own fp16 convolutions with fused ConvGRU gates -- v_rcp / v_exp based sigmoid and
+    tanh --, hoisted context gates, fused heads) at 60x80 / E = 75 against the SAME module evaluated in fp32 on the CPU
+    (plain nn.Sequential formulation, no library or kernel in common): the referee the GPU-vs-GPU test above lacks.
+    Inputs are the fp16-rounded tensors in both runs; tolerance = fp16 rounding of 128 ... 320-term dot products."""
+    import bench
+    import copy
+    from go_slam_amd.droid_net import UpdateModule
+    torch.manual_seed(7)
+    cl = torch.channels_last
+    op = UpdateModule().to(dev).eval().to(memory_format=cl)
+    E, h, w = 75, 60, 80
+    mk = lambda c, f: f(torch.randn(E, c, h, w, device=dev)).half().contiguous(memory_format=cl).unsqueeze(0)
+    net, inp = mk(128, torch.tanh), mk(128, torch.relu)
+    corr = mk(196, lambda t: 0.5 * t)
+    motion = torch.randn(1, E, h, w, 4, device=dev).clamp(-4, 4).permute(0, 1, 4, 2, 3)
+    ii, jj = bench.bench_graph(25, 75, 43)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        out_g = [t.float().cpu() for t in op(net, inp, corr, motion, ii.to(dev), jj.to(dev))]
+    op_c = copy.deepcopy(op).float().cpu()
+    op_c.fuse_epilogues = False
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    with torch.no_grad():
+        out_c = op_c(net.float().cpu().contiguous(), inp.float().cpu().contiguous(), corr.float().cpu().contiguous(),
+                     motion.half().float().cpu().contiguous(), ii, jj)
+    rep = {}
+    for name, a, b in zip(["net", "delta", "weight", "eta", "upmask"], out_g, out_c):
+        b = b.float()
+        assert a.shape == b.shape, name
+        rep[name] = (float((a - b).abs().max()), float((a - b).norm() / b.norm()))
+    # fp16 convolutions against fp32: measured on MI355X (profiles/r03_pathM_parity.json "update_operator_vs_fp32")
+    assert rep["net"][0] < 1.5e-2 and rep["net"][1] < 2e-3, rep
+    assert rep["delta"][1] < 5e-3 and rep["weight"][1] < 5e-3 and rep["eta"][1] < 5e-3 and rep["upmask"][1] < 5e-3, rep
+    _record("update_operator_vs_fp32", {k: {"max_abs": v[0], "rel_l2": v[1]} for k, v in rep.items()})
