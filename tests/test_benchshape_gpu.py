@@ -481,6 +481,7 @@ def test_update_operator_fast_path_at_bench_shape_matches_fp32_cpu_evaluation(bu
         assert a.shape == b.shape, name
         rep[name] = (float((a - b).abs().max()), float((a - b).norm() / b.norm()))
     # fp16 convolutions against fp32: measured on MI355X (profiles/r03_pathM_parity.json "update_operator_vs_fp32")
-    assert rep["net"][0] < 1.5e-2 and rep["net"][1] < 2e-3, rep
-    assert rep["delta"][1] < 5e-3 and rep["weight"][1] < 5e-3 and rep["eta"][1] < 5e-3 and rep["upmask"][1] < 5e-3, rep
+    # measured: net max |error| 6.2e-4 (relative L2 3.2e-4), delta 4.4e-4, weight 2.1e-4, eta 1.5e-5, upmask 3.5e-4
+    assert rep["net"][0] < 3e-3 and rep["net"][1] < 1e-3, rep
+    assert rep["delta"][1] < 2e-3 and rep["weight"][1] < 2e-3 and rep["eta"][1] < 2e-3 and rep["upmask"][1] < 2e-3, rep
     _record("update_operator_vs_fp32", {k: {"max_abs": v[0], "rel_l2": v[1]} for k, v in rep.items()})
