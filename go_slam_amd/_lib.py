@@ -76,7 +76,7 @@ SIGNATURES = {
     "gs_mapping_loss": (c_int, [_P] * 8 + [c_float] * 4 + [c_int] + [_P] * 4 + [c_int, c_int, _P]),
     "gs_map_grad_sqnorm": (c_int, [_P, c_size_t, c_float, _P, c_size_t, _P, _P]),
     "gs_map_adamw": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, _P, c_size_t] + [c_float] * 6 + [c_int, _P, c_float, _P]),
-    "gs_map_step_prep": (c_int, [_P, c_int, _P, c_float, c_float, c_int] + [_P] * 8),
+    "gs_map_step_prep": (c_int, [_P, c_int, _P, c_float, c_float, c_int] + [_P] * 10),
     "gs_map_step_post": (c_int, [_P, c_int, c_float, _P, c_int, _P, _P, _P, c_float, _P, _P, c_int, c_float, c_int, _P, _P, _P]),
     "gs_map_adamw_seg": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, _P, _P, _P, _P, _P, c_size_t] + [c_float] * 6
                          + [c_int, _P, _P, c_float, _P]),
@@ -84,7 +84,7 @@ SIGNATURES = {
     "gs_mlp_backward": (c_int, [_P, _P, _P, _P, c_float, _P, _P, c_int, _P]),
     "gs_neus_backward_points": (c_int, [_P] * 7 + [c_float] + [_P] * 9 + [c_int, c_float, _P, _P, c_int, c_float] + [_P] * 5 + [c_int, c_float, c_int, _P, c_int, c_int, _P]),
     "gs_neus_backward_points_binned": (c_int, [_P] * 7 + [c_float] + [_P] * 9 + [c_int, c_float, _P, _P, c_float] + [_P] * 5
-                                       + [c_int, c_float, c_int, _P, c_int, c_int, _P, c_size_t, _P]),
+                                       + [c_int, c_float, c_int, _P, c_int, c_int, _P, c_size_t, _P, _P]),
     "gs_neus_bin_workspace_bytes": (c_size_t, [c_int]),
 }
 

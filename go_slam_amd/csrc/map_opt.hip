@@ -212,7 +212,8 @@ __global__ __launch_bounds__(1024) void map_step_prep_kernel(const float* __rest
                                                              float w_eik, int s, const float* __restrict__ counts_in,
                                                              float* __restrict__ counts_out, float* __restrict__ inv_s_out,
                                                              float* __restrict__ d_gerr_out, float* __restrict__ d_invs,
-                                                             float* __restrict__ sqnorm, int* __restrict__ step_dev) {
+                                                             float* __restrict__ sqnorm, int* __restrict__ step_dev,
+                                                             const float* __restrict__ sdf_w, float* __restrict__ sdf_wt) {
   __shared__ float red_c[16], red_m[16], bc[3];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (counts_in) {
@@ -246,6 +247,10 @@ __global__ __launch_bounds__(1024) void map_step_prep_kernel(const float* __rest
   }
   const float dg = w_eik / (bc[1] * (float)s);
   for (int i = tid; i < n; i += 1024) d_gerr_out[i] = dg;
+  if (sdf_w && sdf_wt) {                               // [16][2][32] <- sdf_w [32][35] columns 3..34
+    const int lf = tid >> 5, o = tid & 31;
+    sdf_wt[tid] = sdf_w[o * 35 + 3 + lf];
+  }
 }
 
 struct PostArgs {
@@ -323,13 +328,14 @@ __global__ __launch_bounds__(256) void map_step_post_kernel(PostArgs A) {
 
 extern "C" int gs_map_step_prep(const float* rays_depth, int n, const float* variance, float scale_factor, float w_eikonal,
                                 int samples, const float* counts_in, float* counts_out, float* inv_s_out, float* d_gerr_out,
-                                float* d_invs, float* sqnorm, int* step_dev, gs_stream_t stream) {
+                                float* d_invs, float* sqnorm, int* step_dev, const float* sdf_w, float* sdf_wt_out,
+                                gs_stream_t stream) {
   GS_REQUIRE((rays_depth || counts_in) && variance && counts_out && inv_s_out && d_gerr_out && d_invs && sqnorm && step_dev,
              "map_step_prep: null pointer");
   GS_REQUIRE(n >= 0 && samples > 0, "map_step_prep: bad shape");
   map_step_prep_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(rays_depth, n, variance, scale_factor, w_eikonal, samples,
                                                            counts_in, counts_out, inv_s_out, d_gerr_out, d_invs, sqnorm,
-                                                           step_dev);
+                                                           step_dev, sdf_w, sdf_wt_out);
   GS_CHECK_LAUNCH("map_step_prep");
   return GS_OK;
 }

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void neus_ray_bwd_kernel(
 // ---------------------------------------------------------------------------------------
 struct BwdArgs {
   const float* rays_o; const float* rays_d; const float* z_vals; const float* dists;
-  const _Float16* grid; const float* sdf_w; const float* color_B;
+  const _Float16* grid; const float* sdf_w; const float* sdf_wt; const float* color_B;
   float inv_s; const float* inv_s_dev; float bound[6];
   const float* sdf; const float* grad; const uint8_t* mask;
   const float* d_alpha; const float* d_sdf; const float* d_grad; const void* dX;
@@ -217,6 +217,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
     __syncthreads();
   }
   int hord = 0;                                   // ordinal of the current level among the hashed ones
+  // weights are read through the constant address space: uniform, unchanged during the launch -> scalar loads
+  typedef const __attribute__((address_space(4))) float* cfp;
+  cfp cB = (cfp)A.color_B;
   uint32_t* tile = row_tiles[threadIdx.x >> 6];
   _Float16* tile_h = reinterpret_cast<_Float16*>(tile + (threadIdx.x & 63) * ROW_TS);    // this lane's row
   const size_t wave_p0 = (size_t)blockIdx.x * 256 + (threadIdx.x >> 6) * 64;
@@ -342,10 +345,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
       e1 = fmaf(w, v[c][1], e1);
     }
     // value path: d enc_f = sum_o d_out[o] W[o][3+2l+f]
-    const float* wl = A.sdf_w + 3 + 2 * l;
+    cfp wl = (cfp)(A.sdf_w + 3 + 2 * l);
     float de0 = 0.f, de1 = 0.f;
+    if (A.sdf_wt) {
+      // transposed copy [level][feature][output]: the level's 64 weights are contiguous -- four 16-dword scalar loads
+      // instead of 32 strided pairs (the elimination probes put this projection at 0.4 of the kernel's 2.7 ms)
+      // (constant address space: the weights do not change during the launch, so the uniform reads become s_load --
+      // through a plain global pointer the compiler issues one VECTOR load per weight, 64 per level and wave)
+      cfp wt = (cfp)(A.sdf_wt + 64 * l);
 #pragma unroll
-    for (int o = 0; o < 32; ++o) { de0 = fmaf(dov[o], wl[o * 35], de0); de1 = fmaf(dov[o], wl[o * 35 + 1], de1); }
+      for (int o = 0; o < 32; ++o) { de0 = fmaf(dov[o], wt[o], de0); de1 = fmaf(dov[o], wt[32 + o], de1); }
+    } else {
+#pragma unroll
+      for (int o = 0; o < 32; ++o) { de0 = fmaf(dov[o], wl[o * 35], de0); de1 = fmaf(dov[o], wl[o * 35 + 1], de1); }
+    }
     // gradient path: grad_d = (W0[d] + 1/2 sum g_lf dydx_lf,d) * inside * 2/span
     const float g0 = (float)(_Float16)wl[0], g1 = (float)(_Float16)wl[1];
     float dy0[3], dy1[3];
@@ -460,7 +473,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
       for (int e = 0; e < 8; ++e) {
         const int c = c0 + e;
         const int cc = c < 33 ? c : 32;
-        const float arg = (pt[0] * A.color_B[cc] + pt[1] * A.color_B[33 + cc]) + pt[2] * A.color_B[66 + cc];
+        const float arg = (pt[0] * cB[cc] + pt[1] * cB[33 + cc]) + pt[2] * cB[66 + cc];
         da[e] = c < 33 ? dxe[e] * cosf(arg) * live * rs : 0.0f;
       }
 #pragma unroll
@@ -477,7 +490,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
     for (int c = 0; c < 40; c += 8) load_dx8(A, i, c, &dxe[c]);
 #pragma unroll
     for (int c = 0; c < 33; ++c) {
-      const float arg = (pt[0] * A.color_B[c] + pt[1] * A.color_B[33 + c]) + pt[2] * A.color_B[66 + c];
+      const float arg = (pt[0] * cB[c] + pt[1] * cB[33 + c]) + pt[2] * cB[66 + c];
       st_row(A.d_arg, false, (size_t)i * 33 + c, dxe[c] * cosf(arg) * live * rs);
     }
   }
@@ -599,7 +612,7 @@ static int backward_points_impl(const float* rays_o, const float* rays_d, const 
                                        void* grid_grad, int grid_grad_dtype, float grid_grad_scale, void* d_out,
                                        void* lin_in, void* dw0, void* d_arg, void* pts, int row_dtype,
                                        float row_scale, int row_stride, float* d_inv_s, int n, int s,
-                                       void* bin_ws, size_t bin_ws_bytes, gs_stream_t stream) {
+                                       void* bin_ws, size_t bin_ws_bytes, const float* sdf_wt, gs_stream_t stream) {
   GS_REQUIRE(row_stride == 0 || (row_dtype == GS_F16 && row_stride >= 40 && row_stride % 8 == 0),
              "neus_backward_points: row_stride needs f16 rows, >= 40, a multiple of 8");
   GS_REQUIRE(dx_dtype == GS_F32 || dx_dtype == GS_F16, "neus_backward_points: dX dtype f32 or f16");
@@ -613,7 +626,7 @@ static int backward_points_impl(const float* rays_o, const float* rays_d, const 
   if (n == 0) return GS_OK;
   BwdArgs A;
   A.rays_o = rays_o; A.rays_d = rays_d; A.z_vals = z_vals; A.dists = dists;
-  A.grid = (const _Float16*)grid; A.sdf_w = sdf_w; A.color_B = color_B; A.inv_s = inv_s; A.inv_s_dev = inv_s_dev;
+  A.grid = (const _Float16*)grid; A.sdf_w = sdf_w; A.sdf_wt = sdf_wt; A.color_B = color_B; A.inv_s = inv_s; A.inv_s_dev = inv_s_dev;
   for (int k = 0; k < 6; ++k) A.bound[k] = bound_host[k];
   A.sdf = sdf; A.grad = grad; A.mask = mask; A.d_alpha = d_alpha; A.d_sdf = d_sdf; A.d_grad = d_grad; A.dX = dX;
   A.d_gerr_ray = d_gerr_ray;
@@ -674,7 +687,7 @@ extern "C" int gs_neus_backward_points(const float* rays_o, const float* rays_d,
   return backward_points_impl(rays_o, rays_d, z_vals, dists, grid, sdf_w, color_B, inv_s, inv_s_dev, bound_host, sdf, grad,
                               mask, d_alpha, d_sdf, d_grad, dX, dx_dtype, dx_scale, d_gerr_ray, grid_grad, grid_grad_dtype,
                               grid_grad_scale, d_out, lin_in, dw0, d_arg, pts, row_dtype, row_scale, row_stride, d_inv_s, n,
-                              s, nullptr, 0, stream);
+                              s, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int gs_neus_backward_points_binned(const float* rays_o, const float* rays_d, const float* z_vals,
@@ -686,10 +699,11 @@ extern "C" int gs_neus_backward_points_binned(const float* rays_o, const float* 
                                               const float* d_gerr_ray, void* grid_grad, float grid_grad_scale,
                                               void* d_out, void* lin_in, void* dw0, void* d_arg, void* pts,
                                               int row_dtype, float row_scale, int row_stride, float* d_inv_s, int n,
-                                              int s, void* bin_ws, size_t bin_ws_bytes, gs_stream_t stream) {
+                                              int s, void* bin_ws, size_t bin_ws_bytes, const float* sdf_wt,
+                                              gs_stream_t stream) {
   GS_REQUIRE(bin_ws, "neus_backward_points_binned: null workspace");
   return backward_points_impl(rays_o, rays_d, z_vals, dists, grid, sdf_w, color_B, inv_s, inv_s_dev, bound_host, sdf, grad,
                               mask, d_alpha, d_sdf, d_grad, dX, dx_dtype, dx_scale, d_gerr_ray, grid_grad, GS_F16,
                               grid_grad_scale, d_out, lin_in, dw0, d_arg, pts, row_dtype, row_scale, row_stride, d_inv_s, n,
-                              s, bin_ws, bin_ws_bytes, stream);
+                              s, bin_ws, bin_ws_bytes, sdf_wt, stream);
 }

@@ -485,7 +485,7 @@ def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d
                 _lib.ptr(sdf.contiguous()), _lib.ptr(S["grad"]), _lib.ptr(S["mask"]), _lib.ptr(d_alpha), _lib.ptr(d_sdf),
                 _lib.ptr(d_grad), _lib.ptr(dX), 0, LS, _lib.ptr(d_gerr.reshape(-1).contiguous()), _lib.ptr(grid_acc),
                 gscale, d_out.data_ptr(), lin_in.data_ptr(), dw0.data_ptr(), d_arg.data_ptr(), pts.data_ptr(), 0, LS,
-                160, _lib.ptr(d_invs), n, s, _lib.ptr(bws), bws.numel(), st)
+                160, _lib.ptr(d_invs), n, s, _lib.ptr(bws), bws.numel(), _lib.ptr(zb.get("sdf_wt")), st)
         else:
             rc = L.gs_neus_backward_points(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z_vals), _lib.ptr(dists),
                                            _lib.ptr(S["grid"]), _lib.ptr(S["sdf_w"]), _lib.ptr(S["cB"]),

@@ -246,7 +246,8 @@ class MapTrainer:
         if b is None:
             f32 = dict(dtype=torch.float32, device=dev)
             b = dict(counts=torch.zeros(3, **f32), inv_s=torch.zeros(1, **f32), d_gerr=torch.zeros(max(n, 1), 1, **f32),
-                     d_invs=torch.zeros(1, **f32), zeros_n1=torch.zeros(n, 1, **f32), zeros_n3=torch.zeros(n, 3, **f32))
+                     d_invs=torch.zeros(1, **f32), zeros_n1=torch.zeros(n, 1, **f32), zeros_n3=torch.zeros(n, 3, **f32),
+                     sdf_wt=torch.zeros(16 * 2 * 32, **f32))
             if len(self._bufs) >= 2 * MAX_GRAPHS:
                 self._bufs.pop(next(iter(self._bufs)))
             self._bufs[n] = b
@@ -273,7 +274,8 @@ class MapTrainer:
             _lib.check(L.gs_map_step_prep(_lib.ptr(rays_depth), n, _lib.ptr(var_dev), sf, float(w["w_eikonal"]), s,
                                           _lib.ptr(counts), _lib.ptr(B["counts"]), _lib.ptr(B["inv_s"]),
                                           _lib.ptr(B["d_gerr"]), _lib.ptr(B["d_invs"]), _lib.ptr(flat.sqnorm),
-                                          _lib.ptr(flat.step_dev), st), "map_step_prep")
+                                          _lib.ptr(flat.step_dev), _lib.ptr(model.sdf_network.sdf_layer.weight),
+                                          _lib.ptr(B["sdf_wt"]), st), "map_step_prep")
         counts, inv_s_dev = B["counts"], B["inv_s"]
         z_vals, dists = self.renderer.sample(rays_o, rays_d, model.bound, rays_depth, perturb_rand,
                                              gt_max_dev=counts[2:3])

@@ -154,7 +154,9 @@ int gs_neus_backward_points(const float* rays_o, const float* rays_d, const floa
  * workgroups write (13-bit index, 2 x fp16) records to their own segments of per-(level, bin) queues in `bin_ws`, then
  * one workgroup per bin sums its queue in fp32 LDS accumulators and writes its 8192 entries once; neus_bwd.hip).
  * grid_grad is the loss-scaled f16 table gradient (zero it first; the dense levels and any overflow records still
- * arrive as packed atomics).  `bin_ws`: gs_neus_bin_workspace_bytes(n * s) bytes of scratch (no initial state).     */
+ * arrive as packed atomics).  `bin_ws`: gs_neus_bin_workspace_bytes(n * s) bytes of scratch (no initial state).
+ * `sdf_wt` (optional, f32 [16][2][32]): sdf_w's encoding columns transposed, sdf_wt[l][f][o] = sdf_w[o][3 + 2 l + f]
+ * (gs_map_step_prep writes it), which turns the kernel's strided weight reads into contiguous ones.                */
 size_t gs_neus_bin_workspace_bytes(int n_points);
 int gs_neus_backward_points_binned(const float* rays_o, const float* rays_d, const float* z_vals,
                                    const float* dists, const void* grid, const float* sdf_w, const float* color_B,
@@ -164,7 +166,7 @@ int gs_neus_backward_points_binned(const float* rays_o, const float* rays_d, con
                                    const float* d_gerr_ray, void* grid_grad, float grid_grad_scale, void* d_out,
                                    void* lin_in, void* dw0, void* d_arg, void* pts, int row_dtype, float row_scale,
                                    int row_stride, float* d_inv_s, int n, int s, void* bin_ws, size_t bin_ws_bytes,
-                                   gs_stream_t stream);
+                                   const float* sdf_wt, gs_stream_t stream);
 
 /* The mapper's loss without the eikonal term (src/mapping.py:96-132 + InstantNeuS.compute_sdf_error,
  * src/InstantNeuS.py:372-400) and its gradient, one launch.  Rays with rays_depth <= 0 are masked out.
@@ -208,7 +210,7 @@ int gs_map_adamw_seg(float* p, float* m, float* v, void* p16, const void* g16, s
 /* The scalar / reduction arithmetic around the mapper step's kernels in two launches (map_opt.hip):
  *   gs_map_step_prep: counts_out = counts_in if given, else [#rays with depth > 0, n, max depth] of rays_depth [n];
  *     inv_s_out[0] = clamp(exp(variance[0] * scale_factor), 1e-6, 1e6); d_gerr_out[0:n] = w_eikonal / (counts[1] * samples);
- *     d_invs[0] = sqnorm[0] = 0; step_dev[0] += 1.
+ *     d_invs[0] = sqnorm[0] = 0; step_dev[0] += 1; sdf_wt_out[l][f][o] = sdf_w[o][3 + 2 l + f] (both optional).
  *   gs_map_step_post: g32 [mlp 10240 | sdf_w 32x35 | sdf_b 32 | color_B 3x33 | variance 1 | loss 1] from the chunked Gram
  *     product of the per-point rows laid out [d_out 32 | x y z 1 .. 8 | lin_in 40 | dw0 40 | d_arg 40] (gram_chunks f32
  *     [nchunk,40,160] = rows[:, :40]^T rows per chunk, summed over chunks, x inv_loss_scale), the MLP
@@ -216,7 +218,8 @@ int gs_map_adamw_seg(float* p, float* m, float* v, void* p16, const void* g16, s
  *     (counts[1] * samples).                                                                                        */
 int gs_map_step_prep(const float* rays_depth, int n, const float* variance, float scale_factor, float w_eikonal,
                      int samples, const float* counts_in, float* counts_out, float* inv_s_out, float* d_gerr_out,
-                     float* d_invs, float* sqnorm, int* step_dev, gs_stream_t stream);
+                     float* d_invs, float* sqnorm, int* step_dev, const float* sdf_w, float* sdf_wt_out,
+                     gs_stream_t stream);
 int gs_map_step_post(const float* gram_chunks, int nchunk, float inv_loss_scale, const float* mlp_partial, int nb,
                      const float* d_invs, const float* variance, const float* inv_s, float scale_factor,
                      const float* loss_rays, const float* gerr, int n, float w_eikonal, int samples, const float* counts,
