@@ -568,9 +568,10 @@ def main():
             dict({"kernel": "corr_volume_kernel (MFMA all-pairs volume + 3 pooled levels, written once)", "bound": "hbm",
                   "achieved": bgb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bgb / HBM_PEAK_GBS,
                   "bytes_per_launch": br["corr_build_bytes"],
-                  "note": "8 edges per launch (one keyframe's new factors); the time includes the feature-map transpose "
-                          "launch; HBM traffic = algorithmic, the kernel is bound by L2 operand re-reads (DESIGN 3)"},
-                 **pmc_traffic("r02_pmc_corr_volume.json"))]
+                  "note": "8 edges per launch (one keyframe's new factors); the time includes the operand re-ordering "
+                          "and level-3 pooling launches; HBM traffic = algorithmic; a tile's life is dominated by its "
+                          "operand loads queueing behind the CU's stores (phase timeline in DESIGN 3)"},
+                 **pmc_traffic("r03_pmc_corr_volume.json"))]
         line["neus_render"] = neus_render_bench(device)
         line["roofline_other"].append(dict(line["neus_render"]["mlp_mfma"], bound="mfma"))
         if world == 1 and not args.no_cpu_baseline:
