@@ -347,16 +347,6 @@ __global__ __launch_bounds__(SMALL_NT) void chol_small_kernel(const double* __re
         }
       }
       CHOL_ACC(0);
-      __syncthreads();                                // all reads of the old diagonal block are done
-      if (tid < CB) {
-#pragma unroll
-        for (int i = 0; i < CB; ++i)
-          if (i == tid) {
-#pragma unroll
-            for (int j = 0; j <= i; ++j) Lp[tri(k0 + i, k0 + j)] = l[i][j];
-            invd[k0 + i] = inv[i];
-          }
-      }
       // (2) panel rows (the b row included): x = a L11^-T, then (3) the rank-6 update of this row's
       // remaining PANEL columns only; the matrix right of the panel is updated once per panel (4).
       const int pc = pend - s0;                       // panel columns still to be factored
@@ -374,7 +364,16 @@ __global__ __launch_bounds__(SMALL_NT) void chol_small_kernel(const double* __re
         for (int j = 0; j < CB; ++j) Ar[j] = x[j];
       }
       CHOL_ACC(1);
-      __syncthreads();
+      __syncthreads();                                // x is visible; all reads of the old diagonal block are done
+      if (tid < CB) {                                 // ... so its factor can replace it (nothing below reads these rows)
+#pragma unroll
+        for (int i = 0; i < CB; ++i)
+          if (i == tid) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) Lp[tri(k0 + i, k0 + j)] = l[i][j];
+            invd[k0 + i] = inv[i];
+          }
+      }
       {                                               // 4 threads per row, columns interleaved
         const int rq = tid >> 2, q = tid & 3;
         if (rq < rows && pc > 0) {
@@ -385,12 +384,32 @@ __global__ __launch_bounds__(SMALL_NT) void chol_small_kernel(const double* __re
           for (int k = 0; k < CB; ++k) x[k] = Xr[k];
           double* Ar = Lp + tri(r, s0);
           const int cmax = min(pc, rq + 1);           // lower triangle: c <= r
-          for (int c = q; c < cmax; c += 4) {
-            const double* Lc = Lp + tri(s0 + c, k0);
-            double acc = 0.0;
+          // at most (PW - CB) / 4 = 6 columns per thread, two at a time: the LDS reads of both are issued before the
+          // first multiply-add (the rolled loop paid two dependent LDS round trips per column; all six at once spill:
+          // 1024 threads leave 128 VGPRs)
+          constexpr int NC = (PW - CB + 3) / 4;
 #pragma unroll
-            for (int k = 0; k < CB; ++k) acc = fma(x[k], Lc[k], acc);
-            Ar[c] -= acc;
+          for (int it0 = 0; it0 < NC; it0 += 2) {
+            if (q + 4 * it0 >= cmax) break;
+            double lc[2][CB], av[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int c = min(q + 4 * (it0 + u), cmax - 1);
+              const double* Lc = Lp + tri(s0 + c, k0);
+#pragma unroll
+              for (int k = 0; k < CB; ++k) lc[u][k] = Lc[k];
+              av[u] = Ar[c];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int c = q + 4 * (it0 + u);
+              if (c < cmax) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < CB; ++k) acc = fma(x[k], lc[u][k], acc);
+                Ar[c] = av[u] - acc;
+              }
+            }
           }
         }
       }
@@ -398,49 +417,38 @@ __global__ __launch_bounds__(SMALL_NT) void chol_small_kernel(const double* __re
       __syncthreads();
       CHOL_ACC(3);
     }
-    // (4) rank-PW update of everything right of / below the panel, 8x4 register tiles
+    // (4) rank-PW update of everything right of / below the panel on the fp64 matrix cores: one wave per 16x16
+    // tile of the lower triangle, v_mfma_f64_16x16x4_f64 over 8 k-steps (A[i][k] = L[r0+i][p0+k] and B[k][j] =
+    // L[c0+j][p0+k], one double per lane: row/column = lane & 15, k = lane >> 4; D: column = lane & 15, row =
+    // (lane >> 4) + 4 * reg).  16 LDS reads per lane per tile instead of 240 for the same 7 680 multiply-adds: the
+    // 4x4 register tiles this replaces were bound by LDS bandwidth (18 of the 60 us of the factorisation at n = 150).
     const int s1 = pend;
     const int rows1 = n + 1 - s1;                     // rows s1..n (b row included)
     const int pw = pend - p0;
     if (rows1 > 1) {
-      const int T = (rows1 + 3) >> 2, ntile = (T * (T + 1)) >> 1;
-      for (int t = tid; t < ntile; t += SMALL_NT) {
+      typedef double double4v __attribute__((ext_vector_type(4)));
+      const int T = (rows1 + 15) >> 4, ntile = (T * (T + 1)) >> 1;
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+      for (int t = wv; t < ntile; t += SMALL_NT / 64) {
         int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
         while (((ti + 1) * (ti + 2)) >> 1 <= t) ++ti;
         while ((ti * (ti + 1)) >> 1 > t) --ti;
         const int tj = t - ((ti * (ti + 1)) >> 1);
-        const int r0 = s1 + 4 * ti, c0 = s1 + 4 * tj;
-        double acc[4][4];
+        const int r0 = s1 + 16 * ti, c0 = s1 + 16 * tj;
+        const double* pa = Lp + tri(min(r0 + (ln & 15), n), p0);
+        const double* pb = Lp + tri(min(c0 + (ln & 15), n), p0);
+        double4v acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-        const double* pr[4];
-        const double* pcn[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          pr[i] = Lp + tri(min(r0 + i, n), p0);
-          pcn[i] = Lp + tri(min(c0 + i, n), p0);
+        for (int kb = 0; kb < (PW + 3) / 4; ++kb) {
+          const int k = 4 * kb + (ln >> 4);
+          const double a = k < pw ? pa[k] : 0.0, b = k < pw ? pb[k] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
-        for (int k = 0; k < pw; ++k) {
-          double a[4], b[4];
+        const int c = c0 + (ln & 15);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { a[i] = pr[i][k]; b[i] = pcn[i][k]; }
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int rr = r0 + i;
-          if (rr > n) continue;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int c = c0 + j;
-            if (c > rr || c >= n) continue;           // column n (the b row's own diagonal) is unused
-            Lp[tri(rr, c)] -= acc[i][j];
-          }
+        for (int q = 0; q < 4; ++q) {
+          const int rr = r0 + (ln >> 4) + 4 * q;
+          if (rr <= n && c < n && c <= rr) Lp[tri(rr, c)] -= acc[q];   // column n (the b row's own diagonal) is unused
         }
       }
     }
