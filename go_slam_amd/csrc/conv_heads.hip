@@ -35,41 +35,67 @@ __global__ __launch_bounds__(256) void conv3x3_head_kernel(
   const int kh = 8 * (lane >> 5);
 
   half8 a[8];
-  float bi[8][8];
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    a[ks] = *reinterpret_cast<const half8*>(wpack + ((size_t)ks * 64 + lane) * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bi[ks][e] = in_bias ? in_bias[ks * 16 + kh + e] : 0.0f;
-  }
+  for (int ks = 0; ks < 8; ++ks) a[ks] = *reinterpret_cast<const half8*>(wpack + ((size_t)ks * 64 + lane) * 8);
+  // the producer's bias lives in LDS (two 16-byte reads per k-step), not in 64 registers: the second operand buffer
+  // of the prefetch below needs them, and 3 workgroups per CU need <= 168 VGPRs
+  __shared__ __attribute__((aligned(16))) float sb[128];
+  if (tid < 128) sb[tid] = in_bias ? in_bias[tid] : 0.0f;
+  __syncthreads();
   const bool touch = (in_bias != nullptr) || in_relu;
 
-  for (int blk = wv; blk * 32 < npx; blk += 4) {
+  // One 32-pixel block = 8 fragment loads, MFMAs, 16 LDS writes.  All of a workgroup's blocks are resident at once
+  // (750 workgroups on 768 slots at the bench shape), so the kernel's duration IS a wave's chain of blocks: the next
+  // block's loads are issued before this block's MFMAs (two register buffers) instead of after its LDS writes.
+  auto load_block = [&](int blk, half8 (&v)[8]) {
     const int px = blk * 32 + (lane & 31);
-    const bool valid = px < npx;
-    const _Float16* xr = x + ((size_t)(n * h + in_lo) * w + (valid ? px : 0)) * ldx + kh;
+    const _Float16* xr = x + ((size_t)(n * h + in_lo) * w + (px < npx ? px : 0)) * ldx + kh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) v[ks] = *reinterpret_cast<const half8*>(xr + 16 * ks);
+  };
+  auto do_block = [&](int blk, half8 (&v)[8]) {
+    const int px = blk * 32 + (lane & 31);
     float16v c;
 #pragma unroll
     for (int e = 0; e < 16; ++e) c[e] = 0.0f;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      half8 v = *reinterpret_cast<const half8*>(xr + 16 * ks);
+      half8 t = v[ks];
       if (touch) {
+        typedef float float4v __attribute__((ext_vector_type(4)));
+        const float4v b0 = *reinterpret_cast<const float4v*>(sb + ks * 16 + kh);
+        const float4v b1 = *reinterpret_cast<const float4v*>(sb + ks * 16 + kh + 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float f = (float)v[e] + bi[ks][e];
+          float f = (float)t[e] + (e < 4 ? b0[e & 3] : b1[e & 3]);
           if (in_relu) f = fmaxf(f, 0.0f);
-          v[e] = (_Float16)f;
+          t[e] = (_Float16)f;
         }
       }
-      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], v, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], t, c, 0, 0, 0);
     }
-    if (valid) {
+    if (px < npx) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         if (row < NT) cs[px * S + row] = c[reg];
       }
+    }
+  };
+  if (wv * 32 < npx) {
+    half8 va[8], vb[8];
+    int blk = wv;
+    load_block(blk, va);
+    while (true) {
+      const bool more1 = (blk + 4) * 32 < npx;
+      if (more1) load_block(blk + 4, vb);
+      do_block(blk, va);
+      if (!more1) break;
+      const bool more2 = (blk + 8) * 32 < npx;
+      if (more2) load_block(blk + 8, va);
+      do_block(blk + 4, vb);
+      if (!more2) break;
+      blk += 8;
     }
   }
   __syncthreads();
@@ -109,9 +135,9 @@ int launch_head(const void* x, int ldx, const float* in_bias, int in_relu, const
                 int epilogue, float out_scale, float* out, int n, int h, int w, hipStream_t st) {
   constexpr int S = (9 * O) | 1;
   const size_t lds = (size_t)(HEAD_ROWS + 2) * w * S * sizeof(float);
-  GS_REQUIRE(lds <= 160 * 1024, "conv3x3_head: image width %d needs %zu bytes of LDS", w, lds);
+  GS_REQUIRE(lds <= 160 * 1024 - 512, "conv3x3_head: image width %d needs %zu bytes of LDS", w, lds);   // 512: sb
   static GsLdsLimit limit;
-  if (int rc = limit.raise((const void*)conv3x3_head_kernel<O>, 160 * 1024, "conv3x3_head")) return rc;
+  if (int rc = limit.raise((const void*)conv3x3_head_kernel<O>, lds, "conv3x3_head")) return rc;
   conv3x3_head_kernel<O><<<dim3(gs_cdiv(h, HEAD_ROWS), n), 256, lds, st>>>(
       (const _Float16*)x, ldx, in_bias, in_relu, (const _Float16*)wpack, bias, epilogue, out_scale, out, h, w);
   GS_CHECK_LAUNCH("conv3x3_head");
