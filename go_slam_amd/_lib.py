@@ -52,6 +52,8 @@ SIGNATURES = {
     "gs_conv3x3_gru_q": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gs_conv3x3_head": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_float, _P, c_int, c_int, c_int, _P]),
     "gs_segment_mean": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "gs_norm_act_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gs_norm_act": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [c_float, _P, c_size_t, _P]),
     "gs_gru_glo_workspace_bytes": (c_size_t, [c_int]),
     "gs_gru_glo": (c_int, [_P] * 11 + [c_int, c_int, _P, c_size_t, _P]),
     "gs_gru_glo_fused_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -1,0 +1,230 @@
+// InstanceNorm2d (affine = False) + ReLU + residual add + ReLU of the frame encoders, NHWC fp16, three launches
+// (reference: src/modules/extractor.py:4-57 ResidualBlock.forward and :93-126 BasicEncoder.forward; the feature
+// encoder `fnet` is built with norm_fn='instance', the context encoder `cnet` with norm_fn='none').
+//
+// torch runs `relu(norm(conv(x)))` as batch_norm_collect_statistics + batch_norm_calc_invstd +
+// batch_norm_transform_input + clamp, and the block's `relu(skip + y)` as an add and another clamp: 5-7 launches of
+// 3-11 us each on tensors of 1.2-4.9 MB, 200 launches per input frame in all.  Here:
+//   instnorm_stats_kernel : per (image, 256-pixel chunk): sums of (x - k) and (x - k)^2 per channel, k = the chunk's
+//                           first pixel -> (count, mean, M2) of the chunk
+//   instnorm_final_kernel : per image: the chunks merged with Chan's formula -> mean and 1 / sqrt(var + eps) per
+//                           channel (fp32, biased variance, as torch's native kernels)
+//   norm_act_kernel       : x = half(x + bias)              [bias]     (the convolution is called WITHOUT its bias: torch adds
+//                                                                      it in a separate kernel anyway; the statistics see x + bias)
+//                           t = half((x - mean) * invstd)   [norm]     -- every rounding point is the one of the fp16
+//                           t = max(t, 0)                   [relu_in]     tensors the reference materialises
+//                           t = half(skip + t)              [skip]
+//                           t = max(t, 0)                   [relu_out]
+// Memory-bound: one read of x (+ skip) and one write of y; the statistics pass reads x once more (L2-resident: the
+// convolution just wrote it).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int IN_CHUNK = 256;      // pixels per statistics workgroup
+
+struct Moments { float n, mean, m2; };
+
+__device__ __forceinline__ Moments merge(const Moments a, const Moments b) {   // Chan et al.
+  if (b.n == 0.0f) return a;
+  if (a.n == 0.0f) return b;
+  Moments r;
+  r.n = a.n + b.n;
+  const float d = b.mean - a.mean;
+  const float f = b.n / r.n;
+  r.mean = a.mean + d * f;
+  r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+  return r;
+}
+
+// partial: [n][nblk][c] Moments
+__global__ __launch_bounds__(256) void instnorm_stats_kernel(const _Float16* __restrict__ x,
+                                                             const _Float16* __restrict__ bias, int hw, int c,
+                                                             Moments* __restrict__ partial) {
+  __shared__ float ssum[256 * 16];
+  const int img = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  const int tid = threadIdx.x;
+  const int c8n = c >> 3, lanes = 256 / c8n;
+  const int cg = tid % c8n, pl = tid / c8n;
+  const int p0 = blk * IN_CHUNK, p1 = min(p0 + IN_CHUNK, hw);
+  const _Float16* xi = x + (size_t)img * hw * c;
+  // shifted sums with ONE shift per channel and workgroup (the chunk's first pixel): the threads' sums then simply
+  // add -- no pairwise Chan merges (a division each) inside the workgroup
+  float k[8], s1[8], s2[8];
+  half8 bv;
+  {
+    const half8 v0 = *reinterpret_cast<const half8*>(xi + (size_t)p0 * c + cg * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bv[j] = bias ? bias[cg * 8 + j] : (_Float16)0.0f;
+      k[j] = bias ? (float)(_Float16)((float)v0[j] + (float)bv[j]) : (float)v0[j];
+      s1[j] = 0.0f;
+      s2[j] = 0.0f;
+    }
+  }
+  for (int p = p0 + pl; p < p1; p += 4 * lanes) {             // 4 loads in flight per thread
+    half8 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      v[u] = *reinterpret_cast<const half8*>(xi + (size_t)min(p + u * lanes, p1 - 1) * c + cg * 8);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (p + u * lanes >= p1) continue;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = (float)v[u][j];
+        if (bias) f = (float)(_Float16)(f + (float)bv[j]);       // the fp16 tensor conv + bias
+        const float d = f - k[j];
+        s1[j] += d;
+        s2[j] = fmaf(d, d, s2[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {                                // [pl][channel][2]
+    ssum[(pl * c + cg * 8 + j) * 2 + 0] = s1[j];
+    ssum[(pl * c + cg * 8 + j) * 2 + 1] = s2[j];
+  }
+  __syncthreads();
+  for (int col = tid; col < 2 * c; col += 256) {               // column = (channel, which sum): add the pixel lanes
+    float a = 0.0f;
+    for (int l = 0; l < lanes; ++l) a += ssum[l * 2 * c + col];
+    ssum[col] = a;                                             // own column of row 0: nobody else reads or writes it
+  }
+  __syncthreads();
+  if (tid < c) {
+    const float n = (float)(p1 - p0), a1 = ssum[2 * tid], a2 = ssum[2 * tid + 1];
+    // the shift of channel tid: recomputed from the chunk's first pixel
+    float kk = (float)xi[(size_t)p0 * c + tid];
+    if (bias) kk = (float)(_Float16)(kk + (float)bias[tid]);
+    Moments m;
+    m.n = n;
+    m.mean = kk + a1 / n;
+    m.m2 = fmaxf(a2 - a1 * a1 / n, 0.0f);
+    partial[((size_t)img * nblk + blk) * c + tid] = m;
+  }
+}
+
+// One workgroup per image merges the chunks' moments (Chan) and writes mean and 1 / sqrt(var + eps) per channel.  A
+// kernel of its own rather than "the last workgroup to finish": that needs a device-scope fence in every workgroup, and on
+// this part (8 XCDs, one L2 each) such a fence writes the L2's dirty lines back -- the convolution output the
+// statistics were just read from -- which made the statistics pass 17 us instead of 3.
+__global__ __launch_bounds__(256) void instnorm_final_kernel(const Moments* __restrict__ partial, int nblk, int c, float eps,
+                                                             float* __restrict__ final_) {
+  __shared__ Moments sm[256];
+  const int img = blockIdx.x, tid = threadIdx.x;
+  for (int c0 = 0; c0 < c; c0 += 256) {                       // (c <= 256: one pass)
+    const int cc = min(c - c0, 256);
+    const int per = 256 / cc;                                 // threads per channel
+    const int ch = tid % cc, part = tid / cc;
+    Moments acc = {0.0f, 0.0f, 0.0f};
+    if (part < per) {
+      // 8 independent loads per round trip (a rolled loop pays one L2 latency per chunk)
+      for (int b = part; b < nblk; b += 8 * per) {
+        Moments m[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int bb = b + u * per;
+          m[u] = partial[((size_t)img * nblk + min(bb, nblk - 1)) * c + c0 + ch];
+          if (bb >= nblk) m[u].n = 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = merge(acc, m[u]);
+      }
+    }
+    sm[tid] = acc;
+    __syncthreads();
+    if (tid < cc) {
+      Moments r = sm[tid];
+      for (int q = 1; q < per; ++q) r = merge(r, sm[q * cc + tid]);
+      const float var = r.n > 0.0f ? r.m2 / r.n : 0.0f;
+      final_[((size_t)img * c + c0 + tid) * 2 + 0] = r.mean;
+      final_[((size_t)img * c + c0 + tid) * 2 + 1] = 1.0f / sqrtf(var + eps);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void norm_act_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ skip,
+                                                       _Float16* __restrict__ y, const _Float16* __restrict__ bias,
+                                                       const float* __restrict__ final_, int hw, int c, int relu_in,
+                                                       int relu_out, size_t total) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int c8n = c >> 3;
+  const int cg = (int)(t % c8n);
+  const int img = (int)(t / ((size_t)hw * c8n));
+  half8 v = reinterpret_cast<const half8*>(x)[t];
+  if (bias) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)((float)v[j] + (float)bias[cg * 8 + j]);
+  }
+  if (final_) {
+    const float* f = final_ + ((size_t)img * c + cg * 8) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)(((float)v[j] - f[2 * j]) * f[2 * j + 1]);
+  }
+  if (relu_in) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] > (_Float16)0.0f ? v[j] : (_Float16)0.0f;
+  }
+  if (skip) {
+    const half8 s = reinterpret_cast<const half8*>(skip)[t];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)((float)s[j] + (float)v[j]);
+  }
+  if (relu_out) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] > (_Float16)0.0f ? v[j] : (_Float16)0.0f;
+  }
+  reinterpret_cast<half8*>(y)[t] = v;
+}
+
+}  // namespace
+
+extern "C" size_t gs_norm_act_workspace_bytes(int n, int hw, int channels) {
+  if (n <= 0 || hw <= 0 || channels <= 0) return 0;
+  const size_t nblk = (size_t)gs_cdiv(hw, IN_CHUNK);
+  return gs_align((size_t)n * nblk * channels * sizeof(Moments)) + gs_align((size_t)n * channels * 2 * sizeof(float)) + 256;
+}
+
+extern "C" int gs_norm_act(const void* x, const void* bias, const void* skip, void* y, int n, int hw, int channels,
+                           int instance_norm,
+                           int relu_in, int relu_out, float eps, void* workspace, size_t workspace_bytes,
+                           gs_stream_t stream) {
+  GS_REQUIRE(x && y, "norm_act: null pointer");
+  GS_REQUIRE(n >= 0 && hw > 0, "norm_act: bad shape");
+  GS_REQUIRE(channels == 32 || channels == 64 || channels == 128 || channels == 256 || !instance_norm,
+             "norm_act: instance norm supports 32, 64, 128 or 256 channels (got %d)", channels);
+  GS_REQUIRE(channels > 0 && channels % 8 == 0, "norm_act: channels must be a multiple of 8");
+  GS_REQUIRE((((size_t)x | (size_t)y | (size_t)skip) & 15) == 0, "norm_act: tensors must be 16-byte aligned");
+  if (n == 0) return GS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const float* fin = nullptr;
+  if (instance_norm) {
+    GS_REQUIRE(channels <= 256, "norm_act: at most 256 channels");
+    const size_t need = gs_norm_act_workspace_bytes(n, hw, channels);
+    if (!workspace || workspace_bytes < need) {
+      gs_set_error("norm_act: workspace too small (%zu < %zu)", workspace_bytes, need);
+      return GS_ERR_WORKSPACE;
+    }
+    const int nblk = gs_cdiv(hw, IN_CHUNK);
+    char* base = (char*)gs_align((size_t)workspace);
+    Moments* partial = (Moments*)base;
+    float* final_ = (float*)((char*)partial + gs_align((size_t)n * nblk * channels * sizeof(Moments)));
+    GS_REQUIRE(n <= 65535, "norm_act: too many images");
+    instnorm_stats_kernel<<<dim3(nblk, n), 256, 0, st>>>((const _Float16*)x, (const _Float16*)bias, hw, channels, partial);
+    GS_CHECK_LAUNCH("instnorm_stats");
+    instnorm_final_kernel<<<n, 256, 0, st>>>(partial, nblk, channels, eps, final_);
+    GS_CHECK_LAUNCH("instnorm_final");
+    fin = final_;
+  }
+  const size_t total = (size_t)n * hw * (channels / 8);
+  norm_act_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const _Float16*)x, (const _Float16*)skip,
+                                                                   (_Float16*)y, (const _Float16*)bias, fin, hw, channels,
+                                                                   relu_in, relu_out, total);
+  GS_CHECK_LAUNCH("norm_act");
+  return GS_OK;
+}

@@ -242,6 +242,22 @@ int gs_conv3x3_head(const void* x, int x_stride, const float* in_bias, int in_re
  * convolution's epilogue applied on the fly), identity otherwise.                                   */
 int gs_segment_mean(const void* x, int x_stride, const float* in_bias, int in_relu, const int* seg_offsets,
                     const int* seg_edges, void* out, int n_seg, int hw, int channels, gs_stream_t stream);
+/* Frame encoders (src/modules/extractor.py:27-57 ResidualBlock.forward, :113-126 BasicEncoder.forward): the
+ * elementwise tail of every convolution of `fnet` (norm_fn='instance') / `cnet` (norm_fn='none') in three launches
+ * (one without the norm) instead of torch's batch_norm_collect_statistics + calc_invstd + transform_input + clamp
+ * + add + clamp (and the bias add of the convolution before them).  x, skip, y: NHWC fp16 [n, hw, channels], y may
+ * alias x or skip; bias: fp16 [channels] or NULL.
+ *   x = bias ? half(x + bias_c) : x                           the convolution's bias, added to its fp16 output
+ *   t = instance_norm ? half((x - mean_c) * invstd_c) : x     InstanceNorm2d(affine=False): per image and channel,
+ *                                                             biased variance, fp32 statistics, eps inside the sqrt
+ *   t = relu_in  ? max(t, 0) : t
+ *   t = skip     ? half(skip + t) : t
+ *   y = relu_out ? max(t, 0) : t
+ * workspace: gs_norm_act_workspace_bytes bytes (not needed when instance_norm == 0).                      */
+size_t gs_norm_act_workspace_bytes(int n, int hw, int channels);
+int gs_norm_act(const void* x, const void* bias, const void* skip, void* y, int n, int hw, int channels,
+                int instance_norm, int relu_in, int relu_out, float eps, void* workspace, size_t workspace_bytes,
+                gs_stream_t stream);
 /* ConvGRU global context (src/modules/gru.py:22-27): glo = mean_hw(sigmoid(w_pre + w_bias) * net),
  * then the three 1x1 convolutions convz_glo | convr_glo (-> gzr [n,256]) and convq_glo (-> gq [n,128]).
  * w_pre = bias-free 1x1 conv of net, NHWC fp16 [n,hw,128]; wz/wr/wq fp16 [128 out,128 in]; outputs f32

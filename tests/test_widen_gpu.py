@@ -647,6 +647,88 @@ def test_encoders_on_device_match_reference_golden(built_lib):
     assert float((ch.float().cpu() - g["cnet"]).abs().max()) < 3e-2 * sc
 
 
+@pytest.mark.parametrize("n,c,h,w", [(1, 32, 240, 320), (2, 64, 30, 40), (1, 128, 60, 80), (3, 256, 9, 8)])
+def test_norm_act_matches_torch_instance_norm_relu_add_relu(built_lib, n, c, h, w):
+    """gs_norm_act (csrc/instnorm.hip) vs the op sequence of the reference's ResidualBlock on fp16 tensors
+    (src/modules/extractor.py:49-57): relu(norm(x)), norm(x), and relu(skip + relu(norm(x))); and without the norm
+    (cnet).  The statistics are fp32 on both sides but summed in a different order, so a normalised value can land on
+    the neighbouring fp16: <= 1 ulp, on few elements; without the norm the results are bit-equal."""
+    import torch.nn.functional as F
+    from go_slam_amd import extractor as EX
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(n * 1000 + c)
+    x = (torch.randn(n, c, h, w, generator=g) * 1.7 + 0.4).half().to(dev).contiguous(memory_format=torch.channels_last)
+    skip = torch.randn(n, c, h, w, generator=g).half().to(dev).contiguous(memory_format=torch.channels_last)
+
+    def ulps(a, b):
+        ai = a.contiguous().view(torch.int16).int()
+        bi = b.contiguous().view(torch.int16).int()
+        ai = torch.where(ai < 0, -32768 - ai, ai)      # monotone integer order of fp16 values (both zeros -> 0 / -32768)
+        bi = torch.where(bi < 0, -32768 - bi, bi)
+        return (ai - bi).abs()
+
+    ref1 = F.relu(F.instance_norm(x))
+    out1 = EX._norm_act(x.clone(memory_format=torch.preserve_format), None, True, True, False)
+    ref2 = F.instance_norm(x)
+    out2 = EX._norm_act(x.clone(memory_format=torch.preserve_format), None, True, False, False)
+    ref3 = F.relu(skip + F.relu(F.instance_norm(x)))
+    out3 = EX._norm_act(x.clone(memory_format=torch.preserve_format), skip, True, True, True)
+    for ref, out in ((ref1, out1), (ref2, out2)):
+        assert out.is_contiguous(memory_format=torch.channels_last)
+        d = ulps(out, ref)
+        big = (ref.abs() > 1e-2)
+        assert int(d[big].max()) <= 1, "more than one fp16 ulp away from torch's instance norm"
+        assert float((d[big] > 0).float().mean()) < 0.02
+        assert float((out.float() - ref.float()).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max()))
+    # the residual sum cancels: a 1-ulp difference of the normalised operand is 1 ulp OF THAT OPERAND in the sum, plus
+    # the two roundings of the sums themselves
+    tol3 = 2.0 ** -9 * (skip.float().abs() + ref1.float().abs()) + 1e-6
+    assert bool(((out3.float() - ref3.float()).abs() <= tol3).all())
+    assert float((out3 != ref3).float().mean()) < 0.02
+    ref4 = F.relu(skip + F.relu(x))
+    out4 = EX._norm_act(x.clone(memory_format=torch.preserve_format), skip, False, True, True)
+    assert torch.equal(out4, ref4)
+    # the convolution's bias folded in: statistics and output of the fp16 tensor x + b
+    bias = (torch.randn(c, generator=g) * 0.5).half().to(dev)
+    xb = x + bias.view(1, c, 1, 1)
+    ref5 = F.relu(F.instance_norm(xb))
+    out5 = EX._norm_act(x.clone(memory_format=torch.preserve_format), None, True, True, False, bias=bias)
+    d5 = ulps(out5, ref5)
+    assert int(d5[ref5.abs() > 1e-2].max()) <= 1
+    assert torch.equal(EX._norm_act(x.clone(memory_format=torch.preserve_format), skip, False, False, False, bias=bias), skip + xb)
+    # a second call on the same workspace
+    again = EX._norm_act(x.clone(memory_format=torch.preserve_format), None, True, True, False)
+    assert torch.equal(again, out1)
+
+
+def test_encoder_inference_path_matches_module_path(built_lib):
+    """BasicEncoder._forward_fast (fp16 weights cast once, gs_norm_act tails) vs the nn.Module op sequence under the
+    tracker's autocast, for fnet (instance norm) and cnet (no norm) at the tracker's 480 x 640: the convolutions are
+    MIOpen calls on the same fp16 operand values (a few fp16 ulps apart when MIOpen picks another solver for the NHWC weight
+    image); with the norm, the summation order of the statistics adds 1-ulp flips of normalised activations."""
+    from go_slam_amd import extractor as EX
+    from go_slam_amd.droid_net import DroidNet
+    dev = "cuda:0"
+    torch.manual_seed(71)
+    net = DroidNet().to(dev).eval()
+    x = torch.rand(1, 2, 3, 480, 640, device=dev) * 2 - 1
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        assert net.fnet._fast_ok(x.reshape(2, 3, 480, 640))
+        f_fast, c_fast = net.fnet(x), net.cnet(x)
+        EX.FAST_ENCODER = False
+        try:
+            f_mod, c_mod = net.fnet(x), net.cnet(x)
+        finally:
+            EX.FAST_ENCODER = True
+    assert f_fast.dtype == f_mod.dtype == torch.float16 and f_fast.shape == f_mod.shape == (1, 2, 128, 60, 80)
+    assert c_fast.shape == c_mod.shape == (1, 2, 256, 60, 80)
+    sf, sc = float(f_mod.float().abs().max()), float(c_mod.float().abs().max())
+    ef = float((f_fast.float() - f_mod.float()).abs().max())
+    ec = float((c_fast.float() - c_mod.float()).abs().max())
+    assert ec <= 3e-3 * sc, (ec, sc)        # no statistics involved; MIOpen may pick another solver for NHWC weights
+    assert ef <= 1e-2 * sf, (ef, sf)        # 1-ulp flips of normalised activations through 10 layers
+
+
 def _rand_dist(ilen, jlen, seed, scale):
     g = torch.Generator().manual_seed(seed)
     d = torch.rand(ilen, jlen, generator=g) * scale
