@@ -90,15 +90,37 @@ void neus_mlp_bwd_kernel(const _Float16* __restrict__ X, const _Float16* __restr
     zero16(cw3[a]);
   }
 
-  for (int blk = blockIdx.x * 4 + wave; blk < nblk; blk += gridDim.x * 4) {
+  // A wave runs its blocks one after the other, alone on its SIMD (the 192 weight-gradient accumulators): nothing
+  // hides a global round trip.  The NEXT block's inputs (X fragments, d_rgb, rgb) are therefore requested at the head
+  // of the current block and consumed one iteration later.
+  half8 xn[5];
+  float drn[3], yn[3];
+  auto request = [&](int blk) {
+    const int pr = blk * 32 + r;
+    const size_t pcn = (size_t)(pr < np ? pr : np - 1);
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) xn[ks] = ld8(X + pcn * 80 + 16 * ks + kh);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      drn[k] = d_rgb[pcn * 3 + k];
+      yn[k] = rgb ? (float)rgb[pcn * 3 + k] : 0.0f;
+    }
+  };
+  const int blk0 = blockIdx.x * 4 + wave, bstride = gridDim.x * 4;
+  if (blk0 < nblk) request(blk0);
+  for (int blk = blk0; blk < nblk; blk += bstride) {
     const int p0 = blk * 32;
     const bool valid = p0 + r < np;
-    const size_t pc = (size_t)(valid ? p0 + r : np - 1);
     // ---- X: B fragments from the [point][80] rows, and X^T into its tile
     half8 xb[5];
+    float dr[3], yv[3];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) xb[ks] = xn[ks];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { dr[k] = drn[k]; yv[k] = yn[k]; }
+    if (blk + bstride < nblk) request(blk + bstride);
 #pragma unroll
     for (int ks = 0; ks < 5; ++ks) {
-      xb[ks] = ld8(X + pc * 80 + 16 * ks + kh);
 #pragma unroll
       for (int e = 0; e < 8; ++e) XT[(16 * ks + kh + e) * TS + r] = xb[ks][e];
     }
@@ -142,9 +164,9 @@ void neus_mlp_bwd_kernel(const _Float16* __restrict__ X, const _Float16* __restr
     if (hf == 0) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float y = rgb ? (float)rgb[pc * 3 + k] : 0.0f;
+        const float y = yv[k];
         const float dact = rgb ? y * (1.0f - y) : 1.0f;     // rgb == NULL: d_rgb is w.r.t. the raw outputs
-        const float v = valid ? d_rgb[pc * 3 + k] * dact * loss_scale : 0.0f;
+        const float v = valid ? dr[k] * dact * loss_scale : 0.0f;
         bdp[k] = (_Float16)v;
         DP[k * TS + r] = bdp[k];
       }
@@ -256,30 +278,37 @@ void neus_mlp_bwd_kernel(const _Float16* __restrict__ X, const _Float16* __restr
     }
   }
 
-  // ---- reduce the weight-gradient accumulators over the workgroup's waves, write this workgroup's partial
+  // ---- reduce the weight-gradient accumulators over the workgroup's waves, write this workgroup's partial.
+  // The four waves add their 192 accumulators into the LDS image one after the other with plain read-modify-writes
+  // (inside a wave every (register, lane) pair owns its own address): float LDS atomics retire 0.33 lanes per clock on
+  // this part -- 49 152 of them were 62 us, half of the kernel at 4096 rays -- and their order was not reproducible.
   __syncthreads();
   float* red = reinterpret_cast<float*>(sm + NFRAG * 512);
   for (int i = tid; i < NPARAM; i += 256) red[i] = 0.0f;
   __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hf;
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hf;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-      for (int nt = 0; nt < 3; ++nt) {
-        const int f = 32 * nt + r;
-        if (f < 80) atomicAdd(&red[(32 * mt + row) * 80 + f], cw1[mt][nt][reg]);
+          for (int nt = 0; nt < 3; ++nt) {
+            const int f = 32 * nt + r;
+            if (f < 80) red[(32 * mt + row) * 80 + f] += cw1[mt][nt][reg];
+          }
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) red[5120 + (32 * mt + row) * 64 + 32 * nt + r] += cw2[mt][nt][reg];
+        }
+        if (row < 16) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) red[9216 + row * 64 + 32 * nt + r] += cw3[nt][reg];
+        }
       }
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) atomicAdd(&red[5120 + (32 * mt + row) * 64 + 32 * nt + r], cw2[mt][nt][reg]);
     }
-    if (row < 16) {
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) atomicAdd(&red[9216 + row * 64 + 32 * nt + r], cw3[nt][reg]);
-    }
+    __syncthreads();
   }
-  __syncthreads();
   float* out = partial + (size_t)blockIdx.x * NPARAM;
   for (int i = tid; i < NPARAM; i += 256) out[i] = red[i];
 }
