@@ -373,12 +373,14 @@ class MapTrainer:
             inv_scale = self._local_gradients(*args, perturb_rand, counts)
             flat.step(inv_scale, prepped=True)
             return self._global_loss()
-        for dst, src in zip(ent["static"], args):
-            dst.copy_(src)
+        dsts, srcs = list(ent["static"]), list(args)
         if counts is not None:
-            ent["counts"].copy_(counts)
+            dsts.append(ent["counts"])
+            srcs.append(counts)
         if ent["pr"] is not None:
-            ent["pr"].copy_(perturb_rand)
+            dsts.append(ent["pr"])
+            srcs.append(perturb_rand.detach().float().contiguous())
+        torch._foreach_copy_(dsts, srcs)    # ONE launch for the 4-6 input tensors (was a 4.4 us copy kernel each)
         whole = self.world == 1             # single GPU: the optimiser's two launches are part of the graph
 
         def body():
