@@ -176,6 +176,24 @@ def op_breakdown(video, update_op, graph):
     return out
 
 
+def encoder_tail_roofline(device):
+    """gs_norm_act (csrc/instnorm.hip) on the feature encoder's layer-1 activation (1 x 240 x 320 x 32, NHWC fp16):
+    conv bias + InstanceNorm + ReLU + residual add + ReLU in three launches.  HBM-bound: x read for the statistics, then
+    x and skip read and y written = 4 x 2 B per element."""
+    from go_slam_amd import extractor as EX
+    n, c, h, w = 1, 32, 240, 320
+    x = torch.randn(n, c, h, w, device=device).half().contiguous(memory_format=torch.channels_last)
+    skip = torch.randn(n, c, h, w, device=device).half().contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(c, device=device).half()
+    ms = time_op(lambda: EX._norm_act(x, skip, True, True, True, bias=bias), iters=20, warm=3)
+    nbytes = 4 * 2.0 * n * c * h * w
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": "instnorm_stats + instnorm_final + norm_act (gs_norm_act: conv bias + InstanceNorm + ReLU + skip add + "
+                      "ReLU of one encoder block at 240x320x32)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes, "kernel_avg_us": ms * 1e3,
+            "note": "three launches on a 4.9 MB tensor: bound by launch / dependency latency, not by HBM (DESIGN 3b)"}
+
+
 def motion_filter_frame_ms(device):
     """Per INPUT frame (not per keyframe): MotionFilter.track on a 480x640 RGB-D frame that is not promoted to a keyframe
     (src/motion_filter.py:41-90) = feature encoder fnet (7x7 stride-2 stem, residual blocks with instance norm; the
@@ -572,6 +590,10 @@ def main():
                           "and level-3 pooling launches; HBM traffic = algorithmic; a tile's life is dominated by its "
                           "operand loads queueing behind the CU's stores (phase timeline in DESIGN 3)"},
                  **pmc_traffic("r03_pmc_corr_volume.json"))]
+        try:        # the frame encoders' elementwise tail (gs_norm_act) at layer1's shape: never fatal for the headline
+            line["roofline_other"].append(encoder_tail_roofline(device))
+        except Exception as exc:
+            line["roofline_other"].append({"kernel": "gs_norm_act", "error": repr(exc)})
         line["neus_render"] = neus_render_bench(device)
         line["roofline_other"].append(dict(line["neus_render"]["mlp_mfma"], bound="mfma"))
         if world == 1 and not args.no_cpu_baseline:
