@@ -255,13 +255,16 @@ __global__ __launch_bounds__(256) void corr_pyramid_coop_kernel(
 // The cooperative lookup already assembles the 196 channels of 8 pixels per wave in LDS; here the four waves of a
 // workgroup put their 4 x 8 pixels into ONE [32 pixels][208] tile (k padded to 13 MFMA steps, pad columns zero) and each
 // wave multiplies it by ITS 32 of the 128 output channels on the matrix cores (v_mfma_f32_32x32x16_f16, weights = A
-// operand, resident in 52 VGPRs for the whole workgroup: 8 passes = 256 pixels), adds the bias, applies ReLU and the
+// operand, resident in 52 VGPRs for the whole workgroup: 6 passes = 192 pixels), adds the bias, applies ReLU and the
 // [32 pixels][128] fp16 result leaves through LDS as one contiguous 8 KB run.  The 196-channel features (141 MB per
 // update at the bench shape, written once and read once) never exist in HBM, and one launch is gone.
 // Arithmetic = lookup (bit-exact, as above) -> fp16 features -> fp32-accumulated dot products -> + bias -> ReLU -> fp16,
 // i.e. what gs_corr_lookup_pyramid + gs_conv1x1 compute, up to the summation order inside a dot product.
 constexpr int ENC_K = 208;            // 196 padded to 13 k-steps of 16
-constexpr int ENC_PASSES = 8;         // passes of 32 pixels per workgroup
+constexpr int ENC_PASSES = 6;         // passes of 32 pixels per workgroup.  Measured at 75 x 60 x 80 (5 workgroups per CU):
+                                      // 3: 120, 4: 122, 5: 131, 6: 119, 7: 128, 8: 135, 9: 144, 10: 150, 12: 123, 16: 127 us --
+                                      // 8 left a second round of workgroups 11 % full, and chunks that are whole map rows
+                                      // (5, 10 passes at w = 80) start every workgroup in the same column of its plane
 typedef _Float16 enc_h8 __attribute__((ext_vector_type(8)));
 typedef float enc_f16v __attribute__((ext_vector_type(16)));
 
