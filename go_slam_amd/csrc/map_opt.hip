@@ -289,7 +289,19 @@ __global__ __launch_bounds__(256) void map_step_post_kernel(PostArgs A) {
   int out = -1;
   if ((int)blockIdx.x < B_MLP) {
     out = blockIdx.x * 32 + o;
-    for (int k = sl; k < A.nb; k += 8) t += A.mlp_partial[(size_t)k * N_MLP + out];
+    // 8 loads in flight per round trip, added in the same order as one by one (a rolled loop pays one L2 latency per
+    // partial: 32 of them per thread in a launch of 330 small workgroups)
+    for (int k0 = sl; k0 < A.nb; k0 += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + 8 * u;
+        v[u] = k < A.nb ? A.mlp_partial[(size_t)k * N_MLP + out] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + 8 * u < A.nb) t += v[u];
+    }
   } else {
     const int e = ((int)blockIdx.x - B_MLP) * 32 + o;
     if (e < N_DENSE) {
@@ -307,10 +319,21 @@ __global__ __launch_bounds__(256) void map_step_post_kernel(PostArgs A) {
         const int q = e - N_W - N_B, d = q / 33, c = q - d * 33;
         r0 = 32 + d; c0 = 120 + c;
       }
-      for (int k = sl; k < A.nchunk; k += 8) {
-        const float* g = A.gram + (size_t)k * 40 * 160;
-        t += g[r0 * 160 + c0];
-        if (r1 >= 0) t += g[r1 * 160 + c1];
+      for (int k0 = sl; k0 < A.nchunk; k0 += 64) {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = k0 + 8 * u;
+          const float* g = A.gram + (size_t)(k < A.nchunk ? k : 0) * 40 * 160;
+          v0[u] = g[r0 * 160 + c0];
+          v1[u] = r1 >= 0 ? g[r1 * 160 + c1] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (k0 + 8 * u >= A.nchunk) continue;
+          t += v0[u];
+          if (r1 >= 0) t += v1[u];
+        }
       }
     }
   }
