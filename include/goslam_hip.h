@@ -77,7 +77,7 @@ int gs_corr_lookup_enc(const void* vol0, const void* vol1, const void* vol2, con
 /* CorrBlock.__init__ + CorrBlock.corr (src/modules/corr.py:26-41,67-76): all-pairs volume of
  * fp16 feature maps fmap1[e], fmap2[e] ([n,128,h,w], both divided by 4) plus the 3 average-pooled
  * levels, each pooled level computed from the fp16-rounded level below (avg_pool2d on half).
- * Outputs vol[l] f16 [n,h,w,h>>l,w>>l].  Requires w % 8 == 0, w <= 80, h >= 8.
+ * Outputs vol[l] f16 [n,h,w,h>>l,w>>l].  Requires w % 8 == 0, w <= 96, h >= 8.
  * layout GS_CORR_TILE8 (w % 16 == 0): a private layout for the lookup's benefit -- the planes of levels
  * 0 and 1 are stored as 8x8-element (128-byte = one L2 line) tiles, element (y,x) of a plane at
  * ((y>>3) * ceil(wl/8) + (x>>3)) * 64 + (y&7) * 8 + (x&7), plane size gs_corr_level_elems(); an 8x8
