@@ -56,7 +56,7 @@ def bench_graph(num_kf, num_edges, seed=43):
             torch.tensor([p[1] for p in pairs], dtype=torch.long))
 
 
-def build_state(device, seed=43, num_kf=None, num_edges=None, shape=None, corr_impl="volume", upsample=True):
+def build_state(device, seed=43, num_kf=None, num_edges=None, shape=None, corr_impl="volume", upsample=True, rgbd=True):
     from go_slam_amd import synth
     from go_slam_amd.depth_video import DepthVideo
     from go_slam_amd.droid_net import UpdateModule
@@ -69,7 +69,7 @@ def build_state(device, seed=43, num_kf=None, num_edges=None, shape=None, corr_i
     # let MIOpen search its NHWC fp16 solvers once per conv shape (the default immediate-mode
     # pick is ~1.7x slower on the update operator's shapes)
     torch.backends.cudnn.benchmark = True
-    vid = synth.make_video(NUM_KF, SHAPE, seed=seed, rgbd=True, buffer=NUM_KF + 7)
+    vid = synth.make_video(NUM_KF, SHAPE, seed=seed, rgbd=rgbd, buffer=NUM_KF + 7)
     video = DepthVideo(ht, wd, buffer=NUM_KF + 7, device=device)
     video.poses.copy_(vid["poses"])
     video.disps.copy_(vid["disps"])
@@ -112,6 +112,42 @@ def global_ba_stress(device, num_kf=200, num_edges=1200, shape="Scan"):
     finite = bool(torch.isfinite(video.poses).all()) and bool(torch.isfinite(video.disps).all())
     return {"keyframes": num_kf, "edges": int(graph.ii.numel()), "maps": shape, "unknowns": 6 * (num_kf - 1),
             "update_lowmem_step_ms": ms, "state_finite": finite}
+
+
+def mono_window(device, num_kf=50, num_edges=100, shape="Rep", steps=5, warm=2):
+    """BASELINE configs[4]'s TRACKING side: the monocular frontend window of replica_mono.yaml:29,32 (window 50,
+    max_factors 100) at the Replica map size 40x80, no depth prior (disps_sens = 0) -- one step = 6 x
+    FactorGraph.update(iters=2) as in the headline, but on a window whose reduced camera system has 6P = 294
+    unknowns (past the 192 the RGB-D window's LDS-resident Cholesky holds)."""
+    from go_slam_amd import droid_backends as db
+    video, update_op, graph, _ = build_state(device, seed=53, num_kf=num_kf, num_edges=num_edges, shape=shape, rgbd=False)
+    assert not bool(video.disps_sens.any())
+    for _ in range(warm):
+        keyframe_step(graph)
+    torch.cuda.synchronize()
+    tic = time.perf_counter()
+    for _ in range(steps):
+        keyframe_step(graph)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - tic) / steps
+    finite = bool(torch.isfinite(video.poses).all()) and bool(torch.isfinite(video.disps).all())
+    ii, jj = graph.ii, graph.jj
+    ht, wd = graph.ht, graph.wd
+    target = graph.target.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
+    weight = torch.rand_like(target)
+    kx = torch.unique(torch.cat([torch.arange(1, num_kf, device=ii.device), ii]))
+    eta = 0.2 * graph.damping[kx].contiguous() + 1e-7
+    poses0, disps0 = video.poses.clone(), video.disps.clone()
+
+    def ba():
+        video.poses.copy_(poses0)
+        video.disps.copy_(disps0)
+        db.ba(video.poses, video.disps, video.intrinsics[0].contiguous(), video.disps_sens, target, weight, eta,
+              ii, jj, 1, num_kf, 2, 1e-4, 0.1, False)
+    ba_ms = time_op(ba)
+    return {"workload": f"monocular frontend window: {shape} maps {ht}x{wd}, P={num_kf} keyframes, E={int(ii.numel())} edges, "
+                        "no depth prior, 6 updates/keyframe, iters=2", "keyframes_per_s": 1e3 / ms, "ms_per_keyframe": ms,
+            "ba_2iter_ms": ba_ms, "unknowns": 6 * (num_kf - 1), "state_finite": finite}
 
 
 def time_op(fn, iters=10, warm=2):
@@ -390,6 +426,89 @@ def cpu_baseline_neus(n_rays=4096):
                                      "(oracle forward + losses + torch.autograd backward + clip + AdamW)"}}
 
 
+def gather_ceiling(table_mb=25.2, points=None):
+    """G gathers/s ceiling measured by tools/gather_bench.hip on an MI355X (committed: profiles/r04_gather_bench.json):
+    the grid's own corner pattern on a table of `table_mb`; None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r04_gather_bench.json")
+    if not os.path.exists(path):
+        return None
+    rows = [r for r in json.load(open(path))["results"] if abs(r["table_MB"] - table_mb) < 0.2]
+    if points is not None and rows:
+        rows = sorted(rows, key=lambda r: abs(r["points"] - points))[:1]
+    return {"corner8_Ggathers_per_s": max(r["corner8"]["Ggathers_per_s"] for r in rows),
+            "random4_Ggathers_per_s": max(r["random4"]["Ggathers_per_s"] for r in rows),
+            "source": "profiles/r04_gather_bench.json (tools/gather_bench.hip, committed run)"} if rows else None
+
+
+def neus_kernel_rooflines(device, n_rays, steps=5):
+    """The kernels that own path M, timed LIVE with HIP events on the launch stream (the library's kernel timer,
+    gs_timing_*): the eager fused mapper step on `n_rays` rays x 72 samples.  Algorithmic bytes per point:
+    forward 512 B of grid gathers + 12 B in = 524 B; backward 512 B gathers + 512 B table-gradient scatter + 12 B =
+    1036 B; the bin reduce reads the backward's record queues (6 B per record, 128 records per point at most) and
+    writes the 11 hashed levels once.  `gather_rate` = 128 four-byte gathers per point / kernel time, against the
+    measured ceiling of tools/gather_bench.hip."""
+    import go_slam_amd.neus as neus
+    from go_slam_amd import _lib
+    from go_slam_amd.neus.mapper import MapTrainer
+    g = torch.Generator().manual_seed(43)
+    model = neus.InstantNeuS({}, [[-5.0, 5.0]] * 3).to(device)
+    with torch.no_grad():
+        model.sdf_network.encoding.encoding.params.copy_((torch.rand(model.sdf_network.encoding.encoding.params.shape, generator=g) - 0.5) * 0.02)
+        model.sdf_network.sdf_layer.weight[:, 3:] = torch.randn(32, 32, generator=g).to(device) * 0.1
+    n = n_rays
+    o = (torch.rand(n, 3, generator=g) * 6 - 3).to(device)
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1).to(device)
+    gt = torch.rand(n, generator=g) * 3.5 + 0.5
+    gt[torch.rand(n, generator=g) < 0.1] = 0
+    gt = gt.to(device)
+    col = torch.rand(n, 3, generator=g).to(device)
+    pr = torch.rand(24, generator=g).to(device)
+    tr = MapTrainer(model, neus.Renderer(N_samples=24, N_surface=48), graph=False)
+    for _ in range(2):
+        tr.step(o, d, col, gt, pr)
+    torch.cuda.synchronize()
+    with _lib.kernel_timer(device) as kt:
+        for _ in range(steps):
+            tr.step(o, d, col, gt, pr)
+        torch.cuda.synchronize()
+    t = kt.read()
+    pts = n * 72
+    ceil_ = gather_ceiling(25.2, pts)
+    pmc = {}
+    ppath = os.path.join(ROOT, "profiles", "r04_pmc_neus.json")
+    if os.path.exists(ppath):
+        pmc = json.load(open(ppath)).get(f"traffic_bytes_per_launch@{n_rays}", {})
+    nh = 11                         # hashed levels (2^19 entries x 4 B each)
+    spec = [("neus_point", "neus_point_kernel (hash-grid encode + SDF linear + analytic gradient + alpha + MLP input row)",
+             524.0 * pts, True),
+            ("neus_backward_points_binned", "neus_point_bwd_kernel<true> (re-gather + table-gradient records, pass 1 of bin-and-reduce)",
+             1036.0 * pts, True),
+            ("grid_bin_reduce", "grid_bin_reduce_kernel (pass 2: exact integer LDS sums per 8192-entry bin)",
+             6.0 * 88.0 * pts + nh * (1 << 19) * 4.0 * 2, False),
+            ("mlp_backward", "neus_mlp_bwd_kernel (fused colour-MLP backward, MFMA)", (160.0 + 12.0 + 6.0 + 160.0) * pts, False),
+            ("neus_mlp", "neus_mlp_kernel (fused colour MLP forward, MFMA)", (160.0 + 6.0) * pts, False)]
+    out = []
+    for key, name, nbytes, gathers in spec:
+        if key not in t or t[key][1] == 0:
+            continue
+        us = 1e3 * t[key][0] / t[key][1]
+        gbs = nbytes / (us * 1e-6) / 1e9
+        ent = {"kernel": name + f" @ {n_rays} rays x 72 samples", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+               "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes, "kernel_avg_us": us,
+               "launches_timed": t[key][1], "traffic": pmc.get(key),
+               "traffic_source": "profiles/r04_pmc_neus.json (committed PMC passes)" if pmc.get(key) else None}
+        if gathers:
+            rate = pts * 128.0 / (us * 1e-6) / 1e9
+            ent["gather_rate_Ggathers_per_s"] = rate
+            if ceil_:
+                ent["gather_ceiling"] = ceil_
+                ent["gather_frac_of_corner8_ceiling"] = rate / ceil_["corner8_Ggathers_per_s"]
+        out.append(ent)
+    step_us = 1e3 * sum(v[0] for v in t.values()) / steps
+    return out, {"library_kernels_us_per_step": step_us,
+                 "per_kernel_us": {k: round(1e3 * v[0] / steps, 2) for k, v in sorted(t.items(), key=lambda kv: -kv[1][0])}}
+
+
 CONV_LAYERS = (("gru_zr", 320, 256), ("gru_q", 320, 128), ("heads", 128, 384), ("corr_enc2", 128, 128))
 
 
@@ -596,6 +715,18 @@ def main():
             line["roofline_other"].append({"kernel": "gs_norm_act", "error": repr(exc)})
         line["neus_render"] = neus_render_bench(device)
         line["roofline_other"].append(dict(line["neus_render"]["mlp_mfma"], bound="mfma"))
+        if world == 1:
+            for nr in (4096, 32768):        # the kernels that own path M, timed per kernel (eager step + the library's timer)
+                try:
+                    ents, summ = neus_kernel_rooflines(device, nr)
+                    line["roofline_other"] += ents
+                    line.setdefault("neus_step_kernels", {})[str(nr)] = summ
+                except Exception as exc:
+                    line["roofline_other"].append({"kernel": f"path M kernels @ {nr}", "error": repr(exc)})
+            try:
+                line["mono_window"] = mono_window(device)
+            except Exception as exc:
+                line["mono_window"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(2)
             try:        # path M on the host cores (north_star: the render batches "alongside the reference's CPU path")

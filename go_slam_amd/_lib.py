@@ -22,6 +22,10 @@ _P = c_void_p
 SIGNATURES = {
     "gs_version": (ctypes.c_char_p, []),
     "gs_last_error": (ctypes.c_char_p, []),
+    "gs_timing_begin": (c_int, [_P]),
+    "gs_timing_end": (c_int, []),
+    "gs_timing_read": (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
+    "gs_timing_names": (c_int, [ctypes.c_char_p, c_int]),
     "gs_corr_index_forward": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
     "gs_corr_index_backward": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
     "gs_corr_lookup_pyramid": (c_int, [_P] * 6 + [c_int] * 9 + [_P]),
@@ -73,7 +77,7 @@ SIGNATURES = {
     "gs_mlp_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gs_mlp_forward": (c_int, [_P] * 3 + [c_int] * 3 + [_P, c_size_t, _P]),
     "gs_neus_forward_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "gs_neus_forward": (c_int, [_P] * 9 + [c_float] + [_P] * 16 + [c_int, c_int, _P, c_size_t, _P]),
+    "gs_neus_forward": (c_int, [_P] * 9 + [c_float] + [_P] * 17 + [c_int, c_int, _P, c_size_t, _P]),
     "gs_neus_backward_rays": (c_int, [_P] * 13 + [c_int, c_int, _P]),
     "gs_mapping_loss": (c_int, [_P] * 8 + [c_float] * 4 + [c_int] + [_P] * 4 + [c_int, c_int, _P]),
     "gs_map_grad_sqnorm": (c_int, [_P, c_size_t, c_float, _P, c_size_t, _P, _P]),
@@ -135,6 +139,33 @@ def check(rc, what):
     if rc != 0:
         msg = lib().gs_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (status {rc}): {msg}")
+
+
+class kernel_timer:
+    """`with kernel_timer(device) as t: ...; t.read()` -> {launch name: (total ms, launches)} for every kernel the
+    library launched on torch's current stream inside the block (gs_timing_*, include/goslam_hip.h)."""
+
+    def __init__(self, device=None):
+        self.device = device
+
+    def __enter__(self):
+        check(lib().gs_timing_begin(stream_ptr(self.device)), "gs_timing_begin")
+        return self
+
+    def __exit__(self, *exc):
+        lib().gs_timing_end()
+        return False
+
+    def read(self):
+        L = lib()
+        buf = ctypes.create_string_buffer(1 << 16)
+        check(L.gs_timing_names(buf, len(buf)), "gs_timing_names")
+        out = {}
+        for name in [n for n in buf.value.decode().split(",") if n]:
+            ms, cnt = ctypes.c_double(0.0), c_int(0)
+            check(L.gs_timing_read(name.encode(), ctypes.byref(ms), ctypes.byref(cnt)), "gs_timing_read")
+            out[name] = (ms.value, cnt.value)
+        return out
 
 
 def stream_ptr(device=None):

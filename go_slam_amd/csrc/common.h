@@ -21,8 +21,21 @@ void gs_set_error(const char* fmt, ...);
     }                                              \
   } while (0)
 
+// Kernel timer (capi.hip; gs_timing_begin / _end / _read in include/goslam_hip.h): while a thread has it switched on,
+// every GS_CHECK_LAUNCH records a HIP event on the timed stream, so consecutive events bracket each kernel.  Off (the
+// default) it is one thread-local load.
+extern thread_local int gs_timing_on;
+void gs_timing_mark(const char* name);
+
+// placed in front of a launch whose duration must not include whatever the caller enqueued before it
+#define GS_TIMING_PRE()                      \
+  do {                                       \
+    if (gs_timing_on) gs_timing_mark("");    \
+  } while (0)
+
 #define GS_CHECK_LAUNCH(name)                                                   \
   do {                                                                          \
+    if (gs_timing_on) gs_timing_mark(name);                                     \
     hipError_t e_ = hipGetLastError();                                          \
     if (e_ != hipSuccess) {                                                     \
       gs_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));       \

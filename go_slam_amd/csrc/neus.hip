@@ -87,15 +87,20 @@ __global__ __launch_bounds__(256) void render_sample_kernel(
     const float snr = (1.0f - 0.1f) * vd, sfar = (1.0f + 0.1f) * vd;
     return (snr + (sfar - snr) * t) * 0.0f + (0.001f + (gt_max - 0.001f) * t) * (1.0f - 0.0f);
   };
-  // merge the two ascending runs
+  // merge the two monotone runs (= the reference's torch.sort of their concatenation, render.py:168-171).  Both are
+  // ascending except in two degenerate cases, where they are walked backwards: far < near (a ray whose box exit lies
+  // behind the camera: far clamps to 0) and, for rays without depth, a batch maximum below 0.001.
+  const bool rev_a = span < 0.0f, rev_b = !(gd > 0.0f) && gt_max < 0.001f;
+  auto zsa = [&](int j) { return zs(rev_a ? ns - 1 - j : j); };
+  auto zfa = [&](int j) { return zf(rev_b ? nsurf - 1 - j : j); };
   int a = 0, b = 0;
   float prev = 0.f;
   for (int k = 0; k < total; ++k) {
     float z;
-    if (b >= nsurf) z = zs(a++);
-    else if (a >= ns) z = zf(b++);
+    if (b >= nsurf) z = zsa(a++);
+    else if (a >= ns) z = zfa(b++);
     else {
-      const float za = zs(a), zb = zf(b);
+      const float za = zsa(a), zb = zfa(b);
       if (za <= zb) { z = za; ++a; } else { z = zb; ++b; }
     }
     zo[k] = z;
@@ -144,9 +149,12 @@ __global__ __launch_bounds__(256) void render_sample_wave_kernel(
   const int total = ns + nsurf;
   const float span = farv - nearv;
   auto zu = [&](int j) { return nearv + span * t_samples[j]; };
+  // (descending runs -- far < near, or no-depth rays under a batch maximum below 0.001 -- are walked backwards: the
+  // merge below then equals the reference's sort in those degenerate cases too)
+  const bool rev_a = span < 0.0f, rev_b = !(gd > 0.0f) && gt_max < 0.001f;
   float za = INFINITY, zb = INFINITY;
   if (lane < ns) {
-    const int j = lane;
+    const int j = rev_a ? ns - 1 - lane : lane;
     float z = zu(j);
     if (perturb) {
       const float lo = (j == 0) ? z : 0.5f * (zu(j - 1) + z);
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(256) void render_sample_wave_kernel(
     za = z;
   }
   if (lane < nsurf) {
-    const float t = t_surface[lane];
+    const float t = t_surface[rev_b ? nsurf - 1 - lane : lane];
     if (gd > 0.0f) {
       const float snr = (1.0f - 0.1f) * gd, sfar = (1.0f + 0.1f) * gd;
       zb = (snr + (sfar - snr) * t) * 1.0f + (0.001f + (gt_max - 0.001f) * t) * (1.0f - 1.0f);
@@ -269,6 +277,8 @@ struct NeusArgs {
   const _Float16* grid; const float* sdf_w; const float* sdf_b; const float* color_B;
   float inv_s; const float* inv_s_dev;     // inv_s_dev != nullptr: read the scalar from device memory instead
   float bound[6]; float rt_bound[6];
+  const float* rt_bound_dev;               // != nullptr: the realtime bound lives in device memory (replayed graphs see
+                                           // InstantNeuS.update_bound without a re-capture)
   int n, s;
 };
 
@@ -282,8 +292,17 @@ __device__ __forceinline__ bool point_of(const NeusArgs& A, int idx, float pt[3]
     dir[d] = A.rays_d[ray * 3 + d];
     pt[d] = A.rays_o[ray * 3 + d] + dir[d] * zm;
   }
-  return (pt[0] < A.rt_bound[1]) && (pt[0] > A.rt_bound[0]) && (pt[1] < A.rt_bound[3]) && (pt[1] > A.rt_bound[2]) &&
-         (pt[2] < A.rt_bound[5]) && (pt[2] > A.rt_bound[4]);
+  float rb[6];
+  if (A.rt_bound_dev) {   // uniform, unchanged during the launch: constant address space -> s_load
+    typedef const __attribute__((address_space(4))) float* cfp;
+    cfp q = (cfp)(uintptr_t)A.rt_bound_dev;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rb[k] = q[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rb[k] = A.rt_bound[k];
+  }
+  return (pt[0] < rb[1]) && (pt[0] > rb[0]) && (pt[1] < rb[3]) && (pt[1] > rb[2]) && (pt[2] < rb[5]) && (pt[2] > rb[4]);
 }
 
 // "is any point in bound?" -- only the predicate matters (InstantNeuS.py:311), so waves that see
@@ -738,7 +757,7 @@ extern "C" size_t gs_neus_forward_workspace_bytes(int n, int s) {
 extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const float* z_vals, const float* dists,
                                const void* grid, const float* sdf_w, const float* sdf_b, const float* color_B,
                                const void* mlp, float inv_s, const float* inv_s_dev, const float* bound_host,
-                               const float* rt_bound_host,
+                               const float* rt_bound_host, const float* rt_bound_dev,
                                float* color, float* depth, float* depth_var, float* normal, float* weight_sum,
                                float* sdf, float* z_mid, float* grad_err_ray, float* alpha_out, void* rgb_out,
                                float* grad_out, uint8_t* mask_out, void* mlp_in_out, int n, int s, void* workspace,
@@ -762,6 +781,7 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
   A.inv_s = inv_s;
   A.inv_s_dev = inv_s_dev;
   for (int k = 0; k < 6; ++k) { A.bound[k] = bound_host[k]; A.rt_bound[k] = rt_bound_host[k]; }
+  A.rt_bound_dev = rt_bound_dev;
   A.n = n; A.s = s;
   const int np = n * s;
   float* alpha = alpha_out ? alpha_out : ws.alpha;

@@ -515,6 +515,9 @@ __global__ __launch_bounds__(1024) void grid_bin_reduce_kernel(const uint16_t* _
                                                                const uint8_t* __restrict__ q_cnt, int nblk,
                                                                _Float16* __restrict__ tab16, gs_grid_meta m) {
   extern __shared__ unsigned long long acc[];          // [BIN_ENTRIES][2] 64-bit fixed point (two's complement)
+  __shared__ int nonfinite;                            // a NaN / inf record was seen: fix24 saturates, so a second scan
+                                                       // writes those records' own bits (a diverged step stays visible)
+  if (threadIdx.x == 0) nonfinite = 0;
   const int q = blockIdx.x, h = q / BINS_PER_LEVEL, b = q - h * BINS_PER_LEVEL;
   int l = 0;
   for (int k = 0, seen = 0; k < GS_GRID_LEVELS; ++k)
@@ -545,6 +548,7 @@ __global__ __launch_bounds__(1024) void grid_bin_reduce_kernel(const uint16_t* _
           if (s0 + k < c) {
             atomicAdd(&acc[2 * iw[k]], (unsigned long long)fix24(vw[k] & 0xffffu));
             atomicAdd(&acc[2 * iw[k] + 1], (unsigned long long)fix24(vw[k] >> 16));
+            if ((vw[k] & 0x7c00u) == 0x7c00u || (vw[k] & 0x7c000000u) == 0x7c000000u) nonfinite = 1;
           }
         }
       }
@@ -566,6 +570,18 @@ __global__ __launch_bounds__(1024) void grid_bin_reduce_kernel(const uint16_t* _
       nw[k] = pack2h(o0 + a0, o1 + a1);
     }
     reinterpret_cast<uint4*>(out)[e] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
+  }
+  if (nonfinite) {      // rare slow path: entries that received a NaN / inf record become that value, as with atomics
+    __syncthreads();
+    uint16_t* out16 = reinterpret_cast<uint16_t*>(out);
+    for (int sg = tid; sg < nblk; sg += 1024) {
+      const int c = cnt[sg];
+      for (int k = 0; k < c; ++k) {
+        const uint32_t v = qv[(size_t)sg * ST_SLOTS + k], i = qi[(size_t)sg * ST_SLOTS + k];
+        if ((v & 0x7c00u) == 0x7c00u) out16[2 * i] = (uint16_t)(v & 0xffffu);
+        if ((v & 0x7c000000u) == 0x7c000000u) out16[2 * i + 1] = (uint16_t)(v >> 16);
+      }
+    }
   }
 }
 
@@ -662,6 +678,7 @@ static int backward_points_impl(const float* rays_o, const float* rays_d, const 
   A.q_cnt = (uint8_t*)base;                                       // [nq][nblk]
   A.q_val = (uint32_t*)(base + gs_align(nq * nblk));              // [nq][nblk][ST_SLOTS]
   A.q_idx = (uint16_t*)((char*)A.q_val + nq * nblk * ST_SLOTS * 4);
+  GS_TIMING_PRE();
   neus_point_bwd_kernel<true><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(A, m);
   GS_CHECK_LAUNCH("neus_backward_points_binned");
   static GsLdsLimit limit;

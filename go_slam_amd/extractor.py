@@ -17,7 +17,8 @@ import torch.nn.functional as F
 
 DIM = 32
 FAST_ENCODER = True         # module constant, not an environment switch: tests flip it to compare the two paths
-_WS = {}                    # device -> statistics workspace of gs_norm_act
+_WS = {}                    # (device index, stream) -> statistics workspace of gs_norm_act (two encoder calls on
+                            # different streams -- tracking and backend threads -- must not share partial moments)
 
 
 def _norm_act(x, skip, instance, relu_in, relu_out, bias=None):
@@ -28,9 +29,10 @@ def _norm_act(x, skip, instance, relu_in, relu_out, bias=None):
     ws, nbytes = None, 0
     if instance:
         nbytes = int(L.gs_norm_act_workspace_bytes(n, h * w, c))
-        ws = _WS.get(x.device)
+        key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+        ws = _WS.get(key)
         if ws is None or ws.numel() < nbytes:
-            ws = _WS[x.device] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=x.device)
+            ws = _WS[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         rc = L.gs_norm_act(_lib.ptr(x), _lib.ptr(bias), _lib.ptr(skip), _lib.ptr(x), n, h * w, c, int(instance), int(relu_in),
                            int(relu_out), 1e-5, _lib.ptr(ws), ws.numel() if ws is not None else 0,

@@ -274,8 +274,10 @@ class InstantNeuS(nn.Module):
 # fused forward / backward plumbing
 # ------------------------------------------------------------------------------------------
 
-def _neus_forward_raw(model, rays_o, rays_d, z_vals, dists, inv_s, save, inv_s_dev=None):
-    """`inv_s_dev` (optional fp32 device scalar) overrides the host value `inv_s` inside the kernels."""
+def _neus_forward_raw(model, rays_o, rays_d, z_vals, dists, inv_s, save, inv_s_dev=None, rt_bound_dev=None):
+    """`inv_s_dev` (optional fp32 device scalar) overrides the host value `inv_s` inside the kernels; `rt_bound_dev`
+    (optional fp32 [3,2] device tensor, normally `model.realtime_bound` itself) overrides the host copy of the realtime
+    bound -- what a captured launch sequence must use, since `update_bound` rewrites that buffer in place."""
     net = model.sdf_network
     dev = rays_o.device
     n, s = z_vals.shape
@@ -299,7 +301,7 @@ def _neus_forward_raw(model, rays_o, rays_d, z_vals, dists, inv_s, save, inv_s_d
     with torch.cuda.device(dev):
         rc = L.gs_neus_forward(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z_vals), _lib.ptr(dists), _lib.ptr(grid),
                                _lib.ptr(sdf_w), _lib.ptr(sdf_b), _lib.ptr(cB), _lib.ptr(mlp), float(inv_s),
-                               _lib.ptr(inv_s_dev), bh, rh,
+                               _lib.ptr(inv_s_dev), bh, rh, _lib.ptr(rt_bound_dev),
                                _lib.ptr(color), _lib.ptr(depth), _lib.ptr(dvar), _lib.ptr(normal), _lib.ptr(wsum),
                                _lib.ptr(sdf), _lib.ptr(zmid), _lib.ptr(gerr),
                                _lib.ptr(saved.get("alpha")), _lib.ptr(saved.get("rgb")), _lib.ptr(saved.get("grad")),

@@ -242,6 +242,9 @@ class MapTrainer:
 
     # ---- the fused step ------------------------------------------------------------------------------------------
     def _step_buffers(self, n, dev):
+        """persistent per-batch-size scratch of the step.  A captured graph keeps raw pointers into these tensors, so
+        every graph entry holds a reference to the dict it was captured with (`ent["bufs"]`): evicting a size from this
+        cache can then never free memory a replay still reads or writes."""
         b = self._bufs.get(n)
         if b is None:
             f32 = dict(dtype=torch.float32, device=dev)
@@ -253,7 +256,16 @@ class MapTrainer:
             self._bufs[n] = b
         return b
 
-    def _local_gradients(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand, counts):
+    def _rt_bound_dev(self, dev):
+        """the model's `realtime_bound` buffer as the kernels' device-side bound: `InstantNeuS.update_bound` rewrites
+        it in place (src/InstantNeuS.py:255-257), so eager steps and replays of a captured graph both mask with the
+        CURRENT bound (src/InstantNeuS.py:310) -- a host copy passed by value would be frozen at capture time."""
+        rb = self.model.realtime_bound
+        if rb.device != dev or rb.dtype != torch.float32 or not rb.is_contiguous():
+            raise RuntimeError("MapTrainer: model.realtime_bound must be a contiguous fp32 buffer on the rays' device")
+        return rb
+
+    def _local_gradients(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand, counts, bufs=None):
         """THIS RANK's rays: sample + forward + loss kernel + HIP backward, no autograd graph, no collective, no host
         sync.  `counts` = [valid rays, rays, max depth] over ALL ranks (device fp32[3]) or None (single rank: computed
         here).  Leaves the loss-scaled fp16 table gradient in flat.G16, the dense gradients in flat.g32[:nd] and this
@@ -266,7 +278,7 @@ class MapTrainer:
         n = rays_o.shape[0]
         w = self.w
         s = self.renderer.N_samples + self.renderer.N_surface
-        B = self._step_buffers(n, dev)
+        B = bufs if bufs is not None else self._step_buffers(n, dev)
         sf = float(model.variance_network.scale_factor)
         var_dev = model.variance_network.variance
         st = _lib.stream_ptr(dev)
@@ -281,7 +293,8 @@ class MapTrainer:
                                              gt_max_dev=counts[2:3])
         assert z_vals.shape[1] == s
         color, depth, dvar, normal, wsum, sdf, gerr, zmid, saved = _neus_forward_raw(
-            model, rays_o, rays_d, z_vals, dists, 0.0, save=True, inv_s_dev=inv_s_dev)
+            model, rays_o, rays_d, z_vals, dists, 0.0, save=True, inv_s_dev=inv_s_dev,
+            rt_bound_dev=self._rt_bound_dev(dev))
         d_color = torch.empty(n, 3, **f32)
         d_depth = torch.empty(n, 1, **f32)
         d_sdf = torch.empty(n, s, **f32)
@@ -343,17 +356,20 @@ class MapTrainer:
     def _graph_for(self, args, counts, perturb_rand):
         """hipGraph of the step's local part for this batch shape: static input buffers + the captured launch sequence"""
         h = self.flat.hyper
-        key = (tuple(args[0].shape), perturb_rand is None, self.world, h["lr16"], h["lr32"])   # (scalars are baked in)
+        key = (tuple(args[0].shape), perturb_rand is None, self.world, h["lr16"], h["lr32"])   # (host scalars are baked in)
         ent = self._graphs.get(key)
         if ent is not None:
+            self._graphs[key] = self._graphs.pop(key)       # most recently used last
             return ent
-        if len(self._graphs) >= MAX_GRAPHS:
-            return None
+        if len(self._graphs) >= MAX_GRAPHS:                 # evict the least recently used graph (dict order = use order)
+            old = self._graphs.pop(next(iter(self._graphs)))
+            old["graph"] = None
         dev = args[0].device
         static = [torch.empty_like(a) for a in args]
         s_counts = torch.zeros(3, dtype=torch.float32, device=dev) if counts is None else torch.empty_like(counts)
         s_pr = None if perturb_rand is None else torch.empty_like(perturb_rand.detach().float().contiguous())
-        ent = dict(static=static, counts=s_counts, pr=s_pr, graph=None, inv_scale=None, warm=0)
+        ent = dict(static=static, counts=s_counts, pr=s_pr, graph=None, inv_scale=None, warm=0,
+                   bufs=self._step_buffers(args[0].shape[0], dev), rt_bound=self.model.realtime_bound)
         self._graphs[key] = ent
         return ent
 
@@ -369,10 +385,9 @@ class MapTrainer:
         if perturb_rand is None and self.renderer.perturb > 0:      # drawn OUTSIDE the graph: a replay must see new values
             perturb_rand = torch.rand(self.renderer.N_samples, device=args[0].device)
         ent = self._graph_for(args, counts, perturb_rand)
-        if ent is None:                     # more batch shapes than graphs worth keeping: run this one eagerly
-            inv_scale = self._local_gradients(*args, perturb_rand, counts)
-            flat.step(inv_scale, prepped=True)
-            return self._global_loss()
+        if ent["rt_bound"].data_ptr() != self.model.realtime_bound.data_ptr():
+            raise RuntimeError("MapTrainer: model.realtime_bound was re-allocated after a step was captured "
+                               "(model moved / copied); build a new MapTrainer")
         dsts, srcs = list(ent["static"]), list(args)
         if counts is not None:
             dsts.append(ent["counts"])
@@ -384,7 +399,7 @@ class MapTrainer:
         whole = self.world == 1             # single GPU: the optimiser's two launches are part of the graph
 
         def body():
-            inv = self._local_gradients(*ent["static"], ent["pr"], None if whole else ent["counts"])
+            inv = self._local_gradients(*ent["static"], ent["pr"], None if whole else ent["counts"], bufs=ent["bufs"])
             if whole:
                 flat.step(inv, prepped=True)
             return inv

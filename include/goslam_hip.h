@@ -39,6 +39,17 @@ typedef enum { GS_F16 = 0, GS_F32 = 1, GS_F64 = 2 } gs_dtype;
 const char* gs_version(void);
 const char* gs_last_error(void);
 
+/* Kernel timer (measurement mode for bench.py's roofline entries; no counterpart in the reference).  Between
+ * gs_timing_begin(stream) and gs_timing_end() every kernel this THREAD launches through the library is followed by a
+ * HIP event on `stream` (which must be the stream the kernels are launched on); gs_timing_read(name, ...) synchronises
+ * and returns the summed duration [ms] and launch count of the kernels recorded under `name` (the launch names used
+ * in error messages: "neus_point", "grid_bin_reduce", "conv3x3_pp", ...); gs_timing_names writes the comma-separated
+ * names seen.  Nothing is recorded while the stream is being captured into a graph.                                  */
+int gs_timing_begin(gs_stream_t stream);
+int gs_timing_end(void);
+int gs_timing_read(const char* name, double* total_ms, int* count);
+int gs_timing_names(char* buf, int buf_bytes);
+
 /* ------------------------------------------------------------------ correlation ---- */
 
 /* droid_backends.corr_index_forward (src/lib/droid.cpp:149-158, correlation_kernels.cu:19-70,

@@ -80,7 +80,9 @@ int gs_mlp_forward(const void* x, const void* mlp, void* out, int n, int n_in, i
  *   inv_s = clip(exp(10*variance), 1e-6, 1e6) as a host scalar, or -- when inv_s_dev != NULL -- read from that device
  *   scalar instead (a training loop then never reads the variance parameter back to the host);
  *   bound_host / rt_bound_host: HOST f32 [3,2] (static bound for normalisation, realtime bound
- *   for the in-bound mask; 6 floats each, passed by value to the kernels).
+ *   for the in-bound mask; 6 floats each, passed by value to the kernels).  rt_bound_dev (optional, DEVICE f32
+ *   [3,2]): when non-NULL the kernels read the realtime bound from it instead of rt_bound_host, so a captured
+ *   hipGraph of the launch follows InstantNeuS.update_bound (src/InstantNeuS.py:255-257,310) without a re-capture.
  * Outputs f32: color [n,3], depth [n], depth_var [n], normal [n,3], weight_sum [n], sdf [n,s],
  *   z_mid [n,s] (= z_vals + dists/2), grad_err_ray [n] (per-ray sum of (|grad|-1)^2 * mask; the
  *   caller divides the total by n*s); optional per-point alpha f32 [n,s], rgb f16 [n,s,3],
@@ -90,7 +92,7 @@ size_t gs_neus_forward_workspace_bytes(int n, int s);
 int gs_neus_forward(const float* rays_o, const float* rays_d, const float* z_vals,
                     const float* dists, const void* grid, const float* sdf_w, const float* sdf_b,
                     const float* color_B, const void* mlp, float inv_s, const float* inv_s_dev,
-                    const float* bound_host, const float* rt_bound_host,
+                    const float* bound_host, const float* rt_bound_host, const float* rt_bound_dev,
                     float* color, float* depth, float* depth_var, float* normal,
                     float* weight_sum, float* sdf, float* z_mid, float* grad_err_ray,
                     float* alpha_out, void* rgb_out, float* grad_out, uint8_t* mask_out,

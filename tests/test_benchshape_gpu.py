@@ -224,7 +224,7 @@ def _record(name, payload):
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(d, exist_ok=True)
-        path = os.path.join(d, "r03_pathM_parity.json")
+        path = os.path.join(d, "r04_parity.json")
         cur = json.load(open(path)) if os.path.exists(path) else {}
         cur[name] = payload
         json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
@@ -485,3 +485,154 @@ def test_update_operator_fast_path_at_bench_shape_matches_fp32_cpu_evaluation(bu
     assert rep["net"][0] < 3e-3 and rep["net"][1] < 1e-3, rep
     assert rep["delta"][1] < 2e-3 and rep["weight"][1] < 2e-3 and rep["eta"][1] < 2e-3 and rep["upmask"][1] < 2e-3, rep
     _record("update_operator_vs_fp32", {k: {"max_abs": v[0], "rel_l2": v[1]} for k, v in rep.items()})
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[4] (Replica room0 MONOCULAR: replica_mono.yaml:29-35 window 50 / max_factors 100, :54-55 N_samples 48 /
+# N_surface 24) and configs[3] (ScanNet long sequence: >= 200 keyframes in one global BA) at THEIR shapes
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _mono_rays(n, seed):
+    o, d, gt, col, _ = _bench_rays(n, seed)
+    pr = torch.rand(48, generator=torch.Generator().manual_seed(seed + 1))
+    return o, d, gt, col, pr
+
+
+def test_mono_sampling_48_24_bit_exact_and_forward_at_4096_rays(N, NO, dev):
+    """the monocular split of the 72 samples -- 48 stratified + 24 near-surface (replica_mono.yaml:54-55;
+    src/render.py:99-171) -- through render_sample_wave_kernel: z-values bit-exact vs the oracle, incl. the rays without
+    depth (which take N_samples + N_surface stratified samples), then InstantNeuS.forward on the batch."""
+    P = NO.make_params(171, grid_init=0.3)
+    P["rt_bound"] = torch.tensor([[-4.2, 4.6], [-4.4, 4.1], [-3.9, 4.4]])
+    o, d, gt, _, pr = _mono_rays(4096, seed=172)
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load_neus(model, P)
+    model.update_bound(P["rt_bound"])
+    R = N.Renderer(N_samples=48, N_surface=24)
+    R0 = N.Renderer(N_samples=48, N_surface=24, perturb=0.0)      # (perturb > 0 draws its own vector when given None)
+    for perturb in (None, pr):
+        zr, dr = NO.render_sample(o, d, gt, P["bound"], 48, 24, perturb)
+        assert zr.shape == (4096, 72)
+        with torch.no_grad():
+            z, dd = (R0 if perturb is None else R).sample(o.to(dev), d.to(dev), P["bound"].to(dev), gt.to(dev),
+                                                           None if perturb is None else perturb.to(dev))
+        assert torch.equal(z.cpu(), zr), "48 + 24 sample placement must be bit-exact"
+        torch.testing.assert_close(dd.cpu()[:, :-1], dr[:, :-1], rtol=0, atol=0)
+        torch.testing.assert_close(dd.cpu()[:, -1], dr[:, -1], rtol=1e-6, atol=0)     # backend-defined mean: 1-2 ulp
+    # monocular mapping also renders rays WITHOUT any depth (gt = 0 everywhere falls back to pure stratified sampling)
+    z0r, d0r = NO.render_sample(o, d, torch.zeros_like(gt), P["bound"], 48, 24, pr)
+    with torch.no_grad():
+        z0, _ = R.sample(o.to(dev), d.to(dev), P["bound"].to(dev), torch.zeros_like(gt).to(dev), pr.to(dev))
+    assert torch.equal(z0.cpu(), z0r)
+    # ... and rays whose box exit lies BEHIND the camera (origin outside the bound, looking away): far clamps to 0 <
+    # near, the stratified run is descending and only the reference's sort (:168-171) puts it in order
+    o2, d2 = o.clone(), d.clone()
+    o2[:64, 0] = 6.0
+    d2[:64, 0] = d2[:64, 0].abs() + 0.1
+    d2 = torch.nn.functional.normalize(d2, dim=1)
+    z2r, d2r = NO.render_sample(o2, d2, gt, P["bound"], 48, 24, pr)
+    with torch.no_grad():
+        z2, dd2 = R.sample(o2.to(dev), d2.to(dev), P["bound"].to(dev), gt.to(dev), pr.to(dev))
+    assert bool((z2r[:64, 1:] >= z2r[:64, :-1]).all()) and torch.equal(z2.cpu(), z2r)
+    torch.testing.assert_close(dd2.cpu()[:, :-1], d2r[:, :-1], rtol=0, atol=0)
+    ref = NO.neus_forward(o, d, zr, dr, P)
+    with torch.no_grad():
+        out = model(o.to(dev), d.to(dev), z, dd)
+    c = {k: v.cpu() for k, v in out.items()}
+    assert torch.equal(c["sdf"] == 100.0, ref["sdf"] == 100.0)
+    torch.testing.assert_close(c["sdf"], ref["sdf"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(c["depth"], ref["depth"], rtol=0, atol=2e-3)
+    torch.testing.assert_close(c["color"], ref["color"], rtol=0, atol=4e-3)
+    torch.testing.assert_close(c["normal"], ref["normal"], rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(c["weight_sum"], ref["weight_sum"], rtol=0, atol=5e-4)
+    _record("mono_forward_4096_48+24", {"max_abs": {k: float((c[k] - ref[k]).abs().max())
+                                                     for k in ("sdf", "color", "depth", "normal", "weight_sum")}})
+
+
+def test_neus_forward_and_loss_at_32768_rays_match_oracle(N, NO, dev):
+    """configs[4]'s whole 32768-ray batch (2.36 M points), mono sampling, against the CPU ORACLE (round 3 compared the
+    32768-ray step HIP vs HIP only): sdf, in-bound masks, composited outputs, and the mapper loss
+    (src/mapping.py:96-132) evaluated on both."""
+    from oracle import neus_autograd as NA
+    P = NO.make_params(181, grid_init=0.3)
+    P["rt_bound"] = torch.tensor([[-4.2, 4.6], [-4.4, 4.1], [-3.9, 4.4]])
+    o, d, gt, col, pr = _mono_rays(32768, seed=182)
+    zr, dr = NO.render_sample(o, d, gt, P["bound"], 48, 24, pr)
+    with torch.no_grad():
+        ref = NO.neus_forward(o, d, zr, dr, P)
+        ref_loss = NA.mapping_loss(ref, col, gt)
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load_neus(model, P)
+    model.update_bound(P["rt_bound"])
+    R = N.Renderer(N_samples=48, N_surface=24)
+    with torch.no_grad():
+        z, dd = R.sample(o.to(dev), d.to(dev), P["bound"].to(dev), gt.to(dev), pr.to(dev))
+        assert torch.equal(z.cpu(), zr)
+        out = model(o.to(dev), d.to(dev), z, dd)
+        loss = NA.mapping_loss(dict(out), col.to(dev), gt.to(dev))
+    c = {k: v.cpu() for k, v in out.items()}
+    assert torch.equal(c["sdf"] == 100.0, ref["sdf"] == 100.0), "in-bound masks must agree exactly"
+    torch.testing.assert_close(c["sdf"], ref["sdf"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(c["depth"], ref["depth"], rtol=0, atol=2e-3)
+    torch.testing.assert_close(c["color"], ref["color"], rtol=0, atol=4e-3)
+    torch.testing.assert_close(c["gradient_error"], ref["gradient_error"], rtol=2e-3, atol=1e-5)
+    torch.testing.assert_close(loss.cpu(), ref_loss, rtol=1e-3, atol=1e-5)
+    _record("mono_forward_32768", {"loss": float(loss), "ref_loss": float(ref_loss),
+                                   "max_abs": {k: float((c[k] - ref[k]).abs().max()) for k in ("sdf", "color", "depth")}})
+
+
+def _ba_vs_oracle(db, O, dev, prob, lm, ep, motion_only=False, iters=2):
+    K = prob["intrinsics"][0].contiguous()
+    po, do = prob["poses"].clone(), prob["disps"].clone()
+    ref = O.ba(po, do, K, prob["disps_sens"], prob["target"], prob["weight"], prob["eta"], prob["ii"], prob["jj"],
+               prob["t0"], prob["t1"], iters, lm, ep, motion_only)
+    pg, dg = prob["poses"].clone().to(dev), prob["disps"].clone().to(dev)
+    out = db.ba(pg, dg, K.to(dev), prob["disps_sens"].to(dev), prob["target"].to(dev), prob["weight"].to(dev),
+                prob["eta"].to(dev), prob["ii"].to(dev), prob["jj"].to(dev), prob["t0"], prob["t1"], iters, lm, ep,
+                motion_only)
+    torch.cuda.synchronize()
+    return ref, (po, do), out, (pg.cpu(), dg.cpu())
+
+
+def _err(a, b):
+    return {"max_abs_err": float((a - b).abs().max()), "max_abs": float(b.abs().max()), "rel_l2": _rel(a, b)}
+
+
+@pytest.mark.parametrize("shape", ["Rep", "S480"])
+def test_ba_mono_window_50_keyframes_100_edges_matches_oracle(db, O, dev, shape):
+    """The MONOCULAR frontend window (replica_mono.yaml:29,32: window 50, max_factors 100): 6P = 294 unknowns -- past
+    the 192 the LDS-resident Cholesky of the RGB-D window holds --, no depth prior (disps_sens = 0), at the Replica map
+    size (and the bench's 60x80), SURVEY's rtol 1e-4 / atol 1e-6 on dx."""
+    prob = _ba_problem(O, 50, 100, shape, seed=191, rgbd=False)
+    assert not bool(prob["disps_sens"].any())
+    ref, (po, do), out, (pg, dg) = _ba_vs_oracle(db, O, dev, prob, 1e-4, 0.1)
+    assert tuple(out[0].shape) == (49, 6) and float(ref[0].abs().max()) > 1e-4
+    _record(f"ba_mono_window_P50_E100_{shape}", {"dx": _err(out[0].cpu(), ref[0]), "dz": _err(out[1].cpu(), ref[1])})
+    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(pg, po, rtol=0, atol=2e-6)
+    torch.testing.assert_close(out[1].cpu(), ref[1], rtol=1e-4, atol=4e-6)
+    torch.testing.assert_close(dg, do, rtol=0, atol=4e-6)
+
+
+def test_ba_mono_window_cholesky_failure_gives_zero_update(db, O, dev):
+    """6P = 294: an indefinite reduced system (negative damping) must leave dx = 0 -- the reference's fallback when
+    Eigen's LLT fails (src/lib/droid_kernels.cu:1192-1213) -- on the solver the mono window takes, too."""
+    prob = _ba_problem(O, 50, 100, "Scan", seed=192, rgbd=False)
+    ref, (po, do), out, (pg, dg) = _ba_vs_oracle(db, O, dev, prob, -2.0, -1.0, iters=1)
+    assert not bool(ref[0].any()), "oracle: the factorisation should have failed"
+    assert not bool(out[0].cpu().any())
+    torch.testing.assert_close(pg, prob["poses"], rtol=0, atol=0)
+
+
+def test_ba_global_200_keyframes_1200_edges_at_scan_shape_matches_oracle(db, O, dev):
+    """BASELINE configs[3]'s stress shape AT its shape (P = 200, E = 1200, 30x40 maps; src/backend.py:96-123,
+    src/factor_graph.py:255-321): 6P = 1194 unknowns through the blocked Cholesky, 1200-edge CSR rows, Schur pair
+    lists -- dx at SURVEY's rtol 1e-4 / atol 1e-6 (the 'tiny'-map version in test_track_gpu.py runs at 5e-3)."""
+    prob = _ba_problem(O, 200, 1200, "Scan", seed=193, rgbd=True)
+    ref, (po, do), out, (pg, dg) = _ba_vs_oracle(db, O, dev, prob, 1e-5, 1e-2)
+    assert tuple(out[0].shape) == (199, 6) and float(ref[0].abs().max()) > 1e-4
+    _record("ba_global_P200_E1200_Scan", {"dx": _err(out[0].cpu(), ref[0]), "dz": _err(out[1].cpu(), ref[1])})
+    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(pg, po, rtol=0, atol=2e-6)
+    torch.testing.assert_close(out[1].cpu(), ref[1], rtol=1e-4, atol=4e-6)
+    torch.testing.assert_close(dg, do, rtol=0, atol=4e-6)

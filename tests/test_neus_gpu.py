@@ -603,3 +603,104 @@ def test_binned_table_gradient_staging_overflow_falls_back_to_atomics(N, O, dev)
     a = _grid_grads(N, O, dev, P, (o2, d2, z2, dist2), True, torch.float16)
     b = _grid_grads(N, O, dev, P, (o2, d2, z2, dist2), False, torch.float32)
     assert _rel(a, b) < 2e-3
+
+
+def test_graph_replay_follows_update_bound_and_survives_buffer_eviction(N, O, dev):
+    """Two defects a captured step must not have (round-3 advisor findings).  (1) `InstantNeuS.update_bound` between
+    replays: the realtime bound is read from the model's device buffer, so the replay masks with the CURRENT bound
+    (src/InstantNeuS.py:310) exactly as the eager step does -- a bound passed by value would be frozen at capture time
+    and the two trainers would part ways after the change.  (2) The per-batch-size step buffers a graph points into are
+    owned by the graph entry: running more distinct batch sizes than the buffer cache holds must not free them."""
+    from go_slam_amd.neus import mapper as M
+    P = O.make_params(101, grid_init=0.05, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    trainers = []
+    for graph in (False, True):
+        model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+        _load(model, P)
+        trainers.append((model, M.MapTrainer(model, N.Renderer(N_samples=24, N_surface=48), graph=graph)))
+    (m_e, t_e), (m_g, t_g) = trainers
+    g = torch.Generator().manual_seed(102)
+    small = torch.tensor([[-0.6, 0.7], [-0.8, 0.5], [-0.4, 0.9]])
+    big = torch.tensor([[-2.5, 2.5], [-2.5, 2.5], [-2.5, 2.5]])
+    for m in (m_e, m_g):
+        m.update_bound(small)
+
+    def both(it, n=640):
+        o, d, gt = _rays(n, seed=200 + it)
+        args = [t.to(dev) for t in (o, d, torch.rand(n, 3, generator=g), gt, torch.rand(24, generator=g))]
+        l_e, l_g = t_e.step(*args), t_g.step(*args)
+        torch.testing.assert_close(l_g.float().cpu(), l_e.float().cpu(), rtol=3e-4, atol=1e-5,
+                                   msg=lambda s: f"iteration {it}: {s}")
+        return float(l_e)
+    for it in range(4):                         # two eager warm-ups, capture, replay -- all under the small bound
+        both(it)
+    ent = next(iter(t_g._graphs.values()))
+    assert ent["graph"] is not None
+    l_small = both(4)
+    for m in (m_e, m_g):
+        m.update_bound(big)                     # the scene grew (multiview_filter -> Mapper.__call__ -> update_bound)
+    l_big = both(5)                             # a REPLAY of the graph captured under the small bound
+    assert abs(l_big - l_small) > 1e-3 * abs(l_small), "the bound change did not alter the loss: test is vacuous"
+    both(6)
+    # (2) more batch sizes than the buffer cache keeps; then the first graph again
+    owned = ent["bufs"]["counts"].data_ptr()
+    o, d, gt = _rays(64, seed=400)
+    for k in range(2 * M.MAX_GRAPHS + 2):
+        n = 32 + k
+        t_g._step_buffers(n, dev)
+    assert 640 not in t_g._bufs                 # evicted from the cache ...
+    assert ent["bufs"]["counts"].data_ptr() == owned        # ... but alive in the entry
+    junk = [torch.full((3,), float("nan"), device=dev) for _ in range(64)]   # would land in freed 12-byte blocks
+    both(7)
+    both(8)
+    del junk
+
+
+def test_graph_cache_evicts_least_recently_used(N, O, dev):
+    """more (shape, learning-rate) combinations than MAX_GRAPHS: the least recently used graph is dropped and the new
+    combination is captured -- the step never degrades to the eager ~65-launch path for good."""
+    from go_slam_amd.neus import mapper as M
+    P = O.make_params(111, grid_init=0.05, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    tr = M.MapTrainer(model, N.Renderer(N_samples=24, N_surface=48))
+    o, d, gt = _rays(128, seed=112)
+    args = [t.to(dev) for t in (o, d, torch.rand(128, 3), gt)]
+    for k in range(M.MAX_GRAPHS + 2):
+        tr.optimizer.set_lr(grid_lr=1e-2 * (1 + k))
+        for _ in range(3):
+            loss = tr.step(*args)
+        assert torch.isfinite(loss)
+    assert len(tr._graphs) == M.MAX_GRAPHS
+    keys = list(tr._graphs)
+    assert keys[-1][3] == 1e-2 * (M.MAX_GRAPHS + 2) and all(k[3] != 1e-2 for k in keys)     # the oldest lr is gone
+    assert tr._graphs[keys[-1]]["graph"] is not None
+
+
+def test_binned_table_gradient_keeps_non_finite_records_visible(N, O, dev):
+    """A diverged step must stay visible: with a NaN upstream gradient on ONE ray, the table entries that ray touches are
+    non-finite in the binned mode exactly as with tiny-cuda-nn's packed atomics (the bin reduce's fixed-point sums
+    saturate NaN / inf records, so it re-scans a bin that saw one and writes those records' own bits), and every other
+    entry is the ordinary finite sum."""
+    P = O.make_params(121, grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    o, d, gt = _rays(300, seed=122)
+    z, dist = O.render_sample(o, d, gt, P["bound"], 24, 48, None)
+    res = {}
+    for binned in (True, False):
+        model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+        _load(model, P)
+        model.grid_grad_dtype, model.grid_grad_binned = torch.float16, binned
+        out = model(o.to(dev), d.to(dev), z.to(dev), dist.to(dev))
+        poison = torch.zeros(300, 3, device=dev)
+        poison[7] = float("nan")
+        loss = (out["color"].sum() + 0.3 * out["depth"].sum()) / 300 + (out["color"] * poison)[7].sum()
+        loss.backward()
+        res[binned] = model.sdf_network.encoding.encoding.params.grad.detach().float().cpu()
+    gm = O.grid_meta()
+    bad_b, bad_a = ~torch.isfinite(res[True]), ~torch.isfinite(res[False])
+    lo = 2 * int(gm["offset"][5])                  # first hashed level
+    assert int(gm["hashed"][5]) and not int(gm["hashed"][4])
+    assert int(bad_a[lo:].sum()) > 100, "the poisoned ray left no trace in the atomics mode: test is vacuous"
+    assert torch.equal(bad_b, bad_a), (int(bad_b.sum()), int(bad_a.sum()))
+    ok = ~bad_a
+    assert _rel(res[True][ok], res[False][ok]) < 5e-3
