@@ -538,8 +538,35 @@ __global__ __launch_bounds__(SMALL_NT) void chol_small_kernel(const double* __re
 //   * TAIL: the remaining <= 192 columns are loaded as a packed triangle and handled by lds_factor / lds_backward;
 //   * backward substitution of the head columns: y -= L21^T x_tail from global memory, then stage by stage in reverse.
 // Same arithmetic as the blocked path: fp64 throughout, pivot <= 0 anywhere => dx = 0 (droid_kernels.cu:1202-1210).
+#ifndef CHOL_TB
+#define CHOL_TB 2                  // tiles per wave in flight in the head stages' global trailing update
+#endif
 constexpr int MID_N = 450;      // beyond this the multi-kernel path (whole chip on the trailing updates) wins (tools/chol_bench.hip)
 constexpr int MID_SW60_N = 300; // up to here a 60-column stage fits: (n + 1) x 61 doubles + vectors <= 160 KB
+
+// 16x16 tile of A B^T over KS k-steps of 4 on the fp64 matrix cores; the operands of five k-steps are requested from LDS
+// before their products are issued (a rolled loop pays an LDS round trip + a dependent MFMA per k-step)
+template <int KS>
+__device__ __forceinline__ __attribute__((ext_vector_type(4))) double mid_tile_product(const double* pa, const double* pb,
+                                                                                      int ln, int SW) {
+  typedef double double4v __attribute__((ext_vector_type(4)));
+  double4v acc = {0.0, 0.0, 0.0, 0.0};
+  constexpr int G = 5;
+#pragma unroll
+  for (int g0 = 0; g0 < KS; g0 += G) {
+    double a[G], b[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int k = 4 * (g0 + u) + (ln >> 4);
+      a[u] = (g0 + u < KS && k < SW) ? pa[k] : 0.0;
+      b[u] = (g0 + u < KS && k < SW) ? pb[k] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+      if (g0 + u < KS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+  }
+  return acc;
+}
 
 __global__ __launch_bounds__(SMALL_NT) void chol_mid_kernel(double* __restrict__ H, double* __restrict__ bg, int n,
                                                        double lm, double ep, int SW, float* __restrict__ dx,
@@ -561,17 +588,32 @@ __global__ __launch_bounds__(SMALL_NT) void chol_mid_kernel(double* __restrict__
   }
   __syncthreads();
   int c0 = 0;
+  CHOL_STAMP(20);
   for (; n - c0 > SMALL_N; c0 += SW) {
     const int R = n + 1 - c0;                         // rows of the tall panel (b^T last)
+    const int stg_ = (c0 / SW) < 4 ? 21 + 4 * (c0 / SW) : 56;
+    (void)stg_;
     // ---- load: row r (global row c0 + r), columns c0 .. c0 + min(SW - 1, r)
-    for (int idx = tid; idx < R * SW; idx += SMALL_NT) {
-      const int r = idx / SW, k = idx - r * SW;
-      double v = 0.0;
-      if (r == R - 1) v = bg[c0 + k];
-      else if (k <= r) v = H[(size_t)(c0 + r) * n + (c0 + k)];
-      T[r * SWP + k] = v;
+    for (int base = 0; base < R * SW; base += 4 * SMALL_NT) {     // 4 independent loads in flight per thread
+      double v[4];
+      int at[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + u * SMALL_NT + tid;
+        const int r = idx / SW, k = idx - r * SW;
+        v[u] = 0.0;
+        at[u] = idx < R * SW ? r * SWP + k : -1;
+        if (idx < R * SW) {
+          if (r == R - 1) v[u] = bg[c0 + k];
+          else if (k <= r) v[u] = H[(size_t)(c0 + r) * n + (c0 + k)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (at[u] >= 0) T[at[u]] = v[u];
     }
     __syncthreads();
+    CHOL_STAMP(stg_ + 0);
     // ---- factor the SW columns (local indices: column k, row r of T)
     for (int p0 = 0; p0 < SW; p0 += PW) {
       const int pend = p0 + PW;
@@ -673,48 +715,54 @@ __global__ __launch_bounds__(SMALL_NT) void chol_mid_kernel(double* __restrict__
         __syncthreads();
       }
     }
+    CHOL_STAMP(stg_ + 1);
     // ---- rank-SW update of the trailing matrix in global memory: rows / columns [c1, n], the b row included
-    const int c1 = c0 + SW;
     {
-      const int R1 = n + 1 - c1;
+      const int R1 = n + 1 - (c0 + SW);
       const int TT1 = (R1 + 15) >> 4, ntile = (TT1 * (TT1 + 1)) >> 1;
-      const int ksteps = (SW + 3) >> 2;
-      for (int t = wv; t < ntile; t += SMALL_NT / 64) {
-        int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        while (((ti + 1) * (ti + 2)) >> 1 <= t) ++ti;
-        while ((ti * (ti + 1)) >> 1 > t) --ti;
-        const int tj = t - ((ti * (ti + 1)) >> 1);
-        const int r0 = SW + 16 * ti, q0 = SW + 16 * tj;     // local rows of T
-        const double* pa = T + min(r0 + (ln & 15), R - 1) * SWP;
-        const double* pb = T + min(q0 + (ln & 15), R - 1) * SWP;
-        // the tile's current values: requested before the products so that the global loads overlap the MFMAs
-        const int cl = q0 + (ln & 15);                // local column index (= local row index of the other operand)
-        double cur[4];
-        bool ok[4];
+      constexpr int TB = CHOL_TB;                         // tiles in flight per wave: their 16 global loads per lane are
+      for (int tb = wv * TB; tb < ntile; tb += (SMALL_NT / 64) * TB) {   // issued before the first product
+        double cur[TB][4];
+        bool ok[TB][4];
+        int r0s[TB], q0s[TB];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int rl = r0 + (ln >> 4) + 4 * q;
-          ok[q] = rl < R && cl < R - 1 && cl <= rl;   // column n does not exist; lower triangle only
-          cur[q] = 0.0;
-          if (ok[q]) cur[q] = (rl == R - 1) ? bg[c0 + cl] : H[(size_t)(c0 + rl) * n + (c0 + cl)];
-        }
-        double4v acc = {0.0, 0.0, 0.0, 0.0};
-        for (int kb = 0; kb < ksteps; ++kb) {
-          const int k = 4 * kb + (ln >> 4);
-          const double a = k < SW ? pa[k] : 0.0, b = k < SW ? pb[k] : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        for (int u = 0; u < TB; ++u) {
+          const int t = min(tb + u, ntile - 1);
+          int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+          while (((ti + 1) * (ti + 2)) >> 1 <= t) ++ti;
+          while ((ti * (ti + 1)) >> 1 > t) --ti;
+          const int tj = t - ((ti * (ti + 1)) >> 1);
+          r0s[u] = SW + 16 * ti;                      // local rows of T
+          q0s[u] = SW + 16 * tj;
+          const int cl = q0s[u] + (ln & 15);          // local column index (= local row index of the other operand)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int rl = r0s[u] + (ln >> 4) + 4 * q;
+            ok[u][q] = (tb + u < ntile) && rl < R && cl < R - 1 && cl <= rl;   // column n does not exist; lower triangle
+            cur[u][q] = 0.0;
+            if (ok[u][q]) cur[u][q] = (rl == R - 1) ? bg[c0 + cl] : H[(size_t)(c0 + rl) * n + (c0 + cl)];
+          }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int rl = r0 + (ln >> 4) + 4 * q;
-          if (ok[q]) {
-            const double v = cur[q] - acc[q];
-            if (rl == R - 1) bg[c0 + cl] = v;
-            else H[(size_t)(c0 + rl) * n + (c0 + cl)] = v;
+        for (int u = 0; u < TB; ++u) {
+          if (tb + u >= ntile) break;
+          const double* pa = T + min(r0s[u] + (ln & 15), R - 1) * SWP;
+          const double* pb = T + min(q0s[u] + (ln & 15), R - 1) * SWP;
+          const double4v acc = SW == 60 ? mid_tile_product<15>(pa, pb, ln, SW) : mid_tile_product<8>(pa, pb, ln, SW);
+          const int cl = q0s[u] + (ln & 15);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int rl = r0s[u] + (ln >> 4) + 4 * q;
+            if (ok[u][q]) {
+              const double v = cur[u][q] - acc[q];
+              if (rl == R - 1) bg[c0 + cl] = v;
+              else H[(size_t)(c0 + rl) * n + (c0 + cl)] = v;
+            }
           }
         }
       }
     }
+    CHOL_STAMP(stg_ + 2);
     // ---- the stage's columns of L back to H (backward substitution reads them), y of these columns to LDS
     for (int idx = tid; idx < (R - 1) * SW; idx += SMALL_NT) {
       const int r = idx / SW, k = idx - r * SW;
@@ -723,13 +771,16 @@ __global__ __launch_bounds__(SMALL_NT) void chol_mid_kernel(double* __restrict__
     for (int k = tid; k < SW; k += SMALL_NT) yv[c0 + k] = T[(R - 1) * SWP + k];
     __threadfence_block();
     __syncthreads();                                  // global writes of this workgroup are visible to its next loads
+    CHOL_STAMP(stg_ + 3);
   }
   // ---- tail: the remaining m <= 192 columns, LDS-resident (already damped)
   const int m = n - c0;
   double* Lp = T;
   lds_load_packed(Lp, H, bg, n, c0, 0.0, 0.0);
   __syncthreads();
+  CHOL_STAMP(40);
   lds_factor(Lp, invd + c0, m, bad);
+  CHOL_STAMP(41);
   if (tid == 0) s_bad = 0;
   __syncthreads();
   if (bad) s_bad = 1;                                 // every diagonal block was factored by (at least) wave 0
@@ -741,6 +792,7 @@ __global__ __launch_bounds__(SMALL_NT) void chol_mid_kernel(double* __restrict__
   }
   if (tid == 0) *fail_flag = 0;
   lds_backward(Lp, invd + c0, m, dx + c0);
+  CHOL_STAMP(42);
   {                                                   // x of the tail -> yv[c0 .. n)
     const double* xt = Lp + ((m * (m + 1)) >> 1);
     for (int i = tid; i < m; i += SMALL_NT) yv[c0 + i] = xt[i];
@@ -765,6 +817,7 @@ __global__ __launch_bounds__(SMALL_NT) void chol_mid_kernel(double* __restrict__
     }
     __syncthreads();
   }
+  CHOL_STAMP(43);
   // ---- the head stages in reverse: solve the stage's SW x SW triangle (from global into T), then propagate to the left
   for (int a = c0 - SW; a >= 0; a -= SW) {
     for (int idx = tid; idx < SW * SW; idx += SMALL_NT) {
@@ -774,7 +827,7 @@ __global__ __launch_bounds__(SMALL_NT) void chol_mid_kernel(double* __restrict__
     __syncthreads();
     for (int k0 = SW - CB; k0 >= 0; k0 -= CB) {
       double x[CB];
-      {
+      if (tid < ((max(k0, CB) + 63) & ~63)) {         // (only the waves that update a y[c], c < k0, or write x)
         double l[CB][CB];
 #pragma unroll
         for (int i = 0; i < CB; ++i)
@@ -821,6 +874,7 @@ __global__ __launch_bounds__(SMALL_NT) void chol_mid_kernel(double* __restrict__
       __syncthreads();
     }
   }
+  CHOL_STAMP(44);
 }
 
 }  // namespace

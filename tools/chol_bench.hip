@@ -75,6 +75,24 @@ int main(int argc, char** argv) {
       printf("        chol_small phases: load %.1f  factor %.1f  backward %.1f  total %.1f us; thread 0: diag %.1f rows %.1f panelupd %.1f barrier %.1f far %.1f\n",
              usf(0, 1), usf(1, 2), usf(2, 3), usf(0, 3), t[10] / 100.0, t[11] / 100.0, t[12] / 100.0, t[13] / 100.0, t[14] / 100.0);
     }
+    if (n > 192 && n <= 312) {
+      g_chol_force_blocked = 0;
+      hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+      hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice);
+      gs_chol_solve_launch(dA, db, n, 1e-4f, 0.1f, dx, flags, flags + 1, 0);
+      hipDeviceSynchronize();
+      long long t[64];
+      hipMemcpyFromSymbol(t, HIP_SYMBOL(g_chol_t), sizeof(t));
+      auto usf = [&](int a, int c) { return (t[c] - t[a]) / 100.0; };
+      printf("        chol_mid phases: damp %.1f |", usf(0, 20) < 0 ? 0.0 : 0.0);
+      int prev = 20;
+      for (int sgi = 0; sgi < 4 && t[21 + 4 * sgi] > t[20]; ++sgi) {
+        const int q = 21 + 4 * sgi;
+        printf(" stage %d: load %.1f factor %.1f global-update %.1f write-back %.1f |", sgi, usf(prev, q), usf(q, q + 1), usf(q + 1, q + 2), usf(q + 2, q + 3));
+        prev = q + 3;
+      }
+      printf(" tail: load %.1f factor %.1f backward %.1f | heads: L21^T x %.1f stages %.1f | total %.1f us\n", usf(prev, 40), usf(40, 41), usf(41, 42), usf(42, 43), usf(43, 44), usf(20, 44));
+    }
     // an indefinite matrix must give dx = 0 and raise the flag on both paths
     std::vector<double> Aneg = A;
     Aneg[(size_t)(n / 2) * n + n / 2] = -1e6;
