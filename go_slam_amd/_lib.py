@@ -77,20 +77,22 @@ SIGNATURES = {
     "gs_mlp_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gs_mlp_forward": (c_int, [_P] * 3 + [c_int] * 3 + [_P, c_size_t, _P]),
     "gs_neus_forward_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "gs_neus_forward": (c_int, [_P] * 9 + [c_float] + [_P] * 17 + [c_int, c_int, _P, c_size_t, _P]),
+    "gs_neus_forward": (c_int, [_P] * 9 + [c_float] + [_P] * 18 + [c_int, c_int, _P, c_size_t, _P]),
     "gs_neus_backward_rays": (c_int, [_P] * 13 + [c_int, c_int, _P]),
     "gs_mapping_loss": (c_int, [_P] * 8 + [c_float] * 4 + [c_int] + [_P] * 4 + [c_int, c_int, _P]),
     "gs_map_grad_sqnorm": (c_int, [_P, c_size_t, c_float, _P, c_size_t, _P, _P]),
     "gs_map_adamw": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, _P, c_size_t] + [c_float] * 6 + [c_int, _P, c_float, _P]),
+    "gs_map_gram_blocks": (c_int, [c_int]),
+    "gs_map_gram": (c_int, [_P, c_int, _P, _P]),
     "gs_map_step_prep": (c_int, [_P, c_int, _P, c_float, c_float, c_int] + [_P] * 10),
     "gs_map_step_post": (c_int, [_P, c_int, c_float, _P, c_int, _P, _P, _P, c_float, _P, _P, c_int, c_float, c_int, _P, _P, _P]),
     "gs_map_adamw_seg": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, _P, _P, _P, _P, _P, c_size_t] + [c_float] * 6
                          + [c_int, _P, _P, c_float, _P]),
     "gs_mlp_backward_blocks": (c_int, [c_int]),
     "gs_mlp_backward": (c_int, [_P, _P, _P, _P, c_float, _P, _P, c_int, _P]),
-    "gs_neus_backward_points": (c_int, [_P] * 7 + [c_float] + [_P] * 9 + [c_int, c_float, _P, _P, c_int, c_float] + [_P] * 5 + [c_int, c_float, c_int, _P, c_int, c_int, _P]),
+    "gs_neus_backward_points": (c_int, [_P] * 7 + [c_float] + [_P] * 9 + [c_int, c_float, _P, _P, c_int, c_float] + [_P] * 5 + [c_int, c_float, c_int, _P, c_int, c_int, _P, _P]),
     "gs_neus_backward_points_binned": (c_int, [_P] * 7 + [c_float] + [_P] * 9 + [c_int, c_float, _P, _P, c_float] + [_P] * 5
-                                       + [c_int, c_float, c_int, _P, c_int, c_int, _P, c_size_t, _P, _P]),
+                                       + [c_int, c_float, c_int, _P, c_int, c_int, _P, c_size_t, _P, _P, _P]),
     "gs_neus_bin_workspace_bytes": (c_size_t, [c_int]),
 }
 

@@ -349,6 +349,136 @@ __global__ __launch_bounds__(256) void map_step_post_kernel(PostArgs A) {
 
 }  // namespace
 
+// ---- dense-parameter gradients: the per-point rows' partial Gram products on the matrix cores ---------------------------
+// The backward's per-point rows [np, 160] fp16 ([d_out 32 | x y z 1 .. 8 | lin_in 40 | dw0 40 | d_arg 40], loss-scaled)
+// carry every dense-parameter gradient as rows[:, :40]^T rows.  Until round 4 this product was the one library kernel of
+// the fused mapper step (a batched hipBLASLt GEMM over 2048 / 8192-row chunks, 45 us at 4096 rays, 227 us at 32768).
+// Here: the contraction runs over POINTS, so an MFMA operand (8 consecutive k per lane) is a COLUMN of the row-major
+// rows -- each wave streams 16 rows at a time (5 coalesced 16-byte loads per lane, requested one group ahead) through a
+// private LDS tile and gathers its five 32-column fragments F0..F4 from it with 2-byte reads (row stride 336 B: the two
+// half-waves, 8 rows apart, fall into different banks).  Only the six 32x32 products the gradients need are formed:
+// F0^T F1, F0^T F2 (d_out^T lin_in) and F1^T F0, F1^T F2, F1^T F3, F1^T F4 (the [x y z 1] rows: column sums and
+// pts^T d_arg).  The four waves' accumulators are added in LDS in a fixed order; one partial [40][160] per workgroup
+// goes to gs_map_step_post, which sums the partials as it summed the GEMM's chunks.  Memory-bound: 320 B per point read once.
+namespace {
+constexpr int GRAM_TS = 168;                      // LDS tile row stride in halves (336 B: 16-byte aligned, 84 dwords)
+typedef _Float16 gram_h8 __attribute__((ext_vector_type(8)));
+typedef float gram_f16v __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(512) void map_gram_kernel(const _Float16* __restrict__ rows, int ngroups,
+                                                       float* __restrict__ partial) {
+  constexpr int NW = 8;                            // waves per workgroup: two per SIMD, so one wave's LDS gather overlaps the other's MFMAs
+  __shared__ __attribute__((aligned(16))) _Float16 tile[NW][16 * GRAM_TS];
+  __shared__ float red[6][1024];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // groups of 16 rows: this workgroup's contiguous share, dealt to its four waves round-robin
+  const int per = (ngroups + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int g_lo = (int)blockIdx.x * per, g_hi = min(ngroups, g_lo + per);
+  gram_f16v acc[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+  _Float16* tl = tile[wv];
+  // piece p of a group (320 pieces of 16 B): row p / 20, 16-byte part p % 20
+  int prow[5], ppart[5];
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int p = lane + 64 * u;
+    prow[u] = p / 20;
+    ppart[u] = p - prow[u] * 20;
+  }
+  const int r = lane & 31, kh = lane >> 5;
+  struct Group { uint4 p0, p1, p2, p3, p4; };      // (by value: five named registers sets, never an indexed array)
+  const int o0 = prow[0] * 20 + ppart[0], o1 = prow[1] * 20 + ppart[1], o2 = prow[2] * 20 + ppart[2],
+            o3 = prow[3] * 20 + ppart[3], o4 = prow[4] * 20 + ppart[4];
+  const int l0 = prow[0] * GRAM_TS + ppart[0] * 8, l1 = prow[1] * GRAM_TS + ppart[1] * 8,
+            l2 = prow[2] * GRAM_TS + ppart[2] * 8, l3 = prow[3] * GRAM_TS + ppart[3] * 8,
+            l4 = prow[4] * GRAM_TS + ppart[4] * 8;
+  auto fetch = [&](int g) -> Group {
+    const uint4* src = reinterpret_cast<const uint4*>(rows + (size_t)g * 16 * 160);
+    Group v;
+    v.p0 = src[o0]; v.p1 = src[o1]; v.p2 = src[o2]; v.p3 = src[o3]; v.p4 = src[o4];
+    return v;
+  };
+  auto consume = [&](const Group v) {               // one 16-row group: registers -> LDS tile -> fragments -> 6 MFMAs
+    *reinterpret_cast<uint4*>(tl + l0) = v.p0;
+    *reinterpret_cast<uint4*>(tl + l1) = v.p1;
+    *reinterpret_cast<uint4*>(tl + l2) = v.p2;
+    *reinterpret_cast<uint4*>(tl + l3) = v.p3;
+    *reinterpret_cast<uint4*>(tl + l4) = v.p4;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    gram_h8 f[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[t][j] = tl[(8 * kh + j) * GRAM_TS + 32 * t + r];
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], f[1], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], f[2], acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], f[0], acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], f[2], acc[3], 0, 0, 0);
+    acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], f[3], acc[4], 0, 0, 0);
+    acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], f[4], acc[5], 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                // every lane has read the tile before the next group overwrites it
+  };
+  int g = g_lo + wv;
+  Group cur = Group();
+  if (g < g_hi) cur = fetch(g);
+#pragma unroll 1
+  for (; g < g_hi; g += NW) {
+    Group nx = cur;
+    if (g + NW < g_hi) nx = fetch(g + NW);          // the next group's rows are in flight during this group's products
+    consume(cur);
+    cur = nx;
+  }
+  // merge the waves (fixed order: deterministic), C layout: reg e -> m = (e & 3) + 8 (e >> 2) + 4 kh, n = r
+  for (int w = 0; w < NW; ++w) {
+    if (wv == w) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = (e & 3) + 8 * (e >> 2) + 4 * kh;
+          float* dst = &red[t][m * 32 + r];
+          *dst = (w == 0 ? 0.0f : *dst) + acc[t][e];
+        }
+    }
+    __syncthreads();
+  }
+  // tile t = (row block tm, column block tn) of the [40][160] partial; rows >= 40 of the second row block are padding
+  float* out = partial + (size_t)blockIdx.x * 40 * 160;
+  for (int idx = tid; idx < 6 * 1024; idx += 512) {
+    const int t = idx >> 10, m = (idx >> 5) & 31, n = idx & 31;
+    const int tm = t < 2 ? 0 : 1;
+    const int tn = t == 0 ? 1 : (t == 1 ? 2 : (t == 2 ? 0 : t - 1));
+    const int gm = 32 * tm + m;
+    if (gm < 40) out[gm * 160 + 32 * tn + n] = red[t][m * 32 + n];
+  }
+}
+}  // namespace
+
+extern "C" int gs_map_gram_blocks(int n_rows) {
+  const int ngroups = n_rows / 16;
+  int nb = ngroups / 64;                          // >= 64 groups (1024 rows) per workgroup
+  if (nb < 1) nb = 1;
+  return nb > 256 ? 256 : nb;
+}
+
+extern "C" int gs_map_gram(const void* rows, int n_rows, float* partial, gs_stream_t stream) {
+  GS_REQUIRE(rows && partial, "map_gram: null pointer");
+  GS_REQUIRE(n_rows > 0 && n_rows % 16 == 0, "map_gram: the row count must be a positive multiple of 16 (pad with zero rows)");
+  GS_REQUIRE(((size_t)rows & 15) == 0, "map_gram: rows must be 16-byte aligned");
+  const int nb = gs_map_gram_blocks(n_rows);
+  GS_TIMING_PRE();
+  map_gram_kernel<<<nb, 512, 0, (hipStream_t)stream>>>((const _Float16*)rows, n_rows / 16, partial);
+  GS_CHECK_LAUNCH("map_gram");
+  return GS_OK;
+}
+
 extern "C" int gs_map_step_prep(const float* rays_depth, int n, const float* variance, float scale_factor, float w_eikonal,
                                 int samples, const float* counts_in, float* counts_out, float* inv_s_out, float* d_gerr_out,
                                 float* d_invs, float* sqnorm, int* step_dev, const float* sdf_w, float* sdf_wt_out,

@@ -317,7 +317,8 @@ __global__ __launch_bounds__(256) void neus_count_kernel(NeusArgs A, int32_t* __
 __global__ __launch_bounds__(256) void neus_point_kernel(NeusArgs A, gs_grid_meta m, const int32_t* __restrict__ count,
                                                          float* __restrict__ sdf_out, float* __restrict__ zmid_out,
                                                          float* __restrict__ alpha_out, float* __restrict__ grad_out,
-                                                         uint8_t* __restrict__ mask_out, _Float16* __restrict__ mlp_in) {
+                                                         uint8_t* __restrict__ mask_out, _Float16* __restrict__ mlp_in,
+                                                         _Float16* __restrict__ enc_aux) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= A.n * A.s) return;
   float pt[3], dir[3], zm, dist;
@@ -362,6 +363,14 @@ __global__ __launch_bounds__(256) void neus_point_kernel(NeusArgs A, gs_grid_met
     float val[2], dv[3][2];
     grid_level(m, l, A.grid, view, val, dv, true);
     const float e0 = (float)(_Float16)val[0], e1 = (float)(_Float16)val[1];   // encoding output is fp16
+    if (enc_aux) {    // training: what the backward needs of this level's 8 corner values -- the encoding and d enc / d x --
+                      // as one 16-byte record [level][point][8], so that it streams them instead of gathering again
+      half8 rec;
+      rec[0] = (_Float16)val[0]; rec[1] = (_Float16)val[1];
+      rec[2] = (_Float16)dv[0][0]; rec[3] = (_Float16)dv[1][0]; rec[4] = (_Float16)dv[2][0];
+      rec[5] = (_Float16)dv[0][1]; rec[6] = (_Float16)dv[1][1]; rec[7] = (_Float16)dv[2][1];
+      *reinterpret_cast<half8*>(enc_aux + ((size_t)l * ((size_t)A.n * A.s) + idx) * 8) = rec;
+    }
     const float* wl = A.sdf_w + 3 + 2 * l;
 #pragma unroll
     for (int o = 0; o < 32; ++o) out[o] = fmaf(wl[o * 35 + 1], e1, fmaf(wl[o * 35], e0, out[o]));
@@ -760,8 +769,8 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
                                const float* rt_bound_host, const float* rt_bound_dev,
                                float* color, float* depth, float* depth_var, float* normal, float* weight_sum,
                                float* sdf, float* z_mid, float* grad_err_ray, float* alpha_out, void* rgb_out,
-                               float* grad_out, uint8_t* mask_out, void* mlp_in_out, int n, int s, void* workspace,
-                               size_t workspace_bytes, gs_stream_t stream) {
+                               float* grad_out, uint8_t* mask_out, void* mlp_in_out, void* enc_aux_out, int n, int s,
+                               void* workspace, size_t workspace_bytes, gs_stream_t stream) {
   GS_REQUIRE(rays_o && rays_d && z_vals && dists && grid && sdf_w && sdf_b && color_B && mlp && bound_host &&
                  rt_bound_host, "neus_forward: null input");
   GS_REQUIRE(color && depth && depth_var && normal && weight_sum && sdf && z_mid && grad_err_ray,
@@ -792,8 +801,9 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
   if (hipMemsetAsync(ws.count, 0, 4, st) != hipSuccess) { gs_set_error("neus_forward: memset failed"); return GS_ERR_LAUNCH; }
   neus_count_kernel<<<gs_cdiv(np, 256), 256, 0, st>>>(A, ws.count);
   GS_CHECK_LAUNCH("neus_count");
+  GS_TIMING_PRE();
   neus_point_kernel<<<gs_cdiv(np, 256), 256, 0, st>>>(A, host_meta(), ws.count, sdf, z_mid, alpha, grad, ws.mask,
-                                                      ws.mlp_in);
+                                                      ws.mlp_in, (_Float16*)enc_aux_out);
   GS_CHECK_LAUNCH("neus_point");
   const int n_tiles = gs_cdiv(np, 64);
   const int grid_mlp = gs_cdiv(n_tiles, 4) < 1024 ? gs_cdiv(n_tiles, 4) : 1024;

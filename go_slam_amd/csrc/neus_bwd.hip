@@ -143,6 +143,7 @@ struct BwdArgs {
   const float* sdf; const float* grad; const uint8_t* mask;
   const float* d_alpha; const float* d_sdf; const float* d_grad; const void* dX;
   const float* d_gerr_ray;
+  const _Float16* enc_aux;     // [16][n*s][8] f16 records of the forward (encoding, d enc / d x), or nullptr: gather again
   float* grid_grad; _Float16* grid_grad16; float grad_scale16; void* d_out; void* lin_in; void* dw0; void* d_arg; void* pts; float* d_inv_s;
   int rows16; float row_scale; int dx16; float dx_inv_scale; int row_stride16;
   int n, s;
@@ -205,7 +206,8 @@ __device__ __forceinline__ void st_row(void* base, bool h16, size_t idx, float v
   else reinterpret_cast<float*>(base)[idx] = v;
 }
 
-template <bool BINNED>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+template <bool BINNED, bool AUX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void neus_point_bwd_kernel(BwdArgs A, gs_grid_meta m) {
   __shared__ float red[4];
   __shared__ uint32_t row_tiles[4][64 * ROW_TS];
@@ -327,22 +329,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
     const size_t off = (size_t)m.offset[l];
     uint32_t cidx[8];
     float v[8][2];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      cidx[c] = grid_index(m, l, gi[0] + (c & 1), gi[1] + ((c >> 1) & 1), gi[2] + ((c >> 2) & 1));
-      const uint32_t raw = *reinterpret_cast<const uint32_t*>(A.grid + (off + cidx[c]) * 2);
-      v[c][0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw & 0xffffu));
-      v[c][1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw >> 16));
-    }
     float wc[8], e0 = 0.f, e1 = 0.f;
+    half8 rec;
+    if constexpr (AUX) {   // the forward kept this level's encoding and d enc / d x: one coalesced 16-byte load, no gathers
+      rec = *reinterpret_cast<const half8*>(A.enc_aux + ((size_t)l * (size_t)np + i) * 8);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float w = 1.0f;
+      for (int c = 0; c < 8; ++c) {
+        cidx[c] = grid_index(m, l, gi[0] + (c & 1), gi[1] + ((c >> 1) & 1), gi[2] + ((c >> 2) & 1));
+        float w = 1.0f;
 #pragma unroll
-      for (int d = 0; d < 3; ++d) w = w * (((c >> d) & 1) ? f[d] : (1.0f - f[d]));
-      wc[c] = w;
-      e0 = fmaf(w, v[c][0], e0);
-      e1 = fmaf(w, v[c][1], e1);
+        for (int d = 0; d < 3; ++d) w = w * (((c >> d) & 1) ? f[d] : (1.0f - f[d]));
+        wc[c] = w;
+      }
+      e0 = on ? (float)rec[0] : 0.0f;          // (out-of-bound points have no record: select, never multiply)
+      e1 = on ? (float)rec[1] : 0.0f;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        cidx[c] = grid_index(m, l, gi[0] + (c & 1), gi[1] + ((c >> 1) & 1), gi[2] + ((c >> 2) & 1));
+        const uint32_t raw = *reinterpret_cast<const uint32_t*>(A.grid + (off + cidx[c]) * 2);
+        v[c][0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw & 0xffffu));
+        v[c][1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw >> 16));
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float w = 1.0f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) w = w * (((c >> d) & 1) ? f[d] : (1.0f - f[d]));
+        wc[c] = w;
+        e0 = fmaf(w, v[c][0], e0);
+        e1 = fmaf(w, v[c][1], e1);
+      }
     }
     // value path: d enc_f = sum_o d_out[o] W[o][3+2l+f]
     cfp wl = (cfp)(A.sdf_w + 3 + 2 * l);
@@ -376,11 +393,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
         w = w * ((k & 2) ? f[o1] : (1.0f - f[o1]));
         const int cl = ((k & 1) << o0) | (((k >> 1) & 1) << o1);
         const int cr = cl | (1 << gd);
-        a0 = fmaf(w, v[cr][0] - v[cl][0], a0);
-        a1 = fmaf(w, v[cr][1] - v[cl][1], a1);
+        if constexpr (!AUX) {
+          a0 = fmaf(w, v[cr][0] - v[cl][0], a0);
+          a1 = fmaf(w, v[cr][1] - v[cl][1], a1);
+        }
         const float s0 = 0.5f * dG[gd] * g0 * w, s1 = 0.5f * dG[gd] * g1 * w;
         gacc[cr][0] += s0; gacc[cl][0] -= s0;
         gacc[cr][1] += s1; gacc[cl][1] -= s1;
+      }
+      if constexpr (AUX) {
+        a0 = on ? (float)rec[2 + gd] : 0.0f;
+        a1 = on ? (float)rec[5 + gd] : 0.0f;
       }
       dy0[gd] = a0;
       dy1[gd] = a1;
@@ -628,7 +651,8 @@ static int backward_points_impl(const float* rays_o, const float* rays_d, const 
                                        void* grid_grad, int grid_grad_dtype, float grid_grad_scale, void* d_out,
                                        void* lin_in, void* dw0, void* d_arg, void* pts, int row_dtype,
                                        float row_scale, int row_stride, float* d_inv_s, int n, int s,
-                                       void* bin_ws, size_t bin_ws_bytes, const float* sdf_wt, gs_stream_t stream) {
+                                       void* bin_ws, size_t bin_ws_bytes, const float* sdf_wt, const void* enc_aux,
+                                       gs_stream_t stream) {
   GS_REQUIRE(row_stride == 0 || (row_dtype == GS_F16 && row_stride >= 40 && row_stride % 8 == 0),
              "neus_backward_points: row_stride needs f16 rows, >= 40, a multiple of 8");
   GS_REQUIRE(dx_dtype == GS_F32 || dx_dtype == GS_F16, "neus_backward_points: dX dtype f32 or f16");
@@ -646,6 +670,7 @@ static int backward_points_impl(const float* rays_o, const float* rays_d, const 
   for (int k = 0; k < 6; ++k) A.bound[k] = bound_host[k];
   A.sdf = sdf; A.grad = grad; A.mask = mask; A.d_alpha = d_alpha; A.d_sdf = d_sdf; A.d_grad = d_grad; A.dX = dX;
   A.d_gerr_ray = d_gerr_ray;
+  A.enc_aux = (const _Float16*)enc_aux;
   A.grid_grad = grid_grad_dtype == GS_F32 ? (float*)grid_grad : nullptr;
   A.grid_grad16 = grid_grad_dtype == GS_F16 ? (_Float16*)grid_grad : nullptr;
   A.grad_scale16 = grid_grad_scale;
@@ -655,7 +680,8 @@ static int backward_points_impl(const float* rays_o, const float* rays_d, const 
   A.q_idx = nullptr; A.q_val = nullptr; A.q_cnt = nullptr;
   const gs_grid_meta m = host_meta();
   if (!bin_ws) {
-    neus_point_bwd_kernel<false><<<gs_cdiv(n * s, 256), 256, 0, (hipStream_t)stream>>>(A, m);
+    if (enc_aux) neus_point_bwd_kernel<false, true><<<gs_cdiv(n * s, 256), 256, 0, (hipStream_t)stream>>>(A, m);
+    else neus_point_bwd_kernel<false, false><<<gs_cdiv(n * s, 256), 256, 0, (hipStream_t)stream>>>(A, m);
     GS_CHECK_LAUNCH("neus_backward_points");
     return GS_OK;
   }
@@ -679,7 +705,8 @@ static int backward_points_impl(const float* rays_o, const float* rays_d, const 
   A.q_val = (uint32_t*)(base + gs_align(nq * nblk));              // [nq][nblk][ST_SLOTS]
   A.q_idx = (uint16_t*)((char*)A.q_val + nq * nblk * ST_SLOTS * 4);
   GS_TIMING_PRE();
-  neus_point_bwd_kernel<true><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(A, m);
+  if (enc_aux) neus_point_bwd_kernel<true, true><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(A, m);
+  else neus_point_bwd_kernel<true, false><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(A, m);
   GS_CHECK_LAUNCH("neus_backward_points_binned");
   static GsLdsLimit limit;
   const size_t lds = (size_t)2 * BIN_ENTRIES * sizeof(unsigned long long);
@@ -700,11 +727,11 @@ extern "C" int gs_neus_backward_points(const float* rays_o, const float* rays_d,
                                        void* grid_grad, int grid_grad_dtype, float grid_grad_scale, void* d_out,
                                        void* lin_in, void* dw0, void* d_arg, void* pts, int row_dtype,
                                        float row_scale, int row_stride, float* d_inv_s, int n, int s,
-                                       gs_stream_t stream) {
+                                       const void* enc_aux, gs_stream_t stream) {
   return backward_points_impl(rays_o, rays_d, z_vals, dists, grid, sdf_w, color_B, inv_s, inv_s_dev, bound_host, sdf, grad,
                               mask, d_alpha, d_sdf, d_grad, dX, dx_dtype, dx_scale, d_gerr_ray, grid_grad, grid_grad_dtype,
                               grid_grad_scale, d_out, lin_in, dw0, d_arg, pts, row_dtype, row_scale, row_stride, d_inv_s, n,
-                              s, nullptr, 0, nullptr, stream);
+                              s, nullptr, 0, nullptr, enc_aux, stream);
 }
 
 extern "C" int gs_neus_backward_points_binned(const float* rays_o, const float* rays_d, const float* z_vals,
@@ -717,10 +744,10 @@ extern "C" int gs_neus_backward_points_binned(const float* rays_o, const float* 
                                               void* d_out, void* lin_in, void* dw0, void* d_arg, void* pts,
                                               int row_dtype, float row_scale, int row_stride, float* d_inv_s, int n,
                                               int s, void* bin_ws, size_t bin_ws_bytes, const float* sdf_wt,
-                                              gs_stream_t stream) {
+                                              const void* enc_aux, gs_stream_t stream) {
   GS_REQUIRE(bin_ws, "neus_backward_points_binned: null workspace");
   return backward_points_impl(rays_o, rays_d, z_vals, dists, grid, sdf_w, color_B, inv_s, inv_s_dev, bound_host, sdf, grad,
                               mask, d_alpha, d_sdf, d_grad, dX, dx_dtype, dx_scale, d_gerr_ray, grid_grad, GS_F16,
                               grid_grad_scale, d_out, lin_in, dw0, d_arg, pts, row_dtype, row_scale, row_stride, d_inv_s, n,
-                              s, bin_ws, bin_ws_bytes, sdf_wt, stream);
+                              s, bin_ws, bin_ws_bytes, sdf_wt, enc_aux, stream);
 }

@@ -143,7 +143,6 @@ class InstantNeuS(nn.Module):
         # half2 atomics, loss scale 128, unscaled before the optimiser sees it); torch.float32 = exact
         self.grid_grad_dtype = torch.float16
         self.grid_grad_scale = 128.0
-        self.fused_mlp_backward = True         # gs_mlp_backward (one MFMA kernel) instead of hipBLASLt GEMMs
         # fp16 table gradient of the hashed levels by bin-and-reduce (no global atomics; csrc/neus_bwd.hip) -- False:
         # tiny-cuda-nn's packed fp16 atomics for every level (the tests' referee for the binned path)
         self.grid_grad_binned = True
@@ -289,7 +288,10 @@ def _neus_forward_raw(model, rays_o, rays_d, z_vals, dists, inv_s, save, inv_s_d
     if save:
         saved = dict(alpha=torch.empty(n, s, **f32), rgb=torch.empty(n, s, 3, dtype=torch.float16, device=dev),
                      grad=torch.empty(n, s, 3, **f32), mask=torch.empty(n, s, dtype=torch.uint8, device=dev),
-                     mlp_in=torch.empty(n * s, 80, dtype=torch.float16, device=dev))
+                     mlp_in=torch.empty(n * s, 80, dtype=torch.float16, device=dev),
+                     # per level and point [enc0, enc1, d enc / dx]: the backward streams these instead of gathering the
+                     # table a second time (256 B per point)
+                     enc_aux=torch.empty(16, n * s, 8, dtype=torch.float16, device=dev))
     bh, rh = model._bounds_host()
     L = _lib.lib()
     ws = _workspace(dev, L.gs_neus_forward_workspace_bytes(n, s) + 256)
@@ -305,7 +307,7 @@ def _neus_forward_raw(model, rays_o, rays_d, z_vals, dists, inv_s, save, inv_s_d
                                _lib.ptr(color), _lib.ptr(depth), _lib.ptr(dvar), _lib.ptr(normal), _lib.ptr(wsum),
                                _lib.ptr(sdf), _lib.ptr(zmid), _lib.ptr(gerr),
                                _lib.ptr(saved.get("alpha")), _lib.ptr(saved.get("rgb")), _lib.ptr(saved.get("grad")),
-                               _lib.ptr(saved.get("mask")), _lib.ptr(saved.get("mlp_in")), n, s,
+                               _lib.ptr(saved.get("mask")), _lib.ptr(saved.get("mlp_in")), _lib.ptr(saved.get("enc_aux")), n, s,
                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "InstantNeuS.forward")
     saved.update(grid=grid, mlp=mlp, sdf_w=sdf_w, cB=cB)
@@ -324,43 +326,6 @@ def _bin_workspace(device, nbytes):
         buf = torch.empty(int(nbytes * 1.1) + 4096, dtype=torch.uint8, device=device)
         _BIN_WS[key] = buf
     return buf
-
-
-def _tn(A, B, chunk=8192):
-    """A^T @ B for tall-skinny A [K,m], B [K,n] (K ~ 10^5..10^6, m,n <= 80) as a split-K batched
-    GEMM: hipBLASLt has no good single kernel for these shapes (27 ms for K = 2.4 M), the batched
-    form fills the GPU and costs ~0.3 ms."""
-    K = A.shape[0]
-    c = max(1, K // chunk)
-    main = c * chunk if K >= chunk else 0
-    out = torch.zeros(A.shape[1], B.shape[1], dtype=torch.float32, device=A.device)
-    if main:
-        out += _bmm_f32(A[:main].view(c, chunk, -1).transpose(1, 2), B[:main].view(c, chunk, -1)).sum(0)
-    if main < K:
-        out += _bmm_f32(A[main:].t().unsqueeze(0), B[main:].unsqueeze(0))[0]
-    return out
-
-
-_BMM_OUT_DTYPE = [True]
-
-
-def _bmm_f32(a, b):
-    """bmm with an fp32 result; fp16 operands use the fp32-output GEMM when this torch build has it
-    (each chunk's 8192-term sum is otherwise rounded to fp16 before the cross-chunk fp32 sum)."""
-    if a.dtype == torch.float32:
-        return torch.bmm(a, b)
-    if _BMM_OUT_DTYPE[0]:
-        try:
-            return torch.bmm(a, b, out_dtype=torch.float32)
-        except (RuntimeError, TypeError, NotImplementedError):
-            _BMM_OUT_DTYPE[0] = False
-    return torch.bmm(a, b).float()
-
-
-def _colsum(A, chunk=8192):
-    """Column sums of a tall matrix via the same split (a strided torch.sum(0) takes 18 ms here)."""
-    ones = torch.ones(A.shape[0], 8 if A.dtype == torch.float16 else 1, dtype=A.dtype, device=A.device)
-    return _tn(ones, A, chunk)[0].reshape(-1)
 
 
 class _NeusRenderFn(torch.autograd.Function):
@@ -419,36 +384,21 @@ def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d
                                      _lib.ptr(d_grad), n, s, st)
     _lib.check(rc, "InstantNeuS.backward(rays)")
     # ---- colour MLP backward in fp16 with fp32 accumulation and tiny-cuda-nn's loss scale (128) on every
-    # gradient that lives in fp16 -- the reference's network trains exactly like this (tcnn FullyFusedMLP
-    # backward).  Default: the fused MFMA kernel; fallback: the same maths as hipBLASLt GEMMs.
+    # gradient that lives in fp16 -- the reference's network trains exactly like this (tcnn FullyFusedMLP backward).
     LS = float(model.grid_grad_scale)
     X = S["mlp_in"]                                     # [np,80] f16
     W = S["mlp"]
-    if model.fused_mlp_backward:
-        # one MFMA kernel: forward recompute + dX + the three weight gradients (gs_mlp_backward)
-        wpack = _pack_mlp_fragments(W)
-        nb = L.gs_mlp_backward_blocks(np_)
-        partial = torch.empty(nb, 10240, **f32)
-        dX = torch.empty(np_, 80, dtype=torch.float16, device=dev)
-        with torch.cuda.device(dev):
-            rc = L.gs_mlp_backward(_lib.ptr(X), _lib.ptr(wpack), _lib.ptr(d_rgb), _lib.ptr(S["rgb"]), LS,
-                                   _lib.ptr(dX), _lib.ptr(partial), np_, st)
-        _lib.check(rc, "InstantNeuS.backward(mlp)")
-        g_mlp = None if raw_dense is not None else partial.sum(0) / LS
-    else:
-        W1, W2, W3 = W[:5120].view(64, 80), W[5120:9216].view(64, 64), W[9216:].view(16, 64)
-        H1 = torch.relu(X @ W1.t())
-        H2 = torch.relu(H1 @ W2.t())
-        y = S["rgb"].view(np_, 3).float()
-        dpre = torch.zeros(np_, 16, dtype=torch.float16, device=dev)
-        dpre[:, :3] = (d_rgb * y * (1.0 - y)) * LS      # sigmoid', scaled, padded to the 16 output rows
-        dW3 = _tn(dpre, H2) / LS                        # [16,64]; rows 3.. are zero
-        dH2 = (dpre @ W3) * (H2 > 0)
-        dW2 = _tn(dH2, H1) / LS
-        dH1 = (dH2 @ W2) * (H1 > 0)
-        dW1 = _tn(dH1, X) / LS
-        dX = (dH1 @ W1).contiguous()                    # [np,80] f16, loss-scaled; unscaled inside the per-point kernel
-        g_mlp = torch.cat([dW1.reshape(-1), dW2.reshape(-1), dW3.reshape(-1)])
+    # one MFMA kernel: forward recompute + dX + the three weight gradients (gs_mlp_backward; checked against
+    # torch.autograd on the oracle's restatement of the network in tests/)
+    wpack = _pack_mlp_fragments(W)
+    nb = L.gs_mlp_backward_blocks(np_)
+    partial = torch.empty(nb, 10240, **f32)
+    dX = torch.empty(np_, 80, dtype=torch.float16, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.gs_mlp_backward(_lib.ptr(X), _lib.ptr(wpack), _lib.ptr(d_rgb), _lib.ptr(S["rgb"]), LS,
+                               _lib.ptr(dX), _lib.ptr(partial), np_, st)
+    _lib.check(rc, "InstantNeuS.backward(mlp)")
+    g_mlp = None if raw_dense is not None else partial.sum(0) / LS
     # ---- per-point backward: alpha chain, SDF linear, hash grid (value + second-order paths)
     # hash-table gradient: tcnn's mode (fp16, packed atomics, loss scale 128) or fp32 atomics
     half_grads = model.grid_grad_dtype == torch.float16
@@ -459,22 +409,15 @@ def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d
     else:
         grid_acc = torch.zeros(S["grid"].numel(), dtype=model.grid_grad_dtype, device=dev)
     # per-point rows: fp16, gradient rows loss-scaled, all five as column blocks of ONE [np,160] matrix
-    # d_out 0:32 | lin_in 32:72 | dw0 72:112 | d_arg 112:152 | pts,1 152:160 -- its Gram matrix (one split-K
-    # GEMM) contains every dense-parameter gradient: d_out^T lin_in, the column sums (via the ones column)
-    # and pts^T d_arg
-    if raw_dense is not None:
-        # fused step: [d_out 0:32 | pts, 1 32:40 | lin_in 40:80 | dw0 80:120 | d_arg 120:160] -- every dense-parameter gradient
-        # is in rows[:, :40]^T @ rows, a [40,160] product per chunk of GC rows (gs_map_step_post knows this order).
-        # Chunk size measured on MI355X: 2048 rows at 295 k points (41 us; 8192: 73), 8192 at 2.4 M (224 us)
-        GC = 2048 if np_ <= (1 << 19) else 8192
-        np_pad = -(-np_ // GC) * GC
-        rows = torch.empty(np_pad, 160, dtype=torch.float16, device=dev)
-        if np_pad > np_:
-            rows[np_:].zero_()                          # (padding rows add nothing to the products)
-        d_out, pts, lin_in, dw0, d_arg = (rows[:, a:b] for a, b in ((0, 32), (32, 40), (40, 80), (80, 120), (120, 160)))
-    else:
-        rows = torch.empty(np_, 160, dtype=torch.float16, device=dev)
-        d_out, lin_in, dw0, d_arg, pts = (rows[:, a:b] for a, b in ((0, 32), (32, 72), (72, 112), (112, 152), (152, 160)))
+    # [d_out 0:32 | pts, 1 32:40 | lin_in 40:80 | dw0 80:120 | d_arg 120:160] -- every dense-parameter gradient is in
+    # rows[:, :40]^T @ rows: d_out^T lin_in, the column sums (via the ones column) and pts^T d_arg (gs_map_gram: one
+    # [40,160] partial per workgroup on the matrix cores; gs_map_step_post knows this order)
+    GC = 16                                             # gs_map_gram streams groups of 16 rows
+    np_pad = -(-np_ // GC) * GC
+    rows = torch.empty(np_pad, 160, dtype=torch.float16, device=dev)
+    if np_pad > np_:
+        rows[np_:].zero_()                              # (padding rows add nothing to the products)
+    d_out, pts, lin_in, dw0, d_arg = (rows[:, a:b] for a, b in ((0, 32), (32, 40), (40, 80), (80, 120), (120, 160)))
     d_invs = zb["d_invs"] if raw_dense is not None else torch.zeros(1, **f32)
     bh, _ = model._bounds_host()
     binned = half_grads and bool(getattr(model, "grid_grad_binned", True))
@@ -487,7 +430,8 @@ def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d
                 _lib.ptr(sdf.contiguous()), _lib.ptr(S["grad"]), _lib.ptr(S["mask"]), _lib.ptr(d_alpha), _lib.ptr(d_sdf),
                 _lib.ptr(d_grad), _lib.ptr(dX), 0, LS, _lib.ptr(d_gerr.reshape(-1).contiguous()), _lib.ptr(grid_acc),
                 gscale, d_out.data_ptr(), lin_in.data_ptr(), dw0.data_ptr(), d_arg.data_ptr(), pts.data_ptr(), 0, LS,
-                160, _lib.ptr(d_invs), n, s, _lib.ptr(bws), bws.numel(), _lib.ptr(zb.get("sdf_wt")), st)
+                160, _lib.ptr(d_invs), n, s, _lib.ptr(bws), bws.numel(), _lib.ptr(zb.get("sdf_wt")),
+                _lib.ptr(S.get("enc_aux")), st)
         else:
             rc = L.gs_neus_backward_points(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z_vals), _lib.ptr(dists),
                                            _lib.ptr(S["grid"]), _lib.ptr(S["sdf_w"]), _lib.ptr(S["cB"]),
@@ -497,17 +441,19 @@ def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d
                                            _lib.ptr(dX), 0, LS, _lib.ptr(d_gerr.reshape(-1).contiguous()),
                                            _lib.ptr(grid_acc), 0 if half_grads else 1, gscale,
                                            d_out.data_ptr(), lin_in.data_ptr(), dw0.data_ptr(),
-                                           d_arg.data_ptr(), pts.data_ptr(), 0, LS, 160, _lib.ptr(d_invs), n, s, st)
+                                           d_arg.data_ptr(), pts.data_ptr(), 0, LS, 160, _lib.ptr(d_invs), n, s,
+                                           _lib.ptr(S.get("enc_aux")), st)
     _lib.check(rc, "InstantNeuS.backward(points)")
-    if raw_dense is not None:       # one batched GEMM; everything after it happens in gs_map_step_post
-        rc_ = rows.view(np_pad // GC, GC, 160)
-        return {"grid_acc": grid_acc, "grid_scale": gscale, "gram": _bmm_f32(rc_[:, :, :40].transpose(1, 2), rc_),
-                "mlp_partial": partial, "loss_scale": LS}
-    G = _tn(rows, rows) / LS                            # [160,160] Gram matrix, fp32
-    g_sdf_w = G[0:32, 32:67].clone()
-    g_sdf_w[0] += G[155, 72:107]                        # column sums of dw0 (row 155 = the ones column)
-    g_sdf_b = G[155, 0:32].clone()
-    g_cB = G[152:155, 112:145].clone()
+    gram = torch.empty(L.gs_map_gram_blocks(np_pad), 40, 160, **f32)
+    with torch.cuda.device(dev):
+        _lib.check(L.gs_map_gram(_lib.ptr(rows), np_pad, _lib.ptr(gram), st), "map_gram")
+    if raw_dense is not None:       # everything after the Gram partials happens in gs_map_step_post
+        return {"grid_acc": grid_acc, "grid_scale": gscale, "gram": gram, "mlp_partial": partial, "loss_scale": LS}
+    G = gram.sum(0) / LS                                # [40,160], fp32 (only the blocks read below are defined)
+    g_sdf_w = G[0:32, 40:75].clone()
+    g_sdf_w[0] += G[35, 80:115]                         # column sums of dw0 (row 35 = the ones column)
+    g_sdf_b = G[35, 0:32].clone()
+    g_cB = G[32:35, 120:153].clone()
     sf = model.variance_network.scale_factor
     if inv_s_dev is not None:       # device-scalar form: no host value of the variance exists in this step
         raw_d = torch.exp(var_dev.detach().float() * sf)

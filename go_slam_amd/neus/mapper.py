@@ -222,8 +222,7 @@ class MapTrainer:
         self.w = dict(w_color=w_color, w_sdf=w_sdf, w_eikonal=w_eikonal, uncertainty=uncertainty)
         self.group, self.rank, self.world = group, rank, world
         if fused is None:
-            fused = (all(p.is_cuda for p in self.train_params) and model.grid_grad_dtype == torch.float16
-                     and model.fused_mlp_backward)
+            fused = all(p.is_cuda for p in self.train_params) and model.grid_grad_dtype == torch.float16
         self.fused = bool(fused)
         self.graph = bool(self.fused if graph is None else (graph and self.fused))
         self._graphs, self._bufs = {}, {}

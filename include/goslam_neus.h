@@ -87,7 +87,9 @@ int gs_mlp_forward(const void* x, const void* mlp, void* out, int n, int n_in, i
  *   z_mid [n,s] (= z_vals + dists/2), grad_err_ray [n] (per-ray sum of (|grad|-1)^2 * mask; the
  *   caller divides the total by n*s); optional per-point alpha f32 [n,s], rgb f16 [n,s,3],
  *   grad f32 [n,s,3], mask u8 [n,s], mlp_in f16 [n,s,80] (NULL = keep in the workspace; the
- *   training path saves them for gs_neus_backward_*).                                          */
+ *   training path saves them for gs_neus_backward_*); enc_aux_out f16 [16,n*s,8] (optional): per level and point
+ *   the record [enc0, enc1, d enc0 / dx (3), d enc1 / dx (3)] of the in-bound points -- handed to
+ *   gs_neus_backward_points* as `enc_aux`, the backward streams it instead of gathering the table again.      */
 size_t gs_neus_forward_workspace_bytes(int n, int s);
 int gs_neus_forward(const float* rays_o, const float* rays_d, const float* z_vals,
                     const float* dists, const void* grid, const float* sdf_w, const float* sdf_b,
@@ -96,7 +98,7 @@ int gs_neus_forward(const float* rays_o, const float* rays_d, const float* z_val
                     float* color, float* depth, float* depth_var, float* normal,
                     float* weight_sum, float* sdf, float* z_mid, float* grad_err_ray,
                     float* alpha_out, void* rgb_out, float* grad_out, uint8_t* mask_out,
-                    void* mlp_in_out, int n, int s,
+                    void* mlp_in_out, void* enc_aux_out, int n, int s,
                     void* workspace, size_t workspace_bytes, gs_stream_t stream);
 
 /* Backward of InstantNeuS.forward, stage 1 (per ray): from the upstream gradients of the ray
@@ -151,7 +153,7 @@ int gs_neus_backward_points(const float* rays_o, const float* rays_d, const floa
                             const void* dX, int dx_dtype, float dx_scale, const float* d_gerr_ray,
                             void* grid_grad, int grid_grad_dtype, float grid_grad_scale, void* d_out,
                             void* lin_in, void* dw0, void* d_arg, void* pts, int row_dtype, float row_scale,
-                            int row_stride, float* d_inv_s, int n, int s, gs_stream_t stream);
+                            int row_stride, float* d_inv_s, int n, int s, const void* enc_aux, gs_stream_t stream);
 /* The same backward with the table gradient of the HASHED levels accumulated WITHOUT global atomics (bin-and-reduce:
  * workgroups write (13-bit index, 2 x fp16) records to their own segments of per-(level, bin) queues in `bin_ws`, then
  * one workgroup per bin sums its queue in fp32 LDS accumulators and writes its 8192 entries once; neus_bwd.hip).
@@ -168,7 +170,7 @@ int gs_neus_backward_points_binned(const float* rays_o, const float* rays_d, con
                                    const float* d_gerr_ray, void* grid_grad, float grid_grad_scale, void* d_out,
                                    void* lin_in, void* dw0, void* d_arg, void* pts, int row_dtype, float row_scale,
                                    int row_stride, float* d_inv_s, int n, int s, void* bin_ws, size_t bin_ws_bytes,
-                                   const float* sdf_wt, gs_stream_t stream);
+                                   const float* sdf_wt, const void* enc_aux, gs_stream_t stream);
 
 /* The mapper's loss without the eikonal term (src/mapping.py:96-132 + InstantNeuS.compute_sdf_error,
  * src/InstantNeuS.py:372-400) and its gradient, one launch.  Rays with rays_depth <= 0 are masked out.
@@ -218,6 +220,12 @@ int gs_map_adamw_seg(float* p, float* m, float* v, void* p16, const void* g16, s
  *     [nchunk,40,160] = rows[:, :40]^T rows per chunk, summed over chunks, x inv_loss_scale), the MLP
  *     backward's workgroup partials (f32 [nb,10240]), d inv_s, and loss = sum(loss_rays) + w_eikonal * sum(gerr) /
  *     (counts[1] * samples).                                                                                        */
+/* rows[:, :40]^T rows of the backward's per-point rows (f16 [n_rows,160], n_rows % 16 == 0, zero rows as padding) on the
+ * matrix cores: partial f32 [gs_map_gram_blocks(n_rows)][40][160], one slab per workgroup, only the entries
+ * gs_map_step_post reads are written (rows 0..31 x columns 32..95, rows 32..39 x all columns) -- pass it as that
+ * function's gram_chunks with nchunk = gs_map_gram_blocks(n_rows).  Replaces a batched library GEMM.               */
+int gs_map_gram_blocks(int n_rows);
+int gs_map_gram(const void* rows, int n_rows, float* partial, gs_stream_t stream);
 int gs_map_step_prep(const float* rays_depth, int n, const float* variance, float scale_factor, float w_eikonal,
                      int samples, const float* counts_in, float* counts_out, float* inv_s_out, float* d_gerr_out,
                      float* d_invs, float* sqnorm, int* step_dev, const float* sdf_w, float* sdf_wt_out,

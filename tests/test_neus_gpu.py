@@ -183,10 +183,9 @@ def _rel(a, b):
     return float((a - b).norm() / b.norm().clamp(min=1e-12))
 
 
-@pytest.mark.parametrize("fused_mlp", [True, False])
 @pytest.mark.parametrize("grad_dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("grid_init", [0.3])
-def test_training_gradients_match_autograd_oracle(N, O, dev, grid_init, grad_dtype, fused_mlp):
+def test_training_gradients_match_autograd_oracle(N, O, dev, grid_init, grad_dtype):
     """Mapper loss (reference src/mapping.py:96-132) -> gradients of every trained parameter:
     fused HIP backward vs torch.autograd on the differentiable CPU restatement, including the
     second-order path through d sdf/d x (eikonal, normals into the colour net and alpha)."""
@@ -209,7 +208,6 @@ def test_training_gradients_match_autograd_oracle(N, O, dev, grid_init, grad_dty
     _load(model, P)
     model.update_bound(P["rt_bound"])
     model.grid_grad_dtype = grad_dtype      # fp32 atomics, or tcnn's fp16 packed atomics with loss scale 128
-    model.fused_mlp_backward = fused_mlp    # gs_mlp_backward (one MFMA kernel) vs the hipBLASLt formulation
     out = model(o.to(dev), d.to(dev), z.to(dev), dist.to(dev))
     loss = NA.mapping_loss({k: v for k, v in out.items()}, col.to(dev), gt.to(dev))
     loss.backward()
