@@ -22,6 +22,10 @@ _P = c_void_p
 SIGNATURES = {
     "gs_version": (ctypes.c_char_p, []),
     "gs_last_error": (ctypes.c_char_p, []),
+    "gs_enc_conv_wpack_elems": (c_size_t, [c_int, c_int, c_int]),
+    "gs_enc_conv_stat_chunks": (c_int, [c_int, c_int, c_int]),
+    "gs_enc_conv": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "gs_norm_act_workspace_bytes_chunks": (c_size_t, [c_int, c_int, c_int]),
     "gs_timing_begin": (c_int, [_P]),
     "gs_timing_end": (c_int, []),
     "gs_timing_read": (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
@@ -57,7 +61,7 @@ SIGNATURES = {
     "gs_conv3x3_head": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_float, _P, c_int, c_int, c_int, _P]),
     "gs_segment_mean": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
     "gs_norm_act_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "gs_norm_act": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [c_float, _P, c_size_t, _P]),
+    "gs_norm_act": (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [c_float, _P, c_size_t, c_int, _P]),
     "gs_gru_glo_workspace_bytes": (c_size_t, [c_int]),
     "gs_gru_glo": (c_int, [_P] * 11 + [c_int, c_int, _P, c_size_t, _P]),
     "gs_gru_glo_fused_workspace_bytes": (c_size_t, [c_int, c_int]),

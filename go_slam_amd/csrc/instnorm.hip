@@ -147,6 +147,42 @@ __global__ __launch_bounds__(256) void instnorm_final_kernel(const Moments* __re
   }
 }
 
+// The same for partial SUMS [n][nblk][c][2] of d = v - shift and d^2 (gs_enc_conv's epilogue statistics, shift = the
+// convolution's bias): plain additions, eight loads in flight per thread, then mean = shift + S1 / N and the biased
+// variance (S2 - S1^2 / N) / N.
+__global__ __launch_bounds__(256) void instnorm_final_sums_kernel(const float* __restrict__ sums, int nblk, int c, int hw,
+                                                                  const _Float16* __restrict__ shift, float eps,
+                                                                  float* __restrict__ final_) {
+  __shared__ float sm[256][2];
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const int per = 256 / c;                                    // threads per channel (c in {32, 64, 128, 256})
+  const int ch = tid % c, part = tid / c;
+  float a1 = 0.0f, a2 = 0.0f;
+  const float2* src = reinterpret_cast<const float2*>(sums) + (size_t)img * nblk * c + ch;
+  for (int b = part; b < nblk; b += 8 * per) {
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int bb = b + u * per;
+      v[u] = src[(size_t)min(bb, nblk - 1) * c];
+      if (bb >= nblk) v[u] = make_float2(0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a1 += v[u].x; a2 += v[u].y; }
+  }
+  sm[tid][0] = a1;
+  sm[tid][1] = a2;
+  __syncthreads();
+  if (tid < c) {
+    for (int q = 1; q < per; ++q) { a1 += sm[q * c + tid][0]; a2 += sm[q * c + tid][1]; }
+    const float n = (float)hw;
+    const float mean_d = a1 / n;
+    const float var = fmaxf(a2 / n - mean_d * mean_d, 0.0f);
+    final_[((size_t)img * c + tid) * 2 + 0] = (shift ? (float)shift[tid] : 0.0f) + mean_d;
+    final_[((size_t)img * c + tid) * 2 + 1] = 1.0f / sqrtf(var + eps);
+  }
+}
+
 __global__ __launch_bounds__(256) void norm_act_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ skip,
                                                        _Float16* __restrict__ y, const _Float16* __restrict__ bias,
                                                        const float* __restrict__ final_, int hw, int c, int relu_in,
@@ -184,6 +220,12 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const _Float16* __restric
 
 }  // namespace
 
+extern "C" size_t gs_norm_act_workspace_bytes_chunks(int n, int chunks, int channels) {
+  if (n <= 0 || chunks <= 0 || channels <= 0) return 0;
+  const size_t nblk = (size_t)chunks;
+  return gs_align((size_t)n * nblk * channels * sizeof(Moments)) + gs_align((size_t)n * channels * 2 * sizeof(float)) + 256;
+}
+
 extern "C" size_t gs_norm_act_workspace_bytes(int n, int hw, int channels) {
   if (n <= 0 || hw <= 0 || channels <= 0) return 0;
   const size_t nblk = (size_t)gs_cdiv(hw, IN_CHUNK);
@@ -193,7 +235,7 @@ extern "C" size_t gs_norm_act_workspace_bytes(int n, int hw, int channels) {
 extern "C" int gs_norm_act(const void* x, const void* bias, const void* skip, void* y, int n, int hw, int channels,
                            int instance_norm,
                            int relu_in, int relu_out, float eps, void* workspace, size_t workspace_bytes,
-                           gs_stream_t stream) {
+                           int stat_chunks, gs_stream_t stream) {
   GS_REQUIRE(x && y, "norm_act: null pointer");
   GS_REQUIRE(n >= 0 && hw > 0, "norm_act: bad shape");
   GS_REQUIRE(channels == 32 || channels == 64 || channels == 128 || channels == 256 || !instance_norm,
@@ -205,19 +247,27 @@ extern "C" int gs_norm_act(const void* x, const void* bias, const void* skip, vo
   const float* fin = nullptr;
   if (instance_norm) {
     GS_REQUIRE(channels <= 256, "norm_act: at most 256 channels");
-    const size_t need = gs_norm_act_workspace_bytes(n, hw, channels);
+    // stat_chunks > 0: the producing convolution (gs_enc_conv) already left that many chunk moments per image at the
+    // start of the workspace -- only the merge and the apply pass run
+    const size_t need = stat_chunks > 0 ? gs_norm_act_workspace_bytes_chunks(n, stat_chunks, channels)
+                                        : gs_norm_act_workspace_bytes(n, hw, channels);
     if (!workspace || workspace_bytes < need) {
       gs_set_error("norm_act: workspace too small (%zu < %zu)", workspace_bytes, need);
       return GS_ERR_WORKSPACE;
     }
-    const int nblk = gs_cdiv(hw, IN_CHUNK);
+    const int nblk = stat_chunks > 0 ? stat_chunks : gs_cdiv(hw, IN_CHUNK);
     char* base = (char*)gs_align((size_t)workspace);
     Moments* partial = (Moments*)base;
     float* final_ = (float*)((char*)partial + gs_align((size_t)n * nblk * channels * sizeof(Moments)));
     GS_REQUIRE(n <= 65535, "norm_act: too many images");
-    instnorm_stats_kernel<<<dim3(nblk, n), 256, 0, st>>>((const _Float16*)x, (const _Float16*)bias, hw, channels, partial);
-    GS_CHECK_LAUNCH("instnorm_stats");
-    instnorm_final_kernel<<<n, 256, 0, st>>>(partial, nblk, channels, eps, final_);
+    if (stat_chunks <= 0) {
+      instnorm_stats_kernel<<<dim3(nblk, n), 256, 0, st>>>((const _Float16*)x, (const _Float16*)bias, hw, channels, partial);
+      GS_CHECK_LAUNCH("instnorm_stats");
+    }
+    if (stat_chunks > 0)
+      instnorm_final_sums_kernel<<<n, 256, 0, st>>>((const float*)partial, nblk, channels, hw, (const _Float16*)bias, eps, final_);
+    else
+      instnorm_final_kernel<<<n, 256, 0, st>>>(partial, nblk, channels, eps, final_);
     GS_CHECK_LAUNCH("instnorm_final");
     fin = final_;
   }

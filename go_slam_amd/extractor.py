@@ -3,8 +3,11 @@ src/modules/extractor.py:4-126).  Parameter names follow the
 (`conv1`, `norm1`, `layer{1,2,3}.{0,1}.{conv1,conv2,norm1,norm2,norm3,downsample.{0,1}}`, `conv2`) so a pretrained
 `droid.pth` loads with `load_state_dict(strict=True)`.
 
-The convolutions stay on MIOpen.  What this module adds for MI355X:
-  * the memory format: every activation is NHWC (channels_last), which selects MIOpen's NHWC fp16 kernels;
+What this module adds for MI355X:
+  * the convolutions of the inference path on the package's own MFMA kernels (`gs_enc_conv`, csrc/enc_conv.hip: 7x7
+    stride-2 stem, 3x3 at 32 / 64 / 128 channels with stride 1 / 2, strided 1x1 skips, 1x1 projection) -- no library
+    convolution is left in `MotionFilter.track`; OWN_ENC_CONV = False (tests) routes them through MIOpen as the referee;
+  * the memory format: every activation is NHWC (channels_last);
   * an inference path (`BasicEncoder._forward_fast`, used under no_grad on a GPU for norm_fn 'instance' / 'none'):
     fp16 NHWC weights cast ONCE (autocast re-casts weight and bias of all 11 convolutions on every call: 37 copy
     kernels per frame) and the elementwise tail of every convolution -- InstanceNorm + ReLU, and the block's
@@ -17,25 +20,67 @@ import torch.nn.functional as F
 
 DIM = 32
 FAST_ENCODER = True         # module constant, not an environment switch: tests flip it to compare the two paths
+OWN_ENC_CONV = True         # gs_enc_conv for the encoder's convolutions (False: MIOpen NHWC fp16, the tests' referee)
+_ENC_SHAPES = {(7, 4, 32, 2), (3, 32, 32, 1), (3, 32, 64, 2), (3, 64, 64, 1), (3, 64, 128, 2), (3, 128, 128, 1),
+               (1, 32, 64, 2), (1, 64, 128, 2), (1, 128, 128, 1), (1, 128, 256, 1)}    # (k, c_in, c_out, stride) built
+
+
+def pack_enc_conv_weight(weight):
+    """[O, C, k, k] -> gs_enc_conv's MFMA A-fragments (include/goslam_hip.h).  k in {1, 3}: fp16 [k*k][C/16][O/32][64][8]
+    with element [t][s][m][l][e] = W[32 m + (l & 31)][16 s + 8 (l >> 5) + e][t // k][t % k].  k = 7 (the stem, C = 3
+    padded to the 4-channel RGB0 input): [7][2][64][8] with [dy][s][l][e] = W[l & 31][e % 4][dy][4 s + 2 (l >> 5) + e // 4],
+    zero for channel 3 and for tap 7."""
+    O, C, k, _ = weight.shape
+    w = weight.detach().float()
+    dev = w.device
+    lane = torch.arange(64, device=dev)
+    e = torch.arange(8, device=dev)
+    if k == 7:
+        assert O == 32 and C == 3
+        wp = torch.zeros(7, 2, 64, 8, device=dev)
+        for s_ in range(2):
+            tap = 4 * s_ + 2 * (lane[:, None] >> 5) + e[None, :] // 4           # [64, 8]
+            ch = (e[None, :] % 4).expand(64, 8)
+            ok = (tap < 7) & (ch < 3)
+            vals = w[(lane[:, None] & 31).expand(64, 8), ch.clamp(max=2), :, tap.clamp(max=6)]      # [64, 8, 7(dy)]
+            wp[:, s_] = (vals * ok[..., None]).permute(2, 0, 1)
+        return wp.half().contiguous()
+    assert O % 32 == 0 and C % 16 == 0
+    o_idx = (32 * torch.arange(O // 32, device=dev)[:, None, None] + (lane[None, :, None] & 31)).expand(O // 32, 64, 8)
+    wp = torch.empty(k * k, C // 16, O // 32, 64, 8, device=dev)
+    for s_ in range(C // 16):
+        c_idx = (16 * s_ + 8 * (lane[None, :, None] >> 5) + e[None, None, :]).expand(O // 32, 64, 8)
+        vals = w[o_idx, c_idx]                                                  # [O/32, 64, 8, k, k]
+        wp[:, s_] = vals.reshape(O // 32, 64, 8, k * k).permute(3, 0, 1, 2)
+    return wp.half().contiguous()
 _WS = {}                    # (device index, stream) -> statistics workspace of gs_norm_act (two encoder calls on
                             # different streams -- tracking and backend threads -- must not share partial moments)
 
 
-def _norm_act(x, skip, instance, relu_in, relu_out, bias=None):
-    """in place on x (NHWC fp16 [n,c,h,w]): relu_out?(skip + relu_in?(instance_norm?(x + bias)))  -- gs_norm_act"""
+def _stats_workspace(device, nbytes):
+    """per-(device, stream) grow-only workspace of gs_norm_act (chunk moments + mean / invstd)"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WS[key] = torch.empty(max(int(nbytes), 1 << 21), dtype=torch.uint8, device=device)
+    return ws
+
+
+def _norm_act(x, skip, instance, relu_in, relu_out, bias=None, stat_chunks=0):
+    """in place on x (NHWC fp16 [n,c,h,w]): relu_out?(skip + relu_in?(instance_norm?(x + bias)))  -- gs_norm_act.
+    stat_chunks > 0: the convolution that produced x (gs_enc_conv) already left its epilogue's chunk moments in this
+    stream's workspace, so the statistics pass is skipped."""
     from . import _lib
     L = _lib.lib()
     n, c, h, w = x.shape
-    ws, nbytes = None, 0
+    ws = None
     if instance:
-        nbytes = int(L.gs_norm_act_workspace_bytes(n, h * w, c))
-        key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
-        ws = _WS.get(key)
-        if ws is None or ws.numel() < nbytes:
-            ws = _WS[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=x.device)
+        nbytes = int(L.gs_norm_act_workspace_bytes_chunks(n, stat_chunks, c) if stat_chunks
+                     else L.gs_norm_act_workspace_bytes(n, h * w, c))
+        ws = _stats_workspace(x.device, nbytes)
     with torch.cuda.device(x.device):
         rc = L.gs_norm_act(_lib.ptr(x), _lib.ptr(bias), _lib.ptr(skip), _lib.ptr(x), n, h * w, c, int(instance), int(relu_in),
-                           int(relu_out), 1e-5, _lib.ptr(ws), ws.numel() if ws is not None else 0,
+                           int(relu_out), 1e-5, _lib.ptr(ws), ws.numel() if ws is not None else 0, int(stat_chunks),
                            _lib.stream_ptr(x.device))
     _lib.check(rc, "norm_act")
     return x
@@ -100,19 +145,49 @@ class BasicEncoder(nn.Module):
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
 
-    def _conv(self, conv, x, with_bias=True):
-        """conv(x) on fp16 NHWC operands cast once per weight version (what autocast computes, minus the casts).
-        with_bias=False returns (conv(x) without the bias, fp16 bias): torch adds a MIOpen convolution's bias with a
-        separate kernel, gs_norm_act adds it on the fly (same fp16 rounding of conv + bias)."""
+    def _conv(self, conv, x, with_bias=True, stats=None):
+        """conv(x) on fp16 NHWC operands cast / packed once per weight version (what autocast computes, minus the casts).
+        with_bias=False returns (conv(x) without the bias, fp16 bias): gs_norm_act adds it on the fly (same fp16 rounding
+        of conv + bias as the two fp16 tensors torch materialises).  stats=True (own kernels, InstanceNorm next): the
+        convolution's epilogue also leaves the chunk moments of half(conv + bias) in this stream's norm workspace.  With `stats`
+        given (True or False) a third value is returned: the `stat_chunks` to hand to _norm_act (0: none were written)."""
         cache = self.__dict__.setdefault("_w16", {})
         key = (conv.weight._version, conv.bias._version, conv.weight.device, conv.weight.data_ptr())
         hit = cache.get(id(conv))
         if hit is None or hit[0] != key:
-            hit = (key, conv.weight.detach().half().contiguous(memory_format=torch.channels_last),
-                   conv.bias.detach().half().contiguous())
+            hit = [key, conv.weight.detach().half().contiguous(memory_format=torch.channels_last),
+                   conv.bias.detach().half().contiguous(), None]
             cache[id(conv)] = hit
+        k, stride = conv.kernel_size[0], conv.stride[0]
+        n, c, h, w = x.shape
+        shape = (k, c, conv.out_channels, stride)
+        if (OWN_ENC_CONV and shape in _ENC_SHAPES and x.dtype == torch.float16
+                and x.is_contiguous(memory_format=torch.channels_last) and conv.padding[0] == k // 2):
+            from . import _lib
+            if hit[3] is None:
+                hit[3] = pack_enc_conv_weight(conv.weight)
+            ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+            y = torch.empty(n, conv.out_channels, ho, wo, dtype=torch.float16, device=x.device,
+                            memory_format=torch.channels_last)
+            L = _lib.lib()
+            chunks, ws = 0, None
+            if stats:
+                chunks = int(L.gs_enc_conv_stat_chunks(ho, wo, conv.out_channels))
+                ws = _stats_workspace(x.device, int(L.gs_norm_act_workspace_bytes_chunks(n, chunks, conv.out_channels)))
+            with torch.cuda.device(x.device):
+                rc = L.gs_enc_conv(_lib.ptr(x), c, c, _lib.ptr(hit[3]), _lib.ptr(hit[2] if with_bias else None),
+                                   _lib.ptr(y), conv.out_channels, conv.out_channels, k, stride, n, h, w,
+                                   _lib.ptr(hit[2] if stats else None), _lib.ptr(ws), _lib.stream_ptr(x.device))
+            _lib.check(rc, "enc_conv")
+            if stats is not None:
+                return y, hit[2], chunks
+            return y if with_bias else (y, hit[2])
+        if c == 4 and conv.in_channels == 3:            # (the stem's RGB0 input on the library path)
+            x = x[:, :3].contiguous(memory_format=torch.channels_last)
         if with_bias:
             return F.conv2d(x, hit[1], hit[2], conv.stride, conv.padding)
+        if stats is not None:
+            return F.conv2d(x, hit[1], None, conv.stride, conv.padding), hit[2], 0
         return F.conv2d(x, hit[1], None, conv.stride, conv.padding), hit[2]
 
     def _fast_ok(self, x):
@@ -120,24 +195,95 @@ class BasicEncoder(nn.Module):
                 and (x.dtype == torch.float16 or torch.is_autocast_enabled()) and x.shape[-1] % 8 == 0
                 and x.shape[-2] % 8 == 0)
 
+    def _packs(self, conv):
+        """(fp16 NHWC weight, fp16 bias, gs_enc_conv fragments) of a convolution, cached per weight version"""
+        cache = self.__dict__.setdefault("_w16", {})
+        key = (conv.weight._version, conv.bias._version, conv.weight.device, conv.weight.data_ptr())
+        hit = cache.get(id(conv))
+        if hit is None or hit[0] != key:
+            hit = [key, conv.weight.detach().half().contiguous(memory_format=torch.channels_last),
+                   conv.bias.detach().half().contiguous(), None]
+            cache[id(conv)] = hit
+        if hit[3] is None and OWN_ENC_CONV:
+            hit[3] = pack_enc_conv_weight(conv.weight)
+        return hit
+
     def _forward_fast(self, x):
+        """The inference path.  One input frame is ~45 launches of 3-12 us each, so the HOST side decides the frame time:
+        with the own kernels everywhere the stream handle, the device guard and the statistics workspace are taken once
+        per call and the launches go straight to the C ABI with raw pointers (measured: ~4 us of Python per launch
+        instead of ~10)."""
         inst = self.norm_fn == "instance"
+        own = OWN_ENC_CONV
         with torch.autocast("cuda", enabled=False):
-            x = x.half().contiguous(memory_format=torch.channels_last)
-            t, b = self._conv(self.conv1, x, False)
-            y = _norm_act(t, None, inst, True, False, b)
-            for layer in (self.layer1, self.layer2, self.layer3):
-                for blk in layer:
-                    t, b = self._conv(blk.conv1, y, False)
-                    t = _norm_act(t, None, inst, True, False, b)
-                    t, b = self._conv(blk.conv2, t, False)
-                    if blk.downsample is None:
+            n_, _, h_, w_ = x.shape                   # RGB0: the stem kernel reads 8-byte pixels
+            dev = x.device
+            x4 = torch.empty(n_, 4, h_, w_, dtype=torch.float16, device=dev, memory_format=torch.channels_last)
+            x4[:, 3].zero_()
+            x4[:, :3].copy_(x)
+            if not own:
+                return self._forward_fast_generic(x4, inst)
+            from . import _lib
+            L = _lib.lib()
+            st = torch.cuda.current_stream(dev).cuda_stream
+            # statistics workspace: the largest layer (stem / layer1: 32 channels at half resolution) decides
+            ws = _stats_workspace(dev, 16 * n_ * ((h_ // 2) * ((w_ // 2 + 31) // 32) * 32 + 4096) + (1 << 16))
+            wsp, wsn = ws.data_ptr(), ws.numel()
+            cl = torch.channels_last
+
+            def conv(m, xin, stats):
+                k, stride, co = m.kernel_size[0], m.stride[0], m.out_channels
+                n, c, h, w = xin.shape
+                hit = self._packs(m)
+                ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+                y = torch.empty(n, co, ho, wo, dtype=torch.float16, device=dev, memory_format=cl)
+                b = hit[2].data_ptr()
+                rc = L.gs_enc_conv(xin.data_ptr(), c, c, hit[3].data_ptr(), None, y.data_ptr(), co, co, k, stride, n, h, w,
+                                   b if stats else None, wsp if stats else None, st)
+                if rc:
+                    _lib.check(rc, "enc_conv")
+                return y, b, ((ho * ((wo + 31) // 32) * (co // 32) + 3) // 4 if stats else 0)
+
+            def norm(t, skip, relu_in, relu_out, b, chunks):
+                n, c, h, w = t.shape
+                rc = L.gs_norm_act(t.data_ptr(), b, None if skip is None else skip.data_ptr(), t.data_ptr(), n, h * w, c,
+                                   int(inst), int(relu_in), int(relu_out), 1e-5, wsp, wsn, chunks, st)
+                if rc:
+                    _lib.check(rc, "norm_act")
+                return t
+
+            with torch.cuda.device(dev):
+                t, b, ch = conv(self.conv1, x4, inst)
+                y = norm(t, None, True, False, b, ch)
+                for layer in (self.layer1, self.layer2, self.layer3):
+                    for blk in layer:
+                        t, b, ch = conv(blk.conv1, y, inst)
+                        t = norm(t, None, True, False, b, ch)
                         skip = y
-                    else:
-                        skip, bs = self._conv(blk.downsample[0], y, False)
-                        skip = _norm_act(skip, None, inst, False, False, bs)
-                    y = _norm_act(t, skip, inst, True, True, b)
+                        if blk.downsample is not None:
+                            # (before conv2: a convolution's epilogue statistics live in the stream's ONE norm workspace
+                            # until the normalisation that follows it has consumed them)
+                            skip, bs, chs = conv(blk.downsample[0], y, inst)
+                            skip = norm(skip, None, False, False, bs, chs)
+                        t, b, ch = conv(blk.conv2, t, inst)
+                        y = norm(t, skip, True, True, b, ch)
             return self._conv(self.conv2, y)
+
+    def _forward_fast_generic(self, x4, inst):
+        """the same sequence through _conv / _norm_act (library convolutions: OWN_ENC_CONV = False, the tests' referee)"""
+        t, b, ch = self._conv(self.conv1, x4, False, stats=inst)
+        y = _norm_act(t, None, inst, True, False, b, ch)
+        for layer in (self.layer1, self.layer2, self.layer3):
+            for blk in layer:
+                t, b, ch = self._conv(blk.conv1, y, False, stats=inst)
+                t = _norm_act(t, None, inst, True, False, b, ch)
+                skip = y
+                if blk.downsample is not None:
+                    skip, bs, chs = self._conv(blk.downsample[0], y, False, stats=inst)
+                    skip = _norm_act(skip, None, inst, False, False, bs, chs)
+                t, b, ch = self._conv(blk.conv2, t, False, stats=inst)
+                y = _norm_act(t, skip, inst, True, True, b, ch)
+        return self._conv(self.conv2, y)
 
     def forward(self, x):
         b, n = x.shape[:2]

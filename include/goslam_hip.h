@@ -264,11 +264,31 @@ int gs_segment_mean(const void* x, int x_stride, const float* in_bias, int in_re
  *   t = relu_in  ? max(t, 0) : t
  *   t = skip     ? half(skip + t) : t
  *   y = relu_out ? max(t, 0) : t
- * workspace: gs_norm_act_workspace_bytes bytes (not needed when instance_norm == 0).                      */
+ * workspace: gs_norm_act_workspace_bytes bytes (not needed when instance_norm == 0).  stat_chunks > 0: the statistics pass
+ * is skipped -- gs_enc_conv, given the same workspace as `stats_ws`, already wrote stat_chunks = gs_enc_conv_stat_chunks
+ * (h_out, w_out, c_out) partial-sum slabs per image in its epilogue (workspace: gs_norm_act_workspace_bytes_chunks). */
 size_t gs_norm_act_workspace_bytes(int n, int hw, int channels);
+size_t gs_norm_act_workspace_bytes_chunks(int n, int chunks, int channels);
+/* The frame encoders' convolutions (src/modules/extractor.py:61-126: BasicEncoder.conv1 7x7 / stride 2, the residual
+ * blocks' 3x3 convolutions with stride 1 / 2, their strided 1x1 skips, conv2 1x1), NHWC fp16 -> NHWC fp16 with fp32
+ * accumulation and ONE fp16 rounding (+ a second one after the fp16 bias add when `bias` f16 [c_out] is given -- the
+ * rounding points of a library convolution followed by its bias kernel).  Built shapes (ksize, c_in, c_out, stride):
+ * (7,4,32,2) -- the stem on a dense 4-channel RGB0 image --, (3,32,32,1), (3,32,64,2), (3,64,64,1), (3,64,128,2),
+ * (3,128,128,1), (1,32,64,2), (1,64,128,2), (1,128,128,1), (1,128,256,1); padding = ksize / 2; anything else returns
+ * GS_ERR_UNSUPPORTED.  wpack: MFMA A-fragments in lane order, f16 [ksize^2][c_in/16][c_out/32][64][8] with element
+ * [t][s][m][l][e] = W[32 m + (l & 31)][16 s + 8 (l >> 5) + e][t / ksize][t % ksize]; the stem: [7][2][64][8] with
+ * [dy][s][l][e] = W[l & 31][e % 4][dy][4 s + 2 (l >> 5) + e / 4] (0 for channel 3 and tap 7).
+ * stats_ws (optional): the gs_norm_act workspace of the InstanceNorm that follows -- the epilogue leaves per workgroup
+ * and channel the sums of d and d^2, d = half(conv + stat_bias) - stat_bias (stat_bias f16 [c_out], optional), there, and
+ * gs_norm_act is then called with the SAME bias and stat_chunks = gs_enc_conv_stat_chunks(h_out, w_out, c_out).     */
+size_t gs_enc_conv_wpack_elems(int ksize, int c_in, int c_out);
+int gs_enc_conv_stat_chunks(int h_out, int w_out, int c_out);
+int gs_enc_conv(const void* x, int x_stride, int c_in, const void* wpack, const void* bias, void* y, int y_stride,
+                int c_out, int ksize, int stride, int n, int h, int w, const void* stat_bias, void* stats_ws,
+                gs_stream_t stream);
 int gs_norm_act(const void* x, const void* bias, const void* skip, void* y, int n, int hw, int channels,
                 int instance_norm, int relu_in, int relu_out, float eps, void* workspace, size_t workspace_bytes,
-                gs_stream_t stream);
+                int stat_chunks, gs_stream_t stream);
 /* ConvGRU global context (src/modules/gru.py:22-27): glo = mean_hw(sigmoid(w_pre + w_bias) * net),
  * then the three 1x1 convolutions convz_glo | convr_glo (-> gzr [n,256]) and convq_glo (-> gq [n,128]).
  * w_pre = bias-free 1x1 conv of net, NHWC fp16 [n,hw,128]; wz/wr/wq fp16 [128 out,128 in]; outputs f32
