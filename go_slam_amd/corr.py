@@ -25,6 +25,8 @@ class CorrBlock:
             else droid_backends.CORR_ROWMAJOR
         self.corr_pyramid = CorrBlock.build_pyramid(fmap1, fmap2, num_levels, self.layout)
 
+    _warned_fallback = False
+
     @staticmethod
     def corr(fmap1, fmap2):
         """All-pairs correlation (corr.py:67-76): [batch,num,dim,ht,wd] x2 -> [batch,num,ht,wd,ht,wd]."""
@@ -42,7 +44,15 @@ class CorrBlock:
             return droid_backends.corr_volume_pyramid(f1.contiguous(),
                                                       fmap2.reshape(batch * num, dim, ht, wd).contiguous(), layout)
         assert layout == droid_backends.CORR_ROWMAJOR
-        # shapes the fused kernel does not cover (odd widths, w > 80): hipBLASLt + avg_pool2d
+        # shapes the fused kernel does not cover (w % 8 != 0 -- EuRoC's 40 x 60 maps --, w > 96, other dtypes): the
+        # reference's own formulation, a library GEMM + avg_pool2d.  Said out loud once per process: a reader of a
+        # profile should not have to discover a hipBLASLt kernel on this path.
+        if fmap1.is_cuda and not CorrBlock._warned_fallback:
+            import warnings
+            CorrBlock._warned_fallback = True
+            warnings.warn(f"CorrBlock: {ht}x{wd} {fmap1.dtype} feature maps are outside gs_corr_volume_pyramid's shapes "
+                          "(fp16, width a multiple of 8 up to 96); building the volume with torch.matmul + avg_pool2d",
+                          RuntimeWarning, stacklevel=2)
         corr = CorrBlock.corr(fmap1, fmap2)
         batch, num, h1, w1, h2, w2 = corr.shape
         corr = corr.reshape(batch * num * h1 * w1, 1, h2, w2)

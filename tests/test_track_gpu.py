@@ -561,3 +561,52 @@ def test_corrblock_matches_oracle_on_fused_and_fallback_shapes(O, dev, hw, expec
         assert tuple(out.shape) == (1, 2, 196, h, w)
         # level 0 may differ by one fp16 rounding of the fp32 dot product between GEMM implementations
         torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=0, atol=4e-3)
+
+
+@pytest.mark.parametrize("h,w,layout", [(16, 96, "tile8"), (16, 96, "rowmajor"), (12, 88, "rowmajor")])
+def test_corr_volume_pyramid_at_the_kernel_width_limit(db, O, dev, h, w, layout):
+    """corr_volume_kernel's real limit is three 32-column tiles per wave, w <= 96 (the Python gate said 80 until round
+    4): level 0 within one fp16 rounding of the oracle's fp32 dot products, pooled levels exactly the pool of the level
+    below, in both layouts (tile8 needs w % 16 == 0)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(500 + w)
+    f1 = torch.randn(2, 128, h, w, generator=g).half()
+    f2 = torch.randn(2, 128, h, w, generator=g).half()
+    assert db.corr_volume_supported(f1) and db.CORR_VOLUME_MAX_W == 96
+    ref = O.corr_pyramid(f1[None], f2[None])
+    lay = db.CORR_TILE8 if layout == "tile8" else db.CORR_ROWMAJOR
+    out = db.corr_volume_pyramid(f1.to(dev), f2.to(dev), layout=lay)
+    if lay == db.CORR_TILE8:
+        out = [db.corr_untile8(out[l], h >> l, w >> l) if l < 2 else out[l] for l in range(4)]
+    o0, r0 = out[0].cpu().float(), ref[0].float().reshape(out[0].shape)
+    diff = (o0 - r0).abs()
+    assert float(diff.max()) <= 2 ** -10 * max(1.0, float(r0.abs().max())) * 1.01
+    for l in range(1, 4):
+        low = out[l - 1].cpu()
+        hl, wl = low.shape[-2:]
+        pooled = F.avg_pool2d(low.reshape(-1, 1, hl, wl).float(), 2, 2).to(torch.float16)
+        assert torch.equal(out[l].cpu().reshape(-1, 1, hl // 2, wl // 2), pooled), f"level {l}"
+    assert not db.corr_volume_supported(torch.zeros(1, 128, 40, 60).half())         # EuRoC: w % 8 == 4
+    assert not db.corr_volume_supported(torch.zeros(1, 128, 16, 104).half())
+
+
+def test_corr_block_outside_the_kernel_shapes_warns_instead_of_silently_using_the_library(db, O, dev):
+    """EuRoC's 320 x 480 input gives 40 x 60 maps (configs/EuRoC/mh_01_easy.yaml): w % 8 == 4 is outside the fused
+    builder's shapes.  CorrBlock then takes the reference's own formulation (matmul + avg_pool2d) -- with a
+    RuntimeWarning, once -- and its lookup still equals the oracle's."""
+    import warnings
+    from go_slam_amd.corr import CorrBlock
+    g = torch.Generator().manual_seed(611)
+    f1 = torch.randn(1, 2, 128, 40, 60, generator=g).half()
+    f2 = torch.randn(1, 2, 128, 40, 60, generator=g).half()
+    CorrBlock._warned_fallback = False
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        blk = CorrBlock(f1.to(dev), f2.to(dev))
+        CorrBlock(f1.to(dev), f2.to(dev))
+    assert sum(issubclass(w_.category, RuntimeWarning) and "gs_corr_volume_pyramid" in str(w_.message) for w_ in rec) == 1
+    ys, xs = torch.meshgrid(torch.arange(40, dtype=torch.float32), torch.arange(60, dtype=torch.float32), indexing="ij")
+    coords = (torch.stack([xs, ys], -1)[None, None] + 2.0 * torch.randn(1, 2, 40, 60, 2, generator=g)).contiguous()
+    out = blk(coords.to(dev))
+    ref = O.corr_lookup(O.corr_pyramid(f1, f2), coords, 3)
+    torch.testing.assert_close(out.float().cpu().reshape(ref.shape), ref.float(), rtol=0, atol=2e-2)

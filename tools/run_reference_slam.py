@@ -277,7 +277,7 @@ def main():
         net0.update.delta[2].bias.zero_()
     ckpt = os.path.join(out_dir, "droid_random.pth")
     torch.save({"module." + k: v for k, v in net0.state_dict().items()}, ckpt)
-    cfg = make_cfg(H, W, 32, device, ckpt, out_dir, a.mode)
+    cfg = make_cfg(H, W, max(32, a.frames + 24), device, ckpt, out_dir, a.mode)   # every frame is promoted; the trajectory filler appends batches of 16
     args = types.SimpleNamespace(device=device, make_video=False, output=out_dir)
     t0 = time.time()
     slam = slam_mod.SLAM(args, cfg)
@@ -288,6 +288,22 @@ def main():
     if a.cpu_dryrun:                         # no fp16 autocast on the CPU: keep the feature buffers in fp32
         for name in ("fmaps", "nets", "inps"):
             setattr(slam.video, name, getattr(slam.video, name).float())
+    # count the frontend's loop-closure bundle adjustments (src/frontend.py:83-87: once the window is full, every keyframe
+    # runs Backend.loop_ba over ALL keyframes instead of the local update) without touching the reference's code
+    loops = {"calls": 0, "last_keyframes_edges": None}
+    lc = getattr(getattr(slam.tracker, "frontend", None), "loop_closing", None)
+    if lc is not None:
+        real_loop_ba = lc.loop_ba
+
+        def counted_loop_ba(*args_, **kw_):
+            out = real_loop_ba(*args_, **kw_)
+            loops["calls"] += 1
+            try:
+                loops["last_keyframes_edges"] = [int(out[0]), int(out[1])]
+            except Exception:
+                pass
+            return out
+        lc.loop_ba = counted_loop_ba
     stream = SyntheticStream(cfg, a.frames)
     t0 = time.time()
     for (timestamp, image, depth, intrinsic, gt_pose) in stream:      # body of SLAM.tracking (slam.py:214-218)
@@ -301,7 +317,9 @@ def main():
     log["stages"]["tracking"] = {"seconds": round(time.time() - t0, 2), "frames": a.frames, "keyframes": n_kf,
                                  "poses_finite": bool(torch.isfinite(poses).all()),
                                  "disps_finite": bool(torch.isfinite(slam.video.disps[:n_kf]).all()),
-                                 "max_translation": float(poses[:, :3].abs().max())}
+                                 "max_translation": float(poses[:, :3].abs().max()),
+                                 "loop_closure_ba_calls": loops["calls"],
+                                 "last_loop_ba_keyframes_edges": loops["last_keyframes_edges"]}
     t0 = time.time()
     slam.ba.frontend_window = min(slam.ba.frontend_window, max(1, n_kf - 2))       # (25 keyframes would be needed otherwise)
     slam.ba()
