@@ -289,9 +289,38 @@ __device__ __forceinline__ void lds_factor(double* Lp, double* invd, const int n
   for (int p0 = 0; p0 < n; p0 += PW) {
     const int pend = min(p0 + PW, n);                 // panel = columns [p0, pend)
     for (int k0 = p0; k0 < pend; k0 += CB) {
-      // (1) 6x6 diagonal block, redundantly in every wave that owns panel rows, registers
       const int s0 = k0 + CB;
-      const int rows = n + 1 - s0;
+      const int rows = n + 1 - s0;                    // rows below the diagonal block (the b row included)
+      // (0) LEFT-LOOKING inside the panel (round 4): bring this block column (columns k0 .. k0+5, rows k0 .. n) up to
+      // date with the panel's earlier blocks, A[r][k0+c] -= sum_{k in [p0,k0)} L[r][k] L[k0+c][k].  A thread owns one
+      // row and two of the six columns: it reads its row's <= 24 panel entries once and the pivot rows' entries as LDS
+      // multicasts (lanes of a wave share them).  The right-looking form this replaces updated ALL remaining panel
+      // columns after every block and re-read 7 doubles per (row, column): 168 LDS accesses per row and step against
+      // ~30 here -- that pass was LDS-bandwidth bound (19 of the 51 us of the factorisation at n = 150).
+      const int kw = k0 - p0;                         // panel columns already factored (0, 6, .. 24)
+      if (kw > 0) {
+        const int rr = tid / 3, cg = tid - 3 * rr;    // row k0 + rr, columns k0 + 2 cg, k0 + 2 cg + 1
+        if (rr < rows + CB) {
+          const int r = k0 + rr;
+          const double* Xr = Lp + tri(r, p0);
+          const int c0 = 2 * cg, c1 = c0 + 1;
+          const bool ok0 = k0 + c0 <= r && k0 + c0 < n, ok1 = k0 + c1 <= r && k0 + c1 < n;   // lower triangle only
+          const double* L0 = Lp + tri(min(k0 + c0, n - 1), p0);
+          const double* L1 = Lp + tri(min(k0 + c1, n - 1), p0);
+          double a0 = 0.0, a1 = 0.0;
+#pragma unroll 6
+          for (int k = 0; k < kw; ++k) {
+            const double x = Xr[k];
+            a0 = fma(x, L0[k], a0);
+            a1 = fma(x, L1[k], a1);
+          }
+          if (ok0) Lp[tri(r, k0 + c0)] -= a0;
+          if (ok1) Lp[tri(r, k0 + c1)] -= a1;
+        }
+        __syncthreads();
+      }
+      CHOL_ACC(2);
+      // (1) 6x6 diagonal block, redundantly in every wave that owns panel rows, registers
       const bool need = tid < ((max(rows, CB) + 63) & ~63);
       double l[CB][CB], inv[CB];
       if (need) {
@@ -316,9 +345,7 @@ __device__ __forceinline__ void lds_factor(double* Lp, double* invd, const int n
         }
       }
       CHOL_ACC(0);
-      // (2) panel rows (the b row included): x = a L11^-T, then (3) the rank-6 update of this row's
-      // remaining PANEL columns only; the matrix right of the panel is updated once per panel (4).
-      const int pc = pend - s0;                       // panel columns still to be factored
+      // (2) rows below the block (the b row included): x = a L11^-T
       if (tid < rows) {                               // rows <= 187: one thread per row
         double* Ar = Lp + tri(s0 + tid, k0);
         double x[CB];
@@ -334,7 +361,7 @@ __device__ __forceinline__ void lds_factor(double* Lp, double* invd, const int n
       }
       CHOL_ACC(1);
       __syncthreads();                                // x is visible; all reads of the old diagonal block are done
-      if (tid < CB) {                                 // ... so its factor can replace it (nothing below reads these rows)
+      if (tid < CB) {                                 // ... so its factor can replace it (only the backward pass reads it)
 #pragma unroll
         for (int i = 0; i < CB; ++i)
           if (i == tid) {
@@ -343,47 +370,6 @@ __device__ __forceinline__ void lds_factor(double* Lp, double* invd, const int n
             invd[k0 + i] = inv[i];
           }
       }
-      {                                               // 4 threads per row, columns interleaved
-        const int rq = tid >> 2, q = tid & 3;
-        if (rq < rows && pc > 0) {
-          const int r = s0 + rq;
-          const double* Xr = Lp + tri(r, k0);
-          double x[CB];
-#pragma unroll
-          for (int k = 0; k < CB; ++k) x[k] = Xr[k];
-          double* Ar = Lp + tri(r, s0);
-          const int cmax = min(pc, rq + 1);           // lower triangle: c <= r
-          // at most (PW - CB) / 4 = 6 columns per thread, two at a time: the LDS reads of both are issued before the
-          // first multiply-add (the rolled loop paid two dependent LDS round trips per column; all six at once spill:
-          // 1024 threads leave 128 VGPRs)
-          constexpr int NC = (PW - CB + 3) / 4;
-#pragma unroll
-          for (int it0 = 0; it0 < NC; it0 += 2) {
-            if (q + 4 * it0 >= cmax) break;
-            double lc[2][CB], av[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int c = min(q + 4 * (it0 + u), cmax - 1);
-              const double* Lc = Lp + tri(s0 + c, k0);
-#pragma unroll
-              for (int k = 0; k < CB; ++k) lc[u][k] = Lc[k];
-              av[u] = Ar[c];
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int c = q + 4 * (it0 + u);
-              if (c < cmax) {
-                double acc = 0.0;
-#pragma unroll
-                for (int k = 0; k < CB; ++k) acc = fma(x[k], lc[u][k], acc);
-                Ar[c] = av[u] - acc;
-              }
-            }
-          }
-        }
-      }
-      CHOL_ACC(2);
-      __syncthreads();
       CHOL_ACC(3);
     }
     // (4) rank-PW update of everything right of / below the panel on the fp64 matrix cores: one wave per 16x16
@@ -620,6 +606,30 @@ __global__ __launch_bounds__(SMALL_NT) void chol_mid_kernel(double* __restrict__
       for (int k0 = p0; k0 < pend; k0 += CB) {
         const int s0 = k0 + CB;
         const int rows = R - s0;                      // rows below the diagonal block (>= 1: the b row)
+        // left-looking inside the panel, as lds_factor: block column k0 .. k0+5 of rows k0 .. R-1 catches up with the
+        // panel's earlier blocks before it is factored
+        const int kw = k0 - p0;
+        if (kw > 0) {
+          const int cg = tid % 3;
+          for (int rr = tid < 3 * (SMALL_NT / 3) ? tid / 3 : R; rr < rows + CB; rr += SMALL_NT / 3) {   // (341 x 3 threads)
+            const int r = k0 + rr;
+            const double* Xr = T + r * SWP + p0;
+            const int c0 = 2 * cg, c1 = c0 + 1;
+            const bool ok0 = k0 + c0 <= r, ok1 = k0 + c1 <= r;
+            const double* L0 = T + (k0 + c0) * SWP + p0;
+            const double* L1 = T + (k0 + c1) * SWP + p0;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll 6
+            for (int k = 0; k < kw; ++k) {
+              const double x = Xr[k];
+              a0 = fma(x, L0[k], a0);
+              a1 = fma(x, L1[k], a1);
+            }
+            if (ok0) T[r * SWP + k0 + c0] -= a0;
+            if (ok1) T[r * SWP + k0 + c1] -= a1;
+          }
+          __syncthreads();
+        }
         const bool need = tid < ((max(rows, CB) + 63) & ~63);
         double l[CB][CB], inv[CB];
         if (need) {
@@ -666,27 +676,6 @@ __global__ __launch_bounds__(SMALL_NT) void chol_mid_kernel(double* __restrict__
               invd[c0 + k0 + i] = inv[i];
             }
         }
-        const int pc = pend - s0;                     // panel columns still to be factored
-        if (pc > 0) {                                 // rank-6 update of the rest of the panel, 4 threads per row
-          const int q = tid & 3;
-          for (int rq = tid >> 2; rq < rows; rq += SMALL_NT / 4) {
-            const int r = s0 + rq;
-            const double* Xr = T + r * SWP + k0;
-            double x[CB];
-#pragma unroll
-            for (int k = 0; k < CB; ++k) x[k] = Xr[k];
-            double* Ar = T + r * SWP + s0;
-            const int cmax = min(pc, rq + 1);         // lower triangle: local column s0 + c <= row r
-            for (int c = q; c < cmax; c += 4) {
-              const double* Lc = T + (s0 + c) * SWP + k0;
-              double acc = 0.0;
-#pragma unroll
-              for (int k = 0; k < CB; ++k) acc = fma(x[k], Lc[k], acc);
-              Ar[c] -= acc;
-            }
-          }
-        }
-        __syncthreads();
       }
       // rank-30 update of the stage's remaining columns [pend, SW) for rows >= pend (matrix cores, 16x16 tiles)
       if (pend < SW) {
