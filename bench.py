@@ -444,8 +444,9 @@ def neus_kernel_rooflines(device, n_rays, steps=5):
     """The kernels that own path M, timed LIVE with HIP events on the launch stream (the library's kernel timer,
     gs_timing_*): the eager fused mapper step on `n_rays` rays x 72 samples.  Algorithmic bytes per point:
     forward 512 B of grid gathers + 12 B in = 524 B; backward 512 B gathers + 512 B table-gradient scatter + 12 B =
-    1036 B; the bin reduce reads the backward's record queues (6 B per record, 128 records per point at most) and
-    writes the 11 hashed levels once.  `gather_rate` = 128 four-byte gathers per point / kernel time, against the
+    1036 B (since round 4 the production backward streams 256 B per point of forward records instead of gathering; the
+    algorithmic count stays SURVEY's); the bin reduce reads the backward's record queues (6 B per record, 128 records per
+    point at most) and writes the 11 hashed levels once.  `gather_rate` = 128 four-byte gathers per point / kernel time, against the
     measured ceiling of tools/gather_bench.hip."""
     import go_slam_amd.neus as neus
     from go_slam_amd import _lib
@@ -481,7 +482,7 @@ def neus_kernel_rooflines(device, n_rays, steps=5):
     nh = 11                         # hashed levels (2^19 entries x 4 B each)
     spec = [("neus_point", "neus_point_kernel (hash-grid encode + SDF linear + analytic gradient + alpha + MLP input row)",
              524.0 * pts, True),
-            ("neus_backward_points_binned", "neus_point_bwd_kernel<true> (re-gather + table-gradient records, pass 1 of bin-and-reduce)",
+            ("neus_backward_points_binned", "neus_point_bwd_kernel<binned, aux> (streams the forward's per-level records, table-gradient records = pass 1 of bin-and-reduce)",
              1036.0 * pts, True),
             ("grid_bin_reduce", "grid_bin_reduce_kernel (pass 2: exact integer LDS sums per 8192-entry bin)",
              6.0 * 88.0 * pts + nh * (1 << 19) * 4.0 * 2, False),
@@ -684,7 +685,10 @@ def main():
         algo_bytes = 912.0 * ht * wd * br["edges"]            # 912*HW B per edge per lookup
         t_s = br["corr_lookup_ms"] * 1e-3
         achieved = algo_bytes / t_s / 1e9
-        bgb = br["corr_build_bytes"] / (br["corr_build_8edges_ms"] * 1e-3) / 1e9
+        # 2.656 HW^2 bytes per edge (inputs + the four levels written once); the tile8 layout this launch
+        # writes pads levels 0-1 to 8x8 tiles (+6.7 % at 60x80) -- the padded count is reported next to it, not used
+        vol_algo = 8 * (2 * 128 * ht * wd * 2 + 2.0 * (ht * wd) ** 2 * (1 + 0.25 + 1 / 16 + 1 / 64))
+        bgb = vol_algo / (br["corr_build_8edges_ms"] * 1e-3) / 1e9
         line["roofline_other"] = []
         if "corr_lookup_enc0_ms" in br:      # the production lookup: fused with corr_encoder[0]
             fb = (4 * 64 * 2 + 8 + 128 * 2) * ht * wd * br["edges"]       # window reads + coords + 128 fp16 outputs per pixel
@@ -694,7 +698,10 @@ def main():
                            "bias + ReLU; the 196-channel features never reach HBM)", "bound": "hbm", "achieved": fa,
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fa / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": fb,
                  "kernel_avg_us": br["corr_lookup_enc0_ms"] * 1e3,
-                 "replaces_us": (br["corr_lookup_ms"] * 1e3, "+ conv1x1 196->128"), **pmc_traffic("r03_pmc_corr_lookup.json")})
+                 "replaces_us": (br["corr_lookup_ms"] * 1e3, "+ conv1x1 196->128"),
+                 "note": "not HBM-bound in the roofline sense: the 8x8 windows over-fetch 2.4x (traffic 1.93x algorithmic) and "
+                         "the layout model (profiles/r03_lookup_layout_model.json) finds at most -21 % from re-tiling: 0.28 is "
+                         "the floor of this design", **pmc_traffic("r03_pmc_corr_lookup.json")})
         line["roofline_other"] += [
             dict({"kernel": "corr_pyramid_coop_kernel<tile8> (fp16 NHWC, wave-cooperative fused 4-level lookup; the "
                             "unfused ABI entry)",
@@ -704,7 +711,8 @@ def main():
                  **pmc_traffic("r03_pmc_corr_lookup.json", "traffic_bytes_per_launch_unfused")),
             dict({"kernel": "corr_volume_kernel (MFMA all-pairs volume + 3 pooled levels, written once)", "bound": "hbm",
                   "achieved": bgb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bgb / HBM_PEAK_GBS,
-                  "bytes_per_launch": br["corr_build_bytes"],
+                  "algorithmic_bytes_per_launch": vol_algo, "bytes_written_with_tile8_padding": br["corr_build_bytes"],
+                  "kernel_avg_us": br["corr_build_8edges_ms"] * 1e3,
                   "note": "8 edges per launch (one keyframe's new factors); the time includes the operand re-ordering "
                           "and level-3 pooling launches; HBM traffic = algorithmic; a tile's life is dominated by its "
                           "operand loads queueing behind the CU's stores (phase timeline in DESIGN 3)"},
