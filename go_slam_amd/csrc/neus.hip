@@ -270,6 +270,148 @@ __global__ __launch_bounds__(256) void grid_encode_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------
+// fused MLP on MFMA.  H^T[neuron][point] = W[neuron][k] X^T[k][point]
+//   A operand (32 neurons x 16 k): lane l holds W[32*mt + (l&31)][16*ks + 8*(l>>5) .. +7]
+//   B operand (16 k x 32 points) : lane l holds X[32*nt + (l&31)][16*ks + 8*(l>>5) .. +7]
+//   C (32 neurons x 32 points)   : lane l, reg r -> neuron 32*mt + (r&3) + 8*(r>>2) + 4*(l>>5),
+//                                  point 32*nt + (l&31)
+// ---------------------------------------------------------------------------------------
+constexpr int HS = 72;   // LDS row stride (halfs) of the wave-private activation tile [64][64]
+
+__device__ __forceinline__ half8 ld8(const _Float16* p) { return *reinterpret_cast<const half8*>(p); }
+
+template <bool RELU>
+__device__ __forceinline__ void store_act(_Float16* hs, const float16v& c, int mt, int nt, int lane) {
+  const int point = 32 * nt + (lane & 31);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    half4 pk;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v = c[q * 4 + k];
+      if (RELU) v = fmaxf(v, 0.0f);
+      pk[k] = (_Float16)v;
+    }
+    *reinterpret_cast<half4*>(hs + point * HS + 32 * mt + 8 * q + 4 * (lane >> 5)) = pk;
+  }
+}
+
+
+// The colour MLP of ONE wave's 64 points, rows in a wave-private LDS tile xs[64][XS] (fp16, 80 columns used):
+// what neus_mlp_kernel does per tile, with the weights fetched per layer from L1 / L2 (10 KB, shared by every wave of
+// the launch) instead of living in 88 registers for a whole launch, and the activations written back into the SAME
+// tile (row stride XS).  Returns the 16 output rows x 2 x 32 points accumulators (neurons 0..3 = regs 0..3 of lanes 0..31).
+constexpr int XS = 80;   // halves per row (160 B: four 40 KB workgroups fit a CU; 88 would make the b128 reads conflict-free but only three fit)
+
+template <bool RELU>
+__device__ __forceinline__ void store_act_xs(_Float16* xs, const float16v& c, int mt, int nt, int lane) {
+  const int point = 32 * nt + (lane & 31);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    half4 pk;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v = c[q * 4 + k];
+      if (RELU) v = fmaxf(v, 0.0f);
+      pk[k] = (_Float16)v;
+    }
+    *reinterpret_cast<half4*>(xs + point * XS + 32 * mt + 8 * q + 4 * (lane >> 5)) = pk;
+  }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void wave_mlp64(_Float16* xs, const _Float16* __restrict__ w, int lane, float16v (&co)[2]) {
+  const _Float16* W1 = w;                 // [64][80]
+  const _Float16* W2 = w + 64 * 80;       // [64][64]
+  const _Float16* W3 = w + 64 * 80 + 64 * 64;   // [16][64]
+  const int r = lane & 31, kh = 8 * (lane >> 5);
+  float16v c[2][2];
+  // ---- layer 1
+  {
+    half8 a[2][5];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) a[mt][ks] = ld8(W1 + (32 * mt + r) * 80 + 16 * ks + kh);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[mt][nt][e] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {
+        const half8 b = ld8(xs + (32 * nt + r) * XS + 16 * ks + kh);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][ks], b, c[mt][nt], 0, 0, 0);
+      }
+  }
+  wave_lds_sync();                        // every lane has read its input rows: the tile now takes the activations
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) store_act_xs<true>(xs, c[mt][nt], mt, nt, lane);
+  wave_lds_sync();
+  // ---- layer 2
+  {
+    half8 a[2][4], bfr[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[mt][ks] = ld8(W2 + (32 * mt + r) * 64 + 16 * ks + kh);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bfr[nt][ks] = ld8(xs + (32 * nt + r) * XS + 16 * ks + kh);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[mt][nt][e] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][ks], bfr[nt][ks], c[mt][nt], 0, 0, 0);
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) store_act_xs<true>(xs, c[mt][nt], mt, nt, lane);
+  wave_lds_sync();
+  // ---- output layer (16 rows, padded to the 32-row tile with zero weights)
+  {
+    half8 a3[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      a3[ks] = (r < 16) ? ld8(W3 + r * 64 + 16 * ks + kh) : z;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) co[nt][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const half8 b = ld8(xs + (32 * nt + r) * XS + 16 * ks + kh);
+        co[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3[ks], b, co[nt], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // per-point stage
 // ---------------------------------------------------------------------------------------
 struct NeusArgs {
@@ -314,133 +456,144 @@ __global__ __launch_bounds__(256) void neus_count_kernel(NeusArgs A, int32_t* __
   if (__ballot(in) != 0ull && (threadIdx.x & 63) == 0) *count = 1;
 }
 
+// Since round 4 the colour MLP runs in this kernel's tail (wave_mlp64): the 80-wide input row of every point goes into a
+// wave-private LDS tile and the wave evaluates its 64 points on the matrix cores -- at render time the rows never reach
+// HBM (47 MB written + read per 4096-ray batch before) and a launch is gone; the training path still saves them
+// (`mlp_in` != nullptr) for gs_mlp_backward.  All 64 lanes stay until the end (the MFMAs are wave-wide): out-of-bound
+// and past-the-end lanes contribute zero rows.
 __global__ __launch_bounds__(256) void neus_point_kernel(NeusArgs A, gs_grid_meta m, const int32_t* __restrict__ count,
                                                          float* __restrict__ sdf_out, float* __restrict__ zmid_out,
                                                          float* __restrict__ alpha_out, float* __restrict__ grad_out,
                                                          uint8_t* __restrict__ mask_out, _Float16* __restrict__ mlp_in,
-                                                         _Float16* __restrict__ enc_aux) {
+                                                         _Float16* __restrict__ enc_aux, const _Float16* __restrict__ mlp_w,
+                                                         _Float16* __restrict__ rgb_out) {
+  __shared__ __attribute__((aligned(16))) _Float16 xs_all[4 * 64 * XS];
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= A.n * A.s) return;
-  float pt[3], dir[3], zm, dist;
-  bool in = point_of(A, idx, pt, dir, zm, dist);
-  if (*count < 1 && idx < 100) in = true;          // InstantNeuS.py:311-312
-  zmid_out[idx] = zm;
-  mask_out[idx] = in ? 1 : 0;
+  const int np = A.n * A.s;
+  const bool valid = idx < np;
+  const int lane = threadIdx.x & 63;
+  _Float16* xs = xs_all + (threadIdx.x >> 6) * 64 * XS;
+  half8* xrow = reinterpret_cast<half8*>(xs + lane * XS);
+  float pt[3], dir[3], zm = 0.f, dist = 0.f;
+  bool in = false;
+  if (valid) {
+    in = point_of(A, idx, pt, dir, zm, dist);
+    if (*count < 1 && idx < 100) in = true;        // InstantNeuS.py:311-312
+    zmid_out[idx] = zm;
+    mask_out[idx] = in ? 1 : 0;
+  }
   if (!in) {                                        // sdf = 100, grad = feat = rgb = 0, alpha * mask = 0
-    sdf_out[idx] = 100.0f;
-    alpha_out[idx] = 0.0f;
-    grad_out[idx * 3 + 0] = 0.f; grad_out[idx * 3 + 1] = 0.f; grad_out[idx * 3 + 2] = 0.f;
-    // keep the MLP input row finite: the training path runs GEMMs over ALL rows (0 * NaN = NaN)
-    half8* dst = reinterpret_cast<half8*>(mlp_in + (size_t)idx * 80);
     const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (valid) {
+      sdf_out[idx] = 100.0f;
+      alpha_out[idx] = 0.0f;
+      grad_out[idx * 3 + 0] = 0.f; grad_out[idx * 3 + 1] = 0.f; grad_out[idx * 3 + 2] = 0.f;
+      if (mlp_in) {   // keep the saved MLP input row finite: the training path runs GEMMs over ALL rows (0 * NaN = NaN)
+        half8* dst = reinterpret_cast<half8*>(mlp_in + (size_t)idx * 80);
 #pragma unroll
-    for (int q = 0; q < 10; ++q) dst[q] = zero;
-    return;
-  }
-  // normalized_3d_coordinate (InstantNeuS.py:12-32) with the STATIC bound, clamped to [-1,1]
-  float p[3], view[3], inside[3], span[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    span[d] = A.bound[2 * d + 1] - A.bound[2 * d];
-    float q = (pt[d] - A.bound[2 * d]) / span[d] * 2.0f - 1.0f;
-    inside[d] = (q >= -1.0f && q <= 1.0f) ? 1.0f : 0.0f;
-    q = fminf(fmaxf(q, -1.0f), 1.0f);
-    p[d] = q;
-    view[d] = (q + 1.0f) / 2.0f;
-  }
-  // Linear(35 -> 32): xyz part first, then one level (2 inputs) at a time
-  float out[32];
-#pragma unroll
-  for (int o = 0; o < 32; ++o) {
-    float acc = 0.f;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) acc = fmaf(A.sdf_w[o * 35 + d], p[d], acc);
-    out[o] = acc;
-  }
-  float gview[3] = {0.f, 0.f, 0.f};
-#pragma unroll 1
-  for (int l = 0; l < GS_GRID_LEVELS; ++l) {
-    float val[2], dv[3][2];
-    grid_level(m, l, A.grid, view, val, dv, true);
-    const float e0 = (float)(_Float16)val[0], e1 = (float)(_Float16)val[1];   // encoding output is fp16
-    if (enc_aux) {    // training: what the backward needs of this level's 8 corner values -- the encoding and d enc / d x --
-                      // as one 16-byte record [level][point][8], so that it streams them instead of gathering again
-      half8 rec;
-      rec[0] = (_Float16)val[0]; rec[1] = (_Float16)val[1];
-      rec[2] = (_Float16)dv[0][0]; rec[3] = (_Float16)dv[1][0]; rec[4] = (_Float16)dv[2][0];
-      rec[5] = (_Float16)dv[0][1]; rec[6] = (_Float16)dv[1][1]; rec[7] = (_Float16)dv[2][1];
-      *reinterpret_cast<half8*>(enc_aux + ((size_t)l * ((size_t)A.n * A.s) + idx) * 8) = rec;
+        for (int q = 0; q < 10; ++q) dst[q] = zero;
+      }
     }
-    const float* wl = A.sdf_w + 3 + 2 * l;
 #pragma unroll
-    for (int o = 0; o < 32; ++o) out[o] = fmaf(wl[o * 35 + 1], e1, fmaf(wl[o * 35], e0, out[o]));
-    const float g0 = (float)(_Float16)wl[0], g1 = (float)(_Float16)wl[1];     // dL/d enc arrives as fp16
-#pragma unroll
-    for (int d = 0; d < 3; ++d) gview[d] = fmaf(g1, dv[d][1], fmaf(g0, dv[d][0], gview[d]));
-  }
-#pragma unroll
-  for (int o = 0; o < 32; ++o) out[o] = out[o] + A.sdf_b[o];
-  const float sdf = out[0];
-  float grad[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) grad[d] = (A.sdf_w[d] + gview[d] / 2.0f) * inside[d] * 2.0f / span[d];
-  // NeuS alpha (InstantNeuS.py:276-293), cos_anneal_ratio = 1
-  const float true_cos = (dir[0] * grad[0] + dir[1] * grad[1]) + dir[2] * grad[2];
-  const float iter_cos = -(fmaxf(-true_cos * 0.5f + 0.5f, 0.0f) * 0.0f + fmaxf(-true_cos, 0.0f) * 1.0f);
-  const float est_next = sdf + iter_cos * dist / 2.0f;
-  const float est_prev = sdf - iter_cos * dist / 2.0f;
-  const float inv_s_ = A.inv_s_dev ? *A.inv_s_dev : A.inv_s;
-  const float prev_cdf = 1.0f / (1.0f + expf(-(est_prev * inv_s_)));
-  const float next_cdf = 1.0f / (1.0f + expf(-(est_next * inv_s_)));
-  float alpha = (prev_cdf - next_cdf + 1e-5f) / (prev_cdf + 1e-5f);
-  alpha = fminf(fmaxf(alpha, 0.0f), 1.0f);
-  sdf_out[idx] = sdf;
-  alpha_out[idx] = alpha;
-  grad_out[idx * 3 + 0] = grad[0]; grad_out[idx * 3 + 1] = grad[1]; grad_out[idx * 3 + 2] = grad[2];
-  // colour-MLP input row: sin(pts @ B) (33) | normals (3) | feat (31) | ones (13), emitted eight
-  // columns (16 B) at a time so the row never sits in registers as a whole
-  half8* dst = reinterpret_cast<half8*>(mlp_in + (size_t)idx * 80);
-#pragma unroll
-  for (int q = 0; q < 10; ++q) {
-    half8 pk;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int c = q * 8 + k;
-      float v;
-      if (c < 33) v = sinf((pt[0] * A.color_B[c] + pt[1] * A.color_B[33 + c]) + pt[2] * A.color_B[66 + c]);
-      else if (c < 36) v = grad[c - 33];
-      else if (c < 67) v = out[1 + (c - 36)];
-      else v = 1.0f;
-      pk[k] = (_Float16)v;
+    for (int q = 0; q < 10; ++q) xrow[q] = zero;
+  } else {
+    // normalized_3d_coordinate (InstantNeuS.py:12-32) with the STATIC bound, clamped to [-1,1]
+    float p[3], view[3], inside[3], span[3];
+  #pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      span[d] = A.bound[2 * d + 1] - A.bound[2 * d];
+      float q = (pt[d] - A.bound[2 * d]) / span[d] * 2.0f - 1.0f;
+      inside[d] = (q >= -1.0f && q <= 1.0f) ? 1.0f : 0.0f;
+      q = fminf(fmaxf(q, -1.0f), 1.0f);
+      p[d] = q;
+      view[d] = (q + 1.0f) / 2.0f;
     }
-    dst[q] = pk;
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// fused MLP on MFMA.  H^T[neuron][point] = W[neuron][k] X^T[k][point]
-//   A operand (32 neurons x 16 k): lane l holds W[32*mt + (l&31)][16*ks + 8*(l>>5) .. +7]
-//   B operand (16 k x 32 points) : lane l holds X[32*nt + (l&31)][16*ks + 8*(l>>5) .. +7]
-//   C (32 neurons x 32 points)   : lane l, reg r -> neuron 32*mt + (r&3) + 8*(r>>2) + 4*(l>>5),
-//                                  point 32*nt + (l&31)
-// ---------------------------------------------------------------------------------------
-constexpr int HS = 72;   // LDS row stride (halfs) of the wave-private activation tile [64][64]
-
-__device__ __forceinline__ half8 ld8(const _Float16* p) { return *reinterpret_cast<const half8*>(p); }
-
-template <bool RELU>
-__device__ __forceinline__ void store_act(_Float16* hs, const float16v& c, int mt, int nt, int lane) {
-  const int point = 32 * nt + (lane & 31);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    half4 pk;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float v = c[q * 4 + k];
-      if (RELU) v = fmaxf(v, 0.0f);
-      pk[k] = (_Float16)v;
+    // Linear(35 -> 32): xyz part first, then one level (2 inputs) at a time
+    float out[32];
+  #pragma unroll
+    for (int o = 0; o < 32; ++o) {
+      float acc = 0.f;
+  #pragma unroll
+      for (int d = 0; d < 3; ++d) acc = fmaf(A.sdf_w[o * 35 + d], p[d], acc);
+      out[o] = acc;
     }
-    *reinterpret_cast<half4*>(hs + point * HS + 32 * mt + 8 * q + 4 * (lane >> 5)) = pk;
+    float gview[3] = {0.f, 0.f, 0.f};
+  #pragma unroll 1
+    for (int l = 0; l < GS_GRID_LEVELS; ++l) {
+      float val[2], dv[3][2];
+      grid_level(m, l, A.grid, view, val, dv, true);
+      const float e0 = (float)(_Float16)val[0], e1 = (float)(_Float16)val[1];   // encoding output is fp16
+      if (enc_aux) {    // training: what the backward needs of this level's 8 corner values -- the encoding and d enc / d x --
+                        // as one 16-byte record [level][point][8], so that it streams them instead of gathering again
+        half8 rec;
+        rec[0] = (_Float16)val[0]; rec[1] = (_Float16)val[1];
+        rec[2] = (_Float16)dv[0][0]; rec[3] = (_Float16)dv[1][0]; rec[4] = (_Float16)dv[2][0];
+        rec[5] = (_Float16)dv[0][1]; rec[6] = (_Float16)dv[1][1]; rec[7] = (_Float16)dv[2][1];
+        *reinterpret_cast<half8*>(enc_aux + ((size_t)l * ((size_t)A.n * A.s) + idx) * 8) = rec;
+      }
+      const float* wl = A.sdf_w + 3 + 2 * l;
+  #pragma unroll
+      for (int o = 0; o < 32; ++o) out[o] = fmaf(wl[o * 35 + 1], e1, fmaf(wl[o * 35], e0, out[o]));
+      const float g0 = (float)(_Float16)wl[0], g1 = (float)(_Float16)wl[1];     // dL/d enc arrives as fp16
+  #pragma unroll
+      for (int d = 0; d < 3; ++d) gview[d] = fmaf(g1, dv[d][1], fmaf(g0, dv[d][0], gview[d]));
+    }
+  #pragma unroll
+    for (int o = 0; o < 32; ++o) out[o] = out[o] + A.sdf_b[o];
+    const float sdf = out[0];
+    float grad[3];
+  #pragma unroll
+    for (int d = 0; d < 3; ++d) grad[d] = (A.sdf_w[d] + gview[d] / 2.0f) * inside[d] * 2.0f / span[d];
+    // NeuS alpha (InstantNeuS.py:276-293), cos_anneal_ratio = 1
+    const float true_cos = (dir[0] * grad[0] + dir[1] * grad[1]) + dir[2] * grad[2];
+    const float iter_cos = -(fmaxf(-true_cos * 0.5f + 0.5f, 0.0f) * 0.0f + fmaxf(-true_cos, 0.0f) * 1.0f);
+    const float est_next = sdf + iter_cos * dist / 2.0f;
+    const float est_prev = sdf - iter_cos * dist / 2.0f;
+    const float inv_s_ = A.inv_s_dev ? *A.inv_s_dev : A.inv_s;
+    const float prev_cdf = 1.0f / (1.0f + expf(-(est_prev * inv_s_)));
+    const float next_cdf = 1.0f / (1.0f + expf(-(est_next * inv_s_)));
+    float alpha = (prev_cdf - next_cdf + 1e-5f) / (prev_cdf + 1e-5f);
+    alpha = fminf(fmaxf(alpha, 0.0f), 1.0f);
+    sdf_out[idx] = sdf;
+    alpha_out[idx] = alpha;
+    grad_out[idx * 3 + 0] = grad[0]; grad_out[idx * 3 + 1] = grad[1]; grad_out[idx * 3 + 2] = grad[2];
+    // colour-MLP input row: sin(pts @ B) (33) | normals (3) | feat (31) | ones (13), emitted eight
+    // columns (16 B) at a time so the row never sits in registers as a whole
+    half8* dst = mlp_in ? reinterpret_cast<half8*>(mlp_in + (size_t)idx * 80) : nullptr;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      half8 pk;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = q * 8 + k;
+        float v;
+        if (c < 33) v = sinf((pt[0] * A.color_B[c] + pt[1] * A.color_B[33 + c]) + pt[2] * A.color_B[66 + c]);
+        else if (c < 36) v = grad[c - 33];
+        else if (c < 67) v = out[1 + (c - 36)];
+        else v = 1.0f;
+        pk[k] = (_Float16)v;
+      }
+      if (dst) dst[q] = pk;
+      xrow[q] = pk;
+    }
+  }
+  // ---- the colour MLP of this wave's 64 points (tcnn FullyFusedMLP 67(->80)->64->64->3, ReLU, then sigmoid)
+  wave_lds_sync();
+  float16v co[2];
+  wave_mlp64(xs, mlp_w, lane, co);
+  const int wave_p0 = blockIdx.x * 256 + (threadIdx.x >> 6) * 64;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int on = __shfl((int)in, (32 * nt + lane) & 63, 64);
+    const int pnt = wave_p0 + 32 * nt + lane;
+    if (lane < 32 && pnt < np) {
+#pragma unroll
+      for (int o = 0; o < 3; ++o) {
+        float v = (float)(_Float16)co[nt][o];      // network output is fp16
+        v = 1.0f / (1.0f + expf(-v));
+        rgb_out[(size_t)pnt * 3 + o] = on ? (_Float16)v : (_Float16)0.0f;
+      }
+    }
   }
 }
 
@@ -797,18 +950,15 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
   float* grad = grad_out ? grad_out : ws.grad;
   _Float16* rgb = rgb_out ? (_Float16*)rgb_out : ws.rgb;
   if (mask_out) ws.mask = mask_out;
-  if (mlp_in_out) ws.mlp_in = (_Float16*)mlp_in_out;
   if (hipMemsetAsync(ws.count, 0, 4, st) != hipSuccess) { gs_set_error("neus_forward: memset failed"); return GS_ERR_LAUNCH; }
   neus_count_kernel<<<gs_cdiv(np, 256), 256, 0, st>>>(A, ws.count);
   GS_CHECK_LAUNCH("neus_count");
   GS_TIMING_PRE();
+  // (the colour MLP runs in the point kernel's tail; the MLP input rows reach memory only when the caller saves them)
   neus_point_kernel<<<gs_cdiv(np, 256), 256, 0, st>>>(A, host_meta(), ws.count, sdf, z_mid, alpha, grad, ws.mask,
-                                                      ws.mlp_in, (_Float16*)enc_aux_out);
+                                                      (_Float16*)mlp_in_out, (_Float16*)enc_aux_out, (const _Float16*)mlp,
+                                                      rgb);
   GS_CHECK_LAUNCH("neus_point");
-  const int n_tiles = gs_cdiv(np, 64);
-  const int grid_mlp = gs_cdiv(n_tiles, 4) < 1024 ? gs_cdiv(n_tiles, 4) : 1024;
-  neus_mlp_kernel<<<grid_mlp, 256, 0, st>>>(ws.mlp_in, 80, (const _Float16*)mlp, ws.mask, rgb, 3, 3, np, 1, n_tiles);
-  GS_CHECK_LAUNCH("neus_mlp");
   neus_ray_kernel<<<gs_cdiv(n, 4), 256, 0, st>>>(alpha, rgb, z_mid, grad, ws.mask, color, depth, depth_var, normal,
                                                    weight_sum, grad_err_ray, n, s);
   GS_CHECK_LAUNCH("neus_ray");
