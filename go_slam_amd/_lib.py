@@ -81,7 +81,7 @@ SIGNATURES = {
     "gs_mlp_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gs_mlp_forward": (c_int, [_P] * 3 + [c_int] * 3 + [_P, c_size_t, _P]),
     "gs_neus_forward_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "gs_neus_forward": (c_int, [_P] * 9 + [c_float] + [_P] * 18 + [c_int, c_int, _P, c_size_t, _P]),
+    "gs_neus_forward": (c_int, [_P] * 9 + [c_float] + [_P] * 18 + [c_float, _P, c_float, c_int, c_int, _P, c_size_t, _P]),
     "gs_neus_backward_rays": (c_int, [_P] * 13 + [c_int, c_int, _P]),
     "gs_mapping_loss": (c_int, [_P] * 8 + [c_float] * 4 + [c_int] + [_P] * 4 + [c_int, c_int, _P]),
     "gs_map_grad_sqnorm": (c_int, [_P, c_size_t, c_float, _P, c_size_t, _P, _P]),

@@ -3,8 +3,8 @@
 //
 //   render_sample_kernel   one lane per ray: ray/AABB far bound, stratified + near-surface
 //                          samples, merge of the two sorted runs (= the reference's torch.sort)
-//   neus_count_kernel      in-bound count (the reference forces the first 100 points valid when
-//                          no point is in bound, InstantNeuS.py:311-312)
+//   (the reference forces the first 100 points valid when no point is in bound, InstantNeuS.py:311-312: a
+//    one-workgroup second pass of neus_point_kernel)
 //   neus_point_kernel      one lane per sample point: 16-level hash-grid gathers (8 corners x
 //                          2 fp16 features = one 4-byte load each; the table is L2/MALL resident),
 //                          the SDF linear row streamed level by level, the ANALYTIC d sdf/d x
@@ -447,21 +447,17 @@ __device__ __forceinline__ bool point_of(const NeusArgs& A, int idx, float pt[3]
   return (pt[0] < rb[1]) && (pt[0] > rb[0]) && (pt[1] < rb[3]) && (pt[1] > rb[2]) && (pt[2] < rb[5]) && (pt[2] > rb[4]);
 }
 
-// "is any point in bound?" -- only the predicate matters (InstantNeuS.py:311), so waves that see
-// an in-bound point store 1 (same value from everyone, no atomics, no contention).
-__global__ __launch_bounds__(256) void neus_count_kernel(NeusArgs A, int32_t* __restrict__ count) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  float pt[3], dir[3], zm, dist;
-  const bool in = (idx < A.n * A.s) && point_of(A, idx, pt, dir, zm, dist);
-  if (__ballot(in) != 0ull && (threadIdx.x & 63) == 0) *count = 1;
-}
-
 // Since round 4 the colour MLP runs in this kernel's tail (wave_mlp64): the 80-wide input row of every point goes into a
 // wave-private LDS tile and the wave evaluates its 64 points on the matrix cores -- at render time the rows never reach
 // HBM (47 MB written + read per 4096-ray batch before) and a launch is gone; the training path still saves them
 // (`mlp_in` != nullptr) for gs_mlp_backward.  All 64 lanes stay until the end (the MFMAs are wave-wide): out-of-bound
 // and past-the-end lanes contribute zero rows.
-__global__ __launch_bounds__(256) void neus_point_kernel(NeusArgs A, gs_grid_meta m, const int32_t* __restrict__ count,
+// `count` (zeroed by the caller): the main pass sets it when ANY point lies in the realtime bound; the reference forces
+// the first 100 points valid when none does (InstantNeuS.py:311-312), which a second launch of this kernel with
+// force_pass = 1 and ONE workgroup handles: it returns at once unless count is still 0 (a 3 us launch instead of the
+// full-size neus_count_kernel pass over all points that used to precede the main pass).
+__global__ __launch_bounds__(256) void neus_point_kernel(NeusArgs A, gs_grid_meta m, int32_t* __restrict__ count,
+                                                         int force_pass,
                                                          float* __restrict__ sdf_out, float* __restrict__ zmid_out,
                                                          float* __restrict__ alpha_out, float* __restrict__ grad_out,
                                                          uint8_t* __restrict__ mask_out, _Float16* __restrict__ mlp_in,
@@ -476,12 +472,14 @@ __global__ __launch_bounds__(256) void neus_point_kernel(NeusArgs A, gs_grid_met
   half8* xrow = reinterpret_cast<half8*>(xs + lane * XS);
   float pt[3], dir[3], zm = 0.f, dist = 0.f;
   bool in = false;
+  if (force_pass && *count >= 1) return;            // (uniform: some point was in bound, nothing to force)
   if (valid) {
     in = point_of(A, idx, pt, dir, zm, dist);
-    if (*count < 1 && idx < 100) in = true;        // InstantNeuS.py:311-312
+    if (force_pass && idx < 100) in = true;         // InstantNeuS.py:311-312
     zmid_out[idx] = zm;
     mask_out[idx] = in ? 1 : 0;
   }
+  if (!force_pass && __ballot(in) != 0ull && lane == 0) *count = 1;   // same value from everyone: no atomics
   if (!in) {                                        // sdf = 100, grad = feat = rgb = 0, alpha * mask = 0
     const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     if (valid) {
@@ -737,7 +735,8 @@ __global__ __launch_bounds__(256) void neus_ray_kernel(const float* __restrict__
                                                        const uint8_t* __restrict__ mask, float* __restrict__ color,
                                                        float* __restrict__ depth, float* __restrict__ depth_var,
                                                        float* __restrict__ normal, float* __restrict__ weight_sum,
-                                                       float* __restrict__ gerr, int n, int s) {
+                                                       float* __restrict__ gerr, float gerr_scale,
+                                                       float* __restrict__ sdf_var_out, float sdf_var_value, int n, int s) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n) return;
@@ -797,7 +796,8 @@ __global__ __launch_bounds__(256) void neus_ray_kernel(const float* __restrict__
     depth[r] = dep;
     depth_var[r] = var;
     weight_sum[r] = wsum;
-    gerr[r] = ge;
+    gerr[r] = ge * gerr_scale;
+    if (sdf_var_out) sdf_var_out[r] = sdf_var_value;
   }
 }
 
@@ -922,7 +922,8 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
                                const float* rt_bound_host, const float* rt_bound_dev,
                                float* color, float* depth, float* depth_var, float* normal, float* weight_sum,
                                float* sdf, float* z_mid, float* grad_err_ray, float* alpha_out, void* rgb_out,
-                               float* grad_out, uint8_t* mask_out, void* mlp_in_out, void* enc_aux_out, int n, int s,
+                               float* grad_out, uint8_t* mask_out, void* mlp_in_out, void* enc_aux_out, float grad_err_scale,
+                               float* sdf_variance_out, float sdf_variance_value, int n, int s,
                                void* workspace, size_t workspace_bytes, gs_stream_t stream) {
   GS_REQUIRE(rays_o && rays_d && z_vals && dists && grid && sdf_w && sdf_b && color_B && mlp && bound_host &&
                  rt_bound_host, "neus_forward: null input");
@@ -951,16 +952,18 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
   _Float16* rgb = rgb_out ? (_Float16*)rgb_out : ws.rgb;
   if (mask_out) ws.mask = mask_out;
   if (hipMemsetAsync(ws.count, 0, 4, st) != hipSuccess) { gs_set_error("neus_forward: memset failed"); return GS_ERR_LAUNCH; }
-  neus_count_kernel<<<gs_cdiv(np, 256), 256, 0, st>>>(A, ws.count);
-  GS_CHECK_LAUNCH("neus_count");
   GS_TIMING_PRE();
   // (the colour MLP runs in the point kernel's tail; the MLP input rows reach memory only when the caller saves them)
-  neus_point_kernel<<<gs_cdiv(np, 256), 256, 0, st>>>(A, host_meta(), ws.count, sdf, z_mid, alpha, grad, ws.mask,
+  neus_point_kernel<<<gs_cdiv(np, 256), 256, 0, st>>>(A, host_meta(), ws.count, 0, sdf, z_mid, alpha, grad, ws.mask,
                                                       (_Float16*)mlp_in_out, (_Float16*)enc_aux_out, (const _Float16*)mlp,
                                                       rgb);
   GS_CHECK_LAUNCH("neus_point");
+  neus_point_kernel<<<1, 256, 0, st>>>(A, host_meta(), ws.count, 1, sdf, z_mid, alpha, grad, ws.mask,
+                                       (_Float16*)mlp_in_out, (_Float16*)enc_aux_out, (const _Float16*)mlp, rgb);
+  GS_CHECK_LAUNCH("neus_force100");
   neus_ray_kernel<<<gs_cdiv(n, 4), 256, 0, st>>>(alpha, rgb, z_mid, grad, ws.mask, color, depth, depth_var, normal,
-                                                   weight_sum, grad_err_ray, n, s);
+                                                   weight_sum, grad_err_ray, grad_err_scale, sdf_variance_out,
+                                                   sdf_variance_value, n, s);
   GS_CHECK_LAUNCH("neus_ray");
   return GS_OK;
 }

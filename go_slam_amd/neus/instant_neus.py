@@ -242,9 +242,17 @@ class InstantNeuS(nn.Module):
                 net.encoding.encoding.params, net.sdf_layer.weight, net.sdf_layer.bias, self.color_network._B,
                 self.color_network.network.params, self.variance_network.variance)
         else:
+            # no gradients: `gradient_error` (mean over all points) and `sdf_variance` come out of the ray kernel -- the
+            # per-ray eikonal sums pre-scaled by 1 / (n s), the variance column filled there -- instead of three more
+            # one-workgroup torch launches per batch
+            sv = torch.empty(n, 1, **f32)
             color, depth, dvar, normal, wsum, sdf, gerr, zmid = _neus_forward_raw(
                 self, rays_o.detach().float().contiguous(), rays_d.detach().float().contiguous(),
-                z_vals.detach().float().contiguous(), dists.detach().float().contiguous(), inv_s, save=False)[:8]
+                z_vals.detach().float().contiguous(), dists.detach().float().contiguous(), inv_s, save=False,
+                gerr_scale=(1.0 / float(n * s)) if n * s else float("nan"), sdf_var=sv,
+                sdf_var_value=1.0 / math.exp(var * self.variance_network.scale_factor))[:8]
+            return {"color": color, "depth": depth, "depth_variance": dvar, "normal": normal, "weight_sum": wsum,
+                    "sdf_variance": sv, "sdf": sdf, "z_vals": zmid, "gradient_error": gerr.sum().unsqueeze(0)}
         return {
             "color": color, "depth": depth, "depth_variance": dvar, "normal": normal, "weight_sum": wsum,
             "sdf_variance": torch.full((n, 1), 1.0 / math.exp(var * self.variance_network.scale_factor), **f32),
@@ -273,7 +281,8 @@ class InstantNeuS(nn.Module):
 # fused forward / backward plumbing
 # ------------------------------------------------------------------------------------------
 
-def _neus_forward_raw(model, rays_o, rays_d, z_vals, dists, inv_s, save, inv_s_dev=None, rt_bound_dev=None):
+def _neus_forward_raw(model, rays_o, rays_d, z_vals, dists, inv_s, save, inv_s_dev=None, rt_bound_dev=None,
+                      gerr_scale=1.0, sdf_var=None, sdf_var_value=0.0):
     """`inv_s_dev` (optional fp32 device scalar) overrides the host value `inv_s` inside the kernels; `rt_bound_dev`
     (optional fp32 [3,2] device tensor, normally `model.realtime_bound` itself) overrides the host copy of the realtime
     bound -- what a captured launch sequence must use, since `update_bound` rewrites that buffer in place."""
@@ -307,7 +316,8 @@ def _neus_forward_raw(model, rays_o, rays_d, z_vals, dists, inv_s, save, inv_s_d
                                _lib.ptr(color), _lib.ptr(depth), _lib.ptr(dvar), _lib.ptr(normal), _lib.ptr(wsum),
                                _lib.ptr(sdf), _lib.ptr(zmid), _lib.ptr(gerr),
                                _lib.ptr(saved.get("alpha")), _lib.ptr(saved.get("rgb")), _lib.ptr(saved.get("grad")),
-                               _lib.ptr(saved.get("mask")), _lib.ptr(saved.get("mlp_in")), _lib.ptr(saved.get("enc_aux")), n, s,
+                               _lib.ptr(saved.get("mask")), _lib.ptr(saved.get("mlp_in")), _lib.ptr(saved.get("enc_aux")),
+                               float(gerr_scale), _lib.ptr(sdf_var), float(sdf_var_value), n, s,
                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "InstantNeuS.forward")
     saved.update(grid=grid, mlp=mlp, sdf_w=sdf_w, cB=cB)

@@ -89,7 +89,10 @@ int gs_mlp_forward(const void* x, const void* mlp, void* out, int n, int n_in, i
  *   grad f32 [n,s,3], mask u8 [n,s], mlp_in f16 [n,s,80] (NULL = keep in the workspace; the
  *   training path saves them for gs_neus_backward_*); enc_aux_out f16 [16,n*s,8] (optional): per level and point
  *   the record [enc0, enc1, d enc0 / dx (3), d enc1 / dx (3)] of the in-bound points -- handed to
- *   gs_neus_backward_points* as `enc_aux`, the backward streams it instead of gathering the table again.      */
+ *   gs_neus_backward_points* as `enc_aux`, the backward streams it instead of gathering the table again.
+ *   grad_err_scale multiplies grad_err_ray (1 = the raw per-ray sums the training step reduces; 1 / (n s) makes
+ *   sum(grad_err_ray) the `gradient_error` of InstantNeuS.py:360-370 directly); sdf_variance_out f32 [n] (optional)
+ *   is filled with sdf_variance_value (`sdf_variance` of the same dict).                                        */
 size_t gs_neus_forward_workspace_bytes(int n, int s);
 int gs_neus_forward(const float* rays_o, const float* rays_d, const float* z_vals,
                     const float* dists, const void* grid, const float* sdf_w, const float* sdf_b,
@@ -98,7 +101,8 @@ int gs_neus_forward(const float* rays_o, const float* rays_d, const float* z_val
                     float* color, float* depth, float* depth_var, float* normal,
                     float* weight_sum, float* sdf, float* z_mid, float* grad_err_ray,
                     float* alpha_out, void* rgb_out, float* grad_out, uint8_t* mask_out,
-                    void* mlp_in_out, void* enc_aux_out, int n, int s,
+                    void* mlp_in_out, void* enc_aux_out, float grad_err_scale, float* sdf_variance_out,
+                    float sdf_variance_value, int n, int s,
                     void* workspace, size_t workspace_bytes, gs_stream_t stream);
 
 /* Backward of InstantNeuS.forward, stage 1 (per ray): from the upstream gradients of the ray
