@@ -7,8 +7,9 @@
 //   chol_panel_kernel   : every workgroup (one wave) re-factors the 32x32 diagonal block in LDS
 //                         (cheaper than a dependent launch) and solves 64 rows of the panel
 //   chol_trail_kernel   : 64x64 tiles of the trailing matrix, A22 -= L21 L21^T, operands in LDS
-//   chol_solve_kernel   : one workgroup, blocked forward + backward substitution, writes fp32 dx
-// 2 launches per panel; 6P = 150 (frontend window) is 5 panels, 6P = 1200 (global BA) 38.
+//   chol_back_block_kernel : backward substitution, one launch per 64-wide block (b rides along as row n of the
+//                         factorisation, so the forward substitution is free), writes fp32 dx
+// 2 launches per panel + 1 per 64 unknowns; 6P = 1200 (global BA) is 38 panels.
 #include "common.h"
 
 namespace {
@@ -39,7 +40,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // The 32x32 factorisation is wave-synchronous and register-resident: lane i holds row i
 // (32 doubles), pivots and column entries are broadcast with v_readlane, no LDS, no barriers
 // (~1.5 us instead of 32 x 3 barrier-separated LDS sweeps).
-__global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ A, int n, int k0,
+__global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ A, double* __restrict__ bvec, int n, int k0,
                                                         int32_t* fail_flag) {
   __shared__ double D[NB][NB + 1];
   const int lane = threadIdx.x;
@@ -84,11 +85,12 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ A, 
     }
     if (lane == 0 && bad) *fail_flag = 1;
   }
-  // panel rows
+  // panel rows; row n is b^T (round 4: b rides along as an extra row of the matrix, so the forward substitution
+  // L y = b falls out of the factorisation -- the single-workgroup forward sweep cost 0.75 ms at 6P = 1194)
   const int row = k0 + nb + blockIdx.x * PR + lane;
-  if (row < n) {
+  if (row <= n) {
     double x[NB];
-    double* Ar = A + (size_t)row * n + k0;
+    double* Ar = row < n ? A + (size_t)row * n + k0 : bvec + k0;
 #pragma unroll
     for (int c = 0; c < NB; ++c) x[c] = (c < nb) ? Ar[c] : 0.0;
 #pragma unroll
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ A, 
 }
 
 // A22[r][c] -= sum_k L21[r][k] L21[c][k] over lower tiles of the trailing matrix.
-__global__ __launch_bounds__(256) void chol_trail_kernel(double* __restrict__ A, int n, int k0, int nb) {
+__global__ __launch_bounds__(256) void chol_trail_kernel(double* __restrict__ A, double* __restrict__ bvec, int n, int k0,
+                                                         int nb) {
   __shared__ double Lr[TT][NB + 1];
   __shared__ double Lc[TT][NB + 1];
   // decode (ti,tj), tj <= ti, from the flat lower-triangular tile index
@@ -122,7 +125,8 @@ __global__ __launch_bounds__(256) void chol_trail_kernel(double* __restrict__ A,
   const int tid = threadIdx.x;
   for (int idx = tid; idx < TT * NB; idx += 256) {
     const int r = idx / NB, k = idx % NB;
-    Lr[r][k] = (r0 + r < n && k < nb) ? A[(size_t)(r0 + r) * n + (k0 + k)] : 0.0;
+    // (row n = b^T, stored in bvec)
+    Lr[r][k] = (r0 + r <= n && k < nb) ? (r0 + r < n ? A[(size_t)(r0 + r) * n + (k0 + k)] : bvec[k0 + k]) : 0.0;
     Lc[r][k] = (c0 + r < n && k < nb) ? A[(size_t)(c0 + r) * n + (k0 + k)] : 0.0;
   }
   __syncthreads();
@@ -145,90 +149,64 @@ __global__ __launch_bounds__(256) void chol_trail_kernel(double* __restrict__ A,
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = r0 + tr + i;
-    if (r >= n) continue;
+    if (r > n) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = c0 + tc + j;
-      if (c <= r) A[(size_t)r * n + c] -= acc[i][j];
+      if (c <= r && c < n) {
+        if (r < n) A[(size_t)r * n + c] -= acc[i][j];
+        else bvec[c] -= acc[i][j];
+      }
     }
   }
 }
 
-// Blocked forward (L y = b) and backward (L^T x = y) substitution by one workgroup.  The
-// sequential part of each 64-wide diagonal block is wave-synchronous and register-resident:
-// forward, lane i holds ROW i of the block and the solved entries are broadcast with v_readlane;
-// backward, lane j holds COLUMN j (coalesced loads) -- 64 steps of {readlane, fma} instead of 64
-// barrier-separated LDS sweeps.  The off-diagonal updates use all 256 threads.
-__global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restrict__ L, double* __restrict__ b,
-                                                         int n, float* __restrict__ dx,
-                                                         int32_t* fail_flag, int32_t* fail_count) {
-  __shared__ double y[SB];
+// Backward substitution L^T x = y for the multi-kernel path, ONE LAUNCH PER 64-wide block from the last block up (round 4;
+// y = L^-1 b is already in b: it rode along as row n of the factorisation): every workgroup solves the block's
+// triangle redundantly in wave 0 (registers, v_readlane broadcasts: lane j holds COLUMN j), then the workgroups share
+// the update of the columns left of the block, y[c] -= sum_r L[k0 + r][c] x[r] -- consecutive threads read
+// consecutive c, so the loads coalesce.  19 launches of ~7 us at 6P = 1194 instead of one 1.5 ms single-workgroup
+// kernel (forward + backward).
+__global__ __launch_bounds__(256) void chol_back_block_kernel(const double* __restrict__ L, double* __restrict__ b, int n,
+                                                              int k0, float* __restrict__ dx, const int32_t* fail_flag,
+                                                              int32_t* fail_count) {
+  __shared__ double xs[SB];
   const int tid = threadIdx.x;
+  const int nb = min(SB, n - k0);
   if (*fail_flag) {   // reference: zero update on failure (droid_kernels.cu:1207-1210)
-    for (int i = tid; i < n; i += 256) dx[i] = 0.0f;
-    if (tid == 0) *fail_count += 1;
+    if (blockIdx.x == 0) {
+      for (int i = tid; i < nb; i += 256) dx[k0 + i] = 0.0f;
+      if (tid == 0 && k0 == 0) *fail_count += 1;
+    }
     return;
   }
-  const int nblk = (n + SB - 1) / SB;
-  // ---- forward
-  for (int kb = 0; kb < nblk; ++kb) {
-    const int k0 = kb * SB, nb = min(SB, n - k0);
-    if (tid < 64) {
-      const int i = tid;
-      const bool live = i < nb;
-      double a[SB];
-      const double* Lr = L + (size_t)(k0 + (live ? i : 0)) * n + k0;
+  if (tid < 64) {
+    const int j = tid;
+    const bool live = j < nb;
+    double c_[SB];                        // column j of the block: L[k0+i][k0+j], i > j
 #pragma unroll
-      for (int c = 0; c < SB; ++c) a[c] = (live && c < i) ? Lr[c] : 0.0;
-      const double inv_dg = live ? 1.0 / Lr[i] : 1.0;
-      double bv = live ? b[k0 + i] : 0.0;
+    for (int i = 0; i < SB; ++i) c_[i] = (live && i > j && i < nb) ? L[(size_t)(k0 + i) * n + k0 + j] : 0.0;
+    const double inv_dg = live ? 1.0 / L[(size_t)(k0 + j) * n + k0 + j] : 1.0;
+    double yv = live ? b[k0 + j] : 0.0;
 #pragma unroll
-      for (int j = 0; j < SB; ++j) {
-        const double yj = readlane_f64(bv * inv_dg, j);
-        if (i == j) bv = yj;
-        else if (i > j) bv -= a[j] * yj;
-      }
-      y[i] = bv;
-      if (live) b[k0 + i] = bv;
+    for (int i = SB - 1; i >= 0; --i) {
+      const double xi = readlane_f64(yv * inv_dg, i);
+      if (j == i) yv = xi;
+      else if (j < i) yv -= c_[i] * xi;
     }
-    __syncthreads();
-    // b[r] -= L[r][k0:k0+nb] . y  for rows below the block
-    for (int r = k0 + nb + tid; r < n; r += 256) {
-      const double* Lr = L + (size_t)r * n + k0;
-      double s = 0.0;
-      for (int c = 0; c < nb; ++c) s = fma(Lr[c], y[c], s);
-      b[r] -= s;
-    }
-    __syncthreads();
+    xs[j] = yv;
+    if (live && blockIdx.x == 0) dx[k0 + j] = (float)yv;      // (b[k0 ..] keeps y: the other workgroups still read it)
   }
-  // ---- backward
-  for (int kb = nblk - 1; kb >= 0; --kb) {
-    const int k0 = kb * SB, nb = min(SB, n - k0);
-    if (tid < 64) {
-      const int j = tid;
-      const bool live = j < nb;
-      double c_[SB];                      // column j of the block: L[k0+i][k0+j], i > j
-#pragma unroll
-      for (int i = 0; i < SB; ++i) c_[i] = (live && i > j && i < nb) ? L[(size_t)(k0 + i) * n + k0 + j] : 0.0;
-      const double inv_dg = live ? 1.0 / L[(size_t)(k0 + j) * n + k0 + j] : 1.0;
-      double yv = live ? b[k0 + j] : 0.0;
-#pragma unroll
-      for (int i = SB - 1; i >= 0; --i) {
-        const double xi = readlane_f64(yv * inv_dg, i);
-        if (j == i) yv = xi;
-        else if (j < i) yv -= c_[i] * xi;
-      }
-      y[j] = yv;
-      if (live) { b[k0 + j] = yv; dx[k0 + j] = (float)yv; }
+  __syncthreads();
+  const int c = blockIdx.x * 256 + tid;
+  if (c < k0) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = 0; r + 1 < nb; r += 2) {
+      s0 = fma(L[(size_t)(k0 + r) * n + c], xs[r], s0);
+      s1 = fma(L[(size_t)(k0 + r + 1) * n + c], xs[r + 1], s1);
     }
-    __syncthreads();
-    // b[c] -= sum_r L[k0+r][c] * x[r]  for columns left of the block
-    for (int c = tid; c < k0; c += 256) {
-      double s = 0.0;
-      for (int r = 0; r < nb; ++r) s = fma(L[(size_t)(k0 + r) * n + c], y[r], s);
-      b[c] -= s;
-    }
-    __syncthreads();
+    if (nb & 1) s0 = fma(L[(size_t)(k0 + nb - 1) * n + c], xs[nb - 1], s0);
+    b[c] -= s0 + s1;
   }
 }
 
@@ -901,16 +879,19 @@ int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float*
   for (int k0 = 0; k0 < n; k0 += NB) {
     const int nb = (n - k0 < NB) ? (n - k0) : NB;
     const int rem = n - k0 - nb;
-    const int pgrid = rem > 0 ? gs_cdiv(rem, PR) : 1;
-    chol_panel_kernel<<<pgrid, 64, 0, st>>>(H, n, k0, fail_flag);
+    // rows k0+nb .. n: the matrix rows below the panel AND the b row (n), which rides along
+    chol_panel_kernel<<<gs_cdiv(rem + 1, PR), 64, 0, st>>>(H, b, n, k0, fail_flag);
     GS_CHECK_LAUNCH("chol_panel");
     if (rem > 0) {
-      const int T = gs_cdiv(rem, TT);
-      chol_trail_kernel<<<T * (T + 1) / 2, 256, 0, st>>>(H, n, k0, nb);
+      const int T = gs_cdiv(rem + 1, TT);
+      chol_trail_kernel<<<T * (T + 1) / 2, 256, 0, st>>>(H, b, n, k0, nb);
       GS_CHECK_LAUNCH("chol_trail");
     }
   }
-  chol_solve_kernel<<<1, 256, 0, st>>>(H, b, n, dx_out, fail_flag, fail_count);
-  GS_CHECK_LAUNCH("chol_solve");
+  // b now holds y = L^-1 b; backward substitution block by block
+  for (int k0 = ((n - 1) / SB) * SB; k0 >= 0; k0 -= SB) {
+    chol_back_block_kernel<<<gs_cdiv(k0, 256) + 1, 256, 0, st>>>(H, b, n, k0, dx_out, fail_flag, fail_count);
+    GS_CHECK_LAUNCH("chol_back_block");
+  }
   return GS_OK;
 }
