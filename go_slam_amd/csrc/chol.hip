@@ -35,6 +35,18 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// sqrt and reciprocal sqrt of a pivot from v_rsq_f64 + two coupled Goldschmidt steps (full fp64
+// accuracy, ~12 dependent FMAs instead of the ~35-instruction sqrt + divide sequences).
+__device__ __forceinline__ void sqrt_rsqrt(double x, double& s, double& rs) {
+  const double r = __builtin_amdgcn_rsq(x);
+  double g = x * r, h = 0.5 * r;
+  double e = fma(-g, h, 0.5);
+  g = fma(g, e, g); h = fma(h, e, h);
+  e = fma(-g, h, 0.5);
+  g = fma(g, e, g); h = fma(h, e, h);
+  s = g; rs = h + h;
+}
+
 // Factor the diagonal block [k0,k0+nb) (every workgroup redundantly -- cheaper than a dependent
 // launch) and compute L21 = A21 * L11^-T for this workgroup's PR rows.
 // The 32x32 factorisation is wave-synchronous and register-resident: lane i holds row i
@@ -62,18 +74,24 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ A, 
   for (int j = 0; j < NB; ++j) {
     const double piv = readlane_f64(a[j], j);
     if (j < nb && !(piv > 0.0) && piv == piv) bad = true;   // pivot <= 0 (NaN falls through like Eigen)
-    const double dj = sqrt(piv);
+    double dj, rdj;                         // (rsq + two Goldschmidt steps: ~12 dependent FMAs instead of sqrt + divide)
+    sqrt_rsqrt(piv, dj, rdj);
     if (lane == j) a[j] = dj;
-    else if (lane > j) a[j] = a[j] / dj;
+    else if (lane > j) a[j] = a[j] * rdj;
 #pragma unroll
     for (int c = j + 1; c < NB; ++c) {
       const double lcj = readlane_f64(a[j], c);
       if (lane >= c) a[c] -= a[j] * lcj;
     }
   }
+  __shared__ double Dinv[NB];
   if (lane < NB) {
 #pragma unroll
     for (int c = 0; c < NB; ++c) D[lane][c] = a[c];
+    double dg = 1.0;                        // this row's own diagonal entry (statically indexed select)
+#pragma unroll
+    for (int c = 0; c < NB; ++c) dg = (c == lane) ? a[c] : dg;
+    Dinv[lane] = 1.0 / dg;
   }
   __syncthreads();
   if (blockIdx.x == 0) {
@@ -100,7 +118,7 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ A, 
 #pragma unroll
         for (int t = 0; t < NB; ++t)
           if (t < c) s -= x[t] * D[c][t];
-        x[c] = s / D[c][c];
+        x[c] = s * Dinv[c];
       }
     }
 #pragma unroll
@@ -245,18 +263,6 @@ __device__ long long g_chol_t[64];
 #endif
 
 __device__ __forceinline__ int tri(int r, int c) { return ((r * (r + 1)) >> 1) + c; }
-
-// sqrt and reciprocal sqrt of a pivot from v_rsq_f64 + two coupled Goldschmidt steps (full fp64
-// accuracy, ~12 dependent FMAs instead of the ~35-instruction sqrt + divide sequences).
-__device__ __forceinline__ void sqrt_rsqrt(double x, double& s, double& rs) {
-  const double r = __builtin_amdgcn_rsq(x);
-  double g = x * r, h = 0.5 * r;
-  double e = fma(-g, h, 0.5);
-  g = fma(g, e, g); h = fma(h, e, h);
-  e = fma(-g, h, 0.5);
-  g = fma(g, e, g); h = fma(h, e, h);
-  s = g; rs = h + h;
-}
 
 // ---- the LDS-resident core, shared by chol_small_kernel (6P <= 192) and the tail of chol_mid_kernel ------------------
 // Lp: packed lower triangle of [A; b^T] (n + 1 rows, already damped), invd: n reciprocals of the diagonal of L.
