@@ -226,8 +226,16 @@ class BasicEncoder(nn.Module):
             from . import _lib
             L = _lib.lib()
             st = torch.cuda.current_stream(dev).cuda_stream
-            # statistics workspace: the largest layer (stem / layer1: 32 channels at half resolution) decides
-            ws = _stats_workspace(dev, 16 * n_ * ((h_ // 2) * ((w_ // 2 + 31) // 32) * 32 + 4096) + (1 << 16))
+            # statistics workspace: the largest of the three resolutions decides (sizes from the library, once per shape)
+            need = self.__dict__.setdefault("_ws_need", {}).get((n_, h_, w_))
+            if need is None:
+                need = 0
+                for k_, c_ in ((2, 32), (4, 64), (8, 128)):
+                    ho_, wo_ = -(-h_ // k_), -(-w_ // k_)
+                    need = max(need, int(L.gs_norm_act_workspace_bytes_chunks(
+                        n_, int(L.gs_enc_conv_stat_chunks(ho_, wo_, c_)), c_)))
+                self._ws_need[(n_, h_, w_)] = need
+            ws = _stats_workspace(dev, need)
             wsp, wsn = ws.data_ptr(), ws.numel()
             cl = torch.channels_last
 
