@@ -18,14 +18,20 @@
 //  * ALL staging is LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.  The pre-packed weight image
 //    of a tap (8 KB, exactly one 16-byte piece per thread) goes into a ring of 4 buffers, issued 3 taps ahead; the next
 //    chunk's patch goes into the second patch buffer, one 512-slot round per tap.  Out-of-image pixels load from a
-//    16-byte zero page, so there is no masking or zero-fill code.  Loads stay in flight across the barriers (raw
+//    16-byte zero page, so there is no masking code.  Loads stay in flight across the barriers (raw
 //    s_barrier, counted s_waitcnt vmcnt(N), never 0 in the loop); a buffer is read only in the phase AFTER the
 //    barrier that follows the wait which retires it (both groups' pieces).
-//  * patch layout [pixel][4 x 16-byte channel groups] with the group index XOR-swizzled by (pixel >> 2) & 3: the four
-//    DMA lanes of a pixel still read its 64 contiguous bytes, and with the lane-permuted fragment mapping (a
+//  * patch layout [pixel][5 x 16-byte slots]: four channel groups + one pad slot, i.e. an 80-BYTE pixel stride.  The four
+//    DMA lanes of a pixel still read its 64 contiguous bytes (the fifth lane reads the zero page), and 16 consecutive
+//    pixels start 20 banks apart = 16 distinct multiples of 4 banks modulo 64: with the lane-permuted fragment mapping (a
 //    ds_read_b128 service group = 16 consecutive pixels of one patch row, conv3x3_common.h) every B-fragment read is
-//    bank-conflict-free; weight planes [8-channel group][128 channels][8] are conflict-free as they are.
-//  * LDS: 2 x 40 KB patch + 4 x 8 KB weights = 112 KB (TW = 16); one workgroup per CU, 2 waves per SIMD.
+//    bank-conflict-free WITHOUT an address swizzle, so a tap's shift and the second k-step are immediate offsets of the
+//    ds_read: the READ phase is 9 VALU + 12 LDS instructions (the XOR-swizzled 64-byte layout of rounds 2-3 needed 46
+//    VALU per tap for the same reads; bench keyframe 12.66 -> 12.48 ms).  Taps that would cross an image boundary read
+//    a zero region behind the DMA rounds (written once per workgroup) through a per-lane base selected up front.  Weight
+//    planes [8-channel group][128 channels][8] are conflict-free as they are.
+//  * LDS: 2 x 51.3 KB patch (6 DMA rounds + zero region) + 4 x 8 KB weights = 134.5 KB (TW = 16; 148 KB at TW = 8); one
+//    workgroup per CU, 2 waves per SIMD.
 //  * BN = 64 instantiation (flow_encoder[2], 128 -> 64 channels): the same schedule with ONE 32-channel fragment per wave
 //    (a wave owns 128 pixels x 32 channels: 8 MFMAs per phase against 10 fragment reads, so it is bound by the READ
 //    phase, not the matrix pipe); a tap's weight image is 4 KB = one piece per thread of waves 0-3, waves 4-7 issue a
@@ -36,6 +42,12 @@
 namespace {
 
 constexpr int PP_KG = 4;            // 8-channel groups per 32-channel chunk
+constexpr int PP_PSTR = 5;          // 16-byte slots per patch pixel (80-byte pixel stride, see the header)
+// zero slots behind a patch buffer's DMA rounds: the largest tap offset (2 rows + 2 pixels) + the second k-step's + 2
+constexpr int pp_zpad(int tw) { return (((2 * (tw + 2) + 2) * PP_PSTR + 3 + 15) / 16) * 16; }
+constexpr int pp_patch_slots(int tw) {
+  return (((512 / tw + 2) * (tw + 2) * PP_PSTR + 511) / 512) * 512 + pp_zpad(tw);
+}
 
 __device__ __attribute__((aligned(16))) const uint32_t pp_zero_page[4] = {0u, 0u, 0u, 0u};
 
@@ -106,10 +118,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
   constexpr int NJ = BN / 64;                             // 32-channel fragments per wave
   constexpr int PP_TS = NJ == 2 ? 72 : 40;                // epilogue tile row stride in halves (16-byte aligned rows)
   constexpr int TH_ = 512 / TW, PW_ = TW + 2, NPX = (TH_ + 2) * PW_;
-  constexpr int NROUND = (NPX * PP_KG + 511) / 512;       // DMA rounds (512 slots each) per patch
-  constexpr int PSLOTS = NROUND * 512;                    // slots of a patch buffer; [NPX * 4, PSLOTS) hold zeros
-  constexpr int ZSLOT = NPX * PP_KG;                      // a slot that always reads as zero
-  static_assert(PSLOTS > NPX * PP_KG, "the patch buffer needs at least one padding (zero) slot");
+  constexpr int PSTR = PP_PSTR;                           // 16-byte slots per patch pixel: 4 channel groups + 1 pad
+  constexpr int ZPAD = pp_zpad(TW);                       // zero slots behind the DMA rounds (masked taps read there)
+  constexpr int NROUND = (NPX * PSTR + 511) / 512;        // DMA rounds (512 slots each) per patch
+  constexpr int PSLOTS = NROUND * 512 + ZPAD;             // slots of a patch buffer
+  constexpr int ZSLOT = NROUND * 512;                     // first slot of the zero region
+  static_assert(PSLOTS == pp_patch_slots(TW), "launch_pp sizes the LDS with the same formula");
   static_assert(NROUND <= 9, "one DMA round per tap");
   extern __shared__ half8 smem[];                         // patch [2][PSLOTS] | weights [4][PP_WTAP] (| 256 dummy slots)
   half8* const pbuf = smem;
@@ -145,15 +159,31 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
   int poff[NROUND];
 #pragma unroll
   for (int q = 0; q < NROUND; ++q) {
-    const int s = q * 512 + tid, p = s >> 2, ks = s & 3;
+    const int s = q * 512 + tid, p = s / PSTR, kg = s - PSTR * p;
     int off = -1;
-    if (p < NPX) {
-      const int kg = ks ^ ((p >> 2) & 3);
+    if (p < NPX && kg < 4) {                              // the fifth slot of a pixel and the tail of the last round: zeros
       const int pr = p / PW_, pc = p - pr * PW_;
       const int gv = g0 + pr - 1, gx = tx0 + pc - 1;
       if (gv >= 0 && gv < rows && gx >= 0 && gx < W) off = (gv * W + gx) * 4 + kg;
     }
     poff[q] = off;
+  }
+
+  // slot (pixel * 5 + channel group of this half-wave) of this lane's pixel in each fragment: the tap shift and the
+  // second k-step are immediate offsets of the ds_read.  Lanes whose row above (below) belongs to another image read the
+  // zero region instead for the taps of the upper (lower) kernel row.
+  int vb[4], vt[4], vo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    vb[i] = pb[i] * PSTR + kgl;
+    vt[i] = top[i] ? ZSLOT : vb[i];
+    vo[i] = bot[i] ? ZSLOT : vb[i];
+  }
+  {                                                       // the zero regions are written once; no DMA ever targets them
+    const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (tid < ZPAD) pbuf[ZSLOT + tid] = z8;
+    else if (tid < 2 * ZPAD) pbuf[PSLOTS + ZSLOT + tid - ZPAD] = z8;
+    static_assert(2 * ZPAD <= 512, "one store per thread");
   }
 
   float16v acc[NJ][4];
@@ -198,19 +228,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int pbi = pb[i];
-      asm volatile("" : "+v"(pbi));                       // opaque: keeps the 9 x 4 x 2 slot addresses from being hoisted
-      const int p = pbi + toff;                           // out of the chunk loop (72 VGPRs, spills at the 256 cap)
-      int s0 = p * 4 + (kgl ^ ((p >> 2) & 3));            // channel group kgl (s = 0); group 2 + kgl is s0 ^ 2
-      int s1 = s0 ^ 2;
-      bool masked = (dy == 0 && top[i]) || (dy == 2 && bot[i]);     // the row above / below belongs to another image
-      if constexpr (PROBE) masked = masked && !(ep.variant & 2);
-      if (masked) {
-        s0 = ZSLOT;
-        s1 = ZSLOT;
+      int base = dy == 0 ? vt[i] : dy == 2 ? vo[i] : vb[i];     // the row above / below belongs to another image: zeros
+      if constexpr (PROBE) {
+        if (ep.variant & 2) base = vb[i];
       }
-      b[0][i] = pp[s0];
-      b[1][i] = pp[s1];
+      asm volatile("" : "+v"(base));                      // opaque: one address register per read pair, not 24 hoisted ones
+      const half8* q = pp + base;
+      b[0][i] = q[toff * PSTR];                           // channel group kgl (first k-step) ...
+      b[1][i] = q[toff * PSTR + 2];                       // ... and 2 + kgl (second): immediate offsets
     }
   };
   // MATH phase body: 16 MFMAs; `between` (the LDS-DMA issue of this tap) is placed after the first four, so that its
@@ -247,7 +272,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
   issue_w(0, 0);
   issue_w(1, 1);
   issue_w(2, 2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // lgkmcnt: the zero regions' stores (V >= 1)
   PP_BAR();
   pp_stamp<PROBE>(ep.dbg, 1);
   if (grp2 == 1) PP_BAR();                                // group 1 runs one phase behind from here on
@@ -273,7 +298,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pp_kernel(const _Float16* __re
       });
       __builtin_amdgcn_sched_barrier(0);
       // everything issued before this tap has landed (this wave's pieces); the barrier publishes it.  Tap tg + 2's
-      // weights are first read two phases from now, the next patch at the earliest four taps from now.
+      // weights are first read two phases from now, the next patch at the earliest two taps from now.
       if (tap < NROUND) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       PP_BAR();
@@ -403,9 +428,8 @@ template <int TW, int EPI, int BN = 128, bool PROBE = false>
 int launch_pp(const void* x, int x_stride, int c_in, const void* wpack, void* y, int y_stride, int n_out, int n, int h,
               int w, int xcd, hipStream_t st, PpEpi ep = PpEpi()) {
   constexpr int PP_BN = BN, PP_WTAP = PP_KG * BN;
-  constexpr int NPX = (512 / TW + 2) * (TW + 2);
-  constexpr int PSLOTS = ((NPX * PP_KG + 511) / 512) * 512;
-  constexpr size_t lds = (size_t)(2 * PSLOTS + 4 * PP_WTAP + (BN == 64 ? 256 : 0)) * sizeof(half8);
+  constexpr size_t lds = (size_t)(2 * pp_patch_slots(TW) + 4 * PP_WTAP + (BN == 64 ? 256 : 0)) * sizeof(half8);
+  static_assert(lds <= 160 * 1024, "conv3x3_pp: more LDS than a CU has");
   static GsLdsLimit limit;
   if (int rc = limit.raise((const void*)conv3x3_pp_kernel<TW, EPI, BN, PROBE>, lds, "conv3x3_pp")) return rc;
   const long long rows = (long long)n * h;

@@ -4,8 +4,9 @@
                issue, counted wait, barrier and fragment read, and checks for each read that the buffer holds the
                expected tap / chunk, that BOTH groups' pieces were retired by a wait that is followed by a barrier
                before the reading phase, and that no buffer is re-filled before its last reader is done.
-  data_path()  replays every thread's index arithmetic in NumPy -- DMA source addresses incl. the zero page and the XOR
-               swizzle, linear LDS destinations, fragment slot addresses incl. the zero slot of the row-stacked masks,
+  data_path()  replays every thread's index arithmetic in NumPy -- DMA source addresses incl. the zero page and the pad
+               slot of the 80-byte pixel stride, linear LDS destinations, fragment slot addresses (per-lane base +
+               immediate tap offset) incl. the zero region of the row-stacked masks,
                the operand / accumulator layout of v_mfma_f32_32x32x16_f16, the lane-permuted pixel mapping and the
                LDS-transposed epilogue -- and compares the result with F.conv2d.
   bank_model() evaluates the ds_read_b128 service groups (MI355X_MICROARCH.md, LDS) for the B-fragment reads.
@@ -23,6 +24,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from go_slam_amd.droid_net import pack_conv3x3_weight  # noqa: E402
 
+PSTR = 5                                # 16-byte slots per patch pixel (80-byte stride)
 BN, KG, WTAP, TS = 128, 4, 512, 72      # the 128-channel instantiation (schedule / bank model); data_path derives its own
 
 
@@ -52,8 +54,9 @@ def geometry(TW):
     TH = 512 // TW
     PW = TW + 2
     NPX = (TH + 2) * PW
-    NROUND = (NPX * KG + 511) // 512
-    return TH, PW, NPX, NROUND, NROUND * 512, NPX * KG
+    NROUND = (NPX * PSTR + 511) // 512
+    zpad = (((2 * PW + 2) * PSTR + 3 + 15) // 16) * 16
+    return TH, PW, NPX, NROUND, NROUND * 512 + zpad, NROUND * 512
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -172,8 +175,8 @@ def bank_model(TW):
                             for r in grp:
                                 ty, tx = tile_pixel(TW, wm, i, r)
                                 p = ty * PW + tx + toff
-                                s0 = p * 4 + (kgl ^ ((p >> 2) & 3))
-                                slots.append((s0 ^ 2) if s else s0)
+                                s0 = p * PSTR + kgl
+                                slots.append((s0 + 2) if s else s0)
                             ways = max(Counter(sl % 16 for sl in slots).values())
                             worst[ways] += 1
     return dict(worst)
@@ -214,14 +217,14 @@ def data_path(x, xs, C, wt, n, H, W, TW, xcd=0):
         poff = np.full((NROUND, 512), -1, np.int64)
         for q in range(NROUND):
             s = q * 512 + tid
-            p = s >> 2
-            ks = s & 3
-            kg = ks ^ ((p >> 2) & 3)
+            p = s // PSTR
+            kg = s - PSTR * p
             pr, pc = p // PW, p % PW
             gv, gx = g0 + pr - 1, tx0 + pc - 1
-            ok = (p < NPX) & (gv >= 0) & (gv < rows) & (gx >= 0) & (gx < W)
+            ok = (p < NPX) & (kg < 4) & (gv >= 0) & (gv < rows) & (gx >= 0) & (gx < W)
             poff[q] = np.where(ok, (gv * W + gx) * xs + kg * 8, -1)
         pbuf = np.full((2, PSLOTS, 8), np.nan, np.float32)
+        pbuf[:, ZSLOT:] = 0.0                            # the zero regions (written once, never a DMA target)
         wbuf = np.full((4, WTAP, 8), np.nan, np.float32)
 
         def dma_patch(chunk, buf):
@@ -265,12 +268,12 @@ def data_path(x, xs, C, wt, n, H, W, TW, xcd=0):
                             for lane in range(64):
                                 r, kgl = lane & 31, lane >> 5
                                 ty, tx = tile_pixel(TW, wm, i, r)
-                                p = ty * PW + tx + toff
-                                s0 = p * 4 + (kgl ^ ((p >> 2) & 3))
-                                s1 = s0 ^ 2
                                 yy = (g0 + ty) % H
+                                base = (ty * PW + tx) * PSTR + kgl
                                 if (dy == 0 and yy == 0) or (dy == 2 and yy == H - 1):
-                                    s0 = s1 = ZSLOT
+                                    base = ZSLOT
+                                s0 = base + toff * PSTR
+                                s1 = s0 + 2
                                 B[r, 8 * kgl:8 * kgl + 8] = pp[s1 if s else s0]
                             for j in range(NJ):
                                 Cm = A[j] @ B.T
