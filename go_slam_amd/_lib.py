@@ -88,7 +88,7 @@ SIGNATURES = {
     "gs_map_adamw": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, _P, c_size_t] + [c_float] * 6 + [c_int, _P, c_float, _P]),
     "gs_map_gram_blocks": (c_int, [c_int]),
     "gs_map_gram": (c_int, [_P, c_int, _P, _P]),
-    "gs_map_step_prep": (c_int, [_P, c_int, _P, c_float, c_float, c_int] + [_P] * 10),
+    "gs_map_step_prep": (c_int, [_P, c_int, _P, c_float, c_float, c_int] + [_P] * 13),
     "gs_map_step_post": (c_int, [_P, c_int, c_float, _P, c_int, _P, _P, _P, c_float, _P, _P, c_int, c_float, c_int, _P, _P, _P]),
     "gs_map_adamw_seg": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, _P, _P, _P, _P, _P, c_size_t] + [c_float] * 6
                          + [c_int, _P, _P, c_float, _P]),

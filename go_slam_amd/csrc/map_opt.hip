@@ -26,8 +26,26 @@ __global__ __launch_bounds__(256) void map_grad_sqnorm_kernel(const _Float16* __
   const size_t stride = (size_t)gridDim.x * 256;
   float acc = 0.0f;
   const size_t n8 = n16 / 8;
-  for (size_t i = tid; i < n8; i += stride) {
-    const half8 v = reinterpret_cast<const half8*>(g16)[i];
+  const half8* g8 = reinterpret_cast<const half8*>(g16);
+  size_t i0 = tid;
+  {                                                     // four 16-byte loads in flight per thread (one at a time made
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};                 // the 25 MB pass latency-bound: 12.6 us for 12 dependent trips)
+    for (; i0 + 3 * stride < n8; i0 += 4 * stride) {
+      half8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = g8[i0 + u * stride];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float f = (float)v[u][k] * inv_scale16;
+          a4[u] = fmaf(f, f, a4[u]);
+        }
+    }
+    acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  }
+  for (size_t i = i0; i < n8; i += stride) {
+    const half8 v = g8[i];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float f = (float)v[k] * inv_scale16;
@@ -213,7 +231,10 @@ __global__ __launch_bounds__(1024) void map_step_prep_kernel(const float* __rest
                                                              float* __restrict__ counts_out, float* __restrict__ inv_s_out,
                                                              float* __restrict__ d_gerr_out, float* __restrict__ d_invs,
                                                              float* __restrict__ sqnorm, int* __restrict__ step_dev,
-                                                             const float* __restrict__ sdf_w, float* __restrict__ sdf_wt) {
+                                                             const float* __restrict__ sdf_w, float* __restrict__ sdf_wt,
+                                                             const _Float16* __restrict__ mlp16,
+                                                             const int* __restrict__ frag_index,
+                                                             _Float16* __restrict__ mlp_wpack) {
   __shared__ float red_c[16], red_m[16], bc[3];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (counts_in) {
@@ -250,6 +271,12 @@ __global__ __launch_bounds__(1024) void map_step_prep_kernel(const float* __rest
   if (sdf_w && sdf_wt) {                               // [16][2][32] <- sdf_w [32][35] columns 3..34
     const int lf = tid >> 5, o = tid & 31;
     sdf_wt[tid] = sdf_w[o * 35 + 3 + lf];
+  }
+  if (mlp16 && frag_index && mlp_wpack) {              // the MLP backward's 40 A-fragments (was: cat + index + fill launches)
+    for (int i = tid; i < 40 * 64 * 8; i += 1024) {
+      const int j = frag_index[i];
+      mlp_wpack[i] = j < 10240 ? mlp16[j] : (_Float16)0.0f;
+    }
   }
 }
 
@@ -482,13 +509,14 @@ extern "C" int gs_map_gram(const void* rows, int n_rows, float* partial, gs_stre
 extern "C" int gs_map_step_prep(const float* rays_depth, int n, const float* variance, float scale_factor, float w_eikonal,
                                 int samples, const float* counts_in, float* counts_out, float* inv_s_out, float* d_gerr_out,
                                 float* d_invs, float* sqnorm, int* step_dev, const float* sdf_w, float* sdf_wt_out,
-                                gs_stream_t stream) {
+                                const void* mlp16, const int* frag_index, void* mlp_wpack_out, gs_stream_t stream) {
   GS_REQUIRE((rays_depth || counts_in) && variance && counts_out && inv_s_out && d_gerr_out && d_invs && sqnorm && step_dev,
              "map_step_prep: null pointer");
   GS_REQUIRE(n >= 0 && samples > 0, "map_step_prep: bad shape");
   map_step_prep_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(rays_depth, n, variance, scale_factor, w_eikonal, samples,
                                                            counts_in, counts_out, inv_s_out, d_gerr_out, d_invs, sqnorm,
-                                                           step_dev, sdf_w, sdf_wt_out);
+                                                           step_dev, sdf_w, sdf_wt_out, (const _Float16*)mlp16, frag_index,
+                                                           (_Float16*)mlp_wpack_out);
   GS_CHECK_LAUNCH("map_step_prep");
   return GS_OK;
 }

@@ -119,9 +119,9 @@ __global__ __launch_bounds__(256) void render_sample_wave_kernel(
     const float* __restrict__ bound, const float* __restrict__ t_samples, const float* __restrict__ t_surface,
     const float* __restrict__ perturb, float gt_max_host, const float* __restrict__ gt_max_dev,
     float* __restrict__ z_vals, float* __restrict__ dists, int n, int ns, int nsurf) {
-  const float gt_max = gt_max_dev ? *gt_max_dev : gt_max_host;
   __shared__ float sa[4][64], sb[4][64], sz[4][128];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float gt_max = gt_max_dev ? *gt_max_dev : gt_max_host;
   const int r = blockIdx.x * 4 + wave;
   if (r >= n) return;
   float far_bb = INFINITY;
@@ -452,17 +452,20 @@ __device__ __forceinline__ bool point_of(const NeusArgs& A, int idx, float pt[3]
 // HBM (47 MB written + read per 4096-ray batch before) and a launch is gone; the training path still saves them
 // (`mlp_in` != nullptr) for gs_mlp_backward.  All 64 lanes stay until the end (the MFMAs are wave-wide): out-of-bound
 // and past-the-end lanes contribute zero rows.
-// `count` (zeroed by the caller): the main pass sets it when ANY point lies in the realtime bound; the reference forces
-// the first 100 points valid when none does (InstantNeuS.py:311-312), which a second launch of this kernel with
-// force_pass = 1 and ONE workgroup handles: it returns at once unless count is still 0 (a 3 us launch instead of the
-// full-size neus_count_kernel pass over all points that used to precede the main pass).
-__global__ __launch_bounds__(256) void neus_point_kernel(NeusArgs A, gs_grid_meta m, int32_t* __restrict__ count,
-                                                         int force_pass,
-                                                         float* __restrict__ sdf_out, float* __restrict__ zmid_out,
-                                                         float* __restrict__ alpha_out, float* __restrict__ grad_out,
-                                                         uint8_t* __restrict__ mask_out, _Float16* __restrict__ mlp_in,
-                                                         _Float16* __restrict__ enc_aux, const _Float16* __restrict__ mlp_w,
-                                                         _Float16* __restrict__ rgb_out) {
+// `flags` (one byte per wave, every one written by the main pass -- nothing to zero beforehand): whether ANY of the wave's
+// points lies in the realtime bound; the reference forces the first 100 points valid when none does
+// (InstantNeuS.py:311-312), which a second launch of this kernel with force_pass = 1 and ONE workgroup handles: it ORs
+// the flags and returns at once unless all are 0 (a 3 us launch instead of the full-size neus_count_kernel pass over
+// all points that used to precede the main pass).
+// 4 waves per SIMD (amdgpu_waves_per_eu): 124 VGPRs without scratch, 4 x 40 KB workgroups = a CU's LDS exactly.  Left to
+// itself the compiler takes 188 VGPRs (2 waves per SIMD, more gathers in flight per wave) -- measured on one box: 156 vs
+// 130 us for the 4096-ray batch (4608 waves: 2.25 rounds of 2048 resident waves vs 1.125 of 4096), render 19.4 -> 22.1
+// M rays/s with everything else equal.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void neus_point_kernel(
+    NeusArgs A, gs_grid_meta m, uint8_t* __restrict__ flags, int force_pass, float* __restrict__ sdf_out,
+    float* __restrict__ zmid_out, float* __restrict__ alpha_out, float* __restrict__ grad_out,
+    uint8_t* __restrict__ mask_out, _Float16* __restrict__ mlp_in, _Float16* __restrict__ enc_aux,
+    const _Float16* __restrict__ mlp_w, _Float16* __restrict__ rgb_out) {
   __shared__ __attribute__((aligned(16))) _Float16 xs_all[4 * 64 * XS];
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const int np = A.n * A.s;
@@ -472,14 +475,29 @@ __global__ __launch_bounds__(256) void neus_point_kernel(NeusArgs A, gs_grid_met
   half8* xrow = reinterpret_cast<half8*>(xs + lane * XS);
   float pt[3], dir[3], zm = 0.f, dist = 0.f;
   bool in = false;
-  if (force_pass && *count >= 1) return;            // (uniform: some point was in bound, nothing to force)
+  if (force_pass) {                                 // one workgroup: did any wave of the main pass see a point in bound?
+    const int nw = (np + 63) >> 6;
+    int any = 0;                                    // (every wave scans all flags itself: no LDS, no barrier)
+    for (int i = lane * 16; i < nw; i += 1024) {
+      if (i + 16 <= nw) {
+        const uint4 v = *reinterpret_cast<const uint4*>(flags + i);
+        any |= (v.x | v.y | v.z | v.w) != 0u;
+      } else {
+        for (int k = i; k < nw; ++k) any |= flags[k];
+      }
+    }
+    if (__ballot(any != 0) != 0ull) return;         // (uniform) some point was in bound: nothing to force
+  }
   if (valid) {
     in = point_of(A, idx, pt, dir, zm, dist);
     if (force_pass && idx < 100) in = true;         // InstantNeuS.py:311-312
     zmid_out[idx] = zm;
     mask_out[idx] = in ? 1 : 0;
   }
-  if (!force_pass && __ballot(in) != 0ull && lane == 0) *count = 1;   // same value from everyone: no atomics
+  {
+    const unsigned long long anyin = __ballot(in);
+    if (!force_pass && lane == 0) flags[idx >> 6] = anyin != 0ull ? 1 : 0;        // every wave writes its own slot
+  }
   if (!in) {                                        // sdf = 100, grad = feat = rgb = 0, alpha * mask = 0
     const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     if (valid) {
@@ -736,7 +754,8 @@ __global__ __launch_bounds__(256) void neus_ray_kernel(const float* __restrict__
                                                        float* __restrict__ depth, float* __restrict__ depth_var,
                                                        float* __restrict__ normal, float* __restrict__ weight_sum,
                                                        float* __restrict__ gerr, float gerr_scale,
-                                                       float* __restrict__ sdf_var_out, float sdf_var_value, int n, int s) {
+                                                       float* __restrict__ sdf_var_out, float sdf_var_value,
+                                                       int n, int s) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n) return;
@@ -893,14 +912,14 @@ extern "C" int gs_mlp_forward(const void* x, const void* mlp, void* out, int n, 
 
 namespace {
 struct NeusWs {
-  int32_t* count; float* alpha; float* grad; uint8_t* mask; _Float16* mlp_in; _Float16* rgb; size_t total;
+  uint8_t* flags; float* alpha; float* grad; uint8_t* mask; _Float16* mlp_in; _Float16* rgb; size_t total;
 };
 NeusWs carve_neus(void* base, int n, int s) {
   NeusWs w;
   size_t off = 0;
   const size_t np = (size_t)n * s;
   auto take = [&](size_t bytes) { size_t o = off; off += gs_align(bytes); return (char*)base + o; };
-  w.count = (int32_t*)take(64);
+  w.flags = (uint8_t*)take((np + 63) / 64 + 64);
   w.alpha = (float*)take(np * 4);
   w.grad = (float*)take(np * 12);
   w.mask = (uint8_t*)take(np);
@@ -951,14 +970,14 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
   float* grad = grad_out ? grad_out : ws.grad;
   _Float16* rgb = rgb_out ? (_Float16*)rgb_out : ws.rgb;
   if (mask_out) ws.mask = mask_out;
-  if (hipMemsetAsync(ws.count, 0, 4, st) != hipSuccess) { gs_set_error("neus_forward: memset failed"); return GS_ERR_LAUNCH; }
   GS_TIMING_PRE();
   // (the colour MLP runs in the point kernel's tail; the MLP input rows reach memory only when the caller saves them)
-  neus_point_kernel<<<gs_cdiv(np, 256), 256, 0, st>>>(A, host_meta(), ws.count, 0, sdf, z_mid, alpha, grad, ws.mask,
+  neus_point_kernel<<<gs_cdiv(np, 256), 256, 0, st>>>(A, host_meta(), ws.flags, 0, sdf, z_mid, alpha, grad,
+                                                      ws.mask,
                                                       (_Float16*)mlp_in_out, (_Float16*)enc_aux_out, (const _Float16*)mlp,
                                                       rgb);
   GS_CHECK_LAUNCH("neus_point");
-  neus_point_kernel<<<1, 256, 0, st>>>(A, host_meta(), ws.count, 1, sdf, z_mid, alpha, grad, ws.mask,
+  neus_point_kernel<<<1, 256, 0, st>>>(A, host_meta(), ws.flags, 1, sdf, z_mid, alpha, grad, ws.mask,
                                        (_Float16*)mlp_in_out, (_Float16*)enc_aux_out, (const _Float16*)mlp, rgb);
   GS_CHECK_LAUNCH("neus_force100");
   neus_ray_kernel<<<gs_cdiv(n, 4), 256, 0, st>>>(alpha, rgb, z_mid, grad, ws.mask, color, depth, depth_var, normal,

@@ -244,7 +244,9 @@ class InstantNeuS(nn.Module):
         else:
             # no gradients: `gradient_error` (mean over all points) and `sdf_variance` come out of the ray kernel -- the
             # per-ray eikonal sums pre-scaled by 1 / (n s), the variance column filled there -- instead of three more
-            # one-workgroup torch launches per batch
+            # one-workgroup torch launches per batch.  (Adding the n per-ray terms up inside the ray kernel as well was
+            # tried: the last-workgroup ticket needs a device-scope fence per workgroup, and with the point kernel's
+            # output still dirty in the L2s that took the 6 us kernel to 34 us.)
             sv = torch.empty(n, 1, **f32)
             color, depth, dvar, normal, wsum, sdf, gerr, zmid = _neus_forward_raw(
                 self, rays_o.detach().float().contiguous(), rays_d.detach().float().contiguous(),
@@ -400,7 +402,9 @@ def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d
     W = S["mlp"]
     # one MFMA kernel: forward recompute + dX + the three weight gradients (gs_mlp_backward; checked against
     # torch.autograd on the oracle's restatement of the network in tests/)
-    wpack = _pack_mlp_fragments(W)
+    wpack = zb.get("mlp_wpack")                         # the fused step: gathered by gs_map_step_prep
+    if wpack is None:
+        wpack = _pack_mlp_fragments(W)
     nb = L.gs_mlp_backward_blocks(np_)
     partial = torch.empty(nb, 10240, **f32)
     dX = torch.empty(np_, 80, dtype=torch.float16, device=dev)

@@ -5,6 +5,7 @@ import torch
 
 from .. import _lib
 from .distributed import FlatGradReducer, all_reduce_sum_, mapping_loss_sharded, shard_rays
+from .tcnn_compat import _mlp_fragment_index32
 
 MAX_GRAPHS = 8          # captured batch shapes a trainer keeps (the mapper's batches come in a handful of sizes)
 
@@ -249,7 +250,8 @@ class MapTrainer:
             f32 = dict(dtype=torch.float32, device=dev)
             b = dict(counts=torch.zeros(3, **f32), inv_s=torch.zeros(1, **f32), d_gerr=torch.zeros(max(n, 1), 1, **f32),
                      d_invs=torch.zeros(1, **f32), zeros_n1=torch.zeros(n, 1, **f32), zeros_n3=torch.zeros(n, 3, **f32),
-                     sdf_wt=torch.zeros(16 * 2 * 32, **f32))
+                     sdf_wt=torch.zeros(16 * 2 * 32, **f32),
+                     mlp_wpack=torch.zeros(40, 64, 8, dtype=torch.float16, device=dev))
             if len(self._bufs) >= 2 * MAX_GRAPHS:
                 self._bufs.pop(next(iter(self._bufs)))
             self._bufs[n] = b
@@ -286,7 +288,9 @@ class MapTrainer:
                                           _lib.ptr(counts), _lib.ptr(B["counts"]), _lib.ptr(B["inv_s"]),
                                           _lib.ptr(B["d_gerr"]), _lib.ptr(B["d_invs"]), _lib.ptr(flat.sqnorm),
                                           _lib.ptr(flat.step_dev), _lib.ptr(model.sdf_network.sdf_layer.weight),
-                                          _lib.ptr(B["sdf_wt"]), st), "map_step_prep")
+                                          _lib.ptr(B["sdf_wt"]), _lib.ptr(model.color_network.network.params_half()),
+                                          _lib.ptr(_mlp_fragment_index32(dev)), _lib.ptr(B["mlp_wpack"]), st),
+                       "map_step_prep")
         counts, inv_s_dev = B["counts"], B["inv_s"]
         z_vals, dists = self.renderer.sample(rays_o, rays_d, model.bound, rays_depth, perturb_rand,
                                              gt_max_dev=counts[2:3])

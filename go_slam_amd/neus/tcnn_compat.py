@@ -230,6 +230,17 @@ def _mlp_fragment_index(device):
     return idx
 
 
+_FRAG_INDEX32 = {}
+
+
+def _mlp_fragment_index32(device):
+    """the same indices as int32 (gs_map_step_prep gathers the fragments inside the fused mapper step)"""
+    idx = _FRAG_INDEX32.get(device)
+    if idx is None:
+        idx = _FRAG_INDEX32[device] = _mlp_fragment_index(device).to(torch.int32).contiguous()
+    return idx
+
+
 def _pack_mlp_fragments(W):
     """One gather: [10240] fp16 parameters -> [40,64,8] fp16 fragments."""
     ext = torch.cat([W.reshape(-1), W.new_zeros(1)])

@@ -92,7 +92,8 @@ int gs_mlp_forward(const void* x, const void* mlp, void* out, int n, int n_in, i
  *   gs_neus_backward_points* as `enc_aux`, the backward streams it instead of gathering the table again.
  *   grad_err_scale multiplies grad_err_ray (1 = the raw per-ray sums the training step reduces; 1 / (n s) makes
  *   sum(grad_err_ray) the `gradient_error` of InstantNeuS.py:360-370 directly); sdf_variance_out f32 [n] (optional)
- *   is filled with sdf_variance_value (`sdf_variance` of the same dict).                                        */
+ *   is filled with sdf_variance_value (`sdf_variance` of the same dict).
+ * The workspace needs no initial state (the in-bound flags are one byte per wave, each written by its wave).        */
 size_t gs_neus_forward_workspace_bytes(int n, int s);
 int gs_neus_forward(const float* rays_o, const float* rays_d, const float* z_vals,
                     const float* dists, const void* grid, const float* sdf_w, const float* sdf_b,
@@ -218,7 +219,9 @@ int gs_map_adamw_seg(float* p, float* m, float* v, void* p16, const void* g16, s
 /* The scalar / reduction arithmetic around the mapper step's kernels in two launches (map_opt.hip):
  *   gs_map_step_prep: counts_out = counts_in if given, else [#rays with depth > 0, n, max depth] of rays_depth [n];
  *     inv_s_out[0] = clamp(exp(variance[0] * scale_factor), 1e-6, 1e6); d_gerr_out[0:n] = w_eikonal / (counts[1] * samples);
- *     d_invs[0] = sqnorm[0] = 0; step_dev[0] += 1; sdf_wt_out[l][f][o] = sdf_w[o][3 + 2 l + f] (both optional).
+ *     d_invs[0] = sqnorm[0] = 0; step_dev[0] += 1; sdf_wt_out[l][f][o] = sdf_w[o][3 + 2 l + f] (both optional);
+ *     mlp_wpack_out[i] = frag_index[i] == 10240 ? 0 : mlp16[frag_index[i]] for i < 20480 (all three optional): the
+ *     40 A-fragments gs_mlp_backward takes, gathered from the fp16 parameter vector (frag_index: int32 [20480]).
  *   gs_map_step_post: g32 [mlp 10240 | sdf_w 32x35 | sdf_b 32 | color_B 3x33 | variance 1 | loss 1] from the chunked Gram
  *     product of the per-point rows laid out [d_out 32 | x y z 1 .. 8 | lin_in 40 | dw0 40 | d_arg 40] (gram_chunks f32
  *     [nchunk,40,160] = rows[:, :40]^T rows per chunk, summed over chunks, x inv_loss_scale), the MLP
@@ -233,7 +236,7 @@ int gs_map_gram(const void* rows, int n_rows, float* partial, gs_stream_t stream
 int gs_map_step_prep(const float* rays_depth, int n, const float* variance, float scale_factor, float w_eikonal,
                      int samples, const float* counts_in, float* counts_out, float* inv_s_out, float* d_gerr_out,
                      float* d_invs, float* sqnorm, int* step_dev, const float* sdf_w, float* sdf_wt_out,
-                     gs_stream_t stream);
+                     const void* mlp16, const int* frag_index, void* mlp_wpack_out, gs_stream_t stream);
 int gs_map_step_post(const float* gram_chunks, int nchunk, float inv_loss_scale, const float* mlp_partial, int nb,
                      const float* d_invs, const float* variance, const float* inv_s, float scale_factor,
                      const float* loss_rays, const float* gerr, int n, float w_eikonal, int samples, const float* counts,

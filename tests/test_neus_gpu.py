@@ -179,6 +179,34 @@ def test_neus_forward_no_point_in_bound_forces_first_100(N, O, dev):
     torch.testing.assert_close(out["color"].cpu(), ref["color"], rtol=0, atol=4e-3)
 
 
+def test_forward_twice_on_a_dirty_workspace(N, O, dev):
+    """The forward's workspace needs no initial state (per-wave in-bound flags, every one written by its wave): a batch
+    with nothing in bound (forces the first 100 points), then a normal batch, then both again on the SAME scratch
+    give bit-identical results; `gradient_error` equals the oracle's mean."""
+    P = O.make_params(11, grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    far = torch.tensor([[50.0, 51.0], [50.0, 51.0], [50.0, 51.0]])
+    near = torch.tensor([[-2.2, 2.3], [-2.4, 2.1], [-2.0, 2.2]])
+    o, d, gt = _rays(1500, seed=12)
+    z, dist = O.render_sample(o, d, gt, P["bound"], 24, 48, None)
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    args = [t.to(dev) for t in (o, d, z, dist)]
+    outs = []
+    with torch.no_grad():
+        for rb in (far, near, far, near):
+            model.update_bound(rb)
+            outs.append({k: v.clone() for k, v in model(*args).items()})
+    for a, b in ((0, 2), (1, 3)):
+        for k in outs[a]:
+            assert torch.equal(outs[a][k], outs[b][k]), k
+    assert int((outs[0]["sdf"] != 100.0).sum()) == 100
+    P["rt_bound"] = near
+    ref = O.neus_forward(o, d, z, dist, P)
+    assert outs[1]["gradient_error"].shape == ref["gradient_error"].shape == (1,)
+    torch.testing.assert_close(outs[1]["gradient_error"].cpu(), ref["gradient_error"], rtol=2e-3, atol=1e-6)
+    assert int((outs[1]["sdf"] != 100.0).sum()) == int((ref["sdf"] != 100.0).sum()) > 100
+
+
 def _rel(a, b):
     return float((a - b).norm() / b.norm().clamp(min=1e-12))
 
