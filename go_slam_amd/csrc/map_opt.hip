@@ -28,18 +28,18 @@ __global__ __launch_bounds__(256) void map_grad_sqnorm_kernel(const _Float16* __
   const size_t n8 = n16 / 8;
   const half8* g8 = reinterpret_cast<const half8*>(g16);
   size_t i0 = tid;
-  {                                                     // four 16-byte loads in flight per thread (one at a time made
+  {                                                     // eight 16-byte loads in flight per thread (one at a time made
     float a4[4] = {0.f, 0.f, 0.f, 0.f};                 // the 25 MB pass latency-bound: 12.6 us for 12 dependent trips)
-    for (; i0 + 3 * stride < n8; i0 += 4 * stride) {
-      half8 v[4];
+    for (; i0 + 7 * stride < n8; i0 += 8 * stride) {
+      half8 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = g8[i0 + u * stride];
+      for (int u = 0; u < 8; ++u) v[u] = g8[i0 + u * stride];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const float f = (float)v[u][k] * inv_scale16;
-          a4[u] = fmaf(f, f, a4[u]);
+          a4[u & 3] = fmaf(f, f, a4[u & 3]);
         }
     }
     acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
@@ -151,7 +151,8 @@ extern "C" int gs_map_grad_sqnorm(const void* g16, size_t n16, float inv_scale16
   if (n16 + n32 == 0) return GS_OK;
   const size_t work = n16 / 8 + n32;
   unsigned blocks = (unsigned)((work + 255) / 256);
-  if (blocks > 512) blocks = 512;       // every workgroup ends with an atomic on ONE address: 2048 of them cost ~25 us
+  if (blocks > 256) blocks = 256;       // every workgroup ends with an atomic on ONE address: 2048 of them cost ~25 us,
+                                        // 512 still ~6 of this kernel's 12
   if (blocks == 0) blocks = 1;
   map_grad_sqnorm_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const _Float16*)g16, n16, inv_scale16, g32, n32,
                                                                    sqnorm_out);
@@ -278,10 +279,16 @@ __global__ __launch_bounds__(1024) void map_step_prep_kernel(const float* __rest
     sdf_wt[tid] = sdf_w[o * 35 + 3 + lf];
   }
   if (mlp16 && frag_index && mlp_wpack) {              // the MLP backward's 40 A-fragments (was: cat + index + fill launches)
-    for (int i = tid; i < 40 * 64 * 8; i += 1024) {
-      const int j = frag_index[i];
-      mlp_wpack[i] = j < 10240 ? mlp16[j] : (_Float16)0.0f;
-    }
+    // 20 entries per thread: all indices first, then all gathers (rolled, the two dependent loads per entry cost 40
+    // memory round trips in this one-workgroup kernel: 5 -> 19 us)
+    int j[20];
+    _Float16 v[20];
+#pragma unroll
+    for (int u = 0; u < 20; ++u) j[u] = frag_index[tid + 1024 * u];
+#pragma unroll
+    for (int u = 0; u < 20; ++u) v[u] = mlp16[j[u] < 10240 ? j[u] : 0];
+#pragma unroll
+    for (int u = 0; u < 20; ++u) mlp_wpack[tid + 1024 * u] = j[u] < 10240 ? v[u] : (_Float16)0.0f;
   }
 }
 

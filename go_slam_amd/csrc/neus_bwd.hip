@@ -536,8 +536,10 @@ __device__ __forceinline__ long long fix24(uint32_t h) {       // fp16 bits -> v
 __global__ __launch_bounds__(1024) void grid_bin_reduce_kernel(const uint16_t* __restrict__ q_idx,
                                                                const uint32_t* __restrict__ q_val,
                                                                const uint8_t* __restrict__ q_cnt, int nblk,
-                                                               _Float16* __restrict__ tab16, gs_grid_meta m) {
+                                                               int cnt_in_lds, _Float16* __restrict__ tab16,
+                                                               gs_grid_meta m) {
   extern __shared__ unsigned long long acc[];          // [BIN_ENTRIES][2] 64-bit fixed point (two's complement)
+                                                       // | (cnt_in_lds) the bin's nblk fill counts
   __shared__ int nonfinite;                            // a NaN / inf record was seen: fix24 saturates, so a second scan
                                                        // writes those records' own bits (a diverged step stays visible)
   if (threadIdx.x == 0) nonfinite = 0;
@@ -547,31 +549,61 @@ __global__ __launch_bounds__(1024) void grid_bin_reduce_kernel(const uint16_t* _
     if (m.hashed[k]) { if (seen == h) l = k; ++seen; }
   const int tid = threadIdx.x;
   for (int e = tid; e < 2 * BIN_ENTRIES / 2; e += 1024) reinterpret_cast<uint4*>(acc)[e] = make_uint4(0u, 0u, 0u, 0u);
-  __syncthreads();
   const uint8_t* cnt = q_cnt + (size_t)q * nblk;
   const uint16_t* qi = q_idx + (size_t)q * nblk * ST_SLOTS;
   const uint32_t* qv = q_val + (size_t)q * nblk * ST_SLOTS;
+  // The fill counts go to LDS first: read from memory inside the loop below, every segment cost TWO dependent round
+  // trips (count, then records) in a rolled loop of nblk / 85 steps -- 108 steps at 32768 rays, the bulk of this
+  // kernel's 533 us.  With the counts at hand four segments' record loads are issued back to back.
+  uint8_t* lcnt = reinterpret_cast<uint8_t*>(acc + 2 * BIN_ENTRIES);
+  if (cnt_in_lds) {
+    for (int i0 = tid; i0 < nblk; i0 += 1024 * 4) {
+      uint8_t c4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c4[u] = i0 + 1024 * u < nblk ? cnt[i0 + 1024 * u] : (uint8_t)0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + 1024 * u < nblk) lcnt[i0 + 1024 * u] = c4[u];
+    }
+  }
   // a segment (one pass-1 workgroup's records for this bin: ST_SLOTS = 48 slots, `cnt` of them filled) is read by 12
   // threads, 4 records each: one 8-byte index load + one 16-byte value load
   constexpr int TPS = ST_SLOTS / 4;                    // threads per segment
   constexpr int SPB = 1020 / TPS;                      // segments per workgroup step (85)
   const int sub = tid / TPS, part = tid - sub * TPS;
+  __syncthreads();                                     // (zeroed accumulators, counts in LDS)
   if (sub < SPB) {
-    for (int sg = sub; sg < nblk; sg += SPB) {
-      const int c = cnt[sg];
-      const int s0 = 4 * part;
-      if (s0 < c) {
-        const size_t at = (size_t)sg * ST_SLOTS + s0;
-        const uint2 ix = *reinterpret_cast<const uint2*>(qi + at);
-        const uint4 vv = *reinterpret_cast<const uint4*>(qv + at);
-        const uint32_t iw[4] = {ix.x & 0xffffu, ix.x >> 16, ix.y & 0xffffu, ix.y >> 16};
-        const uint32_t vw[4] = {vv.x, vv.y, vv.z, vv.w};
+    constexpr int UN = 4;                              // segments in flight per thread
+    const int s0 = 4 * part;
+    for (int sg0 = sub; sg0 < nblk; sg0 += UN * SPB) {
+      int c[UN];
+      uint2 ix[UN];
+      uint4 vv[UN];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (s0 + k < c) {
-            atomicAdd(&acc[2 * iw[k]], (unsigned long long)fix24(vw[k] & 0xffffu));
-            atomicAdd(&acc[2 * iw[k] + 1], (unsigned long long)fix24(vw[k] >> 16));
-            if ((vw[k] & 0x7c00u) == 0x7c00u || (vw[k] & 0x7c000000u) == 0x7c000000u) nonfinite = 1;
+      for (int u = 0; u < UN; ++u) {
+        const int sg = sg0 + u * SPB;
+        c[u] = sg < nblk ? (int)(cnt_in_lds ? lcnt[sg] : cnt[sg]) : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (s0 < c[u]) {
+          const size_t at = (size_t)(sg0 + u * SPB) * ST_SLOTS + s0;
+          ix[u] = *reinterpret_cast<const uint2*>(qi + at);
+          vv[u] = *reinterpret_cast<const uint4*>(qv + at);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (s0 < c[u]) {
+          const uint32_t iw[4] = {ix[u].x & 0xffffu, ix[u].x >> 16, ix[u].y & 0xffffu, ix[u].y >> 16};
+          const uint32_t vw[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (s0 + k < c[u]) {
+              atomicAdd(&acc[2 * iw[k]], (unsigned long long)fix24(vw[k] & 0xffffu));
+              atomicAdd(&acc[2 * iw[k] + 1], (unsigned long long)fix24(vw[k] >> 16));
+              if ((vw[k] & 0x7c00u) == 0x7c00u || (vw[k] & 0x7c000000u) == 0x7c000000u) nonfinite = 1;
+            }
           }
         }
       }
@@ -709,10 +741,13 @@ static int backward_points_impl(const float* rays_o, const float* rays_d, const 
   else neus_point_bwd_kernel<true, false><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(A, m);
   GS_CHECK_LAUNCH("neus_backward_points_binned");
   static GsLdsLimit limit;
-  const size_t lds = (size_t)2 * BIN_ENTRIES * sizeof(unsigned long long);
+  const size_t acc_bytes = (size_t)2 * BIN_ENTRIES * sizeof(unsigned long long);
+  const size_t cnt_bytes = gs_align(nblk, 16);                        // the bin's fill counts, if they fit beside the sums
+  const int cnt_in_lds = acc_bytes + cnt_bytes + 256 <= (size_t)160 * 1024;
+  const size_t lds = acc_bytes + (cnt_in_lds ? cnt_bytes : 0);
   if (int rc = limit.raise((const void*)grid_bin_reduce_kernel, lds, "grid_bin_reduce")) return rc;
   grid_bin_reduce_kernel<<<(unsigned)nq, 1024, lds, (hipStream_t)stream>>>(A.q_idx, A.q_val, A.q_cnt, (int)nblk,
-                                                                           A.grid_grad16, m);
+                                                                           cnt_in_lds, A.grid_grad16, m);
   GS_CHECK_LAUNCH("grid_bin_reduce");
   return GS_OK;
 }
