@@ -230,11 +230,11 @@ def encoder_tail_roofline(device):
             "note": "three launches on a 4.9 MB tensor: bound by launch / dependency latency, not by HBM (DESIGN 3b)"}
 
 
-def motion_filter_frame_ms(device):
+def motion_filter_frame_ms(device, return_fn=False):
     """Per INPUT frame (not per keyframe): MotionFilter.track on a 480x640 RGB-D frame that is not promoted to a keyframe
     (src/motion_filter.py:41-90) = feature encoder fnet (7x7 stride-2 stem, residual blocks with instance norm; the
-    reference's BasicEncoder, here MIOpen NHWC fp16) + correlation volume against the last keyframe + one update-operator
-    iteration + the keyframe decision (one host scalar)."""
+    reference's BasicEncoder, here gs_enc_conv + gs_norm_act, NHWC fp16) + correlation volume against the last keyframe +
+    one update-operator iteration + the keyframe decision (one host scalar)."""
     from go_slam_amd.depth_video import DepthVideo
     from go_slam_amd.droid_net import DroidNet
     from go_slam_amd.motion_filter import MotionFilter
@@ -250,6 +250,8 @@ def motion_filter_frame_ms(device):
 
     def frame():
         mf.track(1.0, img.clone(), depth, intr)
+    if return_fn:
+        return frame
     return time_op(frame, iters=10, warm=3)
 
 
