@@ -246,7 +246,11 @@ __global__ __launch_bounds__(256) void chol_back_block_kernel(const double* __re
 // y[c] is updated independently, no reductions).
 constexpr int SMALL_N = 192;
 constexpr int CB = 6;      // camera block
-constexpr int SMALL_NT = 1024;   // one workgroup, 16 waves: latency hiding for the LDS-resident steps
+#ifndef GS_CHOL_NT
+#define GS_CHOL_NT 1024
+#endif
+constexpr int SMALL_NT = GS_CHOL_NT;   // one workgroup, 16 waves: latency hiding for the LDS-resident steps (tools/chol_bench.hip
+                                       // builds other sizes with -DGS_CHOL_NT=...)
 constexpr int PW = 30;     // panel width (5 camera blocks): far updates are deferred per panel
 
 #ifdef CHOL_TIMING   // tools/chol_bench.hip only: per-phase wall-clock stamps (100 MHz)

@@ -95,6 +95,7 @@ extern "C" int gs_mapping_loss(const float* color, const float* depth, const flo
                  d_sdf && loss_rays, "mapping_loss: null pointer");
   GS_REQUIRE(n >= 0 && s > 0 && s <= 128, "mapping_loss: 1 <= samples per ray <= 128 (got %d)", s);
   if (n == 0) return GS_OK;
+  GS_TIMING_PRE();
   map_loss_kernel<<<gs_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(color, depth, depth_var, sdf, z_vals, rays_color,
                                                                  rays_depth, counts, truncation, sparse_factor, w_color,
                                                                  w_sdf, uncertainty, d_color, d_depth, d_sdf, loss_rays,

@@ -154,6 +154,7 @@ extern "C" int gs_map_grad_sqnorm(const void* g16, size_t n16, float inv_scale16
   if (blocks > 256) blocks = 256;       // every workgroup ends with an atomic on ONE address: 2048 of them cost ~25 us,
                                         // 512 still ~6 of this kernel's 12
   if (blocks == 0) blocks = 1;
+  GS_TIMING_PRE();
   map_grad_sqnorm_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const _Float16*)g16, n16, inv_scale16, g32, n32,
                                                                    sqnorm_out);
   GS_CHECK_LAUNCH("map_grad_sqnorm");
@@ -172,6 +173,7 @@ static int launch_adamw(AdamArgs A, int step, gs_stream_t stream) {
   unsigned blocks = (unsigned)((work + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   if (blocks == 0) blocks = 1;
+  GS_TIMING_PRE();
   map_adamw_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(A);
   GS_CHECK_LAUNCH("map_adamw");
   return GS_OK;
@@ -538,6 +540,7 @@ extern "C" int gs_map_step_prep(const float* rays_depth, int n, const float* var
   GS_REQUIRE((rays_depth || counts_in) && variance && counts_out && inv_s_out && d_gerr_out && d_invs && sqnorm && step_dev,
              "map_step_prep: null pointer");
   GS_REQUIRE(n >= 0 && samples > 0, "map_step_prep: bad shape");
+  GS_TIMING_PRE();
   map_step_prep_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(rays_depth, n, variance, scale_factor, w_eikonal, samples,
                                                            counts_in, counts_out, inv_s_out, d_gerr_out, d_invs, sqnorm,
                                                            step_dev, sdf_w, sdf_wt_out, (const _Float16*)mlp16, frag_index,
@@ -558,6 +561,7 @@ extern "C" int gs_map_step_post(const float* gram_chunks, int nchunk, float inv_
   A.d_invs = d_invs; A.variance = variance; A.inv_s = inv_s; A.scale_factor = scale_factor; A.loss_rays = loss_rays;
   A.gerr = gerr; A.n = n; A.w_eik = w_eikonal; A.s = samples; A.counts = counts; A.g32 = g32;
   const int blocks = 10240 / 32 + (32 * 35 + 32 + 99 + 31) / 32 + 1;
+  GS_TIMING_PRE();
   map_step_post_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(A);
   GS_CHECK_LAUNCH("map_step_post");
   return GS_OK;

@@ -859,6 +859,7 @@ extern "C" int gs_render_sample(const float* rays_o, const float* rays_d, const 
   GS_REQUIRE(n >= 0 && n_samples > 0 && n_surface >= 0, "render_sample: bad shape");
   GS_REQUIRE(n_surface == 0 || t_surface, "render_sample: t_surface required");
   if (n == 0) return GS_OK;
+  GS_TIMING_PRE();
   if (n_samples <= 64 && n_surface <= 64)
     render_sample_wave_kernel<<<gs_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(
         rays_o, rays_d, gt_depth, bound, t_samples, t_surface, perturb, gt_max, gt_max_dev, z_vals, dists, n, n_samples,

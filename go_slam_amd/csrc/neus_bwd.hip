@@ -667,6 +667,7 @@ extern "C" int gs_neus_backward_rays(const float* alpha, const void* rgb, const 
                  d_alpha && d_rgb && d_grad, "neus_backward_rays: null pointer");
   GS_REQUIRE(n >= 0 && s > 0 && s <= 128, "neus_backward_rays: 1 <= samples per ray <= 128 (got %d)", s);
   if (n == 0) return GS_OK;
+  GS_TIMING_PRE();
   neus_ray_bwd_kernel<<<gs_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(alpha, (const _Float16*)rgb, z_mid, grad, mask,
                                                                      d_color, d_depth, d_depth_var, d_normal,
                                                                      d_weight_sum, d_alpha, d_rgb, d_grad, n, s);

@@ -332,6 +332,7 @@ extern "C" int gs_mlp_backward(const void* x, const void* wpack, const float* d_
   const size_t lds = (size_t)(NFRAG * 512 + 4 * WAVE_LDS) * sizeof(_Float16);
   static GsLdsLimit limit;
   if (int rc = limit.raise((const void*)neus_mlp_bwd_kernel, lds, "mlp_backward")) return rc;
+  GS_TIMING_PRE();
   neus_mlp_bwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const _Float16*)x, (const _Float16*)wpack, d_rgb,
                                                               (const _Float16*)rgb, loss_scale, (_Float16*)dx, partial,
                                                               n, nblk);
