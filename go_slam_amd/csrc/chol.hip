@@ -250,7 +250,9 @@ constexpr int CB = 6;      // camera block
 #define GS_CHOL_NT 1024
 #endif
 constexpr int SMALL_NT = GS_CHOL_NT;   // one workgroup, 16 waves: latency hiding for the LDS-resident steps (tools/chol_bench.hip
-                                       // builds other sizes with -DGS_CHOL_NT=...)
+                                       // builds other sizes with -DGS_CHOL_NT=...; 512 and 768 solve correctly but
+                                       // slower, 256 does not: the work splits below assume >= 8 waves)
+static_assert(SMALL_NT >= 512 && SMALL_NT % 64 == 0 && SMALL_NT <= 1024, "chol: 512 .. 1024 threads");
 constexpr int PW = 30;     // panel width (5 camera blocks): far updates are deferred per panel
 
 #ifdef CHOL_TIMING   // tools/chol_bench.hip only: per-phase wall-clock stamps (100 MHz)
