@@ -478,12 +478,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if (force_pass) {                                 // one workgroup: did any wave of the main pass see a point in bound?
     const int nw = (np + 63) >> 6;
     int any = 0;                                    // (every wave scans all flags itself: no LDS, no barrier)
-    for (int i = lane * 16; i < nw; i += 1024) {
-      if (i + 16 <= nw) {
-        const uint4 v = *reinterpret_cast<const uint4*>(flags + i);
-        any |= (v.x | v.y | v.z | v.w) != 0u;
-      } else {
-        for (int k = i; k < nw; ++k) any |= flags[k];
+    for (int i0 = lane * 16; i0 < nw; i0 += 8 * 1024) {    // eight 16-byte loads in flight (36 dependent trips at 32768
+      uint4 v[8];                                          // rays otherwise: 20 us for a pass that has nothing to do)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 1024 * u;
+        v[u] = i + 16 <= nw ? *reinterpret_cast<const uint4*>(flags + i) : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 1024 * u;
+        any |= (v[u].x | v[u].y | v[u].z | v[u].w) != 0u;
+        if (i < nw && i + 16 > nw)
+          for (int k = i; k < nw; ++k) any |= flags[k];
       }
     }
     if (__ballot(any != 0) != 0ull) return;         // (uniform) some point was in bound: nothing to force
@@ -978,7 +985,7 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
                                                       (_Float16*)mlp_in_out, (_Float16*)enc_aux_out, (const _Float16*)mlp,
                                                       rgb);
   GS_CHECK_LAUNCH("neus_point");
-  neus_point_kernel<<<1, 256, 0, st>>>(A, host_meta(), ws.flags, 1, sdf, z_mid, alpha, grad, ws.mask,
+  neus_point_kernel<<<1, 128, 0, st>>>(A, host_meta(), ws.flags, 1, sdf, z_mid, alpha, grad, ws.mask,   // points 0..127
                                        (_Float16*)mlp_in_out, (_Float16*)enc_aux_out, (const _Float16*)mlp, rgb);
   GS_CHECK_LAUNCH("neus_force100");
   neus_ray_kernel<<<gs_cdiv(n, 4), 256, 0, st>>>(alpha, rgb, z_mid, grad, ws.mask, color, depth, depth_var, normal,
