@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256) void render_sample_kernel(
   };
   // merge the two monotone runs (= the reference's torch.sort of their concatenation, render.py:168-171).  Both are
   // ascending except in two degenerate cases, where they are walked backwards: far < near (a ray whose box exit lies
-  // behind the camera: far clamps to 0) and, for rays without depth, a batch maximum below 0.001.
-  const bool rev_a = span < 0.0f, rev_b = !(gd > 0.0f) && gt_max < 0.001f;
+  // behind the camera: far clamps to 0) and, for rays without depth, a batch maximum below 0.001.  WITHOUT near-surface
+  // samples (no depth image) the reference does not sort at all (:162): a descending run stays descending.
+  const bool rev_a = span < 0.0f && nsurf > 0, rev_b = !(gd > 0.0f) && gt_max < 0.001f;
   auto zsa = [&](int j) { return zs(rev_a ? ns - 1 - j : j); };
   auto zfa = [&](int j) { return zf(rev_b ? nsurf - 1 - j : j); };
   int a = 0, b = 0;
@@ -150,8 +151,9 @@ __global__ __launch_bounds__(256) void render_sample_wave_kernel(
   const float span = farv - nearv;
   auto zu = [&](int j) { return nearv + span * t_samples[j]; };
   // (descending runs -- far < near, or no-depth rays under a batch maximum below 0.001 -- are walked backwards: the
-  // merge below then equals the reference's sort in those degenerate cases too)
-  const bool rev_a = span < 0.0f, rev_b = !(gd > 0.0f) && gt_max < 0.001f;
+  // merge below then equals the reference's sort in those degenerate cases too; without near-surface samples the
+  // reference does not sort, render.py:162, and the run is left as it is)
+  const bool rev_a = span < 0.0f && nsurf > 0, rev_b = !(gd > 0.0f) && gt_max < 0.001f;
   float za = INFINITY, zb = INFINITY;
   if (lane < ns) {
     const int j = rev_a ? ns - 1 - lane : lane;

@@ -15,7 +15,7 @@ submodule empty, `tinycudann` not installed), so those imports are satisfied by 
 What the fixtures therefore PIN is every line of reference Python on the hot path:
   * modules/corr.py      CorrBlock.corr + pyramid build (pure torch)          -> corr_*.npz
   * geom/projective_ops  projective_transform with and without Jacobians      -> proj_*.npz
-  * render.py            Renderer.render_batch_ray sample placement           -> render_sample.npz
+  * render.py            Renderer.render_batch_ray sample placement           -> render_sample.npz, render_sample_mono.npz
   * nerf_func.py         build_rays                                            -> build_rays.npz
   * geom/ba.py + chol.py  BA: the pure-PyTorch dense bundle adjustment (one Gauss-Newton step)  -> ba_python.npz
   * droid_net.py + modules/gru.py  UpdateModule / ConvGRU / GraphAgg / cvx_upsample (CPU fp32)  -> update_module.npz
@@ -190,6 +190,42 @@ def gen_render():
     R.render_batch_ray(o, d, Net(), None, device="cpu", gt_depth=None)
     save("render_sample.npz", rays_o=o, rays_d=d, gt_depth=gt, bound=bound, perturb=pr, z_depth=z1, dists_depth=d1,
          z_nodepth=grabbed["z"], dists_nodepth=grabbed["d"])
+
+
+def gen_render_mono():
+    """configs[4] (configs/Replica/replica_mono.yaml:54-55): 48 stratified + 24 near-surface samples, and the degenerate
+    rays a batch can contain: no depth measurement, the box exit behind the camera (far < near: the stratified run comes out
+    DESCENDING before the reference's sort), an origin outside the bound, a batch whose depth maximum is tiny."""
+    render = importlib.import_module("refsrc.render")
+    cfg = {"rendering": {"lindisp": False, "perturb": 1.0, "N_samples": 48, "N_surface": 24}}
+    slam = types.SimpleNamespace(H=340, W=600, fx=300.0, fy=300.0, cx=299.5, cy=169.5)
+    R = render.Renderer(cfg, None, slam)
+    g = torch.Generator().manual_seed(109)
+    n = 131
+    o = torch.rand(n, 3, generator=g) * 4 - 2
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+    gt = torch.rand(n, generator=g) * 3.5 + 0.5
+    gt[::7] = 0
+    bound = torch.tensor([[-2.5, 2.5], [-2.0, 2.25], [-1.5, 3.0]])
+    o[3] = torch.tensor([4.0, 0.1, 0.2]); d[3] = torch.tensor([1.0, 0.0, 0.0])       # outside, looking away: exit behind
+    o[4] = torch.tensor([-3.5, 0.0, 0.5]); d[4] = torch.tensor([-0.6, 0.8, 0.0])
+    o[5] = torch.tensor([2.4, 2.2, 2.9]); d[5] = torch.nn.functional.normalize(torch.tensor([1.0, 1.0, 1.0]), dim=0)
+    gt[3], gt[4], gt[5] = 1.5, 0.0, 2.0
+    grabbed = {}
+
+    class Net:
+        def __init__(self): self.bound = bound
+        def __call__(self, ro, rd, zv, ds, render_params=None):
+            grabbed["z"], grabbed["d"] = zv.clone(), ds.clone()
+            return {"z": zv}
+    out = {}
+    for tag, depth in (("depth", gt), ("tiny", gt * 2e-4), ("nodepth", None)):
+        torch.manual_seed(4321)
+        R.render_batch_ray(o, d, Net(), None, device="cpu", gt_depth=depth)
+        out["z_" + tag], out["dists_" + tag] = grabbed["z"], grabbed["d"]
+    torch.manual_seed(4321)
+    pr = torch.rand(48)
+    save("render_sample_mono.npz", rays_o=o, rays_d=d, gt_depth=gt, bound=bound, perturb=pr, **out)
 
 
 def gen_neus():
@@ -1045,5 +1081,6 @@ if __name__ == "__main__":
         gen_corr()
         gen_proj()
         gen_render()
+        gen_render_mono()
         gen_rays()
     gen_neus()

@@ -69,6 +69,25 @@ def test_render_sample_bit_exact(N, O, dev, with_depth, perturb):
     torch.testing.assert_close(dd.cpu()[:, -1], dr[:, -1], rtol=3e-7, atol=0)
 
 
+def test_render_sample_mono_golden_from_the_reference_renderer(N, dev):
+    """The kernel against the REFERENCE's own output (tests/golden/render_sample_mono.npz: src/render.py:99-171 executed
+    verbatim with configs[4]'s 48 + 24 split; rays without depth, box exits behind the camera, a batch whose depth
+    maximum is below 0.001) -- no oracle in between."""
+    import numpy as np
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(os.path.dirname(__file__), "golden",
+                                                                  "render_sample_mono.npz")).items()}
+    R = N.Renderer(N_samples=48, N_surface=24, perturb=1.0)
+    o, d, bound, pr = (g[k].to(dev) for k in ("rays_o", "rays_d", "bound", "perturb"))
+    for tag, depth in (("depth", g["gt_depth"]), ("tiny", g["gt_depth"] * 2e-4), ("nodepth", None)):
+        z, dd = R.sample(o, d, bound, None if depth is None else depth.to(dev), pr)
+        z, dd, zr, dr = z.cpu(), dd.cpu(), g["z_" + tag], g["dists_" + tag]
+        assert z.shape == zr.shape, tag
+        assert torch.equal(z.isnan(), zr.isnan()) and torch.equal(dd.isnan(), dr.isnan()), tag
+        assert torch.equal(z.nan_to_num(7.0), zr.nan_to_num(7.0)), (tag, float((z - zr).abs().nan_to_num(0).max()))
+        assert torch.equal(dd[:, :-1].nan_to_num(7.0), dr[:, :-1].nan_to_num(7.0)), tag
+        torch.testing.assert_close(dd[:, -1], dr[:, -1], rtol=3e-7, atol=0, equal_nan=True)   # (a mean in the reference)
+
+
 def test_grid_encode_matches_oracle(N, O, dev):
     P = O.make_params(2, grid_init=0.5)
     g = torch.Generator().manual_seed(4)

@@ -203,6 +203,20 @@ def test_render_sample_matches_reference_renderer():
     assert torch.equal(z, g["z_nodepth"]) and torch.equal(d, g["dists_nodepth"])
 
 
+def test_render_sample_mono_split_and_degenerate_rays_match_reference_renderer():
+    """configs[4]'s split (48 stratified + 24 near-surface, replica_mono.yaml:54-55) through the reference's own
+    Renderer, incl. rays whose box exit lies behind the camera (descending stratified run before the sort), rays without a
+    depth measurement, and a batch whose depth maximum is below the near-surface floor of 0.001."""
+    g = _load("render_sample_mono.npz")
+    for tag, depth in (("depth", g["gt_depth"]), ("tiny", g["gt_depth"] * 2e-4), ("nodepth", None)):
+        z, d = NO.render_sample(g["rays_o"], g["rays_d"], depth, g["bound"], 48, 24, g["perturb"])
+        zr, dr = g["z_" + tag], g["dists_" + tag]
+        assert torch.equal(z.isnan(), zr.isnan()) and torch.equal(d.isnan(), dr.isnan()), tag
+        assert torch.equal(z.nan_to_num(7.0), zr.nan_to_num(7.0)), tag
+        assert torch.equal(d.nan_to_num(7.0), dr.nan_to_num(7.0)), tag
+    assert bool((g["z_depth"][:, 1:] < g["z_depth"][:, :-1]).any()) is False      # the reference's output is sorted
+
+
 def test_neus_forward_matches_reference_instantneus():
     """reference src/InstantNeuS.py:295-400 executed verbatim (masking, normalisation, the sdf
     gradient by autograd.grad through cat/Linear/encoding, get_alpha, compositing, sdf losses)
