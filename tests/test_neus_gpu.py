@@ -181,6 +181,35 @@ def test_neus_forward_matches_oracle(N, O, dev, grid_init):
     torch.testing.assert_close(c["sdf_variance"], ref["sdf_variance"])
 
 
+def test_neus_forward_matches_the_reference_module_fixture(N, O, dev):
+    """The fused forward against tests/golden/neus_forward.npz = the REFERENCE's `InstantNeuS.forward` + `compute_sdf_error`
+    (src/InstantNeuS.py:295-400) executed verbatim on the tcnn stand-in, same rays / samples / parameters -- the fixture the
+    oracle is pinned to (tests/test_oracle_pinned.py), here without the oracle in between."""
+    import numpy as np
+    g = {k: torch.from_numpy(np.asarray(v)) for k, v in
+         np.load(os.path.join(os.path.dirname(__file__), "golden", "neus_forward.npz")).items() if v.dtype.kind in "fiu"}
+    P = O.make_params(int(g["seed"]), grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))   # (parameters only)
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    model.update_bound(g["rt_bound"])
+    with torch.no_grad():
+        out = model(g["rays_o"].to(dev), g["rays_d"].to(dev), g["z_in"].to(dev), g["dists_in"].to(dev))
+        e, f = model.compute_sdf_error(out["sdf"], out["z_vals"], g["gt_depth"].to(dev))
+    c = {k: v.cpu() for k, v in out.items()}
+    assert torch.equal(c["z_vals"], g["z_vals"])
+    assert torch.equal(c["sdf"] == 100.0, g["sdf"] == 100.0), "in-bound masks must agree exactly"
+    torch.testing.assert_close(c["sdf"], g["sdf"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(c["weight_sum"], g["weight_sum"], rtol=0, atol=5e-4)
+    torch.testing.assert_close(c["depth"], g["depth"], rtol=0, atol=2e-3)
+    torch.testing.assert_close(c["depth_variance"], g["depth_variance"], rtol=1e-2, atol=2e-3)
+    torch.testing.assert_close(c["color"], g["color"], rtol=0, atol=4e-3)
+    torch.testing.assert_close(c["normal"], g["normal"], rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(c["gradient_error"], g["gradient_error"], rtol=2e-3, atol=1e-5)
+    torch.testing.assert_close(c["sdf_variance"], g["sdf_variance"])
+    torch.testing.assert_close(e.cpu(), g["sdf_error"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(f.cpu(), g["sdf_front_error"], rtol=1e-3, atol=1e-5)
+
+
 def test_neus_forward_no_point_in_bound_forces_first_100(N, O, dev):
     """Q14 (InstantNeuS.py:311-312): realtime bound far away => first 100 points forced valid."""
     P = O.make_params(11, grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
