@@ -142,6 +142,51 @@ def test_reproject_matches_oracle_and_identity_kat(db, O, dev):
     torch.testing.assert_close(c.cpu()[0], torch.stack([xs, ys], -1)[None].expand(24, -1, -1, -1), atol=2e-4, rtol=0)
 
 
+def _fixture(name):
+    import os
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+    return {k: torch.from_numpy(np.asarray(g[k])) for k in g.files if g[k].dtype.kind in "fiub"}
+
+
+def test_reproject_matches_the_reference_fixture(db, dev):
+    """gs_reproject against tests/golden/proj.npz = the REFERENCE's `projective_transform` (src/geom/projective_ops.py:114-144)
+    executed verbatim (incl. a stereo edge) -- the fixture the oracle is pinned to, here without the oracle in between."""
+    g = _fixture("proj.npz")
+    c, v = db.reproject(g["poses"].to(dev), g["disps"].to(dev), g["intrinsics"].to(dev), g["ii"].to(dev), g["jj"].to(dev))
+    assert torch.equal(v.cpu().reshape(g["valid"].shape), g["valid"])
+    torch.testing.assert_close(c.cpu().reshape(g["coords"].shape), g["coords"], rtol=1e-6, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag,dt", [("f32", torch.float32), ("f16", torch.float16)])
+def test_corrblock_matches_the_reference_fixture(dev, built_lib, tag, dt):
+    """`CorrBlock(fmap1, fmap2)(coords)` against tests/golden/corr_*.npz = the reference's CorrBlock (src/modules/corr.py:26-53,
+    67-76) executed verbatim: the four pyramid levels and the 196-channel lookup.  fp16 takes the MFMA volume kernel (the
+    GEMM's fp32 accumulation order may differ by one fp16 rounding per entry, as for the oracle), fp32 the reference's own
+    matmul + avg_pool2d formulation followed by the HIP lookup."""
+    from go_slam_amd.corr import CorrBlock
+    g = _fixture(f"corr_{tag}.npz")
+    blk = CorrBlock(g["fmap1"].to(dt).to(dev), g["fmap2"].to(dt).to(dev))
+    for i in range(4):
+        ref = g[f"pyr{i}"]
+        got = blk.corr_pyramid[i].float().cpu().reshape(ref.shape)
+        if dt == torch.float32:
+            torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+        else:
+            diff = (got - ref).abs()
+            assert float(diff.max()) <= 2 ** -10 * max(1.0, float(ref.abs().max())), (i, float(diff.max()))
+            assert float((diff == 0).float().mean()) > 0.98, (i, float((diff == 0).float().mean()))
+    out = blk(g["coords"].to(dev)).float().cpu()
+    ref = g["lookup"]
+    assert out.shape == ref.shape
+    if dt == torch.float32:
+        torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    else:       # built from a volume that may differ by one rounding in < 2 % of its entries
+        diff = (out - ref).abs()
+        assert float(diff.max()) <= 2 ** -9 * max(1.0, float(ref.abs().max())), float(diff.max())
+        assert float((diff == 0).float().mean()) > 0.95, float((diff == 0).float().mean())
+
+
 def test_projmap_frame_distance_iproj_depth_filter(db, O, dev):
     vid = synth.make_video(10, "tiny", seed=9)
     ii, jj = synth.make_graph(10, 30, seed=9)
