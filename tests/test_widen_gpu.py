@@ -647,6 +647,43 @@ def test_encoders_on_device_match_reference_golden(built_lib):
     assert float((ch.float().cpu() - g["cnet"]).abs().max()) < 3e-2 * sc
 
 
+def test_update_operator_on_device_matches_reference_module_fixture(built_lib):
+    """The production update operator (own fp16 convolutions, fused GRU gates, fused heads, GraphAgg) and cvx_upsample
+    against tests/golden/update_module.npz = the REFERENCE's own UpdateModule / ConvGRU / GraphAgg / cvx_upsample
+    (src/droid_net.py:26-140, src/modules/gru.py) run in fp32 on the CPU with the same name-seeded weights.  The host
+    mirror is pinned to this fixture on the CPU (tests/test_oracle_pinned.py); here the DEVICE path meets it directly.
+    Tolerance = fp16 inputs, weights and activations against an fp32 evaluation."""
+    import importlib.util
+    import numpy as np
+    from go_slam_amd.droid_net import UpdateModule, cvx_upsample
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(os.path.dirname(__file__), "golden",
+                                                                             "gen_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "update_module.npz"))
+    t = lambda k: torch.from_numpy(np.asarray(G[k]))
+    dev = "cuda:0"
+    cl = torch.channels_last
+    op = UpdateModule().eval()
+    op.load_state_dict(gen.named_weights(op.state_dict()))
+    op = op.to(dev).to(memory_format=cl)
+    h16 = lambda x: x[0].to(dev).half().contiguous(memory_format=cl).unsqueeze(0)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        net, delta, weight, eta, upmask = op(h16(t("net")), h16(t("inp")), h16(t("corr")), t("flow").to(dev),
+                                             t("ii").to(dev), t("jj").to(dev))
+    with torch.no_grad():
+        up = cvx_upsample(t("up_data").to(dev), upmask[0].float())
+    rep = {}
+    for name, got in (("net_out", net), ("delta", delta), ("weight", weight), ("eta", eta), ("upmask", upmask),
+                      ("up_out", up)):
+        a, b = got.float().cpu(), t(name)
+        assert a.shape == b.shape, (name, a.shape, b.shape)
+        rep[name] = (float((a - b).abs().max()), float((a - b).norm() / b.norm().clamp(min=1e-12)))
+    # measured on MI355X (relative L2): net 4.0e-4, delta 3.8e-4, weight 2.5e-4, eta 9.2e-5, upmask 4.1e-4, upsampled 3.6e-5
+    assert rep["net_out"][1] < 1.5e-3, rep
+    assert all(rep[k][1] < 2e-3 for k in ("delta", "weight", "eta", "upmask", "up_out")), rep
+
+
 @pytest.mark.parametrize("n,c,h,w", [(1, 32, 240, 320), (2, 64, 30, 40), (1, 128, 60, 80), (3, 256, 9, 8)])
 def test_norm_act_matches_torch_instance_norm_relu_add_relu(built_lib, n, c, h, w):
     """gs_norm_act (csrc/instnorm.hip) vs the op sequence of the reference's ResidualBlock on fp16 tensors
