@@ -28,6 +28,7 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
   * multiview_filter.py  MultiviewFilter.forward host logic (masks, bound, priority) -> multiview_filter.npz
   * trajectory_filler.py PoseTrajectoryFiller: bracketing, interpolation, parked items, edges -> trajectory_filler.npz
   * mapping.py + depth_video.get_mapping_item  Mapper keyframe schedule and ray batches -> mapper.npz
+  * mapping.py           Mapper.optimize_map: the loss and its gradients w.r.t. the renderer outputs -> mapper_loss.npz
   * factor_graph.py      update_lowmem chunking and call arguments (mocked kernels) -> update_lowmem.npz
   * InstantNeuS.py       normalisation, masking, sdf gradient by autograd.grad, get_alpha,
                          compositing, compute_sdf_error                       -> neus_forward.npz
@@ -963,6 +964,66 @@ def gen_mapper():
     save("mapper.npz", **arrays)
 
 
+def gen_mapper_loss():
+    """The reference's mapping loss and ITS gradients w.r.t. the renderer's outputs: `Mapper.optimize_map`
+    (src/mapping.py:60-137) executed verbatim for one iteration on a fake renderer that hands it leaf tensors, with the
+    reference's own `InstantNeuS.compute_sdf_error` (src/InstantNeuS.py:372-400) bound to a bare object.  total_loss is
+    caught at its .backward() call.  Rays without depth, samples in front of / around / behind the surface, zero and
+    large depth variances."""
+    sys.modules["refsrc.geom"].projective_ops = importlib.import_module("refsrc.geom.projective_ops")
+    droid_modules()
+    dv = importlib.import_module("refsrc.depth_video")
+    mp = importlib.import_module("refsrc.mapping")
+    neus = importlib.import_module("refsrc.InstantNeuS")
+    torch.autograd.set_detect_anomaly(False)
+    video = dv.DepthVideo(mapper_cfg(), types.SimpleNamespace(device="cpu"))
+    fill_mapping_video(video)
+    _, mapper = run_mapper(mp.Mapper, video, schedule=())
+    g = torch.Generator().manual_seed(211)
+    n, s = 157, 72
+    gt = torch.rand(n, generator=g) * 3 + 0.5
+    gt[torch.rand(n, generator=g) < 0.2] = 0.0
+    z = torch.sort(torch.rand(n, s, generator=g) * 4.5, dim=1).values
+    z[:, 30:60] = gt.clamp(min=0.3)[:, None] + (torch.rand(n, 30, generator=g) - 0.5) * 0.3
+    col = torch.rand(n, 3, generator=g)
+    leaf = lambda t: t.clone().requires_grad_(True)
+    dvar = torch.rand(n, 1, generator=g) * 0.1
+    dvar[:5] = 0.0                                                          # weight 1 / sqrt(1e-10) = 1e5
+    ret = {"color": leaf(torch.rand(n, 3, generator=g)), "depth": leaf(torch.rand(n, 1, generator=g) * 4),
+           "depth_variance": leaf(dvar), "sdf": leaf(torch.randn(n, s, generator=g) * 0.2), "z_vals": z,
+           "gradient_error": leaf(torch.tensor([0.37]))}
+    sdf_obj = types.SimpleNamespace(sdf_truncation=0.16, sdf_sparse_factor=5)
+
+    class Net:
+        def to(self, device): return self
+        def compute_sdf_error(self, sdf, z_vals, gt_depth):
+            return neus.InstantNeuS.compute_sdf_error(sdf_obj, sdf=sdf, z_vals=z_vals, gt_depth=gt_depth)
+    mapper.mapping_net = Net()
+    mapper.renderer = types.SimpleNamespace(render_batch_ray=lambda **kw: ret)
+    mapper.train_params = []
+    mapper.verbose = False
+    opt = types.SimpleNamespace(zero_grad=lambda: None, step=lambda: None)
+    caught = {}
+    real_backward = torch.Tensor.backward
+
+    def backward(self, *a, **kw):
+        caught["loss"] = self.detach().clone()
+        return real_backward(self, *a, **kw)
+    torch.Tensor.backward = backward
+    try:
+        with torch.enable_grad():
+            mp.Mapper.optimize_map(mapper, torch.zeros(n, 3), torch.zeros(n, 3), col, gt.clone(), opt, 1)   # (run_mapper put a recorder on the instance)
+    finally:
+        torch.Tensor.backward = real_backward
+    zero = lambda t, like: torch.zeros_like(like) if t is None else t
+    save("mapper_loss.npz", rays_color=col, rays_depth=gt, z_vals=z, color=ret["color"].detach(),
+         depth=ret["depth"].detach(), depth_variance=ret["depth_variance"].detach(), sdf=ret["sdf"].detach(),
+         gradient_error=ret["gradient_error"].detach(), loss=caught["loss"], d_color=ret["color"].grad,
+         d_depth=ret["depth"].grad, d_depth_variance=zero(ret["depth_variance"].grad, dvar), d_sdf=ret["sdf"].grad,
+         d_gradient_error=ret["gradient_error"].grad,
+         weights=torch.tensor([mapper.w_color_loss, mapper.w_sdf_loss, mapper.w_eikonal_loss]))
+
+
 class FakeAltCorr:
     """stands in for AltCorrBlock under update_lowmem (both sides): a deterministic function of its arguments"""
     log = None
@@ -1077,6 +1138,8 @@ if __name__ == "__main__":
         gen_multiview_filter()
         gen_filler()
         gen_mapper()
+    gen_mapper_loss()
+    with torch.no_grad():
         gen_lowmem()
         gen_corr()
         gen_proj()

@@ -399,6 +399,32 @@ def test_fused_mapping_loss_matches_torch_formulation(N, dev):
     assert a[5] is None or not bool(a[5].any())          # the uncertainty weight is detached in both
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_mapping_loss_matches_the_reference_mapper_fixture(N, dev, fused):
+    """gs_mapping_loss (fused = True: value + analytic gradients in one launch) and the masked-sum torch formulation
+    (fused = False) against tests/golden/mapper_loss.npz = the REFERENCE's `Mapper.optimize_map` loss (src/mapping.py:96-132
+    with InstantNeuS.compute_sdf_error) and the gradients its backward() left on the renderer's outputs -- rays without
+    depth, zero depth variances (uncertainty weight 1e5)."""
+    import numpy as np
+    from go_slam_amd.neus.distributed import mapping_loss_sharded
+    g = {k: torch.from_numpy(np.asarray(v)) for k, v in
+         np.load(os.path.join(os.path.dirname(__file__), "golden", "mapper_loss.npz")).items()}
+    model = N.InstantNeuS({}, [[-2.5, 2.5]] * 3).to(dev)
+    assert model.sdf_truncation == 0.16 and model.sdf_sparse_factor == 5
+    leaf = lambda k: g[k].to(dev).requires_grad_(True)
+    ret = {"color": leaf("color"), "depth": leaf("depth"), "depth_variance": leaf("depth_variance"), "sdf": leaf("sdf"),
+           "z_vals": g["z_vals"].to(dev), "gradient_error": leaf("gradient_error")}
+    wc, ws, we = (float(x) for x in g["weights"])
+    loss, glob = mapping_loss_sharded(ret, g["rays_color"].to(dev), g["rays_depth"].to(dev), model.compute_sdf_error,
+                                      None, w_color=wc, w_sdf=ws, w_eikonal=we, uncertainty=True, fused=fused)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().float().cpu(), g["loss"], rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(glob.float().cpu(), g["loss"], rtol=2e-5, atol=1e-6)
+    for k in ("color", "depth", "sdf", "gradient_error"):
+        torch.testing.assert_close(ret[k].grad.cpu(), g["d_" + k], rtol=1e-4, atol=1e-8, msg=lambda m, k=k: f"d_{k}: {m}")
+    assert ret["depth_variance"].grad is None or not bool(ret["depth_variance"].grad.any())
+
+
 def _trainer_pair(N, O, dev, n_rays, seed):
     P = O.make_params(seed, grid_init=0.05, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
     o, d, gt = _rays(n_rays, seed=seed + 1)

@@ -330,3 +330,24 @@ def test_ba_step_matches_reference_python_ba():
     # DepthVideo.ba's clamp_(min=0.001) -- apply the Python's post-processing before comparing
     disps = torch.where(disps > 10, torch.zeros_like(disps), disps).clamp(min=0.0)
     torch.testing.assert_close(disps, G["disps_out"], rtol=0, atol=1e-4)
+
+
+def test_mapping_loss_and_its_output_gradients_match_reference_mapper():
+    """oracle/neus_autograd.mapping_loss (the referee of gs_mapping_loss and of the fused mapper step) against the
+    REFERENCE's `Mapper.optimize_map` loss (src/mapping.py:96-132) and the gradients its backward() leaves on the
+    renderer's outputs (fixture mapper_loss.npz: the method executed verbatim on leaf tensors; rays without depth, zero
+    depth variances = uncertainty weight 1e5)."""
+    from oracle import neus_autograd as NA
+    g = _load("mapper_loss.npz")
+    leaf = lambda k: g[k].clone().requires_grad_(True)
+    ret = {"color": leaf("color"), "depth": leaf("depth"), "depth_variance": leaf("depth_variance"), "sdf": leaf("sdf"),
+           "z_vals": g["z_vals"], "gradient_error": leaf("gradient_error")}
+    wc, ws, we = (float(x) for x in g["weights"])
+    loss = NA.mapping_loss(ret, g["rays_color"], g["rays_depth"], 0.16, 5, wc, ws, we, True)
+    loss.backward()
+    torch.testing.assert_close(loss.detach(), g["loss"], rtol=1e-5, atol=1e-6)
+    for k in ("color", "depth", "sdf", "gradient_error"):
+        torch.testing.assert_close(ret[k].grad, g["d_" + k], rtol=1e-5, atol=1e-9, msg=lambda m, k=k: f"d_{k}: {m}")
+    assert ret["depth_variance"].grad is None or not bool(ret["depth_variance"].grad.any())
+    assert not bool(g["d_depth_variance"].any())                # detached in the reference too
+
