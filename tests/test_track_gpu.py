@@ -158,6 +158,26 @@ def test_reproject_matches_the_reference_fixture(db, dev):
     torch.testing.assert_close(c.cpu().reshape(g["coords"].shape), g["coords"], rtol=1e-6, atol=1e-4)
 
 
+def test_ba_pose_update_matches_the_reference_python_ba_fixture(db, dev):
+    """One Gauss-Newton step of `droid_backends.ba` against tests/golden/ba_python.npz = the reference's OWN pure-PyTorch
+    bundle adjustment (src/geom/ba.py + src/geom/chol.py) run on the CPU: the POSE update (accumulation, Schur
+    complement, damped Cholesky solve, retraction) must agree to the fp32 accuracy of the Python's normal equations.  The
+    depth update is not compared here: the CUDA kernel this path mirrors skips `pose index <= 0` terms in the depth
+    back-substitution, the Python does not (tests/test_oracle_pinned.py compares it with that quirk switched off in the
+    oracle; the quirk itself is checked against the oracle in the BA parity tests)."""
+    G = _fixture("ba_python.npz")
+    poses, disps = G["poses"].clone().to(dev), G["disps"].clone().to(dev)
+    n = poses.shape[0]
+    K = G["intrinsics"][0].contiguous().to(dev)
+    target = G["target"].permute(0, 3, 1, 2).contiguous().to(dev)
+    weight = G["weight"].permute(0, 3, 1, 2).contiguous().to(dev)
+    db.ba(poses, disps, K, torch.zeros_like(disps), target, weight, (G["eta"] + 1e-7).to(dev), G["ii"].to(dev),
+          G["jj"].to(dev), 1, n, 1, 1e-4, 0.1, False)
+    assert float((G["poses_out"] - G["poses"]).abs().max()) > 1e-4          # the step is not a no-op
+    torch.testing.assert_close(poses.cpu(), G["poses_out"], rtol=0, atol=1e-4)
+    assert db.ba_status(dev)["cholesky_failures"] == 0
+
+
 @pytest.mark.parametrize("tag,dt", [("f32", torch.float32), ("f16", torch.float16)])
 def test_corrblock_matches_the_reference_fixture(dev, built_lib, tag, dt):
     """`CorrBlock(fmap1, fmap2)(coords)` against tests/golden/corr_*.npz = the reference's CorrBlock (src/modules/corr.py:26-53,
