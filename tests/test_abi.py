@@ -105,3 +105,45 @@ def test_dropin_install_registers_reference_module_names(built_lib):
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+# ---- register / LDS budgets the kernels' occupancy rests on (compile-only: hipcc -S for gfx950, no GPU) -------------
+_BUDGETS = {
+    # file: {kernel-name substring: (max VGPRs, max LDS bytes)}; scratch must be 0 for all of them
+    "neus.hip": {"neus_point_kernel": (128, 40960)},                 # 4 waves per SIMD, 4 x 40 KB workgroups per CU
+    "neus_bwd.hip": {"grid_bin_reduce_kernel": (128, 16)},           # 1024 threads = 4 waves per SIMD (LDS is dynamic)
+    "conv3x3_pp.hip": {"conv3x3_pp_kernel": (256, 0)},               # 2 waves per SIMD (LDS is dynamic)
+}
+
+
+@pytest.mark.parametrize("src", sorted(_BUDGETS))
+def test_kernel_resource_budgets(src, tmp_path):
+    """`amdgpu_waves_per_eu` and 1024-thread workgroups make the compiler fit a VGPR budget -- by spilling if it has to.
+    A later edit that pushes a hot kernel over its budget would show up as a silent slowdown on the GPU; here it fails
+    the CPU suite: no scratch, VGPRs and static LDS within what the kernel's occupancy assumes."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "go_slam_amd", "csrc")
+    out = tmp_path / "k.s"
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                          "-fno-gpu-rdc", "-munsafe-fp-atomics", "-I", csrc, "-I", os.path.join(ROOT, "include"),
+                          "--cuda-device-only", "-S", os.path.join(csrc, src), "-o", str(out)],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout[-2000:]
+    assert "failed to meet occupancy target" not in res.stdout, res.stdout[-2000:]
+    asm = open(out).read()
+    pat = re.compile(r"\.group_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.name:\s+(\S+)\n(?:.*\n)*?"
+                     r"\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)")
+    seen = {}
+    for m in pat.finditer(asm):
+        lds, name, scratch, vgpr = int(m.group(1)), m.group(2), int(m.group(3)), int(m.group(4))
+        for key, (max_vgpr, max_lds) in _BUDGETS[src].items():
+            if key in name:
+                seen[key] = seen.get(key, 0) + 1
+                assert scratch == 0, f"{name}: {scratch} B of scratch"
+                assert vgpr <= max_vgpr, f"{name}: {vgpr} VGPRs > {max_vgpr}"
+                assert lds <= max_lds, f"{name}: {lds} B of static LDS > {max_lds}"
+    assert set(seen) == set(_BUDGETS[src]), (seen, sorted(_BUDGETS[src]))
