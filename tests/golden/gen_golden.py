@@ -32,6 +32,8 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
   * factor_graph.py      update_lowmem chunking and call arguments (mocked kernels) -> update_lowmem.npz
   * InstantNeuS.py       normalisation, masking, sdf gradient by autograd.grad, get_alpha,
                          compositing, compute_sdf_error                       -> neus_forward.npz
+  * InstantNeuS.py       the SAME forward differentiated by its own autograd graph (autograd.grad(create_graph=True) +
+                         backward) on a twice-differentiable stand-in: every trained parameter's gradient -> neus_backward.npz
 The stand-ins themselves (tcnn / lietorch / CUDA kernels) stay "parity unpinned" (DESIGN.md 4).
 The reference is only imported, never copied; outputs are small .npz files next to this script.
 """
@@ -262,6 +264,100 @@ def gen_neus():
          sdf_error=sdf_err, sdf_front_error=sdf_front, **{k: v for k, v in out.items()},
          state_keys=np.array(list(sd.keys())), state_shapes=np.array([str(tuple(v.shape)) for v in sd.values()]),
          train_param_names=np.array(train_names), volume_param_names=np.array(volume_names))
+
+
+def differentiable_tcnn():
+    """Swap the tinycudann stand-in for a TWICE-differentiable one (pure torch ops from oracle/neus_autograd.py: the
+    hash-grid interpolation as a function of its input AND its table, the MLP with straight-through fp16 roundings), so
+    that the reference module's own `autograd.grad(sdf, pts, create_graph=True)` + `backward()` produce gradients of
+    every trained parameter.  The gradient arriving at the encoding output is rounded to fp16 as tcnn does
+    (kernel_grid_backward_input reads dL/dy as __half), with an identity second derivative."""
+    from oracle import neus_autograd as NA
+    tc = sys.modules["tinycudann"]
+    meta = NO.grid_meta()
+
+    class _HalfGrad(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, y):
+            return y.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            return g + (g.to(torch.float16).to(g.dtype) - g).detach()
+
+    class Encoding(torch.nn.Module):
+        def __init__(self, n_input_dims, encoding_config, **kw):
+            super().__init__()
+            self.n_input_dims, self.n_output_dims = n_input_dims, 32
+            self.params = torch.nn.Parameter(torch.zeros(int(meta["total"]) * 2))
+
+        def forward(self, x):
+            enc, _ = NA.grid_encode_diff(x, self.params, meta, x_differentiable=True)
+            return _HalfGrad.apply(enc)
+
+    class Network(torch.nn.Module):
+        def __init__(self, n_input_dims, n_output_dims, network_config, **kw):
+            super().__init__()
+            self.n_input_dims, self.n_output_dims = n_input_dims, n_output_dims
+            self.params = torch.nn.Parameter(torch.zeros(NO.mlp_num_params(n_input_dims, n_output_dims)))
+
+        def forward(self, x):
+            return NA.mlp_diff(x, self.params, self.n_input_dims, self.n_output_dims)
+    keep = (tc.Encoding, tc.Network)
+    tc.Encoding, tc.Network = Encoding, Network
+    return keep
+
+
+def gen_neus_backward():
+    """The reference's `InstantNeuS.forward` (src/InstantNeuS.py:295-370: masking, normalisation, the sdf gradient by
+    autograd.grad(create_graph=True), get_alpha, sin embedding, compositing) DIFFERENTIATED BY ITS OWN AUTOGRAD GRAPH on
+    the twice-differentiable tcnn stand-in, under the mapper's loss (src/mapping.py:96-132; pinned separately by
+    mapper_loss.npz) -> the gradient of every trained parameter.  Pins oracle/neus_autograd.py's explicit formulation
+    (analytic sdf gradient, second-order terms) -- the referee of the HIP training backward."""
+    from oracle import neus_autograd as NA
+    keep = differentiable_tcnn()
+    tc = sys.modules["tinycudann"]
+    try:
+        neus = importlib.reload(importlib.import_module("refsrc.InstantNeuS"))
+        seed = 127
+        P = NO.make_params(seed, grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+        rt = torch.tensor([[-2.2, 2.3], [-2.4, 2.1], [-2.0, 2.2]])
+        cfg = {"sdf_network": {"d_in": 3, "d_out": 32},
+               "color_network": {"d_in": 3, "d_feat": 31, "d_hidden": 64, "n_layers": 2},
+               "variance_network": {"init_val": 0.2, "scale_factor": 10.0}, "sdf_smooth_std": 0.005,
+               "sdf_sparse_factor": 5, "sdf_truncation": 0.16, "sdf_random_weight": 0.04}
+        torch.manual_seed(5)
+        net = neus.InstantNeuS(cfg, P["bound"].tolist(), device="cpu")
+        with torch.no_grad():
+            net.sdf_network.encoding.encoding.params.copy_(P["grid"])
+            net.sdf_network.sdf_layer.weight.copy_(P["sdf_w"])
+            net.sdf_network.sdf_layer.bias.copy_(P["sdf_b"])
+            net.color_network._B.copy_(P["color_B"])
+            net.color_network.network.params.copy_(P["mlp"])
+        net.update_bound(rt)
+        g = torch.Generator().manual_seed(131)
+        n = 12
+        o = torch.rand(n, 3, generator=g) * 4 - 2
+        d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+        gt = torch.rand(n, generator=g) * 3.5 + 0.5
+        gt[::5] = 0
+        col = torch.rand(n, 3, generator=g)
+        z, dist = NO.render_sample(o, d, gt, P["bound"], 24, 48, torch.rand(24, generator=g))
+        with torch.enable_grad():
+            out = net(o, d, z, dist)
+            loss = NA.mapping_loss(out, col, gt)
+            loss.backward()
+        grid_g = net.sdf_network.encoding.encoding.params.grad
+        nz = torch.nonzero(grid_g).reshape(-1)
+        save("neus_backward.npz", seed=seed, rt_bound=rt, rays_o=o, rays_d=d, gt_depth=gt, rays_color=col, z_in=z,
+             dists_in=dist, loss=loss.detach(), color=out["color"].detach(), depth=out["depth"].detach(),
+             sdf=out["sdf"].detach(), gradient_error=out["gradient_error"].detach(),
+             g_sdf_w=net.sdf_network.sdf_layer.weight.grad, g_sdf_b=net.sdf_network.sdf_layer.bias.grad,
+             g_color_B=net.color_network._B.grad, g_mlp=net.color_network.network.params.grad,
+             g_variance=net.variance_network.variance.grad.reshape(1), g_grid_index=nz, g_grid_value=grid_g[nz])
+    finally:
+        tc.Encoding, tc.Network = keep
+        importlib.reload(importlib.import_module("refsrc.InstantNeuS"))
 
 
 def gen_rays():
@@ -1147,3 +1243,4 @@ if __name__ == "__main__":
         gen_render_mono()
         gen_rays()
     gen_neus()
+    gen_neus_backward()

@@ -351,3 +351,34 @@ def test_mapping_loss_and_its_output_gradients_match_reference_mapper():
     assert ret["depth_variance"].grad is None or not bool(ret["depth_variance"].grad.any())
     assert not bool(g["d_depth_variance"].any())                # detached in the reference too
 
+
+def test_training_gradients_match_the_reference_modules_own_autograd():
+    """oracle/neus_autograd.py (explicit analytic sdf gradient + its second-order terms: the referee of the HIP training
+    backward) against the REFERENCE's `InstantNeuS.forward` differentiated by its own autograd graph
+    (`autograd.grad(sdf, pts, create_graph=True)` at src/InstantNeuS.py:141-148, then loss.backward()) on a
+    twice-differentiable tcnn stand-in (fixture neus_backward.npz, tests/golden/gen_golden.py::gen_neus_backward): the loss
+    and the gradient of every trained parameter -- hash table (78 k touched entries), sdf_layer, colour embedding, colour
+    MLP, variance."""
+    from oracle import neus_autograd as NA
+    g = _load("neus_backward.npz")
+    P = NO.make_params(int(g["seed"]), grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    P["rt_bound"] = g["rt_bound"]
+    Pd = {k: (v.clone().requires_grad_(True) if k in ("grid", "sdf_w", "sdf_b", "color_B", "mlp") else v)
+          for k, v in P.items()}
+    Pd["variance"] = torch.tensor(0.2, requires_grad=True)
+    out = NA.neus_forward_diff(g["rays_o"], g["rays_d"], g["z_in"], g["dists_in"], Pd)
+    loss = NA.mapping_loss(out, g["rays_color"], g["gt_depth"])
+    loss.backward()
+    torch.testing.assert_close(out["sdf"].detach(), g["sdf"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out["color"].detach(), g["color"], rtol=0, atol=2e-4)     # fp16 rgb: an ulp flips on a few
+    torch.testing.assert_close(loss.detach(), g["loss"], rtol=1e-4, atol=1e-6)
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp(min=1e-20))
+    grid_ref = torch.zeros_like(P["grid"])
+    grid_ref[g["g_grid_index"]] = g["g_grid_value"]
+    rep = {"grid": rel(Pd["grid"].grad, grid_ref), "sdf_w": rel(Pd["sdf_w"].grad, g["g_sdf_w"]),
+           "sdf_b": rel(Pd["sdf_b"].grad, g["g_sdf_b"]), "color_B": rel(Pd["color_B"].grad, g["g_color_B"]),
+           "mlp": rel(Pd["mlp"].grad, g["g_mlp"]), "variance": rel(Pd["variance"].grad.reshape(1), g["g_variance"])}
+    assert int((Pd["grid"].grad != 0).sum()) > 0 and int((grid_ref != 0).sum()) == int(g["g_grid_index"].numel())
+    # measured: grid 6.7e-5, sdf_w 3.4e-5, variance 1.0e-5, sdf_b / color_B / mlp < 1e-6 (relative L2)
+    assert all(v < 3e-4 for v in rep.values()), rep
+
