@@ -301,6 +301,36 @@ def test_training_gradients_match_autograd_oracle(N, O, dev, grid_init, grad_dty
         assert r < 5e-3, report
 
 
+@pytest.mark.parametrize("grad_dtype", [torch.float32, torch.float16])
+def test_training_gradients_match_the_reference_module_autograd_fixture(N, O, dev, grad_dtype):
+    """The HIP training backward against tests/golden/neus_backward.npz = the REFERENCE's `InstantNeuS.forward`
+    differentiated by its own autograd graph (autograd.grad(create_graph=True) + backward of the mapper's loss) on a
+    twice-differentiable tcnn stand-in: the gradient of every trained parameter, no oracle in between."""
+    import numpy as np
+    from oracle import neus_autograd as NA          # (only its loss function, itself pinned by mapper_loss.npz)
+    g = {k: torch.from_numpy(np.asarray(v)) for k, v in
+         np.load(os.path.join(os.path.dirname(__file__), "golden", "neus_backward.npz")).items()}
+    P = O.make_params(int(g["seed"]), grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))   # (parameters only)
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    model.update_bound(g["rt_bound"])
+    model.grid_grad_dtype = grad_dtype
+    out = model(g["rays_o"].to(dev), g["rays_d"].to(dev), g["z_in"].to(dev), g["dists_in"].to(dev))
+    loss = NA.mapping_loss({k: v for k, v in out.items()}, g["rays_color"].to(dev), g["gt_depth"].to(dev))
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), g["loss"], rtol=2e-3, atol=1e-4)
+    grid_ref = torch.zeros_like(P["grid"])
+    grid_ref[g["g_grid_index"]] = g["g_grid_value"]
+    pairs = {"grid": (model.sdf_network.encoding.encoding.params.grad, grid_ref),
+             "sdf_w": (model.sdf_network.sdf_layer.weight.grad, g["g_sdf_w"]),
+             "sdf_b": (model.sdf_network.sdf_layer.bias.grad, g["g_sdf_b"]),
+             "color_B": (model.color_network._B.grad, g["g_color_B"]),
+             "mlp": (model.color_network.network.params.grad, g["g_mlp"]),
+             "variance": (model.variance_network.variance.grad.reshape(1), g["g_variance"])}
+    report = {k: _rel(a.cpu().float().reshape(b.shape), b) for k, (a, b) in pairs.items()}
+    assert all(r < 5e-3 for r in report.values()), report
+
+
 def test_training_step_reduces_loss(N, O, dev):
     """Plain gradient descent along the fused backward's gradient decreases the mapper loss
     monotonically; then the reference's optimiser setup (AdamW + clip 35, mapping.py:55-58,135)
