@@ -31,7 +31,7 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
   * mapping.py           Mapper.optimize_map: the loss and its gradients w.r.t. the renderer outputs -> mapper_loss.npz
   * factor_graph.py      update_lowmem chunking and call arguments (mocked kernels) -> update_lowmem.npz
   * InstantNeuS.py       normalisation, masking, sdf gradient by autograd.grad, get_alpha,
-                         compositing, compute_sdf_error                       -> neus_forward.npz
+                         compositing, compute_sdf_error                       -> neus_forward.npz, neus_forward_cases.npz
   * InstantNeuS.py       the SAME forward differentiated by its own autograd graph (autograd.grad(create_graph=True) +
                          backward) on a twice-differentiable stand-in: every trained parameter's gradient -> neus_backward.npz
 The stand-ins themselves (tcnn / lietorch / CUDA kernels) stay "parity unpinned" (DESIGN.md 4).
@@ -264,6 +264,20 @@ def gen_neus():
          sdf_error=sdf_err, sdf_front_error=sdf_front, **{k: v for k, v in out.items()},
          state_keys=np.array(list(sd.keys())), state_shapes=np.array([str(tuple(v.shape)) for v in sd.values()]),
          train_param_names=np.array(train_names), volume_param_names=np.array(volume_names))
+    # the degenerate batches of InstantNeuS.py:309-312: (a) NO point inside the realtime bound -> the first 100 points are
+    # forced valid; (b) a realtime bound that cuts through the rays (most samples masked out: sdf 100, alpha 0); (c) points
+    # outside the STATIC bound but inside the realtime one (normalisation clamps them, `inside` zeroes their gradient)
+    cases = {"forced": torch.tensor([[50.0, 51.0], [50.0, 51.0], [50.0, 51.0]]),
+             "cut": torch.tensor([[-0.4, 0.5], [-2.4, 2.1], [-0.3, 0.6]]),
+             "wide": torch.tensor([[-4.0, 4.0], [-4.0, 4.0], [-4.0, 4.0]])}
+    extra = {}
+    for tag, rtb in cases.items():
+        net.update_bound(rtb)
+        oc = net(o, d, z, dist)
+        extra["rt_" + tag] = rtb
+        for k, v in oc.items():
+            extra[f"{k}_{tag}"] = v
+    save("neus_forward_cases.npz", seed=109, rays_o=o, rays_d=d, gt_depth=gt, z_in=z, dists_in=dist, **extra)
 
 
 def differentiable_tcnn():

@@ -210,6 +210,33 @@ def test_neus_forward_matches_the_reference_module_fixture(N, O, dev):
     torch.testing.assert_close(f.cpu(), g["sdf_front_error"], rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("tag", ["forced", "cut", "wide"])
+def test_neus_forward_degenerate_bounds_match_the_reference_module_fixture(N, O, dev, tag):
+    """The fused forward on the reference module's own outputs (tests/golden/neus_forward_cases.npz) for a realtime bound
+    that contains no point (first 100 forced, InstantNeuS.py:311-312), one that leaves 34 samples, and one LARGER than
+    the static bound (points outside the static bound: clamped normalisation, sdf gradient zeroed)."""
+    import numpy as np
+    g = {k: torch.from_numpy(np.asarray(v)) for k, v in
+         np.load(os.path.join(os.path.dirname(__file__), "golden", "neus_forward_cases.npz")).items()}
+    P = O.make_params(int(g["seed"]), grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))   # (parameters only)
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    model.update_bound(g["rt_" + tag])
+    with torch.no_grad():
+        out = model(g["rays_o"].to(dev), g["rays_d"].to(dev), g["z_in"].to(dev), g["dists_in"].to(dev))
+    c = {k: v.cpu() for k, v in out.items()}
+    ref = lambda k: g[f"{k}_{tag}"]
+    assert torch.equal(c["z_vals"], ref("z_vals"))
+    assert torch.equal(c["sdf"] == 100.0, ref("sdf") == 100.0), "in-bound masks must agree exactly"
+    torch.testing.assert_close(c["sdf"], ref("sdf"), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(c["weight_sum"], ref("weight_sum"), rtol=0, atol=5e-4)
+    torch.testing.assert_close(c["depth"], ref("depth"), rtol=0, atol=2e-3)
+    torch.testing.assert_close(c["depth_variance"], ref("depth_variance"), rtol=1e-2, atol=2e-3)
+    torch.testing.assert_close(c["color"], ref("color"), rtol=0, atol=4e-3)
+    torch.testing.assert_close(c["normal"], ref("normal"), rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(c["gradient_error"], ref("gradient_error"), rtol=2e-3, atol=1e-5)
+
+
 def test_neus_forward_no_point_in_bound_forces_first_100(N, O, dev):
     """Q14 (InstantNeuS.py:311-312): realtime bound far away => first 100 points forced valid."""
     P = O.make_params(11, grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))

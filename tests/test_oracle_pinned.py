@@ -236,6 +236,25 @@ def test_neus_forward_matches_reference_instantneus():
     torch.testing.assert_close(f, g["sdf_front_error"], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("tag", ["forced", "cut", "wide"])
+def test_neus_forward_degenerate_bounds_match_reference_instantneus(tag):
+    """The reference module (fixture neus_forward_cases.npz) on the batches of InstantNeuS.py:309-312: `forced` -- no point
+    inside the realtime bound, the first 100 points are forced valid; `cut` -- a realtime bound that leaves 34 of 2880
+    samples; `wide` -- a realtime bound LARGER than the static one (points outside the static bound are normalised,
+    clamped, and their sdf gradient zeroed by `inside`)."""
+    g = _load("neus_forward_cases.npz")
+    P = NO.make_params(int(g["seed"]), grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    P["rt_bound"] = g["rt_" + tag]
+    out = NO.neus_forward(g["rays_o"], g["rays_d"], g["z_in"], g["dists_in"], P)
+    assert torch.equal(out["sdf"] == 100.0, g["sdf_" + tag] == 100.0)
+    if tag == "forced":
+        assert int((out["sdf"] != 100.0).sum()) == 100
+    torch.testing.assert_close(out["sdf"], g["sdf_" + tag], rtol=1e-5, atol=1e-5)
+    for k, tol in (("color", 1e-3), ("depth", 2e-4), ("depth_variance", 2e-4), ("normal", 1e-3), ("weight_sum", 1e-4)):
+        torch.testing.assert_close(out[k], g[f"{k}_{tag}"], rtol=1e-3, atol=tol, msg=lambda m, k=k: f"{k}: {m}")
+    torch.testing.assert_close(out["gradient_error"], g["gradient_error_" + tag], rtol=1e-3, atol=1e-6)
+
+
 def test_hash_grid_known_answers():
     """SURVEY App. B KATs for the tcnn index function (T = 2^19)."""
     m = NO.grid_meta()
