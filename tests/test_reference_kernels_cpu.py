@@ -1,0 +1,161 @@
+"""oracle/droid_oracle.py against the REFERENCE's OWN tracking kernels.
+
+`oracle/build_ref.py` compiles /root/reference/src/lib/{droid_kernels,correlation_kernels,altcorr_kernel}.cu + droid.cpp --
+the CUDA extension `droid_backends` of the reference -- for the CPU (oracle/ref_build/cuda_on_cpu.h: the blocks of a
+launch run one after the other, the threads of a block are cooperative fibers, __syncthreads() is a real barrier) into
+oracle/_ref/.  What runs here is the reference's code, statement for statement, except: the launch syntax, six
+warp-synchronous statements and five one-warp hand-over points (rewritten at build time, see build_ref.py) and the
+linear solve (Eigen is an empty submodule of the reference: a dense double Cholesky stands in).
+
+Every GPU parity test of the tracking path judges the HIP kernels against the oracle; these tests judge the oracle against
+the code it restates.  Integer / index / fp16-order work is compared bit for bit; the reductions of the geometry and BA
+kernels (fp32 block reductions in the kernel, fp64 sums in the oracle) to fp32 rounding."""
+import pytest
+import torch
+
+from go_slam_amd import synth
+from oracle import droid_oracle as DO
+
+
+@pytest.fixture(scope="module")
+def R():
+    from oracle import build_ref
+    build_ref.build()
+    mod = build_ref.load()
+    if mod is None:
+        pytest.skip("oracle/_ref is not built and /root/reference is absent")
+    return mod
+
+
+def _coords(n, h1, w1, h2, w2, seed, spread=3.0):
+    g = torch.Generator().manual_seed(seed)
+    ys, xs = torch.meshgrid(torch.arange(h1, dtype=torch.float32), torch.arange(w1, dtype=torch.float32), indexing="ij")
+    c = torch.stack([xs * (w2 / w1), ys * (h2 / h1)], 0)[None].repeat(n, 1, 1, 1)
+    c = c + spread * torch.randn(n, 2, h1, w1, generator=g)
+    c[:, :, 0, 0] = torch.tensor([-20.0, 3.0])[None]          # fully outside
+    c[:, :, 0, 1] = torch.tensor([2.0, 2.0])[None]            # exact integer (weights 0 / 1)
+    c[:, :, 1, 0] = torch.tensor([w2 - 1.5, h2 - 0.5])[None]  # straddles the far border
+    c[:, :, 1, 1] = torch.tensor([-0.25, -0.75])[None]        # straddles the near border
+    return c.contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.float64])
+def test_corr_index_forward_and_backward_bit_exact(R, dtype):
+    """correlation_kernels.cu:19-118 (the lookup of every corr level, and its backward): per-dtype accumulation in the
+    kernel's (i, j) order -- the oracle claims that order, so the results must be identical."""
+    n, h1, w1, h2, w2 = 3, 8, 12, 8, 12
+    g = torch.Generator().manual_seed(2)
+    vol = torch.randn(n, h1, w1, h2, w2, generator=g).to(dtype)
+    c = _coords(n, h1, w1, h2, w2, seed=3)
+    ref, = R.corr_index_forward(vol, c, 3)
+    out, = DO.corr_index_forward(vol, c, 3)
+    assert ref.dtype == out.dtype == dtype and torch.equal(ref, out)
+    grad = torch.randn(n, 7, 7, h1, w1, generator=g).to(dtype)
+    ref, = R.corr_index_backward(vol, c, grad, 3)
+    out, = DO.corr_index_backward(vol, c, grad, 3)
+    assert torch.equal(ref, out)
+
+
+def test_altcorr_forward_and_backward_fp32(R):
+    """altcorr_kernel.cu:27-149,151-283 in fp32 -- the only precision the reference calls it with
+    (src/modules/corr.py:123: `CorrLayer.apply(fmap1_i.float(), fmap2_i.float(), ...)`).  The kernel adds 32-channel
+    partial dot products into the output one chunk at a time, the oracle sums all channels at once: fp32 rounding."""
+    g = torch.Generator().manual_seed(5)
+    B, S, C, H, W = 2, 3, 64, 8, 16
+    f1, f2 = torch.randn(B, H, W, C, generator=g), torch.randn(B, H // 2, W // 2, C, generator=g)
+    co = _coords(B * S, H, W, H // 2, W // 2, seed=6).view(B, S, 2, H, W).permute(0, 1, 3, 4, 2).contiguous()
+    ref, = R.altcorr_forward(f1, f2, co, 3)
+    out, = DO.altcorr_forward(f1, f2, co, 3)
+    torch.testing.assert_close(ref, out, rtol=1e-5, atol=1e-5)
+    grad = torch.randn(B, S, 49, H, W, generator=g)
+    rb = R.altcorr_backward(f1, f2, co, grad, 3)
+    ob = DO.altcorr_backward(f1, f2, co, grad, 3)
+    torch.testing.assert_close(rb[0], ob[0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rb[1], ob[1], rtol=1e-5, atol=1e-5)
+    assert not bool(rb[2].any())                               # the kernel never writes coords_grad
+
+
+def test_geometry_kernels(R):
+    """droid_kernels.cu: projmap (:430-515), iproj (:790-840), depth_filter (:662-787) bit for bit; frame_distance
+    (:518-657) to the rounding of its fp32 block reduction."""
+    vid = synth.make_video(8, "tiny", seed=7)
+    ii, jj = synth.make_graph(8, 24, seed=7)
+    ii = torch.cat([ii, torch.tensor([2, 5])])
+    jj = torch.cat([jj, torch.tensor([2, 5])])                  # two i == j edges
+    P, D, K = vid["poses"], vid["disps"], vid["intrinsics"][0].contiguous()
+    rc, rv = R.projmap(P, D, K, ii, jj)
+    oc, ov = DO.projmap(P, D, K, ii, jj)
+    assert torch.equal(rc, oc) and torch.equal(rv, ov)
+    assert torch.equal(R.iproj(P, D, K), DO.iproj(P, D, K))
+    ix, th = torch.tensor([1, 3, 4, 6]), torch.tensor([0.05, 0.01, 0.2, 0.005])
+    assert torch.equal(R.depth_filter(P, D, K, ix, th), DO.depth_filter(P, D, K, ix, th))
+    for beta in (0.3, 0.7):
+        torch.testing.assert_close(R.frame_distance(P, D, K, ii, jj, beta), DO.frame_distance(P, D, K, ii, jj, beta),
+                                   rtol=2e-6, atol=1e-6)
+
+
+def _ba_problem(num_kf, num_edges, seed, rgbd=True, noise=0.5):
+    p = synth.make_ba_problem(num_kf, num_edges, "tiny", seed, rgbd)
+    c, _ = DO.reproject(p["poses"], p["disps"], p["intrinsics"], p["ii"], p["jj"])
+    return synth.make_ba_problem(num_kf, num_edges, "tiny", seed, rgbd, noise_px=noise, coords=c[0])
+
+
+def _run_pair(R, prob, iters, lm, ep, motion_only):
+    K = prob["intrinsics"][0].contiguous()
+    out = []
+    for fn in (R.ba, DO.ba):
+        p, d = prob["poses"].clone(), prob["disps"].clone()
+        res = fn(p, d, K, prob["disps_sens"], prob["target"], prob["weight"], prob["eta"], prob["ii"], prob["jj"],
+                 prob["t0"], prob["t1"], iters, lm, ep, motion_only)
+        out.append((res, p, d))
+    return out
+
+
+@pytest.mark.parametrize("rgbd", [True, False])
+def test_ba_two_iterations(R, rgbd):
+    """ba_cuda (droid_kernels.cu:1314-1434): projective_transform_kernel's Jacobians and per-edge Hessian blocks, the
+    accumulation into the pose system, schur_block's E Q E^T / E Q w products, the damped solve, EvT6x1, pose and
+    disparity retraction -- two Gauss-Newton iterations, with and without the RGB-D prior."""
+    prob = _ba_problem(7, 18, seed=11, rgbd=rgbd)
+    (rr, pr, dr), (ro, po, do) = _run_pair(R, prob, 2, 1e-4, 0.1, False)
+    assert float((pr - prob["poses"]).abs().max()) > 1e-3 and float((dr - prob["disps"]).abs().max()) > 1e-3
+    torch.testing.assert_close(rr[0], ro[0], rtol=1e-4, atol=1e-6)          # dx of the last iteration
+    torch.testing.assert_close(rr[1], ro[1], rtol=1e-4, atol=2e-6)          # dz
+    torch.testing.assert_close(pr, po, rtol=0, atol=2e-6)
+    torch.testing.assert_close(dr, do, rtol=0, atol=2e-6)
+
+
+def test_ba_motion_only_window_and_stereo_edges(R):
+    """motion_only (no depth unknowns), and a window that starts at t0 = 3 with i == j stereo edges: frames before t0
+    stay fixed, the stereo baseline replaces the relative pose (:219-229), and the depth back-substitution skips terms
+    with pose index <= 0 (EvT6x1_kernel :1104: the quirk the HIP path mirrors)."""
+    prob = _ba_problem(7, 18, seed=17)
+    (rr, pr, dr), (ro, po, do) = _run_pair(R, prob, 2, 1e-4, 0.1, True)
+    torch.testing.assert_close(rr[0], ro[0], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(pr, po, rtol=0, atol=2e-6)
+    assert torch.equal(dr, prob["disps"]) and torch.equal(do, prob["disps"])
+    prob = _ba_problem(9, 24, seed=19)
+    prob["ii"] = torch.cat([prob["ii"], torch.tensor([3, 6])])
+    prob["jj"] = torch.cat([prob["jj"], torch.tensor([3, 6])])
+    g = torch.Generator().manual_seed(3)
+    ht, wd, _ = synth.SHAPES["tiny"]
+    prob["target"] = torch.cat([prob["target"], prob["target"][:2] + 0.1], 0).contiguous()
+    prob["weight"] = torch.cat([prob["weight"], torch.rand(2, 2, ht, wd, generator=g)], 0).contiguous()
+    prob["t0"], prob["t1"] = 3, 9
+    kx = torch.unique(torch.cat([torch.arange(3, 9), prob["ii"]]))
+    prob["eta"] = 1e-2 * torch.rand(len(kx), ht, wd, generator=g) + 1e-4
+    (rr, pr, dr), (ro, po, do) = _run_pair(R, prob, 2, 1e-4, 0.1, False)
+    torch.testing.assert_close(rr[0], ro[0], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(pr, po, rtol=0, atol=2e-6)
+    torch.testing.assert_close(dr, do, rtol=0, atol=2e-6)
+    assert torch.equal(pr[:3], prob["poses"][:3])
+
+
+def test_ba_cholesky_failure_gives_zero_pose_update(R):
+    """lm = -2, ep = -1 make the damped system indefinite: the reference returns dx = 0 (:1207-1210) and goes on with the
+    depth update; the oracle (and the HIP path) must do the same."""
+    prob = _ba_problem(6, 14, seed=23)
+    (rr, pr, dr), (ro, po, do) = _run_pair(R, prob, 1, -2.0, -1.0, False)
+    assert not bool(rr[0].any()) and not bool(ro[0].any())
+    assert torch.equal(pr, prob["poses"]) and torch.equal(po, prob["poses"])
+    torch.testing.assert_close(dr, do, rtol=0, atol=2e-6)
