@@ -94,10 +94,10 @@ def test_geometry_kernels(R):
                                    rtol=2e-6, atol=1e-6)
 
 
-def _ba_problem(num_kf, num_edges, seed, rgbd=True, noise=0.5):
-    p = synth.make_ba_problem(num_kf, num_edges, "tiny", seed, rgbd)
+def _ba_problem(num_kf, num_edges, seed, rgbd=True, noise=0.5, shape="tiny"):
+    p = synth.make_ba_problem(num_kf, num_edges, shape, seed, rgbd)
     c, _ = DO.reproject(p["poses"], p["disps"], p["intrinsics"], p["ii"], p["jj"])
-    return synth.make_ba_problem(num_kf, num_edges, "tiny", seed, rgbd, noise_px=noise, coords=c[0])
+    return synth.make_ba_problem(num_kf, num_edges, shape, seed, rgbd, noise_px=noise, coords=c[0])
 
 
 def _run_pair(R, prob, iters, lm, ep, motion_only):
@@ -159,3 +159,17 @@ def test_ba_cholesky_failure_gives_zero_pose_update(R):
     assert not bool(rr[0].any()) and not bool(ro[0].any())
     assert torch.equal(pr, prob["poses"]) and torch.equal(po, prob["poses"])
     torch.testing.assert_close(dr, do, rtol=0, atol=2e-6)
+
+
+def test_ba_at_the_bench_window(R):
+    """The frontend window bench.py times (BASELINE configs[1]: 60x80 maps, P = 25 keyframes, E = 75 edges, RGB-D): two
+    Gauss-Newton iterations of the reference's ba_cuda (26 s on the CPU) vs the oracle, at SURVEY 8c's tolerance for `ba`
+    (dx rtol 1e-4 / atol 1e-6).  tools/reference_kernels_at_bench_shape.py adds the monocular window (P = 50, E = 100)
+    and the lookup / geometry kernels at S480 (profiles/r04_reference_kernels_parity.json)."""
+    prob = _ba_problem(25, 75, seed=31, shape="S480")
+    (rr, pr, dr), (ro, po, do) = _run_pair(R, prob, 2, 1e-4, 0.1, False)
+    assert float((pr - prob["poses"]).abs().max()) > 1e-2
+    torch.testing.assert_close(ro[0], rr[0], rtol=1e-4, atol=2e-6)
+    torch.testing.assert_close(po, pr, rtol=0, atol=3e-6)
+    torch.testing.assert_close(do, dr, rtol=0, atol=4e-6)
+
