@@ -34,7 +34,9 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
                          compositing, compute_sdf_error                       -> neus_forward.npz, neus_forward_cases.npz
   * InstantNeuS.py       the SAME forward differentiated by its own autograd graph (autograd.grad(create_graph=True) +
                          backward) on a twice-differentiable stand-in: every trained parameter's gradient -> neus_backward.npz
-The stand-ins themselves (tcnn / lietorch / CUDA kernels) stay "parity unpinned" (DESIGN.md 4).
+  * lib/*.cu             the reference's CUDA kernels themselves, compiled for the CPU (oracle/build_ref.py): ba,
+                         frame_distance, projmap, iproj, depth_filter on seeded inputs             -> reference_kernels.npz
+The tcnn / lietorch stand-ins stay "parity unpinned" (DESIGN.md 5); the CUDA kernels no longer do.
 The reference is only imported, never copied; outputs are small .npz files next to this script.
 """
 import importlib
@@ -1134,6 +1136,36 @@ def gen_mapper_loss():
          weights=torch.tensor([mapper.w_color_loss, mapper.w_sdf_loss, mapper.w_eikonal_loss]))
 
 
+def gen_reference_kernels():
+    """Outputs of the reference's OWN CUDA kernels (oracle/_ref: src/lib/*.cu compiled for the CPU by oracle/build_ref.py) on
+    the seeded inputs of tests/test_track_gpu.py -- so that the GPU box can compare the HIP kernels with them without
+    loading that module: two `ba` iterations on a 12-keyframe / 40-edge ScanNet-shaped window, frame_distance / projmap /
+    iproj / depth_filter on the 10-keyframe tiny video, the fp16 and fp32 lookups."""
+    from oracle import build_ref
+    build_ref.build()
+    R = build_ref.load()
+    assert R is not None
+    out = {}
+    p = synth.make_ba_problem(12, 40, "Scan", 13, True)
+    c, _ = DO.reproject(p["poses"], p["disps"], p["intrinsics"], p["ii"], p["jj"])
+    p = synth.make_ba_problem(12, 40, "Scan", 13, True, noise_px=0.5, coords=c[0])
+    K = p["intrinsics"][0].contiguous()
+    po, do = p["poses"].clone(), p["disps"].clone()
+    dx, dz = R.ba(po, do, K, p["disps_sens"], p["target"], p["weight"], p["eta"], p["ii"], p["jj"], p["t0"], p["t1"], 2,
+                  1e-4, 0.1, False)
+    out.update(ba_poses=po, ba_disps=do, ba_dx=dx, ba_dz=dz)
+    vid = synth.make_video(10, "tiny", seed=9)
+    ii, jj = synth.make_graph(10, 30, seed=9)
+    P, D, K = vid["poses"], vid["disps"], vid["intrinsics"][0].contiguous()
+    pc, pv = R.projmap(P, D, K, ii, jj)
+    out.update(projmap_coords=pc, projmap_valid=pv, iproj=R.iproj(P, D, K),
+               frame_distance_03=R.frame_distance(P, D, K, ii, jj, 0.3),
+               frame_distance_07=R.frame_distance(P, D, K, ii, jj, 0.7),
+               depth_filter=R.depth_filter(P, D, K, torch.tensor([0, 1, 4, 8, 9]),
+                                           torch.tensor([0.05, 0.1, 0.2, 0.05, 0.3])))
+    save("reference_kernels.npz", **out)
+
+
 class FakeAltCorr:
     """stands in for AltCorrBlock under update_lowmem (both sides): a deterministic function of its arguments"""
     log = None
@@ -1258,3 +1290,4 @@ if __name__ == "__main__":
         gen_rays()
     gen_neus()
     gen_neus_backward()
+    gen_reference_kernels()

@@ -745,3 +745,32 @@ def test_ba_matches_the_reference_kernels(db, RK, O, dev, rgbd):
     torch.testing.assert_close(pg.cpu(), pr, rtol=0, atol=1.3e-5)
     torch.testing.assert_close(dg.cpu(), dr, rtol=0, atol=1.3e-5)
 
+
+def test_hip_kernels_match_the_reference_kernel_fixture(db, O, dev):
+    """The same comparison without loading oracle/_ref on this box: tests/golden/reference_kernels.npz holds what the
+    reference's kernels produced (on the CPU, in the build container: gen_golden.py::gen_reference_kernels) for the seeded
+    inputs below -- two `ba` iterations on the 12-keyframe / 40-edge ScanNet-shaped window of
+    test_ba_two_iterations_frontend_like, and the geometry kernels on the video of
+    test_projmap_frame_distance_iproj_depth_filter."""
+    g = _fixture("reference_kernels.npz")
+    prob = _ba_problem(O, 12, 40, "Scan", seed=13)
+    K = prob["intrinsics"][0].contiguous()
+    pg, dg = prob["poses"].clone().to(dev), prob["disps"].clone().to(dev)
+    out = db.ba(pg, dg, K.to(dev), prob["disps_sens"].to(dev), prob["target"].to(dev), prob["weight"].to(dev),
+                prob["eta"].to(dev), prob["ii"].to(dev), prob["jj"].to(dev), prob["t0"], prob["t1"], 2, 1e-4, 0.1, False)
+    torch.testing.assert_close(out[0].cpu(), g["ba_dx"], rtol=1e-3, atol=3.5e-6)
+    torch.testing.assert_close(pg.cpu(), g["ba_poses"], rtol=0, atol=1.2e-5)
+    torch.testing.assert_close(dg.cpu(), g["ba_disps"], rtol=0, atol=1.2e-5)
+    vid = synth.make_video(10, "tiny", seed=9)
+    ii, jj = synth.make_graph(10, 30, seed=9)
+    Pd, Dd, Kd = vid["poses"].to(dev), vid["disps"].to(dev), vid["intrinsics"][0].contiguous().to(dev)
+    c, v = db.projmap(Pd, Dd, Kd, ii.to(dev), jj.to(dev))
+    assert torch.equal(v.cpu(), g["projmap_valid"])
+    torch.testing.assert_close(c.cpu(), g["projmap_coords"], rtol=1e-6, atol=1e-4)
+    for beta, key in ((0.3, "frame_distance_03"), (0.7, "frame_distance_07")):
+        torch.testing.assert_close(db.frame_distance(Pd, Dd, Kd, ii.to(dev), jj.to(dev), beta).cpu(), g[key],
+                                   rtol=1.1e-4, atol=1.2e-5)
+    torch.testing.assert_close(db.iproj(Pd, Dd, Kd).cpu(), g["iproj"], rtol=1e-6, atol=1e-5)
+    out = db.depth_filter(Pd, Dd, Kd, torch.tensor([0, 1, 4, 8, 9]).to(dev), torch.tensor([0.05, 0.1, 0.2, 0.05, 0.3]).to(dev))
+    assert torch.equal(out.cpu(), g["depth_filter"])
+
