@@ -40,6 +40,7 @@ The tcnn / lietorch stand-ins stay "parity unpinned" (DESIGN.md 5); the CUDA ker
 The reference is only imported, never copied; outputs are small .npz files next to this script.
 """
 import importlib
+import importlib.util
 import os
 import sys
 import types
@@ -1163,6 +1164,21 @@ def gen_reference_kernels():
                frame_distance_07=R.frame_distance(P, D, K, ii, jj, 0.7),
                depth_filter=R.depth_filter(P, D, K, torch.tensor([0, 1, 4, 8, 9]),
                                            torch.tensor([0.05, 0.1, 0.2, 0.05, 0.3])))
+    # the lookups and one-iteration `ba` (with and without the depth prior) on the inputs of the corresponding GPU tests
+    spec = importlib.util.spec_from_file_location("_ttg", os.path.join(os.path.dirname(HERE), "test_track_gpu.py"))
+    ttg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ttg)
+    coords = ttg._rand_coords(3, 12, 16, 12, 16)
+    for tag, dt in (("f16", torch.float16), ("f32", torch.float32)):
+        vol = ttg._rand_volume(3, 12, 16, 12, 16, dt)
+        out["lookup_" + tag] = R.corr_index_forward(vol, coords, 3)[0].float()
+    for tag, rgbd in (("rgbd", True), ("mono", False)):
+        q = ttg._ba_problem(DO, 8, 22, "tiny", seed=11, rgbd=rgbd)
+        K = q["intrinsics"][0].contiguous()
+        po, do = q["poses"].clone(), q["disps"].clone()
+        dx, dz = R.ba(po, do, K, q["disps_sens"], q["target"], q["weight"], q["eta"], q["ii"], q["jj"], q["t0"], q["t1"], 1,
+                      1e-4, 0.1, False)
+        out.update({f"ba1_{tag}_poses": po, f"ba1_{tag}_disps": do, f"ba1_{tag}_dx": dx, f"ba1_{tag}_dz": dz})
     save("reference_kernels.npz", **out)
 
 

@@ -678,78 +678,10 @@ def test_corr_block_outside_the_kernel_shapes_warns_instead_of_silently_using_th
     torch.testing.assert_close(out.float().cpu().reshape(ref.shape), ref.float(), rtol=0, atol=2e-2)
 
 
-# ---------------------------------------------------------------------------------------------------------------------
-# The HIP kernels against the REFERENCE's own kernels (oracle/_ref: src/lib/*.cu compiled for the CPU by
-# oracle/build_ref.py in the build container; the binary travels with the tree) -- no restatement in between.  Same
-# inputs as the oracle tests above; tolerances = theirs + what tests/test_reference_kernels_cpu.py allows between the
-# oracle and the reference kernels (nothing for the lookups, projmap, depth_filter).
-# ---------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def RK():
-    try:
-        from oracle import build_ref
-        mod = build_ref.load()
-    except Exception as exc:      # noqa: BLE001
-        pytest.skip(f"oracle/_ref cannot be loaded here: {exc!r}")
-    if mod is None:
-        pytest.skip("oracle/_ref is not built (it is built where /root/reference exists)")
-    return mod
-
-
-@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
-def test_corr_lookup_matches_the_reference_kernel(db, RK, dev, dtype):
-    n, h1, w1, h2, w2 = 3, 12, 16, 12, 16
-    vol = _rand_volume(n, h1, w1, h2, w2, dtype)
-    coords = _rand_coords(n, h1, w1, h2, w2)
-    ref, = RK.corr_index_forward(vol, coords, 3)                       # correlation_kernels.cu:19-70, on the CPU
-    out, = db.corr_index_forward(vol.to(dev), coords.to(dev), 3)
-    if dtype == torch.float16:
-        assert torch.equal(out.cpu(), ref)
-    else:
-        torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-6)
-
-
-def test_geometry_kernels_match_the_reference_kernels(db, RK, dev):
-    vid = synth.make_video(10, "tiny", seed=9)
-    ii, jj = synth.make_graph(10, 30, seed=9)
-    P, D, K = vid["poses"], vid["disps"], vid["intrinsics"][0].contiguous()
-    Pd, Dd, Kd = P.to(dev), D.to(dev), K.to(dev)
-    rc, rv = RK.projmap(P, D, K, ii, jj)
-    c, v = db.projmap(Pd, Dd, Kd, ii.to(dev), jj.to(dev))
-    assert torch.equal(v.cpu(), rv)
-    torch.testing.assert_close(c.cpu(), rc, rtol=1e-6, atol=1e-4)
-    for beta in (0.3, 0.7):
-        torch.testing.assert_close(db.frame_distance(Pd, Dd, Kd, ii.to(dev), jj.to(dev), beta).cpu(),
-                                   RK.frame_distance(P, D, K, ii, jj, beta), rtol=1.1e-4, atol=1.2e-5)
-    torch.testing.assert_close(db.iproj(Pd, Dd, Kd).cpu(), RK.iproj(P, D, K), rtol=1e-6, atol=1e-5)
-    ix = torch.tensor([0, 1, 4, 8, 9])
-    th = torch.tensor([0.05, 0.1, 0.2, 0.05, 0.3])
-    assert torch.equal(db.depth_filter(Pd, Dd, Kd, ix.to(dev), th.to(dev)).cpu(), RK.depth_filter(P, D, K, ix, th))
-
-
-@pytest.mark.parametrize("rgbd", [True, False])
-def test_ba_matches_the_reference_kernels(db, RK, O, dev, rgbd):
-    """one Gauss-Newton iteration of `droid_backends.ba` vs the reference's ba_cuda (droid_kernels.cu:1314-1434) run on
-    the CPU: Jacobians, accumulation, Schur complement, damped solve (Eigen's there: a dense double Cholesky in
-    oracle/_ref), retraction"""
-    prob = _ba_problem(O, 8, 22, "tiny", seed=11, rgbd=rgbd)
-    K = prob["intrinsics"][0].contiguous()
-    pr, dr = prob["poses"].clone(), prob["disps"].clone()
-    ref = RK.ba(pr, dr, K, prob["disps_sens"], prob["target"], prob["weight"], prob["eta"], prob["ii"], prob["jj"],
-                prob["t0"], prob["t1"], 1, 1e-4, 0.1, False)
-    pg, dg = prob["poses"].clone().to(dev), prob["disps"].clone().to(dev)
-    out = db.ba(pg, dg, K.to(dev), prob["disps_sens"].to(dev), prob["target"].to(dev), prob["weight"].to(dev),
-                prob["eta"].to(dev), prob["ii"].to(dev), prob["jj"].to(dev), prob["t0"], prob["t1"], 1, 1e-4, 0.1, False)
-    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=2.1e-4, atol=2.5e-6)
-    torch.testing.assert_close(out[1].cpu(), ref[1], rtol=1.1e-3, atol=1.3e-5)
-    torch.testing.assert_close(pg.cpu(), pr, rtol=0, atol=1.3e-5)
-    torch.testing.assert_close(dg.cpu(), dr, rtol=0, atol=1.3e-5)
-
-
 def test_hip_kernels_match_the_reference_kernel_fixture(db, O, dev):
-    """The same comparison without loading oracle/_ref on this box: tests/golden/reference_kernels.npz holds what the
-    reference's kernels produced (on the CPU, in the build container: gen_golden.py::gen_reference_kernels) for the seeded
-    inputs below -- two `ba` iterations on the 12-keyframe / 40-edge ScanNet-shaped window of
+    """The HIP kernels against the REFERENCE's own kernels, no restatement in between: tests/golden/reference_kernels.npz holds
+    what src/lib/*.cu produced (compiled for the CPU by oracle/build_ref.py, run in the build container:
+    gen_golden.py::gen_reference_kernels) for the seeded inputs below -- two `ba` iterations on the 12-keyframe / 40-edge ScanNet-shaped window of
     test_ba_two_iterations_frontend_like, and the geometry kernels on the video of
     test_projmap_frame_distance_iproj_depth_filter."""
     g = _fixture("reference_kernels.npz")
@@ -773,4 +705,25 @@ def test_hip_kernels_match_the_reference_kernel_fixture(db, O, dev):
     torch.testing.assert_close(db.iproj(Pd, Dd, Kd).cpu(), g["iproj"], rtol=1e-6, atol=1e-5)
     out = db.depth_filter(Pd, Dd, Kd, torch.tensor([0, 1, 4, 8, 9]).to(dev), torch.tensor([0.05, 0.1, 0.2, 0.05, 0.3]).to(dev))
     assert torch.equal(out.cpu(), g["depth_filter"])
+    # lookups (correlation_kernels.cu:19-70) on the inputs of test_corr_index_forward_matches_oracle
+    coords = _rand_coords(3, 12, 16, 12, 16)
+    for tag, dt in (("f16", torch.float16), ("f32", torch.float32)):
+        vol = _rand_volume(3, 12, 16, 12, 16, dt)
+        out, = db.corr_index_forward(vol.to(dev), coords.to(dev), 3)
+        if dt == torch.float16:
+            assert torch.equal(out.float().cpu(), g["lookup_" + tag])
+        else:
+            torch.testing.assert_close(out.cpu(), g["lookup_" + tag], rtol=1e-5, atol=1e-6)
+    # one `ba` iteration with and without the depth prior, on the problem of test_ba_one_iteration_matches_oracle
+    for tag, rgbd in (("rgbd", True), ("mono", False)):
+        prob = _ba_problem(O, 8, 22, "tiny", seed=11, rgbd=rgbd)
+        K = prob["intrinsics"][0].contiguous()
+        pg, dg = prob["poses"].clone().to(dev), prob["disps"].clone().to(dev)
+        out = db.ba(pg, dg, K.to(dev), prob["disps_sens"].to(dev), prob["target"].to(dev), prob["weight"].to(dev),
+                    prob["eta"].to(dev), prob["ii"].to(dev), prob["jj"].to(dev), prob["t0"], prob["t1"], 1, 1e-4, 0.1,
+                    False)
+        torch.testing.assert_close(out[0].cpu(), g[f"ba1_{tag}_dx"], rtol=2.1e-4, atol=2.5e-6)
+        torch.testing.assert_close(out[1].cpu(), g[f"ba1_{tag}_dz"], rtol=1.1e-3, atol=1.3e-5)
+        torch.testing.assert_close(pg.cpu(), g[f"ba1_{tag}_poses"], rtol=0, atol=1.3e-5)
+        torch.testing.assert_close(dg.cpu(), g[f"ba1_{tag}_disps"], rtol=0, atol=1.3e-5)
 
