@@ -35,8 +35,9 @@ void gs_timing_mark(const char* name);
 
 #define GS_CHECK_LAUNCH(name)                                                   \
   do {                                                                          \
-    if (gs_timing_on) gs_timing_mark(name);                                     \
+    /* the launch's status is read BEFORE the timer's own runtime calls can overwrite the thread's last error */ \
     hipError_t e_ = hipGetLastError();                                          \
+    if (gs_timing_on) gs_timing_mark(name);                                     \
     if (e_ != hipSuccess) {                                                     \
       gs_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));       \
       return GS_ERR_LAUNCH;                                                     \

@@ -74,7 +74,7 @@ __device__ __forceinline__ void store_tile(const float16v& acc, _Float16* tile, 
       const int idx = (int)(__brev((unsigned)(lane & 31)) >> 27);
       const int e16 = idx & 15;
       const int ch = c0 + 8 * (e16 >> 2) + 4 * kh + (e16 & 3);
-      atomicAdd(&red[2 * ch + (idx >> 4)], sv[0]);
+      red[2 * ch + (idx >> 4)] = sv[0];       // this wave's own slab: 64 lanes, 64 distinct (channel, moment) slots
     }
   }
 #pragma unroll
@@ -104,27 +104,32 @@ __device__ __forceinline__ void store_tile(const float16v& acc, _Float16* tile, 
 
 // KS x KS convolution (KS in {1, 3}), padding KS / 2, stride STRIDE, CIN input channels; `mtiles` = c_out / 32
 // workgroup-level tail of the statistics: zero / publish the per-channel LDS accumulators
-__device__ __forceinline__ void red_init(float* red, int n2) {
-  for (int i = threadIdx.x; i < n2; i += 256) red[i] = 0.0f;
+// (one slab of 2 * cout sums per wave, written with plain stores and added in wave order: the statistics -- and with
+// them the encoder features -- are bitwise reproducible; floating-point LDS atomics from four waves were not)
+__device__ __forceinline__ void red_init(float* red, int n2, int slab) {
+  for (int w = 0; w < 4; ++w)
+    for (int i = threadIdx.x; i < n2; i += 256) red[w * slab + i] = 0.0f;
   __syncthreads();
 }
-__device__ __forceinline__ void red_publish(const float* red, const EncArgs& A, int img) {
+__device__ __forceinline__ void red_publish(const float* red, const EncArgs& A, int img, int slab) {
   __syncthreads();
   float* dst = A.stats + ((size_t)img * gridDim.x + blockIdx.x) * A.cout * 2;
-  for (int i = threadIdx.x; i < 2 * A.cout; i += 256) dst[i] = red[i];
+  for (int i = threadIdx.x; i < 2 * A.cout; i += 256)
+    dst[i] = ((red[i] + red[slab + i]) + red[2 * slab + i]) + red[3 * slab + i];
 }
 
 template <int KS, int CIN, int STRIDE>
 __global__ __launch_bounds__(256) void enc_conv_kernel(EncArgs A, int mtiles) {
   constexpr int KSTEPS = CIN / 16, PAD = KS / 2;
   __shared__ __attribute__((aligned(16))) _Float16 tiles[4][32 * 40];
-  __shared__ float red[2 * 256];
+  constexpr int SLAB = 2 * 256;
+  __shared__ float red[4 * SLAB];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int groups_x = (A.wo + 31) / 32;
   const int img = blockIdx.y;                     // a workgroup never straddles two images (its statistics are per image)
   const int wave_id = blockIdx.x * 4 + wv;
   const bool active = wave_id < A.ho * groups_x * mtiles;
-  if (A.stats) red_init(red, 2 * A.cout);
+  if (A.stats) red_init(red, 2 * A.cout, SLAB);
   const int mt = wave_id % mtiles;
   const int pg = wave_id / mtiles;
   const int gx = pg % groups_x;
@@ -156,20 +161,21 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncArgs A, int mtiles) {
       for (int ks = 0; ks < KSTEPS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], b[ks], acc, 0, 0, 0);
     }
   }
-  if (active) store_tile(acc, tiles[wv], A, img, oy, ox0, 32 * mt, lane, red);
-  if (A.stats) red_publish(red, A, img);
+  if (active) store_tile(acc, tiles[wv], A, img, oy, ox0, 32 * mt, lane, red + wv * SLAB);
+  if (A.stats) red_publish(red, A, img, SLAB);
 }
 
 // the stem: 7 x 7, stride 2, padding 3, 4 (RGB0) -> 32 channels.  K = 7 kernel rows x 32 (8 taps x 4 channels, tap 7 = 0)
 __global__ __launch_bounds__(256) void enc_stem_kernel(EncArgs A) {
   __shared__ __attribute__((aligned(16))) _Float16 tiles[4][32 * 40];
-  __shared__ float red[2 * 32];
+  constexpr int SLAB = 2 * 32;
+  __shared__ float red[4 * SLAB];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int groups_x = (A.wo + 31) / 32;
   const int img = blockIdx.y;
   const int wave_id = blockIdx.x * 4 + wv;
   const bool active = wave_id < A.ho * groups_x;
-  if (A.stats) red_init(red, 2 * 32);
+  if (A.stats) red_init(red, 2 * 32, SLAB);
   const int gx = wave_id % groups_x;
   const int oy = active ? wave_id / groups_x : 0;
   const int r = lane & 31, kh = lane >> 5;
@@ -194,8 +200,8 @@ __global__ __launch_bounds__(256) void enc_stem_kernel(EncArgs A) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.wpack[(dy * 2 + ks) * 64 + lane], b, acc, 0, 0, 0);
     }
   }
-  if (active) store_tile(acc, tiles[wv], A, img, oy, ox0, 0, lane, red);
-  if (A.stats) red_publish(red, A, img);
+  if (active) store_tile(acc, tiles[wv], A, img, oy, ox0, 0, lane, red + wv * SLAB);
+  if (A.stats) red_publish(red, A, img, SLAB);
 }
 
 template <int KS, int CIN, int STRIDE>

@@ -175,11 +175,13 @@ __global__ __launch_bounds__(256) void instnorm_final_sums_kernel(const float* _
   __syncthreads();
   if (tid < c) {
     for (int q = 1; q < per; ++q) { a1 += sm[q * c + tid][0]; a2 += sm[q * c + tid][1]; }
-    const float n = (float)hw;
-    const float mean_d = a1 / n;
-    const float var = fmaxf(a2 / n - mean_d * mean_d, 0.0f);
-    final_[((size_t)img * c + tid) * 2 + 0] = (shift ? (float)shift[tid] : 0.0f) + mean_d;
-    final_[((size_t)img * c + tid) * 2 + 1] = 1.0f / sqrtf(var + eps);
+    // E[d^2] - E[d]^2 in fp64: on a near-constant map the two terms agree to ~7 digits and their fp32 difference would be
+    // of the order of eps itself (the sums are of d = v - bias, already centred on the convolution's own mean)
+    const double n = (double)hw;
+    const double mean_d = (double)a1 / n;
+    const double var = fmax((double)a2 / n - mean_d * mean_d, 0.0);
+    final_[((size_t)img * c + tid) * 2 + 0] = (shift ? (float)shift[tid] : 0.0f) + (float)mean_d;
+    final_[((size_t)img * c + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
 

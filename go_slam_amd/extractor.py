@@ -238,6 +238,9 @@ class BasicEncoder(nn.Module):
             ws = _stats_workspace(dev, need)
             wsp, wsn = ws.data_ptr(), ws.numel()
             cl = torch.channels_last
+            chunk_cache = self.__dict__.setdefault("_stat_chunks", {})
+            # (convolution and normalisation are two launches sharing the stream's ONE statistics workspace: this path
+            # is single-threaded per stream -- two host threads encoding on the same stream would need a workspace each)
 
             def conv(m, xin, stats):
                 k, stride, co = m.kernel_size[0], m.stride[0], m.out_channels
@@ -250,7 +253,12 @@ class BasicEncoder(nn.Module):
                                    b if stats else None, wsp if stats else None, st)
                 if rc:
                     _lib.check(rc, "enc_conv")
-                return y, b, ((ho * ((wo + 31) // 32) * (co // 32) + 3) // 4 if stats else 0)
+                if not stats:
+                    return y, b, 0
+                ch = chunk_cache.get((ho, wo, co))          # the kernel's own grid mapping, asked once per layer shape
+                if ch is None:
+                    ch = chunk_cache[(ho, wo, co)] = int(L.gs_enc_conv_stat_chunks(ho, wo, co))
+                return y, b, ch
 
             def norm(t, skip, relu_in, relu_out, b, chunks):
                 n, c, h, w = t.shape

@@ -261,6 +261,24 @@ class InstantNeuS(nn.Module):
             "sdf": sdf, "z_vals": zmid, "gradient_error": (gerr.sum() / float(n * s)).unsqueeze(0),
         }
 
+    def render_rays(self, rays_o, rays_d, gt_depth=None, render_params=None, renderer=None, **sampling):
+        """The entry point BASELINE.json's north_star names.  The reference has no method of this name: a ray batch is
+        rendered by `Renderer.render_batch_ray(rays_o, rays_d, net, render_params, device, gt_depth)`
+        (src/render.py:73-175, called from src/mapping.py:90 and src/mesher.py), i.e. sample placement followed by
+        `InstantNeuS.forward` on chunks of rays.  This is that call with the network as the receiver: the same dict of 9
+        tensors.  `renderer`: a `Renderer` to take the sample counts / chunk size from; without one a default
+        `Renderer(**sampling)` (N_samples = 24, N_surface = 48, perturb = 1: configs/Replica/replica.yaml) is built
+        once and kept."""
+        if renderer is None:
+            key = tuple(sorted(sampling.items()))
+            cache = self.__dict__.setdefault("_render_rays_renderers", {})
+            renderer = cache.get(key)
+            if renderer is None:
+                from .render import Renderer
+                renderer = cache[key] = Renderer(**sampling)
+        return renderer.render_batch_ray(rays_o, rays_d, self, render_params=render_params, device=rays_o.device,
+                                         gt_depth=gt_depth)
+
     def compute_sdf_error(self, sdf, z_vals, gt_depth):
         """src/InstantNeuS.py:372-400.  The reference first gathers the rays with gt_depth > 0 (boolean
         indexing = nonzero + host sync); here those rays are masked out instead, which yields the same sums."""

@@ -386,7 +386,7 @@ class MapTrainer:
             flat.step(inv_scale, prepped=True)
             return self._global_loss()
         if perturb_rand is None and self.renderer.perturb > 0:      # drawn OUTSIDE the graph: a replay must see new values
-            perturb_rand = torch.rand(self.renderer.N_samples, device=args[0].device)
+            perturb_rand = self.renderer._perturb_row(self.renderer.N_samples, args[0].device)
         ent = self._graph_for(args, counts, perturb_rand)
         if ent["rt_bound"].data_ptr() != self.model.realtime_bound.data_ptr():
             raise RuntimeError("MapTrainer: model.realtime_bound was re-allocated after a step was captured "

@@ -19,12 +19,25 @@ class Renderer:
         if self.lindisp:
             raise NotImplementedError("lindisp sampling is off in every reference config (configs/*.yaml)")
         self._lin = {}
+        self._rand = {}
 
     def _linspace(self, steps, device):
         key = (steps, str(device))
         if key not in self._lin:
             self._lin[key] = torch.linspace(0, 1, steps=steps, device=device).float().contiguous()
         return self._lin[key]
+
+    _RAND_ROWS = 128
+
+    def _perturb_row(self, ns, device):
+        """One `torch.rand(N_samples)` vector per batch (render.py:159), drawn `_RAND_ROWS` batches at a time: the same
+        generator stream cut into rows, one launch per 128 batches instead of one per batch."""
+        key = (ns, str(device))
+        pool, used = self._rand.get(key, (None, self._RAND_ROWS))
+        if used >= self._RAND_ROWS:
+            pool, used = torch.rand(self._RAND_ROWS, ns, device=device), 0
+        self._rand[key] = (pool, used + 1)
+        return pool[used]
 
     def sample(self, rays_o, rays_d, bound, gt_depth=None, perturb_rand=None, gt_max_dev=None):
         """z_vals, dists [N, N_samples + N_surface] (render.py:99-171).  `gt_max_dev` (device fp32[1], optional): the
@@ -46,7 +59,7 @@ class Renderer:
         else:
             gt_max, gt_max_dev = 0.0, None
         if self.perturb > 0 and perturb_rand is None:
-            perturb_rand = torch.rand(ns, device=dev)           # one vector shared by all rays (:159)
+            perturb_rand = self._perturb_row(ns, dev)           # one vector shared by all rays (:159)
         z = torch.empty(n, ns + nsurf, dtype=torch.float32, device=dev)
         d = torch.empty_like(z)
         with torch.cuda.device(dev):

@@ -413,13 +413,26 @@ def test_ba_rejects_non_contiguous(db, dev):
               False)
 
 
-def test_ba_large_window_blocked_cholesky(db, O, dev):
-    """6P = 282 unknowns: several Cholesky panels + trailing tiles, and degree-8 keyframes."""
-    prob = _ba_problem(O, 48, 260, "tiny", seed=37)
+# 6P -> solver (csrc/chol.hip, gs_chol_solve_launch): <= 192 chol_small (LDS-resident); 193 .. 450 chol_mid, ONE workgroup with
+# head stages of SW = 60 columns up to 6P = 300 and SW = 30 above (mid_tile_product<15> / <8>); above 450 the multi-kernel
+# blocked path.  Every branch and both of its edges, incl. stage counts that leave a ragged last stage (n % SW != 0):
+@pytest.mark.parametrize("num_kf,path", [(34, "mid, SW 60, one head stage (6P = 198: six columns past chol_small's cap)"),
+                                         (48, "mid, SW 60 (6P = 282, 282 % 60 = 42)"),
+                                         (51, "mid, SW 60 at its upper edge (6P = 300)"),
+                                         (52, "mid, SW 30 at its lower edge (6P = 306, 306 % 30 = 6)"),
+                                         (58, "mid, SW 30 (6P = 342, 342 % 30 = 12)"),
+                                         (61, "mid, SW 30 (6P = 360)"),
+                                         (76, "mid, SW 30 at its upper edge (6P = 450)"),
+                                         (77, "blocked multi-kernel path at its lower edge (6P = 456)")])
+def test_ba_cholesky_path_for_every_window_size(db, O, dev, num_kf, path):
+    """Two Gauss-Newton iterations of `ba` vs the oracle with the pose system going through each solver branch."""
+    prob = _ba_problem(O, num_kf, int(5.4 * num_kf), "tiny", seed=37 + num_kf)
+    assert 6 * (prob["t1"] - prob["t0"]) == 6 * (num_kf - 1), path
     ref, (po, do), out, (pg, dg) = _run_ba_pair(db, O, dev, prob, 2, 1e-5, 1e-2, False)
-    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=2e-3, atol=5e-6)
-    torch.testing.assert_close(pg, po, rtol=0, atol=2e-5)
-    torch.testing.assert_close(dg, do, rtol=0, atol=2e-5)
+    assert db.ba_status(dev)["cholesky_failures"] == 0, path
+    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=2e-3, atol=5e-6, msg=lambda m: path + ": " + m)
+    torch.testing.assert_close(pg, po, rtol=0, atol=2e-5, msg=lambda m: path + ": " + m)
+    torch.testing.assert_close(dg, do, rtol=0, atol=2e-5, msg=lambda m: path + ": " + m)
 
 
 @pytest.mark.parametrize("num_kf", [23, 33])
