@@ -1182,6 +1182,54 @@ def gen_reference_kernels():
     save("reference_kernels.npz", **out)
 
 
+def gen_reference_kernels_bench():
+    """The reference's OWN kernels (oracle/_ref, as gen_reference_kernels) at the BENCH shapes, for the GPU box: two Gauss-Newton
+    iterations of `ba_cuda` on the S480 frontend window bench.py times (60x80 maps, P = 25, E = 75, RGB-D; inputs of
+    tests/test_benchshape_gpu.py::test_ba_bench_window...) and on the monocular window (Replica 40x80, P = 50, E = 100, no depth
+    prior, 6P = 294), `altcorr_forward` (fp32, and fp16 on fp16-representable inputs), `altcorr_backward`'s two gradients and
+    `corr_index_backward`.  Disparity maps are kept at every second row / column (the fixture stays below 1 MB); the pose
+    rows, dx and a float64 checksum cover the rest."""
+    from oracle import build_ref
+    build_ref.build()
+    R = build_ref.load()
+    assert R is not None
+    out = {}
+    for tag, shape, nkf, ne, rgbd, seed in (("s480", "S480", 25, 75, True, 31), ("mono", "Rep", 50, 100, False, 33)):
+        p = synth.make_ba_problem(nkf, ne, shape, seed, rgbd)
+        c, _ = DO.reproject(p["poses"], p["disps"], p["intrinsics"], p["ii"], p["jj"])
+        p = synth.make_ba_problem(nkf, ne, shape, seed, rgbd, noise_px=0.5, coords=c[0])
+        K = p["intrinsics"][0].contiguous()
+        po, do = p["poses"].clone(), p["disps"].clone()
+        dx, dz = R.ba(po, do, K, p["disps_sens"], p["target"], p["weight"], p["eta"], p["ii"], p["jj"], p["t0"], p["t1"], 2,
+                      1e-4, 0.1, False)
+        out.update({f"ba_{tag}_poses": po, f"ba_{tag}_dx": dx, f"ba_{tag}_disps_s2": do[:, ::2, ::2].contiguous(),
+                    f"ba_{tag}_disps_sum": do.double().sum().reshape(1)})
+    # alt-corr (altcorr_kernel.cu:27-149 / :152-290) on the inputs of test_altcorr_forward_matches_oracle
+    g = torch.Generator().manual_seed(41)
+    B, H1, W1, H2, W2, C, S = 3, 9, 13, 5, 7, 128, 2
+    f1 = torch.randn(B, H1, W1, C, generator=g) / 4
+    f2 = torch.randn(B, H2, W2, C, generator=g) / 4
+    ys, xs = torch.meshgrid(torch.arange(H1, dtype=torch.float32), torch.arange(W1, dtype=torch.float32), indexing="ij")
+    base = torch.stack([xs * (W2 / W1), ys * (H2 / H1)], -1)
+    coords = base[None, None] + 2.0 * torch.randn(B, S, H1, W1, 2, generator=g)
+    coords[:, :, 0, 0] = torch.tensor([-9.0, 2.0])
+    coords[:, :, 0, 1] = torch.tensor([3.0, 2.0])
+    out["altcorr_f32"] = R.altcorr_forward(f1, f2, coords, 3)[0]
+    out["altcorr_f16in"] = R.altcorr_forward(f1.half().float(), f2.half().float(), coords, 3)[0]   # fp16-representable inputs
+    gc = torch.randn(B, S, 49, H1, W1, generator=g)
+    d1, d2, _ = R.altcorr_backward(f1, f2, coords, gc, 3)
+    out.update(altcorr_grad=gc, altcorr_d1=d1, altcorr_d2=d2)
+    # corr_index_backward (correlation_kernels.cu:74-140)
+    spec = importlib.util.spec_from_file_location("_ttg", os.path.join(os.path.dirname(HERE), "test_track_gpu.py"))
+    ttg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ttg)
+    vol = ttg._rand_volume(2, 5, 6, 9, 11, torch.float32)
+    cb = ttg._rand_coords(2, 5, 6, 9, 11, spread=1.5)
+    gb = torch.randn(2, 7, 7, 5, 6, generator=torch.Generator().manual_seed(45))
+    out.update(lookup_bwd_grad=gb, lookup_bwd=R.corr_index_backward(vol, cb, gb, 3)[0])
+    save("reference_kernels_bench.npz", **out)
+
+
 class FakeAltCorr:
     """stands in for AltCorrBlock under update_lowmem (both sides): a deterministic function of its arguments"""
     log = None
@@ -1285,6 +1333,10 @@ def gen_lowmem():
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate the fixtures"
     install_stubs()
+    if len(sys.argv) > 1:                                    # python gen_golden.py gen_reference_kernels_bench ...
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     with torch.no_grad():
         gen_update()
         gen_ba()
@@ -1307,3 +1359,4 @@ if __name__ == "__main__":
     gen_neus()
     gen_neus_backward()
     gen_reference_kernels()
+    gen_reference_kernels_bench()

@@ -224,7 +224,7 @@ def _record(name, payload):
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(d, exist_ok=True)
-        path = os.path.join(d, "r04_parity.json")
+        path = os.path.join(d, "r05_parity.json")
         cur = json.load(open(path)) if os.path.exists(path) else {}
         cur[name] = payload
         json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
@@ -702,3 +702,76 @@ def test_ba_recovers_a_one_metre_trajectory_from_exact_correspondences(db, O, de
     assert path > 0.5 and ate0 > 5e-3, rec                        # a real path, a real perturbation
     assert ate_g < 1e-4 and ate_c < 1e-4, rec
     assert raw_gc < 1e-5, rec
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# HIP kernels vs the REFERENCE's own kernels at the bench shapes -- no restatement in between
+# ------------------------------------------------------------------------------------------------------------------
+def _fixture(name):
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+    return {k: torch.from_numpy(np.asarray(g[k])) for k in g.files}
+
+
+@pytest.mark.parametrize("tag,shape,nkf,ne,rgbd,seed", [("s480", "S480", 25, 75, True, 31), ("mono", "Rep", 50, 100, False, 33)])
+def test_ba_at_the_bench_windows_matches_the_reference_kernels(db, O, dev, tag, shape, nkf, ne, rgbd, seed):
+    """`droid_backends.ba` (2 Gauss-Newton iterations) against what the reference's `ba_cuda` (src/lib/droid_kernels.cu:1314-1434,
+    compiled for the CPU by oracle/build_ref.py, run in the build container by tests/golden/gen_golden.py::
+    gen_reference_kernels_bench) produced on the SAME seeded window: the S480 frontend window bench.py times (60x80, P = 25,
+    E = 75, RGB-D, 6P = 144: chol_small) and the monocular window (Replica 40x80, P = 50, E = 100, no depth prior, 6P = 294:
+    chol_mid).  Tolerance = what the reference's own fp32 block reductions allow: its dx differs from the fp64-accumulated
+    oracle's by 1.6e-6 / 3.0e-7 at these windows (profiles/r04_reference_kernels_parity.json), the HIP path from the oracle by
+    <= 3.5e-7 (profiles/r04_parity.json) -- dx rtol 1e-4 / atol 3e-6, poses 4e-6, disparities 5e-6 absolute."""
+    g = _fixture("reference_kernels_bench.npz")
+    prob = _ba_problem(O, nkf, ne, shape, seed=seed, rgbd=rgbd)
+    K = prob["intrinsics"][0].contiguous()
+    pg, dg = prob["poses"].clone().to(dev), prob["disps"].clone().to(dev)
+    out = db.ba(pg, dg, K.to(dev), prob["disps_sens"].to(dev), prob["target"].to(dev), prob["weight"].to(dev),
+                prob["eta"].to(dev), prob["ii"].to(dev), prob["jj"].to(dev), prob["t0"], prob["t1"], 2, 1e-4, 0.1, False)
+    torch.cuda.synchronize()
+    assert db.ba_status(dev)["cholesky_failures"] == 0
+    dx, rdx = out[0].cpu(), g[f"ba_{tag}_dx"]
+    assert float(rdx.abs().max()) > 5e-3, "degenerate window"
+    _record(f"ba_{tag}_window_vs_reference_kernels", {
+        "dx": _err(dx, rdx), "poses": _err(pg.cpu(), g[f"ba_{tag}_poses"]),
+        "disps_every_second_pixel": _err(dg.cpu()[:, ::2, ::2], g[f"ba_{tag}_disps_s2"]),
+        "disps_sum_rel": abs(float(dg.double().sum().cpu()) / float(g[f"ba_{tag}_disps_sum"]) - 1.0)})
+    torch.testing.assert_close(dx, rdx, rtol=1e-4, atol=3e-6)
+    torch.testing.assert_close(pg.cpu(), g[f"ba_{tag}_poses"], rtol=0, atol=4e-6)
+    torch.testing.assert_close(dg.cpu()[:, ::2, ::2], g[f"ba_{tag}_disps_s2"], rtol=0, atol=5e-6)
+    assert abs(float(dg.double().sum().cpu()) / float(g[f"ba_{tag}_disps_sum"]) - 1.0) < 1e-6
+
+
+def test_altcorr_and_lookup_backward_match_the_reference_kernels(db, dev):
+    """`altcorr_forward` (fp32; fp16 operands with fp32 accumulation against the reference kernel run on the same
+    fp16-representable values), `altcorr_backward` and `corr_index_backward` against the outputs of
+    src/lib/altcorr_kernel.cu:27-290 and correlation_kernels.cu:74-140 themselves (reference_kernels_bench.npz)."""
+    g = _fixture("reference_kernels_bench.npz")
+    gen = torch.Generator().manual_seed(41)
+    B, H1, W1, H2, W2, C, S = 3, 9, 13, 5, 7, 128, 2
+    f1 = torch.randn(B, H1, W1, C, generator=gen) / 4
+    f2 = torch.randn(B, H2, W2, C, generator=gen) / 4
+    ys, xs = torch.meshgrid(torch.arange(H1, dtype=torch.float32), torch.arange(W1, dtype=torch.float32), indexing="ij")
+    base = torch.stack([xs * (W2 / W1), ys * (H2 / H1)], -1)
+    coords = base[None, None] + 2.0 * torch.randn(B, S, H1, W1, 2, generator=gen)
+    coords[:, :, 0, 0] = torch.tensor([-9.0, 2.0])
+    coords[:, :, 0, 1] = torch.tensor([3.0, 2.0])
+    out, = db.altcorr_forward(f1.to(dev), f2.to(dev), coords.to(dev), 3)
+    torch.testing.assert_close(out.cpu(), g["altcorr_f32"], rtol=1e-5, atol=1e-5)
+    out16, = db.altcorr_forward(f1.half().to(dev), f2.half().to(dev), coords.to(dev), 3)
+    # fp16 output of fp32-accumulated dot products: half an fp16 ulp of the largest entries (|corr| < 8 -> 2^-8 ulp)
+    torch.testing.assert_close(out16.cpu().float(), g["altcorr_f16in"], rtol=2 ** -10, atol=2 ** -12)
+    assert torch.equal(torch.randn(B, S, 49, H1, W1, generator=gen), g["altcorr_grad"])
+    d1, d2, dc = db.altcorr_backward(f1.to(dev), f2.to(dev), coords.to(dev), g["altcorr_grad"].to(dev), 3)
+    torch.testing.assert_close(d1.cpu(), g["altcorr_d1"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(d2.cpu(), g["altcorr_d2"], rtol=1e-5, atol=2e-5)
+    assert not bool(dc.any())
+    # corr_index_backward on the volume / coordinates of test_track_gpu.py::test_corr_index_backward_matches_oracle
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ttg", os.path.join(os.path.dirname(__file__), "test_track_gpu.py"))
+    ttg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ttg)
+    vol = ttg._rand_volume(2, 5, 6, 9, 11, torch.float32)
+    cb = ttg._rand_coords(2, 5, 6, 9, 11, spread=1.5)
+    vg, = db.corr_index_backward(vol.to(dev), cb.to(dev), g["lookup_bwd_grad"].to(dev), 3)
+    torch.testing.assert_close(vg.cpu(), g["lookup_bwd"], rtol=1e-5, atol=1e-6)

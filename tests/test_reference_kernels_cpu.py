@@ -180,3 +180,46 @@ def test_ba_at_the_bench_window(R):
     torch.testing.assert_close(po, pr, rtol=0, atol=3e-6)
     torch.testing.assert_close(do, dr, rtol=0, atol=4e-6)
 
+
+
+def test_seeded_random_windows_ba_geometry_lookup(R):
+    """20 seeded random windows (the loop of tools/fuzz_oracle_vs_reference_kernels.py, whose round-4 run of 108 problems is
+    the source of the bounds): 4-9 keyframes with 1-3 edges per keyframe on 12x16 maps -- RGB-D and monocular alternating,
+    motion-only every fifth, a window start t0 > 1 every third, 0-2 px of target noise -- two Gauss-Newton iterations of the
+    reference's `ba_cuda` vs the oracle's, `frame_distance`, `projmap` (bit for bit) and the fp16 lookup on pyramid sizes
+    12x16 / 15x20 / 7x10 / 3x5 (bit for bit)."""
+    worst = {}
+
+    def upd(k, a, b):
+        worst[k] = max(worst.get(k, 0.0), float((a.double() - b.double()).abs().max()))
+    for seed in range(100, 120):
+        g = torch.Generator().manual_seed(seed)
+        nkf = int(torch.randint(4, 10, (1,), generator=g))
+        ne = int(torch.randint(nkf, 3 * nkf, (1,), generator=g))
+        rgbd = bool(seed % 2)
+        p = synth.make_ba_problem(nkf, ne, "tiny", seed, rgbd)
+        c, _ = DO.reproject(p["poses"], p["disps"], p["intrinsics"], p["ii"], p["jj"])
+        p = synth.make_ba_problem(nkf, ne, "tiny", seed, rgbd, noise_px=float(torch.rand(1, generator=g)) * 2, coords=c[0])
+        if seed % 3 == 0 and nkf > 5:
+            p["t0"] = int(torch.randint(1, nkf - 2, (1,), generator=g))
+            kx = torch.unique(torch.cat([torch.arange(p["t0"], p["t1"]), p["ii"]]))
+            ht, wd, _ = synth.SHAPES["tiny"]
+            p["eta"] = 1e-2 * torch.rand(len(kx), ht, wd, generator=g) + 1e-4
+        mo = seed % 5 == 0
+        (rr, pr, dr), (ro, po, do) = _run_pair(R, p, 2, 1e-4, 0.1, mo)
+        upd("poses", po, pr); upd("disps", do, dr); upd("dx", ro[0], rr[0])
+        if not mo:
+            upd("dz", ro[1], rr[1])
+        K = p["intrinsics"][0].contiguous()
+        ii, jj = p["ii"], p["jj"]
+        upd("frame_distance", DO.frame_distance(p["poses"], p["disps"], K, ii, jj, 0.3),
+            R.frame_distance(p["poses"], p["disps"], K, ii, jj, 0.3))
+        assert torch.equal(DO.projmap(p["poses"], p["disps"], K, ii, jj)[0], R.projmap(p["poses"], p["disps"], K, ii, jj)[0]), seed
+        h2, w2 = [(7, 10), (3, 5), (15, 20), (12, 16)][seed % 4]
+        vol = torch.randn(2, 6, 9, h2, w2, generator=g).half()
+        ys, xs = torch.meshgrid(torch.arange(6.), torch.arange(9.), indexing="ij")
+        co = (torch.stack([xs * w2 / 9, ys * h2 / 6], 0)[None].repeat(2, 1, 1, 1) + 3 * torch.randn(2, 2, 6, 9, generator=g)).contiguous()
+        assert torch.equal(DO.corr_index_forward(vol, co, 3)[0], R.corr_index_forward(vol, co, 3)[0]), seed
+    # round-4 run over 108 windows: poses 1.1e-6, dx 9.8e-7, disparities / dz 1.6e-5, frame_distance 1.2e-7
+    assert worst["poses"] <= 3e-6 and worst["dx"] <= 3e-6 and worst["disps"] <= 4e-5 and worst["dz"] <= 4e-5, worst
+    assert worst["frame_distance"] <= 1e-6, worst
