@@ -110,8 +110,29 @@ def global_ba_stress(device, num_kf=200, num_edges=1200, shape="Scan"):
                                              corr_impl="alt", upsample=False)
     ms = time_op(lambda: graph.update_lowmem(steps=1, iters=2), iters=3, warm=1)
     finite = bool(torch.isfinite(video.poses).all()) and bool(torch.isfinite(video.disps).all())
-    return {"keyframes": num_kf, "edges": int(graph.ii.numel()), "maps": shape, "unknowns": 6 * (num_kf - 1),
-            "update_lowmem_step_ms": ms, "state_finite": finite}
+    out = {"keyframes": num_kf, "edges": int(graph.ii.numel()), "maps": shape, "unknowns": 6 * (num_kf - 1),
+           "update_lowmem_step_ms": ms, "state_finite": finite}
+    # the on-the-fly correlation of the step, timed per launch by the library's kernel timer (HIP events on the launch
+    # stream): SURVEY 8d prices it at 65,536 * HW flop per edge (4 levels x 64 taps x 128 channels x 2)
+    from go_slam_amd import _lib
+    with _lib.kernel_timer(device) as kt:
+        graph.update_lowmem(steps=1, iters=2)
+        torch.cuda.synchronize()
+    t = kt.read()
+    out["library_launches_per_step"] = int(sum(v[1] for v in t.values()))
+    if "altcorr_pyramid" in t and t["altcorr_pyramid"][1]:
+        tot_ms, n = t["altcorr_pyramid"]
+        flops = 65536.0 * graph.ht * graph.wd * int(graph.ii.numel())
+        tf = flops / (tot_ms * 1e-3) / 1e12
+        out["altcorr_roofline"] = {
+            "kernel": "altcorr_pyramid_kernel (4 levels x 4x4-pixel tiles x union window on v_mfma_f32_16x16x32_f16; "
+                      f"{n} launches = one per 13-keyframe chunk) @ {int(graph.ii.numel())} edges, {graph.ht}x{graph.wd} maps",
+            "bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS,
+            "algorithmic_flops_per_step": flops, "kernel_ms_per_step": tot_ms, "kernel_avg_us": 1e3 * tot_ms / n,
+            "frac_of_fp32_vector_roof_157TF": tf / 157.0,
+            "note": "algorithmic flops = the 64 taps each pixel needs; the dense union-window product issues ~3-4x as many "
+                    "on the matrix cores (round 4: one wave per pixel on v_dot2, 16.4 TFLOP/s = 0.10 of the vector roof)"}
+    return out
 
 
 def mono_window(device, num_kf=50, num_edges=100, shape="Rep", steps=5, warm=2):
@@ -326,10 +347,38 @@ def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768, s
         loss = tr.step(o, d, col, gt, pr)
     sync()
     dt = time.perf_counter() - tic
+    exch = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+        if getattr(tr, "fused", False):
+            # a second, instrumented pass (outside the timed region): events around the collectives on the step's stream ->
+            # per rank the time the compute stream was BLOCKED on an exchange; compute = step - exposed exchange
+            from go_slam_amd.neus.distributed import ExchangeTimer
+            et = ExchangeTimer(device)
+            tr.flat._exchange_timer = et
+            sync()
+            tic2 = time.perf_counter()
+            for _ in range(steps):
+                tr.step(o, d, col, gt, pr)
+            tr.flat.wait_gather()
+            sync()
+            step2 = 1e3 * (time.perf_counter() - tic2) / steps
+            tr.flat._exchange_timer = None
+            ex = et.exposed_ms()
+            mine = torch.tensor([step2, ex["total"] / steps, ex["reduce_scatter_and_dense_allreduce"] / steps,
+                                 ex["clip_norm_allreduce"] / steps, ex["all_gather_wait"] / steps],
+                                device=device, dtype=torch.float64)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            rows = [[round(float(v), 4) for v in r] for r in allr]
+            exch = {"columns": ["step_ms", "exposed_exchange_ms", "reduce_scatter+dense_allreduce_ms", "clip_norm_allreduce_ms",
+                                "all_gather_wait_ms"], "per_rank": rows,
+                    "compute_ms_per_rank": [round(r[0] - r[1], 4) for r in rows],
+                    "deferred_all_gather": bool(tr.flat.overlap_gather),
+                    "note": "instrumented pass after the timed region (one event pair per collective phase on the step's "
+                            "stream); exposed = time the compute stream was blocked on the exchange"}
     ms = 1e3 * dt / steps
     return {"metric": "NeuS mapping train step rays/s (render + loss + backward + all-reduce + clip + AdamW)",
             "value": n / (ms * 1e-3), "unit": "rays/s", "global_rays": n, "rays_per_gpu": n // world, "ms_per_step": ms,
@@ -339,7 +388,8 @@ def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768, s
                                                else (0 if world == 1 else 4 * sum(p.numel() for p in tr.train_params))),
             "exchange": "none" if world == 1 else ("reduce-scatter(fp16 table grad) + sharded AdamW + all-gather(fp16 "
                                                    "table)" if tr.fused else "all-reduce(fp32 flat grad)"),
-            "final_loss": float(loss)}
+            "exchange_exposed_ms": (max(r[1] for r in exch["per_rank"]) if exch else (0.0 if world == 1 else None)),
+            "exchange_per_rank": exch, "final_loss": float(loss)}
 
 
 def cpu_baseline(sample_updates=1):
@@ -428,28 +478,30 @@ def cpu_baseline_neus(n_rays=4096):
                                      "(oracle forward + losses + torch.autograd backward + clip + AdamW)"}}
 
 
-def gather_ceiling(table_mb=25.2, points=None):
-    """G gathers/s ceiling measured by tools/gather_bench.hip on an MI355X (committed: profiles/r04_gather_bench.json):
-    the grid's own corner pattern on a table of `table_mb`; None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r04_gather_bench.json")
+def gather_ceiling(n_rays):
+    """Gather-only replay of the hash grid's OWN index stream on this batch (tools/gather_replay.py on an MI355X, committed:
+    profiles/r05_gather_replay.json): what the table loads of a forward cost with no arithmetic around them -- level-major
+    for the hashed levels + point-major for the dense ones, the order the round-5 forward issues them in.  (Round 4's
+    comparator drew independent random points and the production kernel beat it by up to 1.8x: no ceiling.)"""
+    path = os.path.join(ROOT, "profiles", "r05_gather_replay.json")
     if not os.path.exists(path):
         return None
-    rows = [r for r in json.load(open(path))["results"] if abs(r["table_MB"] - table_mb) < 0.2]
-    if points is not None and rows:
-        rows = sorted(rows, key=lambda r: abs(r["points"] - points))[:1]
-    return {"corner8_Ggathers_per_s": max(r["corner8"]["Ggathers_per_s"] for r in rows),
-            "random4_Ggathers_per_s": max(r["random4"]["Ggathers_per_s"] for r in rows),
-            "source": "profiles/r04_gather_bench.json (tools/gather_bench.hip, committed run)"} if rows else None
+    b = json.load(open(path)).get("batches", {}).get(str(n_rays))
+    if not b:
+        return None
+    return dict(b, source="profiles/r05_gather_replay.json (tools/gather_replay.py, committed run)")
 
 
 def neus_kernel_rooflines(device, n_rays, steps=5):
     """The kernels that own path M, timed LIVE with HIP events on the launch stream (the library's kernel timer,
     gs_timing_*): the eager fused mapper step on `n_rays` rays x 72 samples.  Algorithmic bytes per point:
-    forward 512 B of grid gathers + 12 B in = 524 B; backward 512 B gathers + 512 B table-gradient scatter + 12 B =
-    1036 B (since round 4 the production backward streams 256 B per point of forward records instead of gathering; the
-    algorithmic count stays SURVEY's); the bin reduce reads the backward's record queues (6 B per record, 128 records per
-    point at most) and writes the 11 hashed levels once.  `gather_rate` = 128 four-byte gathers per point / kernel time, against the
-    measured ceiling of tools/gather_bench.hip."""
+    forward 512 B of grid gathers + 12 B in = 524 B -- since round 5 split over neus_encode_levels_kernel (the 11 hashed
+    levels, level-major: 352 B of gathers + 8 B in) and neus_point_kernel (the 5 dense levels: 160 B, + the records);
+    backward 512 B gathers + 512 B table-gradient scatter + 12 B = 1036 B (the production backward streams 256 B per point
+    of forward records instead of gathering; the algorithmic count stays SURVEY's); the bin reduce reads the backward's
+    record queues (6 B per record, 128 records per point at most) and writes the 11 hashed levels once.  `gather_rate` =
+    table loads of the IN-BOUND points / kernel time, against the gather-only replay of the same index stream
+    (`gather_frac_of_replay` = replay time / kernel time <= 1 by construction of the comparator)."""
     import go_slam_amd.neus as neus
     from go_slam_amd import _lib
     from go_slam_amd.neus.mapper import MapTrainer
@@ -476,36 +528,44 @@ def neus_kernel_rooflines(device, n_rays, steps=5):
         torch.cuda.synchronize()
     t = kt.read()
     pts = n * 72
-    ceil_ = gather_ceiling(25.2, pts)
+    ceil_ = gather_ceiling(n_rays)
+    inb = ceil_["points_in_bound"] if ceil_ else pts
     pmc = {}
-    ppath = os.path.join(ROOT, "profiles", "r04_pmc_neus.json")
+    ppath = os.path.join(ROOT, "profiles", "r05_pmc_neus.json")
     if os.path.exists(ppath):
         pmc = json.load(open(ppath)).get(f"traffic_bytes_per_launch@{n_rays}", {})
     nh = 11                         # hashed levels (2^19 entries x 4 B each)
-    spec = [("neus_point", "neus_point_kernel (hash-grid encode + SDF linear + analytic gradient + alpha + MLP input row)",
-             524.0 * pts, True),
-            ("neus_backward_points_binned", "neus_point_bwd_kernel<binned, aux> (streams the forward's per-level records, table-gradient records = pass 1 of bin-and-reduce)",
-             1036.0 * pts, True),
-            ("grid_bin_reduce", "grid_bin_reduce_kernel (pass 2: exact integer LDS sums per 8192-entry bin)",
-             6.0 * 88.0 * pts + nh * (1 << 19) * 4.0 * 2, False),
-            ("mlp_backward", "neus_mlp_bwd_kernel (fused colour-MLP backward, MFMA)", (160.0 + 12.0 + 6.0 + 160.0) * pts, False),
-            ("neus_mlp", "neus_mlp_kernel (fused colour MLP forward, MFMA)", (160.0 + 6.0) * pts, False)]
+    # (timer keys, label, algorithmic bytes, table loads per in-bound point, replay leg)
+    spec = [(("neus_encode_levels", "neus_point"),
+             "forward = neus_encode_levels_kernel (11 hashed levels, level-major, XCD-consecutive) + neus_point_kernel (dense "
+             "levels + SDF linear + analytic gradient + alpha + colour MLP on MFMA)", 524.0 * pts, 128, "round5_forward_gathers_ms"),
+            (("neus_encode_levels",), "neus_encode_levels_kernel (8 gathers per hashed level and point -> 16-byte records)",
+             (352.0 + 8.0) * pts, 88, "level_major_hashed"),
+            (("neus_point",), "neus_point_kernel (streams the records; dense-level gathers, SDF layer, alpha, colour MLP)",
+             (160.0 + 12.0) * pts, 40, "point_major_dense"),
+            (("neus_backward_points_binned",), "neus_point_bwd_kernel<binned, aux> (streams the forward's per-level records, "
+             "table-gradient records = pass 1 of bin-and-reduce)", 1036.0 * pts, 0, None),
+            (("grid_bin_reduce",), "grid_bin_reduce_kernel (pass 2: exact integer LDS sums per 8192-entry bin)",
+             6.0 * 88.0 * pts + nh * (1 << 19) * 4.0 * 2, 0, None),
+            (("mlp_backward",), "neus_mlp_bwd_kernel (fused colour-MLP backward, MFMA)", (160.0 + 12.0 + 6.0 + 160.0) * pts, 0, None)]
     out = []
-    for key, name, nbytes, gathers in spec:
-        if key not in t or t[key][1] == 0:
+    for keys, name, nbytes, loads, leg in spec:
+        if any(k not in t or t[k][1] == 0 for k in keys):
             continue
-        us = 1e3 * t[key][0] / t[key][1]
+        us = sum(1e3 * t[k][0] / t[k][1] for k in keys)
         gbs = nbytes / (us * 1e-6) / 1e9
+        traffic = [pmc.get(k) for k in keys]
         ent = {"kernel": name + f" @ {n_rays} rays x 72 samples", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes, "kernel_avg_us": us,
-               "launches_timed": t[key][1], "traffic": pmc.get(key),
-               "traffic_source": "profiles/r04_pmc_neus.json (committed PMC passes)" if pmc.get(key) else None}
-        if gathers:
-            rate = pts * 128.0 / (us * 1e-6) / 1e9
-            ent["gather_rate_Ggathers_per_s"] = rate
-            if ceil_:
-                ent["gather_ceiling"] = ceil_
-                ent["gather_frac_of_corner8_ceiling"] = rate / ceil_["corner8_Ggathers_per_s"]
+               "launches_timed": t[keys[0]][1], "traffic": sum(traffic) if all(v is not None for v in traffic) else None,
+               "traffic_source": "profiles/r05_pmc_neus.json (committed PMC passes)" if all(v is not None for v in traffic) else None}
+        if loads:
+            ent["gather_rate_Ggathers_per_s"] = inb * float(loads) / (us * 1e-6) / 1e9
+            if ceil_ and leg:
+                rep_ms = ceil_[leg] if isinstance(ceil_[leg], float) else ceil_[leg]["ms"]
+                ent["gather_only_replay_us"] = rep_ms * 1e3
+                ent["gather_frac_of_replay"] = rep_ms * 1e3 / us
+                ent["gather_ceiling_source"] = ceil_["source"]
         out.append(ent)
     step_us = 1e3 * sum(v[0] for v in t.values()) / steps
     return out, {"library_kernels_us_per_step": step_us,
@@ -546,6 +606,38 @@ def conv_roofline(device, E, ht, wd):
            "kernel_us_per_update": ms_sum * 1e3, "layers": layers}
     out.update(pmc_traffic("r03_pmc_conv3x3_pp.json"))
     return out
+
+
+def summary(line):
+    """The headline number of every leg, compact, as the line's last key (a driver that keeps only the tail of stdout
+    still shows them)."""
+    def g(d, *ks):
+        for k in ks:
+            d = d.get(k) if isinstance(d, dict) else None
+        return round(d, 4) if isinstance(d, float) else d
+    pm = {}
+    for ent in line.get("roofline_other", []):
+        k = ent.get("kernel", "")
+        for tag, key in (("forward = ", "fwd"), ("neus_point_bwd_kernel", "bwd1"), ("grid_bin_reduce", "binred"),
+                         ("neus_mlp_bwd", "mlpbwd")):
+            if k.startswith(tag) and "kernel_avg_us" in ent:
+                rays = "32768" if "32768" in k else "4096"
+                pm[f"{key}@{rays}"] = [round(ent["kernel_avg_us"], 1), round(ent["frac"], 3),
+                                       round(ent.get("gather_frac_of_replay", 0.0), 3) or None]
+    return {"keyframes_per_s": g(line, "value"), "ms_per_keyframe": g(line, "ms_per_step"),
+            "conv3x3_frac_of_mfma_peak": g(line, "roofline", "frac"),
+            "neus_render_rays_per_s": g(line, "neus_render", "value"),
+            "neus_train_32768": [g(line, "neus_train", "ms_per_step"), g(line, "neus_train", "value")],
+            "neus_train_4096_per_gpu": [g(line, "neus_train_weak", "ms_per_step"), g(line, "neus_train_weak", "value")],
+            "exchange_ms": [g(line, "neus_train", "exchange_exposed_ms"), g(line, "neus_train_weak", "exchange_exposed_ms")],
+            "pathM_kernels_[us,frac_hbm,frac_replay]": pm,
+            "ba_2iter_ms": g(line, "breakdown_ms", "ba_2iter_ms"),
+            "mono_window": [g(line, "mono_window", "keyframes_per_s"), g(line, "mono_window", "ba_2iter_ms")],
+            "stress_step_ms": g(line, "global_ba_stress", "update_lowmem_step_ms"),
+            "altcorr_[ms_per_step,frac_vector_roof]": [g(line, "global_ba_stress", "altcorr_roofline", "kernel_ms_per_step"),
+                                                        g(line, "global_ba_stress", "altcorr_roofline", "frac_of_fp32_vector_roof_157TF")],
+            "motion_filter_frame_ms": g(line, "breakdown_ms", "motion_filter_frame_ms"),
+            "n_gpus": line.get("n_gpus"), "rccl_ranks": line.get("rccl_ranks")}
 
 
 def free_port():
@@ -743,6 +835,10 @@ def main():
                 line["cpu_baseline"].update(cpu_baseline_neus())
             except Exception as exc:
                 line["cpu_baseline"]["neus_error"] = repr(exc)
+        st = line.get("global_ba_stress") or {}
+        if "altcorr_roofline" in st:
+            line["roofline_other"].append(st["altcorr_roofline"])
+        line["summary"] = summary(line)         # LAST key: a reader of the line's tail sees every leg's headline number
         print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()

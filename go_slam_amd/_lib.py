@@ -39,6 +39,7 @@ SIGNATURES = {
     "gs_corr_level_elems": (c_size_t, [c_int] * 4),
     "gs_altcorr_backward": (c_int, [_P] * 6 + [c_int] * 8 + [_P]),
     "gs_altcorr_forward": (c_int, [_P] * 4 + [c_int] * 9 + [_P]),
+    "gs_altcorr_pyramid": (c_int, [_P] * 8 + [c_int] * 5 + [_P]),
     "gs_reproject": (c_int, [_P] * 7 + [c_int] * 3 + [_P]),
     "gs_projmap": (c_int, [_P] * 7 + [c_int] * 3 + [_P]),
     "gs_frame_distance": (c_int, [_P] * 6 + [c_int] * 3 + [c_float, _P]),

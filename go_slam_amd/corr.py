@@ -7,7 +7,7 @@
 import torch
 import torch.nn.functional as F
 
-from . import droid_backends
+from . import _lib, droid_backends
 
 
 class CorrBlock:
@@ -158,7 +158,41 @@ class AltCorrBlock:
             out.append(corr.float().view(B, N, S, -1, H, W).permute(0, 1, 3, 4, 5, 2))
         return torch.cat(out, dim=2)
 
+    def fused_supported(self, coords):
+        """shapes gs_altcorr_pyramid covers: the reference's configuration (fp16 pyramid of 128 channels, 4 levels, radius
+        3, one coordinate set per edge, batch 1) on maps of at least 8 x 8"""
+        p0 = self.pyramid[0]
+        return (p0.is_cuda and p0.dtype == torch.float16 and p0.shape[-1] == 128 and self.num_levels == 4
+                and self.radius == 3 and p0.shape[0] == 1 and coords.shape[0] == 1 and coords.dim() == 5
+                and min(p0.shape[2], p0.shape[3]) >= 8)
+
+    def lookup_fused(self, coords, ii, jj):
+        """All four levels of one chunk of edges in ONE launch (csrc/altcorr_pyramid.hip): coords f32 [1, E, H, W, 2], ii /
+        jj int64 [E] -> the [1, E, 196, H, W] features as an fp16 tensor in channels-last memory order -- what the update
+        operator's corr_encoder[0] reads, with no gather, scale, cast, permute or cat launch around the kernel."""
+        _, E, H, W, _ = coords.shape
+        dev = coords.device
+        out = torch.empty(E, H, W, 196, dtype=torch.float16, device=dev)
+        c = coords.detach().float().contiguous()
+        ii = ii.to(device=dev, dtype=torch.int64).contiguous()
+        jj = jj.to(device=dev, dtype=torch.int64).contiguous()
+        p = self.pyramid
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gs_altcorr_pyramid(_lib.ptr(p[0]), _lib.ptr(p[1]), _lib.ptr(p[2]), _lib.ptr(p[3]), _lib.ptr(c),
+                                               _lib.ptr(ii), _lib.ptr(jj), _lib.ptr(out), E, H, W, 128, self.radius,
+                                               _lib.stream_ptr(dev))
+        _lib.check(rc, "AltCorrBlock.lookup_fused")
+        return out.permute(0, 3, 1, 2)[None]
+
+    def lookup(self, coords, ii, jj):
+        """What FactorGraph.update_lowmem calls: the one-launch fp16 / channels-last result when the shapes allow it, else
+        `__call__`."""
+        if self.fused_supported(coords):
+            return self.lookup_fused(coords, ii, jj)
+        return self(coords, ii, jj)
+
     def __call__(self, coords, ii, jj):
+        """The reference's contract: a contiguous fp32 [B, N, 196, H, W(, S)] tensor."""
         squeeze = False
         if coords.dim() == 5:
             coords = coords.unsqueeze(-2)

@@ -26,6 +26,7 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (a native vector: what the non-temporal builtins take)
 
 // ---------------------------------------------------------------------------------------
 // sample placement
@@ -449,6 +450,68 @@ __device__ __forceinline__ bool point_of(const NeusArgs& A, int idx, float pt[3]
   return (pt[0] < rb[1]) && (pt[0] > rb[0]) && (pt[1] < rb[3]) && (pt[1] > rb[2]) && (pt[2] < rb[5]) && (pt[2] > rb[4]);
 }
 
+// normalized_3d_coordinate (InstantNeuS.py:12-32) with the STATIC bound, clamped to [-1,1]; `view` = the grid's [0,1] input
+__device__ __forceinline__ void normalise_point(const NeusArgs& A, const float pt[3], float p[3], float view[3],
+                                                float inside[3], float span[3]) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    span[d] = A.bound[2 * d + 1] - A.bound[2 * d];
+    float q = (pt[d] - A.bound[2 * d]) / span[d] * 2.0f - 1.0f;
+    inside[d] = (q >= -1.0f && q <= 1.0f) ? 1.0f : 0.0f;
+    q = fminf(fmaxf(q, -1.0f), 1.0f);
+    p[d] = q;
+    view[d] = (q + 1.0f) / 2.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// LEVEL-MAJOR encode of the hashed levels (round 5).  The 11 hashed levels are 2 MB tables each (2^19 entries x 4 B);
+// a point-major kernel walks all 16 levels per point, so every XCD streams the whole 25 MB table through its 4 MB L2
+// and half of the gathers miss (profiles/r04_pmc_neus.json: 57.5 M line misses per 32768-ray launch, 64 B moved for 4-8
+// useful: 3.1x the algorithmic traffic).  Here a work item is (hashed level, 256-point chunk) and the launch order makes
+// EVERY XCD work through its own eighth of the chunks ONE LEVEL AT A TIME (block b runs on XCD b % 8 -- observed, used for
+// speed only: any placement gives the same records): the level's 2 MB stay in that XCD's L2 while its chunks pass, and
+// the misses shrink to the compulsory 2 MB per level and XCD.  Per (level, in-bound point) the kernel leaves ONE 16-byte
+// record [enc0, enc1 (fp16) | this level's contribution to d sdf / d view (3 x fp32)], written with non-temporal stores so
+// that the stream does not evict the table; neus_point_kernel consumes the records in level order with the same
+// arithmetic as before (the SDF linear layer is evaluated from the same fp16 encodings in the same order: sdf is
+// bit-identical; the gradient sums one rounded fma chain per level instead of one chain over all levels).
+// Training: the backward's record [enc0, enc1, d enc / dx (6)] fp16 (enc_aux) is written here as well.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void neus_encode_levels_kernel(NeusArgs A, gs_grid_meta m, u32x4* __restrict__ rec,
+                                                                 _Float16* __restrict__ enc_aux, int first_hashed,
+                                                                 int chunks_per_xcd) {
+  const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int g = j / chunks_per_xcd, ci = j - g * chunks_per_xcd;
+  const int l = first_hashed + g;
+  const int idx = (ci * 8 + x) * 256 + threadIdx.x;
+  const int np = A.n * A.s;
+  if (idx >= np) return;
+  float pt[3], dir[3], zm, dist;
+  if (!point_of(A, idx, pt, dir, zm, dist)) return;      // (out-of-bound points have no record: nobody reads one)
+  float p[3], view[3], inside[3], span[3];
+  normalise_point(A, pt, p, view, inside, span);
+  float val[2], dv[3][2];
+  grid_level(m, l, A.grid, view, val, dv, true);
+  typedef const __attribute__((address_space(4))) float* cfp;    // uniform, unchanged during the launch -> s_load
+  cfp wl = (cfp)(uintptr_t)(A.sdf_w + 3 + 2 * l);
+  const float g0 = (float)(_Float16)wl[0], g1 = (float)(_Float16)wl[1];     // dL/d enc arrives as fp16
+  u32x4 r;
+  r.x = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)val[0]) |
+        ((uint32_t)__builtin_bit_cast(unsigned short, (_Float16)val[1]) << 16);
+  r.y = __float_as_uint(fmaf(g1, dv[0][1], g0 * dv[0][0]));
+  r.z = __float_as_uint(fmaf(g1, dv[1][1], g0 * dv[1][0]));
+  r.w = __float_as_uint(fmaf(g1, dv[2][1], g0 * dv[2][0]));
+  __builtin_nontemporal_store(r, rec + (size_t)g * (size_t)np + idx);
+  if (enc_aux) {
+    half8 a;
+    a[0] = (_Float16)val[0]; a[1] = (_Float16)val[1];
+    a[2] = (_Float16)dv[0][0]; a[3] = (_Float16)dv[1][0]; a[4] = (_Float16)dv[2][0];
+    a[5] = (_Float16)dv[0][1]; a[6] = (_Float16)dv[1][1]; a[7] = (_Float16)dv[2][1];
+    __builtin_nontemporal_store(a, reinterpret_cast<half8*>(enc_aux + ((size_t)l * (size_t)np + idx) * 8));
+  }
+}
+
 // Since round 4 the colour MLP runs in this kernel's tail (wave_mlp64): the 80-wide input row of every point goes into a
 // wave-private LDS tile and the wave evaluates its 64 points on the matrix cores -- at render time the rows never reach
 // HBM (47 MB written + read per 4096-ray batch before) and a launch is gone; the training path still saves them
@@ -467,7 +530,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     NeusArgs A, gs_grid_meta m, uint8_t* __restrict__ flags, int force_pass, float* __restrict__ sdf_out,
     float* __restrict__ zmid_out, float* __restrict__ alpha_out, float* __restrict__ grad_out,
     uint8_t* __restrict__ mask_out, _Float16* __restrict__ mlp_in, _Float16* __restrict__ enc_aux,
-    const _Float16* __restrict__ mlp_w, _Float16* __restrict__ rgb_out) {
+    const _Float16* __restrict__ mlp_w, _Float16* __restrict__ rgb_out, const u32x4* __restrict__ rec, int first_hashed) {
+  // `rec` != nullptr: the hashed levels (l >= first_hashed) were encoded level-major by neus_encode_levels_kernel -- this
+  // kernel streams their 16-byte records and gathers only the dense levels (2 MB in all, L2-resident, a wave's 64
+  // consecutive samples of a ray share most cells).  rec == nullptr (the one-workgroup force pass, whose points were out of
+  // bound and have no records): every level is gathered here.
   __shared__ __attribute__((aligned(16))) _Float16 xs_all[4 * 64 * XS];
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const int np = A.n * A.s;
@@ -522,17 +589,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int q = 0; q < 10; ++q) xrow[q] = zero;
   } else {
-    // normalized_3d_coordinate (InstantNeuS.py:12-32) with the STATIC bound, clamped to [-1,1]
     float p[3], view[3], inside[3], span[3];
-  #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      span[d] = A.bound[2 * d + 1] - A.bound[2 * d];
-      float q = (pt[d] - A.bound[2 * d]) / span[d] * 2.0f - 1.0f;
-      inside[d] = (q >= -1.0f && q <= 1.0f) ? 1.0f : 0.0f;
-      q = fminf(fmaxf(q, -1.0f), 1.0f);
-      p[d] = q;
-      view[d] = (q + 1.0f) / 2.0f;
-    }
+    normalise_point(A, pt, p, view, inside, span);
     // Linear(35 -> 32): xyz part first, then one level (2 inputs) at a time
     float out[32];
   #pragma unroll
@@ -545,23 +603,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     float gview[3] = {0.f, 0.f, 0.f};
   #pragma unroll 1
     for (int l = 0; l < GS_GRID_LEVELS; ++l) {
-      float val[2], dv[3][2];
-      grid_level(m, l, A.grid, view, val, dv, true);
-      const float e0 = (float)(_Float16)val[0], e1 = (float)(_Float16)val[1];   // encoding output is fp16
-      if (enc_aux) {    // training: what the backward needs of this level's 8 corner values -- the encoding and d enc / d x --
-                        // as one 16-byte record [level][point][8], so that it streams them instead of gathering again
-        half8 rec;
-        rec[0] = (_Float16)val[0]; rec[1] = (_Float16)val[1];
-        rec[2] = (_Float16)dv[0][0]; rec[3] = (_Float16)dv[1][0]; rec[4] = (_Float16)dv[2][0];
-        rec[5] = (_Float16)dv[0][1]; rec[6] = (_Float16)dv[1][1]; rec[7] = (_Float16)dv[2][1];
-        *reinterpret_cast<half8*>(enc_aux + ((size_t)l * ((size_t)A.n * A.s) + idx) * 8) = rec;
-      }
       const float* wl = A.sdf_w + 3 + 2 * l;
+      float e0, e1;
+      if (rec && l >= first_hashed) {     // (uniform) encoded level-major: one coalesced 16-byte load per point
+        const u32x4 r = __builtin_nontemporal_load(rec + (size_t)(l - first_hashed) * (size_t)np + idx);
+        e0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(r.x & 0xffffu));
+        e1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(r.x >> 16));
+        gview[0] += __uint_as_float(r.y); gview[1] += __uint_as_float(r.z); gview[2] += __uint_as_float(r.w);
+      } else {
+        float val[2], dv[3][2];
+        grid_level(m, l, A.grid, view, val, dv, true);
+        e0 = (float)(_Float16)val[0]; e1 = (float)(_Float16)val[1];             // encoding output is fp16
+        if (enc_aux) {  // training: what the backward needs of this level's 8 corner values -- the encoding and d enc / d x --
+                        // as one 16-byte record [level][point][8], so that it streams them instead of gathering again
+          half8 a;
+          a[0] = (_Float16)val[0]; a[1] = (_Float16)val[1];
+          a[2] = (_Float16)dv[0][0]; a[3] = (_Float16)dv[1][0]; a[4] = (_Float16)dv[2][0];
+          a[5] = (_Float16)dv[0][1]; a[6] = (_Float16)dv[1][1]; a[7] = (_Float16)dv[2][1];
+          *reinterpret_cast<half8*>(enc_aux + ((size_t)l * (size_t)np + idx) * 8) = a;
+        }
+        const float g0 = (float)(_Float16)wl[0], g1 = (float)(_Float16)wl[1];   // dL/d enc arrives as fp16
+  #pragma unroll
+        for (int d = 0; d < 3; ++d) gview[d] += fmaf(g1, dv[d][1], g0 * dv[d][0]);      // (as the level-major records)
+      }
   #pragma unroll
       for (int o = 0; o < 32; ++o) out[o] = fmaf(wl[o * 35 + 1], e1, fmaf(wl[o * 35], e0, out[o]));
-      const float g0 = (float)(_Float16)wl[0], g1 = (float)(_Float16)wl[1];     // dL/d enc arrives as fp16
-  #pragma unroll
-      for (int d = 0; d < 3; ++d) gview[d] = fmaf(g1, dv[d][1], fmaf(g0, dv[d][0], gview[d]));
     }
   #pragma unroll
     for (int o = 0; o < 32; ++o) out[o] = out[o] + A.sdf_b[o];
@@ -922,7 +988,7 @@ extern "C" int gs_mlp_forward(const void* x, const void* mlp, void* out, int n, 
 
 namespace {
 struct NeusWs {
-  uint8_t* flags; float* alpha; float* grad; uint8_t* mask; _Float16* mlp_in; _Float16* rgb; size_t total;
+  uint8_t* flags; float* alpha; float* grad; uint8_t* mask; _Float16* mlp_in; _Float16* rgb; u32x4* rec; size_t total;
 };
 NeusWs carve_neus(void* base, int n, int s) {
   NeusWs w;
@@ -935,6 +1001,7 @@ NeusWs carve_neus(void* base, int n, int s) {
   w.mask = (uint8_t*)take(np);
   w.mlp_in = (_Float16*)take(np * 80 * 2);
   w.rgb = (_Float16*)take(np * 3 * 2 + 64);
+  w.rec = (u32x4*)take(np * 16 * GS_GRID_LEVELS);       // level-major records of the hashed levels (<= 16 levels x 16 B)
   w.total = off;
   return w;
 }
@@ -981,14 +1048,25 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
   _Float16* rgb = rgb_out ? (_Float16*)rgb_out : ws.rgb;
   if (mask_out) ws.mask = mask_out;
   GS_TIMING_PRE();
+  // level-major encode of the hashed levels (records in the workspace), then the per-point stage
+  const gs_grid_meta meta = host_meta();
+  int first_hashed = GS_GRID_LEVELS;
+  for (int l = GS_GRID_LEVELS - 1; l >= 0 && meta.hashed[l]; --l) first_hashed = l;      // (the hashed levels are the finest)
+  const int nh = GS_GRID_LEVELS - first_hashed;
+  if (nh > 0) {
+    const int cpx = gs_cdiv(gs_cdiv(np, 256), 8);
+    neus_encode_levels_kernel<<<8 * cpx * nh, 256, 0, st>>>(A, meta, ws.rec, (_Float16*)enc_aux_out, first_hashed, cpx);
+    GS_CHECK_LAUNCH("neus_encode_levels");
+  }
   // (the colour MLP runs in the point kernel's tail; the MLP input rows reach memory only when the caller saves them)
-  neus_point_kernel<<<gs_cdiv(np, 256), 256, 0, st>>>(A, host_meta(), ws.flags, 0, sdf, z_mid, alpha, grad,
+  neus_point_kernel<<<gs_cdiv(np, 256), 256, 0, st>>>(A, meta, ws.flags, 0, sdf, z_mid, alpha, grad,
                                                       ws.mask,
                                                       (_Float16*)mlp_in_out, (_Float16*)enc_aux_out, (const _Float16*)mlp,
-                                                      rgb);
+                                                      rgb, nh > 0 ? ws.rec : nullptr, first_hashed);
   GS_CHECK_LAUNCH("neus_point");
-  neus_point_kernel<<<1, 128, 0, st>>>(A, host_meta(), ws.flags, 1, sdf, z_mid, alpha, grad, ws.mask,   // points 0..127
-                                       (_Float16*)mlp_in_out, (_Float16*)enc_aux_out, (const _Float16*)mlp, rgb);
+  neus_point_kernel<<<1, 128, 0, st>>>(A, meta, ws.flags, 1, sdf, z_mid, alpha, grad, ws.mask,   // points 0..127
+                                       (_Float16*)mlp_in_out, (_Float16*)enc_aux_out, (const _Float16*)mlp, rgb, nullptr,
+                                       first_hashed);
   GS_CHECK_LAUNCH("neus_force100");
   neus_ray_kernel<<<gs_cdiv(n, 4), 256, 0, st>>>(alpha, rgb, z_mid, grad, ws.mask, color, depth, depth_var, normal,
                                                    weight_sum, grad_err_ray, grad_err_scale, sdf_variance_out,

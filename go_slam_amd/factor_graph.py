@@ -478,6 +478,7 @@ class FactorGraph:
         fm = self.video.fmaps[:cur_t + 2]
         num, rig, ch, ht, wd = fm.shape
         corr_op = AltCorrBlock(fm.reshape(1, num * rig, ch, ht, wd))
+        lookup = getattr(corr_op, "lookup", corr_op)     # (all four levels in one launch, fp16 channels-last features)
         idx = self._lowmem_index(t0, t1, rig)
         t0, t1 = idx["t0"], idx["t1"]
         ii_all, jj_all = idx["ii"], idx["jj"]
@@ -488,7 +489,7 @@ class FactorGraph:
             for ck in idx["chunks"]:                    # 13 source keyframes at a time
                 sel, iis, jjs = ck["sel"], ck["ii"], ck["jj"]
                 c1 = coords1.index_select(1, sel)
-                corr1 = corr_op(c1, ck["corr_ii"], ck["corr_jj"])
+                corr1 = lookup(c1, ck["corr_ii"], ck["corr_jj"])
                 with torch.autocast("cuda", dtype=torch.float16):
                     net, delta, weight, damping, upmask = self.update_op(
                         self._select_edges(self.net, sel), ck["inp"](), corr1, motion.index_select(1, sel), iis, jjs,

@@ -51,15 +51,63 @@ def reduce_scatter_sum_(out, inp, group=None):
     return out
 
 
-def all_gather_into_(full, part, group=None):
-    """full = concatenation over ranks of `part` (in place when `part` is this rank's slice of `full`)"""
+def all_gather_into_(full, part, group=None, async_op=False):
+    """full = concatenation over ranks of `part` (in place when `part` is this rank's slice of `full`).  `async_op`: the
+    collective is only ENQUEUED (on RCCL's own stream, behind what the current stream has issued so far); the returned
+    callable makes the current stream wait for it -- kernels launched in between run beside the transfer."""
     if _gloo_on_device(full, group):
         h = torch.empty(full.shape, dtype=full.dtype)
-        dist.all_gather_into_tensor(h, part.cpu(), group=group)
+        work = dist.all_gather_into_tensor(h, part.cpu(), group=group, async_op=async_op)
+        if async_op:
+            def finish():
+                work.wait()
+                full.copy_(h)
+            return finish
         full.copy_(h)
         return full
-    dist.all_gather_into_tensor(full, part, group=group)
-    return full
+    work = dist.all_gather_into_tensor(full, part, group=group, async_op=async_op)
+    return work.wait if async_op else full
+
+
+class ExchangeTimer:
+    """Events on the step's stream around the sharded optimiser's collectives (FlatAdamW.step marks them when a timer is
+    attached): the time the compute stream spends BLOCKED on an exchange -- reduce-scatter + dense all-reduce (rs0..rs1),
+    the clip norm's scalar all-reduce (n0..n1) and the wait for the table all-gather (agw0..agw1; with the deferred
+    all-gather that wait sits at the head of the NEXT step, behind the host-side preparation it overlaps with).  What a
+    multi-GPU bench line reports next to the step time so that a scaling run diagnoses itself."""
+
+    PAIRS = (("rs0", "rs1", "reduce_scatter_and_dense_allreduce"), ("n0", "n1", "clip_norm_allreduce"),
+             ("agw0", "agw1", "all_gather_wait"))
+
+    def __init__(self, device):
+        self.device = device
+        self.marks = []
+
+    def mark(self, name, at=None):
+        if at is not None:                          # alias of an event already recorded
+            ev = next(e for n, e in reversed(self.marks) if n == at)
+        else:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+        self.marks.append((name, ev))
+
+    def reset(self):
+        self.marks = []
+
+    def exposed_ms(self):
+        """{phase: total ms the stream was blocked in it} over everything marked since reset()"""
+        torch.cuda.synchronize(self.device)
+        out = {k: 0.0 for _, _, k in self.PAIRS}
+        for a, b, key in self.PAIRS:
+            start = None
+            for n, e in self.marks:
+                if n == a:
+                    start = e
+                elif n == b and start is not None:
+                    out[key] += start.elapsed_time(e)
+                    start = None
+        out["total"] = sum(out.values())
+        return out
 
 
 class _MapLossFn(torch.autograd.Function):

@@ -129,6 +129,9 @@ class FlatAdamW:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.hyper = dict(lr16=grid_lr, lr32=net_lr, b1=betas[0], b2=betas[1], eps=eps, wd=weight_decay, max_norm=max_norm)
         self.steps = 0
+        self.overlap_gather = True          # world > 1: the all-gather of the updated table is waited for by its next reader
+        self._gather_wait = None
+        self._exchange_timer = None         # bench.py: ExchangeTimer (events around the collectives on the step's stream)
         self._publish()
 
     # the reference's mapper scales its learning rates per iteration (src/mapping.py: lr_factor) through param_groups
@@ -182,23 +185,60 @@ class FlatAdamW:
             self.sqnorm.zero_()
         dense = (self.P[self.n16p:], self.M[self.slice:], self.V[self.slice:], self.P16[self.n16p:], self.g32[:nd])
         if self.world > 1:
+            self.wait_gather()
+            t = self._exchange_timer
+            if t is not None:
+                t.mark("rs0")
             reduce_scatter_sum_(self.g16s, self.G16, self.group)
             all_reduce_sum_(self.g32, self.group)
+            if t is not None:
+                t.mark("rs1")
             K.sqnorm(self.sqnorm, self.g16s, inv_scale16, self.g32[:nd] if self.rank == 0 else None)
+            if t is not None:
+                t.mark("n0")
             all_reduce_sum_(self.sqnorm, self.group)
+            if t is not None:
+                t.mark("n1")
             K.adamw(self.P[self.lo:self.hi], self.M[:self.slice], self.V[:self.slice], self.P16[self.lo:self.hi],
                     self.g16s, inv_scale16, *dense, h, self.steps, self.step_dev, self.sqnorm)
-            all_gather_into_(self.P16[:self.n16p], self.P16[self.lo:self.hi], self.group)
+            # the updated fp16 table travels while the host prepares the next step (input copies, the batch's counts):
+            # the all-gather is only enqueued here; whoever reads the table next -- the next step (wait_gather), a render
+            # between steps (the cache's `_pending` hook), sync_master -- waits for it first.  No other collective is
+            # issued in between, so every rank enqueues the same sequence on the one communicator.
+            if t is not None:
+                t.mark("agq")
+            self._gather_wait = all_gather_into_(self.P16[:self.n16p], self.P16[self.lo:self.hi], self.group,
+                                                 async_op=self.overlap_gather)
+            if not self.overlap_gather:
+                self._gather_wait = None
+                if t is not None:
+                    t.mark("agw0", at="agq")
+                    t.mark("agw1")
         else:
             K.sqnorm(self.sqnorm, self.G16, inv_scale16, self.g32[:nd])
             K.adamw(self.P[:self.n16p], self.M[:self.slice], self.V[:self.slice], self.P16[:self.n16p], self.G16,
                     inv_scale16, *dense, h, self.steps, self.step_dev, self.sqnorm)
         self._publish()
+        if self._gather_wait is not None:
+            self.grid_module._half._pending = self.wait_gather
+
+    def wait_gather(self):
+        """make the current stream wait for the deferred all-gather of the fp16 table (no-op when none is in flight)"""
+        w, self._gather_wait = self._gather_wait, None
+        self.grid_module._half._pending = None
+        if w is not None:
+            t = self._exchange_timer
+            if t is not None:
+                t.mark("agw0")
+            w()
+            if t is not None:
+                t.mark("agw1")
 
     def sync_master(self):
         """all-gather the fp32 master slices so that every rank's `P` (= the modules' parameters, state_dict()) is whole"""
         if self.world > 1:
             from .distributed import all_gather_into_
+            self.wait_gather()
             all_gather_into_(self.P[:self.n16p], self.P[self.lo:self.hi], self.group)
 
     def collective_bytes(self):
@@ -328,31 +368,27 @@ class MapTrainer:
         return c(rays_o), c(rays_d), c(rays_color), c(rays_depth).reshape(-1)
 
     def _counts(self, rays_depth):
-        """None on a single rank (gs_map_step_prep computes them inside the step); otherwise
-        [valid rays, rays, max depth] over ALL ranks: the loss normalisers (means over VALID rays,
-        src/mapping.py:96-121) and the batch-wide depth maximum the sampler clamps with (src/render.py:121,140) -- one
-        small all-gather, reduced locally (sum, sum, max)."""
+        """None on a single rank (gs_map_step_prep computes them inside the step); otherwise [valid rays, rays, max
+        depth] over the WHOLE batch: the loss normalisers (means over VALID rays, src/mapping.py:96-121) and the
+        batch-wide depth maximum the sampler clamps with (src/render.py:121,140).  `rays_depth` is the GLOBAL batch's
+        depth column -- every rank is handed the same batch and renders its shard of it -- so the three numbers are
+        local reductions: no collective (and no collective latency) stands at the head of a step."""
         if self.world == 1:
             return None
-        dev = rays_depth.device
-        n = rays_depth.shape[0]
-        mx = rays_depth.max() if n else torch.zeros((), dtype=torch.float32, device=dev)
-        counts = torch.stack([(rays_depth > 0).sum().float(), torch.full((), float(n), dtype=torch.float32, device=dev),
-                              mx.float()])
-        if self.world > 1:
-            from .distributed import all_gather_into_
-            allc = torch.empty(self.world * 3, dtype=torch.float32, device=dev)
-            all_gather_into_(allc, counts, self.group)
-            allc = allc.view(self.world, 3)
-            counts = torch.cat([allc[:, :2].sum(0), allc[:, 2:].max(0).values])
-        return counts
+        rd = rays_depth.detach().float().reshape(-1)
+        dev = rd.device
+        n = rd.shape[0]
+        mx = rd.max() if n else torch.zeros((), dtype=torch.float32, device=dev)
+        return torch.stack([(rd > 0).sum().float(), torch.full((), float(n), dtype=torch.float32, device=dev), mx.float()])
 
     def fused_gradients(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand=None):
         """forward + loss + HIP backward without an autograd graph and WITHOUT the optimiser's collectives.  Returns
         (this rank's loss share, the rank-local table gradient in loss-scaled fp16, its inverse scale); the dense
         gradients are left in self.flat.g32.  (Tests / tools; `step_fused` is the production entry.)"""
+        counts = self._counts(rays_depth)
         rays_o, rays_d, rays_color, rays_depth = self._prepare(rays_o, rays_d, rays_color, rays_depth)
-        inv_scale = self._local_gradients(rays_o, rays_d, rays_color, rays_depth, perturb_rand, self._counts(rays_depth))
+        self.flat.wait_gather()
+        inv_scale = self._local_gradients(rays_o, rays_d, rays_color, rays_depth, perturb_rand, counts)
         self.flat.step_dev.sub_(1)          # (no optimiser step follows: undo gs_map_step_prep's step count)
         return self.flat.g32[self.flat.nd].clone(), self.flat.G16[:self.flat.n16], inv_scale
 
@@ -379,9 +415,10 @@ class MapTrainer:
     def step_fused(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand=None):
         flat = self.flat
         flat.check_bindings()
+        counts = self._counts(rays_depth)
         args = self._prepare(rays_o, rays_d, rays_color, rays_depth)
-        counts = self._counts(args[3])
         if not self.graph or args[0].shape[0] == 0:
+            flat.wait_gather()
             inv_scale = self._local_gradients(*args, perturb_rand, counts)
             flat.step(inv_scale, prepped=True)
             return self._global_loss()
@@ -399,6 +436,7 @@ class MapTrainer:
             dsts.append(ent["pr"])
             srcs.append(perturb_rand.detach().float().contiguous())
         torch._foreach_copy_(dsts, srcs)    # ONE launch for the 4-6 input tensors (was a 4.4 us copy kernel each)
+        flat.wait_gather()                  # (world > 1) the previous step's table all-gather ran beside everything above
         whole = self.world == 1             # single GPU: the optimiser's two launches are part of the graph
 
         def body():

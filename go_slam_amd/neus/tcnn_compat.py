@@ -45,8 +45,13 @@ class _HalfCache:
 
     _key = None
     _val = None
+    _pending = None     # callable or None: completes an exchange that is still writing `_val` (FlatAdamW's deferred
+                        # all-gather of the updated fp16 table); every reader of the copy passes through get()
 
     def get(self, p):
+        if self._pending is not None:
+            pend, self._pending = self._pending, None
+            pend()
         key = (p.data_ptr(), p._version, p.device, p.dtype)
         if self._key != key:
             self._val = p.detach().to(torch.float16).contiguous()

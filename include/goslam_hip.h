@@ -115,6 +115,18 @@ int gs_altcorr_backward(const float* fmap1, const float* fmap2, const float* coo
                         float* fmap1_grad, float* fmap2_grad, int b, int s, int h1, int w1, int h2, int w2,
                         int c, int radius, gs_stream_t stream);
 
+/* AltCorrBlock.__call__ for one chunk of edges (src/modules/corr.py:95-145 as driven by FactorGraph.update_lowmem,
+ * src/factor_graph.py:283-300): all four pyramid levels of altcorr_forward (altcorr_kernel.cu:27-149) in ONE launch,
+ * features indexed by ii / jj inside the kernel (the reference gathers `pyramid[0][:, ii]`, `pyramid[i][:, jj]` per level)
+ * and coords / 2^l formed in registers.
+ *   pyr0..pyr3 f16 [N, h >> l, w >> l, c] channels-last (c = 128), coords f32 [e, h, w, 2], ii / jj i64 [e] (rows of the
+ *   pyramid) -> out f16 [e, h, w, 196] (= the [e,196,h,w] tensor of the reference in channels-last memory order;
+ *   channel = 49 l + 7 ix + iy).  fp16 products, fp32 accumulation and blend, one rounding: within half an fp16 ulp of
+ *   gs_altcorr_forward on fp16 features.  h, w >= 8.                                                         */
+int gs_altcorr_pyramid(const void* pyr0, const void* pyr1, const void* pyr2, const void* pyr3, const float* coords,
+                       const int64_t* ii, const int64_t* jj, void* out, int e, int h, int w, int c, int radius,
+                       gs_stream_t stream);
+
 /* ------------------------------------------------------------------- geometry ------ */
 
 /* DepthVideo.reproject -> pops.projective_transform(jacobian=False)

@@ -168,6 +168,12 @@ def _opt_run(rank, world, steps=3):
         flat.g32[flat.nd] = float(rank + 1)           # "loss" share: summed by the dense all-reduce
         flat.step(1.0 / 128.0)
     loss = float(flat.g32[flat.nd])
+    if world > 1:
+        # the all-gather of the updated fp16 table is DEFERRED: still in flight after step(), completed by its next reader
+        enc = model.sdf_network.encoding.encoding
+        assert flat._gather_wait is not None and enc._half._pending is not None
+        enc._half.get(enc.params)
+        assert flat._gather_wait is None and enc._half._pending is None
     stale = flat.P[:flat.n16].clone()
     flat.sync_master()
     named = {k: flat.P[a:b].clone() for k, (a, b) in flat.slices.items()}

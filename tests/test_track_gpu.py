@@ -482,6 +482,58 @@ def test_altcorr_block_matches_oracle_lookup(O, dev, built_lib):
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-3, atol=2e-3)
 
 
+def _smooth_coords(n, ht, wd, seed, stretch=0.15, shift=4.0):
+    """a reprojection-like flow: identity grid + per-edge shift + affine stretch + a low-frequency wobble"""
+    g = torch.Generator().manual_seed(seed)
+    ys, xs = torch.meshgrid(torch.arange(ht, dtype=torch.float32), torch.arange(wd, dtype=torch.float32), indexing="ij")
+    out = []
+    for _ in range(n):
+        a = 1.0 + stretch * (torch.rand(4, generator=g) - 0.5)
+        t = shift * torch.randn(2, generator=g)
+        x = a[0] * xs + 0.05 * (a[1] - 1) * ys + t[0] + 0.7 * torch.sin(ys / 5.0 + t[1])
+        y = a[2] * ys + 0.05 * (a[3] - 1) * xs + t[1] + 0.7 * torch.cos(xs / 6.0 + t[0])
+        out.append(torch.stack([x, y], -1))
+    return torch.stack(out)[None].contiguous()
+
+
+@pytest.mark.parametrize("case", ["smooth flow (matrix-core path)", "3 px of per-pixel noise (both paths)",
+                                  "ragged map 10x14 (partial tiles)", "wild coordinates (per-pixel path, nan / inf / 1e9)"])
+def test_altcorr_pyramid_one_launch_matches_oracle_and_the_per_level_kernel(O, dev, built_lib, case):
+    """AltCorrBlock.lookup = gs_altcorr_pyramid (all four levels, features indexed by ii / jj in the kernel, fp16
+    channels-last output) vs the oracle's restatement of corr.py:112-145 + altcorr_kernel.cu:27-149, and vs the per-level
+    gs_altcorr_forward path it replaces in update_lowmem (same fp16 features: at most one fp16 ulp apart)."""
+    from go_slam_amd.corr import AltCorrBlock
+    ht, wd = (10, 14) if case.startswith("ragged") else synth.SHAPES["Scan"][:2]
+    g = torch.Generator().manual_seed(143)
+    fm = (torch.randn(1, 5, 128, ht, wd, generator=g) * 1.5).half()
+    ii = torch.tensor([0, 1, 2, 4, 3, 1, 0, 2, 4])
+    jj = torch.tensor([1, 0, 4, 2, 3, 3, 4, 0, 1])              # nine edges: two rounds of the kernel's 8-edge XCD groups
+    if case.startswith("smooth") or case.startswith("ragged"):
+        coords = _smooth_coords(9, ht, wd, seed=144)
+    else:
+        coords = _rand_coords(9, ht, wd, ht, wd, seed=44, spread=3.0).permute(0, 2, 3, 1)[None].contiguous()
+    if case.startswith("wild"):
+        coords = coords * 3.0 - 20.0
+        coords[0, 0, 2, 3] = torch.tensor([1.0e9, -1.0e9])
+        coords[0, 1, 5, 5] = torch.tensor([float("inf"), 2.0])
+        coords[0, 2, 7, 1] = torch.tensor([float("nan"), 3.0])
+    ref = O.altcorr_lookup(O.altcorr_pyramid(fm), coords, ii, jj, 3)
+    blk = AltCorrBlock(fm.to(dev))
+    assert blk.fused_supported(coords.to(dev))
+    out = blk.lookup(coords.to(dev), ii.to(dev), jj.to(dev))
+    assert tuple(out.shape) == (1, 9, 196, ht, wd) and out.dtype == torch.float16
+    assert out[0].is_contiguous(memory_format=torch.channels_last)
+    per_level = blk(coords.to(dev), ii.to(dev), jj.to(dev))
+    torch.cuda.synchronize()
+    o, pl = out.float().cpu(), per_level.cpu()
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(o), fin) and torch.equal(torch.isfinite(pl), fin)
+    assert bool(fin.float().mean() > 0.99)
+    ulp = 2.0 ** -10 * ref.abs().clamp(min=1.0)
+    assert bool(((o - pl).abs()[fin] <= 1.01 * ulp[fin]).all()), float((o - pl).abs()[fin].max())
+    torch.testing.assert_close(o[fin], ref[fin], rtol=1e-3, atol=2e-3)
+
+
 @pytest.mark.parametrize("C", [64, 128])
 def test_altcorr_backward_matches_oracle(db, O, dev, C):
     """altcorr_backward (training path, fp32) vs autograd over the oracle's forward restatement; target
