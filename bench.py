@@ -501,7 +501,9 @@ def neus_kernel_rooflines(device, n_rays, steps=5):
     of forward records instead of gathering; the algorithmic count stays SURVEY's); the bin reduce reads the backward's
     record queues (6 B per record, 128 records per point at most) and writes the 11 hashed levels once.  `gather_rate` =
     table loads of the IN-BOUND points / kernel time, against the gather-only replay of the same index stream
-    (`gather_frac_of_replay` = replay time / kernel time <= 1 by construction of the comparator)."""
+    (`gather_frac_of_replay` = replay time / kernel time <= 1 by construction of the comparator).  Below the level-major
+    crossover (gs_neus_level_major_min_points: the 4096-ray batch) the forward is the point kernel alone, gathering every
+    level itself; its replay leg is then `point_major_16`."""
     import go_slam_amd.neus as neus
     from go_slam_amd import _lib
     from go_slam_amd.neus.mapper import MapTrainer
@@ -539,18 +541,29 @@ def neus_kernel_rooflines(device, n_rays, steps=5):
     spec = [(("neus_encode_levels", "neus_point"),
              "forward = neus_encode_levels_kernel (11 hashed levels, level-major, XCD-consecutive) + neus_point_kernel (dense "
              "levels + SDF linear + analytic gradient + alpha + colour MLP on MFMA)", 524.0 * pts, 128, "round5_forward_gathers_ms"),
+            (("neus_point", "!neus_encode_levels"),
+             "forward = neus_point_kernel alone (below the level-major crossover: all 16 levels gathered per point + SDF "
+             "linear + analytic gradient + alpha + colour MLP on MFMA)", 524.0 * pts, 128, "point_major_16"),
             (("neus_encode_levels",), "neus_encode_levels_kernel (8 gathers per hashed level and point -> 16-byte records)",
              (352.0 + 8.0) * pts, 88, "level_major_hashed"),
-            (("neus_point",), "neus_point_kernel (streams the records; dense-level gathers, SDF layer, alpha, colour MLP)",
+            (("neus_point", "?neus_encode_levels"), "neus_point_kernel (streams the records; dense-level gathers, SDF layer, alpha, colour MLP)",
              (160.0 + 12.0) * pts, 40, "point_major_dense"),
-            (("neus_backward_points_binned",), "neus_point_bwd_kernel<binned, aux> (streams the forward's per-level records, "
-             "table-gradient records = pass 1 of bin-and-reduce)", 1036.0 * pts, 0, None),
+            (("neus_backward_points_head", "neus_grid_scatter"),
+             "backward pass 1 = neus_point_bwd_head_kernel (per point: alpha chain, SDF layer, dense-gradient rows; streams "
+             "the forward's records) + neus_grid_scatter_kernel (level-major: corner contributions -> table-gradient "
+             "records of bin-and-reduce)", 1036.0 * pts, 0, None),
+            (("neus_backward_points_head",), "neus_point_bwd_head_kernel", (256.0 + 160.0 + 45.0 + 320.0 + 144.0) * pts, 0, None),
+            (("neus_grid_scatter",), "neus_grid_scatter_kernel", 16 * 32.0 * pts + 6.0 * 88.0 * pts, 0, None),
             (("grid_bin_reduce",), "grid_bin_reduce_kernel (pass 2: exact integer LDS sums per 8192-entry bin)",
              6.0 * 88.0 * pts + nh * (1 << 19) * 4.0 * 2, 0, None),
             (("mlp_backward",), "neus_mlp_bwd_kernel (fused colour-MLP backward, MFMA)", (160.0 + 12.0 + 6.0 + 160.0) * pts, 0, None)]
     out = []
     for keys, name, nbytes, loads, leg in spec:
-        if any(k not in t or t[k][1] == 0 for k in keys):
+        absent = [k[1:] for k in keys if k.startswith("!")]             # "!k": only when kernel k did NOT run
+        present = [k[1:] for k in keys if k.startswith("?")]            # "?k": only when k ran (its time is not added)
+        keys = tuple(k for k in keys if k[0] not in "!?")
+        ran = lambda k: k in t and t[k][1] > 0                          # noqa: E731
+        if not all(ran(k) for k in keys + tuple(present)) or any(ran(k) for k in absent):
             continue
         us = sum(1e3 * t[k][0] / t[k][1] for k in keys)
         gbs = nbytes / (us * 1e-6) / 1e9
@@ -618,7 +631,7 @@ def summary(line):
     pm = {}
     for ent in line.get("roofline_other", []):
         k = ent.get("kernel", "")
-        for tag, key in (("forward = ", "fwd"), ("neus_point_bwd_kernel", "bwd1"), ("grid_bin_reduce", "binred"),
+        for tag, key in (("forward = ", "fwd"), ("backward pass 1 = ", "bwd1"), ("grid_bin_reduce", "binred"),
                          ("neus_mlp_bwd", "mlpbwd")):
             if k.startswith(tag) and "kernel_avg_us" in ent:
                 rays = "32768" if "32768" in k else "4096"

@@ -76,6 +76,7 @@ SIGNATURES = {
     "gs_ba_ex": (c_int, [_P] * 9 + [c_int] * 3 + [c_float, c_float] + [c_int] * 6 + [_P, _P, _P, _P, c_size_t, c_int, _P]),
     # include/goslam_neus.h
     "gs_grid_meta_default": (c_int, [_P]),
+    "gs_neus_level_major_min_points": (c_int, [c_int]),
     "gs_render_sample": (c_int, [_P] * 7 + [c_float, _P, _P, _P] + [c_int] * 3 + [_P]),
     "gs_grid_encode": (c_int, [_P] * 4 + [c_int, _P]),
     "gs_grid_backward": (c_int, [_P, _P, _P, c_int, c_float, _P, _P, c_int, c_float, _P, _P, c_int, _P]),

@@ -1007,6 +1007,17 @@ NeusWs carve_neus(void* base, int n, int s) {
 }
 }  // namespace
 
+// crossover of the two gather orders, in sample points (gs_neus_level_major_min_points sets it: tests run both orders on
+// small batches, tools measure the crossover)
+#include <atomic>
+static std::atomic<int> g_level_major_min_points{768 * 1024};
+static int level_major_min_points() { return g_level_major_min_points.load(std::memory_order_relaxed); }
+extern "C" int gs_neus_level_major_min_points(int points) {
+  const int old = g_level_major_min_points.load(std::memory_order_relaxed);
+  if (points >= 0) g_level_major_min_points.store(points, std::memory_order_relaxed);
+  return old;
+}
+
 extern "C" size_t gs_neus_forward_workspace_bytes(int n, int s) {
   if (n < 0 || s < 0) return 0;
   return carve_neus(nullptr, n, s).total + 256;
@@ -1052,7 +1063,13 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
   const gs_grid_meta meta = host_meta();
   int first_hashed = GS_GRID_LEVELS;
   for (int l = GS_GRID_LEVELS - 1; l >= 0 && meta.hashed[l]; --l) first_hashed = l;      // (the hashed levels are the finest)
-  const int nh = GS_GRID_LEVELS - first_hashed;
+  int nh = GS_GRID_LEVELS - first_hashed;
+  // Level-major pays where the table traffic is the bound: measured on MI355X (profiles/r05_*), 32768 rays x 72 samples:
+  // 1149 -> 993 us, gathers 1.07 -> 0.51 ms in the gather-only replay; at 4096 rays a level's chunks do not even fill
+  // one residency round per XCD, both forms are latency-bound (replay 131 vs 71 us) and the extra launch + the record
+  // round trip cost more than the misses (160 -> 174 us).  Below GS_LEVEL_MAJOR_MIN_POINTS the point kernel gathers
+  // every level itself (rec == nullptr), as the one-workgroup force pass always does.
+  if (np < level_major_min_points()) nh = 0;
   if (nh > 0) {
     const int cpx = gs_cdiv(gs_cdiv(np, 256), 8);
     neus_encode_levels_kernel<<<8 * cpx * nh, 256, 0, st>>>(A, meta, ws.rec, (_Float16*)enc_aux_out, first_hashed, cpx);

@@ -270,10 +270,22 @@ def N(built_lib):
     return neus
 
 
+@pytest.fixture
+def gather_order(request):
+    """run a test with the hashed levels gathered per point (the small-batch order) or LEVEL-MAJOR (the order batches of
+    >= 786432 points take: neus_encode_levels_kernel + records) whatever the batch size"""
+    from go_slam_amd import _lib
+    L = _lib.lib()
+    old = L.gs_neus_level_major_min_points(0 if request.param == "level-major" else 1 << 30)
+    yield request.param
+    L.gs_neus_level_major_min_points(old)
+
+
+@pytest.mark.parametrize("gather_order", ["per-point", "level-major"], indirect=True)
 @pytest.mark.parametrize("grid_init", [0.3, 1e-4])
-def test_neus_forward_at_4096_rays_matches_oracle(N, NO, dev, grid_init):
+def test_neus_forward_at_4096_rays_matches_oracle(N, NO, dev, grid_init, gather_order):
     """Renderer.sample + InstantNeuS.forward (src/render.py:99-171, src/InstantNeuS.py:295-370) on ONE 4096-ray x 72
-    sample batch -- 294,912 points -- against the CPU oracle: all 9 outputs, in-bound masks exact."""
+    sample batch -- 294,912 points -- against the CPU oracle: all 9 outputs, in-bound masks exact; in both gather orders."""
     P = NO.make_params(71, grid_init=grid_init)                         # bound [-5, 5]^3 (room0.yaml:4)
     P["rt_bound"] = torch.tensor([[-4.2, 4.6], [-4.4, 4.1], [-3.9, 4.4]])
     o, d, gt, _, pr = _bench_rays(4096, seed=72)
@@ -302,13 +314,14 @@ def test_neus_forward_at_4096_rays_matches_oracle(N, NO, dev, grid_init):
     torch.testing.assert_close(c["normal"], ref["normal"], rtol=2e-3, atol=2e-3)
     torch.testing.assert_close(c["gradient_error"], ref["gradient_error"], rtol=2e-3, atol=1e-5)
     torch.testing.assert_close(c["sdf_variance"], ref["sdf_variance"])
-    _record(f"forward_4096_grid{grid_init:g}", {
+    _record(f"forward_4096_grid{grid_init:g}_{gather_order}", {
         "points_in_bound": n_in,
         "max_abs": {k: float((c[k] - ref[k]).abs().max()) for k in ("sdf", "color", "depth", "normal", "weight_sum")}})
 
 
+@pytest.mark.parametrize("gather_order", ["per-point", "level-major"], indirect=True)
 @pytest.mark.parametrize("grad_dtype", [torch.float16, torch.float32])
-def test_training_gradients_at_4096_rays_match_autograd_oracle(N, NO, dev, grad_dtype):
+def test_training_gradients_at_4096_rays_match_autograd_oracle(N, NO, dev, grad_dtype, gather_order):
     """Mapper loss (src/mapping.py:96-132) -> gradient of every trained parameter at the reference's batch size,
     HIP backward vs torch.autograd on the differentiable CPU restatement; both table-gradient modes (tiny-cuda-nn's
     loss-scaled fp16 packed atomics -- the production mode -- and fp32 atomics).  The measured relative L2 error per
