@@ -548,12 +548,8 @@ def neus_kernel_rooflines(device, n_rays, steps=5):
              (352.0 + 8.0) * pts, 88, "level_major_hashed"),
             (("neus_point", "?neus_encode_levels"), "neus_point_kernel (streams the records; dense-level gathers, SDF layer, alpha, colour MLP)",
              (160.0 + 12.0) * pts, 40, "point_major_dense"),
-            (("neus_backward_points_head", "neus_grid_scatter"),
-             "backward pass 1 = neus_point_bwd_head_kernel (per point: alpha chain, SDF layer, dense-gradient rows; streams "
-             "the forward's records) + neus_grid_scatter_kernel (level-major: corner contributions -> table-gradient "
-             "records of bin-and-reduce)", 1036.0 * pts, 0, None),
-            (("neus_backward_points_head",), "neus_point_bwd_head_kernel", (256.0 + 160.0 + 45.0 + 320.0 + 144.0) * pts, 0, None),
-            (("neus_grid_scatter",), "neus_grid_scatter_kernel", 16 * 32.0 * pts + 6.0 * 88.0 * pts, 0, None),
+            (("neus_backward_points_binned",), "neus_point_bwd_kernel<binned, aux> (streams the forward's per-level records, "
+             "table-gradient records = pass 1 of bin-and-reduce)", 1036.0 * pts, 0, None),
             (("grid_bin_reduce",), "grid_bin_reduce_kernel (pass 2: exact integer LDS sums per 8192-entry bin)",
              6.0 * 88.0 * pts + nh * (1 << 19) * 4.0 * 2, 0, None),
             (("mlp_backward",), "neus_mlp_bwd_kernel (fused colour-MLP backward, MFMA)", (160.0 + 12.0 + 6.0 + 160.0) * pts, 0, None)]
@@ -617,7 +613,7 @@ def conv_roofline(device, E, ht, wd):
            "bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": tf / MFMA_F16_PEAK_TFLOPS, "algorithmic_flops_per_update": flops_sum,
            "kernel_us_per_update": ms_sum * 1e3, "layers": layers}
-    out.update(pmc_traffic("r03_pmc_conv3x3_pp.json"))
+    out.update(pmc_traffic("r05_pmc_conv3x3_pp.json"))
     return out
 
 
@@ -631,7 +627,7 @@ def summary(line):
     pm = {}
     for ent in line.get("roofline_other", []):
         k = ent.get("kernel", "")
-        for tag, key in (("forward = ", "fwd"), ("backward pass 1 = ", "bwd1"), ("grid_bin_reduce", "binred"),
+        for tag, key in (("forward = ", "fwd"), ("neus_point_bwd_kernel", "bwd1"), ("grid_bin_reduce", "binred"),
                          ("neus_mlp_bwd", "mlpbwd")):
             if k.startswith(tag) and "kernel_avg_us" in ent:
                 rays = "32768" if "32768" in k else "4096"

@@ -1010,7 +1010,7 @@ NeusWs carve_neus(void* base, int n, int s) {
 // crossover of the two gather orders, in sample points (gs_neus_level_major_min_points sets it: tests run both orders on
 // small batches, tools measure the crossover)
 #include <atomic>
-static std::atomic<int> g_level_major_min_points{768 * 1024};
+static std::atomic<int> g_level_major_min_points{512 * 1024};
 static int level_major_min_points() { return g_level_major_min_points.load(std::memory_order_relaxed); }
 extern "C" int gs_neus_level_major_min_points(int points) {
   const int old = g_level_major_min_points.load(std::memory_order_relaxed);
@@ -1064,11 +1064,12 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
   int first_hashed = GS_GRID_LEVELS;
   for (int l = GS_GRID_LEVELS - 1; l >= 0 && meta.hashed[l]; --l) first_hashed = l;      // (the hashed levels are the finest)
   int nh = GS_GRID_LEVELS - first_hashed;
-  // Level-major pays where the table traffic is the bound: measured on MI355X (profiles/r05_*), 32768 rays x 72 samples:
-  // 1149 -> 993 us, gathers 1.07 -> 0.51 ms in the gather-only replay; at 4096 rays a level's chunks do not even fill
-  // one residency round per XCD, both forms are latency-bound (replay 131 vs 71 us) and the extra launch + the record
-  // round trip cost more than the misses (160 -> 174 us).  Below GS_LEVEL_MAJOR_MIN_POINTS the point kernel gathers
-  // every level itself (rec == nullptr), as the one-workgroup force pass always does.
+  // Level-major pays where the table traffic is the bound: measured on MI355X (profiles/r05_level_major_crossover.json,
+  // r05_gather_replay.json), 32768 rays x 72 samples: 1149 -> 993 us, the gathers alone 1.07 -> 0.51 ms in the gather-only
+  // replay; at 4096 rays a level's chunks do not fill one residency round per XCD, both orders are latency-bound and the
+  // extra launch + the record round trip cost more than the misses (146 -> 162 us).  The two meet at ~442 K points; below
+  // gs_neus_level_major_min_points (524288) the point kernel gathers every level itself (rec == nullptr), as the
+  // one-workgroup force pass always does.
   if (np < level_major_min_points()) nh = 0;
   if (nh > 0) {
     const int cpx = gs_cdiv(gs_cdiv(np, 256), 8);

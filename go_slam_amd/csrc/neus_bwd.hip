@@ -150,9 +150,6 @@ struct BwdArgs {
   // binned table gradient (BINNED instantiation): record queues [hashed level * 64 + bin][workgroup][ST_SLOTS] and the
   // segments' fill counts [hashed level * 64 + bin][workgroup]
   uint16_t* q_idx; uint32_t* q_val; uint8_t* q_cnt;
-  // split backward (round 5): what the per-point head hands to the level-major scatter -- per level and point the
-  // projections (d enc0, d enc1) of the upstream gradient [16][n*s] float2, per point (dG x, y, z, unused) [n*s] float4
-  float2* de_buf; float4* dg_buf;
 };
 
 constexpr int BIN_SHIFT = 13, BIN_ENTRIES = 1 << BIN_SHIFT;   // 8192 entries per bin
@@ -210,13 +207,8 @@ __device__ __forceinline__ void st_row(void* base, bool h16, size_t idx, float v
 }
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-// SPLIT (needs AUX): the per-point HEAD of the split backward -- everything below except the table scatter; per level it
-// leaves the projections (d enc0, d enc1) and per point dG for neus_grid_scatter_kernel.  No index arithmetic, no record
-// staging: 42 KB of LDS and a register budget that fits three workgroups per CU (the unsplit kernel: 79 KB / 207 VGPRs =
-// two waves per SIMD, 2.25 residency rounds for a 4096-ray batch).
-template <bool BINNED, bool AUX, bool SPLIT>
-__device__ __forceinline__ void point_bwd_body(const BwdArgs& A, const gs_grid_meta& m) {
-  static_assert(!SPLIT || (AUX && !BINNED), "the split head streams the forward's records and stages nothing");
+template <bool BINNED, bool AUX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void neus_point_bwd_kernel(BwdArgs A, gs_grid_meta m) {
   __shared__ float red[4];
   __shared__ uint32_t row_tiles[4][64 * ROW_TS];
   __shared__ uint32_t st_val[BINNED ? 2 : 1][BINNED ? BINS_PER_LEVEL : 1][BINNED ? ST_SLOTS : 1];
@@ -304,9 +296,6 @@ __device__ __forceinline__ void point_bwd_body(const BwdArgs& A, const gs_grid_m
     view[d] = (qn + 1.0f) / 2.0f;
     dG[d] = dg[d] * inside * 2.0f / span;
   }
-  if constexpr (SPLIT) {
-    if (valid) A.dg_buf[i] = make_float4(dG[0], dG[1], dG[2], 0.0f);
-  }
   const bool r16 = A.rows16 != 0;
   const float rs = A.row_scale;
   const size_t o32 = (size_t)i * 32, o35 = (size_t)i * 35;
@@ -347,7 +336,7 @@ __device__ __forceinline__ void point_bwd_body(const BwdArgs& A, const gs_grid_m
       rec = *reinterpret_cast<const half8*>(A.enc_aux + ((size_t)l * (size_t)np + i) * 8);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        cidx[c] = SPLIT ? 0u : grid_index(m, l, gi[0] + (c & 1), gi[1] + ((c >> 1) & 1), gi[2] + ((c >> 2) & 1));
+        cidx[c] = grid_index(m, l, gi[0] + (c & 1), gi[1] + ((c >> 1) & 1), gi[2] + ((c >> 2) & 1));
         float w = 1.0f;
 #pragma unroll
         for (int d = 0; d < 3; ++d) w = w * (((c >> d) & 1) ? f[d] : (1.0f - f[d]));
@@ -434,10 +423,7 @@ __device__ __forceinline__ void point_bwd_body(const BwdArgs& A, const gs_grid_m
         st_row(A.dw0, false, o35 + 3 + 2 * l + 1, v1);
       }
     }
-    if constexpr (SPLIT) {
-      // hand the level's projections to the level-major scatter (zeros for points out of bound / past the end)
-      if (valid) A.de_buf[(size_t)l * (size_t)np + i] = make_float2(de0, de1);
-    } else if (BINNED && m.hashed[l]) {
+    if (BINNED && m.hashed[l]) {
       // ---- pass 1 of bin-and-reduce: stage this workgroup's records of level l per bin, then copy them to the queues
       _Float16* tab16 = A.grid_grad16 + off * 2;
       const int buf = hord & 1;
@@ -539,150 +525,6 @@ __device__ __forceinline__ void point_bwd_body(const BwdArgs& A, const gs_grid_m
   if (threadIdx.x == 0) {
     const float t = (red[0] + red[1]) + (red[2] + red[3]);
     if (t != 0.0f) atomicAdd(A.d_inv_s, t);
-  }
-}
-
-template <bool BINNED, bool AUX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void neus_point_bwd_kernel(BwdArgs A, gs_grid_meta m) {
-  point_bwd_body<BINNED, AUX, false>(A, m);
-}
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void neus_point_bwd_head_kernel(BwdArgs A,
-                                                                                                          gs_grid_meta m) {
-  point_bwd_body<false, true, true>(A, m);
-}
-
-// ---------------------------------------------------------------------------------------
-// The table scatter of the split backward, LEVEL-MAJOR (round 5): a work item is (level, 256-point chunk), a lane one
-// sample point of ONE level.  From the head's hand-off -- (d enc0, d enc1) of this level, dG of the point -- and the
-// point's position it forms the 8 corner contributions (value path + second-order path, the arithmetic of the unsplit
-// kernel statement for statement), pre-reduces runs of equal cells in the wave, and stages / copies the records of a
-// hashed level into this chunk's queue segments (pass 1 of bin-and-reduce; grid_bin_reduce_kernel is unchanged) or
-// issues the packed atomics of a dense level.  ~70 registers and 19 KB of LDS: the index arithmetic that kept the
-// unsplit kernel at 2 waves per SIMD runs at full occupancy, a level's staging needs no double buffer, and the 32
-// upstream-gradient registers of the head are not live across it.
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void neus_grid_scatter_kernel(BwdArgs A, gs_grid_meta m, int chunks_per_xcd, int nchunks) {
-  __shared__ uint32_t st_val[BINS_PER_LEVEL][ST_SLOTS];
-  __shared__ uint16_t st_idx[BINS_PER_LEVEL][ST_SLOTS];
-  __shared__ uint32_t st_cnt[BINS_PER_LEVEL];
-  const int x = blockIdx.x & 7, jb = blockIdx.x >> 3;
-  const int l = jb / chunks_per_xcd, ci = jb - l * chunks_per_xcd;
-  const int chunk = ci * 8 + x;
-  if (chunk >= nchunks) return;                     // (uniform)
-  const bool hashed = m.hashed[l] != 0;
-  int hord = 0;                                     // ordinal of this level among the hashed ones
-  for (int k = 0; k < l; ++k) hord += m.hashed[k] ? 1 : 0;
-  if (hashed) {
-    if (threadIdx.x < BINS_PER_LEVEL) st_cnt[threadIdx.x] = 0u;
-    __syncthreads();
-  }
-  const int lane = threadIdx.x & 63;
-  const int np = A.n * A.s;
-  const int idx = chunk * 256 + threadIdx.x;
-  const bool valid = idx < np;
-  const int i = valid ? idx : np - 1;
-  const bool on = valid && A.mask[i] != 0;
-  const int ray = i / A.s;
-  const float dist = A.dists[i];
-  const float zm = A.z_vals[i] + dist / 2.0f;
-  float view[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const float pt = A.rays_o[ray * 3 + d] + A.rays_d[ray * 3 + d] * zm;
-    const float span = A.bound[2 * d + 1] - A.bound[2 * d];
-    float qn = (pt - A.bound[2 * d]) / span * 2.0f - 1.0f;
-    qn = fminf(fmaxf(qn, -1.0f), 1.0f);
-    view[d] = (qn + 1.0f) / 2.0f;
-  }
-  float2 de = A.de_buf[(size_t)l * (size_t)np + i];
-  float4 dg4 = A.dg_buf[i];
-  if (!on) { de = make_float2(0.f, 0.f); dg4 = make_float4(0.f, 0.f, 0.f, 0.f); }
-  const float dG[3] = {dg4.x, dg4.y, dg4.z};
-  const float scale = m.scale[l];
-  float f[3];
-  uint32_t gi[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const float pos = fmaf(scale, view[d], 0.5f);
-    const float fl = floorf(pos);
-    gi[d] = (uint32_t)(int)fl;
-    f[d] = pos - fl;
-  }
-  uint32_t cidx[8];
-  float gacc[8][2];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    cidx[c] = grid_index(m, l, gi[0] + (c & 1), gi[1] + ((c >> 1) & 1), gi[2] + ((c >> 2) & 1));
-    float w = 1.0f;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) w = w * (((c >> d) & 1) ? f[d] : (1.0f - f[d]));
-    gacc[c][0] = de.x * w;
-    gacc[c][1] = de.y * w;
-  }
-  typedef const __attribute__((address_space(4))) float* cfp;
-  cfp wl = (cfp)(A.sdf_w + 3 + 2 * l);
-  const float g0 = (float)(_Float16)wl[0], g1 = (float)(_Float16)wl[1];
-#pragma unroll
-  for (int gd = 0; gd < 3; ++gd) {
-    const int o0 = (gd == 0) ? 1 : 0, o1 = (gd == 2) ? 1 : 2;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float w = scale;
-      w = w * ((k & 1) ? f[o0] : (1.0f - f[o0]));
-      w = w * ((k & 2) ? f[o1] : (1.0f - f[o1]));
-      const int cl = ((k & 1) << o0) | (((k >> 1) & 1) << o1);
-      const int cr = cl | (1 << gd);
-      const float s0 = 0.5f * dG[gd] * g0 * w, s1 = 0.5f * dG[gd] * g1 * w;
-      gacc[cr][0] += s0; gacc[cl][0] -= s0;
-      gacc[cr][1] += s1; gacc[cl][1] -= s1;
-    }
-  }
-  const size_t off = (size_t)m.offset[l];
-  if (!hashed) {
-    lvl_scatter(A.grid_grad ? A.grid_grad + off * 2 : nullptr, A.grid_grad16 ? A.grid_grad16 + off * 2 : nullptr,
-                A.grad_scale16, cidx, gacc, gi, on, lane);
-    return;
-  }
-  // ---- pass 1 of bin-and-reduce for this (level, chunk): stage per bin, then copy the bins out as contiguous runs
-  _Float16* tab16 = A.grid_grad16 + off * 2;
-  const bool act = lvl_prereduce(gacc, gi, on, lane) && on;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    if (act && (gacc[c][0] != 0.0f || gacc[c][1] != 0.0f)) {
-      const uint32_t e = cidx[c], bin = e >> BIN_SHIFT;
-      const uint32_t packed = pack2h(gacc[c][0] * A.grad_scale16, gacc[c][1] * A.grad_scale16);
-      const uint32_t slot = atomicAdd(&st_cnt[bin], 1u);
-      if (slot < (uint32_t)ST_SLOTS) {
-        st_idx[bin][slot] = (uint16_t)(e & (BIN_ENTRIES - 1));
-        st_val[bin][slot] = packed;
-      } else {                                      // staging bin full: this record goes out as an atomic
-        __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2a*)(tab16 + (size_t)e * 2),
-                                                  __builtin_bit_cast(half2a, packed));
-      }
-    }
-  }
-  __syncthreads();
-  {
-    // wave w copies bins 16 w .. 16 w + 15 to this chunk's segments, four bins per step (16 lanes each)
-    const int wv = threadIdx.x >> 6, sub = lane >> 4, s16 = lane & 15;
-    const size_t nblk = (size_t)nchunks;
-#pragma unroll
-    for (int j = 0; j < BINS_PER_LEVEL / 16; ++j) {
-      const int b = 16 * wv + 4 * j + sub;
-      const uint32_t cn = st_cnt[b];
-      const uint32_t c = cn < (uint32_t)ST_SLOTS ? cn : (uint32_t)ST_SLOTS;
-      const size_t seg = (size_t)(hord * BINS_PER_LEVEL + b) * nblk + chunk;
-#pragma unroll
-      for (int k = 0; k < (ST_SLOTS + 15) / 16; ++k) {
-        const uint32_t sl = s16 + 16 * k;
-        if (sl < c) {
-          A.q_idx[seg * ST_SLOTS + sl] = st_idx[b][sl];
-          A.q_val[seg * ST_SLOTS + sl] = st_val[b][sl];
-        }
-      }
-      if (s16 == 0) A.q_cnt[seg] = (uint8_t)c;
-    }
   }
 }
 
@@ -814,8 +656,7 @@ extern "C" size_t gs_neus_bin_workspace_bytes(int n_points) {
   size_t nh = 0;
   for (int l = 0; l < GS_GRID_LEVELS; ++l) nh += m.hashed[l] ? 1 : 0;
   const size_t nq = nh * BINS_PER_LEVEL, nblk = bin_workgroups((size_t)(n_points > 0 ? n_points : 0));
-  // fill counts | values | indices | the split backward's hand-off: (d enc0, d enc1) per level and point, dG per point
-  return gs_align(nq * nblk) + gs_align(nq * nblk * ST_SLOTS * 6) + (size_t)(n_points > 0 ? n_points : 0) * (16 * 8 + 16) + 1024;
+  return gs_align(nq * nblk) + nq * nblk * ST_SLOTS * 6 + 512;       // fill counts | values | indices
 }
 
 extern "C" int gs_neus_backward_rays(const float* alpha, const void* rgb, const float* z_mid, const float* grad,
@@ -870,7 +711,7 @@ static int backward_points_impl(const float* rays_o, const float* rays_d, const 
   A.d_out = d_out; A.lin_in = lin_in; A.dw0 = dw0; A.d_arg = d_arg; A.pts = pts;
   A.rows16 = row_dtype == GS_F16; A.row_scale = row_scale; A.row_stride16 = row_stride / 8; A.dx16 = dx_dtype == GS_F16; A.dx_inv_scale = 1.0f / dx_scale;
   A.d_inv_s = d_inv_s; A.n = n; A.s = s;
-  A.q_idx = nullptr; A.q_val = nullptr; A.q_cnt = nullptr; A.de_buf = nullptr; A.dg_buf = nullptr;
+  A.q_idx = nullptr; A.q_val = nullptr; A.q_cnt = nullptr;
   const gs_grid_meta m = host_meta();
   if (!bin_ws) {
     if (enc_aux) neus_point_bwd_kernel<false, true><<<gs_cdiv(n * s, 256), 256, 0, (hipStream_t)stream>>>(A, m);
@@ -898,20 +739,9 @@ static int backward_points_impl(const float* rays_o, const float* rays_d, const 
   A.q_val = (uint32_t*)(base + gs_align(nq * nblk));              // [nq][nblk][ST_SLOTS]
   A.q_idx = (uint16_t*)((char*)A.q_val + nq * nblk * ST_SLOTS * 4);
   GS_TIMING_PRE();
-  if (enc_aux) {
-    // split backward: per-point head (no index work, no staging: 3 workgroups per CU) -> level-major scatter
-    char* hand = (char*)A.q_idx + gs_align(nq * nblk * ST_SLOTS * 2);
-    A.de_buf = (float2*)hand;
-    A.dg_buf = (float4*)(hand + (size_t)n * s * 16 * 8);
-    neus_point_bwd_head_kernel<<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(A, m);
-    GS_CHECK_LAUNCH("neus_backward_points_head");
-    const int cpx = gs_cdiv((int)nblk, 8);
-    neus_grid_scatter_kernel<<<(unsigned)(8 * cpx * GS_GRID_LEVELS), 256, 0, (hipStream_t)stream>>>(A, m, cpx, (int)nblk);
-    GS_CHECK_LAUNCH("neus_grid_scatter");
-  } else {
-    neus_point_bwd_kernel<true, false><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(A, m);
-    GS_CHECK_LAUNCH("neus_backward_points_binned");
-  }
+  if (enc_aux) neus_point_bwd_kernel<true, true><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(A, m);
+  else neus_point_bwd_kernel<true, false><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(A, m);
+  GS_CHECK_LAUNCH("neus_backward_points_binned");
   static GsLdsLimit limit;
   const size_t acc_bytes = (size_t)2 * BIN_ENTRIES * sizeof(unsigned long long);
   const size_t cnt_bytes = gs_align(nblk, 16);                        // the bin's fill counts, if they fit beside the sums

@@ -97,7 +97,7 @@ int gs_mlp_forward(const void* x, const void* mlp, void* out, int n, int n_in, i
 size_t gs_neus_forward_workspace_bytes(int n, int s);
 /* gs_neus_forward gathers the hashed levels LEVEL-MAJOR (one 2 MB level at a time per XCD, 16-byte records, then the
  * per-point stage) for batches of at least this many sample points, and per point below it.  Returns the previous value;
- * points < 0 only queries.  Default 786432 (measured crossover on MI355X).  Same results either way up to the
+ * points < 0 only queries.  Default 524288 (measured: the two orders meet at ~442 K points on MI355X, profiles/r05_level_major_crossover.json).  Same results either way up to the
  * fp32 summation order of d sdf / d x.                                                                            */
 int gs_neus_level_major_min_points(int points);
 int gs_neus_forward(const float* rays_o, const float* rays_d, const float* z_vals,

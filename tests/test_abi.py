@@ -112,9 +112,7 @@ _BUDGETS = {
     # file: {kernel-name substring: (max VGPRs, max LDS bytes)}; scratch must be 0 for all of them
     "neus.hip": {"neus_point_kernel": (128, 40960),                  # 4 waves per SIMD, 4 x 40 KB workgroups per CU
                  "neus_encode_levels_kernel": (64, 0)},              # 8 waves per SIMD
-    "neus_bwd.hip": {"grid_bin_reduce_kernel": (128, 16),            # 1024 threads = 4 waves per SIMD (LDS is dynamic)
-                     "neus_point_bwd_head_kernel": (168, 53248),     # 3 waves per SIMD, 3 workgroups per CU
-                     "neus_grid_scatter_kernel": (80, 20480)},       # 6 waves per SIMD
+    "neus_bwd.hip": {"grid_bin_reduce_kernel": (128, 16)},           # 1024 threads = 4 waves per SIMD (LDS is dynamic)
     "altcorr_pyramid.hip": {"altcorr_pyramid_kernel": (168, 53248)},  # 3 waves per SIMD, 3 x 41 KB workgroups per CU
     "conv3x3_pp.hip": {"conv3x3_pp_kernel": (256, 0)},               # 2 waves per SIMD (LDS is dynamic)
 }

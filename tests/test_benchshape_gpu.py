@@ -273,7 +273,7 @@ def N(built_lib):
 @pytest.fixture
 def gather_order(request):
     """run a test with the hashed levels gathered per point (the small-batch order) or LEVEL-MAJOR (the order batches of
-    >= 786432 points take: neus_encode_levels_kernel + records) whatever the batch size"""
+    >= 524288 points take: neus_encode_levels_kernel + records) whatever the batch size"""
     from go_slam_amd import _lib
     L = _lib.lib()
     old = L.gs_neus_level_major_min_points(0 if request.param == "level-major" else 1 << 30)

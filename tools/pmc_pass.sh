@@ -5,7 +5,9 @@ set -u
 out=$(realpath -m "$1"); pat=$2; shift 3        # (absolute: the passes run from /tmp; give the command absolute paths too)
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum" "TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum"; do
+# PMC_GROUPS="A B;C;D E" overrides the counter groups (';' between passes)
+IFS=';' read -r -a groups <<< "${PMC_GROUPS:-FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum;TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum;TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum;TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum}"
+for c in "${groups[@]}"; do
   tag=$(echo $c | tr ' ' '+')
   timeout 180 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$tag -o p -- "$@" > $out/pmc_$tag.log 2>&1 || echo "pass $tag failed (see $out/pmc_$tag.log)"
 done
