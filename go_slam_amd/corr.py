@@ -44,14 +44,14 @@ class CorrBlock:
             return droid_backends.corr_volume_pyramid(f1.contiguous(),
                                                       fmap2.reshape(batch * num, dim, ht, wd).contiguous(), layout)
         assert layout == droid_backends.CORR_ROWMAJOR
-        # shapes the fused kernel does not cover (w % 8 != 0 -- EuRoC's 40 x 60 maps --, w > 96, other dtypes): the
+        # shapes the fused kernel does not cover (w % 4 != 0, w > 96, other dtypes): the
         # reference's own formulation, a library GEMM + avg_pool2d.  Said out loud once per process: a reader of a
         # profile should not have to discover a hipBLASLt kernel on this path.
         if fmap1.is_cuda and not CorrBlock._warned_fallback:
             import warnings
             CorrBlock._warned_fallback = True
             warnings.warn(f"CorrBlock: {ht}x{wd} {fmap1.dtype} feature maps are outside gs_corr_volume_pyramid's shapes "
-                          "(fp16, width a multiple of 8 up to 96); building the volume with torch.matmul + avg_pool2d",
+                          "(fp16, width a multiple of 4 up to 96); building the volume with torch.matmul + avg_pool2d",
                           RuntimeWarning, stacklevel=2)
         corr = CorrBlock.corr(fmap1, fmap2)
         batch, num, h1, w1, h2, w2 = corr.shape

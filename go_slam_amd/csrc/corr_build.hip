@@ -31,9 +31,11 @@ constexpr int ROWS = 4;         // target rows per workgroup (covers the 2x2 and
 constexpr int MAXT = 3;         // n-tiles (32 columns) per wave: 4*w/32/4 <= 3  <=>  w <= 96
 
 // Pixels a feature map is padded to in the workspace: whole 64-pixel source blocks and whole target-row blocks
+// (+ one 32-pixel tile when a target-row block is not a whole number of tiles -- w % 8 == 4, EuRoC's 40 x 60 maps: the
+// last n-tile of a block then reads up to 16 pixels past it)
 __host__ __device__ inline int padded_pixels(int h, int w) {
   const int a = (h * w + BM - 1) / BM * BM, b = (h + ROWS - 1) / ROWS * ROWS * w;
-  return ((a > b ? a : b) + 31) / 32 * 32;
+  return ((a > b ? a : b) + 31) / 32 * 32 + (((ROWS * w) & 31) ? 32 : 0);
 }
 
 // [n,128,HW] -> MFMA-fragment order, x 1/4, for both feature maps in one launch (blockIdx.z = map * n + edge).
@@ -83,8 +85,9 @@ __global__ __launch_bounds__(256, 3) void corr_volume_kernel(
     _Float16* __restrict__ v1, _Float16* __restrict__ v2, int h, int w, int tiled, int ntiles, int padded) {
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
   const int hw = h * w;
-  const int BN = ROWS * w;                 // columns of the tile (multiple of 32)
-  const int LD0 = BN + 8;                  // LDS row strides (halfs)
+  const int BN = ROWS * w;                 // columns of the tile: a multiple of 32 when w % 8 == 0, of 16 when w % 8 == 4
+  const int ntile = (BN + 31) / 32;        // (then the last n-tile is half full; its upper 16 columns are never stored)
+  const int LD0 = 32 * ntile + 8;          // LDS row strides (halfs)
   const int LD1 = (ROWS / 2) * (w / 2) + 8;   // multiple of 8 halves when w % 16 == 0: 16-byte LDS stores
   _Float16* c0 = lds;                      // [BM][LD0]
   _Float16* c1 = c0 + BM * LD0;            // [BM][LD1]
@@ -101,16 +104,21 @@ __global__ __launch_bounds__(256, 3) void corr_volume_kernel(
   const int y2_0 = (tile % gx) * ROWS;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = lane & 31;
-  const int ntile = BN / 32;
   const _Float16* A = f2t + (size_t)e * padded * KDIM;   // target pixels, fragment order
   const _Float16* B = f1t + (size_t)e * padded * KDIM;   // source pixels, fragment order
 
   // A operand (target pixels): the 8 k-step fragments of a 32-pixel tile are 8 coalesced 1 KB loads straight into
   // the fragment registers (corr_prep wrote the map in fragment order) -- no LDS stage, no wave barriers.  The first
   // tile is issued before anything else so that its round trip overlaps the B tile's.
-  const int tile0 = (y2_0 * w) >> 5;                   // ROWS * w is a multiple of 32
+  // (target pixel of lane (hi, r) in n-tile nt: q0 + 32 nt + r.  q0 = y2_0 * w is a multiple of 32 when w % 8 == 0 -- the
+  // lane then reads lane-th piece of stored tile q0 / 32 + nt, one coalesced 1 KB run per wave -- and of 16 when w % 8 == 4:
+  // the n-tile straddles two stored tiles, two 256-byte runs per half-wave)
+  const int q0 = y2_0 * w;
   half8 areg[8];
-  auto frag = [&](int nt, int ks) { return ld8(A + (((size_t)(tile0 + nt) * 8 + ks) * 64 + lane) * 8); };
+  auto frag = [&](int nt, int ks) {
+    const int q = q0 + 32 * nt + r;
+    return ld8(A + (((size_t)(q >> 5) * 8 + ks) * 64 + (lane & 32) + (q & 31)) * 8);
+  };
   if (wave < ntile) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) areg[ks] = frag(wave, ks);
@@ -330,7 +338,7 @@ extern "C" int gs_corr_volume_pyramid(const void* fmap1, const void* fmap2, void
   GS_REQUIRE(fmap1 && fmap2 && vol0 && vol1 && vol2 && vol3, "corr_volume_pyramid: null pointer");
   GS_REQUIRE(dim == KDIM, "corr_volume_pyramid: feature dim %d (DROID uses 128)", dim);
   GS_REQUIRE(n >= 0 && h >= 8 && w >= 8, "corr_volume_pyramid: bad shape");
-  GS_REQUIRE(w % 8 == 0 && w <= 32 * MAXT, "corr_volume_pyramid: map width %d must be a multiple of 8 and <= %d",
+  GS_REQUIRE(w % 4 == 0 && w <= 32 * MAXT, "corr_volume_pyramid: map width %d must be a multiple of 4 and <= %d",
              w, 32 * MAXT);
   if (n == 0) return GS_OK;
   const size_t need = gs_corr_volume_workspace_bytes(n, dim, h, w);
@@ -347,7 +355,7 @@ extern "C" int gs_corr_volume_pyramid(const void* fmap1, const void* fmap2, void
                                                                         f1t, f2t, n, hw, padded);
   GS_CHECK_LAUNCH("corr_prep");
   const int BN = ROWS * w;
-  size_t lds = (size_t)(BM * (BN + 8) + BM * ((ROWS / 2) * (w / 2) + 8)) * 2;     // c0 and c1
+  size_t lds = (size_t)(BM * ((BN + 31) / 32 * 32 + 8) + BM * ((ROWS / 2) * (w / 2) + 8)) * 2;     // c0 and c1
   const size_t btile = (size_t)BM * KDIM * 2;                              // the B tile aliases the output tile
   if (lds < btile) lds = btile;
   static GsLdsLimit limit;

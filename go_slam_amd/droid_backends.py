@@ -323,10 +323,11 @@ CORR_VOLUME_MAX_W = 96      # corr_volume_kernel: three 32-column tiles per wave
 
 
 def corr_volume_supported(fmap1):
-    """shapes gs_corr_volume_pyramid covers: fp16, 128 channels, map width a multiple of 8 up to 96 (every reference
-    config except EuRoC's 40 x 60 maps, whose w % 8 == 4 breaks the 16-byte row alignment the stores rely on)"""
+    """shapes gs_corr_volume_pyramid covers: fp16, 128 channels, map width a multiple of 4 up to 96 -- every reference
+    config, EuRoC's 40 x 60 maps (w % 8 == 4: a block of four target rows is 7.5 MFMA column tiles; the kernel runs the
+    eighth half-empty, csrc/corr_build.hip) included"""
     n, dim, h, w = fmap1.shape
-    return fmap1.dtype == torch.float16 and dim == 128 and h >= 8 and w % 8 == 0 and 8 <= w <= CORR_VOLUME_MAX_W
+    return fmap1.dtype == torch.float16 and dim == 128 and h >= 8 and w % 4 == 0 and 8 <= w <= CORR_VOLUME_MAX_W
 
 
 def corr_tile8_supported(fmap):

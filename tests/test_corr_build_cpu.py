@@ -16,9 +16,12 @@ def _emu():
 
 def test_fragment_order_is_a_bijection_and_one_load_is_one_kilobyte():
     E = _emu()
-    for h, w in ((8, 8), (12, 16), (60, 80), (30, 40), (9, 24)):
+    for h, w in ((8, 8), (12, 16), (60, 80), (30, 40), (9, 24), (40, 60), (9, 12), (10, 92)):
         P = E.padded_pixels(h, w)
         assert P % 32 == 0 and P >= h * w and P >= (h + 3) // 4 * 4 * w and P >= (h * w + 63) // 64 * 64
+        # the last n-tile of the last target-row block stays inside the padded image (w % 8 == 4: it is half full and
+        # reads 16 pixels past the block)
+        assert ((h + 3) // 4 * 4 - 4) * w + (4 * w + 31) // 32 * 32 <= P
         p, c = np.meshgrid(np.arange(P), np.arange(128), indexing="ij")
         off = E.frag_offset(p, c).ravel()
         assert off.min() == 0 and off.max() == P * 128 - 1 and np.unique(off).size == off.size
@@ -83,3 +86,24 @@ def test_workgroup_pipeline_matches_a_plain_matmul():
         b = (f2.T.astype(np.float16) / np.float16(4)).astype(np.float32)[y2_0 * w:(y2_0 + 4) * w]
         ref = (a @ b.T).astype(np.float16)
         assert np.allclose(c0.astype(np.float32), ref.astype(np.float32), rtol=2e-3, atol=2e-3)
+
+
+def test_workgroup_pipeline_at_widths_with_a_half_full_column_tile():
+    """w % 8 == 4 (EuRoC's 40 x 60 maps; here 8 x 12 and 12 x 20): a block of four target rows is an odd number of
+    16-pixel halves, so every second block starts in the MIDDLE of a stored 32-pixel fragment tile and ends in a half-full
+    MFMA column tile -- the per-lane fragment address of corr_volume_kernel's `frag` must pick the right pixels."""
+    E = _emu()
+    rng = np.random.default_rng(7)
+    for h, w in ((8, 12), (12, 20)):
+        f1 = rng.standard_normal((128, h * w)).astype(np.float16)
+        f2 = rng.standard_normal((128, h * w)).astype(np.float16)
+        i1, i2 = E.prep(f1, h, w), E.prep(f2, h, w)
+        for p1_0 in (0, 64):
+            for y2_0 in range(0, h, 4):
+                c0 = E.volume_tile(i1, i2, h, w, p1_0, y2_0)
+                m_valid = min(64, h * w - p1_0)
+                a = (f1.T.astype(np.float16) / np.float16(4)).astype(np.float32)[p1_0:p1_0 + m_valid]
+                b = (f2.T.astype(np.float16) / np.float16(4)).astype(np.float32)[y2_0 * w:(y2_0 + 4) * w]
+                ref = (a @ b.T).astype(np.float16)
+                assert c0.shape == (64, 4 * w)
+                assert np.allclose(c0[:m_valid, :ref.shape[1]].astype(np.float32), ref.astype(np.float32), rtol=2e-3, atol=2e-3), (h, w, p1_0, y2_0)

@@ -694,11 +694,14 @@ def test_corrblock_matches_oracle_on_fused_and_fallback_shapes(O, dev, hw, expec
         torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=0, atol=4e-3)
 
 
-@pytest.mark.parametrize("h,w,layout", [(16, 96, "tile8"), (16, 96, "rowmajor"), (12, 88, "rowmajor")])
+@pytest.mark.parametrize("h,w,layout", [(16, 96, "tile8"), (16, 96, "rowmajor"), (12, 88, "rowmajor"),
+                                        (40, 60, "rowmajor"), (10, 92, "rowmajor"), (9, 12, "rowmajor")])
 def test_corr_volume_pyramid_at_the_kernel_width_limit(db, O, dev, h, w, layout):
     """corr_volume_kernel's real limit is three 32-column tiles per wave, w <= 96 (the Python gate said 80 until round
     4): level 0 within one fp16 rounding of the oracle's fp32 dot products, pooled levels exactly the pool of the level
-    below, in both layouts (tile8 needs w % 16 == 0)."""
+    below, in both layouts (tile8 needs w % 16 == 0).  Round 5: widths with w % 8 == 4 -- EuRoC's 320 x 480 input = 40 x 60
+    maps (configs/EuRoC/mh_01_easy.yaml), 92, 12 -- where a block of four target rows ends in a half-full MFMA column tile,
+    and map heights that are not a multiple of the block (10, 9)."""
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(500 + w)
     f1 = torch.randn(2, 128, h, w, generator=g).half()
@@ -717,27 +720,59 @@ def test_corr_volume_pyramid_at_the_kernel_width_limit(db, O, dev, h, w, layout)
         hl, wl = low.shape[-2:]
         pooled = F.avg_pool2d(low.reshape(-1, 1, hl, wl).float(), 2, 2).to(torch.float16)
         assert torch.equal(out[l].cpu().reshape(-1, 1, hl // 2, wl // 2), pooled), f"level {l}"
-    assert not db.corr_volume_supported(torch.zeros(1, 128, 40, 60).half())         # EuRoC: w % 8 == 4
+    assert db.corr_volume_supported(torch.zeros(1, 128, 40, 60).half())             # EuRoC: w % 8 == 4
+    assert not db.corr_volume_supported(torch.zeros(1, 128, 40, 62).half())         # w % 4 != 0
     assert not db.corr_volume_supported(torch.zeros(1, 128, 16, 104).half())
 
 
-def test_corr_block_outside_the_kernel_shapes_warns_instead_of_silently_using_the_library(db, O, dev):
-    """EuRoC's 320 x 480 input gives 40 x 60 maps (configs/EuRoC/mh_01_easy.yaml): w % 8 == 4 is outside the fused
-    builder's shapes.  CorrBlock then takes the reference's own formulation (matmul + avg_pool2d) -- with a
-    RuntimeWarning, once -- and its lookup still equals the oracle's."""
+def test_corr_block_at_the_euroc_map_size_runs_the_own_kernels(db, O, dev):
+    """EuRoC's 320 x 480 input gives 40 x 60 maps (configs/EuRoC/mh_01_easy.yaml, v1_02_medium, v2_01_easy): w % 8 == 4.
+    Until round 5 CorrBlock took the reference's matmul + avg_pool2d formulation there (with a RuntimeWarning); now the
+    volume comes from gs_corr_volume_pyramid -- no warning, no library GEMM -- and the lookup equals the oracle's."""
     import warnings
     from go_slam_amd.corr import CorrBlock
     g = torch.Generator().manual_seed(611)
     f1 = torch.randn(1, 2, 128, 40, 60, generator=g).half()
     f2 = torch.randn(1, 2, 128, 40, 60, generator=g).half()
     CorrBlock._warned_fallback = False
+    calls = []
+    orig = torch.matmul
+    torch.matmul = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            blk = CorrBlock(f1.to(dev), f2.to(dev))
+    finally:
+        torch.matmul = orig
+    assert not calls and not any(issubclass(w_.category, RuntimeWarning) for w_ in rec)
+    ys, xs = torch.meshgrid(torch.arange(40, dtype=torch.float32), torch.arange(60, dtype=torch.float32), indexing="ij")
+    coords = (torch.stack([xs, ys], -1)[None, None] + 2.0 * torch.randn(1, 2, 40, 60, 2, generator=g)).contiguous()
+    out = blk(coords.to(dev))
+    ref = O.corr_lookup(O.corr_pyramid(f1, f2), coords, 3)
+    torch.testing.assert_close(out.float().cpu().reshape(ref.shape), ref.float(), rtol=0, atol=2e-2)
+    # the frontend's form: channels-last features (row-major volume at this width: tile8 needs w % 16 == 0)
+    blk_cl = CorrBlock(f1.to(dev), f2.to(dev), channels_last=True)
+    assert blk_cl.layout == db.CORR_ROWMAJOR
+    out_cl = blk_cl(coords.to(dev))
+    assert torch.equal(out_cl.float().cpu().reshape(ref.shape), out.float().cpu().reshape(ref.shape))
+
+
+def test_corr_block_outside_the_kernel_shapes_warns_instead_of_silently_using_the_library(db, O, dev):
+    """Widths the fused builder does not cover (w % 4 != 0; here 20 x 30 maps, w % 4 == 2): CorrBlock takes the reference's own
+    formulation (matmul + avg_pool2d) -- with a RuntimeWarning, once -- and its lookup still equals the oracle's."""
+    import warnings
+    from go_slam_amd.corr import CorrBlock
+    g = torch.Generator().manual_seed(612)
+    f1 = torch.randn(1, 2, 128, 20, 30, generator=g).half()
+    f2 = torch.randn(1, 2, 128, 20, 30, generator=g).half()
+    CorrBlock._warned_fallback = False
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
         blk = CorrBlock(f1.to(dev), f2.to(dev))
         CorrBlock(f1.to(dev), f2.to(dev))
     assert sum(issubclass(w_.category, RuntimeWarning) and "gs_corr_volume_pyramid" in str(w_.message) for w_ in rec) == 1
-    ys, xs = torch.meshgrid(torch.arange(40, dtype=torch.float32), torch.arange(60, dtype=torch.float32), indexing="ij")
-    coords = (torch.stack([xs, ys], -1)[None, None] + 2.0 * torch.randn(1, 2, 40, 60, 2, generator=g)).contiguous()
+    ys, xs = torch.meshgrid(torch.arange(20, dtype=torch.float32), torch.arange(30, dtype=torch.float32), indexing="ij")
+    coords = (torch.stack([xs, ys], -1)[None, None] + 2.0 * torch.randn(1, 2, 20, 30, 2, generator=g)).contiguous()
     out = blk(coords.to(dev))
     ref = O.corr_lookup(O.corr_pyramid(f1, f2), coords, 3)
     torch.testing.assert_close(out.float().cpu().reshape(ref.shape), ref.float(), rtol=0, atol=2e-2)

@@ -10,7 +10,7 @@ KDIM, BM, ROWS = 128, 64, 4
 def padded_pixels(h, w):
     a = (h * w + BM - 1) // BM * BM
     b = (h + ROWS - 1) // ROWS * ROWS * w
-    return (max(a, b) + 31) // 32 * 32
+    return (max(a, b) + 31) // 32 * 32 + (32 if (ROWS * w) % 32 else 0)
 
 
 def frag_offset(p, c):
@@ -34,6 +34,17 @@ def fragment(img, tile, ks):
     """what `ld8(A + ((tile * 8 + ks) * 64 + lane) * 8)` gives the 64 lanes: [64, 8]"""
     base = (tile * 8 + ks) * 64 * 8
     return img[base:base + 512].reshape(64, 8)
+
+
+def fragment_at(img, q0, nt, ks):
+    """the target-pixel fragment of corr_volume_kernel's `frag(nt, ks)`: lane (hi, r) reads pixel q = q0 + 32 nt + r at
+    ((q >> 5) * 8 + ks) * 64 + 32 hi + (q & 31) -- one stored tile when q0 % 32 == 0, two half tiles when q0 % 32 == 16"""
+    out = np.zeros((64, 8), img.dtype)
+    for lane in range(64):
+        q = q0 + 32 * nt + (lane & 31)
+        base = (((q >> 5) * 8 + ks) * 64 + (lane & 32) + (q & 31)) * 8
+        out[lane] = img[base:base + 8]
+    return out
 
 
 def mfma_32x32x16(a, b, acc):
@@ -64,13 +75,13 @@ def tile8_addr(y, x, w):
 def volume_tile(f1img, f2img, h, w, p1_0, y2_0):
     """one workgroup of corr_volume_kernel: returns the [BM, ROWS * w] fp16 tile c0 (source pixel m, target column j)"""
     BN = ROWS * w
-    ntile = BN // 32
-    tile0 = (y2_0 * w) >> 5
-    c0 = np.zeros((BM, BN), np.float16)
+    ntile = (BN + 31) // 32
+    q0 = y2_0 * w
+    c0 = np.zeros((BM, 32 * ntile), np.float16)          # (LD0 = 32 ntile + 8; columns >= BN are never stored)
     for nt in range(ntile):
         acc = [np.zeros((64, 16), np.float32) for _ in range(BM // 32)]
         for ks in range(8):
-            af = fragment(f2img, tile0 + nt, ks)
+            af = fragment_at(f2img, q0, nt, ks)
             for mt in range(BM // 32):
                 bfr = fragment(f1img, (p1_0 >> 5) + mt, ks)
                 acc[mt] = mfma_32x32x16(af, bfr, acc[mt])
@@ -80,4 +91,4 @@ def volume_tile(f1img, f2img, h, w, p1_0, y2_0):
                 for q in range(4):
                     for k in range(4):
                         c0[32 * mt + r, 32 * nt + 8 * q + 4 * (lane >> 5) + k] = np.float16(acc[mt][lane, q * 4 + k])
-    return c0
+    return c0[:, :BN]
