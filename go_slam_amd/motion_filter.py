@@ -44,12 +44,14 @@ class MotionFilter:
 
     def _flow_to_last_keyframe(self, gmap, ht, wd):
         """mean flow magnitude predicted by ONE update iteration from the last keyframe to this frame (host scalar)"""
-        corr = CorrBlock(self.fmap[None, [LEFT]], gmap[None, [LEFT]])(self._pixel_grid(ht, wd))
+        # (slices, not `[LEFT]` lists: a list index is a gather -- an index tensor, stride arithmetic on it and a copy
+        # kernel, ~5 launches each on this per-frame path -- where the slice is a view)
+        corr = CorrBlock(self.fmap[None, LEFT:LEFT + 1], gmap[None, LEFT:LEFT + 1])(self._pixel_grid(ht, wd))
         _, delta, _weight = self.update(self.net[None], self.inp[None], corr)
         return float(delta.norm(dim=-1).mean())
 
     def _make_keyframe(self, frames, gmap, timestamp, image, pose, disp, depth, intrinsic, gt_pose):
-        hidden, ctx = self._context(frames[:, [LEFT]])
+        hidden, ctx = self._context(frames[:, LEFT:LEFT + 1])
         self.net, self.inp, self.fmap = hidden, ctx, gmap
         self.video.append(timestamp, image[LEFT], pose, disp, depth, intrinsic / DOWNSCALE, gmap, hidden[LEFT],
                           ctx[LEFT], gt_pose)

@@ -1,0 +1,34 @@
+#!/bin/bash
+# One round's evidence on an MI355X box (run through gpurun from the repository root):
+#   bash tools/round_profile.sh r05
+# full GPU suite, the bench line (driver flags), kernel traces of the tracking keyframe / the three mapping legs /
+# MotionFilter.track / the global-BA stress step, the PMC passes of the mapper step, the Cholesky harness.
+# Everything lands in gpurun_out/<tag>_final/; the summaries that are judged get copied to profiles/ by hand.
+tag=${1:-r05}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/${tag}_final
+mkdir -p $OUT
+cd $R
+( time timeout 1500 python -m pytest tests -m gpu -q ) > $OUT/pytest_gpu.log 2>&1
+tail -6 $OUT/pytest_gpu.log
+timeout 900 python bench.py --steps 20 --warmup 5 2> $OUT/bench.err | tail -1 > $OUT/bench.json
+tail -c 1900 $OUT/bench.json; echo
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_track -o t -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_track.log 2>&1 || echo "prof track failed"
+f=$(find $OUT/prof_track -name '*kernel_trace.csv' | head -1)
+python $R/tools/summarize_trace.py $f --steps 5 --warmup 2 > $OUT/tracking_kernel_stats.md 2> $OUT/summarize.err
+for leg in train train_weak render; do
+  timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_$leg -o t -- python $R/tools/profile_mapping.py $leg 10 > $OUT/prof_$leg.log 2>&1 || echo "prof $leg failed"
+  f=$(find $OUT/prof_$leg -name '*kernel_trace.csv' | head -1)
+  python $R/tools/summarize_kernels.py $f --steps 10 --title "profile_mapping.py $leg" > $OUT/mapping_${leg}_kernel_stats.md 2>> $OUT/summarize.err
+done
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_mf -o t -- python $R/tools/profile_motion_filter.py 20 > $OUT/prof_mf.log 2>&1 || echo "prof mf failed"
+f=$(find $OUT/prof_mf -name '*kernel_trace.csv' | head -1)
+python $R/tools/summarize_kernels.py $f --steps 20 --title "MotionFilter.track, one 480x640 RGB-D input frame (20 frames + one-off setup: model init, first keyframe)" > $OUT/motion_filter_kernel_stats.md 2>> $OUT/summarize.err
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_stress -o t -- python $R/tools/profile_stress.py 4 > $OUT/prof_stress.log 2>&1 || echo "prof stress failed"
+f=$(find $OUT/prof_stress -name '*kernel_trace.csv' | head -1)
+python $R/tools/summarize_kernels.py $f --steps 4 --title "global BA stress (200 keyframes, 1200 edges, 30x40): update_lowmem step" > $OUT/stress_kernel_stats.md 2>> $OUT/summarize.err
+find $OUT -name '*.csv' -delete
+PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum" timeout 600 bash $R/tools/pmc_pass.sh $OUT/pmc_neus _kernel -- python $R/tools/profile_mapping.py train 3 > $OUT/pmc_neus.log 2>&1
+[ -x $R/tools/chol_bench ] && timeout 120 $R/tools/chol_bench 150 192 198 294 300 306 342 360 450 456 > $OUT/chol_bench.txt 2>&1
+head -8 $OUT/tracking_kernel_stats.md; head -8 $OUT/stress_kernel_stats.md; head -4 $OUT/motion_filter_kernel_stats.md; tail -3 $OUT/summarize.err; tail -12 $OUT/chol_bench.txt
