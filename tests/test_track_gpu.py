@@ -672,11 +672,12 @@ def test_oversized_batches_raise(db, dev):
         db.corr_index_forward(vol, torch.zeros(n, 2, h, w, device=dev), 3)
 
 
-@pytest.mark.parametrize("hw,expect_fused", [((16, 32), True), ((16, 96), True), ((8, 104), False), ((12, 20), False)])
+@pytest.mark.parametrize("hw,expect_fused", [((16, 32), True), ((16, 96), True), ((12, 20), True), ((8, 104), False),
+                                             ((12, 18), False)])
 def test_corrblock_matches_oracle_on_fused_and_fallback_shapes(O, dev, hw, expect_fused):
-    """CorrBlock (build + 4-level lookup) vs the oracle at a shape the fused MFMA builder covers and at two it does
-    not (width > 96, width not a multiple of 8: library GEMM + avg_pool2d on the GPU, announced by a RuntimeWarning, then the
-    same HIP lookup)."""
+    """CorrBlock (build + 4-level lookup) vs the oracle at shapes the fused MFMA builder covers (w % 8 == 4 included since
+    round 5) and at two it does not (width > 96, width not a multiple of 4: library GEMM + avg_pool2d on the GPU, announced
+    by a RuntimeWarning, then the same HIP lookup)."""
     from go_slam_amd import droid_backends as db
     from go_slam_amd.corr import CorrBlock
     h, w = hw
