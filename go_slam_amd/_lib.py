@@ -50,6 +50,8 @@ SIGNATURES = {
     "gs_bias_act": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "gs_motion_features": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "gs_ba_inputs": (c_int, [_P] * 6 + [c_int, c_int, c_int, _P]),
+    "gs_lowmem_gather": (c_int, [_P] * 7 + [c_int, c_int, c_int, _P]),
+    "gs_lowmem_scatter": (c_int, [_P] * 8 + [c_int, c_int, c_int, _P]),
     "gs_damping_rows": (c_int, [_P] * 5 + [c_int, c_int, c_float, c_float, _P]),
     "gs_conv1x1": (c_int, [_P, c_int, c_int, _P, _P, c_int, _P, c_int, c_int, ctypes.c_longlong, _P]),
     "gs_conv7x7_c4": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -459,7 +459,11 @@ class FactorGraph:
                   "corr_jj": (rig * jjs + (iis == jjs).long()).to(dev), "uniq": torch.unique(iis, sorted=True).to(dev)}
             seg = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in build_segments(iis).items()}
             ck["seg_kw"] = {"seg": seg} if getattr(self.update_op, "_forward_fast", None) is not None else {}
-            ck["inp"] = (lambda ix=ck["ii"]: self._fmt(self.video.inps[ix]).unsqueeze(0))
+            # (the chunk's context features are per-keyframe constants: gathered and laid out once per edge set -- the
+            # index cache is rebuilt whenever an edge list or, through rm_keyframe, a keyframe slot changes -- instead of
+            # once per step and chunk; 23 MB per chunk at 30 x 40)
+            ck["inp"] = (lambda ix=ck["ii"], box=ck: box.setdefault(
+                "inp_cached", self._fmt(self.video.inps[ix]).unsqueeze(0)))
             chunks.append(ck)
         c = {"key": key, "tens": tens, "t0": a0, "t1": a1, "chunks": chunks, "ii": self.ii.contiguous(),
              "jj": self.jj.contiguous(),
@@ -482,23 +486,53 @@ class FactorGraph:
         idx = self._lowmem_index(t0, t1, rig)
         t0, t1 = idx["t0"], idx["t1"]
         ii_all, jj_all = idx["ii"], idx["jj"]
+        cl = torch.channels_last
         for _ in range(steps):
             coords1, mask = self.video.reproject(ii_all, jj_all)
-            motion = torch.cat([coords1 - self.coords0, self.target - coords1], dim=-1)
-            motion = motion.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
+            # the chunk glue as ONE gather and ONE scatter launch (csrc/lowmem_glue.hip) when the state is in the layouts the
+            # kernels read: fp32 contiguous coordinates / targets / weights, fp16 NHWC recurrent state
+            fast = (coords1.is_cuda and self.channels_last and coords1.dtype == torch.float32 and coords1.is_contiguous()
+                    and self.target.dtype == torch.float32 and self.target.is_contiguous()
+                    and self.weight.dtype == torch.float32 and self.weight.is_contiguous()
+                    and self.net.dtype == torch.float16 and self.net[0].is_contiguous(memory_format=cl)
+                    and tuple(self.target.shape) == tuple(coords1.shape) == tuple(self.weight.shape))
+            if fast:
+                from . import _lib
+                L, st = _lib.lib(), _lib.stream_ptr(self.device)
+                ht, wd = self.ht, self.wd
+            else:
+                motion = torch.cat([coords1 - self.coords0, self.target - coords1], dim=-1)
+                motion = motion.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
             for ck in idx["chunks"]:                    # 13 source keyframes at a time
                 sel, iis, jjs = ck["sel"], ck["ii"], ck["jj"]
-                c1 = coords1.index_select(1, sel)
+                if fast:
+                    n = sel.numel()
+                    c1 = torch.empty(1, n, ht, wd, 2, dtype=torch.float32, device=self.device)
+                    m4 = torch.empty(n, ht, wd, 4, dtype=torch.float16, device=self.device)
+                    net_c = torch.empty(n, ht, wd, 128, dtype=torch.float16, device=self.device)
+                    _lib.check(L.gs_lowmem_gather(_lib.ptr(coords1), _lib.ptr(self.target), _lib.ptr(self.net),
+                                                  _lib.ptr(sel), _lib.ptr(c1), _lib.ptr(m4), _lib.ptr(net_c), n, ht, wd, st),
+                               "lowmem_gather")
+                    net_in = net_c.permute(0, 3, 1, 2).unsqueeze(0)          # logical [1,n,128,h,w], NHWC memory
+                    motion_c = m4.permute(0, 3, 1, 2).unsqueeze(0)           # logical [1,n,4,h,w], NHWC memory
+                else:
+                    c1 = coords1.index_select(1, sel)
+                    net_in, motion_c = self._select_edges(self.net, sel), motion.index_select(1, sel)
                 corr1 = lookup(c1, ck["corr_ii"], ck["corr_jj"])
                 with torch.autocast("cuda", dtype=torch.float16):
                     net, delta, weight, damping, upmask = self.update_op(
-                        self._select_edges(self.net, sel), ck["inp"](), corr1, motion.index_select(1, sel), iis, jjs,
-                        **ck["seg_kw"])
+                        net_in, ck["inp"](), corr1, motion_c, iis, jjs, **ck["seg_kw"])
                     if self.upsample:
                         self.video.upsample(ck["uniq"], upmask[0])
-                self.net[:, sel] = net.to(self.net.dtype)
-                self.target[:, sel] = c1 + delta.float()
-                self.weight[:, sel] = weight.float()
+                if fast and net.dtype == torch.float16 and net[0].is_contiguous(memory_format=cl) \
+                        and delta.dtype == torch.float32 and weight.dtype == torch.float32:
+                    _lib.check(L.gs_lowmem_scatter(_lib.ptr(c1), _lib.ptr(delta.contiguous()), _lib.ptr(weight.contiguous()),
+                                                   _lib.ptr(net), _lib.ptr(sel), _lib.ptr(self.target), _lib.ptr(self.weight),
+                                                   _lib.ptr(self.net), sel.numel(), ht, wd, st), "lowmem_scatter")
+                else:
+                    self.net[:, sel] = net.to(self.net.dtype)
+                    self.target[:, sel] = c1 + delta.float()
+                    self.weight[:, sel] = weight.float()
                 self.damping[ck["uniq"]] = damping.float()
             damping = 0.2 * self.damping[idx["damping_index"]].contiguous() + EPS
             target = self.target.view(-1, self.ht, self.wd, 2).permute(0, 3, 1, 2).contiguous()

@@ -185,6 +185,19 @@ int gs_bias_act(const void* x, const float* bias, void* y, int rows, int channel
  * clamp([coords1 - pixel grid, target - coords1], -64, 64), coords1 / target f32 [n,h,w,2].            */
 int gs_motion_features(const float* coords1, const float* target, void* out, int n, int h, int w,
                        gs_stream_t stream);
+/* The per-chunk glue of FactorGraph.update_lowmem (src/factor_graph.py:283-312), one launch each instead of ~11 torch
+ * launches per chunk of 13 source keyframes:
+ *   gs_lowmem_gather: rows sel[r] (i64 [n_sel], edge indices) of coords1 / target f32 [E,h,w,2] and net f16 [E,h,w,128]
+ *     (NHWC) -> coords_out f32 [n_sel,h,w,2] (= coords1[:, v]), motion_out f16 [n_sel,h,w,4] (= clamp([coords1 - grid,
+ *     target - coords1], +-64): gs_motion_features of the chunk), net_out f16 [n_sel,h,w,128] (= self.net[:, v]).
+ *   gs_lowmem_scatter: target[sel[r]] = coords + delta, weight_all[sel[r]] = weight (all f32 [.,h,w,2]),
+ *     net[sel[r]] = net_new (f16 NHWC) -- the three masked assignments of :308-310.  sel must not repeat an index.     */
+int gs_lowmem_gather(const float* coords1, const float* target, const void* net, const int64_t* sel,
+                     float* coords_out, void* motion_out, void* net_out, int n_sel, int h, int w, gs_stream_t stream);
+int gs_lowmem_scatter(const float* coords, const float* delta, const float* weight, const void* net_new,
+                      const int64_t* sel, float* target, float* weight_all, void* net, int n_sel, int h, int w,
+                      gs_stream_t stream);
+
 /* FactorGraph.update glue (src/factor_graph.py:222-223,244-247): target [n,h,w,2] = coords1 + delta, plus
  * the [n,2,h,w] copies of target and weight that droid_backends.ba takes (ba_target / ba_weight point at
  * the first of these n edges inside the caller's [E_all,2,h,w] buffers).  All f32.                    */

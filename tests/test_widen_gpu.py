@@ -987,3 +987,45 @@ def test_motion_filter_track_issues_no_library_convolution(built_lib):
         torch.nn.functional.conv2d = real
     assert not calls, f"library convolutions were called on {calls}"
     assert video.counter.value == 1
+
+
+def test_lowmem_chunk_glue_equals_the_torch_indexing_it_replaces(built_lib):
+    """gs_lowmem_gather / gs_lowmem_scatter (csrc/lowmem_glue.hip) vs the reference's formulation of update_lowmem's
+    per-chunk glue (src/factor_graph.py:283-312): `coords1[:, v]`, `self.net[:, v]`, the chunk's motion features, and the
+    three masked assignments after the operator -- bit for bit (pure copies, one fp32 add, the fp16 cast of the motion
+    features), on a ragged map (30 x 40 = 18.75 blocks of 64 pixels) and an unsorted edge selection."""
+    from go_slam_amd import _lib
+    from go_slam_amd.factor_graph import coords_grid
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(901)
+    E, h, w = 23, 30, 40
+    coords1 = (torch.rand(1, E, h, w, 2, generator=g) * 50 - 5).to(dev)
+    target = (torch.rand(1, E, h, w, 2, generator=g) * 300 - 100).to(dev)       # some differences beyond the +-64 clamp
+    weight = torch.rand(1, E, h, w, 2, generator=g).to(dev)
+    net = torch.randn(E, 128, h, w, generator=g).half().to(dev).contiguous(memory_format=torch.channels_last)[None]
+    sel = torch.tensor([17, 3, 22, 0, 9, 10, 4], device=dev)
+    n = sel.numel()
+    st = _lib.stream_ptr(dev)
+    c1 = torch.empty(1, n, h, w, 2, device=dev)
+    m4 = torch.empty(n, h, w, 4, dtype=torch.float16, device=dev)
+    net_c = torch.empty(n, h, w, 128, dtype=torch.float16, device=dev)
+    _lib.check(L.gs_lowmem_gather(_lib.ptr(coords1), _lib.ptr(target), _lib.ptr(net), _lib.ptr(sel), _lib.ptr(c1),
+                                  _lib.ptr(m4), _lib.ptr(net_c), n, h, w, st), "gather")
+    grid = coords_grid(h, w, dev)
+    motion = torch.cat([coords1 - grid, target - coords1], dim=-1).permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
+    assert torch.equal(c1, coords1.index_select(1, sel))
+    assert torch.equal(m4.permute(0, 3, 1, 2)[None], motion.index_select(1, sel).half())
+    assert torch.equal(net_c.permute(0, 3, 1, 2)[None], net.index_select(1, sel))
+    # scatter
+    delta = torch.randn(1, n, h, w, 2, generator=g).to(dev)
+    wnew = torch.rand(1, n, h, w, 2, generator=g).to(dev)
+    net_new = torch.randn(n, 128, h, w, generator=g).half().to(dev).contiguous(memory_format=torch.channels_last)[None]
+    t_ref, w_ref, n_ref = target.clone(), weight.clone(), net.clone()
+    t_ref[:, sel] = c1 + delta
+    w_ref[:, sel] = wnew
+    n_ref[:, sel] = net_new
+    _lib.check(L.gs_lowmem_scatter(_lib.ptr(c1), _lib.ptr(delta), _lib.ptr(wnew), _lib.ptr(net_new), _lib.ptr(sel),
+                                   _lib.ptr(target), _lib.ptr(weight), _lib.ptr(net), n, h, w, st), "scatter")
+    torch.cuda.synchronize()
+    assert torch.equal(target, t_ref) and torch.equal(weight, w_ref) and torch.equal(net, n_ref)
