@@ -42,9 +42,13 @@ __device__ __forceinline__ bool lvl_prereduce(float (&gacc)[8][2], const uint32_
     const unsigned long long starts = ~same_mask;     // bit set where a run begins
     const unsigned long long below = starts & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
     const int run_start = 63 - __builtin_clzll(below);
+    // (the scan stops as soon as no lane reaches back `off` lanes inside its run -- i.e. after ceil(log2(longest run)) of
+    // the 6 doubling steps: skipping a step in which no lane takes anything changes nothing, and at the fine levels, where
+    // runs are 2-3 lanes long, it saves 64-80 of the 96 cross-lane moves the backward's ISA count shows per level)
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const bool take = (lane - off) >= run_start;
+      if (__ballot(take) == 0ull) break;            // wave-uniform
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const float u0 = __shfl_up(gacc[c][0], off, 64), u1 = __shfl_up(gacc[c][1], off, 64);
