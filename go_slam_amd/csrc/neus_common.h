@@ -32,9 +32,17 @@ __device__ __forceinline__ uint32_t grid_index(const gs_grid_meta& m, int l, uin
 typedef _Float16 half2a __attribute__((ext_vector_type(2)));
 // Runs of consecutive lanes in the same cell: inclusive segmented sum of the 8 x 2 corner contributions; returns
 // whether this lane is the LAST of its run (the one that holds the run's total and emits it).
+// value of the lane below (lane 0: its own) -- DPP wave_shr:1, one full-rate VALU move instead of the address arithmetic +
+// ds_bpermute + LDS-return wait of __shfl_up(v, 1): the neighbour test and the scan's first (and at the fine levels only)
+// step use 20 of them per level
+__device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ float wave_shr1(float v) {
+  return __builtin_bit_cast(float, wave_shr1(__builtin_bit_cast(int, v)));
+}
+
 __device__ __forceinline__ bool lvl_prereduce(float (&gacc)[8][2], const uint32_t (&gi)[3], bool on, int lane) {
-  const uint32_t p0 = __shfl_up(gi[0], 1, 64), p1 = __shfl_up(gi[1], 1, 64), p2 = __shfl_up(gi[2], 1, 64);
-  const int on_prev = __shfl_up((int)on, 1, 64);
+  const uint32_t p0 = (uint32_t)wave_shr1((int)gi[0]), p1 = (uint32_t)wave_shr1((int)gi[1]), p2 = (uint32_t)wave_shr1((int)gi[2]);
+  const int on_prev = wave_shr1((int)on);
   const bool same = (lane > 0) && on && on_prev && p0 == gi[0] && p1 == gi[1] && p2 == gi[2];
   const unsigned long long same_mask = __ballot(same);
   bool tail = true;
@@ -51,7 +59,8 @@ __device__ __forceinline__ bool lvl_prereduce(float (&gacc)[8][2], const uint32_
       if (__ballot(take) == 0ull) break;            // wave-uniform
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const float u0 = __shfl_up(gacc[c][0], off, 64), u1 = __shfl_up(gacc[c][1], off, 64);
+        const float u0 = off == 1 ? wave_shr1(gacc[c][0]) : __shfl_up(gacc[c][0], off, 64);
+        const float u1 = off == 1 ? wave_shr1(gacc[c][1]) : __shfl_up(gacc[c][1], off, 64);
         if (take) { gacc[c][0] += u0; gacc[c][1] += u1; }
       }
     }
