@@ -370,8 +370,9 @@ def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768, s
             mine = torch.tensor([step2, ex["total"] / steps, ex["reduce_scatter_and_dense_allreduce"] / steps,
                                  ex["clip_norm_allreduce"] / steps, ex["all_gather_wait"] / steps],
                                 device=device, dtype=torch.float64)
-            allr = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(allr, mine)
+            allr = torch.zeros(world, mine.numel(), device=device, dtype=torch.float64)   # (all_reduce of a one-hot-row
+            allr[rank] = mine                                                             # matrix: works on RCCL and gloo)
+            dist.all_reduce(allr)
             rows = [[round(float(v), 4) for v in r] for r in allr]
             exch = {"columns": ["step_ms", "exposed_exchange_ms", "reduce_scatter+dense_allreduce_ms", "clip_norm_allreduce_ms",
                                 "all_gather_wait_ms"], "per_rank": rows,
