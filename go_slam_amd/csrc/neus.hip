@@ -20,6 +20,7 @@
 #include "common.h"
 #include "neus_common.h"
 #include <math.h>
+#include <atomic>
 
 namespace {
 
@@ -1009,7 +1010,6 @@ NeusWs carve_neus(void* base, int n, int s) {
 
 // crossover of the two gather orders, in sample points (gs_neus_level_major_min_points sets it: tests run both orders on
 // small batches, tools measure the crossover)
-#include <atomic>
 static std::atomic<int> g_level_major_min_points{512 * 1024};
 static int level_major_min_points() { return g_level_major_min_points.load(std::memory_order_relaxed); }
 extern "C" int gs_neus_level_major_min_points(int points) {
