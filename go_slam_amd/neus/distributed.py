@@ -39,16 +39,23 @@ def _gloo_on_device(t, group):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def reduce_scatter_sum_(out, inp, group=None):
+def reduce_scatter_sum_(out, inp, group=None, async_op=False):
     """out[i] = sum over ranks of inp[rank * len(out) + i] -- RCCL reduce-scatter over xGMI: every rank ends up with the
-    summed 1/G slice it owns (the sharded optimiser's input), moving (G-1)/G of the buffer once instead of twice."""
+    summed 1/G slice it owns (the sharded optimiser's input), moving (G-1)/G of the buffer once instead of twice.
+    `async_op`: only enqueued (on RCCL's stream, behind what the current stream has issued so far); the returned callable
+    makes the current stream wait for it."""
     if _gloo_on_device(inp, group):
         h = torch.empty(out.shape, dtype=out.dtype)
-        dist.reduce_scatter_tensor(h, inp.cpu(), op=dist.ReduceOp.SUM, group=group)
+        work = dist.reduce_scatter_tensor(h, inp.cpu(), op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if async_op:
+            def finish():
+                work.wait()
+                out.copy_(h)
+            return finish
         out.copy_(h)
         return out
-    dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)
-    return out
+    work = dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return work.wait if async_op else out
 
 
 def all_gather_into_(full, part, group=None, async_op=False):
@@ -76,6 +83,8 @@ class ExchangeTimer:
     all-gather that wait sits at the head of the NEXT step, behind the host-side preparation it overlaps with).  What a
     multi-GPU bench line reports next to the step time so that a scaling run diagnoses itself."""
 
+    # (rs0 is marked where the stream starts to WAIT for the reduce-scatter: with the early start -- under the Gram / post
+    # kernels -- that is the dense all-reduce behind them, not the point where the collective was enqueued)
     PAIRS = (("rs0", "rs1", "reduce_scatter_and_dense_allreduce"), ("n0", "n1", "clip_norm_allreduce"),
              ("agw0", "agw1", "all_gather_wait"))
 

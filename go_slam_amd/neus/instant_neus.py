@@ -383,7 +383,7 @@ class _NeusRenderFn(torch.autograd.Function):
 
 
 def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d_normal, d_wsum, d_sdf, d_gerr,
-                       inv_s_dev=None, var_dev=None, grid_acc_out=None, raw_dense=None):
+                       inv_s_dev=None, var_dev=None, grid_acc_out=None, raw_dense=None, after_table=None):
     """The HIP backward of the fused renderer: upstream gradients of the ray outputs -> gradients of every trained
     parameter.  Returns a dict: grid_acc (the raw table gradient: fp32, or tiny-cuda-nn's loss-scaled fp16 form with
     `grid_scale`), sdf_w, sdf_b, cB, mlp, var (fp32).  Used by the autograd Function above and, without any autograd
@@ -476,6 +476,8 @@ def _neus_backward_raw(model, S, inputs, inv_s, var, d_color, d_depth, d_dvar, d
                                            d_arg.data_ptr(), pts.data_ptr(), 0, LS, 160, _lib.ptr(d_invs), n, s,
                                            _lib.ptr(S.get("enc_aux")), st)
     _lib.check(rc, "InstantNeuS.backward(points)")
+    if after_table is not None:     # the table gradient is complete: a sharded step starts its reduce-scatter here, under
+        after_table()               # the Gram / post kernels that follow (neus/mapper.py)
     gram = torch.empty(L.gs_map_gram_blocks(np_pad), 40, 160, **f32)
     with torch.cuda.device(dev):
         _lib.check(L.gs_map_gram(_lib.ptr(rows), np_pad, _lib.ptr(gram), st), "map_gram")

@@ -131,6 +131,7 @@ class FlatAdamW:
         self.steps = 0
         self.overlap_gather = True          # world > 1: the all-gather of the updated table is waited for by its next reader
         self._gather_wait = None
+        self._rs_wait = None                # world > 1: the reduce-scatter started under the backward's last kernels
         self._exchange_timer = None         # bench.py: ExchangeTimer (events around the collectives on the step's stream)
         self._publish()
 
@@ -189,8 +190,12 @@ class FlatAdamW:
             t = self._exchange_timer
             if t is not None:
                 t.mark("rs0")
-            reduce_scatter_sum_(self.g16s, self.G16, self.group)
+            early, self._rs_wait = self._rs_wait, None
+            if early is None:
+                reduce_scatter_sum_(self.g16s, self.G16, self.group)
             all_reduce_sum_(self.g32, self.group)
+            if early is not None:       # started under the Gram / post kernels (begin_reduce_scatter): enqueued before the
+                early()                 # dense all-reduce on the one communicator, so it is complete by now
             if t is not None:
                 t.mark("rs1")
             K.sqnorm(self.sqnorm, self.g16s, inv_scale16, self.g32[:nd] if self.rank == 0 else None)
@@ -221,6 +226,14 @@ class FlatAdamW:
         self._publish()
         if self._gather_wait is not None:
             self.grid_module._half._pending = self.wait_gather
+
+    def begin_reduce_scatter(self):
+        """start the reduce-scatter of the fp16 table gradient NOW (it is complete: the bin reduce has run) instead of at
+        the head of step(): the Gram and post kernels of the backward then run beside it.  Every rank calls this at the same
+        point of its step, so the collectives are enqueued in the same order everywhere."""
+        if self.world > 1 and self._rs_wait is None:
+            from .distributed import reduce_scatter_sum_
+            self._rs_wait = reduce_scatter_sum_(self.g16s, self.G16, self.group, async_op=True)
 
     def wait_gather(self):
         """make the current stream wait for the deferred all-gather of the fp16 table (no-op when none is in flight)"""
@@ -306,7 +319,7 @@ class MapTrainer:
             raise RuntimeError("MapTrainer: model.realtime_bound must be a contiguous fp32 buffer on the rays' device")
         return rb
 
-    def _local_gradients(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand, counts, bufs=None):
+    def _local_gradients(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand, counts, bufs=None, after_table=None):
         """THIS RANK's rays: sample + forward + loss kernel + HIP backward, no autograd graph, no collective, no host
         sync.  `counts` = [valid rays, rays, max depth] over ALL ranks (device fp32[3]) or None (single rank: computed
         here).  Leaves the loss-scaled fp16 table gradient in flat.G16, the dense gradients in flat.g32[:nd] and this
@@ -351,7 +364,7 @@ class MapTrainer:
         _lib.check(rc, "mapping_loss")
         g = _neus_backward_raw(model, saved, (rays_o, rays_d, z_vals, dists, sdf, zmid), 0.0, 0.0,
                                d_color, d_depth, None, None, None, d_sdf, B["d_gerr"][:n], inv_s_dev=inv_s_dev,
-                               var_dev=var_dev, grid_acc_out=flat.grad_table(), raw_dense=B)
+                               var_dev=var_dev, grid_acc_out=flat.grad_table(), raw_dense=B, after_table=after_table)
         gram, part = g["gram"], g["mlp_partial"]
         with torch.cuda.device(dev):
             _lib.check(L.gs_map_step_post(_lib.ptr(gram), gram.shape[0], 1.0 / float(g["loss_scale"]), _lib.ptr(part),
@@ -402,12 +415,12 @@ class MapTrainer:
             return ent
         if len(self._graphs) >= MAX_GRAPHS:                 # evict the least recently used graph (dict order = use order)
             old = self._graphs.pop(next(iter(self._graphs)))
-            old["graph"] = None
+            old["graph"] = old["tail"] = None
         dev = args[0].device
         static = [torch.empty_like(a) for a in args]
         s_counts = torch.zeros(3, dtype=torch.float32, device=dev) if counts is None else torch.empty_like(counts)
         s_pr = None if perturb_rand is None else torch.empty_like(perturb_rand.detach().float().contiguous())
-        ent = dict(static=static, counts=s_counts, pr=s_pr, graph=None, inv_scale=None, warm=0,
+        ent = dict(static=static, counts=s_counts, pr=s_pr, graph=None, tail=None, inv_scale=None, warm=0,
                    bufs=self._step_buffers(args[0].shape[0], dev), rt_bound=self.model.realtime_bound)
         self._graphs[key] = ent
         return ent
@@ -417,9 +430,10 @@ class MapTrainer:
         flat.check_bindings()
         counts = self._counts(rays_depth)
         args = self._prepare(rays_o, rays_d, rays_color, rays_depth)
+        early = flat.begin_reduce_scatter if self.world > 1 else None     # (the reduce-scatter starts under Gram + post)
         if not self.graph or args[0].shape[0] == 0:
             flat.wait_gather()
-            inv_scale = self._local_gradients(*args, perturb_rand, counts)
+            inv_scale = self._local_gradients(*args, perturb_rand, counts, after_table=early)
             flat.step(inv_scale, prepped=True)
             return self._global_loss()
         if perturb_rand is None and self.renderer.perturb > 0:      # drawn OUTSIDE the graph: a replay must see new values
@@ -439,15 +453,16 @@ class MapTrainer:
         flat.wait_gather()                  # (world > 1) the previous step's table all-gather ran beside everything above
         whole = self.world == 1             # single GPU: the optimiser's two launches are part of the graph
 
-        def body():
-            inv = self._local_gradients(*ent["static"], ent["pr"], None if whole else ent["counts"], bufs=ent["bufs"])
+        def body(after_table=None):
+            inv = self._local_gradients(*ent["static"], ent["pr"], None if whole else ent["counts"], bufs=ent["bufs"],
+                                        after_table=after_table)
             if whole:
                 flat.step(inv, prepped=True)
             return inv
         if ent["graph"] is None:
             if ent["warm"] < 2:             # eager first (workspaces, fp16 caches, lazy library state), then capture
                 ent["warm"] += 1
-                inv = body()
+                inv = body(early)
                 if not whole:
                     flat.step(inv, prepped=True)
                 return self._global_loss()
@@ -455,8 +470,28 @@ class MapTrainer:
             graph = torch.cuda.CUDAGraph()
             # thread-local capture: with world > 1 RCCL's watchdog thread polls events while this thread captures, which a
             # global-mode capture would treat as an illegal call
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                ent["inv_scale"] = body()
+            if whole:
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    ent["inv_scale"] = body()
+            else:
+                # world > 1: TWO graphs sharing one memory pool, cut where the table gradient is complete (after the bin
+                # reduce): [sample ... backward pass 1 + bin reduce] | [Gram + post].  The reduce-scatter is enqueued
+                # between their replays and runs beside the second.
+                tail = torch.cuda.CUDAGraph()
+                dev = ent["static"][0].device
+                torch.cuda.synchronize(dev)
+                cap = torch.cuda.Stream(device=dev)
+                cap.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(cap):
+                    graph.capture_begin(capture_error_mode="thread_local")
+
+                    def cut():
+                        graph.capture_end()
+                        tail.capture_begin(pool=graph.pool(), capture_error_mode="thread_local")
+                    ent["inv_scale"] = body(cut)
+                    tail.capture_end()
+                torch.cuda.current_stream(dev).wait_stream(cap)
+                ent["tail"] = tail
             ent["graph"] = graph
             flat.steps = steps_before       # capture ran nothing: the replay below is the step
         ent["graph"].replay()
@@ -464,6 +499,8 @@ class MapTrainer:
             flat.steps += 1                 # (the device-side count was advanced inside the graph)
             flat._publish()
         else:
+            flat.begin_reduce_scatter()
+            ent["tail"].replay()
             flat.step(ent["inv_scale"], prepped=True)
         return self._global_loss()
 
