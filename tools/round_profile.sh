@@ -35,7 +35,7 @@ for leg in train train_weak render; do
 done
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_mf -o t -- python $R/tools/profile_motion_filter.py 20 > $OUT/prof_mf.log 2>&1 || echo "prof mf failed"
 f=$(find $OUT/prof_mf -name '*kernel_trace.csv' | head -1)
-python $R/tools/summarize_kernels.py $f --steps 20 --title "MotionFilter.track, one 480x640 RGB-D input frame (20 frames + one-off setup: model init, first keyframe)" > $OUT/motion_filter_kernel_stats.md 2>> $OUT/summarize.err
+python $R/tools/summarize_kernels.py $f --steps 20 --after erfinv --title "MotionFilter.track, one 480x640 RGB-D input frame (20 steady-state frames; setup and warm frames excluded by the marker launch)" > $OUT/motion_filter_kernel_stats.md 2>> $OUT/summarize.err
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_stress -o t -- python $R/tools/profile_stress.py 4 > $OUT/prof_stress.log 2>&1 || echo "prof stress failed"
 f=$(find $OUT/prof_stress -name '*kernel_trace.csv' | head -1)
 python $R/tools/summarize_kernels.py $f --steps 4 --title "global BA stress (200 keyframes, 1200 edges, 30x40): update_lowmem step" > $OUT/stress_kernel_stats.md 2>> $OUT/summarize.err

@@ -20,8 +20,14 @@ def main():
     ap.add_argument("--steps", type=int, required=True)
     ap.add_argument("--title", default="")
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--after", default="", help="count only the dispatches after the LAST kernel whose name contains this "
+                                                "substring (a marker launch that separates one-off setup from the steps)")
     a = ap.parse_args()
-    rows = list(csv.DictReader(open(a.trace)))
+    rows = sorted(csv.DictReader(open(a.trace)), key=lambda r: int(r["Start_Timestamp"]))
+    if a.after:
+        marks = [i for i, r in enumerate(rows) if a.after in r["Kernel_Name"]]
+        if marks:
+            rows = rows[marks[-1] + 1:]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in rows:
         e = agg[short(r["Kernel_Name"])]
