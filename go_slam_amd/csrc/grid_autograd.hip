@@ -58,8 +58,7 @@ __global__ __launch_bounds__(256) void grid_backward_kernel(GridBwdArgs A, gs_gr
       f[d] = pos - fl;
     }
     uint32_t cidx[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) cidx[c] = grid_index(m, l, g[0] + (c & 1), g[1] + ((c >> 1) & 1), g[2] + ((c >> 2) & 1));
+    grid_corners(m, l, g, cidx);
     float dyl[2];
     if (A.dy16) {
       const _Float16* p = reinterpret_cast<const _Float16*>(A.dy) + (size_t)ii * 32 + 2 * l;

@@ -214,10 +214,11 @@ __device__ __forceinline__ void grid_level(const gs_grid_meta& m, int l, const _
   }
   const _Float16* tab = grid + (size_t)m.offset[l] * 2;
   float v[8][2];
+  uint32_t cidx[8];
+  grid_corners(m, l, g, cidx);
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    const uint32_t idx = grid_index(m, l, g[0] + (c & 1), g[1] + ((c >> 1) & 1), g[2] + ((c >> 2) & 1));
-    const uint32_t raw = *reinterpret_cast<const uint32_t*>(tab + (size_t)idx * 2);
+    const uint32_t raw = *reinterpret_cast<const uint32_t*>(tab + (size_t)cidx[c] * 2);
     v[c][0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw & 0xffffu));
     v[c][1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw >> 16));
   }
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       for (int k = 0; k < 8; ++k) {
         const int c = q * 8 + k;
         float v;
-        if (c < 33) v = sinf((pt[0] * A.color_B[c] + pt[1] * A.color_B[33 + c]) + pt[2] * A.color_B[66 + c]);
+        if (c < 33) v = emb_sin((pt[0] * A.color_B[c] + pt[1] * A.color_B[33 + c]) + pt[2] * A.color_B[66 + c]);
         else if (c < 36) v = grad[c - 33];
         else if (c < 67) v = out[1 + (c - 36)];
         else v = 1.0f;

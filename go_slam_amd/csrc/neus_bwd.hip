@@ -334,9 +334,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
     if constexpr (AUX) {   // the forward kept this level's encoding and d enc / d x: one coalesced 16-byte load, no gathers
       // (requesting the next level's record here, one level ahead, was measured: 5 % slower at both batch sizes)
       rec = *reinterpret_cast<const half8*>(A.enc_aux + ((size_t)l * (size_t)np + i) * 8);
+      grid_corners(m, l, gi, cidx);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        cidx[c] = grid_index(m, l, gi[0] + (c & 1), gi[1] + ((c >> 1) & 1), gi[2] + ((c >> 2) & 1));
         float w = 1.0f;
 #pragma unroll
         for (int d = 0; d < 3; ++d) w = w * (((c >> d) & 1) ? f[d] : (1.0f - f[d]));
@@ -345,9 +345,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
       e0 = on ? (float)rec[0] : 0.0f;          // (out-of-bound points have no record: select, never multiply)
       e1 = on ? (float)rec[1] : 0.0f;
     } else {
+      grid_corners(m, l, gi, cidx);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        cidx[c] = grid_index(m, l, gi[0] + (c & 1), gi[1] + ((c >> 1) & 1), gi[2] + ((c >> 2) & 1));
         const uint32_t raw = *reinterpret_cast<const uint32_t*>(A.grid + (off + cidx[c]) * 2);
         v[c][0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw & 0xffffu));
         v[c][1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw >> 16));
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
         const int c = c0 + e;
         const int cc = c < 33 ? c : 32;
         const float arg = (pt[0] * cB[cc] + pt[1] * cB[33 + cc]) + pt[2] * cB[66 + cc];
-        da[e] = c < 33 ? dxe[e] * cosf(arg) * live * rs : 0.0f;
+        da[e] = c < 33 ? dxe[e] * emb_cos(arg) * live * rs : 0.0f;
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) trow[16 + (c0 >> 1) + e] = pack2h(da[2 * e], da[2 * e + 1]);
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
 #pragma unroll
     for (int c = 0; c < 33; ++c) {
       const float arg = (pt[0] * cB[c] + pt[1] * cB[33 + c]) + pt[2] * cB[66 + c];
-      st_row(A.d_arg, false, (size_t)i * 33 + c, dxe[c] * cosf(arg) * live * rs);
+      st_row(A.d_arg, false, (size_t)i * 33 + c, dxe[c] * emb_cos(arg) * live * rs);
     }
   }
   // one atomic per workgroup for d inv_s

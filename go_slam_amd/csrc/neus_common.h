@@ -6,6 +6,22 @@
 
 namespace {
 
+// sin / cos of a Fourier-feature argument (InstantNeuS.py:64,72,177,196: `torch.sin(x @ _B)`, _B = 25 * randn -- arguments
+// of a few hundred radians).  The forward rounds the value to fp16 at once (it is a colour-MLP input) and the backward's
+// d arg row is fp16 as well, so libm's sinf / cosf -- ~40 VALU instructions each on its small-argument path, 33 per point:
+// a quarter of the forward point stage's arithmetic -- buy nothing: two-term Cody-Waite reduction to [-pi, pi]
+// (k * 6.28125 is exact for |k| < 2^16, the remainder of 2 pi follows in a second fma: reduction error < 3e-7 rad for
+// |x| < 1e4) and the hardware's v_sin_f32 / v_cos_f32 (argument in revolutions): 6 instructions, |error| < 2e-6 against
+// libm on [-1e3, 1e3] (tests/test_neus_gpu.py::test_embedding_sine_*), i.e. below 1 / 100 of an fp16 ulp at 1.
+__device__ __forceinline__ float emb_reduce(float x) {
+  const float k = __builtin_rintf(x * 0.15915494309189535f);
+  float r = fmaf(-k, 6.28125f, x);
+  r = fmaf(-k, 1.9353071795864769e-3f, r);
+  return r * 0.15915494309189535f;                  // revolutions, |.| <= 1/2 (+ rounding)
+}
+__device__ __forceinline__ float emb_sin(float x) { return __builtin_amdgcn_sinf(emb_reduce(x)); }
+__device__ __forceinline__ float emb_cos(float x) { return __builtin_amdgcn_cosf(emb_reduce(x)); }
+
 __device__ __forceinline__ uint32_t grid_index(const gs_grid_meta& m, int l, uint32_t cx, uint32_t cy, uint32_t cz) {
   const uint32_t size = m.size[l];
   uint32_t idx;
@@ -20,6 +36,36 @@ __device__ __forceinline__ uint32_t grid_index(const gs_grid_meta& m, int l, uin
   // point, a third of a level's arithmetic) only runs when it has to.  Same result in every case.
   if ((size & (size - 1u)) == 0u) return idx & (size - 1u);
   return idx < size ? idx : idx % size;
+}
+
+// The 8 corner indices of one cell, corner c = (c & 1, (c >> 1) & 1, (c >> 2) & 1) -- the same values as eight
+// grid_index calls (uint32 arithmetic is a ring: (cy + 1) * P == cy * P + P), with the level's kind decided ONCE instead of
+// inside every corner: a hashed level costs 2 multiplications + 2 additions + 12 xors + 8 masks instead of 16
+// multiplications (v_mul_lo_u32 is a quarter-rate instruction) + 16 xors + 8 masks + 12 corner additions and five uniform
+// branches per corner; a dense level is the base index plus the uniform strides 1 / res / res^2.
+__device__ __forceinline__ void grid_corners(const gs_grid_meta& m, int l, const uint32_t (&g)[3], uint32_t (&cidx)[8]) {
+  const uint32_t size = m.size[l];
+  if (m.hashed[l]) {
+    const uint32_t y0 = g[1] * 2654435761u, y1 = y0 + 2654435761u;
+    const uint32_t z0 = g[2] * 805459861u, z1 = z0 + 805459861u;
+    const uint32_t x0 = g[0], x1 = g[0] + 1u;
+    const uint32_t yz[4] = {y0 ^ z0, y1 ^ z0, y0 ^ z1, y1 ^ z1};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cidx[c] = ((c & 1) ? x1 : x0) ^ yz[c >> 1];
+  } else {
+    const uint32_t res = m.resolution[l], res2 = res * res;
+    const uint32_t base = g[0] + g[1] * res + g[2] * res2;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cidx[c] = base + (uint32_t)(c & 1) + (((c >> 1) & 1) ? res : 0u) + (((c >> 2) & 1) ? res2 : 0u);
+  }
+  // tcnn: `index % hashmap_size` (see grid_index)
+  if ((size & (size - 1u)) == 0u) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cidx[c] &= size - 1u;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cidx[c] = cidx[c] < size ? cidx[c] : cidx[c] % size;
+  }
 }
 
 // Scatter one level's 8 corners x 2 features.  Lanes are consecutive samples of a ray, so

@@ -181,6 +181,37 @@ def test_neus_forward_matches_oracle(N, O, dev, grid_init):
     torch.testing.assert_close(c["sdf_variance"], ref["sdf_variance"])
 
 
+def test_embedding_sine_stays_within_a_hundredth_of_an_fp16_ulp_of_libm(N, O, dev):
+    """`torch.sin(view_pts @ _B)` (InstantNeuS.py:196, _B = 25 * randn): the kernel reduces the argument with a two-term
+    Cody-Waite step and takes the hardware sine; the value becomes an fp16 colour-MLP input at once.  Arguments of up to
+    ~1500 rad here (points up to 14 m from the origin): every stored value must be the fp16 rounding of a number within
+    3e-6 of the exact sine of the SAME fp32 argument, and all but a handful are the correctly rounded fp16 itself."""
+    from go_slam_amd.neus.instant_neus import _neus_forward_raw
+    P = O.make_params(11, grid_init=0.3, bound=((-10.0, 10.0), (-10.0, 10.0), (-10.0, 10.0)))
+    o, d, gt = _rays(256, seed=3)
+    o = o * 4.0
+    g = torch.Generator().manual_seed(4)
+    z, dist = O.render_sample(o, d, gt, P["bound"], 24, 48, torch.rand(24, generator=g))
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    _, inv_s = model._inv_s()
+    with torch.no_grad():
+        saved = _neus_forward_raw(model, o.to(dev), d.to(dev), z.to(dev), dist.to(dev), inv_s, save=True)[-1]
+    mask = saved["mask"].cpu().bool().reshape(-1)
+    emb = saved["mlp_in"].cpu()[:, :33][mask]
+    zm = z + dist / 2.0                                                 # (the kernel's own fp32 operation order)
+    pts = (o[:, None, :] + d[:, None, :] * zm[..., None]).reshape(-1, 3)[mask]
+    B = P["color_B"]
+    arg = (pts[:, 0:1] * B[0:1] + pts[:, 1:2] * B[1:2]) + pts[:, 2:3] * B[2:3]
+    assert arg.abs().max() > 800.0
+    exact = torch.sin(arg.double())
+    lo = (exact - 3e-6).to(torch.float16)
+    hi = (exact + 3e-6).to(torch.float16)
+    assert bool(((emb >= lo) & (emb <= hi)).all())
+    mismatch = (emb != exact.to(torch.float16)).float().mean().item()
+    assert mismatch < 0.05, mismatch                                    # a 6e-6-wide window around an fp16 rounding boundary
+
+
 def test_neus_forward_matches_the_reference_module_fixture(N, O, dev):
     """The fused forward against tests/golden/neus_forward.npz = the REFERENCE's `InstantNeuS.forward` + `compute_sdf_error`
     (src/InstantNeuS.py:295-400) executed verbatim on the tcnn stand-in, same rays / samples / parameters -- the fixture the
