@@ -650,6 +650,41 @@ def summary(line):
             "n_gpus": line.get("n_gpus"), "rccl_ranks": line.get("rccl_ranks")}
 
 
+def collectives_selftest(device, rank, world):
+    """The collective calls of the sharded mapper step (go_slam_amd/neus/distributed.py: in-place fp16 reduce-scatter,
+    asynchronous in-place fp16 all-gather, fp32 all-reduce) on 8-element slices, checked against their closed forms; the
+    ranks agree on the result with one MIN all-reduce (the call the launch evidence above has already exercised)."""
+    import torch.distributed as dist
+    from go_slam_amd.neus import distributed as D
+    ok, err = 1.0, ""
+    sync = torch.cuda.synchronize if torch.device(device).type == "cuda" else (lambda: None)
+    try:
+        full = (torch.arange(8 * world, device=device, dtype=torch.float32) % 7).to(torch.float16)
+        want = full.float() * world
+        out = torch.empty(8, device=device, dtype=torch.float16)
+        fin = D.reduce_scatter_sum_(out, full.clone(), async_op=True)
+        fin()
+        sync()
+        if not torch.equal(out.float(), want[8 * rank:8 * rank + 8]):
+            raise RuntimeError("reduce-scatter result differs")
+        buf = torch.zeros(8 * world, device=device, dtype=torch.float16)
+        buf[8 * rank:8 * rank + 8] = float(rank + 1)
+        fin = D.all_gather_into_(buf, buf[8 * rank:8 * rank + 8], async_op=True)
+        fin()
+        sync()
+        if not torch.equal(buf.float().reshape(world, 8)[:, 0].cpu(), torch.arange(1, world + 1, dtype=torch.float32)):
+            raise RuntimeError("all-gather result differs")
+        t = torch.full((3,), float(rank), device=device)
+        D.all_reduce_sum_(t)
+        if float(t[0]) != world * (world - 1) / 2:
+            raise RuntimeError("all-reduce result differs")
+    except Exception as exc:
+        ok, err = 0.0, repr(exc)
+    flag = torch.tensor([ok], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() >= 1.0), err
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -767,8 +802,20 @@ def main():
         "updates_per_s": value * UPDATES_PER_KF, "state_finite": finite,
         "rccl_ranks": rccl_ranks, "collective_backend": backend,
     }
-    train = neus_train_bench(device, rank, world)      # collective: every rank takes part
-    train_weak = neus_train_bench(device, rank, world, global_rays=4096 * world, scaling="weak")
+    # collective legs: every rank takes part.  With N > 1 the exact collective calls of the sharded mapper step are first
+    # issued on small tensors and the ranks agree on the outcome -- a launcher / RCCL problem in that path must cost the
+    # path-M legs of the line, never the tracking headline above (tracking does not communicate).
+    coll_ok, coll_err = collectives_selftest(device, rank, world) if distributed else (True, "")
+
+    def train_leg(**kw):
+        if not coll_ok:
+            return {"error": "collective self-test failed on at least one rank: " + (coll_err or "(another rank)")}
+        try:
+            return neus_train_bench(device, rank, world, **kw)
+        except Exception as exc:                       # (a one-sided failure would hang the peers in their next collective;
+            return {"error": repr(exc)}                #  symmetric ones -- API / shape / backend refusals -- end here)
+    train = train_leg()
+    train_weak = train_leg(global_rays=4096 * world, scaling="weak")
     if rank == 0:
         line["neus_train"] = train
         line["neus_train_weak"] = train_weak

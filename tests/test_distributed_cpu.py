@@ -215,3 +215,39 @@ def test_sharded_optimizer_equals_single_process_step(tmp_path):
             torch.testing.assert_close(got[r]["named16"][k].float(), ref["named16"][k].float(), rtol=1e-3, atol=1e-6)
     # before sync_master a rank's fp32 master is current only on its own slice
     assert not torch.equal(got[0]["stale"], ref["named"]["grid"]) and torch.equal(got[0]["stale"][:504], got[0]["named"]["grid"][:504])
+
+
+def _selftest_worker(rank, world, port, out, break_rank):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import bench
+    if break_rank:                  # the collective layer refuses (on every rank: an API / backend refusal is symmetric)
+        from go_slam_amd.neus import distributed as D
+
+        def refuse(*a, **k):
+            raise RuntimeError("refused")
+        D.all_reduce_sum_ = refuse
+    ok, err = bench.collectives_selftest(torch.device("cpu"), rank, world)
+    torch.save({"ok": ok, "err": err}, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("break_rank", [False, True])
+def test_bench_collective_selftest_agrees_across_ranks(tmp_path, break_rank):
+    """bench.py's guard of its path-M legs under N > 1: the sharded step's collective calls on small tensors, results
+    checked against their closed forms; a refusal is caught, agreed on with one MIN all-reduce and costs the path-M legs
+    only -- the tracking headline is printed either way.  (A refusal on ONE rank alone would leave its peers inside the
+    refused collective: nothing above the collective library can recover that, so it is not what this guards.)"""
+    out = str(tmp_path / "st")
+    port = 29900 + (os.getpid() % 2000)
+    mp.start_processes(_selftest_worker, args=(3, port, out, break_rank), nprocs=3, join=True, start_method="spawn")
+    got = [torch.load(out + f".{r}") for r in range(3)]
+    if not break_rank:
+        assert all(g["ok"] for g in got), got
+    else:
+        assert not any(g["ok"] for g in got)
+        assert all("refused" in g["err"] for g in got)
