@@ -428,12 +428,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
       _Float16* tab16 = A.grid_grad16 + off * 2;
       const int buf = hord & 1;
       const bool act = lvl_prereduce(gacc, gi, on, lane) && on;
+      // the 8 slot reservations go out back to back and are waited for once (an LDS atomic with return is a ~100-cycle
+      // round trip: reserved one corner at a time they are 8 dependent round trips per level and wave)
+      uint32_t slot_[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        slot_[c] = 0u;
+        if (act && (gacc[c][0] != 0.0f || gacc[c][1] != 0.0f)) slot_[c] = atomicAdd(&st_cnt[buf][cidx[c] >> BIN_SHIFT], 1u);
+      }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         if (act && (gacc[c][0] != 0.0f || gacc[c][1] != 0.0f)) {
           const uint32_t e = cidx[c], bin = e >> BIN_SHIFT;
           const uint32_t packed = pack2h(gacc[c][0] * A.grad_scale16, gacc[c][1] * A.grad_scale16);
-          const uint32_t slot = atomicAdd(&st_cnt[buf][bin], 1u);
+          const uint32_t slot = slot_[c];
           if (slot < (uint32_t)ST_SLOTS) {
             st_idx[buf][bin][slot] = (uint16_t)(e & (BIN_ENTRIES - 1));
             st_val[buf][bin][slot] = packed;
@@ -449,20 +457,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
       // staging + copy + barrier at 1.0 of the kernel's 2.8 ms.  Staging buffer `buf` is appended to again two hashed
       // levels from now, i.e. after the NEXT level's barrier, which every wave reaches only after this copy.
       {
+        // (round 5: the four fill counts, then all twelve record pairs, are requested from LDS before the first store
+        // goes out -- one count -> records -> stores chain per bin group was 8 dependent LDS round trips per level and
+        // wave; the segment offset is 32-bit arithmetic: the launcher checks that the queues hold < 2^32 records)
         const int wv = threadIdx.x >> 6, sub = lane >> 4, s16 = lane & 15;
-        const size_t nblk = gridDim.x;
+        const uint32_t nblk = gridDim.x;
+        constexpr int NJ = BINS_PER_LEVEL / 16, NK = (ST_SLOTS + 15) / 16;
+        uint32_t cn[NJ], rv[NJ][NK];
+        uint16_t ri[NJ][NK];
 #pragma unroll
-        for (int j = 0; j < BINS_PER_LEVEL / 16; ++j) {
+        for (int j = 0; j < NJ; ++j) cn[j] = st_cnt[buf][16 * wv + 4 * j + sub];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
           const int b = 16 * wv + 4 * j + sub;
-          const uint32_t cn = st_cnt[buf][b];
-          const uint32_t c = cn < (uint32_t)ST_SLOTS ? cn : (uint32_t)ST_SLOTS;
-          const size_t seg = (size_t)(hord * BINS_PER_LEVEL + b) * nblk + blockIdx.x;
 #pragma unroll
-          for (int k = 0; k < (ST_SLOTS + 15) / 16; ++k) {
-            const uint32_t sl = s16 + 16 * k;
-            if (sl < c) {
-              A.q_idx[seg * ST_SLOTS + sl] = st_idx[buf][b][sl];
-              A.q_val[seg * ST_SLOTS + sl] = st_val[buf][b][sl];
+          for (int k = 0; k < NK; ++k) {               // (slots past the fill count hold stale records: read, never stored)
+            ri[j][k] = st_idx[buf][b][s16 + 16 * k];
+            rv[j][k] = st_val[buf][b][s16 + 16 * k];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const uint32_t b = 16 * wv + 4 * j + sub;
+          const uint32_t c = cn[j] < (uint32_t)ST_SLOTS ? cn[j] : (uint32_t)ST_SLOTS;
+          const uint32_t seg = ((uint32_t)hord * BINS_PER_LEVEL + b) * nblk + blockIdx.x;
+          const uint32_t at = seg * ST_SLOTS + s16;
+#pragma unroll
+          for (int k = 0; k < NK; ++k) {
+            if (s16 + 16 * k < c) {
+              A.q_idx[(size_t)(at + 16 * k)] = ri[j][k];
+              A.q_val[(size_t)(at + 16 * k)] = rv[j][k];
             }
           }
           if (s16 == 0) A.q_cnt[seg] = (uint8_t)c;
@@ -734,6 +758,8 @@ static int backward_points_impl(const float* rays_o, const float* rays_d, const 
     return GS_ERR_WORKSPACE;
   }
   const size_t nblk = bin_workgroups((size_t)n * s);
+  // (pass 1 addresses the queues with 32-bit record offsets: 26 GB of queues, ~32 M sample points, is the limit)
+  GS_REQUIRE(nq * nblk * ST_SLOTS < ((size_t)1 << 32), "neus_backward_points_binned: %d x %d sample points exceed the record queues' 32-bit offsets", n, s);
   char* base = (char*)gs_align((size_t)bin_ws);
   A.q_cnt = (uint8_t*)base;                                       // [nq][nblk]
   A.q_val = (uint32_t*)(base + gs_align(nq * nblk));              // [nq][nblk][ST_SLOTS]
