@@ -88,7 +88,7 @@ class FlatAdamW:
     fp32 slices; call it before state_dict() / checkpoints -- MapTrainer.state_dict does)."""
 
     def __init__(self, model, net_lr=1e-3, grid_lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=35.0,
-                 rank=0, world=1, group=None, kernels=None):
+                 rank=0, world=1, group=None, kernels=None, sharded=None):
         net = model.sdf_network
         self.grid_module = net.encoding.encoding
         self.mlp_module = model.color_network.network
@@ -96,6 +96,10 @@ class FlatAdamW:
         self.dense = [("mlp", self.mlp_module.params), ("sdf_w", net.sdf_layer.weight), ("sdf_b", net.sdf_layer.bias),
                       ("cB", model.color_network._B), ("var", model.variance_network.variance)]
         self.rank, self.world, self.group = int(rank), int(world), group
+        # the sharded schedule (reduce-scatter -> slice AdamW -> deferred all-gather) is what world > 1 runs; `sharded=True`
+        # runs the same schedule in a process group of ONE rank -- how a 1-GPU box takes the RCCL path of this class
+        # (tests/test_neus_gpu.py: the collectives become RCCL's own one-rank copies, everything around them is unchanged)
+        self.sharded = (self.world > 1) if sharded is None else bool(sharded)
         self.kernels = kernels if kernels is not None else HipOptKernels()
         dev = self.grid_p.device
         self.n16 = self.grid_p.numel()
@@ -123,7 +127,7 @@ class FlatAdamW:
         self.V = torch.zeros_like(self.M)
         self.P16 = self.P.to(torch.float16)
         self.G16 = torch.zeros(self.n16p, dtype=torch.float16, device=dev)        # the backward's table-gradient buffer
-        self.g16s = torch.empty(self.slice, dtype=torch.float16, device=dev) if self.world > 1 else None
+        self.g16s = torch.empty(self.slice, dtype=torch.float16, device=dev) if self.sharded else None
         self.sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.g32 = torch.zeros(self.nd + 2, dtype=torch.float32, device=dev)      # dense gradients | global loss | spare
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -185,7 +189,7 @@ class FlatAdamW:
             self.step_dev.add_(1)
             self.sqnorm.zero_()
         dense = (self.P[self.n16p:], self.M[self.slice:], self.V[self.slice:], self.P16[self.n16p:], self.g32[:nd])
-        if self.world > 1:
+        if self.sharded:
             self.wait_gather()
             t = self._exchange_timer
             if t is not None:
@@ -231,7 +235,7 @@ class FlatAdamW:
         """start the reduce-scatter of the fp16 table gradient NOW (it is complete: the bin reduce has run) instead of at
         the head of step(): the Gram and post kernels of the backward then run beside it.  Every rank calls this at the same
         point of its step, so the collectives are enqueued in the same order everywhere."""
-        if self.world > 1 and self._rs_wait is None:
+        if self.sharded and self._rs_wait is None:
             from .distributed import reduce_scatter_sum_
             self._rs_wait = reduce_scatter_sum_(self.g16s, self.G16, self.group, async_op=True)
 
@@ -249,7 +253,7 @@ class FlatAdamW:
 
     def sync_master(self):
         """all-gather the fp32 master slices so that every rank's `P` (= the modules' parameters, state_dict()) is whole"""
-        if self.world > 1:
+        if self.sharded:
             from .distributed import all_gather_into_
             self.wait_gather()
             all_gather_into_(self.P[:self.n16p], self.P[self.lo:self.hi], self.group)
@@ -264,24 +268,27 @@ class FlatAdamW:
 
 class MapTrainer:
     def __init__(self, model, renderer, net_lr=1e-3, grid_lr=1e-2, w_color=2.0, w_sdf=2.0, w_eikonal=0.1,
-                 uncertainty=True, group=None, rank=0, world=1, fused=None, graph=None):
+                 uncertainty=True, group=None, rank=0, world=1, fused=None, graph=None, sharded=None):
         """`fused` (default: on for a CUDA model with tiny-cuda-nn's fp16 table gradients): the whole step without an
         autograd graph -- forward, the loss kernel's analytic output gradients, the HIP backward, one flat-buffer
         clip + AdamW -- no parameter read-back to the host (`step_fused`).  `graph` (default: on with `fused`): the
         step's launch sequence is captured once per batch size in a hipGraph and replayed (one graph launch instead of
         ~65 kernel launches; with world > 1 the collectives stay outside: [sample + forward + loss + backward] is one
-        graph, the optimiser's two kernels sit between the collectives)."""
+        graph, the optimiser's two kernels sit between the collectives).  `sharded=True` runs the world > 1 schedule
+        (global counts outside the graph, two graphs around the early reduce-scatter, sharded optimiser, deferred
+        all-gather) in a process group of one rank: the RCCL path of the step on a 1-GPU box."""
         self.model, self.renderer = model, renderer
         self.train_params = model.get_training_parameters() + model.get_volume_parameters()
         self.w = dict(w_color=w_color, w_sdf=w_sdf, w_eikonal=w_eikonal, uncertainty=uncertainty)
         self.group, self.rank, self.world = group, rank, world
+        self.sharded = (world > 1) if sharded is None else bool(sharded)
         if fused is None:
             fused = all(p.is_cuda for p in self.train_params) and model.grid_grad_dtype == torch.float16
         self.fused = bool(fused)
         self.graph = bool(self.fused if graph is None else (graph and self.fused))
         self._graphs, self._bufs = {}, {}
         if self.fused:
-            self.flat = FlatAdamW(model, net_lr, grid_lr, rank=rank, world=world, group=group)
+            self.flat = FlatAdamW(model, net_lr, grid_lr, rank=rank, world=world, group=group, sharded=self.sharded)
             self.optimizer, self.reducer = self.flat, None        # `.param_groups` / `.set_lr` facade
         else:
             self.optimizer = make_optimizer(model, net_lr, grid_lr)
@@ -386,7 +393,7 @@ class MapTrainer:
         batch-wide depth maximum the sampler clamps with (src/render.py:121,140).  `rays_depth` is the GLOBAL batch's
         depth column -- every rank is handed the same batch and renders its shard of it -- so the three numbers are
         local reductions: no collective (and no collective latency) stands at the head of a step."""
-        if self.world == 1:
+        if not self.sharded:
             return None
         rd = rays_depth.detach().float().reshape(-1)
         dev = rd.device
@@ -430,7 +437,7 @@ class MapTrainer:
         flat.check_bindings()
         counts = self._counts(rays_depth)
         args = self._prepare(rays_o, rays_d, rays_color, rays_depth)
-        early = flat.begin_reduce_scatter if self.world > 1 else None     # (the reduce-scatter starts under Gram + post)
+        early = flat.begin_reduce_scatter if self.sharded else None       # (the reduce-scatter starts under Gram + post)
         if not self.graph or args[0].shape[0] == 0:
             flat.wait_gather()
             inv_scale = self._local_gradients(*args, perturb_rand, counts, after_table=early)
@@ -451,7 +458,7 @@ class MapTrainer:
             srcs.append(perturb_rand.detach().float().contiguous())
         torch._foreach_copy_(dsts, srcs)    # ONE launch for the 4-6 input tensors (was a 4.4 us copy kernel each)
         flat.wait_gather()                  # (world > 1) the previous step's table all-gather ran beside everything above
-        whole = self.world == 1             # single GPU: the optimiser's two launches are part of the graph
+        whole = not self.sharded            # single GPU: the optimiser's two launches are part of the graph
 
         def body(after_table=None):
             inv = self._local_gradients(*ent["static"], ent["pr"], None if whole else ent["counts"], bufs=ent["bufs"],

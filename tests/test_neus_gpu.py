@@ -722,6 +722,81 @@ def test_sharded_fused_step_two_ranks_on_one_gpu_equals_single_process(N, O, dev
         assert float(off.float().mean()) < 1e-2 and float(dlt.max()) <= 4 * lr * 1.01, (k, float(off.float().mean()), float(dlt.max()))
 
 
+def _rccl_world1(_index, port, out):
+    """the sharded mapper step and bench.py's collective self-test in an RCCL process group of ONE rank"""
+    import os
+    import sys
+    import torch.distributed as dist
+    from go_slam_amd.neus.mapper import MapTrainer
+    import go_slam_amd.neus as neus
+    from oracle import neus_oracle as NO
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    res = {"backend": dist.get_backend()}
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        res["selftest"] = bench.collectives_selftest(dev, 0, 1)
+        P = NO.make_params(71, grid_init=0.05, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+        model = neus.InstantNeuS({}, P["bound"].tolist()).to(dev)
+        _load(model, P)
+        tr = MapTrainer(model, neus.Renderer(N_samples=24, N_surface=48), rank=0, world=1, sharded=True)
+        o, d, gt = _rays(600, seed=72)
+        g = torch.Generator().manual_seed(73)
+        args = [t.to(dev) for t in (o, d, torch.rand(600, 3, generator=g), gt, torch.rand(24, generator=g))]
+        for _ in range(5):              # 2 eager + capture (two graphs around the early reduce-scatter) + 2 replays
+            loss = tr.step(*args)
+        with torch.no_grad():           # a render between steps waits for the deferred all-gather through the cache hook
+            res["pending_before_render"] = tr.flat._gather_wait is not None
+            model(args[0][:8], args[1][:8], *tr.renderer.sample(args[0][:8], args[1][:8], model.bound, args[3][:8]))
+            res["pending_after_render"] = tr.flat._gather_wait is not None
+        res.update(loss=float(loss), sd={k: v.detach().cpu() for k, v in tr.state_dict().items()},
+                   graphs=len(tr._graphs), two_graphs=all("tail" in e for e in tr._graphs.values()))
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    torch.save(res, out)
+
+
+def test_sharded_schedule_runs_under_rccl_in_a_one_rank_group(N, O, dev, tmp_path):
+    """What a 1-GPU box can say about the RCCL path: `MapTrainer(..., sharded=True)` runs the world > 1 schedule -- counts
+    outside the graph, TWO hipGraphs captured around the early reduce-scatter (thread-local capture beside RCCL's
+    watchdog thread), fp16 reduce-scatter, slice AdamW, deferred in-place fp16 all-gather waited for by the next reader
+    -- in a `nccl` process group of one rank, where the collectives are RCCL's own one-rank copies on its own stream.
+    Five steps must equal the plain single-process trainer; bench.py's collective self-test must pass on the same
+    group.  (The exchange between GPUs itself stays unmeasured: tests/test_distributed_gpu.py needs two.)"""
+    import torch.multiprocessing as mp
+    from go_slam_amd.neus.mapper import MapTrainer
+    out = str(tmp_path / "rccl1.pt")
+    mp.start_processes(_rccl_world1, args=(29300 + (os.getpid() % 600), out), nprocs=1, join=True, start_method="spawn")
+    got = torch.load(out)
+    assert got["backend"] == "nccl" and got["selftest"] == (True, ""), got.get("selftest")
+    assert got["graphs"] == 1 and got["two_graphs"]
+    assert got["pending_before_render"] and not got["pending_after_render"]
+    P = O.make_params(71, grid_init=0.05, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    tr = MapTrainer(model, N.Renderer(N_samples=24, N_surface=48))
+    o, d, gt = _rays(600, seed=72)
+    g = torch.Generator().manual_seed(73)
+    args = [t.to(dev) for t in (o, d, torch.rand(600, 3, generator=g), gt, torch.rand(24, generator=g))]
+    for _ in range(5):
+        loss = tr.step(*args)
+    assert abs(got["loss"] - float(loss)) < 3e-4 * max(1.0, abs(float(loss)))
+    trained = {"sdf_network.encoding.encoding.params", "sdf_network.sdf_layer.weight", "sdf_network.sdf_layer.bias",
+               "color_network._B", "color_network.network.params", "variance_network.variance"}
+    for k, v in tr.state_dict().items():
+        if k not in trained:
+            continue
+        a, b = got["sd"][k].float(), v.detach().cpu().float()
+        dlt = (a - b).abs()
+        lr = 1e-2 if k.endswith("encoding.params") else 1e-3
+        off = dlt > (2e-5 + 2e-3 * b.abs())         # (as the two-rank test: a handful of +-lr flips of rounding-level gradients)
+        assert float(off.float().mean()) < 1e-2 and float(dlt.max()) <= 5 * lr * 1.01, (k, float(off.float().mean()), float(dlt.max()))
+
+
 def _grid_grads(N, O, dev, P, rays, binned, grad_dtype):
     model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
     _load(model, P)
