@@ -311,7 +311,7 @@ def neus_render_bench(device, n_rays=4096, iters=20):
             "gather_GBps": pts * 512.0 / (ms_fwd * 1e-3) / 1e9}
 
 
-def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768, scaling="strong"):
+def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768, scaling="strong", sharded=None):
     """Mapping step (render + losses + backward + grad all-reduce + clip + AdamW) on a GLOBAL batch of
     `global_rays` rays x 72 samples sharded over `world` GPUs (BASELINE configs[4]).  Called twice: strong scaling
     (32768 rays in total) and weak scaling (4096 rays per GPU -- the reference mapper's own per-iteration batch,
@@ -332,8 +332,9 @@ def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768, s
     gt = gt.to(device)
     col = torch.rand(n, 3, generator=g).to(device)
     pr = torch.rand(24, generator=g).to(device)
-    tr = MapTrainer(model, R, rank=rank, world=world)
+    tr = MapTrainer(model, R, rank=rank, world=world, sharded=sharded)
     import torch.distributed as dist
+    sharded = bool(getattr(tr, "sharded", world > 1))
 
     def sync():
         if world > 1:
@@ -348,10 +349,11 @@ def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768, s
     sync()
     dt = time.perf_counter() - tic
     exch = None
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    if sharded:
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
         if getattr(tr, "fused", False):
             # a second, instrumented pass (outside the timed region): events around the collectives on the step's stream ->
             # per rank the time the compute stream was BLOCKED on an exchange; compute = step - exposed exchange
@@ -387,9 +389,9 @@ def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768, s
             "graph_replay": bool(getattr(tr, "graph", False)),
             "collective_bytes_sent_per_rank": (tr.flat.collective_bytes() if tr.fused
                                                else (0 if world == 1 else 4 * sum(p.numel() for p in tr.train_params))),
-            "exchange": "none" if world == 1 else ("reduce-scatter(fp16 table grad) + sharded AdamW + all-gather(fp16 "
-                                                   "table)" if tr.fused else "all-reduce(fp32 flat grad)"),
-            "exchange_exposed_ms": (max(r[1] for r in exch["per_rank"]) if exch else (0.0 if world == 1 else None)),
+            "exchange": "none" if not sharded else ("reduce-scatter(fp16 table grad) + sharded AdamW + all-gather(fp16 "
+                                                    "table)" if tr.fused else "all-reduce(fp32 flat grad)"),
+            "exchange_exposed_ms": (max(r[1] for r in exch["per_rank"]) if exch else (0.0 if not sharded else None)),
             "exchange_per_rank": exch, "final_loss": float(loss)}
 
 
@@ -640,6 +642,8 @@ def summary(line):
             "neus_train_32768": [g(line, "neus_train", "ms_per_step"), g(line, "neus_train", "value")],
             "neus_train_4096_per_gpu": [g(line, "neus_train_weak", "ms_per_step"), g(line, "neus_train_weak", "value")],
             "exchange_ms": [g(line, "neus_train", "exchange_exposed_ms"), g(line, "neus_train_weak", "exchange_exposed_ms")],
+            "sharded_schedule_rccl_1rank_ms_[32768,4096]": [g(line, "neus_train_sharded_schedule_rccl_1rank", "32768", "ms_per_step"),
+                                                             g(line, "neus_train_sharded_schedule_rccl_1rank", "4096", "ms_per_step")],
             "pathM_kernels_[us,frac_hbm,frac_replay]": pm,
             "ba_2iter_ms": g(line, "breakdown_ms", "ba_2iter_ms"),
             "mono_window": [g(line, "mono_window", "keyframes_per_s"), g(line, "mono_window", "ba_2iter_ms")],
@@ -648,6 +652,34 @@ def summary(line):
                                                         g(line, "global_ba_stress", "altcorr_roofline", "frac_of_fp32_vector_roof_157TF")],
             "motion_filter_frame_ms": g(line, "breakdown_ms", "motion_filter_frame_ms"),
             "n_gpus": line.get("n_gpus"), "rccl_ranks": line.get("rccl_ranks")}
+
+
+def sharded_schedule_one_rank(device):
+    """The world > 1 schedule of the mapper step on THIS one GPU, in an RCCL (`nccl`) process group of one rank: global
+    counts outside the graph, two hipGraphs around the early reduce-scatter, fp16 reduce-scatter, slice AdamW, deferred
+    in-place all-gather -- the collectives are RCCL's own one-rank copies on its stream.  What it measures: the fixed cost
+    of that schedule against the whole-step graph of `neus_train` / `neus_train_weak` (no inter-GPU transfer is involved:
+    the exchange itself stays unmeasured until an N > 1 run)."""
+    import torch.distributed as dist
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        created = True
+        flush_c_stdio()
+    try:
+        out = {"collective_backend": dist.get_backend(), "ranks": dist.get_world_size(),
+               "collective_selftest_ok": collectives_selftest(device, 0, 1)[0]}
+        for rays in (32768, 4096):
+            r = neus_train_bench(device, 0, 1, global_rays=rays, sharded=True)
+            out[str(rays)] = {"ms_per_step": r["ms_per_step"], "graph_replay": r["graph_replay"],
+                              "exchange_per_rank": r["exchange_per_rank"], "final_loss": r["final_loss"]}
+    finally:
+        if created:
+            dist.destroy_process_group()
+        flush_c_stdio()
+    return out
 
 
 def collectives_selftest(device, rank, world):
@@ -683,6 +715,17 @@ def collectives_selftest(device, rank, world):
     flag = torch.tensor([ok], device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return bool(flag.item() >= 1.0), err
+
+
+def flush_c_stdio():
+    """RCCL prints a banner ('Librccl path : ...') through C stdio; behind a pipe that buffer is only flushed at process
+    exit, i.e. AFTER Python's own prints -- the bench line must stay the last line of stdout, so the C buffers are
+    flushed as soon as a process group exists and again before the line is printed."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 def free_port():
@@ -760,6 +803,7 @@ def main():
         t = torch.ones(1, device=device)
         dist.all_reduce(t)
         rccl_ranks, backend = int(t.item()), dist.get_backend()
+        flush_c_stdio()
 
     video, update_op, graph, _ = build_state(device)
 
@@ -886,6 +930,10 @@ def main():
                 line["mono_window"] = mono_window(device)
             except Exception as exc:
                 line["mono_window"] = {"error": repr(exc)}
+            try:        # the sharded (world > 1) schedule of the mapper step under RCCL, one rank: its fixed cost on hardware
+                line["neus_train_sharded_schedule_rccl_1rank"] = sharded_schedule_one_rank(device)
+            except Exception as exc:
+                line["neus_train_sharded_schedule_rccl_1rank"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(2)
             try:        # path M on the host cores (north_star: the render batches "alongside the reference's CPU path")
@@ -896,9 +944,13 @@ def main():
         if "altcorr_roofline" in st:
             line["roofline_other"].append(st["altcorr_roofline"])
         line["summary"] = summary(line)         # LAST key: a reader of the line's tail sees every leg's headline number
-        print(json.dumps(line))
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
+    flush_c_stdio()                             # every C-level byte of this process is out before the line is printed:
+    if rank == 0:                               # the line stays the LAST line of stdout
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
