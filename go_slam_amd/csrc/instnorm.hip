@@ -150,12 +150,16 @@ __global__ __launch_bounds__(256) void instnorm_final_kernel(const Moments* __re
 // The same for partial SUMS [n][nblk][c][2] of d = v - shift and d^2 (gs_enc_conv's epilogue statistics, shift = the
 // convolution's bias): plain additions, eight loads in flight per thread, then mean = shift + S1 / N and the biased
 // variance (S2 - S1^2 / N) / N.
-__global__ __launch_bounds__(256) void instnorm_final_sums_kernel(const float* __restrict__ sums, int nblk, int c, int hw,
-                                                                  const _Float16* __restrict__ shift, float eps,
-                                                                  float* __restrict__ final_) {
-  __shared__ float sm[256][2];
+constexpr int FS_NT = 1024;      // one workgroup per image merges <= 600 partial sums per channel: with 256 threads that was
+                                 // 9-10 dependent round trips of 64 chunks (6.5 us, 15 times per input frame); 1024 threads
+                                 // take 256 chunks per round trip.  The order of the additions is fixed (thread `part` adds
+                                 // its chunks in ascending order, thread 0..c-1 then adds the parts in ascending order).
+__global__ __launch_bounds__(FS_NT) void instnorm_final_sums_kernel(const float* __restrict__ sums, int nblk, int c, int hw,
+                                                                    const _Float16* __restrict__ shift, float eps,
+                                                                    float* __restrict__ final_) {
+  __shared__ float sm[FS_NT][2];
   const int img = blockIdx.x, tid = threadIdx.x;
-  const int per = 256 / c;                                    // threads per channel (c in {32, 64, 128, 256})
+  const int per = FS_NT / c;                                  // threads per channel (c in {32, 64, 128, 256})
   const int ch = tid % c, part = tid / c;
   float a1 = 0.0f, a2 = 0.0f;
   const float2* src = reinterpret_cast<const float2*>(sums) + (size_t)img * nblk * c + ch;
@@ -184,7 +188,6 @@ __global__ __launch_bounds__(256) void instnorm_final_sums_kernel(const float* _
     final_[((size_t)img * c + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
-
 __global__ __launch_bounds__(256) void norm_act_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ skip,
                                                        _Float16* __restrict__ y, const _Float16* __restrict__ bias,
                                                        const float* __restrict__ final_, int hw, int c, int relu_in,
@@ -267,7 +270,7 @@ extern "C" int gs_norm_act(const void* x, const void* bias, const void* skip, vo
       GS_CHECK_LAUNCH("instnorm_stats");
     }
     if (stat_chunks > 0)
-      instnorm_final_sums_kernel<<<n, 256, 0, st>>>((const float*)partial, nblk, channels, hw, (const _Float16*)bias, eps, final_);
+      instnorm_final_sums_kernel<<<n, FS_NT, 0, st>>>((const float*)partial, nblk, channels, hw, (const _Float16*)bias, eps, final_);
     else
       instnorm_final_kernel<<<n, 256, 0, st>>>(partial, nblk, channels, eps, final_);
     GS_CHECK_LAUNCH("instnorm_final");
