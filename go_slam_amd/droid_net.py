@@ -564,28 +564,49 @@ class UpdateModule(nn.Module):
     def drop_edge_caches(self):
         """Forget what is cached per edge set (the hoisted context-feature convolutions).  Happens by
         itself when `inp` is a different tensor; callers that reuse one tensor object can force it."""
-        self._inp_tag = None
+        self._inp_pre_cache = None
+
+    INP_CACHE_BYTES = 16 << 30      # hoisted context terms kept at most (least recently used go first; >= 1 entry stays)
 
     def _edge_state(self, inp, n, ht, wd):
         """(hx, inp_pre): the GRU's per-update input buffer [net | corr | flow] (320 ch, NHWC fp16) and
         the hoisted z|r|q convolutions over `inp`, recomputed only when `inp` is a different tensor or
-        was written to -- in the factor graph that is when edges are added or removed."""
+        was written to -- in the factor graph that is when edges are added or removed.  The terms are cached PER `inp`
+        TENSOR (round 5): FactorGraph.update_lowmem walks the same 13-keyframe chunks in every one of its steps, each with
+        its own cached context tensor, and with one slot the 128 -> 384 convolution (+ a layout copy) was redone for every
+        chunk of every step -- 16 x 123 us of a 16.9 ms stress step.  69 MB per 75-edge chunk at 30 x 40 (1.1 GB for the
+        200-keyframe graph), 276 MB for the S480 frontend window: HBM this part has."""
+        import collections
         import weakref
         hx = getattr(self, "_hx", None)
         if hx is None or hx.shape[0] != n or hx.shape[2:] != (ht, wd) or hx.device != inp.device:
             hx = torch.empty((n, 320, ht, wd), dtype=torch.float16, device=inp.device,
                              memory_format=torch.channels_last)
-            self._hx, self._inp_tag = hx, None
-        tag = getattr(self, "_inp_tag", None)
+            self._hx = hx
+        cache = getattr(self, "_inp_pre_cache", None)
+        if cache is None:
+            cache = self._inp_pre_cache = collections.OrderedDict()
         self.gru._half_weights()                              # refreshes gru._hw_key if the weights changed
         wkey = self.gru._hw_key
-        if tag is None or tag[0]() is not inp or tag[1] != inp._version or tag[2] != wkey:
-            inp4 = inp.view(n, -1, ht, wd)
-            if inp4.dtype != torch.float16 or not inp4.is_contiguous(memory_format=torch.channels_last):
-                inp4 = inp4.half().contiguous(memory_format=torch.channels_last)
-            self._inp_pre = self.gru.inp_gates(inp4)
-            self._inp_tag = (weakref.ref(inp), inp._version, wkey)
-        return hx, self._inp_pre
+        key = id(inp)
+        ent = cache.get(key)
+        if ent is not None and ent[0]() is inp and ent[1] == inp._version and ent[2] == wkey:
+            cache.move_to_end(key)
+            return hx, ent[3]
+        inp4 = inp.view(n, -1, ht, wd)
+        if inp4.dtype != torch.float16 or not inp4.is_contiguous(memory_format=torch.channels_last):
+            inp4 = inp4.half().contiguous(memory_format=torch.channels_last)
+        inp_pre = self.gru.inp_gates(inp4)
+        for k in [k for k, e in cache.items() if e[0]() is None or e[2] != wkey]:      # dead tensors, old weights
+            del cache[k]
+        cache[key] = (weakref.ref(inp), inp._version, wkey, inp_pre)
+        nbytes = lambda t: sum(x.numel() * x.element_size() for x in (t if isinstance(t, (tuple, list)) else (t,))
+                               if torch.is_tensor(x))
+        total = sum(nbytes(e[3]) for e in cache.values())
+        while total > self.INP_CACHE_BYTES and len(cache) > 1:
+            _, e = cache.popitem(last=False)
+            total -= nbytes(e[3])
+        return hx, inp_pre
 
     def _head_weights(self):
         """delta[0] | weight[0] | agg.conv1 read the same tensor: one 128->384 convolution."""

@@ -462,8 +462,14 @@ class FactorGraph:
             # (the chunk's context features are per-keyframe constants: gathered and laid out once per edge set -- the
             # index cache is rebuilt whenever an edge list or, through rm_keyframe, a keyframe slot changes -- instead of
             # once per step and chunk; 23 MB per chunk at 30 x 40)
-            ck["inp"] = (lambda ix=ck["ii"], box=ck: box.setdefault(
-                "inp_cached", self._fmt(self.video.inps[ix]).unsqueeze(0)))
+            # (dict.setdefault evaluates its default on EVERY call: until round 5's last day this "cache" redid the gather
+            # and the layout copy per chunk and step and threw the result away -- 16 x 42 us of the stress step)
+            def _inp(ix=ck["ii"], box=ck):
+                v = box.get("inp_cached")
+                if v is None:
+                    v = box["inp_cached"] = self._fmt(self.video.inps[ix]).unsqueeze(0)
+                return v
+            ck["inp"] = _inp
             chunks.append(ck)
         c = {"key": key, "tens": tens, "t0": a0, "t1": a1, "chunks": chunks, "ii": self.ii.contiguous(),
              "jj": self.jj.contiguous(),

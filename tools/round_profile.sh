@@ -36,9 +36,9 @@ done
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_mf -o t -- python $R/tools/profile_motion_filter.py 20 > $OUT/prof_mf.log 2>&1 || echo "prof mf failed"
 f=$(find $OUT/prof_mf -name '*kernel_trace.csv' | head -1)
 python $R/tools/summarize_kernels.py $f --steps 20 --after erfinv --title "MotionFilter.track, one 480x640 RGB-D input frame (20 steady-state frames; setup and warm frames excluded by the marker launch)" > $OUT/motion_filter_kernel_stats.md 2>> $OUT/summarize.err
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_stress -o t -- python $R/tools/profile_stress.py 4 > $OUT/prof_stress.log 2>&1 || echo "prof stress failed"
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_stress -o t -- python $R/tools/profile_stress.py 8 > $OUT/prof_stress.log 2>&1 || echo "prof stress failed"
 f=$(find $OUT/prof_stress -name '*kernel_trace.csv' | head -1)
-python $R/tools/summarize_kernels.py $f --steps 4 --title "global BA stress (200 keyframes, 1200 edges, 30x40): update_lowmem step" > $OUT/stress_kernel_stats.md 2>> $OUT/summarize.err
+python $R/tools/summarize_kernels.py $f --steps 8 --after erfinv --title "global BA stress (200 keyframes, 1200 edges, 30x40): one update_lowmem(steps=8) invocation, per-edge caches cold, per step" > $OUT/stress_kernel_stats.md 2>> $OUT/summarize.err
 find $OUT -name '*.csv' -delete
 PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum" timeout 600 bash $R/tools/pmc_pass.sh $OUT/pmc_neus _kernel -- python $R/tools/profile_mapping.py train 3 > $OUT/pmc_neus.log 2>&1
 # what the backward's pass 1 is bound by: instruction counts and busy cycles of the same launches
