@@ -64,6 +64,46 @@ def test_update_lowmem_global_ba(built_lib):
     assert torch.equal(video.poses[0], p0[0]) and not torch.equal(video.poses[1:40], p0[1:40])
 
 
+def test_update_lowmem_context_caches_change_nothing_and_follow_the_edge_set(built_lib):
+    """The per-chunk caches of update_lowmem (the chunk's gathered context features in FactorGraph's index cache, the
+    hoisted 128 -> 384 context term per `inp` tensor in the update operator): three steps in ONE invocation -- the first
+    fills the caches, the others hit them -- must leave exactly the state of three one-step invocations that each start
+    cold; a changed edge set must not be served another set's terms; the terms are held per chunk, not in one slot."""
+    dev = torch.device("cuda:0")
+    states = []
+    for cold in (False, True):
+        video, op, graph, vid = _setup(dev, 40, "tiny", "alt", seed=5)
+        ii, jj = synth.make_graph(40, 200, seed=5)
+        graph.add_factors(ii.to(dev), jj.to(dev))
+        if cold:
+            for _ in range(3):
+                op.drop_edge_caches()
+                graph._lidx = None                   # (the index cache holds the chunks' gathered context features)
+                graph.update_lowmem(t0=1, t1=40, steps=1, iters=2)
+        else:
+            graph.update_lowmem(t0=1, t1=40, steps=3, iters=2)
+            n_chunks = len(graph._lowmem_index(1, 40, 1)["chunks"])
+            assert n_chunks > 1 and len(op._inp_pre_cache) == n_chunks, (n_chunks, len(op._inp_pre_cache))
+        torch.cuda.synchronize()
+        states.append((video.poses.clone(), video.disps.clone(), graph.net.clone(), graph.target.clone()))
+    for a, b in zip(*states):
+        assert torch.equal(a, b)
+    # a different edge set: new chunks, new context tensors, new terms -- and the result of a cold start on that set
+    video2, op2, graph2, _ = _setup(dev, 40, "tiny", "alt", seed=5)
+    graph2.add_factors(ii.to(dev), jj.to(dev))
+    graph2.update_lowmem(t0=1, t1=40, steps=1, iters=2)             # warm caches of the FULL edge set
+    graph2.rm_factors(graph2.ii == 7, store=False)
+    graph2.update_lowmem(t0=1, t1=40, steps=1, iters=2)
+    video3, op3, graph3, _ = _setup(dev, 40, "tiny", "alt", seed=5)
+    graph3.add_factors(ii.to(dev), jj.to(dev))
+    graph3.update_lowmem(t0=1, t1=40, steps=1, iters=2)
+    graph3.rm_factors(graph3.ii == 7, store=False)
+    op3.drop_edge_caches()
+    graph3.update_lowmem(t0=1, t1=40, steps=1, iters=2)
+    torch.cuda.synchronize()
+    assert torch.equal(video2.poses, video3.poses) and torch.equal(video2.disps, video3.disps)
+
+
 def test_distance_matrix_matches_oracle(built_lib):
     from oracle import droid_oracle as O
     dev = torch.device("cuda:0")
