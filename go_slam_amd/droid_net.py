@@ -567,6 +567,7 @@ class UpdateModule(nn.Module):
         self._inp_pre_cache = None
 
     INP_CACHE_BYTES = 16 << 30      # hoisted context terms kept at most (least recently used go first; >= 1 entry stays)
+    INP_CACHE_ENTRIES = 64          # ... and at most this many edge sets (a 200-keyframe global BA walks 16 chunks)
 
     def _edge_state(self, inp, n, ht, wd):
         """(hx, inp_pre): the GRU's per-update input buffer [net | corr | flow] (320 ch, NHWC fp16) and
@@ -577,7 +578,6 @@ class UpdateModule(nn.Module):
         chunk of every step -- 16 x 123 us of a 16.9 ms stress step.  69 MB per 75-edge chunk at 30 x 40 (1.1 GB for the
         200-keyframe graph), 276 MB for the S480 frontend window: HBM this part has."""
         import collections
-        import weakref
         hx = getattr(self, "_hx", None)
         if hx is None or hx.shape[0] != n or hx.shape[2:] != (ht, wd) or hx.device != inp.device:
             hx = torch.empty((n, 320, ht, wd), dtype=torch.float16, device=inp.device,
@@ -588,24 +588,28 @@ class UpdateModule(nn.Module):
             cache = self._inp_pre_cache = collections.OrderedDict()
         self.gru._half_weights()                              # refreshes gru._hw_key if the weights changed
         wkey = self.gru._hw_key
-        key = id(inp)
+        # keyed by the MEMORY the features live in (address, shape, strides, dtype) and validated by the tensor's version
+        # counter, which views share: `self.inp[None]` is a new Python object on every call (MotionFilter.track, 35 us per
+        # input frame of recomputation with an object-identity key).  An entry keeps `inp` alive, so its address cannot be
+        # handed to another tensor while the entry exists.
+        key = (inp.data_ptr(), tuple(inp.shape), tuple(inp.stride()), inp.dtype)
         ent = cache.get(key)
-        if ent is not None and ent[0]() is inp and ent[1] == inp._version and ent[2] == wkey:
+        if ent is not None and ent[1] == inp._version and ent[2] == wkey:
             cache.move_to_end(key)
             return hx, ent[3]
         inp4 = inp.view(n, -1, ht, wd)
         if inp4.dtype != torch.float16 or not inp4.is_contiguous(memory_format=torch.channels_last):
             inp4 = inp4.half().contiguous(memory_format=torch.channels_last)
         inp_pre = self.gru.inp_gates(inp4)
-        for k in [k for k, e in cache.items() if e[0]() is None or e[2] != wkey]:      # dead tensors, old weights
+        for k in [k for k, e in cache.items() if e[2] != wkey]:                        # terms of old weights
             del cache[k]
-        cache[key] = (weakref.ref(inp), inp._version, wkey, inp_pre)
-        nbytes = lambda t: sum(x.numel() * x.element_size() for x in (t if isinstance(t, (tuple, list)) else (t,))
-                               if torch.is_tensor(x))
-        total = sum(nbytes(e[3]) for e in cache.values())
-        while total > self.INP_CACHE_BYTES and len(cache) > 1:
+        cache[key] = (inp, inp._version, wkey, inp_pre)
+        nbytes = lambda e: e[0].numel() * e[0].element_size() + sum(
+            x.numel() * x.element_size() for x in (e[3] if isinstance(e[3], (tuple, list)) else (e[3],)) if torch.is_tensor(x))
+        total = sum(nbytes(e) for e in cache.values())
+        while (total > self.INP_CACHE_BYTES or len(cache) > self.INP_CACHE_ENTRIES) and len(cache) > 1:
             _, e = cache.popitem(last=False)
-            total -= nbytes(e[3])
+            total -= nbytes(e)
         return hx, inp_pre
 
     def _head_weights(self):
