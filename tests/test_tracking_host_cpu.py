@@ -336,3 +336,52 @@ def test_conv1x1_stage_row_arithmetic_is_exact():
         pieces = (K + 7) // 8
         stride_halves = 8 * (pieces | 1)
         assert stride_halves >= K and (stride_halves // 8) % 2 == 1
+
+
+def test_update_operator_context_term_cache_keys_and_eviction():
+    """UpdateModule._edge_state keeps the hoisted context term per `inp` MEMORY (address, shape, strides, dtype) and
+    validates it with the tensor's version counter: a fresh view of the same features hits (MotionFilter.track passes
+    `self.inp[None]`, a new object per frame), an in-place write misses, different tensors get their own entries
+    (update_lowmem's chunks), an entry keeps its tensor alive so a freed address cannot be served stale, and the LRU
+    honours its entry / byte caps.  The convolution itself is replaced by a counter here (no GPU)."""
+    from go_slam_amd.droid_net import UpdateModule
+    op = UpdateModule()
+    calls = []
+
+    def fake_gates(x):
+        calls.append(x.data_ptr())
+        return x.float().sum().reshape(1)
+    op.gru.inp_gates = fake_gates
+    op.gru._half_weights = lambda: None
+    op.gru._hw_key = 0
+    n, h, w = 3, 4, 5
+    base = torch.randn(n, 128, h, w).half().contiguous(memory_format=torch.channels_last)[None]
+    _, t1 = op._edge_state(base, n, h, w)
+    _, t2 = op._edge_state(base[0][None], n, h, w)              # a NEW view object of the same memory: hit
+    assert len(calls) == 1 and t2 is t1
+    base.mul_(2.0)                                              # written to: the version counter moves -> recomputed
+    _, t3 = op._edge_state(base[0][None], n, h, w)
+    assert len(calls) == 2 and float(t3) != float(t1)
+    others = [torch.randn(n, 128, h, w).half().contiguous(memory_format=torch.channels_last)[None] for _ in range(5)]
+    for o in others:
+        op._edge_state(o, n, h, w)
+    assert len(calls) == 7 and len(op._inp_pre_cache) == 6     # one entry per tensor, the first one still there
+    for o in others:                                            # walking the chunks again: all hits
+        op._edge_state(o, n, h, w)
+    assert len(calls) == 7
+    # an entry owns a reference to its tensor: dropping ours cannot hand the address to new features
+    ptr = others[0].data_ptr()
+    del others[0]
+    fresh = [torch.randn(n, 128, h, w).half().contiguous(memory_format=torch.channels_last)[None] for _ in range(8)]
+    assert all(f.data_ptr() != ptr for f in fresh)
+    # caps: at most INP_CACHE_ENTRIES entries, least recently used first; a weight change drops every old term
+    op.INP_CACHE_ENTRIES = 3
+    for f in fresh:
+        op._edge_state(f, n, h, w)
+    assert len(op._inp_pre_cache) == 3
+    assert [k[0] for k in op._inp_pre_cache] == [f.data_ptr() for f in fresh[-3:]]
+    op.gru._hw_key = 1
+    op._edge_state(fresh[-1], n, h, w)
+    assert len(op._inp_pre_cache) == 1
+    op.drop_edge_caches()
+    assert op._inp_pre_cache is None
