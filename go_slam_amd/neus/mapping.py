@@ -11,7 +11,7 @@ import torch
 
 from .distributed import mapping_loss_sharded
 from .mapper import MapTrainer
-from .rays import build_rays
+from .rays import RayBank, build_rays
 
 
 def random_select(l, k, start=0):
@@ -83,7 +83,11 @@ class Mapper:
         optimizer.zero_grad(set_to_none=False)
 
     def _ray_batch(self, frames, items, n_rays):
-        """n_rays random (mask-aware) rays from each frame, concatenated (src/mapping.py:222-240, 262-283)"""
+        """n_rays random (mask-aware) rays from each frame, concatenated (src/mapping.py:222-240, 262-283).  `items` is a
+        RayBank over the frames of this call (the per-frame glue of build_rays done once per call, rays.py) or the
+        reference's dict frame -> (color, depth, c2w, gt_c2w, mask)."""
+        if isinstance(items, RayBank):
+            return items.sample(frames, n_rays)
         H, W = self.H, self.W
         parts = [[], [], [], []]
         for frame in frames:
@@ -112,6 +116,8 @@ class Mapper:
         visit_frame = {f: v.get_mapping_item(f, self.device, decay=self.decay) for f in visit_list}
         unvisit_frame = {f: v.get_mapping_item(f, self.device, decay=self.decay) for f in unvisit_list}
         self.mapping_net.update_bound(v.get_bound())
+        bank = lambda items: RayBank(items, self.H, self.W, self.fx, self.fy, self.cx, self.cy, self.device)
+        visit_frame, unvisit_frame = bank(visit_frame), bank(unvisit_frame)
         # new keyframes first: window-sized random subsets of them, 10x the iterations on the very first call
         unvisit_factor = num_joint_iters * 10 if self.init else num_joint_iters
         if len(unvisit_list) > 2:

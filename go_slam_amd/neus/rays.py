@@ -32,3 +32,75 @@ def build_rays(H0, H1, W0, W1, n_rays, H, W, fx, fy, cx, cy, c2w, depth, color, 
     rays_d = dirs @ c2w[:3, :3].t()
     rays_o = c2w[:3, 3].reshape(1, 3).repeat(x.shape[0], 1)
     return rays_o, rays_d, depth, color
+
+
+class RayBank:
+    """The mapper's per-iteration ray draw without its per-frame glue.  `Mapper.__call__` (src/mapping.py:222-240,
+    262-283) calls `build_rays` once per visited keyframe in EVERY joint iteration: per frame a pixel grid, a `nonzero`
+    of the mask (a host sync), four full-resolution gathers, the random pick and the direction arithmetic -- ~25
+    launches and a sync, x 16-22 frames = several milliseconds per iteration around a mapper step that takes 0.8 ms
+    here.  What does not change between the iterations of one call (the frames' colours, depths, masks, poses) is
+    stacked ONCE; the rank -> pixel map of each mask is its running sum, and the valid-pixel counts reach the host in
+    one transfer per call.  A draw is then: the SAME `torch.randint(N_f, (n_rays,))` calls in the same frame order as
+    `build_rays` (a seeded run picks the same pixels as the reference), one `searchsorted` over the concatenated
+    running sums, two gathers and the direction arithmetic for all frames at once -- F + ~15 launches, no sync.
+    Frames whose mask leaves fewer than 2 n_rays pixels take `build_rays` itself (it then returns EVERY valid pixel)."""
+
+    def __init__(self, items, H, W, fx, fy, cx, cy, device):
+        self.items, self.H, self.W, self.device = items, H, W, device
+        self.intr = (fx, fy, cx, cy)
+        self.frames = list(items.keys())
+        self.pos = {f: i for i, f in enumerate(self.frames)}
+        F, HW = len(self.frames), H * W
+        if F == 0:
+            self.N = []
+            return
+        color, depth, c2w, mask = [], [], [], []
+        for f in self.frames:
+            col, dep, pose, _, msk = items[f]
+            color.append(col.reshape(HW, 3))
+            depth.append(dep.reshape(HW))
+            if isinstance(pose, np.ndarray):
+                pose = torch.from_numpy(pose)
+            c2w.append(pose.to(device))
+            mask.append(torch.ones(HW, dtype=torch.bool, device=device) if msk is None else msk.reshape(HW).bool())
+        self.color = torch.cat(color, 0)                                    # [F HW, 3]
+        self.depth = torch.cat(depth, 0)                                    # [F HW]
+        c2w = torch.stack(c2w, 0)
+        self.rot_t = c2w[:, :3, :3].transpose(1, 2).contiguous()            # dirs @ R^T per frame
+        self.trans = c2w[:, :3, 3].contiguous()
+        cums = torch.stack(mask, 0).to(torch.int64).cumsum(1)               # rank of every valid pixel, 1-based
+        self.N = [int(n) for n in cums[:, -1].tolist()]                     # the ONE host transfer of a Mapper call
+        # one sorted array for all frames: frame f's running sum shifted by f (HW + 1) -- a rank query of frame f
+        # (1 .. N_f <= HW) cannot land in another frame's stretch
+        self.big = HW + 1
+        self.cums = (cums + self.big * torch.arange(F, device=cums.device)[:, None]).reshape(-1)
+
+    def sample(self, frames, n_rays):
+        """(rays_o, rays_d, color, depth) of `n_rays` random valid pixels of each of `frames`, concatenated in order"""
+        H, W = self.H, self.W
+        fx, fy, cx, cy = self.intr
+        dev = self.device
+        pos = [self.pos[f] for f in frames]
+        if not pos or any(not (0 < n_rays < self.N[p] // 2) for p in pos):
+            parts = [[], [], [], []]                                       # (rare: tiny masks -- the reference's own form)
+            for f in frames:
+                color, depth, c2w, _, mask = self.items[f]
+                out = build_rays(0, H, 0, W, n_rays, H, W, fx, fy, cx, cy, c2w, depth, color, dev,
+                                 nerf_coordinate=False, dir_normalize=False, mask=mask)
+                for acc, x in zip(parts, out):
+                    acc.append(x.float())
+            rays_o, rays_d, depth, color = (torch.cat(p, dim=0) for p in parts)
+            return rays_o, rays_d, color, depth
+        # the reference's random draws, call for call
+        idx = torch.stack([torch.randint(self.N[p], (n_rays,), device=dev).clamp(0, self.N[p] - 1) for p in pos], 0)
+        fi = torch.tensor(pos, dtype=torch.int64, device=dev)
+        HW = H * W
+        g = torch.searchsorted(self.cums, (idx + 1 + self.big * fi[:, None]).reshape(-1))     # global pixel index
+        local = g - (HW * fi)[:, None].expand(-1, n_rays).reshape(-1)
+        x = (local % W).float()
+        y = torch.div(local, W, rounding_mode="floor").float()
+        dirs = torch.stack([(x - cx) / fx, (y - cy) / fy, torch.ones_like(x)], dim=-1).reshape(len(pos), n_rays, 3)
+        rays_d = torch.bmm(dirs, self.rot_t[fi].to(dirs.dtype)).reshape(-1, 3)
+        rays_o = self.trans[fi].to(dirs.dtype)[:, None, :].expand(-1, n_rays, -1).reshape(-1, 3)
+        return rays_o.float(), rays_d.float(), self.color[g].float(), self.depth[g].float()

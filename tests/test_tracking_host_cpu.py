@@ -385,3 +385,60 @@ def test_update_operator_context_term_cache_keys_and_eviction():
     assert len(op._inp_pre_cache) == 1
     op.drop_edge_caches()
     assert op._inp_pre_cache is None
+
+
+def test_ray_bank_draws_what_build_rays_draws(monkeypatch):
+    """neus/rays.RayBank (the frames of one Mapper call stacked once; a draw = the reference's randint calls + one
+    searchsorted over the masks' running sums) against build_rays called frame by frame (src/nerf_func.py:115-181,
+    src/mapping.py:222-240) under the same seed: same pixels -- origins, colours, depths bit for bit, directions to
+    fp32 rounding of the 3 x 3 product -- with ragged masks, a frame without a mask, repeated frames, numpy poses; and
+    the reference's own form when a mask leaves fewer than 2 n_rays pixels (then EVERY valid pixel is returned)."""
+    from go_slam_amd.neus import rays as R
+    g = torch.Generator().manual_seed(5)
+    H, W, F = 24, 40, 5
+    fx, fy, cx, cy = 30.0, 31.0, 19.5, 11.5
+    items = {}
+    for f in range(F):
+        c2w = torch.eye(4)
+        q = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+        c2w[:3, :3], c2w[:3, 3] = q, torch.randn(3, generator=g)
+        mask = (torch.rand(H, W, generator=g) < (0.3 + 0.15 * f)).float() if f != 2 else None
+        items[10 + f] = (torch.rand(H, W, 3, generator=g), torch.rand(H, W, generator=g) * 3 + 0.5,
+                         c2w.numpy() if f == 1 else c2w, None, mask)
+    bank = R.RayBank(items, H, W, fx, fy, cx, cy, "cpu")
+    assert bank.N[2] == H * W and all(0 < n <= H * W for n in bank.N)
+    frames = [12, 10, 14, 10, 13]
+
+    def per_frame(n_rays):
+        parts = [[], [], [], []]
+        for f in frames:
+            color, depth, c2w, _, mask = items[f]
+            out = R.build_rays(0, H, 0, W, n_rays, H, W, fx, fy, cx, cy, c2w, depth, color, "cpu",
+                               nerf_coordinate=False, dir_normalize=False, mask=mask)
+            for acc, x in zip(parts, out):
+                acc.append(x.float())
+        o, d, dep, col = (torch.cat(p, 0) for p in parts)
+        return o, d, col, dep
+    torch.manual_seed(77)
+    want = per_frame(37)
+    real = R.build_rays
+    monkeypatch.setattr(R, "build_rays", lambda *a, **k: (_ for _ in ()).throw(AssertionError("batched path expected")))
+    torch.manual_seed(77)
+    got = bank.sample(frames, 37)
+    monkeypatch.setattr(R, "build_rays", real)
+    assert got[0].shape == (37 * len(frames), 3)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[2]) and torch.equal(got[3], want[3])
+    torch.testing.assert_close(got[1], want[1], rtol=1e-6, atol=1e-6)
+    torch.manual_seed(77)                                          # both consume the generator identically: the next
+    per_frame(37)                                                  # draw after either is the same
+    nxt = torch.rand(3)
+    torch.manual_seed(77)
+    bank.sample(frames, 37)
+    assert torch.equal(torch.rand(3), nxt)
+    # a mask with fewer than 2 n_rays pixels: the reference returns every valid pixel of that frame
+    n_big = min(bank.N) // 2 + 1
+    torch.manual_seed(78)
+    want = per_frame(n_big)
+    torch.manual_seed(78)
+    got = bank.sample(frames, n_big)
+    assert all(torch.equal(x, y) for x, y in zip(got, want))
