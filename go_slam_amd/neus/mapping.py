@@ -23,6 +23,8 @@ def random_select(l, k, start=0):
 
 
 class Mapper:
+    use_ray_bank = True         # False: the reference's per-frame build_rays calls in every iteration (tools/mapper_call_bench.py)
+
     def __init__(self, cfg, args, slam):
         self.cfg, self.args = cfg, args
         self.verbose = getattr(slam, "verbose", False)
@@ -113,11 +115,16 @@ class Mapper:
             order = torch.sort(priority, dim=0, descending=True).indices
             visit_list += list(order.cpu().numpy())[:10]
             visit_list += random_select(self.last_visit, self.mapping_window_size - 12)
-        visit_frame = {f: v.get_mapping_item(f, self.device, decay=self.decay) for f in visit_list}
-        unvisit_frame = {f: v.get_mapping_item(f, self.device, decay=self.decay) for f in unvisit_list}
+        if hasattr(v, "get_mapping_items"):                 # all hand-outs of the call in one pass (depth_video.py)
+            visit_frame = v.get_mapping_items(visit_list, self.device, decay=self.decay)
+            unvisit_frame = v.get_mapping_items(unvisit_list, self.device, decay=self.decay)
+        else:
+            visit_frame = {f: v.get_mapping_item(f, self.device, decay=self.decay) for f in visit_list}
+            unvisit_frame = {f: v.get_mapping_item(f, self.device, decay=self.decay) for f in unvisit_list}
         self.mapping_net.update_bound(v.get_bound())
-        bank = lambda items: RayBank(items, self.H, self.W, self.fx, self.fy, self.cx, self.cy, self.device)
-        visit_frame, unvisit_frame = bank(visit_frame), bank(unvisit_frame)
+        if self.use_ray_bank:
+            bank = lambda items: RayBank(items, self.H, self.W, self.fx, self.fy, self.cx, self.cy, self.device)
+            visit_frame, unvisit_frame = bank(visit_frame), bank(unvisit_frame)
         # new keyframes first: window-sized random subsets of them, 10x the iterations on the very first call
         unvisit_factor = num_joint_iters * 10 if self.init else num_joint_iters
         if len(unvisit_list) > 2:

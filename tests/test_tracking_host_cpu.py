@@ -442,3 +442,26 @@ def test_ray_bank_draws_what_build_rays_draws(monkeypatch):
     torch.manual_seed(78)
     got = bank.sample(frames, n_big)
     assert all(torch.equal(x, y) for x, y in zip(got, want))
+
+
+def test_get_mapping_items_equals_the_per_keyframe_hand_outs():
+    """DepthVideo.get_mapping_items (one pass for all keyframes a Mapper call visits) vs get_mapping_item called once per
+    list entry (src/depth_video.py:153-177): the same five tensors per keyframe bit for bit, and the priorities decayed
+    once per OCCURRENCE (the mapper's visit list repeats keyframes)."""
+    gen = _gen()
+    vids = []
+    for _ in range(2):
+        video = DepthVideo.from_config(gen.mapper_cfg(), types.SimpleNamespace(device="cpu"))
+        gen.fill_mapping_video(video)
+        video.pose_compensate[0] = torch.tensor([0.1, -0.2, 0.05, 0.0, 0.1, 0.0, 0.995]) / torch.tensor(
+            [1, 1, 1, 1, 1, 1, 1.0])
+        vids.append(video)
+    order = [7, 3, 7, 5, 3, 7]
+    one = {i: vids[0].get_mapping_item(i, "cpu", decay=0.5) for i in order}      # (a dict: later hand-outs overwrite)
+    many = vids[1].get_mapping_items(order, "cpu", decay=0.5)
+    assert list(many) == [7, 3, 5]
+    for i in many:
+        for a, b in zip(one[i], many[i]):
+            assert torch.equal(a, b)
+    assert torch.equal(vids[0].update_priority, vids[1].update_priority)
+    assert vids[1].get_mapping_items([], "cpu") == {}
