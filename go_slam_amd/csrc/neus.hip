@@ -992,7 +992,8 @@ namespace {
 struct NeusWs {
   uint8_t* flags; float* alpha; float* grad; uint8_t* mask; _Float16* mlp_in; _Float16* rgb; u32x4* rec; size_t total;
 };
-NeusWs carve_neus(void* base, int n, int s) {
+// `rec_levels`: hashed levels whose level-major records get room (0: the point kernel gathers every level itself)
+NeusWs carve_neus(void* base, int n, int s, int rec_levels) {
   NeusWs w;
   size_t off = 0;
   const size_t np = (size_t)n * s;
@@ -1003,7 +1004,7 @@ NeusWs carve_neus(void* base, int n, int s) {
   w.mask = (uint8_t*)take(np);
   w.mlp_in = (_Float16*)take(np * 80 * 2);
   w.rgb = (_Float16*)take(np * 3 * 2 + 64);
-  w.rec = (u32x4*)take(np * 16 * GS_GRID_LEVELS);       // level-major records of the hashed levels (<= 16 levels x 16 B)
+  w.rec = rec_levels > 0 ? (u32x4*)take(np * 16 * (size_t)rec_levels) : nullptr;   // 16 B per point and hashed level
   w.total = off;
   return w;
 }
@@ -1019,9 +1020,20 @@ extern "C" int gs_neus_level_major_min_points(int points) {
   return old;
 }
 
+static int hashed_levels(const gs_grid_meta& meta, int* first_hashed) {
+  int first = GS_GRID_LEVELS;
+  for (int l = GS_GRID_LEVELS - 1; l >= 0 && meta.hashed[l]; --l) first = l;      // (the hashed levels are the finest)
+  if (first_hashed) *first_hashed = first;
+  return GS_GRID_LEVELS - first;
+}
+
+// Level-major records (16 B per point and HASHED level: 11 of the 16 levels here) are only reserved for batches that use
+// them (>= gs_neus_level_major_min_points sample points): 176 B per point = 415 MB at 32768 x 72, nothing for the mapper's
+// own 4096-ray batches (round 5 reserved 256 B per point for every batch: 75 MB at 4096 rays).
 extern "C" size_t gs_neus_forward_workspace_bytes(int n, int s) {
   if (n < 0 || s < 0) return 0;
-  return carve_neus(nullptr, n, s).total + 256;
+  const bool lm = (long long)n * s >= level_major_min_points();
+  return carve_neus(nullptr, n, s, lm ? hashed_levels(host_meta(), nullptr) : 0).total + 256;
 }
 
 extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const float* z_vals, const float* dists,
@@ -1039,12 +1051,24 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
              "neus_forward: null output");
   GS_REQUIRE(n >= 0 && s > 0, "neus_forward: bad shape");
   if (n == 0) return GS_OK;
-  const size_t need = gs_neus_forward_workspace_bytes(n, s);
+  const gs_grid_meta meta = host_meta();
+  int first_hashed = GS_GRID_LEVELS;
+  int nh = hashed_levels(meta, &first_hashed);
+  const size_t need = carve_neus(nullptr, n, s, 0).total + 256;
   if (!workspace || workspace_bytes < need) {
     gs_set_error("neus_forward: workspace too small (%zu < %zu)", workspace_bytes, need);
     return GS_ERR_WORKSPACE;
   }
-  NeusWs ws = carve_neus((void*)gs_align((size_t)workspace), n, s);
+  // Level-major pays where the table traffic is the bound: measured on MI355X (profiles/r05_level_major_crossover.json,
+  // r05_gather_replay.json), 32768 rays x 72 samples: 1149 -> 993 us, the gathers alone 1.07 -> 0.51 ms in the gather-only
+  // replay; at 4096 rays a level's chunks do not fill one residency round per XCD, both orders are latency-bound and the
+  // extra launch + the record round trip cost more than the misses (146 -> 162 us).  The two meet at ~442 K points; below
+  // gs_neus_level_major_min_points (524288) the point kernel gathers every level itself (rec == nullptr), as the
+  // one-workgroup force pass always does -- and so does a call whose workspace has no room for the records (a caller
+  // that sized it before the crossover was lowered).
+  if ((long long)n * s < level_major_min_points()) nh = 0;
+  if (nh > 0 && workspace_bytes < carve_neus(nullptr, n, s, nh).total + 256) nh = 0;
+  NeusWs ws = carve_neus((void*)gs_align((size_t)workspace), n, s, nh);
   hipStream_t st = (hipStream_t)stream;
   NeusArgs A;
   A.rays_o = rays_o; A.rays_d = rays_d; A.z_vals = z_vals; A.dists = dists;
@@ -1061,17 +1085,6 @@ extern "C" int gs_neus_forward(const float* rays_o, const float* rays_d, const f
   if (mask_out) ws.mask = mask_out;
   GS_TIMING_PRE();
   // level-major encode of the hashed levels (records in the workspace), then the per-point stage
-  const gs_grid_meta meta = host_meta();
-  int first_hashed = GS_GRID_LEVELS;
-  for (int l = GS_GRID_LEVELS - 1; l >= 0 && meta.hashed[l]; --l) first_hashed = l;      // (the hashed levels are the finest)
-  int nh = GS_GRID_LEVELS - first_hashed;
-  // Level-major pays where the table traffic is the bound: measured on MI355X (profiles/r05_level_major_crossover.json,
-  // r05_gather_replay.json), 32768 rays x 72 samples: 1149 -> 993 us, the gathers alone 1.07 -> 0.51 ms in the gather-only
-  // replay; at 4096 rays a level's chunks do not fill one residency round per XCD, both orders are latency-bound and the
-  // extra launch + the record round trip cost more than the misses (146 -> 162 us).  The two meet at ~442 K points; below
-  // gs_neus_level_major_min_points (524288) the point kernel gathers every level itself (rec == nullptr), as the
-  // one-workgroup force pass always does.
-  if (np < level_major_min_points()) nh = 0;
   if (nh > 0) {
     const int cpx = gs_cdiv(gs_cdiv(np, 256), 8);
     neus_encode_levels_kernel<<<8 * cpx * nh, 256, 0, st>>>(A, meta, ws.rec, (_Float16*)enc_aux_out, first_hashed, cpx);

@@ -129,8 +129,35 @@ class DepthVideo:
         for slot, name in ((5, "intrinsics"), (6, "fmaps"), (7, "nets"), (8, "inps")):
             if len(item) > slot and (slot > 5 or item[slot] is not None):
                 getattr(self, name)[index] = item[slot]
+        if len(item) > 6:
+            self._run_write_hooks(index)
         if len(item) > 9 and item[9] is not None and hasattr(self, "poses_gt"):
             self.poses_gt[index] = item[9].to(self.poses_gt.device)
+
+    def add_write_hook(self, fn):
+        """`fn(index)` runs after every `video[index] = item` that wrote context / feature maps (`fmaps`, `nets`, `inps`):
+        the explicit invalidation point for anything cached from those buffers by a reader that cannot see torch's version
+        counters move -- e.g. `video.add_write_hook(lambda ix: net.update.invalidate_context())` in a process that shares
+        the buffers with the writer (the counters are per process).  Hooks are held weakly when they are bound methods."""
+        import weakref
+        hooks = self.__dict__.setdefault("_write_hooks", [])
+        hooks.append(weakref.WeakMethod(fn) if hasattr(fn, "__self__") else (lambda f=fn: f))
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_write_hooks", None)             # per process: a spawned worker registers its own
+        return state
+
+    def _run_write_hooks(self, index):
+        hooks = self.__dict__.get("_write_hooks")
+        if hooks:
+            live = []
+            for h in hooks:
+                fn = h()
+                if fn is not None:
+                    fn(index)
+                    live.append(h)
+            self._write_hooks = live
 
     def __getitem__(self, index):
         """(poses, disps, intrinsics, fmaps, nets, inps) at `index` (src/depth_video.py:127-143; the reference
@@ -144,19 +171,22 @@ class DepthVideo:
         self[self._count()] = item
 
     def get_bound(self):
-        return self.bound[0]
+        with self.mapping.get_lock():                 # src/depth_video.py:145-149
+            return self.bound[0]
 
     def get_mapping_item(self, index, device="cuda:0", decay=0.1):
         """(image [H,W,3], depth [H,W], c2w [4,4], gt_c2w [4,4], mask [H,W]) of a filtered keyframe for the mapper
         (src/depth_video.py:153-177); each hand-out decays the keyframe's update priority."""
         from .lietorch_shim import SE3
-        image = self.images[index].permute(1, 2, 0).contiguous().to(device)
-        mask = self.mask_filtered[index].clone().to(device)
-        depth = 1.0 / (self.disps_filtered[index].to(device) + 1e-7)
-        w2c = SE3(self.poses_filtered[index].clone()).to(device)
-        c2w = (SE3(self.pose_compensate[0].clone()).to(device) * w2c.inv()).matrix()      # origin alignment
-        gt_c2w = self.poses_gt[index].clone().to(device)
-        self.update_priority[index] *= decay
+        with self.mapping.get_lock():       # MultiviewFilter writes these buffers under the same lock (:153)
+            image = self.images[index].permute(1, 2, 0).contiguous().to(device)
+            mask = self.mask_filtered[index].clone().to(device)
+            depth = 1.0 / (self.disps_filtered[index].to(device) + 1e-7)
+            w2c = SE3(self.poses_filtered[index].clone()).to(device)
+            c2w = (SE3(self.pose_compensate[0].clone()).to(device) * w2c.inv()).matrix()      # origin alignment
+            gt_c2w = self.poses_gt[index].clone().to(device)
+            self.update_priority[index] *= decay
+            self._finish_locked_section()
         return image, depth, c2w, gt_c2w, mask
 
     def get_mapping_items(self, indices, device="cuda:0", decay=0.1):
@@ -170,18 +200,20 @@ class DepthVideo:
         if not uniq:
             return {}
         t = torch.as_tensor(uniq, dtype=torch.long, device=self.images.device)
-        images = self.images[t].permute(0, 2, 3, 1).contiguous().to(device)
-        masks = self.mask_filtered[t].clone().to(device)
-        depths = 1.0 / (self.disps_filtered[t].to(device) + 1e-7)
-        w2c = SE3(self.poses_filtered[t].clone()).to(device)
-        c2w = (SE3(self.pose_compensate[0:1].clone()).to(device) * w2c.inv()).matrix()     # origin alignment
-        gt = self.poses_gt[t].clone().to(device)
         count = {}
         for i in order:
             count[i] = count.get(i, 0) + 1
-        for k in range(max(count.values())):                    # (p * d) * d, not p * d^2: the separate calls' rounding
-            sel = [i for i in uniq if count[i] > k]
-            self.update_priority[torch.as_tensor(sel, dtype=torch.long, device=self.update_priority.device)] *= decay
+        with self.mapping.get_lock():       # the filter's writes are atomic w.r.t. the WHOLE batched hand-out
+            images = self.images[t].permute(0, 2, 3, 1).contiguous().to(device)
+            masks = self.mask_filtered[t].clone().to(device)
+            depths = 1.0 / (self.disps_filtered[t].to(device) + 1e-7)
+            w2c = SE3(self.poses_filtered[t].clone()).to(device)
+            c2w = (SE3(self.pose_compensate[0:1].clone()).to(device) * w2c.inv()).matrix()     # origin alignment
+            gt = self.poses_gt[t].clone().to(device)
+            for k in range(max(count.values())):                    # (p * d) * d, not p * d^2: the separate calls' rounding
+                sel = [i for i in uniq if count[i] > k]
+                self.update_priority[torch.as_tensor(sel, dtype=torch.long, device=self.update_priority.device)] *= decay
+            self._finish_locked_section()
         return {i: (images[j], depths[j], c2w[j], gt[j], masks[j]) for j, i in enumerate(uniq)}
 
     def normalize(self):

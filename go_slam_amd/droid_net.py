@@ -562,12 +562,40 @@ class UpdateModule(nn.Module):
         self._head_cache = {}
 
     def drop_edge_caches(self):
-        """Forget what is cached per edge set (the hoisted context-feature convolutions).  Happens by
-        itself when `inp` is a different tensor; callers that reuse one tensor object can force it."""
+        """Forget what is cached per edge set (the hoisted context-feature convolutions).  Happens by itself when `inp`
+        is a different tensor, was written through torch (version counter) or was freed; a caller that writes the
+        features through a RAW POINTER (a HIP launch on `inp.data_ptr()`, another process on shared memory) calls this."""
         self._inp_pre_cache = None
 
-    INP_CACHE_BYTES = 16 << 30      # hoisted context terms kept at most (least recently used go first; >= 1 entry stays)
+    invalidate_context = drop_edge_caches       # the explicit hook (DepthVideo.add_write_hook(update.invalidate_context))
+
+    # hoisted context terms kept at most: an eighth of the device's memory, never more than this (least recently used go
+    # first; >= 1 entry stays).  An entry lives only as long as the `inp` tensor it was computed from (weak reference).
+    INP_CACHE_BYTES = 16 << 30
     INP_CACHE_ENTRIES = 64          # ... and at most this many edge sets (a 200-keyframe global BA walks 16 chunks)
+    # debug mode (GOSLAM_CACHE_CHECK=1 or `update.cache_check = True`): every cache hit re-reads `inp` and compares a
+    # checksum with the one taken when the term was computed -- one reduction + one host sync per update, so a write the
+    # version counter cannot see (raw pointer, other process) raises instead of silently serving the old term
+    cache_check = os.environ.get("GOSLAM_CACHE_CHECK", "0") == "1"
+
+    @staticmethod
+    def _checksum(inp):
+        flat = inp.detach().reshape(-1)
+        if flat.dtype in (torch.float16, torch.bfloat16):
+            flat = flat.view(torch.int16)
+        elif flat.dtype == torch.float32:
+            flat = flat.view(torch.int32)
+        w = (torch.arange(flat.numel(), device=flat.device, dtype=torch.int64) % 8191) + 1      # position-sensitive
+        return int((flat.to(torch.int64) * w).sum())
+
+    def _cache_cap(self, device):
+        cap = self.INP_CACHE_BYTES
+        if device.type == "cuda":
+            try:
+                cap = min(cap, torch.cuda.mem_get_info(device)[1] // 8)
+            except RuntimeError:
+                pass
+        return cap
 
     def _edge_state(self, inp, n, ht, wd):
         """(hx, inp_pre): the GRU's per-update input buffer [net | corr | flow] (320 ch, NHWC fp16) and
@@ -576,8 +604,17 @@ class UpdateModule(nn.Module):
         TENSOR (round 5): FactorGraph.update_lowmem walks the same 13-keyframe chunks in every one of its steps, each with
         its own cached context tensor, and with one slot the 128 -> 384 convolution (+ a layout copy) was redone for every
         chunk of every step -- 16 x 123 us of a 16.9 ms stress step.  69 MB per 75-edge chunk at 30 x 40 (1.1 GB for the
-        200-keyframe graph), 276 MB for the S480 frontend window: HBM this part has."""
+        200-keyframe graph), 276 MB for the S480 frontend window.
+
+        Lifetime (round 6): an entry holds a WEAK reference to the tensor that owns the features' memory (`inp`, or the
+        tensor `inp` is a view of) and disappears with it -- FactorGraph.add_factors / rm_factors build a new `self.inp`
+        on every edge-set change, and with strong references the frontend pinned up to 64 dead edge sets (8 GB at
+        30 x 40, the 16 GB cap at 60 x 80).  While the owner lives its address cannot be handed to another tensor, so a
+        hit on (address, shape, strides, dtype) + the shared version counter is the same memory with the same content.
+        The byte cap follows the device (an eighth of its memory), and an out-of-memory while computing a term empties
+        the cache and tries once more."""
         import collections
+        import weakref
         hx = getattr(self, "_hx", None)
         if hx is None or hx.shape[0] != n or hx.shape[2:] != (ht, wd) or hx.device != inp.device:
             hx = torch.empty((n, 320, ht, wd), dtype=torch.float16, device=inp.device,
@@ -590,24 +627,42 @@ class UpdateModule(nn.Module):
         wkey = self.gru._hw_key
         # keyed by the MEMORY the features live in (address, shape, strides, dtype) and validated by the tensor's version
         # counter, which views share: `self.inp[None]` is a new Python object on every call (MotionFilter.track, 35 us per
-        # input frame of recomputation with an object-identity key).  An entry keeps `inp` alive, so its address cannot be
-        # handed to another tensor while the entry exists.
+        # input frame of recomputation with an object-identity key).
+        owner = inp._base if inp._base is not None else inp
         key = (inp.data_ptr(), tuple(inp.shape), tuple(inp.stride()), inp.dtype)
         ent = cache.get(key)
-        if ent is not None and ent[1] == inp._version and ent[2] == wkey:
+        if ent is not None and ent[0]() is owner and ent[1] == inp._version and ent[2] == wkey:
+            if self.cache_check and ent[4] != self._checksum(inp):
+                raise RuntimeError("UpdateModule: the context features `inp` were modified behind the version counter "
+                                   "(raw-pointer write?) while their hoisted convolution was cached; call "
+                                   "update.invalidate_context() after such writes")
             cache.move_to_end(key)
             return hx, ent[3]
         inp4 = inp.view(n, -1, ht, wd)
         if inp4.dtype != torch.float16 or not inp4.is_contiguous(memory_format=torch.channels_last):
             inp4 = inp4.half().contiguous(memory_format=torch.channels_last)
-        inp_pre = self.gru.inp_gates(inp4)
-        for k in [k for k, e in cache.items() if e[2] != wkey]:                        # terms of old weights
+        try:
+            inp_pre = self.gru.inp_gates(inp4)
+        except torch.OutOfMemoryError:
+            cache.clear()
+            torch.cuda.empty_cache()
+            inp_pre = self.gru.inp_gates(inp4)
+        for k in [k for k, e in cache.items() if e[2] != wkey or e[0]() is None]:       # old weights / dead owners
             del cache[k]
-        cache[key] = (inp, inp._version, wkey, inp_pre)
-        nbytes = lambda e: e[0].numel() * e[0].element_size() + sum(
-            x.numel() * x.element_size() for x in (e[3] if isinstance(e[3], (tuple, list)) else (e[3],)) if torch.is_tensor(x))
+
+        def _gone(_ref, key=key, cache_ref=weakref.ref(cache)):
+            c = cache_ref()
+            if c is not None:
+                e = c.get(key)
+                if e is not None and e[0] is _ref:
+                    del c[key]
+        cache[key] = (weakref.ref(owner, _gone), inp._version, wkey, inp_pre,
+                      self._checksum(inp) if self.cache_check else None)
+        nbytes = lambda e: sum(x.numel() * x.element_size()
+                               for x in (e[3] if isinstance(e[3], (tuple, list)) else (e[3],)) if torch.is_tensor(x))
         total = sum(nbytes(e) for e in cache.values())
-        while (total > self.INP_CACHE_BYTES or len(cache) > self.INP_CACHE_ENTRIES) and len(cache) > 1:
+        cap = self._cache_cap(inp.device)
+        while (total > cap or len(cache) > self.INP_CACHE_ENTRIES) and len(cache) > 1:
             _, e = cache.popitem(last=False)
             total -= nbytes(e)
         return hx, inp_pre

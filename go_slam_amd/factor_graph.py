@@ -439,7 +439,9 @@ class FactorGraph:
         stereo pairs), the source keyframes to upsample and the GraphAgg segments."""
         from .droid_net import build_segments
         tens = (self.ii, self.jj)
-        key = tuple(x._version for x in tens) + (t0, t1, rig)
+        # (the chunks keep laid-out copies of video.inps rows: a torch write to that buffer -- a keyframe appended or
+        # shifted by rm_keyframe -- rebuilds them; writers torch cannot see use DepthVideo.add_write_hook)
+        key = tuple(x._version for x in tens) + (t0, t1, rig, getattr(getattr(self.video, "inps", None), "_version", 0))
         c = getattr(self, "_lidx", None)
         if c is not None and c["key"] == key and all(a is b for a, b in zip(c["tens"], tens)):
             return c
@@ -501,6 +503,7 @@ class FactorGraph:
                     and self.target.dtype == torch.float32 and self.target.is_contiguous()
                     and self.weight.dtype == torch.float32 and self.weight.is_contiguous()
                     and self.net.dtype == torch.float16 and self.net[0].is_contiguous(memory_format=cl)
+                    and self.net.shape[2] == 128          # gs_lowmem_gather / _scatter move 16 uint4 of state per pixel
                     and tuple(self.target.shape) == tuple(coords1.shape) == tuple(self.weight.shape))
             if fast:
                 from . import _lib
@@ -531,8 +534,11 @@ class FactorGraph:
                     if self.upsample:
                         self.video.upsample(ck["uniq"], upmask[0])
                 if fast and net.dtype == torch.float16 and net[0].is_contiguous(memory_format=cl) \
-                        and delta.dtype == torch.float32 and weight.dtype == torch.float32:
-                    _lib.check(L.gs_lowmem_scatter(_lib.ptr(c1), _lib.ptr(delta.contiguous()), _lib.ptr(weight.contiguous()),
+                        and tuple(net.shape) == (1, sel.numel(), 128, ht, wd) \
+                        and delta.dtype == torch.float32 and weight.dtype == torch.float32 \
+                        and tuple(delta.shape) == tuple(weight.shape) == (1, sel.numel(), ht, wd, 2):
+                    delta_c, weight_c = delta.contiguous(), weight.contiguous()     # (bound: alive across the launch)
+                    _lib.check(L.gs_lowmem_scatter(_lib.ptr(c1), _lib.ptr(delta_c), _lib.ptr(weight_c),
                                                    _lib.ptr(net), _lib.ptr(sel), _lib.ptr(self.target), _lib.ptr(self.weight),
                                                    _lib.ptr(self.net), sel.numel(), ht, wd, st), "lowmem_scatter")
                 else:

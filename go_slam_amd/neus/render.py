@@ -8,7 +8,7 @@ from .. import _lib
 
 class Renderer:
     def __init__(self, cfg=None, args=None, slam=None, points_batch_size=1e4, ray_batch_size=5e3,
-                 N_samples=24, N_surface=48, perturb=1.0, lindisp=False):
+                 N_samples=24, N_surface=48, perturb=1.0, lindisp=False, rand_pool_rows=1):
         self.ray_batch_size = int(ray_batch_size)
         self.points_batch_size = int(points_batch_size)
         r = (cfg or {}).get("rendering", {})
@@ -18,6 +18,11 @@ class Renderer:
         self.N_surface = r.get("N_surface", N_surface)
         if self.lindisp:
             raise NotImplementedError("lindisp sampling is off in every reference config (configs/*.yaml)")
+        # 1 (default): one `torch.rand(N_samples, device=...)` per batch -- the reference's own call (render.py:159), so a
+        # seeded run consumes the device generator exactly as the reference does (the mapper's pixel draws between two
+        # batches come from the same stream).  > 1: one [rows, N_samples] draw per `rows` batches (one launch less per
+        # batch; NOT the same Philox consumption, so not the reference's numbers under a seed)
+        self.rand_pool_rows = int(rand_pool_rows)
         self._lin = {}
         self._rand = {}
 
@@ -27,15 +32,15 @@ class Renderer:
             self._lin[key] = torch.linspace(0, 1, steps=steps, device=device).float().contiguous()
         return self._lin[key]
 
-    _RAND_ROWS = 128
-
     def _perturb_row(self, ns, device):
-        """One `torch.rand(N_samples)` vector per batch (render.py:159), drawn `_RAND_ROWS` batches at a time: the same
-        generator stream cut into rows, one launch per 128 batches instead of one per batch."""
+        """The `torch.rand(N_samples)` vector of one batch (render.py:159), shared by all its rays."""
+        rows = self.rand_pool_rows
+        if rows <= 1:
+            return torch.rand(ns, device=device)
         key = (ns, str(device))
-        pool, used = self._rand.get(key, (None, self._RAND_ROWS))
-        if used >= self._RAND_ROWS:
-            pool, used = torch.rand(self._RAND_ROWS, ns, device=device), 0
+        pool, used = self._rand.get(key, (None, rows))
+        if used >= rows:
+            pool, used = torch.rand(rows, ns, device=device), 0
         self._rand[key] = (pool, used + 1)
         return pool[used]
 

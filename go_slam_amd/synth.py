@@ -125,3 +125,28 @@ def make_features(num, shape="S480", seed=43, dim=128, dtype=torch.float16):
     g = torch.Generator().manual_seed(seed + 3)
     ht, wd, _ = SHAPES[shape]
     return torch.randn(num, dim, ht, wd, generator=g).to(dtype)
+
+
+def make_altcorr_chunk(seed=211):
+    """Inputs of the one-launch alt-corr fixture (tests/golden/gen_golden.py::gen_reference_altcorr_pyramid and its GPU
+    test): a 9-edge chunk over 5 ScanNet-shaped keyframes (30 x 40 maps, fp16 features); edges 0-4 carry a smooth reprojection-like
+    flow (the matrix-core path), 5-7 three pixels of per-pixel noise (both paths), edge 8 coordinates far outside the map."""
+    ht, wd, _ = SHAPES["Scan"]
+    g = torch.Generator().manual_seed(seed)
+    fm = (torch.randn(1, 5, 128, ht, wd, generator=g) * 1.5).half()
+    ii = torch.tensor([0, 1, 2, 4, 3, 1, 0, 2, 4])
+    jj = torch.tensor([1, 0, 4, 2, 3, 3, 4, 0, 1])
+    ys, xs = torch.meshgrid(torch.arange(ht, dtype=torch.float32), torch.arange(wd, dtype=torch.float32), indexing="ij")
+    coords = []
+    for e in range(9):
+        a = 1.0 + 0.15 * (torch.rand(4, generator=g) - 0.5)
+        t = 4.0 * torch.randn(2, generator=g)
+        x = a[0] * xs + 0.05 * (a[1] - 1) * ys + t[0] + 0.7 * torch.sin(ys / 5.0 + t[1])
+        y = a[2] * ys + 0.05 * (a[3] - 1) * xs + t[1] + 0.7 * torch.cos(xs / 6.0 + t[0])
+        c = torch.stack([x, y], -1)
+        if e >= 5:
+            c = c + 3.0 * torch.randn(ht, wd, 2, generator=g)
+        if e == 8:
+            c = c * 3.0 - 20.0
+        coords.append(c)
+    return fm, ii, jj, torch.stack(coords)[None].contiguous()

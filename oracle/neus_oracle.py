@@ -75,9 +75,28 @@ def _grid_index(meta, l, cx, cy, cz):
     return (idx % size).astype(np.int64)
 
 
-def grid_encode(x, params, meta=None, want_grad=False):
+# How the 8 corner values of a level are summed / how a layer's dot products are accumulated.  tiny-cuda-nn is absent from
+# /root/reference and unpinned, so WHICH of these the installed binary did cannot be checked here:
+#   "float"        (default; what the HIP kernels follow) fp32 fused multiply-adds, ONE rounding to fp16 at the end;
+#   "half"         upstream's types as published: kernel_grid keeps `result` in vector_t<T = __half> and adds each corner with a
+#                  half fma (weight rounded to half, one rounding per corner); FullyFusedMLP keeps wmma accumulator fragments
+#                  in half (one rounding per 16-wide k-step, products and the 16-term sum exact inside the matrix unit);
+#   "half_mul_add" the older kernel_grid form `result += (T)(weight * (float)val)`: the product rounded to half, then a half add.
+# tests/test_oracle_pinned.py::test_half_accumulation_* measures how far the three are apart (profiles/r06_tcnn_half_accumulation.json).
+ACCUMULATE = "float"
+
+
+def _h(a):
+    """round an fp32 / fp64 numpy array to fp16 and back (round-to-nearest-even, numpy's conversion)"""
+    return a.astype(np.float16).astype(np.float32)
+
+
+def grid_encode(x, params, meta=None, want_grad=False, accumulate=None):
     """tcnn kernel_grid<T=half,3,2> forward (+ dy_dx): x f32 [n,3] in [0,1]; params f16 (or f32
-    master, cast to f16) [total*2].  Returns enc f16 [n,32] and (optionally) dy_dx f32 [n,32,3]."""
+    master, cast to f16) [total*2].  Returns enc f16 [n,32] and (optionally) dy_dx f32 [n,32,3] (dy_dx is accumulated in
+    fp32 upstream too: `vector_fullp_t` gradients).  `accumulate`: see ACCUMULATE above."""
+    accumulate = accumulate or ACCUMULATE
+    assert accumulate in ("float", "half", "half_mul_add")
     meta = meta or grid_meta()
     n = x.shape[0]
     p16 = params.detach().to(torch.float16).float().numpy().reshape(-1, N_FEATS)
@@ -105,8 +124,12 @@ def grid_encode(x, params, meta=None, want_grad=False):
                     cc.append(gi[:, d])
             idx = _grid_index(meta, l, cc[0], cc[1], cc[2]) + off
             val = p16[idx]
-            # result = fmaf(w, val, result)
-            res = (w[:, None].astype(np.float64) * val.astype(np.float64) + res.astype(np.float64)).astype(np.float32)
+            if accumulate == "float":      # result = fmaf(w, val, result)
+                res = (w[:, None].astype(np.float64) * val.astype(np.float64) + res.astype(np.float64)).astype(np.float32)
+            elif accumulate == "half":     # result = __hfma((half)w, val, result): exact in fp64 (11 + 11 bit product), one rounding
+                res = _h(_h(w)[:, None].astype(np.float64) * val.astype(np.float64) + res.astype(np.float64))
+            else:                          # result += (half)(w * (float)val)
+                res = _h(_h(w[:, None] * val).astype(np.float64) + res.astype(np.float64))
         enc[:, 2 * l:2 * l + 2] = res
         if want_grad:
             for gd in range(3):
@@ -136,10 +159,24 @@ def grid_encode(x, params, meta=None, want_grad=False):
     return enc16
 
 
-def mlp_forward(x, params, n_in=67, n_out=3, width=64):
+def _layer(h, W, accumulate):
+    """h [n,k] @ W[out,k]^T on fp16-representable values -> fp32 tensor holding the layer's pre-activation as the chosen
+    accumulator type would leave it."""
+    if accumulate == "float":
+        return h @ W.t()
+    acc = torch.zeros(h.shape[0], W.shape[0], dtype=torch.float64)
+    for k in range(0, h.shape[1], 16):     # one 16x16x16 matrix-unit step: exact products + sum, then the accumulator's rounding
+        acc = (acc + h[:, k:k + 16].double() @ W[:, k:k + 16].double().t()).to(torch.float16).double()
+    return acc.float()
+
+
+def mlp_forward(x, params, n_in=67, n_out=3, width=64, accumulate=None):
     """tcnn FullyFusedMLP (2 hidden layers, ReLU, no bias) behind tcnn.Network: input cast to
     fp16 and padded to a multiple of 16 with ONES, weights fp16 row-major [out,in] in layer
-    order, fp32 accumulation, activations stored fp16, output sliced to n_out.  x [n,n_in]."""
+    order, fp32 accumulation (`accumulate="half"`: half accumulator fragments, see ACCUMULATE), activations stored fp16,
+    output sliced to n_out.  x [n,n_in]."""
+    accumulate = accumulate or ACCUMULATE
+    accumulate = "half" if accumulate == "half_mul_add" else accumulate
     pad_in = (n_in + 15) // 16 * 16
     pad_out = (n_out + 15) // 16 * 16
     w = params.detach().to(torch.float16).float()
@@ -150,9 +187,9 @@ def mlp_forward(x, params, n_in=67, n_out=3, width=64):
     n = x.shape[0]
     xin = torch.ones(n, pad_in)
     xin[:, :n_in] = x.detach().to(torch.float16).float()
-    h = torch.relu(xin @ W1.t()).to(torch.float16).float()
-    h = torch.relu(h @ W2.t()).to(torch.float16).float()
-    out = (h @ W3.t()).to(torch.float16)
+    h = torch.relu(_layer(xin, W1, accumulate)).to(torch.float16).float()
+    h = torch.relu(_layer(h, W2, accumulate)).to(torch.float16).float()
+    out = _layer(h, W3, accumulate).to(torch.float16)
     return out[:, :n_out]
 
 

@@ -36,6 +36,8 @@ What the fixtures therefore PIN is every line of reference Python on the hot pat
                          backward) on a twice-differentiable stand-in: every trained parameter's gradient -> neus_backward.npz
   * lib/*.cu             the reference's CUDA kernels themselves, compiled for the CPU (oracle/build_ref.py): ba,
                          frame_distance, projmap, iproj, depth_filter on seeded inputs             -> reference_kernels.npz
+  * modules/corr.py + lib/altcorr_kernel.cu  AltCorrBlock over the reference's own alt-corr kernel, 4 levels, 9 edges
+                                                                                -> reference_altcorr_pyramid.npz
 The tcnn / lietorch stand-ins stay "parity unpinned" (DESIGN.md 5); the CUDA kernels no longer do.
 The reference is only imported, never copied; outputs are small .npz files next to this script.
 """
@@ -1230,6 +1232,34 @@ def gen_reference_kernels_bench():
     save("reference_kernels_bench.npz", **out)
 
 
+def gen_reference_altcorr_pyramid():
+    """The reference's OWN `AltCorrBlock` (src/modules/corr.py:95-145, imported and run as is: feature pyramid, the per-level
+    `pyramid[0][:, ii]` / `pyramid[i][:, jj]` gathers, `coords / 2^i`, the fp32 cast, permutes and the concatenation) over the
+    reference's OWN `altcorr_forward_kernel` (src/lib/altcorr_kernel.cu:27-149, compiled for the CPU by oracle/build_ref.py) on
+    the 9-edge chunk of synth.make_altcorr_chunk -- what `update_lowmem` evaluates per 13-keyframe chunk, and what `gs_altcorr_pyramid` computes in one
+    launch.  Kept: the fp32 result at every third row / column (988 KB) and float64 sums per (edge, level) of the whole map."""
+    from oracle import build_ref
+    build_ref.build()
+    R = build_ref.load()
+    assert R is not None
+    corr = importlib.import_module("refsrc.modules.corr")
+    stub = sys.modules["droid_backends"]
+    keep = stub.altcorr_forward
+    stub.altcorr_forward = lambda f1, f2, c, r: R.altcorr_forward(f1.contiguous(), f2.contiguous(), c.contiguous(), r)
+    try:
+        fm, ii, jj, coords = synth.make_altcorr_chunk()
+        with torch.no_grad():
+            out = corr.AltCorrBlock(fm)(coords, ii, jj)              # [1, 9, 196, 30, 40] fp32
+    finally:
+        stub.altcorr_forward = keep
+    assert out.dtype == torch.float32 and tuple(out.shape) == (1, 9, 196, 30, 40)
+    ora = DO.altcorr_lookup(DO.altcorr_pyramid(fm), coords, ii, jj, 3)
+    print("reference AltCorrBlock vs oracle restatement: max abs", float((out - ora).abs().max()))
+    sums = out[0].double().reshape(9, 4, 49, -1).sum(dim=(2, 3))
+    save("reference_altcorr_pyramid.npz", ii=ii, jj=jj, fmaps_sum=fm.double().sum().reshape(1),
+         coords_sum=coords.double().sum().reshape(1), corr_s3=out[0, :, :, ::3, ::3].contiguous(), level_sums=sums)
+
+
 class FakeAltCorr:
     """stands in for AltCorrBlock under update_lowmem (both sides): a deterministic function of its arguments"""
     log = None
@@ -1360,3 +1390,4 @@ if __name__ == "__main__":
     gen_neus_backward()
     gen_reference_kernels()
     gen_reference_kernels_bench()
+    gen_reference_altcorr_pyramid()

@@ -722,6 +722,98 @@ def test_sharded_fused_step_two_ranks_on_one_gpu_equals_single_process(N, O, dev
         assert float(off.float().mean()) < 1e-2 and float(dlt.max()) <= 4 * lr * 1.01, (k, float(off.float().mean()), float(dlt.max()))
 
 
+def _one_gpu_rank_gradients(rank, world, port, out):
+    """one rank of the pre-optimiser comparison: its shard's table gradient, then exactly the step's two gradient
+    collectives (FlatAdamW.step: reduce-scatter of the fp16 table gradient, all-reduce of the fp32 dense gradients)"""
+    import os
+    import torch.distributed as dist
+    from go_slam_amd.neus.mapper import MapTrainer
+    from go_slam_amd.neus.distributed import all_reduce_sum_, reduce_scatter_sum_
+    import go_slam_amd.neus as neus
+    from oracle import neus_oracle as NO
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    P = NO.make_params(171, grid_init=0.05, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    model = neus.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    tr = MapTrainer(model, neus.Renderer(N_samples=24, N_surface=48), rank=rank, world=world)
+    n = 4096 * world
+    o, d, gt = _rays(n, seed=172)
+    g = torch.Generator().manual_seed(173)
+    args = [t.to(dev) for t in (o, d, torch.rand(n, 3, generator=g), gt, torch.rand(24, generator=g))]
+    _, g16, inv_scale = tr.fused_gradients(*args)
+    flat = tr.flat
+    local = flat.G16.clone()
+    reduce_scatter_sum_(flat.g16s, flat.G16, None)
+    all_reduce_sum_(flat.g32, None)
+    torch.cuda.synchronize()
+    torch.save({"local": local.cpu(), "slice": flat.g16s.cpu(), "lo": flat.lo, "hi": flat.hi, "inv_scale": inv_scale,
+                "g32": flat.g32.cpu(), "n16": flat.n16, "nd": flat.nd}, out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_table_gradient_before_the_optimiser_equals_single_process(N, O, dev, tmp_path):
+    """The quantity the exchange carries, compared BEFORE AdamW's sign normalisation can hide its size: 2 ranks (both on
+    cuda:0, gloo carrying the collectives) x 4096 rays each run their shard's HIP backward, reduce-scatter the loss-scaled
+    fp16 table gradient and all-reduce the fp32 dense gradients exactly as FlatAdamW.step does; the single process runs the
+    8192-ray batch.  Each rank's table gradient is the fp16 rounding of an exact fixed-point bin sum, the collective adds two
+    of those in fp16: three roundings of 2^-11 against the single process's one.  Bounds (stated, measured into
+    gpurun_out/r06_parity.json): the collective's own sum vs the exact fp64 sum of the two rank gradients rel-L2 <= 3e-4 (one
+    fp16 rounding); reduced vs single-process table gradient rel-L2 <= 6e-4 and every entry within 2^-10 (|g_0| + |g_1| + |g|)
+    + one fp16 subnormal step; dense gradients + loss rel 2e-4."""
+    import json
+    import torch.multiprocessing as mp
+    from go_slam_amd.neus.mapper import MapTrainer
+    out = str(tmp_path / "grad%d.pt")
+    mp.start_processes(_one_gpu_rank_gradients, args=(2, 29500 + (os.getpid() % 400), out), nprocs=2, join=True,
+                       start_method="spawn")
+    r = [torch.load(out % k) for k in range(2)]
+    n16, nd = r[0]["n16"], r[0]["nd"]
+    assert r[0]["lo"] == 0 and r[0]["hi"] == r[1]["lo"] and r[1]["hi"] >= n16 and r[0]["inv_scale"] == r[1]["inv_scale"]
+    reduced = torch.cat([r[0]["slice"], r[1]["slice"]])[:n16].double() * r[0]["inv_scale"]
+    loc = [x["local"][:n16].double() * r[0]["inv_scale"] for x in r]
+    exact = loc[0] + loc[1]
+    assert bool(torch.isfinite(reduced).all()) and float((loc[0] != 0).double().mean()) > 0.01
+    assert float(((loc[0] != 0) & (loc[1] != 0)).double().mean()) > 0.005, "the shards must meet in table entries"
+    P = O.make_params(171, grid_init=0.05, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    tr = MapTrainer(model, N.Renderer(N_samples=24, N_surface=48))
+    o, d, gt = _rays(8192, seed=172)
+    g = torch.Generator().manual_seed(173)
+    args = [t.to(dev) for t in (o, d, torch.rand(8192, 3, generator=g), gt, torch.rand(24, generator=g))]
+    loss, g16, inv_scale = tr.fused_gradients(*args)
+    assert inv_scale == r[0]["inv_scale"]
+    single = g16.double().cpu() * inv_scale
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    sub = 2.0 ** -24 * inv_scale                                    # one fp16 subnormal step of the scaled gradient
+    bound = 2.0 ** -10 * (loc[0].abs() + loc[1].abs() + single.abs()) + sub
+    worst = float(((reduced - single).abs() / bound).max())
+    rec = {"rays_per_rank": 4096, "table_entries_touched": int((single != 0).sum()),
+           "collective_vs_exact_sum_rel_l2": rel(reduced, exact), "reduced_vs_single_rel_l2": rel(reduced, single),
+           "exact_sum_vs_single_rel_l2": rel(exact, single), "max_abs_diff": float((reduced - single).abs().max()),
+           "max_abs_grad": float(single.abs().max()), "worst_entry_over_bound": worst,
+           "dense_rel_l2": rel(r[0]["g32"][:nd].double(), tr.flat.g32[:nd].double().cpu())}
+    d_ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d_, exist_ok=True)
+        path = os.path.join(d_, "r06_parity.json")
+        cur = json.load(open(path)) if os.path.exists(path) else {}
+        cur["sharded_table_gradient_2_ranks_vs_single_process"] = rec
+        json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    assert rec["collective_vs_exact_sum_rel_l2"] <= 3e-4, rec
+    assert rec["reduced_vs_single_rel_l2"] <= 6e-4, rec
+    assert worst <= 1.0, rec
+    assert torch.equal(reduced != 0, single != 0) or float(((reduced != 0) != (single != 0)).double().mean()) < 1e-4
+    torch.testing.assert_close(r[0]["g32"][:nd], tr.flat.g32[:nd].cpu(), rtol=2e-4, atol=1e-6)
+    torch.testing.assert_close(r[0]["g32"][nd], loss.cpu(), rtol=2e-4, atol=1e-6)
+    assert torch.equal(r[0]["g32"], r[1]["g32"])
+
+
 def _rccl_world1(_index, port, out):
     """the sharded mapper step and bench.py's collective self-test in an RCCL process group of ONE rank"""
     import os
@@ -967,3 +1059,67 @@ def test_binned_table_gradient_keeps_non_finite_records_visible(N, O, dev):
     assert torch.equal(bad_b, bad_a), (int(bad_b.sum()), int(bad_a.sum()))
     ok = ~bad_a
     assert _rel(res[True][ok], res[False][ok]) < 5e-3
+
+
+@pytest.mark.parametrize("with_depth", [True, False])
+def test_render_rays_equals_render_batch_ray_and_the_oracle_at_4096_rays(N, O, dev, with_depth):
+    """`InstantNeuS.render_rays(rays_o, rays_d, gt_depth)` -- the entry point BASELINE.json's north_star names -- against
+    (i) `Renderer.render_batch_ray(rays_o, rays_d, net, None, device, gt_depth)` (src/render.py:73-175) under the same device
+    generator state: bit for bit, every one of the 9 outputs; (ii) the oracle's restatement of render.py:99-171 +
+    InstantNeuS.py:295-370 with the `torch.rand(N_samples)` vector the call drew: sample positions bit-exact, the rest at
+    the tolerances of test_neus_forward_matches_oracle.  4096 rays x 72 (24 + 48) samples with depth, x 24 without."""
+    P = O.make_params(17, grid_init=0.3, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
+    P["rt_bound"] = torch.tensor([[-2.2, 2.3], [-2.4, 2.1], [-2.0, 2.2]])
+    o, d, gt = _rays(4096, seed=18)
+    gt = gt if with_depth else None
+    model = N.InstantNeuS({}, P["bound"].tolist()).to(dev)
+    _load(model, P)
+    model.update_bound(P["rt_bound"])
+    od, dd, gd = o.to(dev), d.to(dev), (gt.to(dev) if with_depth else None)
+    with torch.no_grad():
+        torch.manual_seed(1234)
+        a = model.render_rays(od, dd, gd)
+        torch.manual_seed(1234)
+        b = N.Renderer(N_samples=24, N_surface=48).render_batch_ray(od, dd, model, None, dev, gd)
+        torch.manual_seed(1234)
+        pr = torch.rand(24, device=dev).cpu()                      # the reference's draw (render.py:159)
+        c = model.render_rays(od, dd, gd)                           # a second call continues the generator stream
+    assert set(a) == set(b) == {"color", "depth", "depth_variance", "normal", "weight_sum", "sdf_variance", "sdf", "z_vals",
+                                "gradient_error"}
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert not torch.equal(a["z_vals"], c["z_vals"]), "every batch draws a new perturbation vector"
+    z, dist = O.render_sample(o, d, gt, P["bound"], 24, 48, pr)
+    ref = O.neus_forward(o, d, z, dist, P)
+    got = {k: v.cpu() for k, v in a.items()}
+    assert tuple(got["sdf"].shape) == (4096, 72 if with_depth else 24)
+    assert torch.equal(got["z_vals"], ref["z_vals"])
+    assert torch.equal(got["sdf"] == 100.0, ref["sdf"] == 100.0)
+    torch.testing.assert_close(got["sdf"], ref["sdf"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(got["weight_sum"], ref["weight_sum"], rtol=0, atol=5e-4)
+    torch.testing.assert_close(got["depth"], ref["depth"], rtol=0, atol=2e-3)
+    torch.testing.assert_close(got["depth_variance"], ref["depth_variance"], rtol=1e-2, atol=2e-3)
+    torch.testing.assert_close(got["color"], ref["color"], rtol=0, atol=4e-3)
+    torch.testing.assert_close(got["normal"], ref["normal"], rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(got["gradient_error"], ref["gradient_error"], rtol=2e-3, atol=1e-5)
+    torch.testing.assert_close(got["sdf_variance"], ref["sdf_variance"])
+
+
+def test_renderer_consumes_the_device_generator_like_the_reference(N, dev):
+    """render.py:159 draws `torch.rand(N_samples, device=device)` once per batch; the default Renderer issues that very call,
+    so under a seed the k-th batch gets the k-th such draw and the generator is left where the reference leaves it (the
+    mapper's `randint` pixel draws in between see the same stream).  `rand_pool_rows > 1` trades that for one launch per
+    `rows` batches and is NOT stream-compatible (checked: it must differ, or the flag documents nothing)."""
+    R = N.Renderer(N_samples=24, N_surface=48)
+    torch.manual_seed(77)
+    rows = [R._perturb_row(24, dev).clone() for _ in range(3)]
+    after = torch.randint(0, 1 << 30, (4,), device=dev)
+    torch.manual_seed(77)
+    ref = [torch.rand(24, device=dev) for _ in range(3)]
+    ref_after = torch.randint(0, 1 << 30, (4,), device=dev)
+    assert all(torch.equal(a, b) for a, b in zip(rows, ref)) and torch.equal(after, ref_after)
+    Rp = N.Renderer(N_samples=24, N_surface=48, rand_pool_rows=128)
+    torch.manual_seed(77)
+    pooled = [Rp._perturb_row(24, dev).clone() for _ in range(3)]
+    assert not all(torch.equal(a, b) for a, b in zip(pooled, ref))
+    assert float(torch.stack(pooled).min()) >= 0.0 and float(torch.stack(pooled).max()) < 1.0

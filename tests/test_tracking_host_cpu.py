@@ -342,8 +342,11 @@ def test_update_operator_context_term_cache_keys_and_eviction():
     """UpdateModule._edge_state keeps the hoisted context term per `inp` MEMORY (address, shape, strides, dtype) and
     validates it with the tensor's version counter: a fresh view of the same features hits (MotionFilter.track passes
     `self.inp[None]`, a new object per frame), an in-place write misses, different tensors get their own entries
-    (update_lowmem's chunks), an entry keeps its tensor alive so a freed address cannot be served stale, and the LRU
-    honours its entry / byte caps.  The convolution itself is replaced by a counter here (no GPU)."""
+    (update_lowmem's chunks), an entry lives exactly as long as the tensor that owns the features' memory (weak reference:
+    the frontend replaces `graph.inp` on every edge-set change and must not pin the old ones; a new tensor that receives
+    a freed address computes its own term), the LRU honours its entry / byte caps, and the debug checksum mode catches a
+    write the version counter does not see.  The convolution itself is replaced by a counter here (no GPU)."""
+    import gc
     from go_slam_amd.droid_net import UpdateModule
     op = UpdateModule()
     calls = []
@@ -369,11 +372,38 @@ def test_update_operator_context_term_cache_keys_and_eviction():
     for o in others:                                            # walking the chunks again: all hits
         op._edge_state(o, n, h, w)
     assert len(calls) == 7
-    # an entry owns a reference to its tensor: dropping ours cannot hand the address to new features
-    ptr = others[0].data_ptr()
-    del others[0]
+    # an entry dies with the tensor that owns its memory: nothing is pinned, and the freed address serves nothing stale
+    ptr, term = others[0].data_ptr(), op._inp_pre_cache[next(k for k in op._inp_pre_cache if k[0] == others[0].data_ptr())][3]
+    del others[0], o
+    gc.collect()
+    assert len(op._inp_pre_cache) == 5 and all(k[0] != ptr for k in op._inp_pre_cache)
     fresh = [torch.randn(n, 128, h, w).half().contiguous(memory_format=torch.channels_last)[None] for _ in range(8)]
-    assert all(f.data_ptr() != ptr for f in fresh)
+    for f in fresh:
+        if f.data_ptr() == ptr:                                 # the allocator handed the address out again
+            k = len(calls)
+            _, tf = op._edge_state(f, n, h, w)
+            assert len(calls) == k + 1 and tf is not term
+    # debug checksum mode: a write through an alias with its own version counter (`.data`: what a raw-pointer write from a
+    # HIP launch or another process looks like to torch) is served stale silently by default -- and raises in debug mode
+    chk = UpdateModule()
+    chk.gru.inp_gates, chk.gru._half_weights, chk.gru._hw_key = fake_gates, (lambda: None), 0
+    victim = torch.randn(n, 128, h, w).half().contiguous(memory_format=torch.channels_last)[None]
+    _, v1 = chk._edge_state(victim, n, h, w)
+    v = victim._version
+    victim.data.add_(1.0)
+    assert victim._version == v
+    _, v2 = chk._edge_state(victim, n, h, w)
+    assert v2 is v1                                             # (the default trusts the version counter)
+    chk.invalidate_context()                                    # the explicit hook for such writers
+    _, v3 = chk._edge_state(victim, n, h, w)
+    assert v3 is not v1 and float(v3) != float(v1)
+    chk.cache_check = True
+    chk.invalidate_context()
+    chk._edge_state(victim, n, h, w)
+    chk._edge_state(victim, n, h, w)                            # unchanged: fine
+    victim.data.add_(1.0)
+    with pytest.raises(RuntimeError, match="behind the version counter"):
+        chk._edge_state(victim, n, h, w)
     # caps: at most INP_CACHE_ENTRIES entries, least recently used first; a weight change drops every old term
     op.INP_CACHE_ENTRIES = 3
     for f in fresh:
@@ -465,3 +495,31 @@ def test_get_mapping_items_equals_the_per_keyframe_hand_outs():
             assert torch.equal(a, b)
     assert torch.equal(vids[0].update_priority, vids[1].update_priority)
     assert vids[1].get_mapping_items([], "cpu") == {}
+
+
+def test_depth_video_write_hooks_fire_on_feature_writes_and_stay_out_of_pickles():
+    """DepthVideo.add_write_hook: the explicit invalidation point for caches built from `fmaps / nets / inps` by readers
+    that cannot see torch's version counters move (another process on the shared buffers, a raw-pointer writer)."""
+    import pickle
+    from go_slam_amd.depth_video import DepthVideo
+    v = DepthVideo(4, 6, buffer=5, device="cpu")
+    seen = []
+
+    class Reader:
+        def forget(self, index):
+            seen.append(("m", index))
+    r = Reader()
+    v.add_write_hook(r.forget)
+    v.add_write_hook(lambda ix: seen.append(("f", ix)))
+    img = torch.zeros(3, 32, 48)
+    f = torch.zeros(1, 128, 4, 6).half()
+    v[0] = (0.0, img, None, None, None, None)                              # no feature write: no hook
+    assert seen == []
+    v[1] = (1.0, img, None, None, None, None, f, f[0], f[0])
+    assert seen == [("m", 1), ("f", 1)]
+    del r                                                                  # bound methods are held weakly
+    v[2] = (2.0, img, None, None, None, None, f, f[0], f[0])
+    assert seen[2:] == [("f", 2)]
+    w = pickle.loads(pickle.dumps({k: x for k, x in v.__getstate__().items() if not k.startswith("_counter") and k not in
+                                   ("ready", "mapping", "ba_lock", "global_ba_lock")}))
+    assert "_write_hooks" not in w
