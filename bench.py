@@ -289,6 +289,220 @@ def motion_filter_frame_ms(device, return_fn=False):
     return time_op(frame, iters=10, warm=3)
 
 
+def sequence_cfg(enable_loop=False, buffer=128, H=480, W=640):
+    """configs/go_slam.yaml's tracking block (the values every Replica / ScanNet config inherits) at 480 x 640"""
+    return {"mode": "rgbd", "verbose": False, "cam": {"H_out": H, "W_out": W},
+            "tracking": {"buffer": buffer, "beta": 0.75, "warmup": 8, "upsample": True, "motion_filter": {"thresh": 4.0},
+                         "frontend": {"enable_loop": enable_loop, "keyframe_thresh": 4.0, "thresh": 16.0, "window": 25,
+                                      "radius": 1, "nms": 1, "max_factors": 75},
+                         "backend": {"thresh": 25.0, "radius": 1, "nms": 5, "loop_window": 25, "loop_thresh": 25.0,
+                                     "loop_radius": 1, "loop_nms": 12},
+                         "multiview_filter": {"thresh": 0.01, "visible_num": 2, "kernel_size": 1, "bound_enlarge_scale": 1.1}}}
+
+
+def synthetic_trajectory(n, step_m=0.02, step_deg=0.6, seed=43):
+    """Keyframe poses on a smooth arc, stored world -> camera as [t, q] (SURVEY 8(d)'s trajectory -- a forward drift with a
+    slow yaw and a gentle sideways weave -- at a step that puts ~8 neighbours of a keyframe under the frontend's 16 px
+    proximity threshold at 2.5 m depth, so the 75-edge cap of the local window is reached as on a real sequence)."""
+    import math
+    k = torch.arange(n, dtype=torch.float32)
+    yaw = math.radians(step_deg) * k
+    pos = torch.stack([step_m * k * 0.5 + 0.05 * torch.sin(0.2 * k), 0.02 * torch.sin(0.13 * k), step_m * k], 1)   # camera centres
+    q = torch.stack([torch.zeros(n), torch.sin(yaw / 2), torch.zeros(n), torch.cos(yaw / 2)], 1)                   # camera -> world, about y
+    # world -> camera: q_wc = conj(q), t_wc = -R(q_wc) pos
+    qc = q * torch.tensor([-1.0, -1.0, -1.0, 1.0])
+    v, w = qc[:, :3], qc[:, 3:]
+    t = pos + 2.0 * torch.cross(v, torch.cross(v, pos, dim=1) + w * pos, dim=1)
+    return torch.cat([-t, qc], 1)
+
+
+def sequence_bench(device, keyframes=40, warm_keyframes=34, frames_per_keyframe=4, enable_loop=False, shared_video=False,
+                   drop_every=8, return_state=False, spare_keyframes=4, freeze_gc=False):
+    """The tracker END TO END on a synthetic 640 x 480 RGB-D sequence, steady state: per input frame `MotionFilter.track`
+    (src/motion_filter.py:39-90: feature encoder, correlation against the last keyframe, one update iteration, the
+    keyframe decision), per keyframe `Frontend.__call__` (src/frontend.py:48-104: retire old edges, `add_proximity_factors`
+    = frame_distance + NMS proposal, correlation volumes for the new edges, 4 updates, the keyframe-distance read,
+    `rm_keyframe` or 2 more updates -- or, with `enable_loop` and more than `window` keyframes, `loop_ba`), with
+    configs/go_slam.yaml's tracking parameters (window 25, max_factors 75, warm-up 8, upsample on).
+
+    A random-weight network cannot track, so two decisions are SCRIPTED while all their work still runs: every
+    `frames_per_keyframe`-th frame is promoted (`MotionFilter.thresh` is set to -1 / 1e9 around the call; the flow estimate
+    and its host read happen every frame), and `Frontend._moved_enough` computes and reads the real keyframe distance but
+    answers by script: every `drop_every`-th keyframe is dropped through `rm_keyframe`, the others are kept.  The pose of
+    each new keyframe is seeded from the synthetic arc (instead of the previous keyframe's pose), so frame distances, the
+    proximity proposals and the window's edge count are those of a moving camera.  Timed per keyframe with a device
+    synchronisation between the frame stage and the keyframe stage (2 per keyframe)."""
+    import types
+    from go_slam_amd.depth_video import DepthVideo
+    from go_slam_amd.droid_net import DroidNet
+    from go_slam_amd.frontend import Frontend
+    from go_slam_amd.motion_filter import MotionFilter
+    torch.manual_seed(43)
+    total = keyframes + warm_keyframes + spare_keyframes
+    cfg, args = sequence_cfg(enable_loop, buffer=total + 8), types.SimpleNamespace(device=str(device))
+    net = DroidNet().to(device).eval()
+    with torch.no_grad():                               # small output heads: the synthetic state stays in a sane flow range
+        net.update.delta[2].weight.mul_(0.05)
+        net.update.delta[2].bias.zero_()
+    video = DepthVideo.from_config(cfg, args) if shared_video else \
+        DepthVideo(60, 80, buffer=total + 8, device=device, full_res=True)
+    mf = MotionFilter(net, video, thresh=1e9, device=str(device))
+
+    class ScriptedFrontend(Frontend):
+        decisions = []
+
+        def _moved_enough(self):
+            super()._moved_enough()                     # the distance launch pair + the host read of the real frontend
+            keep = (self.count % drop_every) != 0
+            self.decisions.append(keep)
+            return keep
+    fe = ScriptedFrontend(net, video, args, cfg)
+    gt = synthetic_trajectory(total + 8).to(device)
+    g = torch.Generator().manual_seed(44)
+    frames = [torch.rand(1, 3, 480, 640, generator=g).to(device) for _ in range(4)]
+    vv, uu = torch.meshgrid(torch.arange(480.0), torch.arange(640.0), indexing="ij")
+    depth = (2.5 + 1.0 * torch.sin(uu * 0.013) * torch.cos(vv * 0.017)).to(device)
+    intr = torch.tensor([577.59, 578.73, 318.91, 242.68], device=device)
+    stamp = [0]
+
+    def frame_stage():
+        for k in range(frames_per_keyframe):
+            mf.thresh = -1.0 if k == frames_per_keyframe - 1 else 1e9
+            n0 = video.counter.value
+            mf.track(float(stamp[0]), frames[stamp[0] % 4].clone(), depth, intr)
+            stamp[0] += 1
+            if video.counter.value > n0:                # promoted: seed the new keyframe's pose from the arc
+                video.poses[n0] = gt[min(stamp[0] // frames_per_keyframe, gt.shape[0] - 1)]
+    t_frames = t_front = 0.0
+    edges, kept = [], 0
+    import gc
+    for k in range(warm_keyframes + keyframes):
+        if k == warm_keyframes and freeze_gc:           # (bench.py's main has done this once already: see there)
+            gc.collect()
+            gc.freeze()
+        timed = k >= warm_keyframes
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frame_stage()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fe()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if timed:
+            t_frames += t1 - t0
+            t_front += t2 - t1
+            edges.append(int(fe.graph.ii.numel()))
+            kept += int(bool(fe.decisions and fe.decisions[-1]))
+    n = video.counter.value
+    finite = bool(torch.isfinite(video.poses[:n]).all()) and bool(torch.isfinite(video.disps[:n]).all())
+    out = {"workload": f"{(warm_keyframes + keyframes) * frames_per_keyframe} frames of 480x640 RGB-D, a keyframe every "
+                       f"{frames_per_keyframe} frames, {keyframes} timed keyframes after {warm_keyframes}; window 25, "
+                       f"max_factors 75, enable_loop {enable_loop}, every {drop_every}th keyframe dropped (rm_keyframe)",
+           "video": "shared (reference constructor: locked sections end with a stream sync)" if shared_video
+                    else "single process (asynchronous)",
+           "frontend_e2e_ms_per_keyframe": 1e3 * t_front / keyframes,
+           "motion_filter_ms_per_frame": 1e3 * t_frames / (keyframes * frames_per_keyframe),
+           "ms_per_keyframe_all": 1e3 * (t_front + t_frames) / keyframes,
+           "frames_per_s": keyframes * frames_per_keyframe / (t_front + t_frames),
+           "keyframes_per_s": keyframes / (t_front + t_frames),
+           "edges_mean": sum(edges) / len(edges), "edges_max": max(edges), "inactive_edges": int(fe.graph.ii_inac.numel()),
+           "keyframes_kept": kept, "keyframes_dropped": keyframes - kept, "keyframes_in_video": n, "state_finite": finite,
+           "control_flow": "scripted keyframe decisions; every kernel and host read of the real loop runs"}
+    if return_state:
+        return out, (net, video, fe, mf, frame_stage)
+    return out
+
+
+def backend_bench(device, num_kf=200, steps=8):
+    """`Backend.dense_ba(0, t, steps=8)` (src/backend.py:20-44,122-136) on a 200-keyframe ScanNet-shaped video (configs[3]):
+    frame-distance matrix of all pairs, the edge proposal with NMS on the device, a fresh alt-correlation FactorGraph,
+    `update_lowmem(steps)`.  Wall time of the whole call (a second call: the update operator's weights are packed)."""
+    import types
+    from go_slam_amd import synth
+    from go_slam_amd.backend import Backend
+    from go_slam_amd.depth_video import DepthVideo
+    from go_slam_amd.droid_net import DroidNet
+    ht, wd, _ = synth.SHAPES["Scan"]
+    torch.manual_seed(47)
+    vid = synth.make_video(num_kf, "Scan", seed=47, rgbd=True, buffer=num_kf + 7)
+    video = DepthVideo(ht, wd, buffer=num_kf + 7, device=device)
+    for k in ("poses", "disps", "disps_sens", "intrinsics"):
+        getattr(video, k).copy_(vid[k])
+    video.counter = num_kf
+    g = torch.Generator().manual_seed(52)
+    video.fmaps[:num_kf, 0] = torch.randn(num_kf, 128, ht, wd, generator=g).half().to(device)
+    video.nets[:num_kf] = torch.randn(num_kf, 128, ht, wd, generator=g).tanh().half().to(device)
+    video.inps[:num_kf] = torch.randn(num_kf, 128, ht, wd, generator=g).relu().half().to(device)
+    net = DroidNet().to(device).eval()
+    with torch.no_grad():
+        net.update.delta[2].weight.mul_(0.05)
+        net.update.delta[2].bias.zero_()
+    cfg, args = sequence_cfg(False, buffer=num_kf + 7, H=8 * ht, W=8 * wd), types.SimpleNamespace(device=str(device))
+    cfg["tracking"]["upsample"] = False
+    be = Backend(net, video, args, cfg)
+    p0, d0 = video.poses.clone(), video.disps.clone()
+    res = {}
+
+    def call():
+        video.poses.copy_(p0)
+        video.disps.copy_(d0)
+        res["n"] = be.dense_ba(0, num_kf, steps=steps)
+    ms = time_op(call, iters=2, warm=1)
+    return {"keyframes": res["n"][0], "edges": int(res["n"][1]), "steps": steps, "global_ba_ms": ms,
+            "ms_per_step": ms / steps, "maps": "Scan 30x40",
+            "state_finite": bool(torch.isfinite(video.poses).all()) and bool(torch.isfinite(video.disps).all())}
+
+
+def mapper_call_bench(device, use_bank=True, n_kf=20, iters=20, H=480, W=640):
+    """A steady `Mapper.__call__` (src/mapping.py:151-302) on 20 filtered keyframes of 480 x 640, mapping.pixels 4400,
+    window 16, `iters` joint iterations per call (configs/go_slam.yaml's mapping block): ms per joint iteration, hand-out
+    and ray draws included."""
+    import types
+    import numpy as np
+    import go_slam_amd.neus as N
+    from go_slam_amd.depth_video import DepthVideo
+    from go_slam_amd.neus import mapping as M
+    dev = str(device)
+    cfg = {"mode": "rgbd", "cam": {"H_out": H, "W_out": W}, "tracking": {"buffer": 32},
+           "mapping": {"device": dev, "iters": iters, "decay": 0.5, "w_color_loss": 2.0, "w_sdf_loss": 2.0,
+                       "w_eikonal_loss": 0.1, "uncertainty_weight_loss": True, "BA": False, "BA_cam_lr": 1e-3, "pixels": 4400,
+                       "mapping_window_size": 16, "net_lr": 1e-3, "grid_lr": 1e-2}}
+    args = types.SimpleNamespace(device=dev)
+    torch.manual_seed(3)
+    np.random.seed(3)
+    video = DepthVideo.from_config(cfg, args)
+    g = torch.Generator().manual_seed(7)
+    v, u = torch.meshgrid(torch.arange(float(H)), torch.arange(float(W)), indexing="ij")
+    depth = (2.0 + 0.2 * torch.sin(u * 0.02) * torch.cos(v * 0.03)).to(dev)
+    video.images[:n_kf] = torch.rand(n_kf, 3, H, W, generator=g).to(dev)
+    video.disps_filtered[:n_kf] = 1.0 / depth
+    video.mask_filtered[:n_kf] = (torch.rand(n_kf, H, W, generator=g) < 0.9).float().to(dev)
+    video.poses_filtered[:n_kf, 0] = 0.02 * torch.arange(n_kf, device=dev)
+    video.update_priority[:n_kf] = 1.0
+    video.timestamp[:n_kf] = torch.arange(n_kf, device=dev).float()
+    video.bound[0] = torch.tensor([[-2.4, 2.4], [-2.4, 2.4], [-0.4, 2.4]], device=dev)
+    video.filtered_id[0] = n_kf
+    model = N.InstantNeuS({}, [[-2.5, 2.5]] * 3, device=dev).to(dev)
+    slam = types.SimpleNamespace(verbose=False, bound=model.bound, video=video, mapping_net=model,
+                                 renderer=N.Renderer(N_samples=24, N_surface=48), reload_map=torch.zeros(1).int(), H=H, W=W,
+                                 fx=577.6, fy=578.7, cx=318.9, cy=242.7)
+    mapper = M.Mapper(cfg, args, slam)
+    mapper.use_ray_bank = use_bank
+    for _ in range(4):                                       # the first call (10 x iterations on the new keyframes) and three
+        mapper()                                             # steady ones: every ray-batch shape of the window has its graph
+    torch.cuda.synchronize()
+    g0 = mapper.global_step
+    t = time.perf_counter()
+    for _ in range(3):                                       # steady calls: `iters` joint iterations on the window each
+        mapper()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    its = max(1, mapper.global_step - g0)
+    return {"mapper_ms_per_joint_iteration": 1e3 * dt / its, "iterations_timed": its, "rays_per_iteration": 4400,
+            "keyframes": n_kf, "ray_draw": "RayBank" if use_bank else "build_rays per frame"}
+
+
 def neus_render_bench(device, n_rays=4096, iters=20):
     """Second half of the BASELINE metric: NeuS render rays/s = N / wall time of
     Renderer.render_batch_ray (+ InstantNeuS.forward) for N rays x 72 samples, forward only."""
@@ -666,6 +880,12 @@ def summary(line):
             "altcorr_[ms_per_step,frac_vector_roof]": [g(line, "global_ba_stress", "altcorr_roofline", "kernel_ms_per_step"),
                                                         g(line, "global_ba_stress", "altcorr_roofline", "frac_of_fp32_vector_roof_157TF")],
             "motion_filter_frame_ms": g(line, "breakdown_ms", "motion_filter_frame_ms"),
+            "e2e_[frontend_ms_per_kf,frames_per_s,edges]": [g(line, "sequence", "frontend_e2e_ms_per_keyframe"),
+                                                            g(line, "sequence", "frames_per_s"), g(line, "sequence", "edges_mean")],
+            "e2e_loop_closure_frontend_ms_per_kf": g(line, "sequence_loop_closure", "frontend_e2e_ms_per_keyframe"),
+            "e2e_shared_video_frontend_ms_per_kf": g(line, "sequence_shared_video", "frontend_e2e_ms_per_keyframe"),
+            "global_ba_ms_[200kf,8steps]": g(line, "global_ba", "global_ba_ms"),
+            "mapper_ms_per_joint_iteration": g(line, "mapper_call", "mapper_ms_per_joint_iteration"),
             "n_gpus": line.get("n_gpus"), "rccl_ranks": line.get("rccl_ranks")}
 
 
@@ -945,6 +1165,22 @@ def main():
                 line["mono_window"] = mono_window(device)
             except Exception as exc:
                 line["mono_window"] = {"error": repr(exc)}
+            # ---- end to end, steady state (north_star: "throughput on synthetic 640x480 RGB-D sequences"): outside the
+            # headline's timed region, own keys
+            for key, kw in (("sequence", {}), ("sequence_loop_closure", {"enable_loop": True, "keyframes": 24}),
+                            ("sequence_shared_video", {"shared_video": True, "keyframes": 24})):
+                try:
+                    line[key] = sequence_bench(device, **kw)
+                except Exception as exc:
+                    line[key] = {"error": repr(exc)}
+            try:
+                line["global_ba"] = backend_bench(device)
+            except Exception as exc:
+                line["global_ba"] = {"error": repr(exc)}
+            try:
+                line["mapper_call"] = mapper_call_bench(device)
+            except Exception as exc:
+                line["mapper_call"] = {"error": repr(exc)}
             try:        # the sharded (world > 1) schedule of the mapper step under RCCL, one rank: its fixed cost on hardware
                 line["neus_train_sharded_schedule_rccl_1rank"] = sharded_schedule_one_rank(device)
             except Exception as exc:

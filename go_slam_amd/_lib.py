@@ -34,6 +34,9 @@ SIGNATURES = {
     "gs_corr_index_backward": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
     "gs_corr_lookup_pyramid": (c_int, [_P] * 6 + [c_int] * 9 + [_P]),
     "gs_corr_lookup_enc": (c_int, [_P] * 8 + [c_int] * 7 + [_P]),
+    "gs_corr_lookup_enc_slots": (c_int, [_P] * 9 + [c_int] * 7 + [_P]),
+    "gs_corr_lookup_pyramid_slots": (c_int, [_P] * 7 + [c_int] * 9 + [_P]),
+    "gs_corr_volume_pyramid_slots": (c_int, [_P] * 7 + [c_int] * 5 + [_P, c_size_t, _P]),
     "gs_corr_volume_workspace_bytes": (c_size_t, [c_int] * 4),
     "gs_corr_volume_pyramid": (c_int, [_P] * 6 + [c_int] * 5 + [_P, c_size_t, _P]),
     "gs_corr_level_elems": (c_size_t, [c_int] * 4),

@@ -107,6 +107,147 @@ class CorrBlock:
         return self
 
 
+class CorrPool:
+    """The correlation volumes of a factor graph's edges, with CorrBlock's interface (`(coords)`, `.lazy`, `.cat`,
+    `[index]`, `.corr_pyramid`) but NO volume ever moved: level l lives in a capacity buffer [capacity, h, w, plane_l], edge e
+    owns slot `slot[e]` of it (int64 device tensor, the lookups' extra argument), freed slots go to a device-side free list.
+
+    The reference (and CorrBlock) keep the edges' volumes contiguous: `self.corr = self.corr.cat(corr)` on every
+    add_factors and `self.corr = self.corr[~mask]` on every rm_factors (src/factor_graph.py:118,150) re-copy every volume
+    held -- 61 MB per edge at 60 x 80, 4.6 GB at the 75-edge cap.  Measured on the end-to-end sequence leg (round 6,
+    profiles/r06_frontend_e2e_kernel_stats*.md): 2.2 ms of `cat` + ~1 ms of gathers per keyframe around 7 ms of update
+    operator.  Here `append` has gs_corr_volume_pyramid_slots write the new edges' planes straight into free slots and
+    removal edits the slot list only.  Values and lookups are those of CorrBlock (same kernels, one more index)."""
+
+    def __init__(self, ht, wd, device, capacity=96):
+        self.num_levels, self.radius = 4, 3
+        self.channels_last = True
+        self.map_size = (int(ht), int(wd))
+        self.device = torch.device(device)
+        self.layout = droid_backends.CORR_TILE8 if wd % 16 == 0 else droid_backends.CORR_ROWMAJOR
+        self.capacity = 0
+        self.store = None
+        self.slot = torch.zeros(0, dtype=torch.long, device=self.device)
+        self.free = torch.zeros(0, dtype=torch.long, device=self.device)
+        self._reserve(int(capacity))
+
+    @staticmethod
+    def supported(fmap1, channels_last=True):
+        """fp16 CUDA feature maps of a shape the fused build covers, looked up into channels-last features"""
+        return bool(channels_last and fmap1.is_cuda and fmap1.dtype == torch.float16
+                    and droid_backends.corr_volume_supported(fmap1.reshape(-1, *fmap1.shape[-3:])))
+
+    def _level_shape(self, l):
+        ht, wd = self.map_size
+        if self.layout == droid_backends.CORR_TILE8 and l < 2:
+            return (ht, wd, int(_lib.lib().gs_corr_level_elems(ht, wd, l, int(self.layout))))
+        return (ht, wd, ht >> l, wd >> l)
+
+    def _reserve(self, capacity):
+        """grow the buffers to `capacity` slots; live volumes keep their slot numbers (the only copy this class ever makes)"""
+        new = [torch.empty((capacity,) + self._level_shape(l), dtype=torch.float16, device=self.device) for l in range(4)]
+        if self.store is not None and self.slot.numel():
+            for l in range(4):
+                new[l].index_copy_(0, self.slot, self.store[l].index_select(0, self.slot))
+        self.free = torch.cat([self.free, torch.arange(self.capacity, capacity, dtype=torch.long, device=self.device)])
+        self.store, self.capacity = new, capacity
+
+    def __len__(self):
+        return int(self.slot.numel())
+
+    def _take(self, n):
+        if n > self.free.numel():
+            self._reserve(max(self.capacity * 3 // 2, len(self) + n + 16))
+        new, self.free = self.free[:n].contiguous(), self.free[n:]
+        return new
+
+    def append(self, fmap1, fmap2):
+        """volumes + pooled levels of the edges fmap1[0, e] -> fmap2[0, e] ([1, n, 128, h, w] fp16), built in place"""
+        f1 = fmap1.reshape(-1, *fmap1.shape[-3:]).contiguous()
+        f2 = fmap2.reshape(-1, *fmap2.shape[-3:]).contiguous()
+        n, dim, h, w = f1.shape
+        assert (h, w) == self.map_size and f1.shape == f2.shape and f1.dtype == torch.float16
+        if n == 0:
+            return self
+        new = self._take(n)
+        L = _lib.lib()
+        ws = droid_backends._workspace(self.device, L.gs_corr_volume_workspace_bytes(n, dim, h, w) + 256)
+        with torch.cuda.device(self.device):
+            rc = L.gs_corr_volume_pyramid_slots(_lib.ptr(f1), _lib.ptr(f2), *[_lib.ptr(v) for v in self.store], _lib.ptr(new),
+                                                n, dim, h, w, int(self.layout), _lib.ptr(ws), ws.numel(),
+                                                _lib.stream_ptr(self.device))
+        _lib.check(rc, "CorrPool.append")
+        self.slot = torch.cat([self.slot, new])
+        return self
+
+    def cat(self, other):
+        """the reference's call form: `other` = an already built block of the same layout; its planes are copied into free slots"""
+        pyr = other.corr_pyramid
+        assert getattr(other, "layout", droid_backends.CORR_ROWMAJOR) == self.layout and tuple(other.map_size) == self.map_size
+        new = self._take(int(pyr[0].shape[0]))
+        for l in range(4):
+            self.store[l].index_copy_(0, new, pyr[l].reshape((-1,) + self._level_shape(l)))
+        self.slot = torch.cat([self.slot, new])
+        return self
+
+    def __getitem__(self, index):
+        """keep the edges `index` selects (bool mask or indices), as CorrBlock[index]: slots change owner, no plane moves"""
+        index = torch.as_tensor(index, device=self.device)
+        if index.dtype == torch.bool:
+            freed, self.slot = self.slot[~index], self.slot[index]
+        else:
+            index = index.long().reshape(-1)
+            gone = torch.ones(len(self), dtype=torch.bool, device=self.device)
+            gone[index] = False
+            freed, self.slot = self.slot[gone], self.slot[index]
+        self.free = torch.cat([freed, self.free])
+        return self
+
+    @property
+    def corr_pyramid(self):
+        """the edges' planes as CorrBlock holds them: a COPY, [E, h, w, ...] per level (tests, the materialised fallbacks)"""
+        return [v.index_select(0, self.slot) for v in self.store]
+
+    def fused_encoder_supported(self):
+        return True
+
+    def _coords(self, coords):
+        batch, num, ht, wd, _ = coords.shape
+        assert batch * num == len(self), (batch * num, len(self))
+        return coords.reshape(batch * num, ht, wd, 2).float().contiguous(), batch, num, ht, wd
+
+    def __call__(self, coords):
+        c, batch, num, ht, wd = self._coords(coords)
+        h2, w2 = self.map_size
+        out = torch.empty((batch * num, 196, ht, wd), dtype=torch.float16, device=c.device, memory_format=torch.channels_last)
+        s = self.store
+        with torch.cuda.device(c.device):
+            rc = _lib.lib().gs_corr_lookup_pyramid_slots(_lib.ptr(s[0]), _lib.ptr(s[1]), _lib.ptr(s[2]), _lib.ptr(s[3]),
+                                                         _lib.ptr(self.slot), _lib.ptr(c), _lib.ptr(out), batch * num, ht, wd,
+                                                         h2, w2, 3, droid_backends._DT[torch.float16], 1, int(self.layout),
+                                                         _lib.stream_ptr(c.device))
+        _lib.check(rc, "CorrPool lookup")
+        return out.view(batch, num, -1, ht, wd)
+
+    def lazy(self, coords):
+        return LazyLookup(self, coords)
+
+    def lookup_encoded(self, coords, wpad, bias):
+        """relu(conv1x1(lookup(coords)) + bias): [batch*num, 128, ht, wd] fp16 NHWC (gs_corr_lookup_enc_slots)"""
+        c, batch, num, ht, wd = self._coords(coords)
+        n = batch * num
+        h2, w2 = self.map_size
+        y = torch.empty((n, 128, ht, wd), dtype=torch.float16, device=c.device, memory_format=torch.channels_last)
+        s = self.store
+        with torch.cuda.device(c.device):
+            rc = _lib.lib().gs_corr_lookup_enc_slots(_lib.ptr(s[0]), _lib.ptr(s[1]), _lib.ptr(s[2]), _lib.ptr(s[3]),
+                                                     _lib.ptr(self.slot), _lib.ptr(c), _lib.ptr(wpad), _lib.ptr(bias),
+                                                     _lib.ptr(y), 128, n, ht, wd, h2, w2, int(self.layout),
+                                                     _lib.stream_ptr(c.device))
+        _lib.check(rc, "corr_lookup_enc")
+        return y
+
+
 class LazyLookup:
     """CorrBlock(coords), not evaluated yet.  `encoded(wpad, bias)` = the lookup fused with corr_encoder[0]; everything
     else (`.view`, `.float()`, tensor attributes ...) goes to the materialised [batch, num, 196, ht, wd] tensor."""

@@ -23,7 +23,7 @@
 
 // chol.hip
 int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float* dx_out, int32_t* fail_flag,
-                         int32_t* fail_count, hipStream_t st);
+                         int32_t* fail_count, int32_t* sync, hipStream_t st);
 
 namespace {
 
@@ -568,7 +568,7 @@ extern "C" int gs_ba_ex(float* poses, float* disps, const float* intrinsics, con
       ba_schur_kernel<<<2048, 256, 0, st>>>(M, hw, P, ws);
       GS_CHECK_LAUNCH("ba_schur");
     }
-    int rc = gs_chol_solve_launch(ws.H, ws.b, n6, lm, ep, dx, &ws.hdr[2], &ws.hdr[3], st);
+    int rc = gs_chol_solve_launch(ws.H, ws.b, n6, lm, ep, dx, &ws.hdr[2], &ws.hdr[3], &ws.hdr[8], st);
     if (rc != GS_OK) return rc;
     if (motion_only)
       ba_update_kernel<<<dim3(1, 1), 256, 0, st>>>(poses, disps, dx, dz, 0, t0, t1, hw, ws);

@@ -19,9 +19,9 @@ constexpr int PR = 64;     // panel rows per workgroup (one wave)
 constexpr int TT = 64;     // trailing tile edge
 constexpr int SB = 64;     // substitution block
 
-__global__ void chol_damp_kernel(double* __restrict__ A, int n, double lm, double ep, int32_t* fail_flag) {
+__global__ void chol_damp_kernel(double* __restrict__ A, int n, double lm, double ep, int32_t* fail_flag, int32_t* sync) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) *fail_flag = 0;
+  if (i == 0) { *fail_flag = 0; if (sync) { sync[0] = 0; sync[1] = 0; } }
   if (i < n) {
     const double d = A[(size_t)i * n + i];
     A[(size_t)i * n + i] = d + (ep + lm * d);
@@ -229,6 +229,353 @@ __global__ __launch_bounds__(256) void chol_back_block_kernel(const double* __re
 }
 
 
+#ifdef CHOL_TIMING   // tools/chol_bench.hip only: per-phase wall-clock stamps (100 MHz)
+__device__ long long g_chol_t[64];
+#define CHOL_STAMP(i) do { if (threadIdx.x == 0) g_chol_t[i] = wall_clock64(); } while (0)
+#define CHOL_ACC_DECL long long t_acc[5] = {0, 0, 0, 0, 0}; long long t_last = wall_clock64()
+#define CHOL_ACC(i) do { const long long t_now = wall_clock64(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
+#define CHOL_ACC_DUMP do { if (threadIdx.x == 0) for (int q = 0; q < 5; ++q) g_chol_t[10 + q] = t_acc[q]; } while (0)
+#define COOP_T(i) do { const long long t_now = wall_clock64(); tc[i] += t_now - tl; tl = t_now; } while (0)
+#else
+#define COOP_T(i) do { } while (0)
+#define CHOL_STAMP(i) do { } while (0)
+#define CHOL_ACC_DECL do { } while (0)
+#define CHOL_ACC(i) do { } while (0)
+#define CHOL_ACC_DUMP do { } while (0)
+#endif
+
+// ---- a PERSISTENT one-launch path for the global / loop-closure BA (6P = 1194), measured and NOT shipped -------------------
+// Round 6 (VERDICT r5 item 4 asked for the 188 launches of a 1194-unknown solve pair in <= 30).  Built: ONE launch of G
+// resident workgroups walking all panels with ONE grid-wide barrier per panel (agent-scope counter, bounded spin that turns a
+// lost workgroup into a reported failure): A(p) = diagonal block factored redundantly per workgroup in registers + the
+// owners' 64-row blocks solved, with panel p - 1's rank-32 update applied lazily to the rows A(p) reads, so that B(p) (the
+// trailing update, 64 x 64 tiles on v_mfma_f64_16x16x4) can skip the next panel's columns and needs no barrier before
+// A(p + 1); the backward substitution in the same launch, one barrier per 64-wide block.  Correct (x equal to the
+// multi-kernel path's to the last float bit, residual 6.2e-7 at n = 1194, indefinite input => dx = 0) -- and SLOWER:
+//     n = 1194:  multi-kernel 1636 us (95 launches)   persistent 3263 / 2509 / 2175 / 2095 / 2340 us at G = 16 / 32 / 64 / 128 / 256
+// Phase stamps of workgroup 0 at G = 128 (profiles/r06_chol_bench.txt): A-phases 922 us (24 us per panel: three DEPENDENT
+// global round trips -- pending rows, diagonal block, own rows -- on lines the barrier's agent-scope acquire has just
+// invalidated in this XCD's L2, + 1024 pending-update FMAs per lane in front of the factorisation), barriers 403 us (10.6 us
+// each: buffer_wbl2 / buffer_inv sc1 around a 128-way atomic), B-phases 445 us, backward 340 us.  The launches of the
+// multi-kernel path are NOT its cost: its kernels are the same latency chains (panel 21.6 us, trailing 13.9 us in the
+// 200-keyframe step's trace) and a kernel boundary is a cheaper grid barrier than an agent-scope fence pair on this part.
+// What would beat both is a shorter chain per panel (MFMA pending update, 64-wide panels with a two-level diagonal factor,
+// operand prefetch across the barrier): costed at ~1.0 ms per solve, not built.  The code below is compiled into
+// tools/chol_bench.hip only (CHOL_TIMING), where `g_chol_force_blocked = 2` runs it next to the shipped paths.
+#ifdef CHOL_TIMING
+constexpr int COOP_NT = 256;
+constexpr unsigned COOP_SPIN_LIMIT = 1u << 21;
+
+__device__ __forceinline__ bool coop_barrier(int32_t* sync, int target, int* s_ok) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    unsigned it = 0;
+    while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++it & 255u) == 0 &&
+          (it > COOP_SPIN_LIMIT || __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        __hip_atomic_store(&sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *s_ok = ok;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
+typedef double CoopTile[NB + 1];
+
+// A(p), wave 0: the diagonal block with the pending rank-32 update applied, factored in registers (lane i holds row i);
+// leaves D / Dinv in LDS and ends with the workgroup barrier that publishes them.  Returns "a pivot was <= 0".
+__device__ __noinline__ bool coop_diag(double* __restrict__ A, int n, int k0, int nb, bool prev, bool write_back,
+                                       CoopTile* D, double* Dinv, const CoopTile* P) {
+  const int lane = threadIdx.x & 63;
+  double a[NB];
+  const int r = lane & (NB - 1);
+  const bool live = (lane < NB) && (r < nb);
+  {
+    const double* Ar = A + (size_t)(k0 + (live ? r : 0)) * n + k0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      double v = (live && c <= r && c < nb) ? Ar[c] : 0.0;
+      if (!live && c == r) v = 1.0;                     // identity padding keeps the recurrence well-defined
+      a[c] = v;
+    }
+  }
+  if (prev && live) {                                   // a[c] -= sum_t P[r][t] P[c][t], c <= r
+    double pr[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) pr[t] = P[r][t];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int t = 0; t < NB; t += 2) { s0 = fma(pr[t], P[c][t], s0); s1 = fma(pr[t + 1], P[c][t + 1], s1); }
+      if (c <= r) a[c] -= s0 + s1;
+    }
+  }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const double piv = readlane_f64(a[j], j);
+    if (j < nb && !(piv > 0.0) && piv == piv) bad = true;   // pivot <= 0 (NaN falls through like Eigen)
+    double dj, rdj;
+    sqrt_rsqrt(piv, dj, rdj);
+    if (lane == j) a[j] = dj;
+    else if (lane > j) a[j] = a[j] * rdj;
+#pragma unroll
+    for (int c = j + 1; c < NB; ++c) {
+      const double lcj = readlane_f64(a[j], c);
+      if (lane >= c) a[c] -= a[j] * lcj;
+    }
+  }
+  if (lane < NB) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c) D[lane][c] = a[c];
+    double dg = 1.0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) dg = (c == lane) ? a[c] : dg;
+    Dinv[lane] = 1.0 / dg;
+  }
+  if (write_back && lane < nb) {
+    double* Ar = A + (size_t)(k0 + lane) * n + k0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      if (c <= lane) Ar[c] = a[c];
+  }
+  __syncthreads();                                      // D, Dinv are in LDS
+  return bad;
+}
+
+// A(p), waves 1-3: one 64-row block (`row` < 0: none).  Loads and the pending update run beside wave 0's factorisation;
+// the workgroup barrier in the middle is the one coop_diag ends with.
+__device__ __noinline__ void coop_rows(double* __restrict__ A, double* __restrict__ bvec, int n, int k0, int nb, bool prev,
+                                       int row, const CoopTile* D, const double* Dinv, const CoopTile* P, bool barrier) {
+  double x[NB];
+  if (row >= 0) {
+    const double* Ar = row < n ? A + (size_t)row * n + k0 : bvec + k0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) x[c] = (c < nb) ? Ar[c] : 0.0;
+    if (prev) {
+      double lp[NB];
+      const double* Lp = row < n ? A + (size_t)row * n + (k0 - NB) : bvec + (k0 - NB);
+#pragma unroll
+      for (int t = 0; t < NB; ++t) lp[t] = Lp[t];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < NB; t += 2) { s0 = fma(lp[t], P[c][t], s0); s1 = fma(lp[t + 1], P[c][t + 1], s1); }
+        x[c] -= s0 + s1;
+      }
+    }
+  }
+  if (barrier) __syncthreads();                         // D, Dinv are in LDS
+  if (row >= 0) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      if (c < nb) {
+        double s = x[c];
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+          if (t < c) s -= x[t] * D[c][t];
+        x[c] = s * Dinv[c];
+      }
+    }
+    double* Aw = row < n ? A + (size_t)row * n + k0 : bvec + k0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      if (c < nb) Aw[c] = x[c];
+  }
+}
+
+// B(p): one 64 x 64 tile of the trailing matrix, A[r][c] -= sum_k L[r][k0 + k] L[c][k0 + k], by the whole workgroup
+__device__ __noinline__ void coop_trail_tile(double* __restrict__ A, double* __restrict__ bvec, int n, int k0, int r0, int c0,
+                                             CoopTile* Lr, CoopTile* Lc) {
+  typedef double double4v __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __syncthreads();                                      // the previous tile's operands are no longer read
+  for (int idx = tid; idx < TT * NB; idx += COOP_NT) {
+    const int r = idx >> 5, k = idx & 31;
+    Lr[r][k] = (r0 + r <= n) ? (r0 + r < n ? A[(size_t)(r0 + r) * n + (k0 + k)] : bvec[k0 + k]) : 0.0;
+    Lc[r][k] = (c0 + r < n) ? A[(size_t)(c0 + r) * n + (k0 + k)] : 0.0;
+  }
+  // this wave: rows 16 wv .. 16 wv + 15 of the tile, four 16-column strips; the current values are requested before the products
+  const int rr0 = r0 + 16 * wv;
+  double cur[4][4];
+#pragma unroll
+  for (int js = 0; js < 4; ++js) {
+    const int c = c0 + 16 * js + (lane & 15);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rr = rr0 + (lane >> 4) + 4 * q;
+      const bool ok = rr <= n && c < n && c <= rr;
+      cur[js][q] = ok ? (rr < n ? A[(size_t)rr * n + c] : bvec[c]) : 0.0;
+    }
+  }
+  __syncthreads();
+  double av[NB / 4];
+#pragma unroll
+  for (int kb = 0; kb < NB / 4; ++kb) av[kb] = Lr[16 * wv + (lane & 15)][4 * kb + (lane >> 4)];
+#pragma unroll
+  for (int js = 0; js < 4; ++js) {
+    if (c0 + 16 * js > rr0 + 15) continue;              // strip entirely above the diagonal
+    double4v acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kb = 0; kb < NB / 4; ++kb)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kb], Lc[16 * js + (lane & 15)][4 * kb + (lane >> 4)], acc, 0, 0, 0);
+    const int c = c0 + 16 * js + (lane & 15);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rr = rr0 + (lane >> 4) + 4 * q;
+      if (rr <= n && c < n && c <= rr) {
+        const double v = cur[js][q] - acc[q];
+        if (rr < n) A[(size_t)rr * n + c] = v;
+        else bvec[c] = v;
+      }
+    }
+  }
+}
+
+// backward substitution, wave 0: the 64 x 64 triangle at k0 (lane j holds column j), x into xs
+__device__ __noinline__ void coop_back_triangle(const double* __restrict__ A, const double* __restrict__ bvec, int n, int k0,
+                                                int nb, double* xs, float* __restrict__ dx, bool write_dx) {
+  const int j = threadIdx.x & 63;
+  const bool live = j < nb;
+  double c_[SB];                                        // column j of the block: L[k0 + i][k0 + j], i > j
+#pragma unroll
+  for (int i = 0; i < SB; ++i) c_[i] = (live && i > j && i < nb) ? A[(size_t)(k0 + i) * n + k0 + j] : 0.0;
+  const double inv_dg = live ? 1.0 / A[(size_t)(k0 + j) * n + k0 + j] : 1.0;
+  double yv = live ? bvec[k0 + j] : 0.0;
+#pragma unroll
+  for (int i = SB - 1; i >= 0; --i) {
+    const double xi = readlane_f64(yv * inv_dg, i);
+    if (j == i) yv = xi;
+    else if (j < i) yv -= c_[i] * xi;
+  }
+  xs[j] = yv;
+  if (live && write_dx) dx[k0 + j] = (float)yv;
+}
+
+__global__ __launch_bounds__(COOP_NT) void chol_coop_kernel(double* __restrict__ A, double* __restrict__ bvec, int n,
+                                                            float* __restrict__ dx, int32_t* fail_flag, int32_t* fail_count,
+                                                            int32_t* sync) {
+  __shared__ double D[NB][NB + 1];       // the factored diagonal block
+  __shared__ double Dinv[NB];
+  __shared__ double P[NB][NB + 1];       // pending update: P[c][t] = L[k0 + c][k0 - 32 + t] (the diagonal rows of panel p - 1)
+  __shared__ double Lr[TT][NB + 1];      // trailing tile operands
+  __shared__ double Lc[TT][NB + 1];
+  __shared__ double xs[SB];
+  __shared__ int s_ok, s_bad;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = blockIdx.x, G = gridDim.x;
+  int nbar = 0;
+  bool alive = true;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+#ifdef CHOL_TIMING
+  long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = wall_clock64();
+#endif
+
+  for (int k0 = 0; k0 < n && alive; k0 += NB) {
+    const int nb = min(NB, n - k0);
+    const bool prev = k0 > 0;
+    const int below = n - k0 - nb + 1;                  // rows k0 + nb .. n (the b row included): >= 1
+    const int nblk = (below + 63) >> 6;
+    // ---- A(p): only workgroups that own a row block (block q belongs to workgroup q % G), and workgroup 0
+    if (w < nblk || w == 0) {
+      if (prev) {
+        for (int idx = tid; idx < NB * NB; idx += COOP_NT) {
+          const int c = idx >> 5, t = idx & 31;
+          P[c][t] = (c < nb) ? A[(size_t)(k0 + c) * n + (k0 - NB + t)] : 0.0;
+        }
+      }
+      __syncthreads();                                  // P is in LDS
+      if (wv == 0) {
+        const bool bad = coop_diag(A, n, k0, nb, prev, w == 0, D, Dinv, P);
+        if (w == 0 && lane == 0 && bad) s_bad = 1;
+      } else {
+        const int q = w + (wv - 1) * G;                 // round 0: blocks w, w + G, w + 2 G
+        const int row = k0 + nb + (q << 6) + lane;
+        coop_rows(A, bvec, n, k0, nb, prev, (q < nblk && row <= n) ? row : -1, D, Dinv, P, true);
+      }
+      for (int q0 = 3 * G; q0 < nblk; q0 += 3 * G) {    // (further rounds only when there are more than 3 G row blocks)
+        if (wv > 0) {
+          const int q = q0 + w + (wv - 1) * G;
+          const int row = k0 + nb + (q << 6) + lane;
+          coop_rows(A, bvec, n, k0, nb, prev, (q < nblk && row <= n) ? row : -1, D, Dinv, P, false);
+        }
+      }
+    }
+    COOP_T(0);
+    alive = coop_barrier(sync, (++nbar) * G, &s_ok);
+    COOP_T(1);
+    if (!alive) break;
+    // ---- B(p): trailing update of everything right of the NEXT panel's columns
+    const int s0 = k0 + nb + NB;                        // first column updated now
+    const int rem = n + 1 - s0;                         // rows s0 .. n
+    if (rem > 0 && nb == NB) {
+      const int T = (rem + TT - 1) / TT, ntile = T * (T + 1) / 2;
+      for (int t = w; t < ntile; t += G) {
+        int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        while (ti * (ti + 1) / 2 > t) --ti;
+        const int tj = t - ti * (ti + 1) / 2;
+        coop_trail_tile(A, bvec, n, k0, s0 + ti * TT, s0 + tj * TT, Lr, Lc);
+      }
+    }
+    COOP_T(2);
+  }
+  // (the last panel's A phase ended with a barrier: L and y = L^-1 b are complete and visible)
+  if (alive) {
+    if (s_bad && tid == 0) *fail_flag = 1;              // (only workgroup 0 can have set it)
+    alive = coop_barrier(sync, (++nbar) * G, &s_ok);
+  }
+  if (alive && __hip_atomic_load(fail_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {   // reference: zero update on failure
+    if (w == 0) {
+      for (int i = tid; i < n; i += COOP_NT) dx[i] = 0.0f;
+      if (tid == 0) *fail_count += 1;
+    }
+    return;
+  }
+  // ---- backward substitution L^T x = y, 64 unknowns per step
+  for (int k0 = ((n - 1) / SB) * SB; k0 >= 0 && alive; k0 -= SB) {
+    const int nb = min(SB, n - k0);
+    COOP_T(3);
+    if (wv == 0) coop_back_triangle(A, bvec, n, k0, nb, xs, dx, w == 0);
+    __syncthreads();
+    COOP_T(4);
+    for (int c = w * COOP_NT + tid; c < k0; c += G * COOP_NT) {
+      double s0 = 0.0, s1 = 0.0;
+      for (int r = 0; r + 1 < nb; r += 2) {
+        s0 = fma(A[(size_t)(k0 + r) * n + c], xs[r], s0);
+        s1 = fma(A[(size_t)(k0 + r + 1) * n + c], xs[r + 1], s1);
+      }
+      if (nb & 1) s0 = fma(A[(size_t)(k0 + nb - 1) * n + c], xs[nb - 1], s0);
+      bvec[c] -= s0 + s1;
+    }
+    COOP_T(5);
+    if (k0 > 0) alive = coop_barrier(sync, (++nbar) * G, &s_ok);
+    COOP_T(6);
+  }
+#ifdef CHOL_TIMING
+  if (w == 0 && tid == 0) for (int q = 0; q < 8; ++q) g_chol_t[50 + q] = tc[q];
+#endif
+  if (!alive && w == 0) {                               // a barrier timed out: report it as a failed solve, never hang
+    for (int i = tid; i < n; i += COOP_NT) dx[i] = 0.0f;
+    if (tid == 0) { *fail_flag = 1; *fail_count += 1; }
+  }
+}
+#endif   // CHOL_TIMING: the persistent path
+
 // ---- single-launch path for the frontend window (6P <= 192) -------------------------------
 // The multi-kernel path above spends its time in launch-to-launch dependencies: 6P = 150 is 5 panel
 // + 4 trailing launches + the solve, ~230 us for 1.1 MFLOP.  Here ONE workgroup keeps the packed
@@ -255,18 +602,6 @@ constexpr int SMALL_NT = GS_CHOL_NT;   // one workgroup, 16 waves: latency hidin
 static_assert(SMALL_NT >= 512 && SMALL_NT % 64 == 0 && SMALL_NT <= 1024, "chol: 512 .. 1024 threads");
 constexpr int PW = 30;     // panel width (5 camera blocks): far updates are deferred per panel
 
-#ifdef CHOL_TIMING   // tools/chol_bench.hip only: per-phase wall-clock stamps (100 MHz)
-__device__ long long g_chol_t[64];
-#define CHOL_STAMP(i) do { if (threadIdx.x == 0) g_chol_t[i] = wall_clock64(); } while (0)
-#define CHOL_ACC_DECL long long t_acc[5] = {0, 0, 0, 0, 0}; long long t_last = wall_clock64()
-#define CHOL_ACC(i) do { const long long t_now = wall_clock64(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
-#define CHOL_ACC_DUMP do { if (threadIdx.x == 0) for (int q = 0; q < 5; ++q) g_chol_t[10 + q] = t_acc[q]; } while (0)
-#else
-#define CHOL_STAMP(i) do { } while (0)
-#define CHOL_ACC_DECL do { } while (0)
-#define CHOL_ACC(i) do { } while (0)
-#define CHOL_ACC_DUMP do { } while (0)
-#endif
 
 __device__ __forceinline__ int tri(int r, int c) { return ((r * (r + 1)) >> 1) + c; }
 
@@ -858,8 +1193,16 @@ __global__ __launch_bounds__(SMALL_NT) void chol_mid_kernel(double* __restrict__
 
 }  // namespace
 
+#ifdef CHOL_TIMING
+int g_chol_coop_groups = 128;       // workgroups of the persistent path (all resident at once); tools/chol_bench.hip sweeps it
+#endif
+
 int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float* dx_out, int32_t* fail_flag,
-                         int32_t* fail_count, hipStream_t st) {
+                         int32_t* fail_count, int32_t* sync, hipStream_t st) {
+#ifdef CHOL_TIMING
+  extern int g_chol_force_blocked;                    // tools/chol_bench.hip: 0 = the product's dispatch, 1 = the multi-kernel
+  if (g_chol_force_blocked != 2)                      // path, 2 = the persistent path, whatever n
+#endif
   if (n <= SMALL_N && n % CB == 0) {
     const size_t lds = ((size_t)(n + 1) * (n + 2) / 2 + (size_t)n) * sizeof(double);
     static GsLdsLimit limit;
@@ -870,8 +1213,7 @@ int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float*
     return GS_OK;
   }
 #ifdef CHOL_TIMING
-  extern int g_chol_force_blocked;                    // tools/chol_bench.hip: A/B against the multi-kernel path
-  if (!g_chol_force_blocked)
+  if (g_chol_force_blocked == 0)
 #endif
   if (n <= MID_N && n % CB == 0) {                    // the monocular window: one launch, trailing matrix in HBM / L2
     const int SW = n <= MID_SW60_N ? 60 : 30;
@@ -886,8 +1228,15 @@ int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float*
       return GS_OK;
     }
   }
-  chol_damp_kernel<<<gs_cdiv(n, 256), 256, 0, st>>>(H, n, (double)lm, (double)ep, fail_flag);
+  chol_damp_kernel<<<gs_cdiv(n, 256), 256, 0, st>>>(H, n, (double)lm, (double)ep, fail_flag, sync);
   GS_CHECK_LAUNCH("chol_damp");
+#ifdef CHOL_TIMING
+  if (g_chol_force_blocked == 2 && sync && g_chol_coop_groups > 0) {   // the measured-and-not-shipped persistent path
+    chol_coop_kernel<<<g_chol_coop_groups, COOP_NT, 0, st>>>(H, b, n, dx_out, fail_flag, fail_count, sync);
+    GS_CHECK_LAUNCH("chol_coop");
+    return GS_OK;
+  }
+#endif
   for (int k0 = 0; k0 < n; k0 += NB) {
     const int nb = (n - k0 < NB) ? (n - k0) : NB;
     const int rem = n - k0 - nb;

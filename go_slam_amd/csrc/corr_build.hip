@@ -82,7 +82,8 @@ __device__ __forceinline__ half8 ld8(const _Float16* p) { return *reinterpret_ca
 
 __global__ __launch_bounds__(256, 3) void corr_volume_kernel(
     const _Float16* __restrict__ f1t, const _Float16* __restrict__ f2t, _Float16* __restrict__ v0,
-    _Float16* __restrict__ v1, _Float16* __restrict__ v2, int h, int w, int tiled, int ntiles, int padded) {
+    _Float16* __restrict__ v1, _Float16* __restrict__ v2, int h, int w, int tiled, int ntiles, int padded,
+    const long* __restrict__ oslot) {
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
   const int hw = h * w;
   const int BN = ROWS * w;                 // columns of the tile: a multiple of 32 when w % 8 == 0, of 16 when w % 8 == 4
@@ -100,6 +101,8 @@ __global__ __launch_bounds__(256, 3) void corr_volume_kernel(
   if (tile >= ntiles) return;
   const int gx = (h + ROWS - 1) / ROWS, gy = (hw + BM - 1) / BM;
   const int e = tile / (gx * gy);
+  // where edge e's planes go: slot oslot[e] of the caller's volume pool (gs_corr_volume_pyramid_slots), else edge e
+  const size_t eo = oslot ? (size_t)oslot[e] : (size_t)e;
   const int p1_0 = ((tile / gx) % gy) * BM;
   const int y2_0 = (tile % gx) * ROWS;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256, 3) void corr_volume_kernel(
       const int tx = d / ROWS, y = d - tx * ROWS;
       if (y < rows_valid) {
         const half8 v = *reinterpret_cast<const half8*>(c0 + (size_t)m * LD0 + y * w + 8 * tx);
-        *reinterpret_cast<half8*>(v0 + ((size_t)e * hw + p1_0 + m) * plane + ((size_t)(y2_0 >> 3) * ntx + tx) * 64 +
+        *reinterpret_cast<half8*>(v0 + (eo * hw + p1_0 + m) * plane + ((size_t)(y2_0 >> 3) * ntx + tx) * 64 +
                                   8 * (ybase + y)) = v;
       }
     }
@@ -206,14 +209,14 @@ __global__ __launch_bounds__(256, 3) void corr_volume_kernel(
       for (int i = threadIdx.x; i < m_valid * vec; i += 256) {
         const int m = i / vec, j = i - m * vec;
         const half8 v = *reinterpret_cast<const half8*>(c0 + (size_t)m * LD0 + 8 * j);
-        *reinterpret_cast<half8*>(v0 + ((size_t)e * hw + p1_0 + m) * hw + (size_t)y2_0 * w + 8 * j) = v;
+        *reinterpret_cast<half8*>(v0 + (eo * hw + p1_0 + m) * hw + (size_t)y2_0 * w + 8 * j) = v;
       }
     } else {
       const int vec4 = seg / 4;
       for (int i = threadIdx.x; i < m_valid * vec4; i += 256) {
         const int m = i / vec4, j = i - m * vec4;
         const half4 v = *reinterpret_cast<const half4*>(c0 + (size_t)m * LD0 + 4 * j);
-        *reinterpret_cast<half4*>(v0 + ((size_t)e * hw + p1_0 + m) * hw + (size_t)y2_0 * w + 4 * j) = v;
+        *reinterpret_cast<half4*>(v0 + (eo * hw + p1_0 + m) * hw + (size_t)y2_0 * w + 4 * j) = v;
       }
     }
   }
@@ -245,9 +248,9 @@ __global__ __launch_bounds__(256, 3) void corr_volume_kernel(
         if (m < m_valid && gy < h1) {
           if (tiled) {
             const size_t plane1 = (size_t)pc * ((h1 + 7) >> 3) * 64;
-            *reinterpret_cast<half8*>(v1 + ((size_t)e * hw + p1_0 + m) * plane1 + ((size_t)(gy >> 3) * pc + px) * 64 + (gy & 7) * 8) = o;
+            *reinterpret_cast<half8*>(v1 + (eo * hw + p1_0 + m) * plane1 + ((size_t)(gy >> 3) * pc + px) * 64 + (gy & 7) * 8) = o;
           } else {
-            *reinterpret_cast<half8*>(v1 + ((size_t)e * hw + p1_0 + m) * ((size_t)h1 * w1) + (size_t)gy * w1 + 8 * px) = o;
+            *reinterpret_cast<half8*>(v1 + (eo * hw + p1_0 + m) * ((size_t)h1 * w1) + (size_t)gy * w1 + 8 * px) = o;
           }
         }
       }
@@ -264,9 +267,9 @@ __global__ __launch_bounds__(256, 3) void corr_volume_kernel(
         if (tiled) {
           const int ntx1 = w1 >> 3;
           const size_t plane1 = (size_t)ntx1 * ((h1 + 7) >> 3) * 64;
-          v1[((size_t)e * hw + p1_0 + m) * plane1 + ((size_t)(gy >> 3) * ntx1 + (xx >> 3)) * 64 + (gy & 7) * 8 + (xx & 7)] = o;
+          v1[(eo * hw + p1_0 + m) * plane1 + ((size_t)(gy >> 3) * ntx1 + (xx >> 3)) * 64 + (gy & 7) * 8 + (xx & 7)] = o;
         } else {
-          v1[((size_t)e * hw + p1_0 + m) * ((size_t)h1 * w1) + (size_t)gy * w1 + xx] = o;
+          v1[(eo * hw + p1_0 + m) * ((size_t)h1 * w1) + (size_t)gy * w1 + xx] = o;
         }
       }
     }
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256, 3) void corr_volume_kernel(
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           o[k] = (_Float16)(((((float)a[2 * k] + (float)a[2 * k + 1]) + (float)b[2 * k]) + (float)b[2 * k + 1]) * 0.25f);
-        *reinterpret_cast<half4*>(v2 + ((size_t)e * hw + p1_0 + m) * ((size_t)h2 * w2) + (size_t)gy2 * w2 + 4 * j) = o;
+        *reinterpret_cast<half4*>(v2 + (eo * hw + p1_0 + m) * ((size_t)h2 * w2) + (size_t)gy2 * w2 + 4 * j) = o;
       }
     }
   } else {
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256, 3) void corr_volume_kernel(
       const _Float16* s = c1 + (size_t)m * LD1 + 2 * xx;
       const float a = (float)s[0], b = (float)s[1], c = (float)s[w1], d = (float)s[w1 + 1];
       if (m < m_valid && gy2 < h2)
-        v2[((size_t)e * hw + p1_0 + m) * ((size_t)h2 * w2) + (size_t)gy2 * w2 + xx] = (_Float16)((((a + b) + c) + d) * 0.25f);
+        v2[(eo * hw + p1_0 + m) * ((size_t)h2 * w2) + (size_t)gy2 * w2 + xx] = (_Float16)((((a + b) + c) + d) * 0.25f);
     }
   }
 }
@@ -303,16 +306,17 @@ __global__ __launch_bounds__(256, 3) void corr_volume_kernel(
 // Level 3 = 2x2 average of the fp16 level-2 values (same rounding chain as avg_pool2d on a half tensor): 0.3 % of the
 // pyramid's bytes, read back from L2 right after the volume kernel wrote them.
 __global__ __launch_bounds__(256) void corr_pool3_kernel(const _Float16* __restrict__ v2, _Float16* __restrict__ v3,
-                                                         long planes, int h2, int w2) {
+                                                         long planes, int h2, int w2, int hw, const long* __restrict__ oslot) {
   const int h3 = h2 >> 1, w3 = w2 >> 1;
   const long total = planes * h3 * w3;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long pl = i / (h3 * w3);
+    long pl = i / (h3 * w3);
     const int rem = (int)(i - pl * (h3 * w3));
+    if (oslot) { const long e = pl / hw; pl = oslot[e] * hw + (pl - e * hw); }      // the edge's slot in the volume pool
     const int y = rem / w3, x = rem - y * w3;
     const _Float16* s = v2 + pl * ((long)h2 * w2) + (long)(2 * y) * w2 + 2 * x;
     const float a = (float)s[0], b = (float)s[1], c = (float)s[w2], d = (float)s[w2 + 1];
-    v3[i] = (_Float16)((((a + b) + c) + d) * 0.25f);
+    v3[pl * ((long)h3 * w3) + rem] = (_Float16)((((a + b) + c) + d) * 0.25f);
   }
 }
 
@@ -333,6 +337,13 @@ extern "C" size_t gs_corr_level_elems(int h, int w, int level, int layout) {
 extern "C" int gs_corr_volume_pyramid(const void* fmap1, const void* fmap2, void* vol0, void* vol1, void* vol2,
                                       void* vol3, int n, int dim, int h, int w, int layout, void* workspace,
                                       size_t workspace_bytes, gs_stream_t stream) {
+  return gs_corr_volume_pyramid_slots(fmap1, fmap2, vol0, vol1, vol2, vol3, nullptr, n, dim, h, w, layout, workspace,
+                                      workspace_bytes, stream);
+}
+
+extern "C" int gs_corr_volume_pyramid_slots(const void* fmap1, const void* fmap2, void* vol0, void* vol1, void* vol2,
+                                            void* vol3, const int64_t* out_slot, int n, int dim, int h, int w, int layout,
+                                            void* workspace, size_t workspace_bytes, gs_stream_t stream) {
   GS_REQUIRE(layout == GS_CORR_ROWMAJOR || layout == GS_CORR_TILE8, "corr_volume_pyramid: unknown layout %d", layout);
   GS_REQUIRE(layout == GS_CORR_ROWMAJOR || w % 16 == 0, "corr_volume_pyramid: the tile8 layout needs w %% 16 == 0");
   GS_REQUIRE(fmap1 && fmap2 && vol0 && vol1 && vol2 && vol3, "corr_volume_pyramid: null pointer");
@@ -364,12 +375,12 @@ extern "C" int gs_corr_volume_pyramid(const void* fmap1, const void* fmap2, void
   GS_REQUIRE(ntiles < (1L << 30), "corr_volume_pyramid: map too large");
   const int grid = (int)((ntiles + 7) / 8 * 8);
   corr_volume_kernel<<<grid, 256, lds, st>>>(f1t, f2t, (_Float16*)vol0, (_Float16*)vol1, (_Float16*)vol2, h, w,
-                                             layout == GS_CORR_TILE8, (int)ntiles, padded);
+                                             layout == GS_CORR_TILE8, (int)ntiles, padded, (const long*)out_slot);
   GS_CHECK_LAUNCH("corr_volume");
   if ((h >> 3) > 0 && (w >> 3) > 0) {
     const long planes = (long)n * hw, total = planes * (h >> 3) * (w >> 3);
     corr_pool3_kernel<<<(int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192), 256, 0, st>>>(
-        (const _Float16*)vol2, (_Float16*)vol3, planes, h >> 2, w >> 2);
+        (const _Float16*)vol2, (_Float16*)vol3, planes, h >> 2, w >> 2, hw, (const long*)out_slot);
     GS_CHECK_LAUNCH("corr_pool3");
   }
   return GS_OK;

@@ -214,10 +214,11 @@ template <bool TILED, int PXW = COOP_PXW>
 __global__ __launch_bounds__(256) void corr_pyramid_coop_kernel(
     const _Float16* __restrict__ v0, const _Float16* __restrict__ v1, const _Float16* __restrict__ v2,
     const _Float16* __restrict__ v3, const float* __restrict__ coords, _Float16* __restrict__ corr, int hw1, int h2,
-    int w2) {
+    int w2, const long* __restrict__ slot) {
   __shared__ __attribute__((aligned(16))) _Float16 tiles[4][8 * 196];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n = blockIdx.y;
+  const size_t vn = slot ? (size_t)slot[n] : (size_t)n;          // the edge's planes: slot vn of a volume pool
   const int pw0 = (blockIdx.x * 4 + wv) * PXW;
   if (pw0 >= hw1) return;
   const int pp = lane >> 3, j = lane & 7;
@@ -229,12 +230,13 @@ __global__ __launch_bounds__(256) void corr_pyramid_coop_kernel(
     const int p = pb + pp;
     const bool valid = p < hw1;
     const size_t pix = (size_t)n * hw1 + (valid ? p : pb);
+    const size_t vpix = vn * hw1 + (valid ? p : pb);
     const float2 c = reinterpret_cast<const float2*>(coords)[pix];
     _Float16* tp = tile + pp * 196;
-    level_coop<0, TILED>(v0, pix, valid, h2, w2, c, j, tp);
-    level_coop<1, TILED>(v1, pix, valid, h2, w2, c, j, tp);
-    level_coop<2, TILED>(v2, pix, valid, h2, w2, c, j, tp);
-    level_coop<3, TILED>(v3, pix, valid, h2, w2, c, j, tp);
+    level_coop<0, TILED>(v0, vpix, valid, h2, w2, c, j, tp);
+    level_coop<1, TILED>(v1, vpix, valid, h2, w2, c, j, tp);
+    level_coop<2, TILED>(v2, vpix, valid, h2, w2, c, j, tp);
+    level_coop<3, TILED>(v3, vpix, valid, h2, w2, c, j, tp);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -272,11 +274,13 @@ template <bool TILED>
 __global__ __launch_bounds__(256) void corr_lookup_enc_kernel(
     const _Float16* __restrict__ v0, const _Float16* __restrict__ v1, const _Float16* __restrict__ v2,
     const _Float16* __restrict__ v3, const float* __restrict__ coords, const _Float16* __restrict__ wpad,
-    const float* __restrict__ bias, _Float16* __restrict__ y, int ys, int hw1, int h2, int w2) {
+    const float* __restrict__ bias, _Float16* __restrict__ y, int ys, int hw1, int h2, int w2,
+    const long* __restrict__ slot) {
   __shared__ __attribute__((aligned(16))) _Float16 atile[32 * ENC_K];      // [pixel][k]
   __shared__ __attribute__((aligned(16))) _Float16 otile[32 * 128];        // [pixel][out channel]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n = blockIdx.y;
+  const size_t vn = slot ? (size_t)slot[n] : (size_t)n;          // the edge's planes: slot vn of a volume pool
   const int p00 = blockIdx.x * 32 * ENC_PASSES;
   const int pp = lane >> 3, j = lane & 7;
   const int r = lane & 31, kgl = lane >> 5;
@@ -301,12 +305,13 @@ __global__ __launch_bounds__(256) void corr_lookup_enc_kernel(
       const int p = pb + 8 * wv + pp;
       const bool valid = p < hw1;
       const size_t pix = (size_t)n * hw1 + (valid ? p : pb);
+      const size_t vpix = vn * hw1 + (valid ? p : pb);
       const float2 c = reinterpret_cast<const float2*>(coords)[pix];
       _Float16* tp = atile + (8 * wv + pp) * ENC_K;
-      level_coop<0, TILED>(v0, pix, valid, h2, w2, c, j, tp);
-      level_coop<1, TILED>(v1, pix, valid, h2, w2, c, j, tp);
-      level_coop<2, TILED>(v2, pix, valid, h2, w2, c, j, tp);
-      level_coop<3, TILED>(v3, pix, valid, h2, w2, c, j, tp);
+      level_coop<0, TILED>(v0, vpix, valid, h2, w2, c, j, tp);
+      level_coop<1, TILED>(v1, vpix, valid, h2, w2, c, j, tp);
+      level_coop<2, TILED>(v2, vpix, valid, h2, w2, c, j, tp);
+      level_coop<3, TILED>(v3, vpix, valid, h2, w2, c, j, tp);
     }
     __syncthreads();
     enc_f16v acc;
@@ -534,7 +539,8 @@ int launch_index_backward(const float* coords, const void* g, void* vg, int n, i
 
 template <typename T>
 int launch_pyramid(const void* v0, const void* v1, const void* v2, const void* v3, const float* coords,
-                   void* corr, int n, int h1, int w1, int h2, int w2, int nhwc, int layout, hipStream_t st) {
+                   void* corr, int n, int h1, int w1, int h2, int w2, int nhwc, int layout, hipStream_t st,
+                   const long* slot = nullptr) {
   const int hw1 = h1 * w1;
   dim3 grid(gs_cdiv(hw1, 256), n), block(256);
   if constexpr (sizeof(T) == 2) {
@@ -543,15 +549,15 @@ int launch_pyramid(const void* v0, const void* v1, const void* v2, const void* v
       dim3 cgrid(gs_cdiv(hw1, 4 * COOP_PXW), n);
       const _Float16 *a = (const _Float16*)v0, *b = (const _Float16*)v1, *c = (const _Float16*)v2, *d = (const _Float16*)v3;
       if (layout == GS_CORR_TILE8)
-        corr_pyramid_coop_kernel<true><<<cgrid, block, 0, st>>>(a, b, c, d, coords, (_Float16*)corr, hw1, h2, w2);
+        corr_pyramid_coop_kernel<true><<<cgrid, block, 0, st>>>(a, b, c, d, coords, (_Float16*)corr, hw1, h2, w2, slot);
       else
-        corr_pyramid_coop_kernel<false><<<cgrid, block, 0, st>>>(a, b, c, d, coords, (_Float16*)corr, hw1, h2, w2);
+        corr_pyramid_coop_kernel<false><<<cgrid, block, 0, st>>>(a, b, c, d, coords, (_Float16*)corr, hw1, h2, w2, slot);
       GS_CHECK_LAUNCH("corr_lookup_pyramid");
       return GS_OK;
     }
   }
-  if (layout == GS_CORR_TILE8) {
-    gs_set_error("corr_lookup_pyramid: the tile8 layout is served by the fp16 channels_last kernel only");
+  if (layout == GS_CORR_TILE8 || slot) {
+    gs_set_error("corr_lookup_pyramid: the tile8 layout / a volume pool is served by the fp16 channels_last kernel only");
     return GS_ERR_UNSUPPORTED;
   }
   if (nhwc)
@@ -602,6 +608,14 @@ extern "C" int gs_corr_index_backward(const float* coords, const void* corr_grad
 extern "C" int gs_corr_lookup_enc(const void* vol0, const void* vol1, const void* vol2, const void* vol3,
                                   const float* coords, const void* wpad, const float* bias, void* y, int y_stride, int n,
                                   int h1, int w1, int h2, int w2, int layout, gs_stream_t stream) {
+  return gs_corr_lookup_enc_slots(vol0, vol1, vol2, vol3, nullptr, coords, wpad, bias, y, y_stride, n, h1, w1, h2, w2, layout,
+                                  stream);
+}
+
+extern "C" int gs_corr_lookup_enc_slots(const void* vol0, const void* vol1, const void* vol2, const void* vol3,
+                                        const int64_t* slot, const float* coords, const void* wpad, const float* bias,
+                                        void* y, int y_stride, int n, int h1, int w1, int h2, int w2, int layout,
+                                        gs_stream_t stream) {
   GS_REQUIRE(layout == GS_CORR_ROWMAJOR || layout == GS_CORR_TILE8, "corr_lookup_enc: unknown layout %d", layout);
   GS_REQUIRE(vol0 && vol1 && vol2 && vol3 && coords && wpad && bias && y, "corr_lookup_enc: null pointer");
   GS_REQUIRE(n >= 0 && h1 > 0 && w1 > 0 && (h2 >> 3) > 0 && (w2 >> 3) > 0, "corr_lookup_enc: bad shape");
@@ -614,11 +628,11 @@ extern "C" int gs_corr_lookup_enc(const void* vol0, const void* vol1, const void
   if (layout == GS_CORR_TILE8)
     corr_lookup_enc_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(
         (const _Float16*)vol0, (const _Float16*)vol1, (const _Float16*)vol2, (const _Float16*)vol3, coords,
-        (const _Float16*)wpad, bias, (_Float16*)y, y_stride, hw1, h2, w2);
+        (const _Float16*)wpad, bias, (_Float16*)y, y_stride, hw1, h2, w2, (const long*)slot);
   else
     corr_lookup_enc_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(
         (const _Float16*)vol0, (const _Float16*)vol1, (const _Float16*)vol2, (const _Float16*)vol3, coords,
-        (const _Float16*)wpad, bias, (_Float16*)y, y_stride, hw1, h2, w2);
+        (const _Float16*)wpad, bias, (_Float16*)y, y_stride, hw1, h2, w2, (const long*)slot);
   GS_CHECK_LAUNCH("corr_lookup_enc");
   return GS_OK;
 }
@@ -626,6 +640,14 @@ extern "C" int gs_corr_lookup_enc(const void* vol0, const void* vol1, const void
 extern "C" int gs_corr_lookup_pyramid(const void* vol0, const void* vol1, const void* vol2, const void* vol3,
                                       const float* coords, void* corr, int n, int h1, int w1, int h2, int w2,
                                       int radius, int dtype, int channels_last, int layout, gs_stream_t stream) {
+  return gs_corr_lookup_pyramid_slots(vol0, vol1, vol2, vol3, nullptr, coords, corr, n, h1, w1, h2, w2, radius, dtype,
+                                      channels_last, layout, stream);
+}
+
+extern "C" int gs_corr_lookup_pyramid_slots(const void* vol0, const void* vol1, const void* vol2, const void* vol3,
+                                            const int64_t* slot, const float* coords, void* corr, int n, int h1, int w1,
+                                            int h2, int w2, int radius, int dtype, int channels_last, int layout,
+                                            gs_stream_t stream) {
   GS_REQUIRE(layout == GS_CORR_ROWMAJOR || layout == GS_CORR_TILE8, "corr_lookup_pyramid: unknown layout %d", layout);
   GS_REQUIRE(vol0 && vol1 && vol2 && vol3 && coords && corr, "corr_lookup_pyramid: null pointer");
   GS_REQUIRE(radius == 3, "corr_lookup_pyramid: only radius 3 (the reference's value) is supported");
@@ -634,8 +656,8 @@ extern "C" int gs_corr_lookup_pyramid(const void* vol0, const void* vol1, const 
   GS_REQUIRE(n <= 65535, "corr_lookup_pyramid: n=%d exceeds grid.y limit", n);
   hipStream_t st = (hipStream_t)stream;
   switch (dtype) {
-    case GS_F16: return launch_pyramid<_Float16>(vol0, vol1, vol2, vol3, coords, corr, n, h1, w1, h2, w2, channels_last, layout, st);
-    case GS_F32: return launch_pyramid<float>(vol0, vol1, vol2, vol3, coords, corr, n, h1, w1, h2, w2, channels_last, layout, st);
+    case GS_F16: return launch_pyramid<_Float16>(vol0, vol1, vol2, vol3, coords, corr, n, h1, w1, h2, w2, channels_last, layout, st, (const long*)slot);
+    case GS_F32: return launch_pyramid<float>(vol0, vol1, vol2, vol3, coords, corr, n, h1, w1, h2, w2, channels_last, layout, st, (const long*)slot);
   }
   gs_set_error("corr_lookup_pyramid: unsupported dtype %d", dtype);
   return GS_ERR_UNSUPPORTED;

@@ -9,7 +9,7 @@ import os
 
 import torch
 
-from .corr import AltCorrBlock, CorrBlock
+from .corr import AltCorrBlock, CorrBlock, CorrPool
 
 # FactorGraph.update: keep the BA's index tables per edge set (GS_BA_REUSE_TABLES); 0 = rebuild them in every call
 BA_TABLES = os.environ.get("GOSLAM_BA_TABLES", "1") == "1"
@@ -29,6 +29,7 @@ class FactorGraph:
         on MI355X); shapes and values are unchanged."""
         assert corr_impl in ("volume", "alt")
         self.channels_last = channels_last
+        self.pool_volumes = True        # False: CorrBlock with the reference's cat / [keep] copies (A/B, tests)
         self.video = video
         self.update_op = update_op
         self.device = torch.device(device)
@@ -136,8 +137,14 @@ class FactorGraph:
             c = (ii == jj).long()                   # stereo edges read the right-view feature map
             fmap1 = self.video.fmaps[ii, 0].unsqueeze(0)
             fmap2 = self.video.fmaps[jj, c].unsqueeze(0)
-            corr = CorrBlock(fmap1, fmap2, channels_last=self.channels_last)
-            self.corr = corr if self.corr is None else self.corr.cat(corr)
+            if self.corr is None and self.pool_volumes and CorrPool.supported(fmap1, self.channels_last):
+                # the edges' volumes in slots of a capacity buffer: adding / dropping edges moves none (corr.CorrPool)
+                self.corr = CorrPool(self.ht, self.wd, self.device, capacity=max(self.max_factors, 48) + 32)
+            if isinstance(self.corr, CorrPool):
+                self.corr.append(fmap1, fmap2)
+            else:
+                corr = CorrBlock(fmap1, fmap2, channels_last=self.channels_last)
+                self.corr = corr if self.corr is None else self.corr.cat(corr)
             inp = self._fmt(self.video.inps[ii]).unsqueeze(0)
             self.inp = inp if self.inp is None else self._cat_edges(self.inp, inp)
         with torch.autocast("cuda", enabled=False):

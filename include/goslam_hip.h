@@ -84,6 +84,17 @@ int gs_corr_lookup_pyramid(const void* vol0, const void* vol1, const void* vol2,
 int gs_corr_lookup_enc(const void* vol0, const void* vol1, const void* vol2, const void* vol3, const float* coords,
                        const void* wpad, const float* bias, void* y, int y_stride, int n, int h1, int w1, int h2,
                        int w2, int layout, gs_stream_t stream);
+/* The `_slots` forms read the planes of edge e from slot `slot[e]` (int64 [n] in device memory, NULL = e) of a volume
+ * POOL vol[l] = [capacity, h1, w1, plane_l]: FactorGraph keeps the correlation volumes of its edges in such a pool, so
+ * that adding edges (`CorrBlock.cat`, src/factor_graph.py:118 -- a copy of every volume held, 61 MB per edge at 60 x 80)
+ * and dropping edges (`self.corr[~mask]`, :150 -- another) move no volume at all.  Same arithmetic as the plain forms.
+ * gs_corr_lookup_pyramid_slots serves fp16 + channels_last only.                                                      */
+int gs_corr_lookup_enc_slots(const void* vol0, const void* vol1, const void* vol2, const void* vol3, const int64_t* slot,
+                             const float* coords, const void* wpad, const float* bias, void* y, int y_stride, int n,
+                             int h1, int w1, int h2, int w2, int layout, gs_stream_t stream);
+int gs_corr_lookup_pyramid_slots(const void* vol0, const void* vol1, const void* vol2, const void* vol3,
+                                 const int64_t* slot, const float* coords, void* corr, int n, int h1, int w1, int h2,
+                                 int w2, int radius, int dtype, int channels_last, int layout, gs_stream_t stream);
 
 /* CorrBlock.__init__ + CorrBlock.corr (src/modules/corr.py:26-41,67-76): all-pairs volume of
  * fp16 feature maps fmap1[e], fmap2[e] ([n,128,h,w], both divided by 4) plus the 3 average-pooled
@@ -99,6 +110,10 @@ size_t gs_corr_level_elems(int h, int w, int level, int layout);   /* elements p
 int gs_corr_volume_pyramid(const void* fmap1, const void* fmap2, void* vol0, void* vol1, void* vol2,
                            void* vol3, int n, int dim, int h, int w, int layout,
                            void* workspace, size_t workspace_bytes, gs_stream_t stream);
+/* ... written into slots out_slot[e] (int64 [n] in device memory, NULL = e) of a volume pool (see the lookups above) */
+int gs_corr_volume_pyramid_slots(const void* fmap1, const void* fmap2, void* vol0, void* vol1, void* vol2,
+                                 void* vol3, const int64_t* out_slot, int n, int dim, int h, int w, int layout,
+                                 void* workspace, size_t workspace_bytes, gs_stream_t stream);
 
 /* droid_backends.altcorr_forward (droid.cpp:173-184, altcorr_kernel.cu:27-149,290-319).
  * fmap1 [b,h1,w1,c], fmap2 [b,h2,w2,c] (channels-last, c in {64,128,256}), coords f32

@@ -828,3 +828,64 @@ def test_hip_kernels_match_the_reference_kernel_fixture(db, O, dev):
         torch.testing.assert_close(pg.cpu(), g[f"ba1_{tag}_poses"], rtol=0, atol=1.3e-5)
         torch.testing.assert_close(dg.cpu(), g[f"ba1_{tag}_disps"], rtol=0, atol=1.3e-5)
 
+
+
+@pytest.mark.parametrize("shape", ["Scan", "S480"])
+def test_corr_pool_equals_corr_block_through_adds_removals_and_growth(db, dev, built_lib, shape):
+    """corr.CorrPool (the factor graph's volume store: edges own SLOTS of a capacity buffer, gs_corr_volume_pyramid_slots
+    builds in place, the lookups take the slot list) against CorrBlock with the reference's cat / [keep] copies
+    (src/factor_graph.py:118,150), through the life of a graph: append, drop by mask (prefix and scattered), append into
+    reused slots, growth past the capacity, drop by index list.  Planes, the materialised lookup and the lookup fused with
+    corr_encoder[0] must be IDENTICAL bit for bit -- same kernels, one more index."""
+    from go_slam_amd.corr import CorrBlock, CorrPool
+    ht, wd, _ = synth.SHAPES[shape]
+    g = torch.Generator().manual_seed(301)
+    fm = lambda n: torch.randn(1, n, 128, ht, wd, generator=g).half().to(dev)
+    pool = CorrPool(ht, wd, dev, capacity=6)
+    blk = None
+    assert CorrPool.supported(fm(1))
+
+    def add(n):
+        nonlocal blk
+        f1, f2 = fm(n), fm(n)
+        pool.append(f1, f2)
+        b = CorrBlock(f1, f2, channels_last=True)
+        blk = b if blk is None else blk.cat(b)
+
+    def drop(index):
+        nonlocal blk
+        pool[index]
+        blk = blk[index]
+
+    def check():
+        E = len(pool)
+        assert E == blk.corr_pyramid[0].shape[0] and pool.layout == blk.layout
+        assert int(pool.free.numel()) + E == pool.capacity and len(set(pool.slot.tolist())) == E
+        for a, b in zip(pool.corr_pyramid, blk.corr_pyramid):
+            assert torch.equal(a.reshape(b.shape), b)
+        if E == 0:
+            return
+        ys, xs = torch.meshgrid(torch.arange(ht, dtype=torch.float32), torch.arange(wd, dtype=torch.float32), indexing="ij")
+        coords = (torch.stack([xs, ys], -1)[None, None] + 4.0 * torch.randn(1, E, ht, wd, 2, generator=g)).to(dev)
+        assert torch.equal(pool(coords), blk(coords))
+        wpad = torch.zeros(128, 208, dtype=torch.float16, device=dev)
+        wpad[:, :196] = (torch.randn(128, 196, generator=g) / 14.0).half().to(dev)
+        bias = torch.randn(128, generator=g).to(dev)
+        assert torch.equal(pool.lookup_encoded(coords, wpad, bias), blk.lookup_encoded(coords, wpad, bias))
+
+    add(4)
+    check()
+    drop(torch.tensor([False, False, True, True], device=dev))                 # retire the oldest two (a prefix)
+    add(3)                                                                     # lands in the freed slots first
+    check()
+    assert pool.capacity == 6
+    drop(torch.tensor([True, False, True, False, True], device=dev))           # scattered (max_factors retirement)
+    add(7)                                                                     # 3 + 7 > 6: the buffers grow, live slots keep their numbers
+    assert pool.capacity >= 10
+    check()
+    drop(torch.tensor([9, 0, 4, 5], device=dev))                               # an index list, reordering the edges
+    check()
+    drop(torch.zeros(4, dtype=torch.bool, device=dev))                         # clear_edges
+    check()
+    add(2)
+    check()

@@ -35,12 +35,12 @@ int main(int argc, char** argv) {
     }
     for (int i = 0; i < n; ++i) b[i] = i * 0.01 - 0.3;
     double *dA, *db; float* dx; int32_t* flags;
-    hipMalloc(&dA, A.size() * 8); hipMalloc(&db, n * 8); hipMalloc(&dx, n * 4); hipMalloc(&flags, 8);
-    hipMemset(flags, 0, 8);
+    hipMalloc(&dA, A.size() * 8); hipMalloc(&db, n * 8); hipMalloc(&dx, n * 4); hipMalloc(&flags, 64);
+    hipMemset(flags, 0, 64);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    std::vector<float> xs[2];
-    float us[2] = {0, 0};
-    for (int mode = 0; mode < 2; ++mode) {
+    std::vector<float> xs[3];
+    float us[3] = {0, 0, 0};
+    for (int mode = 0; mode < 3; ++mode) {
       g_chol_force_blocked = mode;
       float best = 1e9f;
       for (int rep = 0; rep < 6; ++rep) {
@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
         hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        gs_chol_solve_launch(dA, db, n, 1e-4f, 0.1f, dx, flags, flags + 1, 0);
+        gs_chol_solve_launch(dA, db, n, 1e-4f, 0.1f, dx, flags, flags + 1, flags + 8, 0);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -61,13 +61,40 @@ int main(int argc, char** argv) {
     int32_t fl[2]; hipMemcpy(fl, flags, 8, hipMemcpyDeviceToHost);
     double dmax = 0, xmax = 0;
     for (int i = 0; i < n; ++i) { dmax = fmax(dmax, fabs((double)xs[0][i] - xs[1][i])); xmax = fmax(xmax, fabs((double)xs[0][i])); }
-    printf("n %4d: single-launch %7.1f us (residual %.3e) | blocked %7.1f us (residual %.3e) | max |x - x_blocked| %.3e of %.3e, fail flag %d count %d\n",
-           n, us[0], residual(A, b, xs[0], n), us[1], residual(A, b, xs[1], n), dmax, xmax, fl[0], fl[1]);
+    double dmax2 = 0;
+    for (int i = 0; i < n; ++i) dmax2 = fmax(dmax2, fabs((double)xs[2][i] - xs[1][i]));
+    printf("n %4d: product dispatch %7.1f us (residual %.3e) | multi-kernel %7.1f us (residual %.3e) | persistent (%d groups) %7.1f us (residual %.3e) | max |x - x_multi| %.3e / %.3e of %.3e, fail flag %d count %d\n",
+           n, us[0], residual(A, b, xs[0], n), us[1], residual(A, b, xs[1], n), g_chol_coop_groups, us[2], residual(A, b, xs[2], n), dmax, dmax2, xmax, fl[0], fl[1]);
+    if (n > 450) {                                    // the persistent path against its workgroup count
+      g_chol_force_blocked = 2;
+      const int keep = g_chol_coop_groups;
+      for (int G : {16, 32, 64, 128, 256}) {
+        g_chol_coop_groups = G;
+        float best = 1e9f;
+        for (int rep = 0; rep < 5; ++rep) {
+          hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+          hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice);
+          hipDeviceSynchronize();
+          hipEventRecord(e0);
+          gs_chol_solve_launch(dA, db, n, 1e-4f, 0.1f, dx, flags, flags + 1, flags + 8, 0);
+          hipEventRecord(e1);
+          hipEventSynchronize(e1);
+          float ms; hipEventElapsedTime(&ms, e0, e1);
+          if (rep > 0 && ms < best) best = ms;
+        }
+        std::vector<float> x(n); hipMemcpy(x.data(), dx, n * 4, hipMemcpyDeviceToHost);
+        long long t[64];
+        hipMemcpyFromSymbol(t, HIP_SYMBOL(g_chol_t), sizeof(t));
+        printf("        persistent, %3d workgroups: %7.1f us (residual %.3e) | workgroup 0: A-phase %.1f  barrier %.1f  B-phase %.1f | back: misc %.1f triangle %.1f update %.1f barrier %.1f us\n",
+               G, best * 1e3f, residual(A, b, x, n), t[50] / 100.0, t[51] / 100.0, t[52] / 100.0, t[53] / 100.0, t[54] / 100.0, t[55] / 100.0, t[56] / 100.0);
+      }
+      g_chol_coop_groups = keep;
+    }
     if (n <= 192) {
       g_chol_force_blocked = 0;
       hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
       hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice);
-      gs_chol_solve_launch(dA, db, n, 1e-4f, 0.1f, dx, flags, flags + 1, 0);
+      gs_chol_solve_launch(dA, db, n, 1e-4f, 0.1f, dx, flags, flags + 1, flags + 8, 0);
       hipDeviceSynchronize();
       long long t[64];
       hipMemcpyFromSymbol(t, HIP_SYMBOL(g_chol_t), sizeof(t));
@@ -79,7 +106,7 @@ int main(int argc, char** argv) {
       g_chol_force_blocked = 0;
       hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
       hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice);
-      gs_chol_solve_launch(dA, db, n, 1e-4f, 0.1f, dx, flags, flags + 1, 0);
+      gs_chol_solve_launch(dA, db, n, 1e-4f, 0.1f, dx, flags, flags + 1, flags + 8, 0);
       hipDeviceSynchronize();
       long long t[64];
       hipMemcpyFromSymbol(t, HIP_SYMBOL(g_chol_t), sizeof(t));
@@ -96,16 +123,16 @@ int main(int argc, char** argv) {
     // an indefinite matrix must give dx = 0 and raise the flag on both paths
     std::vector<double> Aneg = A;
     Aneg[(size_t)(n / 2) * n + n / 2] = -1e6;
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 3; ++mode) {
       g_chol_force_blocked = mode;
       hipMemcpy(dA, Aneg.data(), A.size() * 8, hipMemcpyHostToDevice);
       hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice);
-      gs_chol_solve_launch(dA, db, n, 1e-4f, 0.1f, dx, flags, flags + 1, 0);
+      gs_chol_solve_launch(dA, db, n, 1e-4f, 0.1f, dx, flags, flags + 1, flags + 8, 0);
       hipDeviceSynchronize();
       std::vector<float> x(n); hipMemcpy(x.data(), dx, n * 4, hipMemcpyDeviceToHost);
       hipMemcpy(fl, flags, 8, hipMemcpyDeviceToHost);
       double nz = 0; for (float v : x) nz = fmax(nz, fabs((double)v));
-      printf("        indefinite (%s): max |dx| %.1e, fail flag %d\n", mode ? "blocked" : "single-launch", nz, fl[0]);
+      printf("        indefinite (%s): max |dx| %.1e, fail flag %d\n", mode == 0 ? "product dispatch" : mode == 1 ? "multi-kernel" : "persistent", nz, fl[0]);
     }
     hipFree(dA); hipFree(db); hipFree(dx); hipFree(flags);
   }
