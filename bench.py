@@ -396,12 +396,27 @@ def sequence_bench(device, keyframes=40, warm_keyframes=34, frames_per_keyframe=
             kept += int(bool(fe.decisions and fe.decisions[-1]))
     n = video.counter.value
     finite = bool(torch.isfinite(video.poses[:n]).all()) and bool(torch.isfinite(video.disps[:n]).all())
+    # the headline's unit -- 6 x FactorGraph.update, per-edge-set caches dropped once (keyframe_step) -- on THIS graph as the
+    # sequence left it (its active + inactive edges, its window): what the end-to-end keyframe is to be compared with
+    g_ = fe.graph
+
+    def unit():
+        g_._eidx = None
+        g_.update_op.drop_edge_caches()
+        for _ in range(UPDATES_PER_KF):
+            g_.update(None, None, use_inactive=True)
+    p0, d0 = video.poses.clone(), video.disps.clone()
+    unit_ms = time_op(unit, iters=5, warm=2)
+    video.poses.copy_(p0)
+    video.disps.copy_(d0)
     out = {"workload": f"{(warm_keyframes + keyframes) * frames_per_keyframe} frames of 480x640 RGB-D, a keyframe every "
                        f"{frames_per_keyframe} frames, {keyframes} timed keyframes after {warm_keyframes}; window 25, "
                        f"max_factors 75, enable_loop {enable_loop}, every {drop_every}th keyframe dropped (rm_keyframe)",
            "video": "shared (reference constructor: locked sections end with a stream sync)" if shared_video
                     else "single process (asynchronous)",
            "frontend_e2e_ms_per_keyframe": 1e3 * t_front / keyframes,
+           "six_update_unit_ms_on_the_final_graph": unit_ms, "final_graph_edges": int(g_.ii.numel()),
+           "e2e_over_unit": (1e3 * t_front / keyframes) / unit_ms,
            "motion_filter_ms_per_frame": 1e3 * t_frames / (keyframes * frames_per_keyframe),
            "ms_per_keyframe_all": 1e3 * (t_front + t_frames) / keyframes,
            "frames_per_s": keyframes * frames_per_keyframe / (t_front + t_frames),

@@ -68,15 +68,17 @@ class FactorGraph:
         if c is not None and c["key"] == key and all(a is b for a, b in zip(c["tens"], tens)):
             return c
         dev = self.device
-        ii_c, jj_c = self.ii.cpu(), self.jj.cpu()
+        E, Ei = self.ii.numel(), self.ii_inac.numel()
+        host = torch.cat([self.ii, self.jj, self.ii_inac, self.jj_inac]).cpu()     # ONE device-to-host read per edge set
+        ii_c, jj_c = host[:E], host[E:2 * E]
         a0 = max(1, int(ii_c.min()) + 1) if t0 is None else t0
         a0 = max(1, a0)
         a1 = (max(int(ii_c.max()), int(jj_c.max())) + 1) if t1 is None else t1
         seg = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in build_segments(ii_c).items()}
-        c = {"key": key, "tens": tens, "t0": a0, "t1": a1, "seg": seg, "sel": None}
+        c = {"key": key, "tens": tens, "t0": a0, "t1": a1, "seg": seg, "sel": None, "ii_min": int(ii_c.min())}
         ii_all = ii_c
         if use_inactive:
-            iin, jin = self.ii_inac.cpu(), self.jj_inac.cpu()
+            iin, jin = host[2 * E:2 * E + Ei], host[2 * E + Ei:]
             m = (iin >= a0 - 3) & (jin >= a0 - 3)
             c["sel"] = torch.nonzero(m).reshape(-1).to(dev)
             ii_all = torch.cat([iin[m], ii_c])
@@ -167,22 +169,32 @@ class FactorGraph:
 
     @torch.no_grad()
     def rm_factors(self, mask, store=False):
-        """drop edges (src/factor_graph.py:132-158), optionally keeping them as inactive."""
+        """drop edges (src/factor_graph.py:132-158), optionally keeping them as inactive.  The reference indexes nine
+        tensors with the boolean mask -- a `nonzero` (four scan launches + a host sync) each; here the mask becomes two
+        index lists once and everything is an index_select."""
+        mask = mask.to(device=self.device, dtype=torch.bool).reshape(-1)
+        if mask.is_cuda:                                # both lists from ONE device-to-host read
+            order = torch.argsort(mask.to(torch.uint8), stable=True)     # kept edges first, in order; then the dropped
+            n_keep = mask.numel() - int(mask.sum())
+            keep, gone = order[:n_keep], order[n_keep:]
+        else:
+            keep, gone = torch.nonzero(~mask).reshape(-1), torch.nonzero(mask).reshape(-1)
+        if gone.numel() == 0:
+            return
         if store:
-            self.ii_inac = torch.cat([self.ii_inac, self.ii[mask]])
-            self.jj_inac = torch.cat([self.jj_inac, self.jj[mask]])
-            self.target_inac = torch.cat([self.target_inac, self.target[:, mask]], 1)
-            self.weight_inac = torch.cat([self.weight_inac, self.weight[:, mask]], 1)
-        keep = ~mask
-        self.ii, self.jj, self.age = self.ii[keep], self.jj[keep], self.age[keep]
+            self.ii_inac = torch.cat([self.ii_inac, self.ii.index_select(0, gone)])
+            self.jj_inac = torch.cat([self.jj_inac, self.jj.index_select(0, gone)])
+            self.target_inac = torch.cat([self.target_inac, self.target.index_select(1, gone)], 1)
+            self.weight_inac = torch.cat([self.weight_inac, self.weight.index_select(1, gone)], 1)
+        self.ii, self.jj, self.age = (x.index_select(0, keep) for x in (self.ii, self.jj, self.age))
         if self.corr_impl == "volume" and self.corr is not None:
             self.corr = self.corr[keep]
         if self.inp is not None:
-            self.inp = self._fmt(self.inp[0][keep]).unsqueeze(0)
+            self.inp = self._select_edges(self.inp, keep)
         if self.net is not None:
-            self.net = self._fmt(self.net[0][keep]).unsqueeze(0)
-        self.target = self.target[:, keep]
-        self.weight = self.weight[:, keep]
+            self.net = self._select_edges(self.net, keep)
+        self.target = self.target.index_select(1, keep)
+        self.weight = self.weight.index_select(1, keep)
 
     # ---- edge-set management (src/factor_graph.py:43-53, 70-83, 159-197, 368-450) -----------------------
     @staticmethod
@@ -197,9 +209,15 @@ class FactorGraph:
     def _filter_repeated_edges(self, ii, jj):
         """drop proposed edges that are already active or inactive (src/factor_graph.py:43-53).  As in the
         reference, duplicates WITHIN the proposal are kept."""
-        have = set(self._edges_on_host((self.ii, self.jj), (self.ii_inac, self.jj_inac)))
-        if not have or ii.numel() == 0:
+        if ii.numel() == 0 or self.ii.numel() + self.ii_inac.numel() == 0:
             return ii, jj
+        if ii.is_cuda:                                  # one key per edge, membership on the device, ONE host read
+            have = torch.cat([self.ii, self.ii_inac]) * (1 << 20) + torch.cat([self.jj, self.jj_inac])
+            keep = torch.nonzero(~torch.isin(ii * (1 << 20) + jj, have)).reshape(-1)
+            if keep.numel() == ii.numel():
+                return ii, jj
+            return ii.index_select(0, keep), jj.index_select(0, keep)
+        have = set(self._edges_on_host((self.ii, self.jj), (self.ii_inac, self.jj_inac)))
         keep = torch.tensor([e not in have for e in zip(ii.cpu().tolist(), jj.cpu().tolist())],
                             dtype=torch.bool, device=ii.device)
         return ii[keep], jj[keep]

@@ -121,7 +121,9 @@ class Frontend:
         v = self.video
         v.poses[self.t1] = v.poses[self.t1 - 1]
         v.disps[self.t1] = v.disps[self.t1 - 1].mean()
-        v.dirty[int(self.graph.ii.min()):self.t1] = True
+        c = getattr(self.graph, "_eidx", None)          # (the cached edge index knows the oldest source keyframe: no device read)
+        lo = c["ii_min"] if c is not None and c["tens"][0] is self.graph.ii and "ii_min" in c else int(self.graph.ii.min())
+        v.dirty[lo:self.t1] = True
 
     @torch.no_grad()
     def _update(self):

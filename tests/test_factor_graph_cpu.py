@@ -141,9 +141,13 @@ class _FakeCorr:
         self.n += other.n
         return self
 
-    def __getitem__(self, keep):
-        assert keep.numel() == self.n
-        self.n = int(keep.sum())
+    def __getitem__(self, keep):            # a boolean mask over the edges, or the list of kept edge indices
+        if keep.dtype == torch.bool:
+            assert keep.numel() == self.n
+            self.n = int(keep.sum())
+        else:
+            assert keep.numel() <= self.n and (keep.numel() == 0 or int(keep.max()) < self.n)
+            self.n = int(keep.numel())
         return self
 
 
