@@ -636,7 +636,11 @@ def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768, s
             "exchange": "none" if not sharded else ("reduce-scatter(fp16 table grad) + sharded AdamW + all-gather(fp16 "
                                                     "table)" if tr.fused else "all-reduce(fp32 flat grad)"),
             "exchange_exposed_ms": (max(r[1] for r in exch["per_rank"]) if exch else (0.0 if not sharded else None)),
-            "exchange_per_rank": exch, "final_loss": float(loss)}
+            "exchange_per_rank": exch, "final_loss": float(loss),
+            "collectives_captured": (bool(tr._graphs) and all(bool(e.get("one")) for e in tr._graphs.values()
+                                                               if e.get("graph") is not None and e.get("tail") is None))
+            if (sharded and getattr(tr, "fused", False)) else None,
+            "capture_error": getattr(tr, "capture_collectives_error", None)}
 
 
 def cpu_baseline(sample_updates=1):
@@ -924,6 +928,8 @@ def sharded_schedule_one_rank(device):
         for rays in (32768, 4096):
             r = neus_train_bench(device, 0, 1, global_rays=rays, sharded=True)
             out[str(rays)] = {"ms_per_step": r["ms_per_step"], "graph_replay": r["graph_replay"],
+                              "collectives_captured_in_the_graph": r.get("collectives_captured"),
+                              "capture_error": r.get("capture_error"),
                               "exchange_per_rank": r["exchange_per_rank"], "final_loss": r["final_loss"]}
     finally:
         if created:

@@ -179,9 +179,12 @@ class FlatAdamW:
         self.G16.zero_()
         return self.G16[:self.n16]
 
-    def step(self, inv_scale16, prepped=False):
+    def step(self, inv_scale16, prepped=False, captured=False):
         """table gradient / inv_scale16 is in self.G16 (fp16), the dense gradients (+ the loss in slot nd) in self.g32.
-        `prepped`: gs_map_step_prep already advanced the device-side step count and zeroed the norm accumulator."""
+        `prepped`: gs_map_step_prep already advanced the device-side step count and zeroed the norm accumulator.
+        `captured`: the call is being captured into a hipGraph together with its collectives (MapTrainer's one-graph
+        sharded step): every collective is stream-ordered (no deferred all-gather, no timer events) and the host-side
+        bookkeeping (`_publish`) is the caller's, once per replay."""
         from .distributed import all_gather_into_, all_reduce_sum_, reduce_scatter_sum_
         K, h, nd = self.kernels, self.hyper, self.nd
         self.steps += 1
@@ -190,8 +193,9 @@ class FlatAdamW:
             self.sqnorm.zero_()
         dense = (self.P[self.n16p:], self.M[self.slice:], self.V[self.slice:], self.P16[self.n16p:], self.g32[:nd])
         if self.sharded:
-            self.wait_gather()
-            t = self._exchange_timer
+            if not captured:
+                self.wait_gather()
+            t = None if captured else self._exchange_timer
             if t is not None:
                 t.mark("rs0")
             early, self._rs_wait = self._rs_wait, None
@@ -217,8 +221,8 @@ class FlatAdamW:
             if t is not None:
                 t.mark("agq")
             self._gather_wait = all_gather_into_(self.P16[:self.n16p], self.P16[self.lo:self.hi], self.group,
-                                                 async_op=self.overlap_gather)
-            if not self.overlap_gather:
+                                                 async_op=self.overlap_gather and not captured)
+            if captured or not self.overlap_gather:
                 self._gather_wait = None
                 if t is not None:
                     t.mark("agw0", at="agq")
@@ -227,6 +231,8 @@ class FlatAdamW:
             K.sqnorm(self.sqnorm, self.G16, inv_scale16, self.g32[:nd])
             K.adamw(self.P[:self.n16p], self.M[:self.slice], self.V[:self.slice], self.P16[:self.n16p], self.G16,
                     inv_scale16, *dense, h, self.steps, self.step_dev, self.sqnorm)
+        if captured:
+            return
         self._publish()
         if self._gather_wait is not None:
             self.grid_module._half._pending = self.wait_gather
@@ -286,6 +292,13 @@ class MapTrainer:
             fused = all(p.is_cuda for p in self.train_params) and model.grid_grad_dtype == torch.float16
         self.fused = bool(fused)
         self.graph = bool(self.fused if graph is None else (graph and self.fused))
+        # sharded step as ONE hipGraph with its collectives captured (RCCL enqueues are graph nodes: no host-side launch
+        # between the two halves of the step, no optimiser launches outside a graph): tried on the first capture when the
+        # group's backend is RCCL, given up for good (two graphs around eager collectives, as rounds 4-5) if the capture is
+        # refused.  GOSLAM_CAPTURE_COLLECTIVES=0 turns the attempt off.
+        import os
+        self.capture_collectives = os.environ.get("GOSLAM_CAPTURE_COLLECTIVES", "1") == "1"
+        self.capture_collectives_error = None
         self._graphs, self._bufs = {}, {}
         if self.fused:
             self.flat = FlatAdamW(model, net_lr, grid_lr, rank=rank, world=world, group=group, sharded=self.sharded)
@@ -415,7 +428,8 @@ class MapTrainer:
     def _graph_for(self, args, counts, perturb_rand):
         """hipGraph of the step's local part for this batch shape: static input buffers + the captured launch sequence"""
         h = self.flat.hyper
-        key = (tuple(args[0].shape), perturb_rand is None, self.world, h["lr16"], h["lr32"])   # (host scalars are baked in)
+        key = (tuple(args[0].shape), perturb_rand is None, self.world, h["lr16"], h["lr32"],     # (host scalars are baked in)
+               self._one_graph())
         ent = self._graphs.get(key)
         if ent is not None:
             self._graphs[key] = self._graphs.pop(key)       # most recently used last
@@ -431,6 +445,16 @@ class MapTrainer:
                    bufs=self._step_buffers(args[0].shape[0], dev), rt_bound=self.model.realtime_bound)
         self._graphs[key] = ent
         return ent
+
+    def _one_graph(self):
+        """the sharded step's collectives are captured with it (RCCL process group, no exchange timer attached)"""
+        if not (self.sharded and self.capture_collectives and self.flat._exchange_timer is None):
+            return False
+        import torch.distributed as dist
+        try:
+            return dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+        except (RuntimeError, ValueError):
+            return False
 
     def step_fused(self, rays_o, rays_d, rays_color, rays_depth, perturb_rand=None):
         flat = self.flat
@@ -459,12 +483,13 @@ class MapTrainer:
         torch._foreach_copy_(dsts, srcs)    # ONE launch for the 4-6 input tensors (was a 4.4 us copy kernel each)
         flat.wait_gather()                  # (world > 1) the previous step's table all-gather ran beside everything above
         whole = not self.sharded            # single GPU: the optimiser's two launches are part of the graph
+        one = self._one_graph()             # sharded, collectives captured: also ONE graph
 
-        def body(after_table=None):
+        def body(after_table=None, captured=False):
             inv = self._local_gradients(*ent["static"], ent["pr"], None if whole else ent["counts"], bufs=ent["bufs"],
                                         after_table=after_table)
-            if whole:
-                flat.step(inv, prepped=True)
+            if whole or captured:
+                flat.step(inv, prepped=True, captured=captured)
             return inv
         if ent["graph"] is None:
             if ent["warm"] < 2:             # eager first (workspaces, fp16 caches, lazy library state), then capture
@@ -480,6 +505,20 @@ class MapTrainer:
             if whole:
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     ent["inv_scale"] = body()
+            elif one:
+                try:
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                        ent["inv_scale"] = body(early, captured=True)
+                    ent["one"] = True
+                except Exception as exc:        # noqa: BLE001 -- RCCL / torch refused: eager collectives from now on
+                    self.capture_collectives, self.capture_collectives_error = False, repr(exc)[:300]
+                    flat._rs_wait = None
+                    flat.steps = steps_before
+                    torch.cuda.synchronize(ent["static"][0].device)
+                    self._graphs.pop(next(k for k, v in self._graphs.items() if v is ent))
+                    inv = self._local_gradients(*args, perturb_rand, counts, after_table=early)
+                    flat.step(inv, prepped=True)
+                    return self._global_loss()
             else:
                 # world > 1: TWO graphs sharing one memory pool, cut where the table gradient is complete (after the bin
                 # reduce): [sample ... backward pass 1 + bin reduce] | [Gram + post].  The reduce-scatter is enqueued
@@ -502,7 +541,7 @@ class MapTrainer:
             ent["graph"] = graph
             flat.steps = steps_before       # capture ran nothing: the replay below is the step
         ent["graph"].replay()
-        if whole:
+        if whole or ent.get("one"):
             flat.steps += 1                 # (the device-side count was advanced inside the graph)
             flat._publish()
         else:
