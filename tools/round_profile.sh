@@ -4,7 +4,7 @@
 # full GPU suite, the bench line (driver flags), kernel traces of the tracking keyframe / the three mapping legs /
 # MotionFilter.track / the global-BA stress step, the PMC passes of the mapper step, the Cholesky harness.
 # Everything lands in gpurun_out/<tag>_final/; the summaries that are judged get copied to profiles/ by hand.
-tag=${1:-r05}
+tag=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${tag}_final
 mkdir -p $OUT
@@ -36,6 +36,10 @@ done
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_mf -o t -- python $R/tools/profile_motion_filter.py 20 > $OUT/prof_mf.log 2>&1 || echo "prof mf failed"
 f=$(find $OUT/prof_mf -name '*kernel_trace.csv' | head -1)
 python $R/tools/summarize_kernels.py $f --steps 20 --after erfinv --title "MotionFilter.track, one 480x640 RGB-D input frame (20 steady-state frames; setup and warm frames excluded by the marker launch)" > $OUT/motion_filter_kernel_stats.md 2>> $OUT/summarize.err
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_e2e -o t -- python $R/tools/profile_frontend_e2e.py 16 > $OUT/prof_e2e.log 2>&1 || echo "prof e2e failed"
+f=$(find $OUT/prof_e2e -name '*kernel_trace.csv' | head -1)
+python $R/tools/summarize_kernels.py $f --steps 16 --after erfinv --title "end to end on a synthetic 640x480 RGB-D sequence, per keyframe: 4 x MotionFilter.track + Frontend.__call__ (window 25, max_factors 75; 16 steady-state keyframes after the marker launch)" > $OUT/frontend_e2e_kernel_stats.md 2>> $OUT/summarize.err
+timeout 200 python $R/tools/profile_frontend_e2e.py 16 --ops > $OUT/frontend_e2e_ops.json 2> $OUT/frontend_e2e_ops.err
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_stress -o t -- python $R/tools/profile_stress.py 8 > $OUT/prof_stress.log 2>&1 || echo "prof stress failed"
 f=$(find $OUT/prof_stress -name '*kernel_trace.csv' | head -1)
 python $R/tools/summarize_kernels.py $f --steps 8 --after erfinv --title "global BA stress (200 keyframes, 1200 edges, 30x40): one update_lowmem(steps=8) invocation, per-edge caches cold, per step" > $OUT/stress_kernel_stats.md 2>> $OUT/summarize.err
@@ -43,5 +47,6 @@ find $OUT -name '*.csv' -delete
 PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum" timeout 600 bash $R/tools/pmc_pass.sh $OUT/pmc_neus _kernel -- python $R/tools/profile_mapping.py train 3 > $OUT/pmc_neus.log 2>&1
 # what the backward's pass 1 is bound by: instruction counts and busy cycles of the same launches
 PMC_GROUPS="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS;SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES;SQ_BUSY_CYCLES GRBM_GUI_ACTIVE;SQ_WAIT_INST_ANY SQ_WAIT_ANY" timeout 600 bash $R/tools/pmc_pass.sh $OUT/pmc_neus_sq _kernel -- python $R/tools/profile_mapping.py train 3 > $OUT/pmc_neus_sq.log 2>&1
-[ -x $R/tools/chol_bench ] && timeout 120 $R/tools/chol_bench 150 192 198 294 300 306 342 360 450 456 > $OUT/chol_bench.txt 2>&1
-head -8 $OUT/tracking_kernel_stats.md; head -8 $OUT/stress_kernel_stats.md; head -4 $OUT/motion_filter_kernel_stats.md; tail -3 $OUT/summarize.err; tail -12 $OUT/chol_bench.txt
+[ -x $R/tools/chol_bench ] && timeout 150 $R/tools/chol_bench 150 192 198 294 300 306 342 360 450 456 1194 > $OUT/chol_bench.txt 2>&1
+cd $R && timeout 900 bash $R/tools/gemm_comparator.sh $OUT/gemm > $OUT/gemm_comparator.log 2>&1
+head -8 $OUT/tracking_kernel_stats.md; head -8 $OUT/stress_kernel_stats.md; head -4 $OUT/motion_filter_kernel_stats.md; head -4 $OUT/frontend_e2e_kernel_stats.md; tail -3 $OUT/summarize.err; tail -12 $OUT/chol_bench.txt
