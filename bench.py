@@ -784,7 +784,7 @@ def neus_kernel_rooflines(device, n_rays, steps=5):
     ceil_ = gather_ceiling(n_rays)
     inb = ceil_["points_in_bound"] if ceil_ else pts
     pmc = {}
-    ppath = os.path.join(ROOT, "profiles", "r05_pmc_neus.json")
+    ppath = os.path.join(ROOT, "profiles", "r06_pmc_neus.json")
     if os.path.exists(ppath):
         pmc = json.load(open(ppath)).get(f"traffic_bytes_per_launch@{n_rays}", {})
     nh = 11                         # hashed levels (2^19 entries x 4 B each)
@@ -818,7 +818,10 @@ def neus_kernel_rooflines(device, n_rays, steps=5):
         ent = {"kernel": name + f" @ {n_rays} rays x 72 samples", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes, "kernel_avg_us": us,
                "launches_timed": t[keys[0]][1], "traffic": sum(traffic) if all(v is not None for v in traffic) else None,
-               "traffic_source": "profiles/r05_pmc_neus.json (committed PMC passes)" if all(v is not None for v in traffic) else None}
+               "traffic_source": "profiles/r06_pmc_neus.json (committed PMC passes)" if all(v is not None for v in traffic) else None}
+        if keys[0] in ("grid_bin_reduce", "mlp_backward"):
+            ent["bytes_are"] = ("this design's own traffic (record queues read + table written / saved activations + dX), NOT a "
+                                "SURVEY 8(d) figure: the step's fraction on SURVEY's bytes is the `mapper step, whole` entry")
         if loads:
             ent["gather_rate_Ggathers_per_s"] = inb * float(loads) / (us * 1e-6) / 1e9
             if ceil_ and leg:
@@ -865,6 +868,7 @@ def conv_roofline(device, E, ht, wd):
            "frac": tf / MFMA_F16_PEAK_TFLOPS, "algorithmic_flops_per_update": flops_sum,
            "kernel_us_per_update": ms_sum * 1e3, "layers": layers}
     out.update(pmc_traffic("r05_pmc_conv3x3_pp.json"))
+    out["same_box_gemm_comparator"] = "profiles/r06_gemm_comparator.json: hipBLASLt at this layer's own M x N x K 0.31-0.34 of peak, 8192^3 0.50-0.53"
     return out
 
 
@@ -893,6 +897,8 @@ def summary(line):
             "sharded_schedule_rccl_1rank_ms_[32768,4096]": [g(line, "neus_train_sharded_schedule_rccl_1rank", "32768", "ms_per_step"),
                                                              g(line, "neus_train_sharded_schedule_rccl_1rank", "4096", "ms_per_step")],
             "pathM_kernels_[us,frac_hbm,frac_replay]": pm,
+            "mapper_step_frac_hbm_on_survey_bytes_[32768,4096]": [round(e["frac"], 4) for e in line.get("roofline_other", [])
+                                                                 if str(e.get("kernel", "")).startswith("mapper step, whole")],
             "ba_2iter_ms": g(line, "breakdown_ms", "ba_2iter_ms"),
             "mono_window": [g(line, "mono_window", "keyframes_per_s"), g(line, "mono_window", "ba_2iter_ms")],
             "stress_step_ms": g(line, "global_ba_stress", "update_lowmem_step_ms"),
@@ -1206,6 +1212,17 @@ def main():
                 line["neus_train_sharded_schedule_rccl_1rank"] = sharded_schedule_one_rank(device)
             except Exception as exc:
                 line["neus_train_sharded_schedule_rccl_1rank"] = {"error": repr(exc)}
+        # the mapper step as a WHOLE on SURVEY 8(d)'s bytes: render 524 B + train 1036 B (512 gathers + 512 scatter + 12 in) per
+        # sample point + AdamW's 353 MB (12.6 M parameters x 28 B), over the graph-replayed step time of the legs above
+        for leg, rays in (("neus_train", 32768), ("neus_train_weak", 4096)):
+            ms = (line.get(leg) or {}).get("ms_per_step")
+            if world == 1 and ms:
+                nb = (524.0 + 1036.0) * rays * 72 + 353.0e6
+                line["roofline_other"].append(
+                    {"kernel": f"mapper step, whole (sample + forward + loss + backward + bin reduce + clip + AdamW, one hipGraph) @ {rays} rays x 72 samples",
+                     "bound": "hbm", "achieved": nb / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nb, "kernel_avg_us": ms * 1e3,
+                     "note": "SURVEY 8(d): (524 + 1036) B per sample point + 353 MB of optimiser traffic"})
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(2)
             try:        # path M on the host cores (north_star: the render batches "alongside the reference's CPU path")
