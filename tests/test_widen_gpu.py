@@ -118,7 +118,7 @@ class _OracleNatives:
         return False
 
 
-def _run_frontend(dev, n_frames, state_dict=None):
+def _run_frontend(dev, n_frames, state_dict=None, pool_volumes=None):
     from go_slam_amd.depth_video import DepthVideo
     from go_slam_amd.droid_net import DroidNet
     from go_slam_amd.frontend import Frontend
@@ -138,6 +138,8 @@ def _run_frontend(dev, n_frames, state_dict=None):
             setattr(video, name, getattr(video, name).float())
     mf = MotionFilter(net, video, thresh=0.0, device=dev)
     fe = Frontend(net, video, args, cfg)
+    if pool_volumes is not None:
+        fe.graph.pool_volumes = pool_volumes
     intr = torch.tensor([120.0, 120.0, 64.0, 64.0])
     g = torch.Generator().manual_seed(5)
     for t in range(n_frames):
@@ -183,6 +185,31 @@ def test_frontend_trajectory_matches_the_loop_assembled_from_oracle_pieces(built
     # fp16 update operator + fp16 correlation volumes against an fp32 evaluation, fed back through ~50 updates: the
     # bound is set from the measurement recorded in profiles/r03_trajectory_parity.json
     assert rmse_raw < 0.05 * path and rmse_aligned < 0.05 * path and rel_disp < 2e-2, rec
+
+
+def test_frontend_with_the_volume_pool_equals_the_frontend_with_corrblock_copies(built_lib):
+    """Round 6: `FactorGraph` keeps its correlation volumes in `corr.CorrPool` (slots of a capacity buffer; nothing is copied
+    when edges come and go) where the reference -- and `graph.pool_volumes = False` -- concatenates and re-gathers every volume
+    on every edge-set change (src/factor_graph.py:118,150).  Same 16 frames through MotionFilter + Frontend both ways: the same
+    edge lists in the same order (active AND inactive), the same volumes per edge, and trajectories that differ by no more than
+    the BA's own run-to-run noise (its fp64 atomics commute only up to rounding): the pool is a change of storage, not of
+    arithmetic."""
+    from go_slam_amd.corr import CorrBlock, CorrPool
+    net, poses_a, disps_a, fe_a = _run_frontend("cuda:0", 16, pool_volumes=True)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    _, poses_b, disps_b, fe_b = _run_frontend("cuda:0", 16, state_dict=sd, pool_volumes=False)
+    assert isinstance(fe_a.graph.corr, CorrPool) and isinstance(fe_b.graph.corr, CorrBlock)
+    for name in ("ii", "jj", "ii_inac", "jj_inac"):
+        assert torch.equal(getattr(fe_a.graph, name), getattr(fe_b.graph, name)), name
+    assert fe_a.graph.ii.numel() > 0 and fe_a.graph.ii_inac.numel() > 0 and fe_a.count >= 6
+    for l, (a, b) in enumerate(zip(fe_a.graph.corr.corr_pyramid, fe_b.graph.corr.corr_pyramid)):
+        assert a.shape[0] == fe_a.graph.ii.numel()
+        torch.testing.assert_close(a.float().reshape(b.shape), b.float(), rtol=0, atol=2e-3, msg=f"level {l}")   # (features of
+        # keyframes whose poses differ in the last bits are the same tensors: encoders do not depend on the BA)
+    assert poses_a.shape == poses_b.shape
+    torch.testing.assert_close(poses_a, poses_b, rtol=0, atol=2e-4)
+    torch.testing.assert_close(disps_a, disps_b, rtol=0, atol=2e-3)
+    torch.testing.assert_close(fe_a.graph.target, fe_b.graph.target, rtol=0, atol=5e-2)
 
 
 def test_multiview_filter_on_device_matches_golden(built_lib):
