@@ -30,6 +30,7 @@ namespace {
 constexpr float kMinDepth = 0.25f;   // droid_kernels.cu:26
 constexpr float kAlpha = 0.05f;      // droid_kernels.cu:1396
 constexpr int kPrepThreads = 1024;
+constexpr int kAccSplit = 4;         // ba_accum: workgroups that share one depth keyframe's out-edge list (round 6)
 constexpr int kMaxBuf = 4096;        // frames addressable by the prep kernel's LDS tables
 
 struct BaWs {
@@ -47,6 +48,7 @@ struct BaWs {
   float* W;           // [M,HW]
   float* Ei;          // [M,6,HW]
   float* Eij;         // [E,6,HW]
+  float* part;        // [kAccSplit,M,8,HW] per-pixel partial sums (C, w, Ei) of keyframes whose edge list is split
   double* H;          // [6P,6P] lower triangle used
   double* b;          // [6P]
   size_t total;
@@ -70,6 +72,7 @@ BaWs carve(void* base, int E, int P, int M, int nbuf, int hw) {
   w.W = (float*)take((size_t)M * hw * 4);
   w.Ei = (float*)take((size_t)M * 6 * hw * 4);
   w.Eij = (float*)take((size_t)E * 6 * hw * 4);
+  w.part = (float*)take((size_t)kAccSplit * M * 8 * hw * 4);
   const size_t n = (size_t)6 * P;
   w.H = (double*)take((n * n + n) * 8);   // H then b, contiguous so one memset clears both
   w.b = w.H + n * n;
@@ -201,9 +204,20 @@ __global__ __launch_bounds__(256) void ba_accum_kernel(
     int motion_only, int reset_fail, BaWs w) {
   __shared__ float red[4][92];
   // (a call that reuses an earlier call's tables skips ba_prep_kernel, which is where the failure counters are cleared)
-  if (reset_fail && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { w.hdr[2] = 0; w.hdr[3] = 0; }
+  if (reset_fail && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { w.hdr[2] = 0; w.hdr[3] = 0; }
   const int m = blockIdx.y;
   if (m >= w.hdr[0]) return;   // only when n_depth over-states the graph (status word 1)
+  // Round 6: the out-edges of keyframe m are dealt to up to kAccSplit workgroups (edge e_beg + s, e_beg + s + kAccSplit, ...):
+  // the launch is ONE resident round whose length was the longest edge list (32 us at the bench window's <= 6 out-edges,
+  // 86 us in the live frontend, where the window's inactive edges make lists of ~20).  The per-EDGE sums go to the fp64
+  // system as before; the per-PIXEL sums over a keyframe's edges (C, w, Ei) of a split list leave as partials and are
+  // added in split order by ba_accum_finish_kernel (deterministic: no atomics); an unsplit list finishes here.
+  // The launcher splits only graphs whose lists are long on average (edges >= 6 x depth keyframes: the live window with its
+  // inactive edges 62 + 6 us instead of 86, the 200-keyframe graph); at the bench window's 3 edges per keyframe the split
+  // kernel + the finishing launch (24.5 + 5.6 us) only equal the unsplit kernel (32 us), so gridDim.z is 1 there.
+  const int split = blockIdx.z, nsp = gridDim.z;
+  const int nsplit = min(nsp, max(w.row_ptr[m + 1] - w.row_ptr[m], 1));
+  if (split >= nsplit) return;
   const int tid = threadIdx.x;
   const int p = blockIdx.x * 256 + tid;
   const bool active = p < hw;
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(256) void ba_accum_kernel(
   float Ei[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const int e_beg = w.row_ptr[m], e_end = w.row_ptr[m + 1];
-  for (int idx = e_beg; idx < e_end; ++idx) {
+  for (int idx = e_beg + split; idx < e_end; idx += nsp) {
     const int e = w.csr_edge[idx];
     const int jx = (int)jj[e];
     float tij[3], qij[4];
@@ -372,6 +386,14 @@ __global__ __launch_bounds__(256) void ba_accum_kernel(
   }
 
   if (!motion_only && active) {
+    if (nsplit > 1) {          // this workgroup's share of the keyframe's per-pixel sums
+      float* po = w.part + (((size_t)split * gridDim.y + m) * 8) * hw + p;     // (gridDim.y = the M the workspace was carved for)
+      po[0] = Csum;
+      po[(size_t)hw] = wsum;
+#pragma unroll
+      for (int n = 0; n < 6; ++n) po[(size_t)(2 + n) * hw] = Ei[n];
+      return;
+    }
     const size_t o = (size_t)m * hw + p;
     const float sens = disps_sens[(size_t)k * hw + p];
     const float mk = (sens > 0.0f) ? 1.0f : 0.0f;
@@ -384,6 +406,43 @@ __global__ __launch_bounds__(256) void ba_accum_kernel(
 #pragma unroll
       for (int n = 0; n < 6; ++n) eo[(size_t)n * hw] = Ei[n];
     }
+  }
+}
+
+// the per-pixel sums of the keyframes whose edge list ba_accum_kernel split: partials added in split order, then the same
+// depth prior / damping / Q = 1 / C as the unsplit path
+__global__ __launch_bounds__(256) void ba_accum_finish_kernel(const float* __restrict__ disps,
+                                                              const float* __restrict__ disps_sens,
+                                                              const float* __restrict__ eta, int t0, int t1, int hw, int nsp,
+                                                              BaWs w) {
+  const int m = blockIdx.y;
+  if (m >= w.hdr[0]) return;
+  const int nsplit = min(nsp, max(w.row_ptr[m + 1] - w.row_ptr[m], 1));
+  if (nsplit <= 1) return;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= hw) return;
+  float acc[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) acc[n] = 0.0f;
+  for (int s2 = 0; s2 < nsplit; ++s2) {
+    const float* pi_ = w.part + (((size_t)s2 * gridDim.y + m) * 8) * hw + p;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] += pi_[(size_t)n * hw];
+  }
+  const int k = w.kx[m];
+  const size_t o = (size_t)m * hw + p;
+  const float disp = disps[(size_t)k * hw + p];
+  const float sens = disps_sens[(size_t)k * hw + p];
+  const float mk = (sens > 0.0f) ? 1.0f : 0.0f;
+  const float C = acc[0] + mk * kAlpha + (1.0f - mk) * eta[o];
+  const float ww = acc[1] - mk * kAlpha * (disp - sens);
+  w.Q[o] = 1.0f / C;
+  w.W[o] = ww;
+  const int pi = k - t0;
+  if (pi >= 0 && pi < t1 - t0) {
+    float* eo = w.Ei + ((size_t)m * 6) * hw + p;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) eo[(size_t)n * hw] = acc[2 + n];
   }
 }
 
@@ -561,10 +620,16 @@ extern "C" int gs_ba_ex(float* poses, float* disps, const float* intrinsics, con
       gs_set_error("ba: memset failed");
       return GS_ERR_LAUNCH;
     }
-    ba_accum_kernel<<<dim3(chunks, M), 256, 0, st>>>(poses, disps, intrinsics, disps_sens, targets, weights,
-                                                     eta, jj, t0, t1, hw, w, motion_only, (reuse && it == 0) ? 1 : 0, ws);
+    const int nsp = (!motion_only && n_edges >= 6 * M) ? kAccSplit : 1;      // (see ba_accum_kernel)
+    ba_accum_kernel<<<dim3(chunks, M, nsp), 256, 0, st>>>(poses, disps, intrinsics, disps_sens, targets, weights,
+                                                          eta, jj, t0, t1, hw, w, motion_only,
+                                                          (reuse && it == 0) ? 1 : 0, ws);
     GS_CHECK_LAUNCH("ba_accum");
     if (!motion_only) {
+      if (nsp > 1) {
+        ba_accum_finish_kernel<<<dim3(chunks, M), 256, 0, st>>>(disps, disps_sens, eta, t0, t1, hw, nsp, ws);
+        GS_CHECK_LAUNCH("ba_accum_finish");
+      }
       ba_schur_kernel<<<2048, 256, 0, st>>>(M, hw, P, ws);
       GS_CHECK_LAUNCH("ba_schur");
     }

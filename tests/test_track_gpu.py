@@ -270,6 +270,35 @@ def test_ba_one_iteration_matches_oracle(db, O, dev, rgbd):
     torch.testing.assert_close(dg, do, rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("rgbd,motion_only", [(True, False), (False, False), (True, True)])
+def test_ba_with_long_out_edge_lists_takes_the_split_accumulation(db, O, dev, rgbd, motion_only):
+    """The live frontend's BA runs over the window's active AND inactive edges: ~8 out-edges per keyframe, lists of 20.  From
+    6 edges per depth keyframe on, `gs_ba` deals every keyframe's list to 4 workgroups (`ba_accum_kernel`, gridDim.z = 4) and
+    adds the per-pixel partial sums in `ba_accum_finish_kernel`; below, one workgroup per keyframe finishes by itself.  Here:
+    12 keyframes / 110 edges at the ScanNet map size (9.2 edges per keyframe, lists from 2 to 19 long -- unsplit lists,
+    lists shorter than the split count and lists of several rounds in ONE launch) against the fp64-accumulated oracle at
+    SURVEY's tolerance, two Gauss-Newton iterations; motion-only never splits (no per-pixel sums exist)."""
+    prob = _ba_problem(O, 12, 110, "Scan", seed=17, rgbd=rgbd)
+    keep = torch.ones(110, dtype=torch.bool)                 # thin two keyframes' lists to 2 and 1 edges
+    for kf, left in ((3, 2), (5, 1)):
+        idx = torch.nonzero(prob["ii"] == kf).reshape(-1)
+        keep[idx[left:]] = False
+    for k in ("ii", "jj", "target", "weight"):
+        prob[k] = prob[k][keep].contiguous()
+    deg = torch.bincount(prob["ii"], minlength=12)
+    assert prob["ii"].numel() >= 6 * 12 and int(deg.max()) >= 9 and sorted(deg.tolist())[:2] == [1, 2], deg.tolist()
+    ref, (po, do), out, (pg, dg) = _run_ba_pair(db, O, dev, prob, 2, 1e-4, 0.1, motion_only)
+    assert float(ref[0].abs().max()) > 1e-4
+    torch.testing.assert_close(out[0].cpu(), ref[0], rtol=1e-4, atol=2e-6)
+    torch.testing.assert_close(pg, po, rtol=0, atol=1e-5)
+    if motion_only:
+        assert out[1] is None and torch.equal(dg, prob["disps"])
+    else:
+        torch.testing.assert_close(out[1].cpu(), ref[1], rtol=1e-3, atol=1e-5)
+        torch.testing.assert_close(dg, do, rtol=0, atol=1e-5)
+    assert db.ba_status(dev)["cholesky_failures"] == 0
+
+
 def test_ba_two_iterations_frontend_like(db, O, dev):
     prob = _ba_problem(O, 12, 40, "Scan", seed=13)
     ref, (po, do), out, (pg, dg) = _run_ba_pair(db, O, dev, prob, 2, 1e-4, 0.1, False)
