@@ -481,22 +481,39 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(int M, int hw, int P, BaW
 #pragma unroll
     for (int i = 0; i < 36; ++i) S[i] = 0.f;
     float vv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int p = tid; p < hw; p += 256) {
-      const float q = Qm[p];
-      float ea[6], eb_[6];
+    // Four pixels per trip, all 4 x 14 loads requested before the first product (round 6): a pair's 4800 pixels were 19
+    // dependent round trips of one pixel per lane (19.7 us per launch at the bench window, 44 us in the live frontend:
+    // one resident round of workgroups, each as long as ITS pair's latency chain).  Same products in the same order.
+    constexpr int UP = 4;
+    for (int p0 = tid; p0 < hw; p0 += UP * 256) {
+      float q[UP], ea[UP][6], eb_[UP][6], ww[UP];
 #pragma unroll
-      for (int n = 0; n < 6; ++n) {
-        ea[n] = Ea[(size_t)n * hw + p] * q;
-        eb_[n] = Eb[(size_t)n * hw + p];
+      for (int u = 0; u < UP; ++u) {
+        const int p = p0 + 256 * u;
+        const bool ok = p < hw;
+        const int pc = ok ? p : tid;
+        q[u] = Qm[pc];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+          ea[u][n] = Ea[(size_t)n * hw + pc];
+          eb_[u][n] = Eb[(size_t)n * hw + pc];
+        }
+        ww[u] = diag ? Wm[pc] : 0.0f;
       }
 #pragma unroll
-      for (int n = 0; n < 6; ++n)
+      for (int u = 0; u < UP; ++u) {
+        if (p0 + 256 * u < hw) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) S[n * 6 + c] = fmaf(ea[n], eb_[c], S[n * 6 + c]);
-      if (diag) {
-        const float ww = Wm[p];
+          for (int n = 0; n < 6; ++n) ea[u][n] = ea[u][n] * q[u];
 #pragma unroll
-        for (int n = 0; n < 6; ++n) vv[n] = fmaf(ea[n], ww, vv[n]);
+          for (int n = 0; n < 6; ++n)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) S[n * 6 + c] = fmaf(ea[u][n], eb_[u][c], S[n * 6 + c]);
+          if (diag) {
+#pragma unroll
+            for (int n = 0; n < 6; ++n) vv[n] = fmaf(ea[u][n], ww[u], vv[n]);
+          }
+        }
       }
     }
     {
