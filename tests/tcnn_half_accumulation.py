@@ -5,7 +5,8 @@ accumulator fragments in FullyFusedMLP)?  tiny-cuda-nn is absent from /root/refe
 run; this measures the distance between the two restatements on the trained-like grid, per stage and end to end through
 `InstantNeuS.forward`'s restatement, against SURVEY's fp16-level tolerance (rtol 5e-3 / atol 1e-3).  CPU only.
 
-    python tools/tcnn_half_accumulation.py            # -> profiles/r06_tcnn_half_accumulation.json
+    python tests/tcnn_half_accumulation.py            # -> profiles/r06_tcnn_half_accumulation.json
+(lives under tests/: it executes the oracle, which only test infrastructure may do)
 """
 import json
 import os

@@ -407,11 +407,11 @@ def test_half_accumulation_reading_of_tcnn_stays_inside_the_stated_tolerance():
     """tiny-cuda-nn is absent and unpinned; upstream's published types accumulate the 8 grid corners in `vector_t<__half>` and the
     FullyFusedMLP layers in half wmma fragments, the oracle (and the HIP kernels) accumulate in fp32 and round once.  The
     oracle's `accumulate="half"` / `"half_mul_add"` modes restate those; this measures the distance between the readings on the
-    trained-like grid (tools/tcnn_half_accumulation.py -> profiles/r06_tcnn_half_accumulation.json) and requires BOTH to sit
+    trained-like grid (tests/tcnn_half_accumulation.py -> profiles/r06_tcnn_half_accumulation.json) and requires BOTH to sit
     inside SURVEY 8c's fp16-level tolerance (rtol 5e-3 / atol 1e-3) per stage and end to end through InstantNeuS.forward."""
     import importlib.util
     spec = importlib.util.spec_from_file_location(
-        "_tha", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "tcnn_half_accumulation.py"))
+        "_tha", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tcnn_half_accumulation.py"))
     tha = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(tha)
     r = tha.report(n_rays=96)
