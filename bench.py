@@ -159,6 +159,7 @@ def mono_window(device, num_kf=50, num_edges=100, shape="Rep", steps=5, warm=2):
     for _ in range(warm):
         keyframe_step(graph)
     torch.cuda.synchronize()
+    quiesce_gc()
     tic = time.perf_counter()
     for _ in range(steps):
         keyframe_step(graph)
@@ -184,9 +185,20 @@ def mono_window(device, num_kf=50, num_edges=100, shape="Rep", steps=5, warm=2):
             "ba_2iter_ms": ba_ms, "unknowns": 6 * (num_kf - 1), "state_finite": finite}
 
 
+def quiesce_gc():
+    """What main() does once before the headline's timed region, repeated before every other leg's: the objects built so
+    far leave the cyclic collector's reach, so that a full collection (~20 ms on this process's heap) cannot land inside a
+    timed loop of a few milliseconds -- one did, in a 10-step loop of the 4096-ray mapper leg: 2.76 ms per step instead
+    of 0.76.  Garbage created from here on is still collected."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def time_op(fn, iters=10, warm=2):
     for _ in range(warm):
         fn()
+    quiesce_gc()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     s.record()
@@ -379,9 +391,8 @@ def sequence_bench(device, keyframes=40, warm_keyframes=34, frames_per_keyframe=
     edges, kept = [], 0
     import gc
     for k in range(warm_keyframes + keyframes):
-        if k == warm_keyframes and freeze_gc:           # (bench.py's main has done this once already: see there)
-            gc.collect()
-            gc.freeze()
+        if k == warm_keyframes:                         # (see quiesce_gc)
+            quiesce_gc()
         timed = k >= warm_keyframes
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -591,6 +602,7 @@ def neus_train_bench(device, rank, world, steps=10, warm=3, global_rays=32768, s
     for _ in range(warm):
         loss = tr.step(o, d, col, gt, pr)
     sync()
+    quiesce_gc()
     tic = time.perf_counter()
     for _ in range(steps):
         loss = tr.step(o, d, col, gt, pr)
@@ -670,6 +682,7 @@ def cpu_baseline(sample_updates=1):
     target, _ = O.reproject(poses, disps, vid["intrinsics"], ii, jj)
     K = vid["intrinsics"][0].contiguous()
     t0, t1 = 1, NUM_KF
+    quiesce_gc()
     tic = time.perf_counter()
     with torch.no_grad():
         for _ in range(sample_updates):
@@ -707,6 +720,7 @@ def cpu_baseline_neus(n_rays=4096):
     col = torch.rand(n_rays, 3, generator=g)
     pr = torch.rand(24, generator=g)
     with torch.no_grad():
+        quiesce_gc()
         tic = time.perf_counter()
         z, dist = NO.render_sample(o, d, gt, P["bound"], 24, 48, pr)
         NO.neus_forward(o, d, z, dist, P)
@@ -717,6 +731,7 @@ def cpu_baseline_neus(n_rays=4096):
     params = [Pd[k] for k in names] + [Pd["variance"]]
     opt = torch.optim.AdamW([{"params": params[1:], "lr": 1e-3}, {"params": params[:1], "lr": 1e-2}],
                             betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    quiesce_gc()
     tic = time.perf_counter()
     z, dist = NO.render_sample(o, d, gt, P["bound"], 24, 48, pr)
     loss = NA.mapping_loss(NA.neus_forward_diff(o, d, z, dist, Pd), col, gt)
