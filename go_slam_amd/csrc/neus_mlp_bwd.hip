@@ -6,29 +6,44 @@
 //   H1 = relu(W1 X), H2 = relu(W2 H1)                          (recomputed exactly as neus_mlp_kernel does)
 //   dH2 = (W3^T dpre) * [H2 > 0],  dH1 = (W2^T dH2) * [H1 > 0],  dX = W1^T dH1
 //   dW3 += dpre H2^T,  dW2 += dH2 H1^T,  dW1 += dH1 X^T
-// all on v_mfma_f32_32x32x16_f16 with 32 points per wave-block as the N (data GEMMs) or K (weight GEMMs)
-// dimension.  Every operand is needed twice, once [point][neuron] (B operand of the next data GEMM) and
-// once [neuron][point] (A/B operand of a weight GEMM, whose reduction runs over points), so each
-// accumulator tile is written to two wave-private LDS tiles; the 40 KB of pre-packed weight fragments
-// (W1, W2, W3^T, W2^T, W1^T) sit in LDS for the whole launch; the weight-gradient accumulators (192
-// registers) stay in the register file across the wave's blocks and are reduced once per workgroup.
+// all on v_mfma_f32_32x32x16_f16, a wave working on blocks of 32 points: the points are the N dimension of the data
+// GEMMs and the K dimension of the weight GEMMs.
+//
+// Round 6 form (VERDICT r5 item 2 / DESIGN 9.6a asked for this kernel at <= 340 us per 32768-ray step; the round-3 form
+// took 505 us with the matrix pipes 12 % busy: every operand went through LDS twice -- once [point][neuron] as the B
+// operand of the next data GEMM, once [neuron][point] with sixteen 2-byte stores per tile and lane as the operand of a
+// weight GEMM -- and each of the seven GEMM stages waited for the previous one's LDS round trip):
+//   * the DATA path never touches LDS.  An accumulator tile holds, per lane, 16 neurons of ONE point: exactly what the
+//     next data GEMM wants as its B fragment, if its contraction index is enumerated in the accumulator's order.  The
+//     hidden-neuron K index of W2, W2^T and W1^T is therefore PERMUTED in the pre-packed A fragments (k-step ks, half
+//     hf, element e  <->  neuron 32 (ks >> 1) + 8 (2 (ks & 1) + (e >> 2)) + 4 hf + (e & 3); include/goslam_neus.h), and
+//     relu / mask + fp16 rounding of accumulator registers 8 (ks & 1) .. + 7 of tile ks >> 1 IS the B fragment of
+//     k-step ks;
+//   * the WEIGHT GEMMs contract over points, so they need the transpose.  Every tile is stored ONCE, [point][32
+//     channels] with 8-byte stores (the accumulator's natural pieces; the 8-byte slot index is XORed with (point >> 1)
+//     & 7, which makes the stores and the reads below bank-conflict-free), and read back as MFMA operands with gfx950's
+//     transposing LDS read (`ds_read_b64_tr_b16`: a 16-lane group fetches 4 points x 16 channels and every lane gets
+//     ITS channel of the 4 points): 2 reads per 8-point fragment, no 2-byte traffic at all;
+//   * a wave alone on its SIMD (the 192 weight-gradient accumulators) has nothing to hide its dependent chains behind,
+//     so it works on TWO 32-point sub-blocks at a time (NSUB = 2): four independent accumulator chains per data GEMM,
+//     one sub-block's conversions beside the other's MFMAs, and every weight fragment read from LDS serves both.
+// The 40 KB of pre-packed weight fragments (W1, W2, W3^T, W2^T, W1^T) sit in LDS for the whole launch; the weight-gradient
+// accumulators stay in the register file across the wave's blocks and are reduced once per workgroup.
 // Gradients travel in fp16 multiplied by the caller's loss scale (tcnn: 128), as in the reference.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
-constexpr int HS2 = 72;            // [point][neuron] tile stride (halves)
-constexpr int TS = 40;             // [row][point] tile stride (halves): 32 points + pad, 80-byte rows
-constexpr int OFF_HS = 0;          // 32 x 72
-constexpr int OFF_XT = 2304;       // 96 x 40 (rows 80..95 stay zero); doubles as the dX staging tile [32][88]
-constexpr int OFF_TA = OFF_XT + 3840;   // 64 x 40: H1^T, then dH1^T
-constexpr int OFF_TB = OFF_TA + 2560;   // 64 x 40: H2^T, then dH2^T
-constexpr int OFF_DP = OFF_TB + 2560;   // 32 x 40: dpre^T (rows 3..31 stay zero)
-constexpr int WAVE_LDS = OFF_DP + 1280; // 12544 halves = 25088 B per wave
+// per-sub-block LDS (halves): X [2][32][32] + [32][16] (later the [32][80] dX staging tile) | TA [2][32][32]: H1, then
+// dH1 | TB [2][32][32]: H2, then dH2 | DP [32][16]: dpre (channels 3..15 stay zero)
+constexpr int OFF_X = 0, OFF_TA = 2560, OFF_TB = OFF_TA + 2048, OFF_DP = OFF_TB + 2048;
+constexpr int SUB_LDS = OFF_DP + 512;   // 7168 halves = 14336 B
 constexpr int NFRAG = 40;          // W1 (10) | W2 (8) | W3^T (2) | W2^T (8) | W1^T (12), 1 KB each
 constexpr int F_W1 = 0, F_W2 = 10, F_W3T = 18, F_W2T = 20, F_W1T = 28;
 constexpr int NPARAM = 64 * 80 + 64 * 64 + 16 * 64;   // 10240, tcnn's layout
@@ -43,25 +58,66 @@ __device__ __forceinline__ void zero16(float16v& c) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) c[e] = 0.f;
 }
-
-// accumulator tile (rows = neurons 32*mt.., cols = the wave's 32 points) -> fp16 values `f(c, reg)`, stored
-// both as [point][neuron] (8-byte groups) and as [neuron][point] (2-byte, consecutive lanes consecutive)
-template <typename F>
-__device__ __forceinline__ void store_tiles(const float16v& c, int mt, int lane, _Float16* pn, _Float16* np_, F f) {
-  const int pt = lane & 31, hf = lane >> 5;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    half4 pk;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const _Float16 h = f(c[4 * q + k], 4 * q + k);
-      pk[k] = h;
-      if (np_) np_[(32 * mt + 8 * q + 4 * hf + k) * TS + pt] = h;
-    }
-    if (pn) *reinterpret_cast<half4*>(pn + pt * HS2 + 32 * mt + 8 * q + 4 * hf) = pk;
-  }
+// transposing LDS read: the 16 lanes of a group fetch 8 bytes each (lane i: row i >> 2, 4-channel piece i & 3 of a
+// [4 points][16 channels] block); lane c of the group receives channel c of the 4 points
+__device__ __forceinline__ half4 trd(const _Float16* p) {
+  return __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)p));
+}
+__device__ __forceinline__ half8 cat8(half4 lo, half4 hi) {
+  return half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// An accumulator tile (rows = 32 neurons, cols = the 32 points) leaves the fp32 registers as 8 dwords of fp16 PAIRS
+// (registers 2 j, 2 j + 1 = two consecutive neurons of this lane's point), and everything after the rounding is packed
+// 16-bit integer arithmetic on those dwords -- ReLU is a signed max with 0 on the bit patterns (negative floats are
+// negative integers; -0 becomes +0), its derivative a multiplication of the gradient's bits by min(bits of H, 1) -- two
+// values per instruction and no compare / select / mask-bit bookkeeping (the fp32 form cost ~4.5 vector instructions per
+// value).  Dwords 0..3 / 4..7 are the B fragments of the next data GEMM's k-steps 2 mt / 2 mt + 1 (permuted K, see the
+// header); dwords 2 q, 2 q + 1 are the 8-byte piece q of the [point][32 channels] tile.
+typedef short short2v __attribute__((ext_vector_type(2)));
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
+typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+
+typedef _Float16 half16v __attribute__((ext_vector_type(16)));
+typedef uint32_t uint8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void pack_tile(const float16v& c, uint32_t (&h)[8]) {
+  const uint8v u = __builtin_bit_cast(uint8v, __builtin_convertvector(c, half16v));     // v_cvt_pk_f16_f32 per pair
+#pragma unroll
+  for (int j = 0; j < 8; ++j) h[j] = u[j];
+}
+__device__ __forceinline__ void relu_tile(uint32_t (&h)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    h[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(short2v, h[j]), short2v{0, 0}));
+}
+// d * [H > 0] on the bit patterns (H >= +0 after relu_tile: H > 0 <=> bits != 0).  Written as the two instructions it is
+// (from `d * min(H, 1)` the compiler builds two 16-bit compares and two selects per pair).
+__device__ __forceinline__ void mask_tile(uint32_t (&d)[8], const uint32_t (&H)[8]) {
+  const uint32_t ones = 0x00010001u;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    uint32_t step;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(step) : "v"(H[j]), "s"(ones));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(d[j]) : "v"(d[j]), "v"(step));
+  }
+}
+__device__ __forceinline__ half8 bfrag(const uint32_t (&h)[8], int half) {
+  return __builtin_bit_cast(half8, uint4v{h[4 * half], h[4 * half + 1], h[4 * half + 2], h[4 * half + 3]});
+}
+__device__ __forceinline__ void store_tile(const uint32_t (&h)[8], _Float16* blk, const int (&st_off)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2v*>(blk + st_off[q]) = uint2v{h[2 * q], h[2 * q + 1]};
+}
+
+#ifdef MLPB_STAMP
+#define STAMP(i) do { const long long t_now = wall_clock64(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+template <int NSUB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void neus_mlp_bwd_kernel(const _Float16* __restrict__ X, const _Float16* __restrict__ wpack,
                          const float* __restrict__ d_rgb, const _Float16* __restrict__ rgb, float loss_scale,
@@ -69,16 +125,31 @@ void neus_mlp_bwd_kernel(const _Float16* __restrict__ X, const _Float16* __restr
   extern __shared__ __attribute__((aligned(16))) _Float16 sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   _Float16* wl = sm;
-  _Float16* wb = sm + NFRAG * 512 + wave * WAVE_LDS;
-  _Float16 *hs = wb + OFF_HS, *XT = wb + OFF_XT, *TA = wb + OFF_TA, *TB = wb + OFF_TB, *DP = wb + OFF_DP;
+  _Float16* wb = sm + NFRAG * 512 + wave * (NSUB * SUB_LDS);
   for (int i = tid; i < NFRAG * 64; i += 256) reinterpret_cast<half8*>(wl)[i] = reinterpret_cast<const half8*>(wpack)[i];
   {
     const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = lane; i < WAVE_LDS / 8; i += 64) reinterpret_cast<half8*>(wb)[i] = z;
+    for (int i = lane; i < NSUB * SUB_LDS / 8; i += 64) reinterpret_cast<half8*>(wb)[i] = z;
   }
   __syncthreads();
   const int r = lane & 31, hf = lane >> 5, kh = 8 * hf;
   auto A = [&](int frag) { return ld8(wl + ((size_t)frag * 64 + lane) * 8); };
+  // [point][32 channels] tiles: the 8-byte slot s of point p sits at slot s ^ ((p >> 1) & 7)
+  const int swl = ((r >> 1) & 7) << 2;
+  int st_off[4];                                   // this lane's accumulator pieces: channels 8 q + 4 hf .. + 3 of point r
+#pragma unroll
+  for (int q = 0; q < 4; ++q) st_off[q] = r * 32 + (((2 * q + hf) << 2) ^ swl);
+  // transposing reads: group g = lane >> 4 covers channels 16 (g & 1) .. + 15 and points 8 (g >> 1) .. + 7 of a k-step
+  const int i16 = lane & 15, gz = (lane >> 4) & 1;
+  const int trA = (kh + (i16 >> 2)) * 32 + (((4 * gz + (i16 & 3)) ^ (4 * hf + (i16 >> 3))) << 2);
+  const int trB = (kh + 4 + (i16 >> 2)) * 32 + (((4 * gz + (i16 & 3)) ^ (4 * hf + (i16 >> 3) + 2)) << 2);
+  const int t16 = (kh + (i16 >> 2)) * 16 + (i16 & 3) * 4;          // 16-channel tiles (X columns 64.., dpre)
+  const _Float16* zp = wb + OFF_DP + 4;                            // 8 zero bytes (dpre channels 4..7 of point 0)
+  auto frag32 = [&](const _Float16* T, int kst) { return cat8(trd(T + kst * 512 + trA), trd(T + kst * 512 + trB)); };
+  auto frag16 = [&](const _Float16* T, int kst) {  // channels 16..31 of the fragment do not exist: zeros
+    const _Float16* p = T + kst * 256 + t16;
+    return cat8(trd(gz ? zp : p), trd(gz ? zp : p + 64));
+  };
 
   float16v cw1[2][3], cw2[2][2], cw3[2];
 #pragma unroll
@@ -89,168 +160,242 @@ void neus_mlp_bwd_kernel(const _Float16* __restrict__ X, const _Float16* __restr
     for (int b = 0; b < 2; ++b) zero16(cw2[a][b]);
     zero16(cw3[a]);
   }
+  float16v zacc;
+  zero16(zacc);
 
-  // A wave runs its blocks one after the other, alone on its SIMD (the 192 weight-gradient accumulators): nothing
-  // hides a global round trip.  The NEXT block's inputs (X fragments, d_rgb, rgb) are therefore requested at the head
-  // of the current block and consumed one iteration later.
-  half8 xn[5];
-  float drn[3], yn[3];
-  auto request = [&](int blk) {
-    const int pr = blk * 32 + r;
-    const size_t pcn = (size_t)(pr < np ? pr : np - 1);
+  // A wave runs its blocks one after the other, alone on its SIMD: nothing hides a global round trip, so a block's inputs
+  // (X fragments, d_rgb, rgb) are requested one block of 64 points (NSUB = 2) or two blocks of 32 (NSUB = 1: the loop body
+  // exists twice, register set A / set B, which keeps the rotation free of copies) ahead.  Two things made the round-3
+  // form's prefetch synchronous, both found with phase stamps (-DMLPB_STAMP, tools/mlp_bwd_check.py) + the ISA:
+  //   * the registers must hold what the loads return and NOTHING derived from it: `yn = (float)rgb[..]` inside the
+  //     request put a conversion, hence an s_waitcnt vmcnt(0), right behind the loads -- every block paid one full memory
+  //     round trip (1.35 us of its 4.5 us);
+  //   * requests and dX stores must be UNCONDITIONAL (see `request(in, min(..))` and `sink` below): behind a branch the
+  //     compiler cannot count the younger memory operations in flight at the next block's head and waits for all of them,
+  //     i.e. for the stores' write acknowledgements and the other set's fresh request.
+  struct Inputs { half8 x[NSUB][5]; float dr[NSUB][3]; _Float16 y[NSUB][3]; };
+  const _Float16* rgbp = rgb ? rgb : X;           // (rgb == NULL: the values are not used; any readable address)
+  Inputs inA, inB;
+  auto request = [&](Inputs& in, int blk) {
 #pragma unroll
-    for (int ks = 0; ks < 5; ++ks) xn[ks] = ld8(X + pcn * 80 + 16 * ks + kh);
+    for (int sb = 0; sb < NSUB; ++sb) {
+      const int pr = (blk * NSUB + sb) * 32 + r;
+      const size_t pcn = (size_t)(pr < np ? pr : np - 1);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      drn[k] = d_rgb[pcn * 3 + k];
-      yn[k] = rgb ? (float)rgb[pcn * 3 + k] : 0.0f;
+      for (int ks = 0; ks < 5; ++ks) in.x[sb][ks] = ld8(X + pcn * 80 + 16 * ks + kh);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        in.dr[sb][k] = d_rgb[pcn * 3 + k];
+        in.y[sb][k] = rgbp[pcn * 3 + k];
+      }
     }
   };
   const int blk0 = blockIdx.x * 4 + wave, bstride = gridDim.x * 4;
-  if (blk0 < nblk) request(blk0);
-  for (int blk = blk0; blk < nblk; blk += bstride) {
-    const int p0 = blk * 32;
-    const bool valid = p0 + r < np;
-    // ---- X: B fragments from the [point][80] rows, and X^T into its tile
-    half8 xb[5];
-    float dr[3], yv[3];
+  constexpr int DEPTH = NSUB == 1 ? 2 : 1;        // (two sub-blocks x two sets do not fit the register file)
+  request(inA, min(blk0, nblk - 1));
+  if (DEPTH == 2) request(inB, min(blk0 + bstride, nblk - 1));
+#ifdef MLPB_STAMP
+  long long t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = wall_clock64();
+#endif
+  // (16 bytes per lane of this workgroup's slab of `partial`, which the epilogue overwrites: where stores of rows >= np go)
+  _Float16* sink = reinterpret_cast<_Float16*>(partial + (size_t)blockIdx.x * NPARAM) + tid * 8;
+  auto body = [&](Inputs& in, const int blk) {
+    half8 (&xb)[NSUB][5] = in.x;
+    // ---- X into its [point][channel] tile (operand of dW1)
 #pragma unroll
-    for (int ks = 0; ks < 5; ++ks) xb[ks] = xn[ks];
+    for (int sb = 0; sb < NSUB; ++sb) {
+      _Float16* XT = wb + sb * SUB_LDS + OFF_X;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { dr[k] = drn[k]; yv[k] = yn[k]; }
-    if (blk + bstride < nblk) request(blk + bstride);
-#pragma unroll
-    for (int ks = 0; ks < 5; ++ks) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) XT[(16 * ks + kh + e) * TS + r] = xb[ks][e];
+      for (int ks = 0; ks < 4; ++ks) {
+        const int s = 4 * (ks & 1) + 2 * hf;       // features 16 ks + 8 hf .. + 7 = slots s, s + 1 of block ks >> 1
+        _Float16* B = XT + (ks >> 1) * 1024 + r * 32;
+        const half8 v = xb[sb][ks];
+        *reinterpret_cast<half4*>(B + ((s << 2) ^ swl)) = half4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<half4*>(B + (((s + 1) << 2) ^ swl)) = half4{v[4], v[5], v[6], v[7]};
+      }
+      *reinterpret_cast<half8*>(XT + 2048 + r * 16 + kh) = xb[sb][4];
     }
-    // ---- layer 1 (recompute), H1 -> hs [pt][n] and TA [n][pt]
-    unsigned m1 = 0, m2 = 0;                       // ReLU masks, bit 16*mt + reg
-    {
-      float16v c[2];
-      zero16(c[0]); zero16(c[1]);
+    // ---- dpre = d_rgb * y (1 - y) * loss_scale (sigmoid'), as the B fragment of W3^T dpre and as [point][channel] rows
+    half8 bdp[NSUB];
 #pragma unroll
-      for (int ks = 0; ks < 5; ++ks)
+    for (int sb = 0; sb < NSUB; ++sb) {
+      const bool valid = (blk * NSUB + sb) * 32 + r < np;
+      bdp[sb] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (hf == 0) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) c[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A(F_W1 + mt * 5 + ks), xb[ks], c[mt], 0, 0, 0);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        store_tiles(c[mt], mt, lane, hs, TA, [&](float v, int reg) {
-          if (v > 0.0f) m1 |= 1u << (16 * mt + reg);
-          return (_Float16)fmaxf(v, 0.0f);
-        });
-    }
-    wsync();
-    // ---- layer 2 (recompute), H2 -> TB [n][pt]
-    {
-      half8 b[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) b[ks] = ld8(hs + r * HS2 + 16 * ks + kh);
-      float16v c[2];
-      zero16(c[0]); zero16(c[1]);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) c[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A(F_W2 + mt * 4 + ks), b[ks], c[mt], 0, 0, 0);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        store_tiles(c[mt], mt, lane, (_Float16*)nullptr, TB, [&](float v, int reg) {
-          if (v > 0.0f) m2 |= 1u << (16 * mt + reg);
-          return (_Float16)fmaxf(v, 0.0f);
-        });
-    }
-    // ---- dpre = d_rgb * y (1 - y) * loss_scale (sigmoid'), as the B fragment of W3^T dpre and as dpre^T rows
-    half8 bdp = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hf == 0) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float y = yv[k];
-        const float dact = rgb ? y * (1.0f - y) : 1.0f;     // rgb == NULL: d_rgb is w.r.t. the raw outputs
-        const float v = valid ? dr[k] * dact * loss_scale : 0.0f;
-        bdp[k] = (_Float16)v;
-        DP[k * TS + r] = bdp[k];
+        for (int k = 0; k < 3; ++k) {
+          const float y = (float)in.y[sb][k];
+          const float dact = rgb ? y * (1.0f - y) : 1.0f;     // rgb == NULL: d_rgb is w.r.t. the raw outputs
+          const float v = valid ? in.dr[sb][k] * dact * loss_scale : 0.0f;
+          bdp[sb][k] = (_Float16)v;
+        }
+        *reinterpret_cast<half4*>(wb + sb * SUB_LDS + OFF_DP + r * 16) = half4{bdp[sb][0], bdp[sb][1], bdp[sb][2], (_Float16)0.0f};
       }
     }
-    wsync();
-    // ---- dW3 += dpre^T-rows x H2  (K = the 32 points)
+    STAMP(0);
+    // ---- layer 1 (recompute): H1 -> B fragments of layer 2 (registers) and TA
+    uint32_t h1[NSUB][2][8], h2[NSUB][2][8];       // H1 / H2 of this lane's point, packed (kept for the ReLU derivatives)
+    {
+      float16v c[NSUB][2];
 #pragma unroll
-    for (int kst = 0; kst < 2; ++kst) {
-      const half8 a = ld8(DP + r * TS + 16 * kst + kh);
+      for (int sb = 0; sb < NSUB; ++sb) { c[sb][0] = zacc; c[sb][1] = zacc; }
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-        cw3[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ld8(TB + (32 * nt + r) * TS + 16 * kst + kh), cw3[nt], 0, 0, 0);
+      for (int ks = 0; ks < 5; ++ks) {
+        const half8 a0 = A(F_W1 + ks), a1 = A(F_W1 + 5 + ks);
+#pragma unroll
+        for (int sb = 0; sb < NSUB; ++sb) {
+          c[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xb[sb][ks], c[sb][0], 0, 0, 0);
+          c[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xb[sb][ks], c[sb][1], 0, 0, 0);
+        }
+      }
+      // this set's registers are free again (past the end: the last block once more, never consumed)
+      request(in, min(blk + DEPTH * bstride, nblk - 1));
+#pragma unroll
+      for (int sb = 0; sb < NSUB; ++sb)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          pack_tile(c[sb][mt], h1[sb][mt]);
+          relu_tile(h1[sb][mt]);
+          store_tile(h1[sb][mt], wb + sb * SUB_LDS + OFF_TA + mt * 1024, st_off);
+        }
     }
-    // ---- dH2 = (W3^T dpre) * [H2 > 0]
-    float16v cd[2];
+    STAMP(1);
+    // ---- layer 2 (recompute): H2 -> TB
+    {
+      float16v c[NSUB][2];
+#pragma unroll
+      for (int sb = 0; sb < NSUB; ++sb) { c[sb][0] = zacc; c[sb][1] = zacc; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const half8 a0 = A(F_W2 + ks), a1 = A(F_W2 + 4 + ks);
+#pragma unroll
+        for (int sb = 0; sb < NSUB; ++sb) {
+          const half8 b = bfrag(h1[sb][ks >> 1], ks & 1);
+          c[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b, c[sb][0], 0, 0, 0);
+          c[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b, c[sb][1], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int sb = 0; sb < NSUB; ++sb)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          pack_tile(c[sb][mt], h2[sb][mt]);
+          relu_tile(h2[sb][mt]);
+          store_tile(h2[sb][mt], wb + sb * SUB_LDS + OFF_TB + mt * 1024, st_off);
+        }
+    }
+    STAMP(2);
+    // ---- dH2 (pre-mask) = W3^T dpre
+    float16v cd[NSUB][2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      zero16(cd[mt]);
-      cd[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A(F_W3T + mt), bdp, cd[mt], 0, 0, 0);
+      const half8 a = A(F_W3T + mt);
+#pragma unroll
+      for (int sb = 0; sb < NSUB; ++sb) cd[sb][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bdp[sb], zacc, 0, 0, 0);
     }
-    wsync();                                       // dW3 has read H2^T: TB may be overwritten
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-      store_tiles(cd[mt], mt, lane, hs, TB, [&](float v, int reg) {
-        return (_Float16)(((m2 >> (16 * mt + reg)) & 1u) ? v : 0.0f);
-      });
     wsync();
-    // ---- dW2 += dH2 x H1^T-rows
+    // ---- dW3 += dpre^T x H2   (K = the 32 points of each sub-block)
 #pragma unroll
-    for (int kst = 0; kst < 2; ++kst) {
-      half8 bh[2];
+    for (int sb = 0; sb < NSUB; ++sb)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) bh[nt] = ld8(TA + (32 * nt + r) * TS + 16 * kst + kh);
+      for (int kst = 0; kst < 2; ++kst) {
+        const half8 a = frag16(wb + sb * SUB_LDS + OFF_DP, kst);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          cw3[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, frag32(wb + sb * SUB_LDS + OFF_TB + nt * 1024, kst), cw3[nt], 0, 0, 0);
+      }
+    wsync();                                       // dW3 has read H2: TB may be overwritten
+    STAMP(2);
+    STAMP(3);
+    // ---- dH2 = (W3^T dpre) * [H2 > 0] -> B fragments of the next GEMM and TB
+    uint32_t dh[NSUB][2][8];
+#pragma unroll
+    for (int sb = 0; sb < NSUB; ++sb)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        const half8 a = ld8(TB + (32 * mt + r) * TS + 16 * kst + kh);
+        pack_tile(cd[sb][mt], dh[sb][mt]);
+        mask_tile(dh[sb][mt], h2[sb][mt]);
+        store_tile(dh[sb][mt], wb + sb * SUB_LDS + OFF_TB + mt * 1024, st_off);
+      }
+    // ---- dH1 (pre-mask) = W2^T dH2
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) cw2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh[nt], cw2[mt][nt], 0, 0, 0);
+    for (int sb = 0; sb < NSUB; ++sb) { cd[sb][0] = zacc; cd[sb][1] = zacc; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const half8 a0 = A(F_W2T + ks), a1 = A(F_W2T + 4 + ks);
+#pragma unroll
+      for (int sb = 0; sb < NSUB; ++sb) {
+        const half8 b = bfrag(dh[sb][ks >> 1], ks & 1);
+        cd[sb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b, cd[sb][0], 0, 0, 0);
+        cd[sb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b, cd[sb][1], 0, 0, 0);
       }
     }
-    // ---- dH1 = (W2^T dH2) * [H1 > 0]
-    {
-      half8 b[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) b[ks] = ld8(hs + r * HS2 + 16 * ks + kh);
-      zero16(cd[0]); zero16(cd[1]);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) cd[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A(F_W2T + mt * 4 + ks), b[ks], cd[mt], 0, 0, 0);
-    }
-    wsync();                                       // dW2 has read H1^T, dH1 has read hs
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-      store_tiles(cd[mt], mt, lane, hs, TA, [&](float v, int reg) {
-        return (_Float16)(((m1 >> (16 * mt + reg)) & 1u) ? v : 0.0f);
-      });
     wsync();
-    // ---- dW1 += dH1 x X^T-rows
+    STAMP(4);
+    // ---- dW2 += dH2^T x H1
 #pragma unroll
-    for (int kst = 0; kst < 2; ++kst) {
-      half8 bx[3];
+    for (int sb = 0; sb < NSUB; ++sb)
 #pragma unroll
-      for (int nt = 0; nt < 3; ++nt) bx[nt] = ld8(XT + (32 * nt + r) * TS + 16 * kst + kh);
+      for (int kst = 0; kst < 2; ++kst) {
+        half8 bf[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bf[nt] = frag32(wb + sb * SUB_LDS + OFF_TA + nt * 1024, kst);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const half8 a = frag32(wb + sb * SUB_LDS + OFF_TB + mt * 1024, kst);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) cw2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[nt], cw2[mt][nt], 0, 0, 0);
+        }
+      }
+    wsync();                                       // dW2 has read H1: TA may be overwritten
+    STAMP(5);
+    // ---- dH1 = (W2^T dH2) * [H1 > 0] -> B fragments of the dX GEMM and TA
+#pragma unroll
+    for (int sb = 0; sb < NSUB; ++sb)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        const half8 a = ld8(TA + (32 * mt + r) * TS + 16 * kst + kh);
-#pragma unroll
-        for (int nt = 0; nt < 3; ++nt) cw1[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bx[nt], cw1[mt][nt], 0, 0, 0);
+        pack_tile(cd[sb][mt], dh[sb][mt]);
+        mask_tile(dh[sb][mt], h1[sb][mt]);
+        store_tile(dh[sb][mt], wb + sb * SUB_LDS + OFF_TA + mt * 1024, st_off);
       }
-    }
     // ---- dX = W1^T dH1  (rows = the 80 input features)
-    {
-      half8 b[4];
+    float16v cx[NSUB][3];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) b[ks] = ld8(hs + r * HS2 + 16 * ks + kh);
-      float16v cx[3];
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int sb = 0; sb < NSUB; ++sb) cx[sb][mt] = zacc;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)                 // (k-step outermost: three independent accumulator chains per sub-block)
 #pragma unroll
       for (int mt = 0; mt < 3; ++mt) {
-        zero16(cx[mt]);
+        const half8 a = A(F_W1T + mt * 4 + ks);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) cx[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A(F_W1T + mt * 4 + ks), b[ks], cx[mt], 0, 0, 0);
+        for (int sb = 0; sb < NSUB; ++sb)
+          cx[sb][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfrag(dh[sb][ks >> 1], ks & 1), cx[sb][mt], 0, 0, 0);
       }
-      wsync();                                     // dW1 has read X^T: its tile becomes the [32][88] staging tile
+    wsync();
+    STAMP(6);
+    // ---- dW1 += dH1^T x X
+#pragma unroll
+    for (int sb = 0; sb < NSUB; ++sb)
+#pragma unroll
+      for (int kst = 0; kst < 2; ++kst) {
+        half8 bx[3];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bx[nt] = frag32(wb + sb * SUB_LDS + OFF_X + nt * 1024, kst);
+        bx[2] = frag16(wb + sb * SUB_LDS + OFF_X + 2048, kst);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const half8 a = frag32(wb + sb * SUB_LDS + OFF_TA + mt * 1024, kst);
+#pragma unroll
+          for (int nt = 0; nt < 3; ++nt) cw1[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bx[nt], cw1[mt][nt], 0, 0, 0);
+        }
+      }
+    wsync();                                       // dW1 has read X: its tile becomes the [32][80] dX staging tile
+    STAMP(7);
+#pragma unroll
+    for (int sb = 0; sb < NSUB; ++sb) {
+      _Float16* XT = wb + sb * SUB_LDS + OFF_X;
 #pragma unroll
       for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
@@ -259,66 +404,100 @@ void neus_mlp_bwd_kernel(const _Float16* __restrict__ X, const _Float16* __restr
           if (f < 80) {
             half4 pk;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pk[k] = (_Float16)cx[mt][4 * q + k];
-            *reinterpret_cast<half4*>(XT + r * 88 + f) = pk;
+            for (int k = 0; k < 4; ++k) pk[k] = (_Float16)cx[sb][mt][4 * q + k];
+            *reinterpret_cast<half4*>(XT + r * 80 + f) = pk;
           }
         }
     }
     wsync();
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {               // 32 points x 10 pieces of 16 bytes, contiguous in dX
-      const int idx = it * 64 + lane;
-      const int pp = idx / 10, part = idx - pp * 10;
-      if (p0 + pp < np) *reinterpret_cast<half8*>(dX + (size_t)(p0 + pp) * 80 + 8 * part) = ld8(XT + pp * 88 + 8 * part);
-    }
-    wsync();
-    {                                              // rows 70.4+ of the staging tile overlap nothing that must stay
-      // zero, but the staging area [0, 2816) covered X^T rows 0..70: they are rewritten next block; rows 80..95
-      // (offset 3200..3839) were never touched and are still zero.
-    }
-  }
-
-  // ---- reduce the weight-gradient accumulators over the workgroup's waves, write this workgroup's partial.
-  // The four waves add their 192 accumulators into the LDS image one after the other with plain read-modify-writes
-  // (inside a wave every (register, lane) pair owns its own address): float LDS atomics retire 0.33 lanes per clock on
-  // this part -- 49 152 of them were 62 us, half of the kernel at 4096 rays -- and their order was not reproducible.
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(sm + NFRAG * 512);
-  for (int i = tid; i < NPARAM; i += 256) red[i] = 0.0f;
-  __syncthreads();
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
+    for (int sb = 0; sb < NSUB; ++sb) {
+      const _Float16* XT = wb + sb * SUB_LDS + OFF_X;
+      const int p0 = (blk * NSUB + sb) * 32;
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hf;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-          for (int nt = 0; nt < 3; ++nt) {
-            const int f = 32 * nt + r;
-            if (f < 80) red[(32 * mt + row) * 80 + f] += cw1[mt][nt][reg];
-          }
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) red[5120 + (32 * mt + row) * 64 + 32 * nt + r] += cw2[mt][nt][reg];
-        }
-        if (row < 16) {
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) red[9216 + row * 64 + 32 * nt + r] += cw3[nt][reg];
-        }
+      for (int it = 0; it < 5; ++it) {             // 32 points x 10 pieces of 16 bytes, contiguous in dX and in the tile
+        const int idx = it * 64 + lane;
+        const int pp = idx / 10;
+        _Float16* dst = dX + (size_t)p0 * 80 + 8 * idx;
+        if (p0 + pp >= np) dst = sink;               // rows past the end: into this lane's 16 bytes of the sink
+        *reinterpret_cast<half8*>(dst) = ld8(XT + 8 * idx);
       }
     }
-    __syncthreads();
+    wsync();
+    STAMP(8);
+  };
+  if constexpr (DEPTH == 2) {
+    int blk = blk0;
+    for (; blk + bstride < nblk; blk += 2 * bstride) {      // (both bodies unconditional: straight-line memory traffic)
+      body(inA, blk);
+      body(inB, blk + bstride);
+    }
+    if (blk < nblk) body(inA, blk);
+  } else {
+    for (int blk = blk0; blk < nblk; blk += bstride) body(inA, blk);
   }
+
+  // ---- reduce the weight-gradient accumulators over the workgroup's four waves, write this workgroup's partial.
+  // Two rounds of 96 accumulators (dW1; dW2 | dW3): every wave parks its registers in its own 24 KB slab of LDS (the
+  // weight fragments and tiles are dead by now) with conflict-free dword stores, then all 256 threads add the four slabs
+  // in a fixed order and write tcnn's parameter layout in 128-byte runs.  (Round 3's form -- the waves adding into one
+  // image one after the other, 192 read-modify-writes each behind a barrier -- took 20 us per launch: a third of the
+  // kernel at 4096 rays.  Float LDS atomics are slower still, 0.33 lanes per clock, and not reproducible.)
+  float* slab = reinterpret_cast<float*>(sm);
   float* out = partial + (size_t)blockIdx.x * NPARAM;
-  for (int i = tid; i < NPARAM; i += 256) out[i] = red[i];
+  auto park = [&](int t, const float16v& c) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) slab[(wave * 96 + t * 16 + reg) * 64 + lane] = c[reg];
+  };
+  auto summed = [&](int idx) {
+    return (slab[idx] + slab[96 * 64 + idx]) + (slab[2 * 96 * 64 + idx] + slab[3 * 96 * 64 + idx]);
+  };
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) park(mt * 3 + nt, cw1[mt][nt]);
+  __syncthreads();
+  for (int idx = tid; idx < 96 * 64; idx += 256) {
+    const int t = idx >> 10, reg = (idx >> 6) & 15, l = idx & 63;
+    const int mt = t / 3, nt = t - 3 * mt;
+    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5), f = 32 * nt + (l & 31);
+    if (f < 80) out[(32 * mt + row) * 80 + f] = summed(idx);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) park(mt * 2 + nt, cw2[mt][nt]);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) park(4 + nt, cw3[nt]);
+  __syncthreads();
+  for (int idx = tid; idx < 96 * 64; idx += 256) {
+    const int t = idx >> 10, reg = (idx >> 6) & 15, l = idx & 63;
+    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5), col = l & 31;
+    if (t < 4) out[5120 + (32 * (t >> 1) + row) * 64 + 32 * (t & 1) + col] = summed(idx);
+    else if (row < 16) out[9216 + row * 64 + 32 * (t - 4) + col] = summed(idx);
+  }
+#ifdef MLPB_STAMP
+  __syncthreads();
+  if (tid == 0) { STAMP(9); for (int q = 0; q < 10; ++q) out[q] = (float)t_acc[q]; }
+#endif
+}
+
+// points per wave and loop iteration: two 32-point sub-blocks once every wave of the chip has at least two iterations
+// of them; below that (and in tools' A/B runs: GS_MLP_BWD_NSUB = 1 / 2) single sub-blocks quantise better
+int mlp_bwd_nsub(int n) {
+  static const int forced = [] { const char* e = getenv("GS_MLP_BWD_NSUB"); return e ? atoi(e) : 0; }();
+  if (forced == 1 || forced == 2) return forced;
+  return n >= 2 * 64 * 1024 ? 2 : 1;
 }
 
 }  // namespace
 
 extern "C" int gs_mlp_backward_blocks(int n) {
   if (n <= 0) return 0;
-  const int nblk = (n + 31) / 32;
-  const int want = 256;                            // one persistent workgroup per CU (140 KB of LDS each)
+  const int nblk = (n + 32 * mlp_bwd_nsub(n) - 1) / (32 * mlp_bwd_nsub(n));
+  const int want = 256;                            // one persistent workgroup per CU (152 KB of LDS each)
   return nblk < 4 * want ? (nblk + 3) / 4 : want;
 }
 
@@ -327,15 +506,24 @@ extern "C" int gs_mlp_backward(const void* x, const void* wpack, const float* d_
   GS_REQUIRE(x && wpack && d_rgb && dx && partial, "mlp_backward: null pointer");
   GS_REQUIRE(n >= 0 && loss_scale > 0.0f, "mlp_backward: bad arguments");
   if (n == 0) return GS_OK;
-  const int nblk = (n + 31) / 32;
+  const int nsub = mlp_bwd_nsub(n);
+  const int nblk = (n + 32 * nsub - 1) / (32 * nsub);
   const int grid = gs_mlp_backward_blocks(n);
-  const size_t lds = (size_t)(NFRAG * 512 + 4 * WAVE_LDS) * sizeof(_Float16);
-  static GsLdsLimit limit;
-  if (int rc = limit.raise((const void*)neus_mlp_bwd_kernel, lds, "mlp_backward")) return rc;
+  const size_t lds = (size_t)(NFRAG * 512 + 4 * nsub * SUB_LDS) * sizeof(_Float16);
   GS_TIMING_PRE();
-  neus_mlp_bwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const _Float16*)x, (const _Float16*)wpack, d_rgb,
-                                                              (const _Float16*)rgb, loss_scale, (_Float16*)dx, partial,
-                                                              n, nblk);
+  if (nsub == 2) {
+    static GsLdsLimit limit;
+    if (int rc = limit.raise((const void*)neus_mlp_bwd_kernel<2>, lds, "mlp_backward")) return rc;
+    neus_mlp_bwd_kernel<2><<<grid, 256, lds, (hipStream_t)stream>>>((const _Float16*)x, (const _Float16*)wpack, d_rgb,
+                                                                   (const _Float16*)rgb, loss_scale, (_Float16*)dx, partial,
+                                                                   n, nblk);
+  } else {
+    static GsLdsLimit limit;
+    if (int rc = limit.raise((const void*)neus_mlp_bwd_kernel<1>, lds, "mlp_backward")) return rc;
+    neus_mlp_bwd_kernel<1><<<grid, 256, lds, (hipStream_t)stream>>>((const _Float16*)x, (const _Float16*)wpack, d_rgb,
+                                                                   (const _Float16*)rgb, loss_scale, (_Float16*)dx, partial,
+                                                                   n, nblk);
+  }
   GS_CHECK_LAUNCH("mlp_backward");
   return GS_OK;
 }

@@ -224,11 +224,17 @@ def _mlp_fragment_index(device):
         for mt in range(n_mt):
             for ks in range(n_ks):
                 frags.append(fn(32 * mt + r + 0 * kk, 16 * ks + kk + 0 * r))
+    # the contraction index over HIDDEN neurons is enumerated in the order an MFMA accumulator tile holds them (the
+    # kernel feeds one GEMM's accumulators to the next as its B fragments): position 16 ks + 8 hf + e <-> neuron
+    # 32 (ks >> 1) + 8 (2 (ks & 1) + (e >> 2)) + 4 hf + (e & 3)
+    pos = np.arange(64)
+    ks_, hf_, e_ = pos >> 4, (pos >> 3) & 1, pos & 7
+    hid = 32 * (ks_ >> 1) + 8 * (2 * (ks_ & 1) + (e_ >> 2)) + 4 * hf_ + (e_ & 3)
     add(2, 5, lambda row, k: row * 80 + k)                                     # W1
-    add(2, 4, lambda row, k: 5120 + row * 64 + k)                               # W2
+    add(2, 4, lambda row, k: 5120 + row * 64 + hid[k])                          # W2 (K = H1 neurons, permuted)
     add(2, 1, lambda row, k: 9216 + k * 64 + row)                               # W3^T
-    add(2, 4, lambda row, k: 5120 + k * 64 + row)                               # W2^T
-    add(3, 4, lambda row, k: np.where(row < 80, k * 80 + row, ZERO))            # W1^T, rows padded to 96
+    add(2, 4, lambda row, k: 5120 + hid[k] * 64 + row)                          # W2^T (K = dH2 neurons, permuted)
+    add(3, 4, lambda row, k: np.where(row < 80, hid[k] * 80 + row, ZERO))       # W1^T (K = dH1 neurons), rows padded to 96
     idx = torch.from_numpy(np.stack(frags).astype(np.int64).reshape(-1)).to(device)
     assert idx.numel() == 40 * 64 * 8
     _FRAG_INDEX[device] = idx

@@ -125,9 +125,12 @@ int gs_neus_backward_rays(const float* alpha, const void* rgb, const float* z_mi
  *   x f16 [n,80] (the saved MLP input rows), d_rgb f32 [n,3] (gradient w.r.t. the sigmoid outputs), rgb f16
  *   [n,3] (the saved outputs; NULL = no output activation, d_rgb is the gradient w.r.t. the raw network outputs,
  *   which is tcnn.Network's own contract: `output_activation: none`, src/InstantNeuS.py:184-192), loss_scale (tcnn: 128) multiplies every gradient that travels in fp16.
- *   wpack f16 [40][64][8]: MFMA A-fragments A[l][e] = M[32 mt + (l&31)][16 ks + 8 (l>>5) + e] of, in this
+ *   wpack f16 [40][64][8]: MFMA A-fragments A[l][e] = M[32 mt + (l&31)][k(ks, l>>5, e)] of, in this
  *   order, M = W1 (mt<2, ks<5), W2 (mt<2, ks<4), W3^T (mt<2, ks=0), W2^T (mt<2, ks<4), W1^T zero-padded to 96
- *   rows (mt<3, ks<4), each block mt-major.
+ *   rows (mt<3, ks<4), each block mt-major.  k(ks, hf, e) = 16 ks + 8 hf + e where the contraction runs over inputs /
+ *   outputs (W1, W3^T); where it runs over HIDDEN neurons (W2, W2^T, W1^T) it is the order in which an accumulator
+ *   tile of the previous GEMM holds them: k = 32 (ks >> 1) + 8 (2 (ks & 1) + (e >> 2)) + 4 hf + (e & 3) -- the kernel
+ *   feeds one GEMM's accumulator registers to the next as its B fragments (gs_map_step_prep gathers this layout).
  * Outputs: dx f16 [n,80] = loss_scale * dL/dx;  partial f32 [gs_mlp_backward_blocks(n)][10240]: per-workgroup
  *   partial sums of loss_scale * (dW1 [64,80] | dW2 [64,64] | dW3 [16,64]) in tcnn's parameter layout -- sum
  *   over the first axis and divide by loss_scale.                                                        */

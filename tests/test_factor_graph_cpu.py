@@ -117,18 +117,25 @@ def test_mfma_fragment_packers_match_their_documented_layouts():
             col = l & 31
             want = Wh[col % O, 16 * ks + 8 * (l >> 5) + e, (col // O) // 3, (col // O) % 3] if col < 9 * O else 0.0
             assert P[ks, l, e] == want, (O, ks, l, e)
-    # colour-MLP backward: 40 fragments of W1 | W2 | W3^T | W2^T | W1^T (padded to 96 rows)
+    # colour-MLP backward: 40 fragments of W1 | W2 | W3^T | W2^T | W1^T (padded to 96 rows).  Where the contraction runs
+    # over HIDDEN neurons (W2, W2^T, W1^T) position 16 ks + 8 hf + e stands for neuron hid(ks, hf, e): the order in which
+    # an MFMA accumulator tile holds the previous layer's outputs (include/goslam_neus.h)
+    def hid(ks, hf, e):
+        return 32 * (ks >> 1) + 8 * (2 * (ks & 1) + (e >> 2)) + 4 * hf + (e & 3)
+    assert sorted(hid(ks, hf, e) for ks in range(4) for hf in range(2) for e in range(8)) == list(range(64))
     Wv = torch.randn(10240, generator=g)
     P = _pack_mlp_fragments(Wv)
     W1, W2, W3 = Wv[:5120].view(64, 80), Wv[5120:9216].view(64, 64), Wv[9216:].view(16, 64)
-    mats = [(0, W1, 5), (10, W2, 4), (18, W3.t(), 1), (20, W2.t(), 4)]
-    for base, M, nks in mats:
-        for mt, ks, l, e in [(0, 0, 0, 0), (1, nks - 1, 63, 7), (1, 0, 33, 2)]:
-            assert P[base + mt * nks + ks, l, e] == M[32 * mt + (l & 31), 16 * ks + 8 * (l >> 5) + e]
+    cases = [(0, 0, 0, 0), (1, -1, 63, 7), (1, 0, 33, 2), (0, 1, 47, 5)]
+    for base, M, nks, permuted in [(0, W1, 5, False), (10, W2, 4, True), (18, W3.t(), 1, False), (20, W2.t(), 4, True)]:
+        for mt, ks, l, e in cases:
+            ks = ks % nks
+            k = hid(ks, l >> 5, e) if permuted else 16 * ks + 8 * (l >> 5) + e
+            assert P[base + mt * nks + ks, l, e] == M[32 * mt + (l & 31), k]
     W1T = torch.zeros(96, 64)
     W1T[:80] = W1.t()
-    for mt, ks, l, e in [(0, 0, 0, 0), (2, 3, 63, 7), (2, 1, 15, 3), (2, 2, 16, 0)]:
-        assert P[28 + mt * 4 + ks, l, e] == W1T[32 * mt + (l & 31), 16 * ks + 8 * (l >> 5) + e]
+    for mt, ks, l, e in [(0, 0, 0, 0), (2, 3, 63, 7), (2, 1, 15, 3), (2, 2, 16, 0), (1, 1, 40, 6)]:
+        assert P[28 + mt * 4 + ks, l, e] == W1T[32 * mt + (l & 31), hid(ks, l >> 5, e)]
 
 
 class _FakeCorr:
