@@ -11,7 +11,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libgoslam_hip.so")
+# (GOSLAM_HIP_LIB: another build of the same ABI, e.g. the previous kernel for a same-box A/B in tools/)
+LIB_PATH = os.environ.get("GOSLAM_HIP_LIB") or os.path.join(CSRC, "libgoslam_hip.so")
 
 _lib = None
 

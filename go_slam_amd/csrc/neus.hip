@@ -603,33 +603,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       out[o] = acc;
     }
     float gview[3] = {0.f, 0.f, 0.f};
+    // levels gathered here: all of them, or the dense ones in front of the level-major records
+    const int l_rec = rec ? first_hashed : GS_GRID_LEVELS;
   #pragma unroll 1
-    for (int l = 0; l < GS_GRID_LEVELS; ++l) {
+    for (int l = 0; l < l_rec; ++l) {
       const float* wl = A.sdf_w + 3 + 2 * l;
-      float e0, e1;
-      if (rec && l >= first_hashed) {     // (uniform) encoded level-major: one coalesced 16-byte load per point
-        const u32x4 r = __builtin_nontemporal_load(rec + (size_t)(l - first_hashed) * (size_t)np + idx);
-        e0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(r.x & 0xffffu));
-        e1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(r.x >> 16));
-        gview[0] += __uint_as_float(r.y); gview[1] += __uint_as_float(r.z); gview[2] += __uint_as_float(r.w);
-      } else {
-        float val[2], dv[3][2];
-        grid_level(m, l, A.grid, view, val, dv, true);
-        e0 = (float)(_Float16)val[0]; e1 = (float)(_Float16)val[1];             // encoding output is fp16
-        if (enc_aux) {  // training: what the backward needs of this level's 8 corner values -- the encoding and d enc / d x --
-                        // as one 16-byte record [level][point][8], so that it streams them instead of gathering again
-          half8 a;
-          a[0] = (_Float16)val[0]; a[1] = (_Float16)val[1];
-          a[2] = (_Float16)dv[0][0]; a[3] = (_Float16)dv[1][0]; a[4] = (_Float16)dv[2][0];
-          a[5] = (_Float16)dv[0][1]; a[6] = (_Float16)dv[1][1]; a[7] = (_Float16)dv[2][1];
-          *reinterpret_cast<half8*>(enc_aux + ((size_t)l * (size_t)np + idx) * 8) = a;
-        }
-        const float g0 = (float)(_Float16)wl[0], g1 = (float)(_Float16)wl[1];   // dL/d enc arrives as fp16
-  #pragma unroll
-        for (int d = 0; d < 3; ++d) gview[d] += fmaf(g1, dv[d][1], g0 * dv[d][0]);      // (as the level-major records)
+      float val[2], dv[3][2];
+      grid_level(m, l, A.grid, view, val, dv, true);
+      const float e0 = (float)(_Float16)val[0], e1 = (float)(_Float16)val[1];   // encoding output is fp16
+      if (enc_aux) {  // training: what the backward needs of this level's 8 corner values -- the encoding and d enc / d x --
+                      // as one 16-byte record [level][point][8], so that it streams them instead of gathering again
+        half8 a;
+        a[0] = (_Float16)val[0]; a[1] = (_Float16)val[1];
+        a[2] = (_Float16)dv[0][0]; a[3] = (_Float16)dv[1][0]; a[4] = (_Float16)dv[2][0];
+        a[5] = (_Float16)dv[0][1]; a[6] = (_Float16)dv[1][1]; a[7] = (_Float16)dv[2][1];
+        *reinterpret_cast<half8*>(enc_aux + ((size_t)l * (size_t)np + idx) * 8) = a;
       }
+      const float g0 = (float)(_Float16)wl[0], g1 = (float)(_Float16)wl[1];     // dL/d enc arrives as fp16
+  #pragma unroll
+      for (int d = 0; d < 3; ++d) gview[d] += fmaf(g1, dv[d][1], g0 * dv[d][0]);        // (as the level-major records)
   #pragma unroll
       for (int o = 0; o < 32; ++o) out[o] = fmaf(wl[o * 35 + 1], e1, fmaf(wl[o * 35], e0, out[o]));
+    }
+    if (rec) {
+      // encoded level-major: one coalesced 16-byte record per point and hashed level.  The record of level l + 1 is
+      // REQUESTED before level l's 64 multiply-adds (two register sets, the loop body twice: a rotation through copies
+      // would wait for the load it has just issued): consumed where it is loaded, every level was one exposed memory
+      // round trip -- eleven per wave at 4 waves per SIMD (round 5's counters: this kernel's waves waiting 48 %).
+      const u32x4* rp = rec + idx;
+      auto request = [&](int l) {      // (past the last level: the last level again, never consumed)
+        return __builtin_nontemporal_load(rp + (size_t)(min(l, GS_GRID_LEVELS - 1) - first_hashed) * (size_t)np);
+      };
+      auto consume = [&](const u32x4& r, int l) {
+        const float* wl = A.sdf_w + 3 + 2 * l;
+        const float e0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(r.x & 0xffffu));
+        const float e1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(r.x >> 16));
+        gview[0] += __uint_as_float(r.y); gview[1] += __uint_as_float(r.z); gview[2] += __uint_as_float(r.w);
+  #pragma unroll
+        for (int o = 0; o < 32; ++o) out[o] = fmaf(wl[o * 35 + 1], e1, fmaf(wl[o * 35], e0, out[o]));
+      };
+      int l = first_hashed;
+      u32x4 ra = request(l), rb;
+      if ((GS_GRID_LEVELS - l) & 1) {   // an odd count: one level in front, so that the pairs below have no branch inside
+        rb = request(l + 1);            // (behind a branch the compiler sinks a request down to its first use)
+        consume(ra, l);
+        ra = rb;
+        ++l;
+      }
+  #pragma unroll 1
+      for (; l < GS_GRID_LEVELS; l += 2) {
+        rb = request(l + 1);
+        consume(ra, l);
+        ra = request(l + 2);
+        consume(rb, l + 1);
+      }
     }
   #pragma unroll
     for (int o = 0; o < 32; ++o) out[o] = out[o] + A.sdf_b[o];

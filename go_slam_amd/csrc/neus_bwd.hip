@@ -150,24 +150,43 @@ struct BwdArgs {
   // binned table gradient (BINNED instantiation): record queues [hashed level * 64 + bin][workgroup][ST_SLOTS] and the
   // segments' fill counts [hashed level * 64 + bin][workgroup]
   uint16_t* q_idx; uint32_t* q_val; uint8_t* q_cnt;
+#ifdef GS_BWD_STAMP
+  unsigned long long* stamp;   // [16] phase times summed over the workgroups' thread 0 (100 MHz ticks); -DGS_BWD_STAMP builds only
+#endif
 };
+#ifdef GS_BWD_STAMP
+#define BSTAMP(i) do { const long long t_now = wall_clock64(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
 
 constexpr int BIN_SHIFT = 13, BIN_ENTRIES = 1 << BIN_SHIFT;   // 8192 entries per bin
 constexpr int BINS_PER_LEVEL = 64;                            // hashed levels hold 2^19 entries
 constexpr int ST_SLOTS = 48;                                  // records per (workgroup, level, bin): staging AND queue segment
                                                               // (expected 256 x 8 / 64 = 32 at most; beyond: atomics)
 
-// 8 consecutive entries of row i of dX (fp32, or loss-scaled fp16 straight from the MLP-backward GEMM)
-__device__ __forceinline__ void load_dx8(const BwdArgs& A, int i, int c, float* out) {
+// 40 consecutive entries of row i of dX: ALL loads are issued before the first conversion.  (One chunk at a time --
+// load, convert, next chunk, each behind the dtype branch -- every conversion waits for its own load with nothing else in
+// flight: five serialized memory round trips at the head of every wave and five more at its tail, of a wave that lives
+// ~22 us; found in the ISA after the same pattern turned up in the MLP backward's prefetch.)
+__device__ __forceinline__ void load_dx40(const BwdArgs& A, int i, int c, float* out) {
   if (A.dx16) {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    const h8 v = *reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(A.dX) + (size_t)i * 80 + c);
+    const h8* r = reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(A.dX) + (size_t)i * 80 + c);
+    h8 v[5];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) out[e] = (float)v[e] * A.dx_inv_scale;
+    for (int k = 0; k < 5; ++k) v[k] = r[k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) out[8 * k + e] = (float)v[k][e] * A.dx_inv_scale;
   } else {
     const float4* r = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(A.dX) + (size_t)i * 80 + c);
-    const float4 a = r[0], b = r[1];
-    out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+    float4 v[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) v[k] = r[k];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { out[4 * k] = v[k].x; out[4 * k + 1] = v[k].y; out[4 * k + 2] = v[k].z; out[4 * k + 3] = v[k].w; }
   }
 }
 
@@ -218,6 +237,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
     if (threadIdx.x < 2 * BINS_PER_LEVEL) (&st_cnt[0][0])[threadIdx.x] = 0u;
     __syncthreads();
   }
+#ifdef GS_BWD_STAMP
+  long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = wall_clock64();
+#endif
   int hord = 0;                                   // ordinal of the current level among the hashed ones
   // weights are read through the constant address space: uniform, unchanged during the launch -> scalar loads
   typedef const __attribute__((address_space(4))) float* cfp;
@@ -230,16 +252,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
   const int np = A.n * A.s;
   const bool valid = idx < np;
   const int i = valid ? idx : np - 1;
-  const bool on = valid && A.mask[i] != 0;
   const int ray = i / A.s;
-  const float dist = A.dists[i];
-  const float zm = A.z_vals[i] + dist / 2.0f;
-  float pt[3], dir[3];
+  // ---- every input of the point is REQUESTED here, before anything is computed from it (see load_dx40: the round-5 form
+  // interleaved loads, branches and first uses, and its head was a chain of ~10 dependent memory round trips)
+  const uint8_t mk = A.mask[i];
+  const float dist = A.dists[i], zv = A.z_vals[i], sdf = A.sdf[i];
+  const float d_sdf_in = A.d_sdf[i], da_in = A.d_alpha[i], gerr_ray = A.d_gerr_ray[ray];
+  float g[3], dg_in[3], dir[3], org[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
+    g[d] = A.grad[i * 3 + d];
+    dg_in[d] = A.d_grad[i * 3 + d];
     dir[d] = A.rays_d[ray * 3 + d];
-    pt[d] = A.rays_o[ray * 3 + d] + dir[d] * zm;
+    org[d] = A.rays_o[ray * 3 + d];
   }
+  const float inv_s_ = A.inv_s_dev ? *A.inv_s_dev : A.inv_s;
+  // colour-MLP input gradient row dX[i, 32:72] (normal / feature part; the embedding part is re-read at the
+  // end so that it does not occupy registers across the level loop)
+  float dxh[40];
+  load_dx40(A, i, 32, dxh);
+  const bool on = valid && mk != 0;
+  const float zm = zv + dist / 2.0f;
+  float pt[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) pt[d] = org[d] + dir[d] * zm;
   if (valid && !A.rows16) {
     const size_t o3 = (size_t)i * 3;
     st_row(A.pts, false, o3 + 0, pt[0]); st_row(A.pts, false, o3 + 1, pt[1]); st_row(A.pts, false, o3 + 2, pt[2]);
@@ -247,27 +283,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
   // Every lane runs the whole body (wave-level run reduction below needs uniform control flow);
   // lanes that are out of bound / past the end carry zero upstream gradients and store nothing.
   const float live = on ? 1.0f : 0.0f;
-  const float sdf = A.sdf[i];
-  const float g[3] = {A.grad[i * 3 + 0], A.grad[i * 3 + 1], A.grad[i * 3 + 2]};
-  // colour-MLP input gradient row dX[i, 32:72] (normal / feature part; the embedding part is re-read at the
-  // end so that it does not occupy registers across the level loop)
-  float dxh[40];
-#pragma unroll
-  for (int c = 0; c < 40; c += 8) load_dx8(A, i, 32 + c, &dxh[c]);
   // ---- total gradient w.r.t. sdf and grad ----------------------------------------------------
-  float d_sdf = A.d_sdf[i] * live;
+  float d_sdf = d_sdf_in * live;
   float dg[3];
   const float gn = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
-  const float eik = (gn > 0.f) ? A.d_gerr_ray[ray] * 2.0f * (gn - 1.0f) / gn : 0.0f;
+  const float eik = (gn > 0.f) ? gerr_ray * 2.0f * (gn - 1.0f) / gn : 0.0f;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) dg[d] = (A.d_grad[i * 3 + d] + eik * g[d] + dxh[1 + d]) * live;
+  for (int d = 0; d < 3; ++d) dg[d] = (dg_in[d] + eik * g[d] + dxh[1 + d]) * live;
   float d_invs_local = 0.f;
   {   // NeuS alpha (InstantNeuS.py:276-293)
-    const float da = A.d_alpha[i] * live;
+    const float da = da_in * live;
     const float cosv = (dir[0] * g[0] + dir[1] * g[1]) + dir[2] * g[2];
     const float c = -fmaxf(-cosv, 0.0f);
     const float est_next = sdf + c * dist / 2.0f, est_prev = sdf - c * dist / 2.0f;
-    const float inv_s_ = A.inv_s_dev ? *A.inv_s_dev : A.inv_s;
     const float p = 1.0f / (1.0f + expf(-(est_prev * inv_s_)));
     const float q = 1.0f / (1.0f + expf(-(est_next * inv_s_)));
     const float raw = (p - q + 1e-5f) / (p + 1e-5f);
@@ -314,6 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
 #pragma unroll
     for (int d = 0; d < 3; ++d) { st_row(A.lin_in, false, o35 + d, p_[d] * live); st_row(A.dw0, false, o35 + d, dG[d] * rs); }
   }
+  BSTAMP(0);
 #pragma unroll 1
   for (int l = 0; l < GS_GRID_LEVELS; ++l) {
     const float scale = m.scale[l];
@@ -366,13 +395,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
     cfp wl = (cfp)(A.sdf_w + 3 + 2 * l);
     float de0 = 0.f, de1 = 0.f;
     if (A.sdf_wt) {
-      // transposed copy [level][feature][output]: the level's 64 weights are contiguous -- four 16-dword scalar loads
-      // instead of 32 strided pairs (the elimination probes put this projection at 0.4 of the kernel's 2.7 ms)
+      // packed copy [level][output][feature]: the level's 64 weights are contiguous -- four 16-dword scalar loads
+      // instead of 32 strided pairs (the elimination probes put this projection at 0.4 of the kernel's 2.7 ms) -- and an
+      // output's two weights are an aligned register PAIR, which is what v_pk_fma_f32 takes: {de0, de1} += d_out[o] *
+      // {w0, w1} in one instruction (round 5's [level][feature][output] order made the compiler assemble every pair with
+      // two s_mov and run out of scalar registers: 54 s_mov + 32 v_writelane spills per level in the ISA)
       // (constant address space: the weights do not change during the launch, so the uniform reads become s_load --
       // through a plain global pointer the compiler issues one VECTOR load per weight, 64 per level and wave)
       cfp wt = (cfp)(A.sdf_wt + 64 * l);
 #pragma unroll
-      for (int o = 0; o < 32; ++o) { de0 = fmaf(dov[o], wt[o], de0); de1 = fmaf(dov[o], wt[32 + o], de1); }
+      for (int o = 0; o < 32; ++o) { de0 = fmaf(dov[o], wt[2 * o], de0); de1 = fmaf(dov[o], wt[2 * o + 1], de1); }
     } else {
 #pragma unroll
       for (int o = 0; o < 32; ++o) { de0 = fmaf(dov[o], wl[o * 35], de0); de1 = fmaf(dov[o], wl[o * 35 + 1], de1); }
@@ -423,11 +455,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
         st_row(A.dw0, false, o35 + 3 + 2 * l + 1, v1);
       }
     }
+    BSTAMP(1);
     if (BINNED && m.hashed[l]) {
       // ---- pass 1 of bin-and-reduce: stage this workgroup's records of level l per bin, then copy them to the queues
       _Float16* tab16 = A.grid_grad16 + off * 2;
       const int buf = hord & 1;
       const bool act = lvl_prereduce(gacc, gi, on, lane) && on;
+      BSTAMP(2);
       // the 8 slot reservations go out back to back and are waited for once (an LDS atomic with return is a ~100-cycle
       // round trip: reserved one corner at a time they are 8 dependent round trips per level and wave)
       uint32_t slot_[8];
@@ -451,7 +485,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
           }
         }
       }
+      BSTAMP(3);
       __syncthreads();
+      BSTAMP(4);
       // wave w copies bins 16 w .. 16 w + 15 to this workgroup's segments, FOUR bins per step (16 lanes each, <= 3
       // strides of 16 records): 4 steps per level instead of 16 serial bin copies -- the elimination probes put
       // staging + copy + barrier at 1.0 of the kernel's 2.8 ms.  Staging buffer `buf` is appended to again two hashed
@@ -496,14 +532,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
         if (lane < 16) st_cnt[buf][16 * wv + lane] = 0u;
       }
       ++hord;
+      BSTAMP(5);
     } else {
       lvl_scatter(A.grid_grad ? A.grid_grad + off * 2 : nullptr, A.grid_grad16 ? A.grid_grad16 + off * 2 : nullptr,
                   A.grad_scale16, cidx, gacc, gi, on, lane);
+      BSTAMP(6);
     }
   }
   // ---- colour embedding sin(pts @ B): d arg = d emb * cos(arg)
   const size_t np_all = (size_t)np;
   if (r16) {
+    // the embedding part of the dX row: all five loads at once, and d arg formed in registers BEFORE the row flushes (a
+    // load consumed behind the flushes' predicated stores is waited for with vmcnt(0), i.e. behind their write
+    // acknowledgements; the round-5 form fetched and waited for 8 columns at a time, five round trips per wave)
+    uint32_t dap[20];
+    {
+      float dxe[40];
+      load_dx40(A, i, 0, dxe);
+#pragma unroll
+      for (int c = 0; c < 40; c += 2) {
+        float da[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int cc = c + e < 33 ? c + e : 32;
+          const float arg = (pt[0] * cB[cc] + pt[1] * cB[33 + cc]) + pt[2] * cB[66 + cc];
+          da[e] = c + e < 33 ? dxe[c + e] * emb_cos(arg) * live * rs : 0.0f;
+        }
+        dap[c >> 1] = pack2h(da[0], da[1]);
+      }
+    }
     // lin | w0 rows are complete: flush them, then reuse the tile for d_out, d_arg and pts
     wave_sync_lds();
     tile_flush(tile, 0, 20, A.lin_in, wave_p0, np_all, lane, A.row_stride16);
@@ -512,21 +569,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
     uint32_t* trow = tile + lane * ROW_TS;
 #pragma unroll
     for (int o = 0; o < 16; ++o) trow[o] = pack2h(dov[2 * o] * rs, dov[2 * o + 1] * rs);
-#pragma unroll 1
-    for (int c0 = 0; c0 < 40; c0 += 8) {           // 8 embedding columns at a time (keeps the tail's registers low)
-      float dxe[8];
-      load_dx8(A, i, c0, dxe);
-      float da[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int c = c0 + e;
-        const int cc = c < 33 ? c : 32;
-        const float arg = (pt[0] * cB[cc] + pt[1] * cB[33 + cc]) + pt[2] * cB[66 + cc];
-        da[e] = c < 33 ? dxe[e] * emb_cos(arg) * live * rs : 0.0f;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) trow[16 + (c0 >> 1) + e] = pack2h(da[2 * e], da[2 * e + 1]);
-    }
+    for (int e = 0; e < 20; ++e) trow[16 + e] = dap[e];
     trow[36] = pack2h(pt[0], pt[1]); trow[37] = pack2h(pt[2], 1.0f); trow[38] = 0u; trow[39] = 0u;   // (x, y, z, 1): the 1 yields column sums
     wave_sync_lds();
     tile_flush(tile, 0, 16, A.d_out, wave_p0, np_all, lane, A.row_stride16);
@@ -534,14 +578,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
     tile_flush(tile, 36, 4, A.pts, wave_p0, np_all, lane, A.row_stride16);
   } else if (valid) {
     float dxe[40];
-#pragma unroll
-    for (int c = 0; c < 40; c += 8) load_dx8(A, i, c, &dxe[c]);
+    load_dx40(A, i, 0, dxe);
 #pragma unroll
     for (int c = 0; c < 33; ++c) {
       const float arg = (pt[0] * cB[c] + pt[1] * cB[33 + c]) + pt[2] * cB[66 + c];
       st_row(A.d_arg, false, (size_t)i * 33 + c, dxe[c] * emb_cos(arg) * live * rs);
     }
   }
+  BSTAMP(7);
+#ifdef GS_BWD_STAMP
+  if (threadIdx.x == 0 && A.stamp)
+    for (int q = 0; q < 8; ++q) atomicAdd(A.stamp + q, (unsigned long long)t_acc[q]);
+#endif
   // one atomic per workgroup for d inv_s
   const float ws = gs_wave_sum(d_invs_local);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ws;
@@ -736,6 +784,9 @@ static int backward_points_impl(const float* rays_o, const float* rays_d, const 
   A.rows16 = row_dtype == GS_F16; A.row_scale = row_scale; A.row_stride16 = row_stride / 8; A.dx16 = dx_dtype == GS_F16; A.dx_inv_scale = 1.0f / dx_scale;
   A.d_inv_s = d_inv_s; A.n = n; A.s = s;
   A.q_idx = nullptr; A.q_val = nullptr; A.q_cnt = nullptr;
+#ifdef GS_BWD_STAMP
+  A.stamp = nullptr;
+#endif
   const gs_grid_meta m = host_meta();
   if (!bin_ws) {
     if (enc_aux) neus_point_bwd_kernel<false, true><<<gs_cdiv(n * s, 256), 256, 0, (hipStream_t)stream>>>(A, m);
@@ -764,10 +815,26 @@ static int backward_points_impl(const float* rays_o, const float* rays_d, const 
   A.q_cnt = (uint8_t*)base;                                       // [nq][nblk]
   A.q_val = (uint32_t*)(base + gs_align(nq * nblk));              // [nq][nblk][ST_SLOTS]
   A.q_idx = (uint16_t*)((char*)A.q_val + nq * nblk * ST_SLOTS * 4);
+#ifdef GS_BWD_STAMP
+  static unsigned long long* stamp_dev = nullptr;
+  if (!stamp_dev) (void)hipMalloc((void**)&stamp_dev, 16 * sizeof(unsigned long long));
+  (void)hipMemsetAsync(stamp_dev, 0, 16 * sizeof(unsigned long long), (hipStream_t)stream);
+  A.stamp = stamp_dev;
+#endif
   GS_TIMING_PRE();
   if (enc_aux) neus_point_bwd_kernel<true, true><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(A, m);
   else neus_point_bwd_kernel<true, false><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(A, m);
   GS_CHECK_LAUNCH("neus_backward_points_binned");
+#ifdef GS_BWD_STAMP
+  {
+    unsigned long long h[16];
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipMemcpy(h, stamp_dev, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[bwd stamp] %zu workgroups; us per workgroup (thread 0): prolog %.2f | per step: value-path %.2f prereduce %.2f stage %.2f barrier %.2f copy-out %.2f | dense levels %.2f | tail %.2f\n",
+            nblk, h[0] / 100.0 / nblk, h[1] / 100.0 / nblk, h[2] / 100.0 / nblk, h[3] / 100.0 / nblk, h[4] / 100.0 / nblk,
+            h[5] / 100.0 / nblk, h[6] / 100.0 / nblk, h[7] / 100.0 / nblk);
+  }
+#endif
   static GsLdsLimit limit;
   const size_t acc_bytes = (size_t)2 * BIN_ENTRIES * sizeof(unsigned long long);
   const size_t cnt_bytes = gs_align(nblk, 16);                        // the bin's fill counts, if they fit beside the sums
