@@ -205,8 +205,11 @@ __global__ __launch_bounds__(256) void ba_accum_kernel(
   __shared__ float red[4][92];
   // (a call that reuses an earlier call's tables skips ba_prep_kernel, which is where the failure counters are cleared)
   if (reset_fail && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { w.hdr[2] = 0; w.hdr[3] = 0; }
+  typedef const __attribute__((address_space(4))) int* cip;
+  typedef const __attribute__((address_space(4))) int64_t* clp;
+  typedef const __attribute__((address_space(4))) float* cfp;
   const int m = blockIdx.y;
-  if (m >= w.hdr[0]) return;   // only when n_depth over-states the graph (status word 1)
+  if (m >= ((cip)w.hdr)[0]) return;   // only when n_depth over-states the graph (status word 1)
   // Round 6: the out-edges of keyframe m are dealt to up to kAccSplit workgroups (edge e_beg + s, e_beg + s + kAccSplit, ...):
   // the launch is ONE resident round whose length was the longest edge list (32 us at the bench window's <= 6 out-edges,
   // 86 us in the live frontend, where the window's inactive edges make lists of ~20).  The per-EDGE sums go to the fp64
@@ -216,22 +219,22 @@ __global__ __launch_bounds__(256) void ba_accum_kernel(
   // inactive edges 62 + 6 us instead of 86, the 200-keyframe graph); at the bench window's 3 edges per keyframe the split
   // kernel + the finishing launch (24.5 + 5.6 us) only equal the unsplit kernel (32 us), so gridDim.z is 1 there.
   const int split = blockIdx.z, nsp = gridDim.z;
-  const int nsplit = min(nsp, max(w.row_ptr[m + 1] - w.row_ptr[m], 1));
+  const int nsplit = min(nsp, max(((cip)w.row_ptr)[m + 1] - ((cip)w.row_ptr)[m], 1));
   if (split >= nsplit) return;
   const int tid = threadIdx.x;
   const int p = blockIdx.x * 256 + tid;
   const bool active = p < hw;
   const int pc = active ? p : hw - 1;
-  const int k = w.kx[m];
+  const int k = ((cip)w.kx)[m];
   const int P = t1 - t0;
   const int n6 = 6 * P;
-  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  const float fx = ((cfp)intr)[0], fy = ((cfp)intr)[1], cx = ((cfp)intr)[2], cy = ((cfp)intr)[3];
   const float u = (float)(pc % wd), v = (float)(pc / wd);
   const float disp = disps[(size_t)k * hw + pc];
   float Xi[4] = {(u - cx) / fx, (v - cy) / fy, 1.0f, disp};
   float ti[3], qi[4];
   {
-    const float* pp = poses + (size_t)k * 7;
+    cfp pp = (cfp)(poses + (size_t)k * 7);
     ti[0] = pp[0]; ti[1] = pp[1]; ti[2] = pp[2];
     qi[0] = pp[3]; qi[1] = pp[4]; qi[2] = pp[5]; qi[3] = pp[6];
   }
@@ -241,16 +244,24 @@ __global__ __launch_bounds__(256) void ba_accum_kernel(
   float Csum = 0.f, wsum = 0.f;
   float Ei[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  const int e_beg = w.row_ptr[m], e_end = w.row_ptr[m + 1];
+  // The edge list, the edges' targets and the target keyframes' poses are uniform over the workgroup and unchanged
+  // during the launch: read through the constant address space they are SCALAR loads (tens of ns from the scalar cache).
+  // As vector loads -- what a plain pointer gives once the kernel has stored anything -- list entry -> edge -> jj -> pose
+  // was a chain of three dependent ~1 us round trips in front of every edge's arithmetic, ~10 us of this 33 us kernel.
+  const int e_beg = ((cip)w.row_ptr)[m], e_end = ((cip)w.row_ptr)[m + 1];
   for (int idx = e_beg + split; idx < e_end; idx += nsp) {
-    const int e = w.csr_edge[idx];
-    const int jx = (int)jj[e];
+    const int e = ((cip)w.csr_edge)[idx];
+    const int jx = (int)((clp)jj)[e];
+    // (the edge's four per-pixel inputs: requested here, in front of the pose arithmetic, and unconditionally -- pc is in
+    // range; behind `close || !active` each was its own load -> wait)
+    const size_t tb = ((size_t)e * 2) * hw + pc;
+    const float w_u = weights[tb], w_v = weights[tb + hw], t_u = targets[tb], t_v = targets[tb + hw];
     float tij[3], qij[4];
     if (jx == k) {   // stereo frames (droid_kernels.cu:219-229)
       tij[0] = -0.1f; tij[1] = 0.f; tij[2] = 0.f;
       qij[0] = 0.f; qij[1] = 0.f; qij[2] = 0.f; qij[3] = 1.f;
     } else {
-      const float* pj = poses + (size_t)jx * 7;
+      cfp pj = (cfp)(poses + (size_t)jx * 7);
       float tj[3] = {pj[0], pj[1], pj[2]};
       float qj[4] = {pj[3], pj[4], pj[5], pj[6]};
       gs_rel_se3(ti, qi, tj, qj, tij, qij);
@@ -261,11 +272,10 @@ __global__ __launch_bounds__(256) void ba_accum_kernel(
     const bool close = Xj[2] < kMinDepth;
     const float d = close ? 0.0f : 1.0f / Xj[2];
     const float d2 = d * d;
-    const size_t tb = ((size_t)e * 2) * hw + pc;
-    float wu = (close || !active) ? 0.0f : 0.001f * weights[tb];
-    float wv = (close || !active) ? 0.0f : 0.001f * weights[tb + hw];
-    const float ru = targets[tb] - (fx * d * x + cx);
-    const float rv = targets[tb + hw] - (fy * d * y + cy);
+    float wu = (close || !active) ? 0.0f : 0.001f * w_u;
+    float wv = (close || !active) ? 0.0f : 0.001f * w_v;
+    const float ru = t_u - (fx * d * x + cx);
+    const float rv = t_v - (fy * d * y + cy);
 
     float hij[78];
 #pragma unroll
@@ -455,23 +465,28 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(int M, int hw, int P, BaW
   __shared__ float red[4][44];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int n_pairs = w.pair_ptr[M];
+  // (the pair tables are uniform over the workgroup and unchanged during the launch: through the constant address space
+  // the binary search and the entity look-ups are scalar loads -- as vector loads they were ~9 dependent round trips in
+  // front of every pair's pixel loop)
+  typedef const __attribute__((address_space(4))) int* cip;
+  cip pair_ptr = (cip)w.pair_ptr, ent_ptr = (cip)w.ent_ptr, ent_pose = (cip)w.ent_pose, ent_src = (cip)w.ent_src;
+  const int n_pairs = pair_ptr[M];
   const int n6 = 6 * P;
   for (int pidx = blockIdx.x; pidx < n_pairs; pidx += gridDim.x) {
     // binary search: largest m with pair_ptr[m] <= pidx
     int lo = 0, hi = M;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if (w.pair_ptr[mid] <= pidx) lo = mid; else hi = mid;
+      if (pair_ptr[mid] <= pidx) lo = mid; else hi = mid;
     }
     const int m = lo;
-    const int eb = w.ent_ptr[m];
-    const int nm = w.ent_ptr[m + 1] - eb;
-    const int r = pidx - w.pair_ptr[m];
+    const int eb = ent_ptr[m];
+    const int nm = ent_ptr[m + 1] - eb;
+    const int r = pidx - pair_ptr[m];
     const int a = r / nm, b = r - a * nm;
-    const int pa = w.ent_pose[eb + a], pb = w.ent_pose[eb + b];
+    const int pa = ent_pose[eb + a], pb = ent_pose[eb + b];
     if (pa < pb) continue;   // covered by the transposed pair
-    const int sa = w.ent_src[eb + a], sb = w.ent_src[eb + b];
+    const int sa = ent_src[eb + a], sb = ent_src[eb + b];
     const float* Ea = (sa < M) ? w.Ei + (size_t)sa * 6 * hw : w.Eij + (size_t)(sa - M) * 6 * hw;
     const float* Eb = (sb < M) ? w.Ei + (size_t)sb * 6 * hw : w.Eij + (size_t)(sb - M) * 6 * hw;
     const float* Qm = w.Q + (size_t)m * hw;
