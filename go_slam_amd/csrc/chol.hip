@@ -740,15 +740,18 @@ __device__ __forceinline__ void lds_factor(double* Lp, double* invd, const int n
 
 // backward substitution L^T x = y (y sits in row n of Lp), column-oriented, 6 unknowns per step; dx[i] = (float) x[i],
 // and the solved x replaces y in LDS (row n), which the mid-size kernel's head stages read afterwards.
+// ONE wave does it (round 6).  A step is a 6-pivot dependent chain + 6 multiply-adds per remaining column: nothing for
+// 16 waves to share, and in the 1024-thread form every step paid two workgroup barriers -- 25 steps x 2 barriers were
+// ~10 of the backward's 15 us at n = 150.  Inside a wave the LDS is in order: a step's writes to y are visible to the
+// next step's reads with no barrier at all.  The columns are dealt from k0 - 1 downwards, so the six entries the NEXT
+// step's chain starts from are updated in the first trip.  Ends with a workgroup barrier (x is in row n for everyone).
 __device__ __forceinline__ void lds_backward(double* Lp, const double* invd, const int n, float* __restrict__ dx) {
-  const int tid = threadIdx.x;
   const int npk = (n * (n + 1)) >> 1;
   double* y = Lp + npk;
-  for (int k0 = n - CB; k0 >= 0; k0 -= CB) {
-    const bool need = tid < ((max(k0, CB) + 63) & ~63);
-    double x[CB];
-    if (need) {
-      double l[CB][CB];
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    for (int k0 = n - CB; k0 >= 0; k0 -= CB) {
+      double l[CB][CB], x[CB];
 #pragma unroll
       for (int i = 0; i < CB; ++i)
 #pragma unroll
@@ -760,21 +763,25 @@ __device__ __forceinline__ void lds_backward(double* Lp, const double* invd, con
         for (int t = i + 1; t < CB; ++t) sacc = fma(-l[t][i], x[t], sacc);
         x[i] = sacc * invd[k0 + i];
       }
-    }
-    __syncthreads();                                  // everyone has read y[k0..k0+5] before it is reused
-    if (tid < CB) {
+      for (int c = k0 - 1 - lane; c >= 0; c -= 64) {
+        double s = y[c];
 #pragma unroll
-      for (int i = 0; i < CB; ++i)
-        if (i == tid) { dx[k0 + i] = (float)x[i]; y[k0 + i] = x[i]; }
-    }
-    for (int c = tid; c < k0; c += SMALL_NT) {
-      double s = y[c];
+        for (int i = 0; i < CB; ++i) s = fma(-Lp[tri(k0 + i, c)], x[i], s);
+        y[c] = s;
+      }
+      if (lane < CB) {
+        double xl = x[0];
 #pragma unroll
-      for (int i = 0; i < CB; ++i) s = fma(-Lp[tri(k0 + i, c)], x[i], s);
-      y[c] = s;
+        for (int i = 1; i < CB; ++i) xl = (i == lane) ? x[i] : xl;
+        dx[k0 + lane] = (float)xl;
+        y[k0 + lane] = xl;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __syncthreads();
   }
+  __syncthreads();
 }
 
 // packed lower triangle of [A; b^T] from global memory (rows / columns [c0, n) of the dense n x n array H, b from bg),
