@@ -38,8 +38,22 @@ struct EncArgs {
 };
 
 // one fp32 accumulator tile (32 channels x 32 pixels) -> fp16 NHWC rows through a wave-private LDS tile [32 px][40]
+// this lane's 16 channels of a per-channel fp16 vector (channels c0 + 8 g + 4 kh + e): four 8-byte loads, REQUESTED
+// at the head of the kernel.  (Read where they are used -- one 2-byte load per accumulator register, each converted at
+// once -- the epilogue of every wave was 32 dependent cache round trips: a third of a 12-18 us launch.)
+struct EncBias { half4 q[4]; };
+__device__ __forceinline__ EncBias load_bias16(const _Float16* p, const void* any, int c0, int lane) {
+  // (a null vector is read from `any` -- readable, >= 64 bytes, values unused -- so that the loads sit behind no branch
+  // and stay in flight across the convolution's loop)
+  const _Float16* q = p ? p + c0 : reinterpret_cast<const _Float16*>(any);
+  EncBias b;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) b.q[g] = *reinterpret_cast<const half4*>(q + 8 * g + 4 * (lane >> 5));
+  return b;
+}
+
 __device__ __forceinline__ void store_tile(const float16v& acc, _Float16* tile, const EncArgs& A, int img, int oy, int ox0,
-                                           int c0, int lane, float* red) {
+                                           int c0, int lane, float* red, const EncBias& bias, const EncBias& sbias) {
   constexpr int TS = 40;
   const int r = lane & 31, kh = lane >> 5;
   if (A.stats) {
@@ -52,11 +66,10 @@ __device__ __forceinline__ void store_tile(const float16v& acc, _Float16* tile, 
     float sv[32];                                  // [0..15] = d, [16..31] = d^2 of this lane's pixel, per accumulator register
 #pragma unroll
     for (int e16 = 0; e16 < 16; ++e16) {
-      const int ch = c0 + 8 * (e16 >> 2) + 4 * kh + (e16 & 3);
       const float v = (float)(_Float16)acc[e16];
       float d = v;
       if (A.stat_bias) {
-        const float bsh = (float)A.stat_bias[ch];
+        const float bsh = (float)sbias.q[e16 >> 2][e16 & 3];
         d = (float)(_Float16)(v + bsh) - bsh;
       }
       if (r >= nvalid) d = 0.0f;
@@ -83,7 +96,7 @@ __device__ __forceinline__ void store_tile(const float16v& acc, _Float16* tile, 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float v = (float)(_Float16)acc[4 * g + e];
-      if (A.bias) v = (float)(_Float16)(v + (float)A.bias[c0 + 8 * g + 4 * kh + e]);
+      if (A.bias) v = (float)(_Float16)(v + (float)bias.q[g][e]);
       o[e] = (_Float16)v;
     }
     *reinterpret_cast<half4*>(tile + r * TS + 8 * g + 4 * kh) = o;
@@ -139,6 +152,7 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncArgs A, int mtiles) {
   float16v acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  const EncBias bias = load_bias16(A.bias, A.wpack, 32 * mt, lane), sbias = load_bias16(A.stat_bias, A.wpack, 32 * mt, lane);
   const _Float16* ximg = A.x + (size_t)img * A.h * A.w * A.xs;
   const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -154,14 +168,15 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncArgs A, int mtiles) {
       half8 b[KSTEPS], a[KSTEPS];
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
-        b[ks] = ok ? *reinterpret_cast<const half8*>(px + 16 * ks) : zero8;
+        const half8 t = *reinterpret_cast<const half8*>(px + 16 * ks);      // (px is clamped into the image: no branch
+        b[ks] = ok ? t : zero8;                                              //  around the load, the taps' loads overlap)
         a[ks] = wt[(size_t)ks * mtiles * 64];
       }
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], b[ks], acc, 0, 0, 0);
     }
   }
-  if (active) store_tile(acc, tiles[wv], A, img, oy, ox0, 32 * mt, lane, red + wv * SLAB);
+  if (active) store_tile(acc, tiles[wv], A, img, oy, ox0, 32 * mt, lane, red + wv * SLAB, bias, sbias);
   if (A.stats) red_publish(red, A, img, SLAB);
 }
 
@@ -183,6 +198,7 @@ __global__ __launch_bounds__(256) void enc_stem_kernel(EncArgs A) {
   float16v acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  const EncBias bias = load_bias16(A.bias, A.wpack, 0, lane), sbias = load_bias16(A.stat_bias, A.wpack, 0, lane);
   const half4* ximg = reinterpret_cast<const half4*>(A.x) + (size_t)img * A.h * A.w;
   const half4 zero4 = {0, 0, 0, 0};
 #pragma unroll
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(256) void enc_stem_kernel(EncArgs A) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.wpack[(dy * 2 + ks) * 64 + lane], b, acc, 0, 0, 0);
     }
   }
-  if (active) store_tile(acc, tiles[wv], A, img, oy, ox0, 0, lane, red + wv * SLAB);
+  if (active) store_tile(acc, tiles[wv], A, img, oy, ox0, 0, lane, red + wv * SLAB, bias, sbias);
   if (A.stats) red_publish(red, A, img, SLAB);
 }
 
@@ -235,6 +251,7 @@ extern "C" int gs_enc_conv(const void* x, int x_stride, int c_in, const void* wp
   GS_REQUIRE(x_stride >= c_in && (x_stride % 8 == 0 || ksize == 7) && y_stride >= c_out && y_stride % 8 == 0,
              "enc_conv: strides must cover the channels and be multiples of 8");
   GS_REQUIRE((((size_t)x | (size_t)y | (size_t)wpack) & 15) == 0, "enc_conv: buffers must be 16-byte aligned");
+  GS_REQUIRE((((size_t)bias | (size_t)stat_bias) & 7) == 0, "enc_conv: bias vectors must be 8-byte aligned");
   GS_REQUIRE(!stats_ws || c_out <= 256, "enc_conv: epilogue statistics support at most 256 output channels");
   if (n == 0) return GS_OK;
   EncArgs A;
