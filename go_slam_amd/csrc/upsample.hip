@@ -132,9 +132,13 @@ __global__ __launch_bounds__(512, 1) void upmask_upsample_kernel(const _Float16*
     for (int e = 0; e < 4; ++e) bv[k][e] = bias[64 * k + 8 * wv + 4 * kgl + e];
   const long gstride = (long)gridDim.x * 32;
   up_h8 bnext[8];
+  long fnext;                                        // the frame of the next block's pixel: requested with its rows
+  const int64_t* ixp = ix ? ix : reinterpret_cast<const int64_t*>(disps);   // (no index list: any readable words, unused)
   {
     const long g0 = (long)blockIdx.x * 32;
     const long pq0 = (g0 + r < total) ? g0 + r : (g0 < total ? g0 : 0);
+    const int n0 = (int)(pq0 / hw);
+    { const long f = ixp[n0]; fnext = ix ? f : (long)n0; }
     const _Float16* xr0 = x + (size_t)pq0 * xs + 8 * kgl;
 #pragma unroll
     for (int s = 0; s < 8; ++s) bnext[s] = *reinterpret_cast<const up_h8*>(xr0 + 16 * s);
@@ -143,15 +147,31 @@ __global__ __launch_bounds__(512, 1) void upmask_upsample_kernel(const _Float16*
     const long pix = g0 + r;
     const bool valid = pix < total;
     const long pq = valid ? pix : g0;
+    const int n = (int)(pq / hw), p = (int)(pq - (long)n * hw);
+    const long frame = fnext;                        // (the frame index is the head of a two-step chain: it arrives with the rows)
     up_h8 bcur[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) bcur[s] = bnext[s];
     {
       const long g1 = g0 + gstride;
       const long pq1 = (g1 + r < total) ? g1 + r : (g1 < total ? g1 : pq);
+      const int n1 = (int)(pq1 / hw);
+      { const long f = ixp[n1]; fnext = ix ? f : (long)n1; }
       const _Float16* xr1 = x + (size_t)pq1 * xs + 8 * kgl;
 #pragma unroll
       for (int s = 0; s < 8; ++s) bnext[s] = *reinterpret_cast<const up_h8*>(xr1 + 16 * s);
+    }
+    // the pixel's 3 x 3 disparities are requested BEFORE the mask's MFMAs (frame index -> nine loads is a chain of two
+    // round trips that sat exposed between the MFMAs and the softmax), behind no branch: coordinates clamped, zeros selected
+    const int y = p / w, xq = p - y * w;
+    const float* d = disps + frame * hw;
+    float nb[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int yy = y + k / 3 - 1, xx = xq + k % 3 - 1;          // F.unfold(3x3, padding 1): zero padded
+      const bool in = yy >= 0 && yy < h && xx >= 0 && xx < w;
+      const float v = d[min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)];
+      nb[k] = in ? v : 0.0f;
     }
     up_f16v acc[3];
 #pragma unroll
@@ -162,16 +182,6 @@ __global__ __launch_bounds__(512, 1) void upmask_upsample_kernel(const _Float16*
     for (int s = 0; s < 8; ++s) {
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[t][s], bcur[s], acc[t], 0, 0, 0);
-    }
-    const int n = (int)(pq / hw), p = (int)(pq - (long)n * hw);
-    const int y = p / w, xq = p - y * w;
-    const long frame = ix ? ix[n] : n;
-    const float* d = disps + frame * hw;
-    float nb[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int yy = y + k / 3 - 1, xx = xq + k % 3 - 1;          // F.unfold(3x3, padding 1): zero padded
-      nb[k] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? d[yy * w + xx] : 0.0f;
     }
     float res[4];
 #pragma unroll
