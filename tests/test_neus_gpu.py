@@ -153,6 +153,56 @@ def test_mlp_layout_is_not_transposed(N, dev):
     assert out[:, 0].abs().max() == 0 and out[:, 2].abs().max() == 0
 
 
+def _mlp_backward_reference(X, W, d_rgb, rgb, ls):
+    """gs_mlp_backward's contract (include/goslam_neus.h) in fp32 torch with its fp16 rounding points: H1, H2, dpre, dH2,
+    dH1, dX are fp16 values; every product accumulates in fp32."""
+    W1, W2, W3 = W[:5120].view(64, 80).float(), W[5120:9216].view(64, 64).float(), W[9216:].view(16, 64).float()
+    Xf = X.float()
+    H1 = torch.relu(Xf @ W1.t()).half().float()
+    H2 = torch.relu(H1 @ W2.t()).half().float()
+    dpre = torch.zeros(X.shape[0], 16, device=X.device)
+    dact = rgb.float() * (1 - rgb.float()) if rgb is not None else 1.0
+    dpre[:, :3] = (d_rgb * dact * ls).half().float()
+    dH2 = ((dpre @ W3) * (H2 > 0)).half().float()
+    dH1 = ((dH2 @ W2) * (H1 > 0)).half().float()
+    return (dH1 @ W1).half(), torch.cat([(dH1.t() @ Xf).reshape(-1), (dH2.t() @ H1).reshape(-1), (dpre.t() @ H2).reshape(-1)])
+
+
+@pytest.mark.parametrize("n", [1, 31, 33, 97, 4099, 131072 + 17])
+@pytest.mark.parametrize("with_rgb", [True, False])
+def test_mlp_backward_ragged_sizes_both_block_forms(N, dev, n, with_rgb):
+    """The rebuilt colour-MLP backward at sizes that end inside a 32-point block (rows past the end go to the sink), below
+    and above the switch to two sub-blocks per iteration (131072 points), with and without the sigmoid derivative (`rgb`
+    NULL = tcnn.Network's contract).  Random asymmetric weights: a wrong K permutation of the packed fragments, a
+    transposed tile or a mis-addressed transposing read is an O(1) error in dX / dW."""
+    from go_slam_amd import _lib
+    from go_slam_amd.neus.tcnn_compat import _pack_mlp_fragments
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(100 + n % 97)
+    X = (torch.randn(n, 80, generator=g) * 0.5).half().to(dev)
+    X[:, 67:] = 1.0
+    W = (torch.randn(10240, generator=g) * 0.15).half().to(dev)
+    d_rgb = (torch.randn(n, 3, generator=g) * 1e-3).to(dev)
+    rgb = torch.rand(n, 3, generator=g).half().to(dev) if with_rgb else None
+    nb = L.gs_mlp_backward_blocks(n)
+    partial = torch.full((nb, 10240), float("nan"), device=dev)       # (every entry must be written)
+    dX = torch.full((n, 80), float("nan"), dtype=torch.float16, device=dev)
+    guard = torch.zeros(4096, dtype=torch.float16, device=dev)         # (allocated right behind: nothing may land past dX)
+    rc = L.gs_mlp_backward(_lib.ptr(X), _lib.ptr(_pack_mlp_fragments(W)), _lib.ptr(d_rgb), _lib.ptr(rgb) if with_rgb else None,
+                           128.0, _lib.ptr(dX), _lib.ptr(partial), n, _lib.stream_ptr(dev))
+    _lib.check(rc, "mlp_backward")
+    torch.cuda.synchronize()
+    rdX, rg = _mlp_backward_reference(X, W, d_rgb, rgb, 128.0)
+    gk = partial.sum(0)
+    assert torch.isfinite(dX.float()).all() and torch.isfinite(gk).all() and float(guard.float().abs().max()) == 0.0
+
+    def rel(a, b):
+        return float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20))
+    assert rel(dX, rdX) < 2e-3, rel(dX, rdX)                 # fp16 outputs of fp32-accumulated products: ~1e-5 measured
+    for name, a, b in (("dW1", gk[:5120], rg[:5120]), ("dW2", gk[5120:9216], rg[5120:9216]), ("dW3", gk[9216:], rg[9216:])):
+        assert rel(a, b) < 2e-3, (name, rel(a, b))
+
+
 @pytest.mark.parametrize("grid_init", [1e-4, 0.3])
 def test_neus_forward_matches_oracle(N, O, dev, grid_init):
     P = O.make_params(7, grid_init=grid_init, bound=((-2.5, 2.5), (-2.5, 2.5), (-2.5, 2.5)))
