@@ -276,9 +276,9 @@ __global__ __launch_bounds__(1024) void map_step_prep_kernel(const float* __rest
   }
   const float dg = w_eik / (bc[1] * (float)s);
   for (int i = tid; i < n; i += 1024) d_gerr_out[i] = dg;
-  if (sdf_w && sdf_wt) {                               // [16][32][2] <- sdf_w [32][35] columns 3..34
-    const int l = tid >> 6, o = (tid >> 1) & 31, f = tid & 1;
-    sdf_wt[tid] = sdf_w[o * 35 + 3 + 2 * l + f];
+  if (sdf_w && sdf_wt) {                               // [16][2][32] <- sdf_w [32][35] columns 3..34
+    const int lf = tid >> 5, o = tid & 31;
+    sdf_wt[tid] = sdf_w[o * 35 + 3 + lf];
   }
   if (mlp16 && frag_index && mlp_wpack) {              // the MLP backward's 40 A-fragments (was: cat + index + fill launches)
     // 20 entries per thread: all indices first, then all gathers (rolled, the two dependent loads per entry cost 40

@@ -393,22 +393,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void n
     }
     // value path: d enc_f = sum_o d_out[o] W[o][3+2l+f]
     cfp wl = (cfp)(A.sdf_w + 3 + 2 * l);
-    float de0 = 0.f, de1 = 0.f;
+    // Two partial sums per feature, over the even and the odd outputs: {even, odd} += {d_out[o], d_out[o + 1]} * {w[o],
+    // w[o + 1]} is ONE v_pk_fma_f32 whose operands are register pairs as they lie -- two consecutive d_out registers and two
+    // consecutive scalar weights.  (One chain per feature, round 5's form, makes d_out[o] the broadcast operand: the
+    // compiler duplicates it into a pair with two v_mov per product, 64 per level and wave -- the level loop's largest
+    // single item in the ISA, and with [level][output][feature] weights 54 s_mov + 32 v_writelane on top.)
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};       // (written as 2-vectors: left to itself the vectoriser pairs the two FEATURES)
     if (A.sdf_wt) {
-      // packed copy [level][output][feature]: the level's 64 weights are contiguous -- four 16-dword scalar loads
-      // instead of 32 strided pairs (the elimination probes put this projection at 0.4 of the kernel's 2.7 ms) -- and an
-      // output's two weights are an aligned register PAIR, which is what v_pk_fma_f32 takes: {de0, de1} += d_out[o] *
-      // {w0, w1} in one instruction (round 5's [level][feature][output] order made the compiler assemble every pair with
-      // two s_mov and run out of scalar registers: 54 s_mov + 32 v_writelane spills per level in the ISA)
+      // transposed copy [level][feature][output]: the level's 64 weights are contiguous -- scalar loads of whole pairs
+      // instead of 32 strided ones (the elimination probes put this projection at 0.4 of the kernel's 2.7 ms)
       // (constant address space: the weights do not change during the launch, so the uniform reads become s_load --
       // through a plain global pointer the compiler issues one VECTOR load per weight, 64 per level and wave)
       cfp wt = (cfp)(A.sdf_wt + 64 * l);
 #pragma unroll
-      for (int o = 0; o < 32; ++o) { de0 = fmaf(dov[o], wt[2 * o], de0); de1 = fmaf(dov[o], wt[2 * o + 1], de1); }
+      for (int o = 0; o < 32; o += 2) {
+        const f2v d = {dov[o], dov[o + 1]};
+        acc0 = __builtin_elementwise_fma(d, f2v{wt[o], wt[o + 1]}, acc0);
+        acc1 = __builtin_elementwise_fma(d, f2v{wt[32 + o], wt[32 + o + 1]}, acc1);
+      }
     } else {
 #pragma unroll
-      for (int o = 0; o < 32; ++o) { de0 = fmaf(dov[o], wl[o * 35], de0); de1 = fmaf(dov[o], wl[o * 35 + 1], de1); }
+      for (int o = 0; o < 32; o += 2) {
+        const f2v d = {dov[o], dov[o + 1]};
+        acc0 = __builtin_elementwise_fma(d, f2v{wl[o * 35], wl[(o + 1) * 35]}, acc0);
+        acc1 = __builtin_elementwise_fma(d, f2v{wl[o * 35 + 1], wl[(o + 1) * 35 + 1]}, acc1);
+      }
     }
+    const float de0 = acc0[0] + acc0[1], de1 = acc1[0] + acc1[1];
     // gradient path: grad_d = (W0[d] + 1/2 sum g_lf dydx_lf,d) * inside * 2/span
     const float g0 = (float)(_Float16)wl[0], g1 = (float)(_Float16)wl[1];
     float dy0[3], dy1[3];

@@ -172,7 +172,7 @@ int gs_neus_backward_points(const float* rays_o, const float* rays_d, const floa
  * one workgroup per bin sums its queue in fp32 LDS accumulators and writes its 8192 entries once; neus_bwd.hip).
  * grid_grad is the loss-scaled f16 table gradient (zero it first; the dense levels and any overflow records still
  * arrive as packed atomics).  `bin_ws`: gs_neus_bin_workspace_bytes(n * s) bytes of scratch (no initial state).
- * `sdf_wt` (optional, f32 [16][32][2]): sdf_w's encoding columns packed per level, sdf_wt[l][o][f] = sdf_w[o][3 + 2 l + f]
+ * `sdf_wt` (optional, f32 [16][2][32]): sdf_w's encoding columns transposed, sdf_wt[l][f][o] = sdf_w[o][3 + 2 l + f]
  * (gs_map_step_prep writes it), which turns the kernel's strided weight reads into contiguous ones.                */
 size_t gs_neus_bin_workspace_bytes(int n_points);
 int gs_neus_backward_points_binned(const float* rays_o, const float* rays_d, const float* z_vals,
@@ -227,7 +227,7 @@ int gs_map_adamw_seg(float* p, float* m, float* v, void* p16, const void* g16, s
 /* The scalar / reduction arithmetic around the mapper step's kernels in two launches (map_opt.hip):
  *   gs_map_step_prep: counts_out = counts_in if given, else [#rays with depth > 0, n, max depth] of rays_depth [n];
  *     inv_s_out[0] = clamp(exp(variance[0] * scale_factor), 1e-6, 1e6); d_gerr_out[0:n] = w_eikonal / (counts[1] * samples);
- *     d_invs[0] = sqnorm[0] = 0; step_dev[0] += 1; sdf_wt_out[l][o][f] = sdf_w[o][3 + 2 l + f] (both optional);
+ *     d_invs[0] = sqnorm[0] = 0; step_dev[0] += 1; sdf_wt_out[l][f][o] = sdf_w[o][3 + 2 l + f] (both optional);
  *     mlp_wpack_out[i] = frag_index[i] == 10240 ? 0 : mlp16[frag_index[i]] for i < 20480 (all three optional): the
  *     40 A-fragments gs_mlp_backward takes, gathered from the fp16 parameter vector (frag_index: int32 [20480]).
  *   gs_map_step_post: g32 [mlp 10240 | sdf_w 32x35 | sdf_b 32 | color_B 3x33 | variance 1 | loss 1] from the chunked Gram
