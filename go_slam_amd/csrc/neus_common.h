@@ -103,11 +103,17 @@ __device__ __forceinline__ bool lvl_prereduce(float (&gacc)[8][2], const uint32_
     for (int off = 1; off < 64; off <<= 1) {
       const bool take = (lane - off) >= run_start;
       if (__ballot(take) == 0ull) break;            // wave-uniform
+      // all sixteen lane exchanges first, then ONE predicated block of adds (round 6: exchange + select + add per value
+      // was 243 v_cndmask per level in the ISA -- half of this function's vector instructions)
+      float u[8][2];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const float u0 = off == 1 ? wave_shr1(gacc[c][0]) : __shfl_up(gacc[c][0], off, 64);
-        const float u1 = off == 1 ? wave_shr1(gacc[c][1]) : __shfl_up(gacc[c][1], off, 64);
-        if (take) { gacc[c][0] += u0; gacc[c][1] += u1; }
+        u[c][0] = off == 1 ? wave_shr1(gacc[c][0]) : __shfl_up(gacc[c][0], off, 64);
+        u[c][1] = off == 1 ? wave_shr1(gacc[c][1]) : __shfl_up(gacc[c][1], off, 64);
+      }
+      if (take) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { gacc[c][0] += u[c][0]; gacc[c][1] += u[c][1]; }
       }
     }
     tail = (lane == 63) || (((starts >> (lane + 1)) & 1ull) != 0ull);
