@@ -289,14 +289,12 @@ template <bool RELU>
 __device__ __forceinline__ void store_act(_Float16* hs, const float16v& c, int mt, int nt, int lane) {
   const int point = 32 * nt + (lane & 31);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    half4 pk;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float v = c[q * 4 + k];
-      if (RELU) v = fmaxf(v, 0.0f);
-      pk[k] = (_Float16)v;
-    }
+  for (int q = 0; q < 4; ++q) {       // (round, then ReLU as a signed 16-bit max on the bit patterns: see store_act_xs)
+    typedef float float4q __attribute__((ext_vector_type(4)));
+    typedef short short4q __attribute__((ext_vector_type(4)));
+    const float4q v4 = {c[q * 4], c[q * 4 + 1], c[q * 4 + 2], c[q * 4 + 3]};
+    half4 pk = __builtin_convertvector(v4, half4);
+    if (RELU) pk = __builtin_bit_cast(half4, __builtin_elementwise_max(__builtin_bit_cast(short4q, pk), short4q{0, 0, 0, 0}));
     *reinterpret_cast<half4*>(hs + point * HS + 32 * mt + 8 * q + 4 * (lane >> 5)) = pk;
   }
 }
@@ -313,13 +311,14 @@ __device__ __forceinline__ void store_act_xs(_Float16* xs, const float16v& c, in
   const int point = 32 * nt + (lane & 31);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    half4 pk;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float v = c[q * 4 + k];
-      if (RELU) v = fmaxf(v, 0.0f);
-      pk[k] = (_Float16)v;
-    }
+    // round first, then ReLU as a signed 16-bit max with 0 on the bit patterns (rounding is monotone and keeps the sign:
+    // the same values as max-then-round, -0 becomes +0): v_cvt_pk + v_pk_max_i16 per pair, where fmaxf on floats costs a
+    // canonicalising v_max + the max per VALUE (257 v_max_f32 in this kernel's ISA)
+    typedef float float4q __attribute__((ext_vector_type(4)));
+    typedef short short4q __attribute__((ext_vector_type(4)));
+    const float4q v4 = {c[q * 4], c[q * 4 + 1], c[q * 4 + 2], c[q * 4 + 3]};
+    half4 pk = __builtin_convertvector(v4, half4);
+    if (RELU) pk = __builtin_bit_cast(half4, __builtin_elementwise_max(__builtin_bit_cast(short4q, pk), short4q{0, 0, 0, 0}));
     *reinterpret_cast<half4*>(xs + point * XS + 32 * mt + 8 * q + 4 * (lane >> 5)) = pk;
   }
 }
