@@ -106,6 +106,7 @@ SIGNATURES = {
     "gs_neus_backward_points_binned": (c_int, [_P] * 7 + [c_float] + [_P] * 9 + [c_int, c_float, _P, _P, c_float] + [_P] * 5
                                        + [c_int, c_float, c_int, _P, c_int, c_int, _P, c_size_t, _P, _P, _P]),
     "gs_neus_bin_workspace_bytes": (c_size_t, [c_int]),
+    "gs_ray_draw": (c_int, [_P] * 7 + [c_int] * 4 + [c_float] * 4 + [_P] * 5),
 }
 
 

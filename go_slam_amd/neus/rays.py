@@ -1,6 +1,8 @@
 """Ray generation for the mapper (reference src/nerf_func.py:115-181 `build_rays`): random pixel
 pick (mask-aware) and ray directions d = K^-1 [u, v, 1] R^T, o = t.  Negligible cost
 (SURVEY.md 8 a11): stays PyTorch, RNG stays on the host side of the kernels."""
+import os
+
 import numpy as np
 import torch
 
@@ -71,6 +73,14 @@ class RayBank:
         self.trans = c2w[:, :3, 3].contiguous()
         cums = torch.stack(mask, 0).to(torch.int64).cumsum(1)               # rank of every valid pixel, 1-based
         self.N = [int(n) for n in cums[:, -1].tolist()]                     # the ONE host transfer of a Mapper call
+        # the device draw (gs_ray_draw: one launch per iteration) wants fp32 planes it can index and 32-bit running sums
+        self.fused = (os.environ.get("GOSLAM_RAY_DRAW_FUSED", "1") != "0" and self.color.is_cuda and self.color.dtype == torch.float32 and self.depth.dtype == torch.float32
+                      and c2w.dtype == torch.float32 and HW < 2 ** 31)
+        if self.fused:
+            self.color, self.depth = self.color.contiguous(), self.depth.contiguous()
+            self.cum32 = cums.to(torch.int32).contiguous()
+            self._fpos = {}
+            return
         # one sorted array for all frames: frame f's running sum shifted by f (HW + 1) -- a rank query of frame f
         # (1 .. N_f <= HW) cannot land in another frame's stretch
         self.big = HW + 1
@@ -92,6 +102,8 @@ class RayBank:
                     acc.append(x.float())
             rays_o, rays_d, depth, color = (torch.cat(p, dim=0) for p in parts)
             return rays_o, rays_d, color, depth
+        if self.fused:
+            return self._sample_fused(pos, n_rays)
         # the reference's random draws, call for call
         idx = torch.stack([torch.randint(self.N[p], (n_rays,), device=dev).clamp(0, self.N[p] - 1) for p in pos], 0)
         fi = torch.tensor(pos, dtype=torch.int64, device=dev)
@@ -104,3 +116,33 @@ class RayBank:
         rays_d = torch.bmm(dirs, self.rot_t[fi].to(dirs.dtype)).reshape(-1, 3)
         rays_o = self.trans[fi].to(dirs.dtype)[:, None, :].expand(-1, n_rays, -1).reshape(-1, 3)
         return rays_o.float(), rays_d.float(), self.color[g].float(), self.depth[g].float()
+
+    def _sample_fused(self, pos, n_rays):
+        """The same draw on the device path: the reference's `torch.randint` calls, call for call (written into the rows of
+        one index tensor; `clamp(0, N - 1)` is the identity on their range), then ONE launch (gs_ray_draw: rank -> pixel
+        through the running mask sums, directions, origins, colour and depth of every frame's rays)."""
+        from .. import _lib
+        dev = self.color.device
+        nf = len(pos)
+        idx = torch.empty(nf, n_rays, dtype=torch.int64, device=dev)
+        for k, p in enumerate(pos):
+            torch.randint(self.N[p], (n_rays,), device=dev, out=idx[k])
+        key = tuple(pos)
+        fpos = self._fpos.get(key)
+        if fpos is None:
+            if len(self._fpos) > 64:
+                self._fpos.clear()
+            fpos = self._fpos[key] = torch.tensor(pos, dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        n = nf * n_rays
+        rays_o, rays_d, color = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 3, **f32)
+        depth = torch.empty(n, **f32)
+        fx, fy, cx, cy = self.intr
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gs_ray_draw(_lib.ptr(idx), _lib.ptr(fpos), _lib.ptr(self.cum32), _lib.ptr(self.color),
+                                        _lib.ptr(self.depth), _lib.ptr(self.rot_t), _lib.ptr(self.trans), nf, n_rays,
+                                        self.H * self.W, self.W, float(fx), float(fy), float(cx), float(cy),
+                                        _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(color), _lib.ptr(depth),
+                                        _lib.stream_ptr(dev))
+        _lib.check(rc, "RayBank.sample")
+        return rays_o, rays_d, color, depth

@@ -185,6 +185,19 @@ int gs_neus_backward_points_binned(const float* rays_o, const float* rays_d, con
                                    int row_stride, float* d_inv_s, int n, int s, void* bin_ws, size_t bin_ws_bytes,
                                    const float* sdf_wt, const void* enc_aux, gs_stream_t stream);
 
+/* The mapper's ray draw for all frames of one joint iteration (src/nerf_func.py:115-181 build_rays after its random pick;
+ * src/mapping.py:222-240,262-283 calls it per visited keyframe): ray t = (k, r) of drawn frame k takes the (rank[t] + 1)-th
+ * valid pixel p of bank frame f = frame_pos[k] -- the first p with cums[f][p] >= rank[t] + 1, cums = the running sum of the
+ * frame's mask over its hw = H * W pixels (row-major), rank[t] < cums[f][hw - 1] -- and writes
+ *   rays_d[t] = [(u - cx) / fx, (v - cy) / fy, 1] @ rot_t[f]   (u = p % width, v = p / width; rot_t[f] = c2w[:3,:3]^T)
+ *   rays_o[t] = trans[f],  out_color[t] = color[f * hw + p],  out_depth[t] = depth[f * hw + p].
+ * rank i64 [n_frames_drawn * n_rays] (the reference's torch.randint draws), frame_pos i32 [n_frames_drawn], cums i32
+ * [F][hw], color f32 [F * hw][3], depth f32 [F * hw], rot_t f32 [F][3][3], trans f32 [F][3]; outputs f32.           */
+int gs_ray_draw(const long long* rank, const int* frame_pos, const int* cums, const float* color, const float* depth,
+                const float* rot_t, const float* trans, int n_frames_drawn, int n_rays, int hw, int width, float fx,
+                float fy, float cx, float cy, float* rays_o, float* rays_d, float* out_color, float* out_depth,
+                gs_stream_t stream);
+
 /* The mapper's loss without the eikonal term (src/mapping.py:96-132 + InstantNeuS.compute_sdf_error,
  * src/InstantNeuS.py:372-400) and its gradient, one launch.  Rays with rays_depth <= 0 are masked out.
  *   loss_rays[r] = ( w_color |c - c*|_1 / 3 + |d - d*| uw + w_sdf (e_r + f_r) ) / counts[0]

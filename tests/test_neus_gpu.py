@@ -1199,3 +1199,63 @@ def test_renderer_consumes_the_device_generator_like_the_reference(N, dev):
     pooled = [Rp._perturb_row(24, dev).clone() for _ in range(3)]
     assert not all(torch.equal(a, b) for a, b in zip(pooled, ref))
     assert float(torch.stack(pooled).min()) >= 0.0 and float(torch.stack(pooled).max()) < 1.0
+
+
+@pytest.mark.parametrize("H,W,F,n_rays", [(24, 40, 5, 37), (480, 640, 20, 220)])
+def test_ray_bank_device_draw_equals_build_rays(N, dev, H, W, F, n_rays):
+    """neus/rays.RayBank on the device (the reference's randint calls + ONE gs_ray_draw launch) against build_rays called
+    frame by frame on the device (src/nerf_func.py:115-181, src/mapping.py:222-240) under the same seed: the same pixels --
+    origins, colours, depths bit for bit, directions to fp32 rounding of the 3 x 3 product -- with ragged masks, a frame
+    without a mask, repeated frames, a numpy pose; and the same generator consumption (the next draw after either is
+    the same)."""
+    import numpy as np
+    from go_slam_amd.neus import rays as R
+    g = torch.Generator().manual_seed(5)
+    fx, fy, cx, cy = 0.9 * W, 0.91 * W, W / 2 - 0.5, H / 2 - 0.5
+    items = {}
+    for f in range(F):
+        c2w = torch.eye(4)
+        q = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+        c2w[:3, :3], c2w[:3, 3] = q, torch.randn(3, generator=g)
+        mask = (torch.rand(H, W, generator=g) < (0.3 + 0.6 * f / F)).float().to(dev) if f != 2 else None
+        items[10 + f] = (torch.rand(H, W, 3, generator=g).to(dev), (torch.rand(H, W, generator=g) * 3 + 0.5).to(dev),
+                         c2w.numpy() if f == 1 else c2w.to(dev), None, mask)
+    bank = R.RayBank(items, H, W, fx, fy, cx, cy, dev)
+    assert bank.fused
+    assert bank.N[2] == H * W and all(0 < n <= H * W for n in bank.N)
+    frames = [10 + k for k in (2, 0, F - 1, 0, 3)] + [10 + k for k in range(F)]
+
+    def per_frame():
+        parts = [[], [], [], []]
+        for f in frames:
+            color, depth, c2w, _, mask = items[f]
+            out = R.build_rays(0, H, 0, W, n_rays, H, W, fx, fy, cx, cy, c2w, depth, color, dev,
+                               nerf_coordinate=False, dir_normalize=False, mask=mask)
+            for acc, x in zip(parts, out):
+                acc.append(x.float())
+        o, d, dep, col = (torch.cat(p, 0) for p in parts)
+        return o, d, col, dep
+    torch.manual_seed(77)
+    want = per_frame()
+    nxt = torch.rand(3, device=dev)
+    torch.manual_seed(77)
+    got = bank.sample(frames, n_rays)
+    assert torch.equal(torch.rand(3, device=dev), nxt)
+    assert got[0].shape == (n_rays * len(frames), 3)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[2]) and torch.equal(got[3], want[3])
+    torch.testing.assert_close(got[1], want[1], rtol=1e-6, atol=1e-6)
+    # the first and the last valid pixel of a frame (ranks 0 and N - 1) land where nonzero puts them
+    p = bank.pos[10]
+    first_last = torch.tensor([[0] * n_rays, [bank.N[p] - 1] * n_rays], dtype=torch.int64, device=dev)
+    keep = torch.nonzero(items[10][4].reshape(-1).bool()).reshape(-1)
+    import go_slam_amd._lib as _lib
+    f32 = dict(dtype=torch.float32, device=dev)
+    o, d, c = (torch.empty(2 * n_rays, 3, **f32) for _ in range(3))
+    z = torch.empty(2 * n_rays, **f32)
+    fp = torch.tensor([p, p], dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().gs_ray_draw(_lib.ptr(first_last), _lib.ptr(fp), _lib.ptr(bank.cum32), _lib.ptr(bank.color),
+                                      _lib.ptr(bank.depth), _lib.ptr(bank.rot_t), _lib.ptr(bank.trans), 2, n_rays, H * W, W,
+                                      fx, fy, cx, cy, _lib.ptr(o), _lib.ptr(d), _lib.ptr(c), _lib.ptr(z),
+                                      _lib.stream_ptr(dev)), "ray_draw")
+    depth10 = items[10][1].reshape(-1)
+    assert torch.equal(z[:n_rays], depth10[keep[0]].expand(n_rays)) and torch.equal(z[n_rays:], depth10[keep[-1]].expand(n_rays))
