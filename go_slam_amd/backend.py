@@ -92,7 +92,9 @@ class Backend:
         if t_start_loop is None or not loop:
             t_start_loop = t_start
         assert t_start_loop >= t_start, f"short: {t_start_loop}, long: {t_start}."
-        ii, jj = torch.meshgrid(torch.arange(t_start_loop, t_end), torch.arange(t_start, t_end), indexing="ij")
+        vdev = torch.device(self.device)         # (built on the device: a host grid is two blocking uploads per call)
+        ii, jj = torch.meshgrid(torch.arange(t_start_loop, t_end, device=vdev), torch.arange(t_start, t_end, device=vdev),
+                                indexing="ij")
         d = self.video.distance(ii.reshape(-1), jj.reshape(-1), beta=self.beta)
         stereo = bool(getattr(self.video, "stereo", False))
         if d.is_cuda and (t_end - t_start_loop) * (t_end - t_start) <= 512 * 512:

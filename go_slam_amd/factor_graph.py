@@ -21,6 +21,37 @@ def coords_grid(ht, wd, device):
     return torch.stack([x, y], dim=-1)
 
 
+def upload_tables(host, device):
+    """{name: host tensor | other} -> the same dict with every tensor on `device`, through ONE host-to-device copy per dtype
+    (the pieces are views into one buffer, each starting on a 16-byte boundary).  A `.to(device)` of a pageable host tensor
+    is a blocking copy enqueued behind everything the stream holds: nine of them per edge-set change (the edge index) and
+    six per 13-keyframe chunk (the loop-closure BA's chunk index) were that many pipeline drains per keyframe."""
+    out = dict(host)
+    if torch.device(device).type == "cpu":
+        return out
+    if os.environ.get("GOSLAM_BATCH_UPLOADS", "1") == "0":      # (A/B runs: one blocking copy per table, the round-5 form)
+        return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in host.items()}
+    groups = {}
+    for k, v in host.items():
+        if torch.is_tensor(v):
+            groups.setdefault(v.dtype, []).append(k)
+    for dt, keys in groups.items():
+        per16 = max(1, 16 // torch.empty(0, dtype=dt).element_size())
+        pieces, spans, off = [], [], 0
+        for k in keys:
+            n = host[k].numel()
+            pad = (-n) % per16
+            pieces.append(host[k].reshape(-1))
+            if pad:
+                pieces.append(torch.zeros(pad, dtype=dt))
+            spans.append((k, off, n))
+            off += n + pad
+        flat = torch.cat(pieces).to(device) if off else torch.zeros(0, dtype=dt, device=device)
+        for k, o, n in spans:
+            out[k] = flat[o:o + n].view(host[k].shape)
+    return out
+
+
 class FactorGraph:
     def __init__(self, video, update_op, device="cuda:0", corr_impl="volume", max_factors=-1, upsample=False,
                  channels_last=True):
@@ -74,25 +105,31 @@ class FactorGraph:
         a0 = max(1, int(ii_c.min()) + 1) if t0 is None else t0
         a0 = max(1, a0)
         a1 = (max(int(ii_c.max()), int(jj_c.max())) + 1) if t1 is None else t1
-        seg = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in build_segments(ii_c).items()}
-        c = {"key": key, "tens": tens, "t0": a0, "t1": a1, "seg": seg, "sel": None, "ii_min": int(ii_c.min())}
+        seg_h = build_segments(ii_c)
+        c = {"key": key, "tens": tens, "t0": a0, "t1": a1, "seg": None, "sel": None, "ii_min": int(ii_c.min())}
+        up = {"seg." + k: v for k, v in seg_h.items() if torch.is_tensor(v)}       # everything below goes up in ONE copy per dtype
         ii_all = ii_c
         if use_inactive:
             iin, jin = host[2 * E:2 * E + Ei], host[2 * E + Ei:]
             m = (iin >= a0 - 3) & (jin >= a0 - 3)
-            c["sel"] = torch.nonzero(m).reshape(-1).to(dev)
+            up["sel"] = torch.nonzero(m).reshape(-1)
             ii_all = torch.cat([iin[m], ii_c])
-            c["ii"] = ii_all.to(dev)
-            c["jj"] = torch.cat([jin[m], jj_c]).to(dev)
+            up["ii"] = ii_all
+            up["jj"] = torch.cat([jin[m], jj_c])
         else:
             c["ii"], c["jj"] = self.ii.contiguous(), self.jj.contiguous()
         dindex = torch.unique(torch.cat([torch.arange(a0, a1), ii_all]), sorted=True)
-        c["damping_index"] = dindex.to(dev)
+        up["damping_index"] = dindex
         # row of the operator's eta output (one per unique source keyframe of the ACTIVE edges) for every damping row
         uniq = torch.unique(ii_c, sorted=True)
         pos = torch.searchsorted(uniq, dindex).clamp_(max=max(uniq.numel() - 1, 0))
         inv = torch.where(uniq[pos] == dindex, pos, torch.full_like(pos, -1)) if uniq.numel() else torch.full_like(dindex, -1)
-        c["damping_inv"] = inv.to(torch.int32).to(dev)
+        up["damping_inv"] = inv.to(torch.int32)
+        up = upload_tables(up, dev)
+        c["seg"] = {k: (up["seg." + k] if torch.is_tensor(v) else v) for k, v in seg_h.items()}
+        for k in ("sel", "ii", "jj", "damping_index", "damping_inv"):
+            if k in up:
+                c[k] = up[k]
         c["uniq_host"] = uniq
         self._eidx = c
         return c
@@ -234,7 +271,11 @@ class FactorGraph:
     @torch.no_grad()
     def clear_edges(self):
         """src/factor_graph.py:79-82"""
-        self.rm_factors(self.ii >= 0)
+        if self.ii.numel():                     # every edge goes: nothing to read back (the reference's mask form costs a
+            if self.corr_impl == "volume" and self.corr is not None:                 # reduction and a host sync)
+                self.corr = self.corr[torch.zeros(0, dtype=torch.long, device=self.ii.device)]
+            self.ii, self.jj, self.age = (x.new_empty((0,)) for x in (self.ii, self.jj, self.age))
+            self.target, self.weight = (x.new_empty((x.shape[0], 0) + tuple(x.shape[2:])) for x in (self.target, self.weight))
         self.net = None
         self.inp = None
 
@@ -352,7 +393,8 @@ class FactorGraph:
         t = max_t if max_t is not None else int(getattr(cnt, "value", cnt))
         if t <= t0 or t <= t1:
             return
-        ii, jj = torch.meshgrid(torch.arange(t0, t), torch.arange(t1, t), indexing="ij")
+        vdev = torch.device(self.device)         # (index grids built where they are used: a host grid is two blocking uploads)
+        ii, jj = torch.meshgrid(torch.arange(t0, t, device=vdev), torch.arange(t1, t, device=vdev), indexing="ij")
         ii, jj = ii.reshape(-1), jj.reshape(-1)
         d_dev = self.video.distance(ii, jj, beta=beta)
         if d_dev.is_cuda and (t - t0) * (t - t1) <= 512 * 512:
@@ -363,6 +405,7 @@ class FactorGraph:
                 self.add_factors(e[:, 0].contiguous(), e[:, 1].contiguous(), remove)
             return
         d = d_dev.detach().float().cpu()
+        ii, jj = ii.cpu(), jj.cpu()
         d[ii - rad < jj] = float("inf")
         d[d > 100] = float("inf")
         d = d.reshape(t - t0, t - t1).numpy().copy()
@@ -475,16 +518,23 @@ class FactorGraph:
         a0 = max(1, int(ii_c.min()) + 1) if t0 is None else t0
         a0 = max(1, a0)
         a1 = (max(int(ii_c.max()), int(jj_c.max())) + 1) if t1 is None else t1
-        chunks = []
+        chunks, up, segs = [], {}, []
         s = 13
         for i in range(int(ii_c.min()), int(ii_c.max()) + 1, s):
             sel = torch.nonzero((ii_c >= i) & (ii_c < i + s)).reshape(-1)
             if sel.numel() < 1:
                 continue
             iis, jjs = ii_c[sel], jj_c[sel]
-            ck = {"sel": sel.to(dev), "ii": iis.to(dev), "jj": jjs.to(dev), "corr_ii": (rig * iis).to(dev),
-                  "corr_jj": (rig * jjs + (iis == jjs).long()).to(dev), "uniq": torch.unique(iis, sorted=True).to(dev)}
-            seg = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in build_segments(iis).items()}
+            n = len(segs)
+            up.update({f"{n}.sel": sel, f"{n}.ii": iis, f"{n}.jj": jjs, f"{n}.corr_ii": rig * iis,
+                       f"{n}.corr_jj": rig * jjs + (iis == jjs).long(), f"{n}.uniq": torch.unique(iis, sorted=True)})
+            segs.append(build_segments(iis))
+            up.update({f"{n}.seg.{k}": v for k, v in segs[-1].items() if torch.is_tensor(v)})
+        up["damping_index"] = torch.unique(torch.cat([torch.arange(a0, a1), ii_c]), sorted=True)
+        up = upload_tables(up, dev)                     # every chunk's tables in ONE copy per dtype
+        for n, seg_h in enumerate(segs):
+            ck = {k: up[f"{n}.{k}"] for k in ("sel", "ii", "jj", "corr_ii", "corr_jj", "uniq")}
+            seg = {k: (up[f"{n}.seg.{k}"] if torch.is_tensor(v) else v) for k, v in seg_h.items()}
             ck["seg_kw"] = {"seg": seg} if getattr(self.update_op, "_forward_fast", None) is not None else {}
             # (the chunk's context features are per-keyframe constants: gathered and laid out once per edge set -- the
             # index cache is rebuilt whenever an edge list or, through rm_keyframe, a keyframe slot changes -- instead of
@@ -499,8 +549,7 @@ class FactorGraph:
             ck["inp"] = _inp
             chunks.append(ck)
         c = {"key": key, "tens": tens, "t0": a0, "t1": a1, "chunks": chunks, "ii": self.ii.contiguous(),
-             "jj": self.jj.contiguous(),
-             "damping_index": torch.unique(torch.cat([torch.arange(a0, a1), ii_c]), sorted=True).to(dev)}
+             "jj": self.jj.contiguous(), "damping_index": up["damping_index"]}
         self._lidx = c
         return c
 

@@ -72,6 +72,7 @@ class Frontend:
         self.enable_loop, self.max_age, self.iters1, self.iters2 = o.enable_loop, o.max_age, o.iters_first, o.iters_second
         self.loop_closing = LoopClosing(net, video, args, cfg)
         self.last_loop_t = -1
+        self.device = args.device
         self.graph = FactorGraph(video, net.update, device=args.device, corr_impl="volume", max_factors=o.max_factors,
                                  upsample=o.upsample)
         self.t0 = self.t1 = 0            # local optimisation window [t0, t1)
@@ -97,7 +98,11 @@ class Frontend:
 
     def _moved_enough(self):
         """the one host read of a keyframe: mean flow between the two newest keyframes vs keyframe_thresh"""
-        d = self.video.distance([self.t1 - 3], [self.t1 - 2], beta=self.opt.beta, bidirectional=True)
+        ar = getattr(self, "_arange", None)     # (views of a device arange: two index lists would be two blocking uploads)
+        if ar is None or ar.numel() <= self.t1:
+            ar = self._arange = torch.arange(2 * (self.t1 + 64), device=torch.device(self.device))
+        d = self.video.distance(ar[self.t1 - 3:self.t1 - 2], ar[self.t1 - 2:self.t1 - 1], beta=self.opt.beta,
+                                bidirectional=True)
         return float(d) >= self.opt.keyframe_thresh
 
     def _drop_previous_keyframe(self):

@@ -63,6 +63,49 @@ if "--ops" in sys.argv:
     print(json.dumps(res, indent=1))
     sys.exit(0)
 
+if "--copies" in sys.argv:                           # WHERE the host <-> device copies and scalar reads of a keyframe come from
+    import traceback
+    from collections import Counter
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    class CopyTracer(TorchDispatchMode):
+        def __init__(self):
+            super().__init__()
+            self.sites = Counter()
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func.name())
+            kind = None
+            if name == "aten::_to_copy" and torch.is_tensor(args[0]):
+                dst = (kwargs or {}).get("device")
+                if dst is not None and torch.device(dst).type != args[0].device.type:
+                    kind = "H2D" if args[0].device.type == "cpu" else "D2H"
+            elif name in ("aten::_local_scalar_dense", "aten::nonzero", "aten::item"):
+                kind = name.split("::")[1]
+            elif name in ("aten::lift_fresh", "aten::scalar_tensor"):
+                kind = None
+            if kind is not None:
+                fr = [f for f in traceback.extract_stack() if "go_slam_amd" in f.filename or "bench.py" in f.filename]
+                site = " < ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in fr[-3:][::-1])
+                self.sites[(kind, site)] += 1
+            return func(*args, **(kwargs or {}))
+    tr = CopyTracer()
+    for _ in range(n_kf):
+        if "--frames" in sys.argv:                   # the four MotionFilter.track calls instead of the frontend
+            with tr:
+                frame_stage()
+        else:
+            frame_stage()
+        torch.cuda.synchronize()
+        if "--frames" in sys.argv:
+            fe()
+        else:
+            with tr:
+                fe()
+        torch.cuda.synchronize()
+    print(json.dumps([[k[0], k[1], round(v / n_kf, 2)] for k, v in tr.sites.most_common(60)], indent=0))
+    sys.exit(0)
+
 if "--cprofile" in sys.argv:                         # where the HOST time of a keyframe goes (no device sync inside)
     import cProfile
     import io
