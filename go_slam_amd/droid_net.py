@@ -588,13 +588,21 @@ class UpdateModule(nn.Module):
         w = (torch.arange(flat.numel(), device=flat.device, dtype=torch.int64) % 8191) + 1      # position-sensitive
         return int((flat.to(torch.int64) * w).sum())
 
+    _device_caps = {}               # device index -> an eighth of its memory (asked ONCE: the driver query takes tens to
+                                    # hundreds of microseconds and this runs on every edge-set change)
+
     def _cache_cap(self, device):
         cap = self.INP_CACHE_BYTES
         if device.type == "cuda":
-            try:
-                cap = min(cap, torch.cuda.mem_get_info(device)[1] // 8)
-            except RuntimeError:
-                pass
+            idx = device.index if device.index is not None else torch.cuda.current_device()
+            dev_cap = UpdateModule._device_caps.get(idx)
+            if dev_cap is None:
+                try:
+                    dev_cap = torch.cuda.mem_get_info(device)[1] // 8
+                except RuntimeError:
+                    dev_cap = cap
+                UpdateModule._device_caps[idx] = dev_cap
+            cap = min(cap, dev_cap)
         return cap
 
     def _edge_state(self, inp, n, ht, wd):

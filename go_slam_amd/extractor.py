@@ -14,6 +14,8 @@ What this module adds for MI355X:
     `relu(skip + y)` -- in the three launches of `gs_norm_act` (csrc/instnorm.hip; one without the norm) instead of
     torch's 6-8 including the bias add: 200 launches per input frame become ~115, with the rounding points of the fp16 tensors the reference materialises.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -21,6 +23,9 @@ import torch.nn.functional as F
 DIM = 32
 FAST_ENCODER = True         # module constant, not an environment switch: tests flip it to compare the two paths
 OWN_ENC_CONV = True         # gs_enc_conv for the encoder's convolutions (False: MIOpen NHWC fp16, the tests' referee)
+# the inference path as ONE hipGraph per (input shape, weight version): ~60 launches of 3-17 us per input frame replayed
+# back to back instead of enqueued one by one (GOSLAM_ENCODER_GRAPHS=0: always eager)
+ENCODER_GRAPHS = os.environ.get("GOSLAM_ENCODER_GRAPHS", "1") != "0"
 _ENC_SHAPES = {(7, 4, 32, 2), (3, 32, 32, 1), (3, 32, 64, 2), (3, 64, 64, 1), (3, 64, 128, 2), (3, 128, 128, 1),
                (1, 32, 64, 2), (1, 64, 128, 2), (1, 128, 128, 1), (1, 128, 256, 1)}    # (k, c_in, c_out, stride) built
 
@@ -301,11 +306,55 @@ class BasicEncoder(nn.Module):
                 y = _norm_act(t, skip, inst, True, True, b, ch)
         return self._conv(self.conv2, y)
 
+    def _weights_key(self):
+        ps = self.__dict__.get("_graph_params")
+        if ps is None:
+            ps = self.__dict__["_graph_params"] = list(self.parameters())
+        return sum(p._version for p in ps), sum(p.data_ptr() for p in ps)
+
+    def _forward_graphed(self, x):
+        """_forward_fast(x) replayed from a hipGraph: captured per (input shape, dtype, device, weight versions and
+        addresses) after two eager calls (workspaces, packed weights); the input is copied into the graph's static
+        buffer and the result is returned as a fresh tensor (the static output is overwritten by the next replay).  A
+        capture that fails (a library fallback that allocates with the driver, a foreign stream state) is recorded in
+        `graph_error` and the shape stays eager."""
+        graphs = self.__dict__.setdefault("_graphs", {})
+        key = (tuple(x.shape), x.dtype, x.device, torch.is_autocast_enabled()) + self._weights_key()
+        ent = graphs.get(key)
+        if ent is None:
+            if len(graphs) >= 4:                        # old weight versions / shapes: drop their graphs and pools
+                graphs.clear()
+            ent = graphs[key] = {"warm": 0, "graph": None, "failed": False}
+        if ent["failed"]:
+            return self._forward_fast(x)
+        if ent["graph"] is None:
+            if ent["warm"] < 2:
+                ent["warm"] += 1
+                return self._forward_fast(x)
+            try:
+                static_in = torch.empty_like(x, memory_format=torch.contiguous_format)
+                static_in.copy_(x)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    static_out = self._forward_fast(static_in)
+                ent.update(graph=g, inp=static_in, out=static_out)
+            except Exception as exc:                    # noqa: BLE001 -- whatever refused the capture: this shape stays eager
+                ent["failed"] = True
+                self.graph_error = repr(exc)[:300]
+                torch.cuda.synchronize(x.device)
+                return self._forward_fast(x)
+        ent["inp"].copy_(x)
+        ent["graph"].replay()
+        return ent["out"].clone()
+
     def forward(self, x):
         b, n = x.shape[:2]
         x = x.reshape(b * n, *x.shape[2:])
         if self._fast_ok(x):
-            x = self._forward_fast(x)
+            if ENCODER_GRAPHS and OWN_ENC_CONV and not torch.cuda.is_current_stream_capturing():
+                x = self._forward_graphed(x)
+            else:
+                x = self._forward_fast(x)
             return x.view(b, n, *x.shape[1:])
         if x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)

@@ -795,6 +795,42 @@ def test_encoder_inference_path_matches_module_path(built_lib):
     assert ef <= 1e-2 * sf, (ef, sf)        # 1-ulp flips of normalised activations through 10 layers
 
 
+def test_encoder_graph_replay_equals_the_eager_inference_path(built_lib):
+    """BasicEncoder's inference path replayed from a hipGraph (extractor._forward_graphed: captured on the third call of
+    a shape) against the same launches enqueued one by one: bit for bit on fresh inputs, for fnet (instance norm: the
+    statistics workspace is part of the capture) and cnet, at the tracker's 480 x 640; the results are tensors of their
+    own (a later replay does not overwrite an earlier result); an in-place weight edit re-captures."""
+    from go_slam_amd import extractor as EX
+    from go_slam_amd.droid_net import DroidNet
+    dev = "cuda:0"
+    torch.manual_seed(72)
+    net = DroidNet().to(dev).eval()
+    xs = [torch.rand(1, 1, 3, 480, 640, device=dev) * 2 - 1 for _ in range(5)]
+    assert EX.ENCODER_GRAPHS
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        EX.ENCODER_GRAPHS = False
+        try:
+            want = [(net.fnet(x), net.cnet(x)) for x in xs]
+        finally:
+            EX.ENCODER_GRAPHS = True
+        got = [(net.fnet(x), net.cnet(x)) for x in xs]         # calls 1-2 eager, 3 captures + replays, 4-5 replay
+        for enc in (net.fnet, net.cnet):
+            ents = list(enc._graphs.values())
+            assert len(ents) == 1 and ents[0]["graph"] is not None and not ents[0]["failed"], getattr(enc, "graph_error", None)
+        for (f, c), (fw, cw) in zip(got, want):
+            assert torch.equal(f, fw) and torch.equal(c, cw)
+        assert len({t.data_ptr() for pair in got for t in pair}) == 10
+        net.fnet.conv2.bias.add_(0.25)                          # a weight edit: a new graph, the new result
+        f_new = [net.fnet(xs[0]) for _ in range(4)][-1]
+        EX.ENCODER_GRAPHS = False
+        try:
+            f_ref = net.fnet(xs[0])
+        finally:
+            EX.ENCODER_GRAPHS = True
+        assert torch.equal(f_new, f_ref) and not torch.equal(f_new, want[0][0])
+        assert len(net.fnet._graphs) == 2
+
+
 def _rand_dist(ilen, jlen, seed, scale):
     g = torch.Generator().manual_seed(seed)
     d = torch.rand(ilen, jlen, generator=g) * scale
