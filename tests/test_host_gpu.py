@@ -351,3 +351,27 @@ def test_conv1x1_kernel(built_lib, k_in, n_out, act):
         ref = torch.relu(ref)
     assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
     torch.testing.assert_close(got.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_index_tables_upload_in_one_copy_per_dtype_and_equal_the_per_tensor_form(built_lib):
+    """factor_graph.upload_tables (the edge index's and the loop-closure chunk index's tables in ONE host-to-device copy
+    per dtype) against `.to(device)` per tensor: equal values, shapes and dtypes, every piece on a 16-byte boundary of
+    one buffer per dtype, empty tables and non-tensor entries passed through.  (What the edge index and the chunk index
+    put into the tables is pinned on the CPU: tests/test_factor_graph_cpu.py::test_edge_index_matches_reference_logic,
+    ::test_lowmem_index_chunks_and_cache.)"""
+    from go_slam_amd import factor_graph as FG
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    host = {"a": torch.randint(0, 99, (7,), generator=g), "b": torch.zeros(0, dtype=torch.long), "n": 5,
+            "c": torch.randint(0, 9, (3, 5), generator=g).to(torch.int32), "d": torch.arange(13),
+            "e": torch.randint(0, 9, (1,), generator=g).to(torch.int32), "f": torch.rand(6, generator=g)}
+    up = FG.upload_tables(host, dev)
+    assert up["n"] == 5 and set(up) == set(host)
+    for k, v in host.items():
+        if torch.is_tensor(v):
+            assert up[k].device.type == "cuda" and up[k].dtype == v.dtype and up[k].shape == v.shape
+            assert torch.equal(up[k].cpu(), v)
+            assert v.numel() == 0 or up[k].data_ptr() % 16 == 0
+    base = {k: up[k].untyped_storage().data_ptr() for k in ("a", "d")}
+    assert len(set(base.values())) == 1                           # one buffer for the int64 tables
+    assert up["c"].untyped_storage().data_ptr() == up["e"].untyped_storage().data_ptr()
