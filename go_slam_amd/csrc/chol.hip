@@ -3,13 +3,16 @@
 //   L = A;  diag(L) += ep + lm * diag(L);  LLT;  x = solve(b);  failure (pivot <= 0) => x = 0.
 //
 // The (6P x 6P) matrix lives in HBM/L2 as a dense row-major fp64 array whose LOWER triangle is
-// valid.  Right-looking blocked factorisation, NB = 32:
-//   chol_panel_kernel   : every workgroup (one wave) re-factors the 32x32 diagonal block in LDS
-//                         (cheaper than a dependent launch) and solves 64 rows of the panel
-//   chol_trail_kernel   : 64x64 tiles of the trailing matrix, A22 -= L21 L21^T, operands in LDS
+// valid.  Right-looking blocked factorisation, NB = 32, ONE launch per panel (round 6):
+//   chol_panel_kernel   : panel 0 -- every workgroup (one wave) re-factors the 32x32 diagonal block (cheaper than a
+//                         dependent launch) and solves 64 rows of the panel
+//   chol_step_kernel    : panel k + 1 AND the trailing update of panel k in the same launch: the panel workgroups apply
+//                         panel k's rank-32 update to their own 32 columns themselves (v_mfma_f64_16x16x4), the tile
+//                         workgroups update what lies beyond those columns (64x64 tiles, operands in LDS)
 //   chol_back_block_kernel : backward substitution, one launch per 64-wide block (b rides along as row n of the
 //                         factorisation, so the forward substitution is free), writes fp32 dx
-// 2 launches per panel + 1 per 64 unknowns; 6P = 1200 (global BA) is 38 panels.
+// 1 launch per panel + 1 per 64 unknowns; 6P = 1194 (global BA) is 38 + 19 launches, 1.14 ms (1.64 ms as 76 + 19 launches
+// with the right-looking diagonal factor of rounds 3-5; tools/chol_bench.hip times both forms).
 #include "common.h"
 
 namespace {
@@ -47,14 +50,67 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double& s, double& rs) {
   s = g; rs = h + h;
 }
 
+constexpr int DS = NB + 2;  // row stride of the factored diagonal block in LDS: even, so that a row's entries can be read in
+                            // 16-byte pairs (every read of it is a broadcast: the stride needs no bank padding)
+
+// The 32x32 diagonal factorisation of a panel by ONE wave, lane i = row i (32 doubles in registers), LEFT-looking:
+//   step j:  s_i = a_i[j] - sum_{t<j} L[i][t] L[j][t]   (the lane's own finished entries x row j of L)
+//            L[j][j] = sqrt(s_j),  L[i][j] = s_i / L[j][j]  (i > j)
+// Row j of L is read from LDS as broadcasts, two entries per ds_read_b128 -- every lane files L[i][j] there as soon as it
+// has it -- and only the pivot travels through v_readlane.  The right-looking form this replaces (rounds 3-5) updated
+// every remaining column after every pivot with the column entry fetched by two v_readlane per (pivot, column): 496 x
+// (2 readlane + multiply-add + lane mask) = ~3000 instructions behind each other, ~10 us of the panel kernel's 21.5 and,
+// 38 panels deep, the longest link of the 6P = 1194 solve's dependency chain; here ~500 multiply-adds and ~250 LDS reads.
+// Lanes >= nb carry identity rows.  Leaves L11 in D (lower triangle; lanes >= NB store nothing) and 1 / diag in Dinv.
+__device__ __forceinline__ void panel_diag_factor(double (&a)[NB], int nb, int lane, bool& bad, double (*D)[DS],
+                                                  double* Dinv) {
+  typedef double double2v __attribute__((ext_vector_type(2)));
+  double mydiag = 1.0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    double s0 = a[j], s1 = 0.0;
+#pragma unroll
+    for (int t = 0; t + 1 < j; t += 2) {
+      const double2v d = *reinterpret_cast<const double2v*>(&D[j][t]);
+      s0 = fma(-a[t], d[0], s0);
+      s1 = fma(-a[t + 1], d[1], s1);
+    }
+    if (j & 1) s0 = fma(-a[j - 1], D[j][j - 1], s0);
+    const double s = s0 + s1;
+    const double piv = readlane_f64(s, j);
+    if (j < nb && !(piv > 0.0) && piv == piv) bad = true;   // pivot <= 0 (NaN falls through like Eigen)
+    double dj, rdj;                         // (rsq + two Goldschmidt steps: ~12 dependent FMAs instead of sqrt + divide)
+    sqrt_rsqrt(piv, dj, rdj);
+    a[j] = lane == j ? dj : (lane > j ? s * rdj : 0.0);
+    if (lane == j) mydiag = dj;
+    if (lane < NB) D[lane][j] = a[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (one wave: its LDS operations retire in order; this only
+    __builtin_amdgcn_wave_barrier();                            // keeps the compiler from moving the next step's reads up)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if (lane < NB) Dinv[lane] = 1.0 / mydiag;
+}
+
+// one panel row: x = a L11^-T (forward substitution against the factored diagonal block in LDS)
+__device__ __forceinline__ void panel_row_solve(double (&x)[NB], int nb, double (*D)[DS], const double* Dinv) {
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    if (c < nb) {
+      double s = x[c];
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+        if (t < c) s -= x[t] * D[c][t];
+      x[c] = s * Dinv[c];
+    }
+  }
+}
+
 // Factor the diagonal block [k0,k0+nb) (every workgroup redundantly -- cheaper than a dependent
 // launch) and compute L21 = A21 * L11^-T for this workgroup's PR rows.
-// The 32x32 factorisation is wave-synchronous and register-resident: lane i holds row i
-// (32 doubles), pivots and column entries are broadcast with v_readlane, no LDS, no barriers
-// (~1.5 us instead of 32 x 3 barrier-separated LDS sweeps).
 __global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ A, double* __restrict__ bvec, int n, int k0,
                                                         int32_t* fail_flag) {
-  __shared__ double D[NB][NB + 1];
+  __shared__ __attribute__((aligned(16))) double D[NB][DS];
+  __shared__ double Dinv[NB];
   const int lane = threadIdx.x;
   const int nb = min(NB, n - k0);
   double a[NB];
@@ -70,29 +126,7 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ A, 
     }
   }
   bool bad = false;
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const double piv = readlane_f64(a[j], j);
-    if (j < nb && !(piv > 0.0) && piv == piv) bad = true;   // pivot <= 0 (NaN falls through like Eigen)
-    double dj, rdj;                         // (rsq + two Goldschmidt steps: ~12 dependent FMAs instead of sqrt + divide)
-    sqrt_rsqrt(piv, dj, rdj);
-    if (lane == j) a[j] = dj;
-    else if (lane > j) a[j] = a[j] * rdj;
-#pragma unroll
-    for (int c = j + 1; c < NB; ++c) {
-      const double lcj = readlane_f64(a[j], c);
-      if (lane >= c) a[c] -= a[j] * lcj;
-    }
-  }
-  __shared__ double Dinv[NB];
-  if (lane < NB) {
-#pragma unroll
-    for (int c = 0; c < NB; ++c) D[lane][c] = a[c];
-    double dg = 1.0;                        // this row's own diagonal entry (statically indexed select)
-#pragma unroll
-    for (int c = 0; c < NB; ++c) dg = (c == lane) ? a[c] : dg;
-    Dinv[lane] = 1.0 / dg;
-  }
+  panel_diag_factor(a, nb, lane, bad, D, Dinv);
   __syncthreads();
   if (blockIdx.x == 0) {
     if (lane < nb) {
@@ -111,34 +145,22 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ A, 
     double* Ar = row < n ? A + (size_t)row * n + k0 : bvec + k0;
 #pragma unroll
     for (int c = 0; c < NB; ++c) x[c] = (c < nb) ? Ar[c] : 0.0;
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      if (c < nb) {
-        double s = x[c];
-#pragma unroll
-        for (int t = 0; t < NB; ++t)
-          if (t < c) s -= x[t] * D[c][t];
-        x[c] = s * Dinv[c];
-      }
-    }
+    panel_row_solve(x, nb, D, Dinv);
 #pragma unroll
     for (int c = 0; c < NB; ++c)
       if (c < nb) Ar[c] = x[c];
   }
 }
 
-// A22[r][c] -= sum_k L21[r][k] L21[c][k] over lower tiles of the trailing matrix.
-__global__ __launch_bounds__(256) void chol_trail_kernel(double* __restrict__ A, double* __restrict__ bvec, int n, int k0,
-                                                         int nb) {
-  __shared__ double Lr[TT][NB + 1];
-  __shared__ double Lc[TT][NB + 1];
+// A22[r][c] -= sum_k L21[r][k] L21[c][k] over ONE 64x64 lower tile `t` of the matrix that starts at row / column s0 (the
+// b row, row n, included), L21 = columns [k0, k0 + nb); operands staged in LDS (Lr, Lc: [TT][NB + 1] each).
+__device__ __forceinline__ void trail_tile(double* __restrict__ A, double* __restrict__ bvec, int n, int k0, int nb, int s0,
+                                           int t, double (*Lr)[NB + 1], double (*Lc)[NB + 1]) {
   // decode (ti,tj), tj <= ti, from the flat lower-triangular tile index
-  const int t = blockIdx.x;
   int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
   while (ti * (ti + 1) / 2 > t) --ti;
   const int tj = t - ti * (ti + 1) / 2;
-  const int s0 = k0 + nb;
   const int r0 = s0 + ti * TT, c0 = s0 + tj * TT;
   const int tid = threadIdx.x;
   for (int idx = tid; idx < TT * NB; idx += 256) {
@@ -176,6 +198,134 @@ __global__ __launch_bounds__(256) void chol_trail_kernel(double* __restrict__ A,
         else bvec[c] -= acc[i][j];
       }
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void chol_trail_kernel(double* __restrict__ A, double* __restrict__ bvec, int n, int k0,
+                                                         int nb) {
+  __shared__ double Lr[TT][NB + 1];
+  __shared__ double Lc[TT][NB + 1];
+  trail_tile(A, bvec, n, k0, nb, k0 + nb, blockIdx.x, Lr, Lc);
+}
+
+// ONE launch per panel step (round 6): the trailing update of panel kp and the factorisation of panel kp + NB side by
+// side.  The two-launch form (panel, then trailing update, 38 times at 6P = 1194) is a chain of 76 kernels each bound by
+// its own latency (launch, a dependent load round trip, the 32-pivot chain, a store round trip); but panel kp + NB only
+// needs panel kp's rank-32 update on ITS OWN 32 columns, so:
+//   workgroups [0, n_panel)        factor panel c1 = kp + NB after applying that PENDING update to the diagonal block and to
+//                                  their own 64 rows themselves (Lp Lp^T and Lr Lp^T on v_mfma_f64_16x16x4, operands and
+//                                  results through LDS: lane = row layouts on both sides of the matrix cores), one wave each;
+//   workgroups [n_panel, ...)      the trailing update of panel kp on what lies right of / below panel c1 (origin s1 = c1 +
+//                                  nb1): tiles that neither read nor write panel c1's columns.
+// Nothing in one role depends on the other inside the launch; the kernel boundary orders step kp after step kp - NB.
+__global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, double* __restrict__ bvec, int n, int kp,
+                                                        int n_panel, int32_t* fail_flag) {
+  extern __shared__ __attribute__((aligned(16))) double step_lds[];
+  const int c1 = kp + NB, nb1 = min(NB, n - c1), s1 = c1 + nb1;
+  if ((int)blockIdx.x >= n_panel) {
+    double (*Lr)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_lds);
+    double (*Lc)[NB + 1] = Lr + TT;
+    trail_tile(A, bvec, n, kp, NB, s1, (int)blockIdx.x - n_panel, Lr, Lc);
+    return;
+  }
+  if (threadIdx.x >= 64) return;                  // the panel role is one wave (lane = row); LDS phases are wave-ordered
+  typedef double double4v __attribute__((ext_vector_type(4)));
+  double (*D)[DS] = reinterpret_cast<double (*)[DS]>(step_lds);                // [NB]  (first: 16-byte aligned rows)
+  double (*Lp)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(D + NB);          // [NB]  rows c1 .. of panel kp's L21
+  double (*Lr)[NB + 1] = Lp + NB;                                               // [PR]  this workgroup's rows of it
+  double (*U)[NB + 1] = Lr + PR;                                                // [PR]  products, lane = row on the way out
+  double* Dinv = reinterpret_cast<double*>(U + PR);                             // [NB]
+  const int lane = threadIdx.x;
+  auto lds_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // ---- everything this wave reads from memory is requested up front: diagonal block row + its L21 row (lanes < NB), own
+  // row of the panel's columns + its L21 row
+  double a[NB], lp[NB], x[NB], lr[NB];
+  {
+    const int r = lane & (NB - 1);
+    const bool live = (lane < NB) && (r < nb1);
+    const double* Ar = A + (size_t)(c1 + (live ? r : 0)) * n;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      double v = (live && c <= r && c < nb1) ? Ar[c1 + c] : 0.0;
+      if (!live && c == r) v = 1.0;            // identity padding keeps the recurrence well-defined
+      a[c] = v;
+      lp[c] = live ? Ar[kp + c] : 0.0;
+    }
+  }
+  const int row = s1 + (int)blockIdx.x * PR + lane;
+  const bool has_row = row <= n;
+  double* Xr = row < n ? A + (size_t)row * n + c1 : bvec + c1;
+  {
+    const double* Lrow = row < n ? A + (size_t)row * n + kp : bvec + kp;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      x[c] = (has_row && c < nb1) ? Xr[c] : 0.0;
+      lr[c] = has_row ? Lrow[c] : 0.0;
+    }
+  }
+  if (lane < NB) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c) Lp[lane][c] = lp[c];
+  }
+#pragma unroll
+  for (int c = 0; c < NB; ++c) Lr[lane][c] = lr[c];
+  lds_sync();
+  // ---- pending update of the diagonal block: a[c] -= sum_k Lp[i][k] Lp[c][k], lower tiles (0,0) (1,0) (1,1)
+  const int m16 = lane & 15, k4 = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int ti = t > 0 ? 1 : 0, tj = t > 1 ? 1 : 0;
+    double4v acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kb = 0; kb < NB / 4; ++kb)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[16 * ti + m16][4 * kb + k4], Lp[16 * tj + m16][4 * kb + k4], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) U[16 * ti + k4 + 4 * q][16 * tj + m16] = acc[q];
+  }
+  lds_sync();
+  if (lane < NB) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      if (c <= lane) a[c] -= U[lane][c];
+  }
+  lds_sync();
+  // ---- pending update of this workgroup's rows: x[c] -= sum_k Lr[row][k] Lp[c][k]
+#pragma unroll
+  for (int ti = 0; ti < PR / 16; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < NB / 16; ++tj) {
+      double4v acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kb = 0; kb < NB / 4; ++kb)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lr[16 * ti + m16][4 * kb + k4], Lp[16 * tj + m16][4 * kb + k4], acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) U[16 * ti + k4 + 4 * q][16 * tj + m16] = acc[q];
+    }
+  lds_sync();
+#pragma unroll
+  for (int c = 0; c < NB; ++c) x[c] -= U[lane][c];
+  // ---- the panel itself, as chol_panel_kernel
+  bool bad = false;
+  panel_diag_factor(a, nb1, lane, bad, D, Dinv);
+  lds_sync();
+  if (blockIdx.x == 0) {
+    if (lane < nb1) {
+      double* Ar = A + (size_t)(c1 + lane) * n + c1;
+#pragma unroll
+      for (int c = 0; c < NB; ++c)
+        if (c <= lane) Ar[c] = a[c];
+    }
+    if (lane == 0 && bad) *fail_flag = 1;
+  }
+  if (has_row) {
+    panel_row_solve(x, nb1, D, Dinv);
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      if (c < nb1) Xr[c] = x[c];
   }
 }
 
@@ -1244,16 +1394,34 @@ int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float*
     return GS_OK;
   }
 #endif
-  for (int k0 = 0; k0 < n; k0 += NB) {
-    const int nb = (n - k0 < NB) ? (n - k0) : NB;
-    const int rem = n - k0 - nb;
-    // rows k0+nb .. n: the matrix rows below the panel AND the b row (n), which rides along
-    chol_panel_kernel<<<gs_cdiv(rem + 1, PR), 64, 0, st>>>(H, b, n, k0, fail_flag);
+#ifdef CHOL_TIMING
+  extern int g_chol_two_launches;                     // tools/chol_bench.hip: the round-5 form (panel, then trailing update)
+  if (g_chol_two_launches) {
+    for (int k0 = 0; k0 < n; k0 += NB) {
+      const int nb = (n - k0 < NB) ? (n - k0) : NB;
+      const int rem = n - k0 - nb;
+      chol_panel_kernel<<<gs_cdiv(rem + 1, PR), 64, 0, st>>>(H, b, n, k0, fail_flag);
+      if (rem > 0) {
+        const int T = gs_cdiv(rem + 1, TT);
+        chol_trail_kernel<<<T * (T + 1) / 2, 256, 0, st>>>(H, b, n, k0, nb);
+      }
+    }
+  } else
+#endif
+  {
+    // panel 0 on its own (rows NB .. n: the matrix rows below the panel AND the b row, which rides along), then ONE launch
+    // per further panel: its factorisation beside the previous panel's trailing update (chol_step_kernel)
+    const int nb0 = n < NB ? n : NB;
+    chol_panel_kernel<<<gs_cdiv(n - nb0 + 1, PR), 64, 0, st>>>(H, b, n, 0, fail_flag);
     GS_CHECK_LAUNCH("chol_panel");
-    if (rem > 0) {
-      const int T = gs_cdiv(rem + 1, TT);
-      chol_trail_kernel<<<T * (T + 1) / 2, 256, 0, st>>>(H, b, n, k0, nb);
-      GS_CHECK_LAUNCH("chol_trail");
+    constexpr size_t step_lds = ((size_t)NB * DS + (size_t)(NB + 2 * PR) * (NB + 1) + NB) * sizeof(double);
+    static_assert(step_lds >= (size_t)2 * TT * (NB + 1) * sizeof(double), "chol_step: the trailing role's operands fit");
+    for (int kp = 0; kp + NB < n; kp += NB) {
+      const int c1 = kp + NB, nb1 = (n - c1 < NB) ? (n - c1) : NB, rem1 = n - c1 - nb1;
+      const int n_panel = gs_cdiv(rem1 + 1, PR);
+      const int T = rem1 > 0 ? gs_cdiv(rem1 + 1, TT) : 0;
+      chol_step_kernel<<<n_panel + T * (T + 1) / 2, 256, step_lds, st>>>(H, b, n, kp, n_panel, fail_flag);
+      GS_CHECK_LAUNCH("chol_step");
     }
   }
   // b now holds y = L^-1 b; backward substitution block by block

@@ -5,6 +5,7 @@
 // also chol_small_kernel's phase stamps.
 #define CHOL_TIMING 1
 int g_chol_force_blocked = 0;
+int g_chol_two_launches = 0;        // 1: the multi-kernel path in its round-5 form (panel launch, then trailing-update launch)
 #include "../go_slam_amd/csrc/chol.hip"
 #include <cstdio>
 #include <vector>
@@ -65,6 +66,28 @@ int main(int argc, char** argv) {
     for (int i = 0; i < n; ++i) dmax2 = fmax(dmax2, fabs((double)xs[2][i] - xs[1][i]));
     printf("n %4d: product dispatch %7.1f us (residual %.3e) | multi-kernel %7.1f us (residual %.3e) | persistent (%d groups) %7.1f us (residual %.3e) | max |x - x_multi| %.3e / %.3e of %.3e, fail flag %d count %d\n",
            n, us[0], residual(A, b, xs[0], n), us[1], residual(A, b, xs[1], n), g_chol_coop_groups, us[2], residual(A, b, xs[2], n), dmax, dmax2, xmax, fl[0], fl[1]);
+    {   // the multi-kernel path in its two-launch form (round 5) against the one-launch-per-panel form that ships
+      g_chol_force_blocked = 1;
+      g_chol_two_launches = 1;
+      float best = 1e9f;
+      for (int rep = 0; rep < 6; ++rep) {
+        hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+        hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        gs_chol_solve_launch(dA, db, n, 1e-4f, 0.1f, dx, flags, flags + 1, flags + 8, 0);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && ms < best) best = ms;
+      }
+      g_chol_two_launches = 0;
+      std::vector<float> x(n); hipMemcpy(x.data(), dx, n * 4, hipMemcpyDeviceToHost);
+      double d2 = 0;
+      for (int i = 0; i < n; ++i) d2 = fmax(d2, fabs((double)x[i] - xs[1][i]));
+      printf("        multi-kernel, two launches per panel (round 5): %7.1f us (residual %.3e), max |x - x_one_launch| %.3e\n",
+             best * 1e3f, residual(A, b, x, n), d2);
+    }
     if (n > 450) {                                    // the persistent path against its workgroup count
       g_chol_force_blocked = 2;
       const int keep = g_chol_coop_groups;
