@@ -442,17 +442,21 @@ def test_ba_rejects_non_contiguous(db, dev):
               False)
 
 
-# 6P -> solver (csrc/chol.hip, gs_chol_solve_launch): <= 192 chol_small (LDS-resident); 193 .. 450 chol_mid, ONE workgroup with
-# head stages of SW = 60 columns up to 6P = 300 and SW = 30 above (mid_tile_product<15> / <8>); above 450 the multi-kernel
-# blocked path.  Every branch and both of its edges, incl. stage counts that leave a ragged last stage (n % SW != 0):
+# 6P -> solver (csrc/chol.hip, gs_chol_solve_launch): <= 192 chol_small (LDS-resident); 193 .. 342 chol_mid, ONE workgroup with
+# head stages of SW = 60 columns up to 6P = 300 and SW = 30 above (mid_tile_product<15> / <8>); above 342 the multi-kernel
+# blocked path (one launch per 32-column panel: chol_panel_kernel, then chol_step_kernel = the next panel beside the previous
+# panel's trailing update).  Every branch and both of its edges, incl. stage counts that leave a ragged last stage
+# (n % SW != 0) and panel counts that leave a ragged last panel (6P % 32 != 0):
 @pytest.mark.parametrize("num_kf,path", [(34, "mid, SW 60, one head stage (6P = 198: six columns past chol_small's cap)"),
                                          (48, "mid, SW 60 (6P = 282, 282 % 60 = 42)"),
                                          (51, "mid, SW 60 at its upper edge (6P = 300)"),
                                          (52, "mid, SW 30 at its lower edge (6P = 306, 306 % 30 = 6)"),
-                                         (58, "mid, SW 30 (6P = 342, 342 % 30 = 12)"),
-                                         (61, "mid, SW 30 (6P = 360)"),
-                                         (76, "mid, SW 30 at its upper edge (6P = 450)"),
-                                         (77, "blocked multi-kernel path at its lower edge (6P = 456)")])
+                                         (58, "mid, SW 30 at its upper edge (6P = 342, 342 % 30 = 12)"),
+                                         (59, "blocked multi-kernel path at its lower edge (6P = 348, 348 % 32 = 28)"),
+                                         (61, "blocked multi-kernel path (6P = 360, 360 % 32 = 8)"),
+                                         (65, "blocked multi-kernel path, whole panels (6P = 384 = 12 x 32)"),
+                                         (76, "blocked multi-kernel path (6P = 450, last panel of 2 columns)"),
+                                         (77, "blocked multi-kernel path (6P = 456)")])
 def test_ba_cholesky_path_for_every_window_size(db, O, dev, num_kf, path):
     """Two Gauss-Newton iterations of `ba` vs the oracle with the pose system going through each solver branch."""
     prob = _ba_problem(O, num_kf, int(5.4 * num_kf), "tiny", seed=37 + num_kf)
