@@ -163,14 +163,41 @@ __device__ __forceinline__ void trail_tile(double* __restrict__ A, double* __res
   const int tj = t - ti * (ti + 1) / 2;
   const int r0 = s0 + ti * TT, c0 = s0 + tj * TT;
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < TT * NB; idx += 256) {
-    const int r = idx / NB, k = idx % NB;
-    // (row n = b^T, stored in bvec)
-    Lr[r][k] = (r0 + r <= n && k < nb) ? (r0 + r < n ? A[(size_t)(r0 + r) * n + (k0 + k)] : bvec[k0 + k]) : 0.0;
-    Lc[r][k] = (c0 + r < n && k < nb) ? A[(size_t)(c0 + r) * n + (k0 + k)] : 0.0;
+  // operands: all sixteen loads of a thread requested before the first LDS write (one load, one wait, one write per
+  // element was 16 dependent round trips at the head of every tile); rows past the end read a valid address and are
+  // zeroed by a select; row n = b^T lives in bvec
+  {
+    constexpr int PER = TT * NB / 256;
+    double vr[PER], vc[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int idx = tid + 256 * u, r = idx / NB, k = idx % NB;
+      const int rr = r0 + r, cc = c0 + r;
+      const double* pr = rr < n ? A + (size_t)rr * n + (k0 + k) : bvec + (k0 + k);
+      const double* pc = A + (size_t)min(cc, n - 1) * n + (k0 + k);
+      vr[u] = *pr;
+      vc[u] = *pc;
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int idx = tid + 256 * u, r = idx / NB, k = idx % NB;
+      Lr[r][k] = (r0 + r <= n && k < nb) ? vr[u] : 0.0;
+      Lc[r][k] = (c0 + r < n && k < nb) ? vc[u] : 0.0;
+    }
   }
   __syncthreads();
   const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;
+  // the tile's current values are requested before the products (they were 16 load - wait - store round trips behind them)
+  double old[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = min(r0 + tr + i, n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = min(c0 + tc + j, n - 1);
+      old[i][j] = r < n ? A[(size_t)r * n + c] : bvec[c];
+    }
+  }
   double acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -194,8 +221,8 @@ __device__ __forceinline__ void trail_tile(double* __restrict__ A, double* __res
     for (int j = 0; j < 4; ++j) {
       const int c = c0 + tc + j;
       if (c <= r && c < n) {
-        if (r < n) A[(size_t)r * n + c] -= acc[i][j];
-        else bvec[c] -= acc[i][j];
+        if (r < n) A[(size_t)r * n + c] = old[i][j] - acc[i][j];
+        else bvec[c] = old[i][j] - acc[i][j];
       }
     }
   }
@@ -351,11 +378,13 @@ __global__ __launch_bounds__(256) void chol_back_block_kernel(const double* __re
   if (tid < 64) {
     const int j = tid;
     const bool live = j < nb;
+    // (the diagonal entry and y are requested WITH the column: behind it they were two more dependent round trips)
+    const double dg = live ? L[(size_t)(k0 + j) * n + k0 + j] : 1.0;
+    double yv = live ? b[k0 + j] : 0.0;
     double c_[SB];                        // column j of the block: L[k0+i][k0+j], i > j
 #pragma unroll
     for (int i = 0; i < SB; ++i) c_[i] = (live && i > j && i < nb) ? L[(size_t)(k0 + i) * n + k0 + j] : 0.0;
-    const double inv_dg = live ? 1.0 / L[(size_t)(k0 + j) * n + k0 + j] : 1.0;
-    double yv = live ? b[k0 + j] : 0.0;
+    const double inv_dg = 1.0 / dg;
 #pragma unroll
     for (int i = SB - 1; i >= 0; --i) {
       const double xi = readlane_f64(yv * inv_dg, i);
@@ -368,13 +397,21 @@ __global__ __launch_bounds__(256) void chol_back_block_kernel(const double* __re
   __syncthreads();
   const int c = blockIdx.x * 256 + tid;
   if (c < k0) {
+    // sixteen rows' entries of this column in flight per round trip (a rolled two-row loop was 32 dependent round trips:
+    // most of this kernel's 15 us); the sums are formed in the same order as before -- even rows, odd rows, then both
     double s0 = 0.0, s1 = 0.0;
-    for (int r = 0; r + 1 < nb; r += 2) {
-      s0 = fma(L[(size_t)(k0 + r) * n + c], xs[r], s0);
-      s1 = fma(L[(size_t)(k0 + r + 1) * n + c], xs[r + 1], s1);
+    const double bc = b[c];
+    for (int r0 = 0; r0 < nb; r0 += 16) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = L[(size_t)(k0 + min(r0 + u, nb - 1)) * n + c];
+#pragma unroll
+      for (int u = 0; u < 16; u += 2) {
+        if (r0 + u < nb) s0 = fma(v[u], xs[r0 + u], s0);
+        if (r0 + u + 1 < nb) s1 = fma(v[u + 1], xs[r0 + u + 1], s1);
+      }
     }
-    if (nb & 1) s0 = fma(L[(size_t)(k0 + nb - 1) * n + c], xs[nb - 1], s0);
-    b[c] -= s0 + s1;
+    b[c] = bc - (s0 + s1);
   }
 }
 
