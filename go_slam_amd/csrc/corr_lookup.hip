@@ -87,17 +87,21 @@ __device__ __forceinline__ void load_window<_Float16>(const _Float16* __restrict
   const int d = min(max(xs - xc, -8), 8);       // s[i] = row[i + d]
   const bool none = (d <= -8) || (d >= 8);
   const int sh = 16 * (d < 0 ? -d : d);
+  // all eight rows are requested before the first one is used, from row indices clamped into the plane (rows outside it
+  // are zeroed by a select afterwards): one load per row behind its own `if (yin)` was eight dependent round trips per
+  // level and lane -- 32 per lookup, most of the single-edge lookup's 27 us in MotionFilter.track
+  typedef struct __attribute__((packed, aligned(2))) { u128 q; } U;
+  u128 raw[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    raw[j] = reinterpret_cast<const U*>(slice + (size_t)min(max(ys + j, 0), h2 - 1) * w2 + xc)->q;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int y1 = ys + j;
     const bool yin = (y1 >= 0) && (y1 < h2) && !none;
-    u128 v = 0;
-    if (yin) {
-      typedef struct __attribute__((packed, aligned(2))) { u128 q; } U;
-      v = reinterpret_cast<const U*>(slice + (size_t)y1 * w2 + xc)->q;
-      if (d > 0) v >>= sh;
-      else if (d < 0) v <<= sh;
-    }
+    u128 v = yin ? raw[j] : (u128)0;
+    if (d > 0) v >>= sh;
+    else if (d < 0) v <<= sh;
     const unsigned long long lo = (unsigned long long)v, hi = (unsigned long long)(v >> 64);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

@@ -27,9 +27,20 @@ __global__ __launch_bounds__(256) void lowmem_gather_kernel(const float2* __rest
   const size_t e = (size_t)sel[r];
   const int p0 = blockIdx.x * 64;
   const int np = min(64, hw - p0);
-  if (threadIdx.x < np) {
-    const int p = p0 + threadIdx.x;
-    const float2 c = coords1[e * hw + p], tg = target[e * hw + p];
+  // the state's four 16-byte pieces per thread are requested FIRST and behind no branch (index clamped, the stores stay
+  // predicated): each behind its own `if`, the compiler waited for one before it issued the next -- the copy of 23 MB per
+  // call ran as four dependent round trips per thread, ~1 TB/s
+  const uint4* src = net + (e * hw + p0) * 16;             // 128 halves = 16 pieces of 16 B per pixel
+  uint4* dst = net_out + ((size_t)r * hw + p0) * 16;
+  uint4 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = src[min((int)threadIdx.x + 256 * k, np * 16 - 1)];
+  const int pc = p0 + min((int)threadIdx.x, np - 1);
+  const float2 c_in = coords1[e * hw + pc], tg_in = target[e * hw + pc];
+  {   // (threads past the tile's last pixel / piece repeat the last one: the same values to the same addresses -- a
+      // predicated store would pull its load back behind the branch)
+    const int p = pc;
+    const float2 c = c_in, tg = tg_in;
     c_out[(size_t)r * hw + p] = c;
     const float gx = (float)(p % w), gy = (float)(p / w);
     half4g o;
@@ -39,19 +50,8 @@ __global__ __launch_bounds__(256) void lowmem_gather_kernel(const float2* __rest
     o[3] = (_Float16)fminf(fmaxf(tg.y - c.y, -64.0f), 64.0f);
     reinterpret_cast<half4g*>(motion)[(size_t)r * hw + p] = o;
   }
-  const uint4* src = net + (e * hw + p0) * 16;             // 128 halves = 16 pieces of 16 B per pixel
-  uint4* dst = net_out + ((size_t)r * hw + p0) * 16;
-  uint4 v[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int i = threadIdx.x + 256 * k;
-    if (i < np * 16) v[k] = src[i];
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int i = threadIdx.x + 256 * k;
-    if (i < np * 16) dst[i] = v[k];
-  }
+  for (int k = 0; k < 4; ++k) dst[min((int)threadIdx.x + 256 * k, np * 16 - 1)] = v[k];
 }
 
 __global__ __launch_bounds__(256) void lowmem_scatter_kernel(const float2* __restrict__ coords, const float2* __restrict__ delta,
@@ -64,25 +64,20 @@ __global__ __launch_bounds__(256) void lowmem_scatter_kernel(const float2* __res
   const size_t e = (size_t)sel[r];
   const int p0 = blockIdx.x * 64;
   const int np = min(64, hw - p0);
-  if (threadIdx.x < np) {
-    const size_t i = (size_t)r * hw + p0 + threadIdx.x, o = e * hw + p0 + threadIdx.x;
-    const float2 c = coords[i], d = delta[i];
-    target[o] = make_float2(c.x + d.x, c.y + d.y);
-    weight_all[o] = weight[i];
-  }
-  const uint4* src = net_new + ((size_t)r * hw + p0) * 16;
+  const uint4* src = net_new + ((size_t)r * hw + p0) * 16;  // (loads first and behind no branch: see lowmem_gather_kernel)
   uint4* dst = net + (e * hw + p0) * 16;
   uint4 v[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int i = threadIdx.x + 256 * k;
-    if (i < np * 16) v[k] = src[i];
+  for (int k = 0; k < 4; ++k) v[k] = src[min((int)threadIdx.x + 256 * k, np * 16 - 1)];
+  const size_t ic = (size_t)r * hw + p0 + min((int)threadIdx.x, np - 1);
+  const float2 c = coords[ic], d = delta[ic], wv = weight[ic];
+  {
+    const size_t o = e * hw + p0 + min((int)threadIdx.x, np - 1);
+    target[o] = make_float2(c.x + d.x, c.y + d.y);
+    weight_all[o] = wv;
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int i = threadIdx.x + 256 * k;
-    if (i < np * 16) dst[i] = v[k];
-  }
+  for (int k = 0; k < 4; ++k) dst[min((int)threadIdx.x + 256 * k, np * 16 - 1)] = v[k];
 }
 
 }  // namespace
