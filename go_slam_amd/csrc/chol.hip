@@ -91,16 +91,23 @@ __device__ __forceinline__ void panel_diag_factor(double (&a)[NB], int nb, int l
   if (lane < NB) Dinv[lane] = 1.0 / mydiag;
 }
 
-// one panel row: x = a L11^-T (forward substitution against the factored diagonal block in LDS)
+// one panel row: x = a L11^-T (forward substitution against the factored diagonal block in LDS): two partial sums per
+// entry and row c of L read as 16-byte broadcasts, like the diagonal factor's inner loop (one sum fed by one 8-byte read
+// per term was a dependent chain of 2 c instructions per entry: 6.5 us of a 22 us panel step in tools/chol_bench's stamps)
 __device__ __forceinline__ void panel_row_solve(double (&x)[NB], int nb, double (*D)[DS], const double* Dinv) {
+  typedef double double2v __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
     if (c < nb) {
-      double s = x[c];
+      double s0 = x[c], s1 = 0.0;
 #pragma unroll
-      for (int t = 0; t < NB; ++t)
-        if (t < c) s -= x[t] * D[c][t];
-      x[c] = s * Dinv[c];
+      for (int t = 0; t + 1 < c; t += 2) {
+        const double2v d = *reinterpret_cast<const double2v*>(&D[c][t]);
+        s0 = fma(-x[t], d[0], s0);
+        s1 = fma(-x[t + 1], d[1], s1);
+      }
+      if (c & 1) s0 = fma(-x[c - 1], D[c][c - 1], s0);
+      x[c] = (s0 + s1) * Dinv[c];
     }
   }
 }
@@ -235,6 +242,15 @@ __global__ __launch_bounds__(256) void chol_trail_kernel(double* __restrict__ A,
   trail_tile(A, bvec, n, k0, nb, k0 + nb, blockIdx.x, Lr, Lc);
 }
 
+#ifdef CHOL_TIMING   // tools/chol_bench.hip: where a step's panel wave spends its time (workgroup 0, summed over the steps)
+__device__ long long g_step_t[8];
+#define STEP_T0() long long st_last = wall_clock64()
+#define STEP_T(i) do { const long long t_now = wall_clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_step_t[i] += t_now - st_last; st_last = t_now; } while (0)
+#else
+#define STEP_T0() do { } while (0)
+#define STEP_T(i) do { } while (0)
+#endif
+
 // ONE launch per panel step (round 6): the trailing update of panel kp and the factorisation of panel kp + NB side by
 // side.  The two-launch form (panel, then trailing update, 38 times at 6P = 1194) is a chain of 76 kernels each bound by
 // its own latency (launch, a dependent load round trip, the 32-pivot chain, a store round trip); but panel kp + NB only
@@ -256,6 +272,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
     return;
   }
   if (threadIdx.x >= 64) return;                  // the panel role is one wave (lane = row); LDS phases are wave-ordered
+  STEP_T0();
   typedef double double4v __attribute__((ext_vector_type(4)));
   double (*D)[DS] = reinterpret_cast<double (*)[DS]>(step_lds);                // [NB]  (first: 16-byte aligned rows)
   double (*Lp)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(D + NB);          // [NB]  rows c1 .. of panel kp's L21
@@ -301,6 +318,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
 #pragma unroll
   for (int c = 0; c < NB; ++c) Lr[lane][c] = lr[c];
   lds_sync();
+  STEP_T(0);                                      // loads arrived + staged
   // ---- pending update of the diagonal block: a[c] -= sum_k Lp[i][k] Lp[c][k], lower tiles (0,0) (1,0) (1,1)
   const int m16 = lane & 15, k4 = lane >> 4;
 #pragma unroll
@@ -335,10 +353,12 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
   lds_sync();
 #pragma unroll
   for (int c = 0; c < NB; ++c) x[c] -= U[lane][c];
+  STEP_T(1);                                      // pending updates
   // ---- the panel itself, as chol_panel_kernel
   bool bad = false;
   panel_diag_factor(a, nb1, lane, bad, D, Dinv);
   lds_sync();
+  STEP_T(2);                                      // diagonal factor
   if (blockIdx.x == 0) {
     if (lane < nb1) {
       double* Ar = A + (size_t)(c1 + lane) * n + c1;
@@ -350,10 +370,12 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
   }
   if (has_row) {
     panel_row_solve(x, nb1, D, Dinv);
+    STEP_T(3);                                    // row solve
 #pragma unroll
     for (int c = 0; c < NB; ++c)
       if (c < nb1) Xr[c] = x[c];
   }
+  STEP_T(4);                                      // stores issued
 }
 
 // Backward substitution L^T x = y for the multi-kernel path, ONE LAUNCH PER 64-wide block from the last block up (round 4;

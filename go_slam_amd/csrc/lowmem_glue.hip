@@ -37,8 +37,8 @@ __global__ __launch_bounds__(256) void lowmem_gather_kernel(const float2* __rest
   for (int k = 0; k < 4; ++k) v[k] = src[min((int)threadIdx.x + 256 * k, np * 16 - 1)];
   const int pc = p0 + min((int)threadIdx.x, np - 1);
   const float2 c_in = coords1[e * hw + pc], tg_in = target[e * hw + pc];
-  {   // (threads past the tile's last pixel / piece repeat the last one: the same values to the same addresses -- a
-      // predicated store would pull its load back behind the branch)
+  if (threadIdx.x < 64) {   // (wave 0, no lane predicate: lanes past the tile's last pixel / piece repeat the last one -- the
+                            // same values to the same addresses; a predicated store would pull its load back behind the branch)
     const int p = pc;
     const float2 c = c_in, tg = tg_in;
     c_out[(size_t)r * hw + p] = c;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void lowmem_scatter_kernel(const float2* __res
   for (int k = 0; k < 4; ++k) v[k] = src[min((int)threadIdx.x + 256 * k, np * 16 - 1)];
   const size_t ic = (size_t)r * hw + p0 + min((int)threadIdx.x, np - 1);
   const float2 c = coords[ic], d = delta[ic], wv = weight[ic];
-  {
+  if (threadIdx.x < 64) {
     const size_t o = e * hw + p0 + min((int)threadIdx.x, np - 1);
     target[o] = make_float2(c.x + d.x, c.y + d.y);
     weight_all[o] = wv;

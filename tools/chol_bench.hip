@@ -88,6 +88,19 @@ int main(int argc, char** argv) {
       printf("        multi-kernel, two launches per panel (round 5): %7.1f us (residual %.3e), max |x - x_one_launch| %.3e\n",
              best * 1e3f, residual(A, b, x, n), d2);
     }
+    if (n > 450) {                                    // where the one-launch form's panel wave spends a step (workgroup 0)
+      long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      hipMemcpyToSymbol(HIP_SYMBOL(g_step_t), z, sizeof(z));
+      g_chol_force_blocked = 1;
+      hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+      hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice);
+      gs_chol_solve_launch(dA, db, n, 1e-4f, 0.1f, dx, flags, flags + 1, flags + 8, 0);
+      hipDeviceSynchronize();
+      hipMemcpyFromSymbol(z, HIP_SYMBOL(g_step_t), sizeof(z));
+      const double steps = (n - 1) / 32;
+      printf("        chol_step panel wave, us per step: loads + staging %.2f | pending updates %.2f | diagonal factor %.2f | row solve %.2f | stores issued %.2f\n",
+             z[0] / 100.0 / steps, z[1] / 100.0 / steps, z[2] / 100.0 / steps, z[3] / 100.0 / steps, z[4] / 100.0 / steps);
+    }
     if (n > 450) {                                    // the persistent path against its workgroup count
       g_chol_force_blocked = 2;
       const int keep = g_chol_coop_groups;
