@@ -96,17 +96,27 @@ __device__ __forceinline__ void panel_diag_factor(double (&a)[NB], int nb, int l
 // per term was a dependent chain of 2 c instructions per entry: 6.5 us of a 22 us panel step in tools/chol_bench's stamps)
 __device__ __forceinline__ void panel_row_solve(double (&x)[NB], int nb, double (*D)[DS], const double* Dinv) {
   typedef double double2v __attribute__((ext_vector_type(2)));
+  // row c + 1 of L is requested BEFORE entry c's arithmetic (its reads depend on nothing the solve computes): consumed where
+  // they are read, every entry waited one LDS round trip for its own row -- 32 exposed round trips of a lone wave
+  double2v cur[NB / 2], nxt[NB / 2];
+#pragma unroll
+  for (int q = 0; q < NB / 2; ++q) nxt[q] = double2v{0.0, 0.0};           // (row 0: entry 0 has no terms)
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
+#pragma unroll
+    for (int q = 0; q < NB / 2; ++q) cur[q] = nxt[q];
+    if (c + 1 < NB) {
+#pragma unroll
+      for (int q = 0; 2 * q < c + 1; ++q) nxt[q] = *reinterpret_cast<const double2v*>(&D[c + 1][2 * q]);
+    }
     if (c < nb) {
       double s0 = x[c], s1 = 0.0;
 #pragma unroll
       for (int t = 0; t + 1 < c; t += 2) {
-        const double2v d = *reinterpret_cast<const double2v*>(&D[c][t]);
-        s0 = fma(-x[t], d[0], s0);
-        s1 = fma(-x[t + 1], d[1], s1);
+        s0 = fma(-x[t], cur[t >> 1][0], s0);
+        s1 = fma(-x[t + 1], cur[t >> 1][1], s1);
       }
-      if (c & 1) s0 = fma(-x[c - 1], D[c][c - 1], s0);
+      if (c & 1) s0 = fma(-x[c - 1], cur[c >> 1][0], s0);
       x[c] = (s0 + s1) * Dinv[c];
     }
   }
