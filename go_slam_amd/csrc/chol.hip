@@ -57,25 +57,40 @@ constexpr int DS = NB + 2;  // row stride of the factored diagonal block in LDS:
 //   step j:  s_i = a_i[j] - sum_{t<j} L[i][t] L[j][t]   (the lane's own finished entries x row j of L)
 //            L[j][j] = sqrt(s_j),  L[i][j] = s_i / L[j][j]  (i > j)
 // Row j of L is read from LDS as broadcasts, two entries per ds_read_b128 -- every lane files L[i][j] there as soon as it
-// has it -- and only the pivot travels through v_readlane.  The right-looking form this replaces (rounds 3-5) updated
-// every remaining column after every pivot with the column entry fetched by two v_readlane per (pivot, column): 496 x
-// (2 readlane + multiply-add + lane mask) = ~3000 instructions behind each other, ~10 us of the panel kernel's 21.5 and,
-// 38 panels deep, the longest link of the 6P = 1194 solve's dependency chain; here ~500 multiply-adds and ~250 LDS reads.
+// has it -- and only the pivot and the newest entry of the row travel through v_readlane.  The right-looking form this
+// replaces (rounds 3-5) updated every remaining column after every pivot with the column entry fetched by two v_readlane
+// per (pivot, column): 496 x (2 readlane + multiply-add + lane mask) = ~3000 instructions behind each other, ~10 us of the
+// panel kernel's 21.5 and, 38 panels deep, the longest link of the 6P = 1194 solve's dependency chain; here ~500
+// multiply-adds and ~250 LDS reads.
 // Lanes >= nb carry identity rows.  Leaves L11 in D (lower triangle; lanes >= NB store nothing) and 1 / diag in Dinv.
 __device__ __forceinline__ void panel_diag_factor(double (&a)[NB], int nb, int lane, bool& bad, double (*D)[DS],
                                                   double* Dinv) {
   typedef double double2v __attribute__((ext_vector_type(2)));
   double mydiag = 1.0;
+  // Row j's entries L[j][t], t <= j - 2, are requested one step AHEAD (they were all filed by step j - 2), and the one entry
+  // step j - 1 has just produced, L[j][j-1], comes from lane j through v_readlane: read where it is used, every step waited
+  // an LDS round trip for a row whose last entry had only just been written (32 exposed round trips of a lone wave).
+  // (One wave: its LDS operations retire in order, and every access goes through D with a lane-dependent index, so the
+  // compiler keeps the stores of a step in front of the later steps' reads.)
+  double2v cur[NB / 2], nxt[NB / 2];
+#pragma unroll
+  for (int q = 0; q < NB / 2; ++q) nxt[q] = double2v{0.0, 0.0};
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
+#pragma unroll
+    for (int q = 0; q < NB / 2; ++q) cur[q] = nxt[q];
+    if (j + 1 < NB) {                       // row j + 1, entries t <= j - 1 (columns filed by the steps before this one)
+#pragma unroll
+      for (int q = 0; 2 * q <= j - 1; ++q) nxt[q] = *reinterpret_cast<const double2v*>(&D[j + 1][2 * q]);
+    }
     double s0 = a[j], s1 = 0.0;
 #pragma unroll
-    for (int t = 0; t + 1 < j; t += 2) {
-      const double2v d = *reinterpret_cast<const double2v*>(&D[j][t]);
-      s0 = fma(-a[t], d[0], s0);
-      s1 = fma(-a[t + 1], d[1], s1);
+    for (int t = 0; t + 1 <= j - 2; t += 2) {
+      s0 = fma(-a[t], cur[t >> 1][0], s0);
+      s1 = fma(-a[t + 1], cur[t >> 1][1], s1);
     }
-    if (j & 1) s0 = fma(-a[j - 1], D[j][j - 1], s0);
+    if (j >= 2 && ((j - 2) & 1) == 0) s0 = fma(-a[j - 2], cur[(j - 2) >> 1][0], s0);   // (an unpaired last entry t = j - 2)
+    if (j >= 1) s1 = fma(-a[j - 1], readlane_f64(a[j - 1], j), s1);                    // L[j][j-1], from lane j itself
     const double s = s0 + s1;
     const double piv = readlane_f64(s, j);
     if (j < nb && !(piv > 0.0) && piv == piv) bad = true;   // pivot <= 0 (NaN falls through like Eigen)
@@ -84,10 +99,10 @@ __device__ __forceinline__ void panel_diag_factor(double (&a)[NB], int nb, int l
     a[j] = lane == j ? dj : (lane > j ? s * rdj : 0.0);
     if (lane == j) mydiag = dj;
     if (lane < NB) D[lane][j] = a[j];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (one wave: its LDS operations retire in order; this only
-    __builtin_amdgcn_wave_barrier();                            // keeps the compiler from moving the next step's reads up)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (lane < NB) Dinv[lane] = 1.0 / mydiag;
 }
 
