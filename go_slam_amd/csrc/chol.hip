@@ -344,17 +344,24 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
   for (int c = 0; c < NB; ++c) Lr[lane][c] = lr[c];
   lds_sync();
   STEP_T(0);                                      // loads arrived + staged
-  // ---- pending update of the diagonal block: a[c] -= sum_k Lp[i][k] Lp[c][k], lower tiles (0,0) (1,0) (1,1)
+  // ---- pending update of the diagonal block: a[c] -= sum_k Lp[i][k] Lp[c][k], lower tiles (0,0) (1,0) (1,1) -- the three
+  // accumulators advance together (one tile after the other, each tile's eight products wait for one another)
   const int m16 = lane & 15, k4 = lane >> 4;
+  {
+    double4v acc00 = {0.0, 0.0, 0.0, 0.0}, acc10 = acc00, acc11 = acc00;
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int ti = t > 0 ? 1 : 0, tj = t > 1 ? 1 : 0;
-    double4v acc = {0.0, 0.0, 0.0, 0.0};
+    for (int kb = 0; kb < NB / 4; ++kb) {
+      const double p0 = Lp[m16][4 * kb + k4], p1 = Lp[16 + m16][4 * kb + k4];
+      acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, p0, acc00, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(p1, p0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(p1, p1, acc11, 0, 0, 0);
+    }
 #pragma unroll
-    for (int kb = 0; kb < NB / 4; ++kb)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[16 * ti + m16][4 * kb + k4], Lp[16 * tj + m16][4 * kb + k4], acc, 0, 0, 0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) U[16 * ti + k4 + 4 * q][16 * tj + m16] = acc[q];
+    for (int q = 0; q < 4; ++q) {
+      U[k4 + 4 * q][m16] = acc00[q];
+      U[16 + k4 + 4 * q][m16] = acc10[q];
+      U[16 + k4 + 4 * q][16 + m16] = acc11[q];
+    }
   }
   lds_sync();
   if (lane < NB) {
@@ -363,18 +370,34 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
       if (c <= lane) a[c] -= U[lane][c];
   }
   lds_sync();
-  // ---- pending update of this workgroup's rows: x[c] -= sum_k Lr[row][k] Lp[c][k]
+  // ---- pending update of this workgroup's rows: x[c] -= sum_k Lr[row][k] Lp[c][k]: all eight 16 x 16 tiles at once (six
+  // operand reads feed eight products per k-step)
+  {
+    double4v acc[PR / 16][NB / 16];
 #pragma unroll
-  for (int ti = 0; ti < PR / 16; ++ti)
+    for (int ti = 0; ti < PR / 16; ++ti)
 #pragma unroll
-    for (int tj = 0; tj < NB / 16; ++tj) {
-      double4v acc = {0.0, 0.0, 0.0, 0.0};
+      for (int tj = 0; tj < NB / 16; ++tj) acc[ti][tj] = double4v{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int kb = 0; kb < NB / 4; ++kb)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lr[16 * ti + m16][4 * kb + k4], Lp[16 * tj + m16][4 * kb + k4], acc, 0, 0, 0);
+    for (int kb = 0; kb < NB / 4; ++kb) {
+      double pa[PR / 16], pb[NB / 16];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) U[16 * ti + k4 + 4 * q][16 * tj + m16] = acc[q];
+      for (int ti = 0; ti < PR / 16; ++ti) pa[ti] = Lr[16 * ti + m16][4 * kb + k4];
+#pragma unroll
+      for (int tj = 0; tj < NB / 16; ++tj) pb[tj] = Lp[16 * tj + m16][4 * kb + k4];
+#pragma unroll
+      for (int ti = 0; ti < PR / 16; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NB / 16; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti], pb[tj], acc[ti][tj], 0, 0, 0);
     }
+#pragma unroll
+    for (int ti = 0; ti < PR / 16; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < NB / 16; ++tj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) U[16 * ti + k4 + 4 * q][16 * tj + m16] = acc[ti][tj][q];
+  }
   lds_sync();
 #pragma unroll
   for (int c = 0; c < NB; ++c) x[c] -= U[lane][c];
