@@ -296,15 +296,17 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
     trail_tile(A, bvec, n, kp, NB, s1, (int)blockIdx.x - n_panel, Lr, Lc);
     return;
   }
-  if (threadIdx.x >= 64) return;                  // the panel role is one wave (lane = row); LDS phases are wave-ordered
+  // the panel role: wave 0 owns the rows (lane = row); waves 1-3 only help with the pending-update products
+  const int wv = threadIdx.x >> 6;
   STEP_T0();
   typedef double double4v __attribute__((ext_vector_type(4)));
   double (*D)[DS] = reinterpret_cast<double (*)[DS]>(step_lds);                // [NB]  (first: 16-byte aligned rows)
   double (*Lp)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(D + NB);          // [NB]  rows c1 .. of panel kp's L21
   double (*Lr)[NB + 1] = Lp + NB;                                               // [PR]  this workgroup's rows of it
   double (*U)[NB + 1] = Lr + PR;                                                // [PR]  products, lane = row on the way out
-  double* Dinv = reinterpret_cast<double*>(U + PR);                             // [NB]
-  const int lane = threadIdx.x;
+  double (*UD)[NB + 1] = U + PR;                                                // [NB]  ... of the diagonal block
+  double* Dinv = reinterpret_cast<double*>(UD + NB);                            // [NB]
+  const int lane = threadIdx.x & 63;
   auto lds_sync = [] {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -313,7 +315,10 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
   // ---- everything this wave reads from memory is requested up front: diagonal block row + its L21 row (lanes < NB), own
   // row of the panel's columns + its L21 row
   double a[NB], lp[NB], x[NB], lr[NB];
-  {
+  const int row = s1 + (int)blockIdx.x * PR + lane;
+  const bool has_row = row <= n;
+  double* Xr = row < n ? A + (size_t)row * n + c1 : bvec + c1;
+  if (wv == 0) {
     const int r = lane & (NB - 1);
     const bool live = (lane < NB) && (r < nb1);
     const double* Ar = A + (size_t)(c1 + (live ? r : 0)) * n;
@@ -324,30 +329,27 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
       a[c] = v;
       lp[c] = live ? Ar[kp + c] : 0.0;
     }
-  }
-  const int row = s1 + (int)blockIdx.x * PR + lane;
-  const bool has_row = row <= n;
-  double* Xr = row < n ? A + (size_t)row * n + c1 : bvec + c1;
-  {
     const double* Lrow = row < n ? A + (size_t)row * n + kp : bvec + kp;
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
       x[c] = (has_row && c < nb1) ? Xr[c] : 0.0;
       lr[c] = has_row ? Lrow[c] : 0.0;
     }
-  }
-  if (lane < NB) {
+    if (lane < NB) {
 #pragma unroll
-    for (int c = 0; c < NB; ++c) Lp[lane][c] = lp[c];
-  }
+      for (int c = 0; c < NB; ++c) Lp[lane][c] = lp[c];
+    }
 #pragma unroll
-  for (int c = 0; c < NB; ++c) Lr[lane][c] = lr[c];
-  lds_sync();
+    for (int c = 0; c < NB; ++c) Lr[lane][c] = lr[c];
+  }
+  __syncthreads();
   STEP_T(0);                                      // loads arrived + staged
-  // ---- pending update of the diagonal block: a[c] -= sum_k Lp[i][k] Lp[c][k], lower tiles (0,0) (1,0) (1,1) -- the three
-  // accumulators advance together (one tile after the other, each tile's eight products wait for one another)
+  // ---- the pending rank-32 update, eleven 16 x 16 x 32 products dealt to the workgroup's four waves (the fp64 matrix rate of
+  // this part equals its vector rate: one wave alone spent 2.7 of the step's 21 us here):
+  //   wave 0: the diagonal block's lower tiles (0,0) (1,0) (1,1), sum_k Lp[i][k] Lp[c][k] -> UD
+  //   waves 1-3: the rows' eight tiles, sum_k Lr[row][k] Lp[c][k] -> U, three / three / two each
   const int m16 = lane & 15, k4 = lane >> 4;
-  {
+  if (wv == 0) {
     double4v acc00 = {0.0, 0.0, 0.0, 0.0}, acc10 = acc00, acc11 = acc00;
 #pragma unroll
     for (int kb = 0; kb < NB / 4; ++kb) {
@@ -358,47 +360,32 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ A, 
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      U[k4 + 4 * q][m16] = acc00[q];
-      U[16 + k4 + 4 * q][m16] = acc10[q];
-      U[16 + k4 + 4 * q][16 + m16] = acc11[q];
+      UD[k4 + 4 * q][m16] = acc00[q];
+      UD[16 + k4 + 4 * q][m16] = acc10[q];
+      UD[16 + k4 + 4 * q][16 + m16] = acc11[q];
+    }
+  } else {
+    const int first = 3 * (wv - 1), count = wv == 3 ? 2 : 3;      // tile id = 2 ti + tj
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      if (u < count) {
+        const int id = first + u, ti = id >> 1, tj = id & 1;
+        double4v acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kb = 0; kb < NB / 4; ++kb)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lr[16 * ti + m16][4 * kb + k4], Lp[16 * tj + m16][4 * kb + k4], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) U[16 * ti + k4 + 4 * q][16 * tj + m16] = acc[q];
+      }
     }
   }
-  lds_sync();
+  __syncthreads();
+  if (wv != 0) return;
   if (lane < NB) {
 #pragma unroll
     for (int c = 0; c < NB; ++c)
-      if (c <= lane) a[c] -= U[lane][c];
+      if (c <= lane) a[c] -= UD[lane][c];
   }
-  lds_sync();
-  // ---- pending update of this workgroup's rows: x[c] -= sum_k Lr[row][k] Lp[c][k]: all eight 16 x 16 tiles at once (six
-  // operand reads feed eight products per k-step)
-  {
-    double4v acc[PR / 16][NB / 16];
-#pragma unroll
-    for (int ti = 0; ti < PR / 16; ++ti)
-#pragma unroll
-      for (int tj = 0; tj < NB / 16; ++tj) acc[ti][tj] = double4v{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kb = 0; kb < NB / 4; ++kb) {
-      double pa[PR / 16], pb[NB / 16];
-#pragma unroll
-      for (int ti = 0; ti < PR / 16; ++ti) pa[ti] = Lr[16 * ti + m16][4 * kb + k4];
-#pragma unroll
-      for (int tj = 0; tj < NB / 16; ++tj) pb[tj] = Lp[16 * tj + m16][4 * kb + k4];
-#pragma unroll
-      for (int ti = 0; ti < PR / 16; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < NB / 16; ++tj)
-          acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti], pb[tj], acc[ti][tj], 0, 0, 0);
-    }
-#pragma unroll
-    for (int ti = 0; ti < PR / 16; ++ti)
-#pragma unroll
-      for (int tj = 0; tj < NB / 16; ++tj)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) U[16 * ti + k4 + 4 * q][16 * tj + m16] = acc[ti][tj][q];
-  }
-  lds_sync();
 #pragma unroll
   for (int c = 0; c < NB; ++c) x[c] -= U[lane][c];
   STEP_T(1);                                      // pending updates
@@ -1523,7 +1510,7 @@ int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float*
     const int nb0 = n < NB ? n : NB;
     chol_panel_kernel<<<gs_cdiv(n - nb0 + 1, PR), 64, 0, st>>>(H, b, n, 0, fail_flag);
     GS_CHECK_LAUNCH("chol_panel");
-    constexpr size_t step_lds = ((size_t)NB * DS + (size_t)(NB + 2 * PR) * (NB + 1) + NB) * sizeof(double);
+    constexpr size_t step_lds = ((size_t)NB * DS + (size_t)(2 * NB + 2 * PR) * (NB + 1) + NB) * sizeof(double);   // 59.6 KB
     static_assert(step_lds >= (size_t)2 * TT * (NB + 1) * sizeof(double), "chol_step: the trailing role's operands fit");
     for (int kp = 0; kp + NB < n; kp += NB) {
       const int c1 = kp + NB, nb1 = (n - c1 < NB) ? (n - c1) : NB, rem1 = n - c1 - nb1;
