@@ -1103,9 +1103,9 @@ __global__ __launch_bounds__(SMALL_NT) void chol_small_kernel(const double* __re
 #ifndef CHOL_TB
 #define CHOL_TB 2                  // tiles per wave in flight in the head stages' global trailing update
 #endif
-constexpr int MID_N = 342;      // beyond this the multi-kernel path (whole chip on the trailing updates) wins: 305 vs 304 us at
-                                // 6P = 342, 339 vs 326 at 360, 556 vs 419 at 450 (tools/chol_bench.hip; until the round-6
-                                // one-launch-per-panel form the two met at 450)
+constexpr int MID_N = 300;      // beyond this the multi-kernel path (whole chip on the trailing updates) wins: 201 vs 231 us at
+                                // 6P = 294, 243 vs 227 at 306, 306 vs 249 at 342, 556 vs 419 at 450 (tools/chol_bench.hip;
+                                // until the round-6 one-launch-per-panel form the two met at 450)
 constexpr int MID_SW60_N = 300; // up to here a 60-column stage fits: (n + 1) x 61 doubles + vectors <= 160 KB
 
 // 16x16 tile of A B^T over KS k-steps of 4 on the fp64 matrix cores; the operands of five k-steps are requested from LDS

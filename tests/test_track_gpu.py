@@ -442,17 +442,16 @@ def test_ba_rejects_non_contiguous(db, dev):
               False)
 
 
-# 6P -> solver (csrc/chol.hip, gs_chol_solve_launch): <= 192 chol_small (LDS-resident); 193 .. 342 chol_mid, ONE workgroup with
-# head stages of SW = 60 columns up to 6P = 300 and SW = 30 above (mid_tile_product<15> / <8>); above 342 the multi-kernel
-# blocked path (one launch per 32-column panel: chol_panel_kernel, then chol_step_kernel = the next panel beside the previous
-# panel's trailing update).  Every branch and both of its edges, incl. stage counts that leave a ragged last stage
-# (n % SW != 0) and panel counts that leave a ragged last panel (6P % 32 != 0):
-@pytest.mark.parametrize("num_kf,path", [(34, "mid, SW 60, one head stage (6P = 198: six columns past chol_small's cap)"),
-                                         (48, "mid, SW 60 (6P = 282, 282 % 60 = 42)"),
-                                         (51, "mid, SW 60 at its upper edge (6P = 300)"),
-                                         (52, "mid, SW 30 at its lower edge (6P = 306, 306 % 30 = 6)"),
-                                         (58, "mid, SW 30 at its upper edge (6P = 342, 342 % 30 = 12)"),
-                                         (59, "blocked multi-kernel path at its lower edge (6P = 348, 348 % 32 = 28)"),
+# 6P -> solver (csrc/chol.hip, gs_chol_solve_launch): <= 192 chol_small (LDS-resident); 193 .. 300 chol_mid, ONE workgroup with
+# head stages of 60 columns (mid_tile_product<15>); above 300 the multi-kernel blocked path (one launch per 32-column panel:
+# chol_panel_kernel, then chol_step_kernel = the next panel beside the previous panel's trailing update).  Every branch and
+# both of its edges, incl. stage counts that leave a ragged last stage (n % 60 != 0) and panel counts that leave a ragged
+# last panel (6P % 32 != 0):
+@pytest.mark.parametrize("num_kf,path", [(34, "mid, one head stage (6P = 198: six columns past chol_small's cap)"),
+                                         (48, "mid (6P = 282, 282 % 60 = 42)"),
+                                         (51, "mid at its upper edge (6P = 300)"),
+                                         (52, "blocked multi-kernel path at its lower edge (6P = 306, 306 % 32 = 18)"),
+                                         (58, "blocked multi-kernel path (6P = 342, 342 % 32 = 22)"),
                                          (61, "blocked multi-kernel path (6P = 360, 360 % 32 = 8)"),
                                          (65, "blocked multi-kernel path, whole panels (6P = 384 = 12 x 32)"),
                                          (76, "blocked multi-kernel path (6P = 450, last panel of 2 columns)"),
