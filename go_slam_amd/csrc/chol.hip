@@ -11,8 +11,8 @@
 //                         workgroups update what lies beyond those columns (64x64 tiles, operands in LDS)
 //   chol_back_block_kernel : backward substitution, one launch per 64-wide block (b rides along as row n of the
 //                         factorisation, so the forward substitution is free), writes fp32 dx
-// 1 launch per panel + 1 per 64 unknowns; 6P = 1194 (global BA) is 38 + 19 launches, 1.14 ms (1.64 ms as 76 + 19 launches
-// with the right-looking diagonal factor of rounds 3-5; tools/chol_bench.hip times both forms).
+// 1 launch per panel + 1 per 64 unknowns; 6P = 1194 (global BA) is 38 + 19 launches, 0.86 ms (1.64 ms as 76 + 19 launches
+// with the right-looking diagonal factor of rounds 3-5; tools/chol_bench.hip times both forms and stamps the phases).
 #include "common.h"
 
 namespace {
@@ -432,16 +432,30 @@ __global__ __launch_bounds__(256) void chol_back_block_kernel(const double* __re
     }
     return;
   }
-  if (tid < 64) {
-    const int j = tid;
-    const bool live = j < nb;
-    // (the diagonal entry and y are requested WITH the column: behind it they were two more dependent round trips)
-    const double dg = live ? L[(size_t)(k0 + j) * n + k0 + j] : 1.0;
-    double yv = live ? b[k0 + j] : 0.0;
-    double c_[SB];                        // column j of the block: L[k0+i][k0+j], i > j
+  // Everything is requested before anything is computed, the triangle first (the memory counter retires in order: what is
+  // waited for first must be asked for first): column j = lane of the block for the solve -- every wave asks, only wave 0
+  // solves; a load behind the `tid < 64` branch would be issued after the update's -- then this thread's column of the
+  // update, y[c] -= sum_r L[k0 + r][c] x[r], which needs nothing of x (behind the solve and the barrier it was a second
+  // exposed round trip of every launch).
+  const int j = tid & 63;
+  const bool live = j < nb;
+  const double dg = L[(size_t)(k0 + min(j, nb - 1)) * n + k0 + min(j, nb - 1)];
+  double yv = b[k0 + min(j, nb - 1)];
+  double c_[SB];                          // column j of the block: L[k0+i][k0+j], i > j
 #pragma unroll
-    for (int i = 0; i < SB; ++i) c_[i] = (live && i > j && i < nb) ? L[(size_t)(k0 + i) * n + k0 + j] : 0.0;
-    const double inv_dg = 1.0 / dg;
+  for (int i = 0; i < SB; ++i) c_[i] = L[(size_t)(k0 + min(i, nb - 1)) * n + k0 + min(j, nb - 1)];
+  const int c = blockIdx.x * 256 + tid;
+  const int cc = min(c, max(k0 - 1, 0));
+  double v[SB];
+#pragma unroll
+  for (int u = 0; u < SB; ++u) v[u] = L[(size_t)(k0 + min(u, nb - 1)) * n + cc];
+  const double bc = b[cc];
+  if (tid < 64) {
+    if (!live) yv = 0.0;
+#pragma unroll
+    for (int i = 0; i < SB; ++i)
+      if (!(live && i > j && i < nb)) c_[i] = 0.0;
+    const double inv_dg = live ? 1.0 / dg : 1.0;
 #pragma unroll
     for (int i = SB - 1; i >= 0; --i) {
       const double xi = readlane_f64(yv * inv_dg, i);
@@ -452,21 +466,14 @@ __global__ __launch_bounds__(256) void chol_back_block_kernel(const double* __re
     if (live && blockIdx.x == 0) dx[k0 + j] = (float)yv;      // (b[k0 ..] keeps y: the other workgroups still read it)
   }
   __syncthreads();
-  const int c = blockIdx.x * 256 + tid;
   if (c < k0) {
-    // sixteen rows' entries of this column in flight per round trip (a rolled two-row loop was 32 dependent round trips:
-    // most of this kernel's 15 us); the sums are formed in the same order as before -- even rows, odd rows, then both
+    // (a rolled two-row loop was 32 dependent round trips: most of this kernel's 15 us until round 6); the sums are formed in
+    // the same order as before -- even rows, odd rows, then both
     double s0 = 0.0, s1 = 0.0;
-    const double bc = b[c];
-    for (int r0 = 0; r0 < nb; r0 += 16) {
-      double v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = L[(size_t)(k0 + min(r0 + u, nb - 1)) * n + c];
-#pragma unroll
-      for (int u = 0; u < 16; u += 2) {
-        if (r0 + u < nb) s0 = fma(v[u], xs[r0 + u], s0);
-        if (r0 + u + 1 < nb) s1 = fma(v[u + 1], xs[r0 + u + 1], s1);
-      }
+    for (int u = 0; u < SB; u += 2) {
+      if (u < nb) s0 = fma(v[u], xs[u], s0);
+      if (u + 1 < nb) s1 = fma(v[u + 1], xs[u + 1], s1);
     }
     b[c] = bc - (s0 + s1);
   }
