@@ -9,9 +9,9 @@
 //   chol_step_kernel    : panel k + 1 AND the trailing update of panel k in the same launch: the panel workgroups apply
 //                         panel k's rank-32 update to their own 32 columns themselves (v_mfma_f64_16x16x4), the tile
 //                         workgroups update what lies beyond those columns (64x64 tiles, operands in LDS)
-//   chol_back_block_kernel : backward substitution, one launch per 64-wide block (b rides along as row n of the
-//                         factorisation, so the forward substitution is free), writes fp32 dx
-// 1 launch per panel + 1 per 64 unknowns; 6P = 1194 (global BA) is 38 + 19 launches, 0.86 ms (1.64 ms as 76 + 19 launches
+//   chol_back_pair_kernel / chol_back_block_kernel : backward substitution, two 64-wide blocks per launch (b rides along
+//                         as row n of the factorisation, so the forward substitution is free), writes fp32 dx
+// 1 launch per panel + 1 per 128 unknowns; 6P = 1194 (global BA) is 38 + 10 launches, 0.85 ms (1.64 ms as 1 + 76 + 19 launches
 // with the right-looking diagonal factor of rounds 3-5; tools/chol_bench.hip times both forms and stamps the phases).
 #include "common.h"
 
@@ -139,8 +139,11 @@ __device__ __forceinline__ void panel_row_solve(double (&x)[NB], int nb, double 
 
 // Factor the diagonal block [k0,k0+nb) (every workgroup redundantly -- cheaper than a dependent
 // launch) and compute L21 = A21 * L11^-T for this workgroup's PR rows.
+// `damp` (panel 0 of the one-launch-per-panel path): the solve's damping, diag += ep + lm * diag, applied on the way -- by
+// lane r to the diagonal block's entry it holds, by every row's lane to its own diagonal entry further down (nothing else in
+// this launch touches those) -- and the failure flag (re)set by its only writer: what chol_damp_kernel does as a launch.
 __global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ A, double* __restrict__ bvec, int n, int k0,
-                                                        int32_t* fail_flag) {
+                                                        int32_t* fail_flag, int damp = 0, double lm = 0.0, double ep = 0.0) {
   __shared__ __attribute__((aligned(16))) double D[NB][DS];
   __shared__ double Dinv[NB];
   const int lane = threadIdx.x;
@@ -153,10 +156,14 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ A, 
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
       double v = (live && c <= r && c < nb) ? Ar[c] : 0.0;
+      if (damp && live && c == r) v = v + (ep + lm * v);
       if (!live && c == r) v = 1.0;            // identity padding keeps the recurrence well-defined
       a[c] = v;
     }
   }
+  const int row = k0 + nb + blockIdx.x * PR + lane;
+  double own_diag = 0.0;
+  if (damp && row < n) own_diag = A[(size_t)row * n + row];
   bool bad = false;
   panel_diag_factor(a, nb, lane, bad, D, Dinv);
   __syncthreads();
@@ -167,11 +174,11 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ A, 
       for (int c = 0; c < NB; ++c)
         if (c <= lane) Ar[c] = a[c];
     }
-    if (lane == 0 && bad) *fail_flag = 1;
+    if (lane == 0 && (bad || damp)) *fail_flag = bad ? 1 : 0;
   }
+  if (damp && row < n) A[(size_t)row * n + row] = own_diag + (ep + lm * own_diag);
   // panel rows; row n is b^T (round 4: b rides along as an extra row of the matrix, so the forward substitution
   // L y = b falls out of the factorisation -- the single-workgroup forward sweep cost 0.75 ms at 6P = 1194)
-  const int row = k0 + nb + blockIdx.x * PR + lane;
   if (row <= n) {
     double x[NB];
     double* Ar = row < n ? A + (size_t)row * n + k0 : bvec + k0;
@@ -479,6 +486,83 @@ __global__ __launch_bounds__(256) void chol_back_block_kernel(const double* __re
   }
 }
 
+
+// TWO 64-wide blocks per launch (round 6): the block at k_hi = k_lo + 64 (nb_hi <= 64 unknowns) and the full block at k_lo.
+// Wave 0 of every workgroup solves the upper triangle, takes its solution out of the lower block's right-hand side
+// (y_lo[j] -= sum_r L[k_hi + r][k_lo + j] x_hi[r], a 64 x 64 product: lane j = column, coalesced) and solves the lower
+// triangle -- redundantly per workgroup, as the single-block kernel does; waves 1-3 then update the columns left of k_lo
+// with both blocks' rows, 192 columns per workgroup.  Half the launches of the substitution, i.e. half of its kernel
+// boundaries (each a launch gap and a first-touch round trip).
+__global__ __launch_bounds__(256) void chol_back_pair_kernel(const double* __restrict__ L, double* __restrict__ b, int n,
+                                                             int k_lo, float* __restrict__ dx, const int32_t* fail_flag,
+                                                             int32_t* fail_count) {
+  __shared__ double xs[2 * SB];                       // x of [k_lo, k_lo + 64 + nb_hi)
+  const int tid = threadIdx.x, wv = tid >> 6, j = tid & 63;
+  const int k_hi = k_lo + SB, nb_hi = min(SB, n - k_hi);
+  if (*fail_flag) {   // reference: zero update on failure (droid_kernels.cu:1207-1210)
+    if (blockIdx.x == 0) {
+      for (int i = tid; i < SB + nb_hi; i += 256) dx[k_lo + i] = 0.0f;
+      if (tid == 0 && k_lo == 0) *fail_count += 1;
+    }
+    return;
+  }
+  if (wv == 0) {
+    const bool live = j < nb_hi;
+    const int jc = min(j, nb_hi - 1);
+    // everything wave 0 needs, requested before anything is computed: upper triangle column j, the 64 x nb_hi block
+    // between the two (column k_lo + j of rows k_hi ..), lower triangle column j, both right-hand sides
+    const double dg_hi = L[(size_t)(k_hi + jc) * n + k_hi + jc], dg_lo = L[(size_t)(k_lo + j) * n + k_lo + j];
+    double y_hi = b[k_hi + jc], y_lo = b[k_lo + j];
+    double c_hi[SB], g[SB], c_lo[SB];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) c_hi[i] = L[(size_t)(k_hi + min(i, nb_hi - 1)) * n + k_hi + jc];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) g[i] = L[(size_t)(k_hi + min(i, nb_hi - 1)) * n + k_lo + j];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) c_lo[i] = L[(size_t)(k_lo + i) * n + k_lo + j];
+    if (!live) y_hi = 0.0;
+    const double inv_hi = live ? 1.0 / dg_hi : 1.0, inv_lo = 1.0 / dg_lo;
+#pragma unroll
+    for (int i = SB - 1; i >= 0; --i) {               // upper triangle; x_hi[i] also leaves the lower right-hand side
+      const double xi = readlane_f64(y_hi * inv_hi, i);
+      if (j == i) y_hi = xi;
+      else if (live && j < i && i < nb_hi) y_hi -= c_hi[i] * xi;
+      if (i < nb_hi) y_lo -= g[i] * xi;
+    }
+#pragma unroll
+    for (int i = SB - 1; i >= 0; --i) {               // lower triangle
+      const double xi = readlane_f64(y_lo * inv_lo, i);
+      if (j == i) y_lo = xi;
+      else if (j < i) y_lo -= c_lo[i] * xi;
+    }
+    xs[j] = y_lo;
+    xs[SB + j] = live ? y_hi : 0.0;
+    if (blockIdx.x == 0) {
+      dx[k_lo + j] = (float)y_lo;                     // (b keeps y: the other workgroups still read it)
+      if (live) dx[k_hi + j] = (float)y_hi;
+    }
+  }
+  // waves 1-3: this thread's column of the update, requested before the barrier (it needs nothing of x)
+  const int c = blockIdx.x * 192 + (tid - 64);
+  const int cc = min(max(c, 0), max(k_lo - 1, 0));
+  double v[2 * SB];
+  double bc = 0.0;
+  if (wv != 0) {
+#pragma unroll
+    for (int u = 0; u < 2 * SB; ++u) v[u] = L[(size_t)(k_lo + min(u, SB + nb_hi - 1)) * n + cc];
+    bc = b[cc];
+  }
+  __syncthreads();
+  if (wv != 0 && c < k_lo) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < 2 * SB; u += 2) {
+      if (u < SB + nb_hi) s0 = fma(v[u], xs[u], s0);
+      if (u + 1 < SB + nb_hi) s1 = fma(v[u + 1], xs[u + 1], s1);
+    }
+    b[c] = bc - (s0 + s1);
+  }
+}
 
 #ifdef CHOL_TIMING   // tools/chol_bench.hip only: per-phase wall-clock stamps (100 MHz)
 __device__ long long g_chol_t[64];
@@ -1488,8 +1572,10 @@ int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float*
       return GS_OK;
     }
   }
-  chol_damp_kernel<<<gs_cdiv(n, 256), 256, 0, st>>>(H, n, (double)lm, (double)ep, fail_flag, sync);
-  GS_CHECK_LAUNCH("chol_damp");
+#ifdef CHOL_TIMING                                    // (the harness's other forms keep the damping launch)
+  extern int g_chol_two_launches;
+  if (g_chol_force_blocked == 2 || g_chol_two_launches) chol_damp_kernel<<<gs_cdiv(n, 256), 256, 0, st>>>(H, n, (double)lm, (double)ep, fail_flag, sync);
+#endif
 #ifdef CHOL_TIMING
   if (g_chol_force_blocked == 2 && sync && g_chol_coop_groups > 0) {   // the measured-and-not-shipped persistent path
     chol_coop_kernel<<<g_chol_coop_groups, COOP_NT, 0, st>>>(H, b, n, dx_out, fail_flag, fail_count, sync);
@@ -1498,8 +1584,7 @@ int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float*
   }
 #endif
 #ifdef CHOL_TIMING
-  extern int g_chol_two_launches;                     // tools/chol_bench.hip: the round-5 form (panel, then trailing update)
-  if (g_chol_two_launches) {
+  if (g_chol_two_launches) {                          // tools/chol_bench.hip: the round-5 form (panel, then trailing update)
     for (int k0 = 0; k0 < n; k0 += NB) {
       const int nb = (n - k0 < NB) ? (n - k0) : NB;
       const int rem = n - k0 - nb;
@@ -1515,7 +1600,7 @@ int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float*
     // panel 0 on its own (rows NB .. n: the matrix rows below the panel AND the b row, which rides along), then ONE launch
     // per further panel: its factorisation beside the previous panel's trailing update (chol_step_kernel)
     const int nb0 = n < NB ? n : NB;
-    chol_panel_kernel<<<gs_cdiv(n - nb0 + 1, PR), 64, 0, st>>>(H, b, n, 0, fail_flag);
+    chol_panel_kernel<<<gs_cdiv(n - nb0 + 1, PR), 64, 0, st>>>(H, b, n, 0, fail_flag, 1, (double)lm, (double)ep);
     GS_CHECK_LAUNCH("chol_panel");
     constexpr size_t step_lds = ((size_t)NB * DS + (size_t)(2 * NB + 2 * PR) * (NB + 1) + NB) * sizeof(double);   // 59.6 KB
     static_assert(step_lds >= (size_t)2 * TT * (NB + 1) * sizeof(double), "chol_step: the trailing role's operands fit");
@@ -1527,9 +1612,22 @@ int gs_chol_solve_launch(double* H, double* b, int n, float lm, float ep, float*
       GS_CHECK_LAUNCH("chol_step");
     }
   }
-  // b now holds y = L^-1 b; backward substitution block by block
-  for (int k0 = ((n - 1) / SB) * SB; k0 >= 0; k0 -= SB) {
-    chol_back_block_kernel<<<gs_cdiv(k0, 256) + 1, 256, 0, st>>>(H, b, n, k0, dx_out, fail_flag, fail_count);
+  // b now holds y = L^-1 b; backward substitution from the last block up, two 64-wide blocks per launch (a single block is
+  // left when their number is odd)
+  int k0 = ((n - 1) / SB) * SB;
+#ifdef CHOL_TIMING
+  if (g_chol_two_launches) {
+    for (; k0 >= 0; k0 -= SB) chol_back_block_kernel<<<gs_cdiv(k0, 256) + 1, 256, 0, st>>>(H, b, n, k0, dx_out, fail_flag, fail_count);
+    return GS_OK;
+  }
+#endif
+  for (; k0 >= SB; k0 -= 2 * SB) {
+    const int k_lo = k0 - SB;
+    chol_back_pair_kernel<<<gs_cdiv(k_lo, 192) + 1, 256, 0, st>>>(H, b, n, k_lo, dx_out, fail_flag, fail_count);
+    GS_CHECK_LAUNCH("chol_back_pair");
+  }
+  if (k0 == 0) {
+    chol_back_block_kernel<<<1, 256, 0, st>>>(H, b, n, 0, dx_out, fail_flag, fail_count);
     GS_CHECK_LAUNCH("chol_back_block");
   }
   return GS_OK;
