@@ -624,6 +624,10 @@ class FactorGraph:
             target = self.target.view(-1, self.ht, self.wd, 2).permute(0, 3, 1, 2).contiguous()
             weight = self.weight.view(-1, self.ht, self.wd, 2).permute(0, 3, 1, 2).contiguous()
             lm, ep = (1e-4, 1e-1) if ba_type == "loop" else (1e-5, 1e-2)
+            # (the cached chunk index also keeps the BA's index tables, as update()'s edge index does: built by the first step
+            # on this edge set -- ba_prep_kernel, 183 us at 1200 edges -- and reused by the other steps of the invocation)
+            kw = {"tables": idx.setdefault("ba_tables", {})} if (BA_TABLES and getattr(self.video, "ba_accepts_tables", False)) \
+                else {}
             self.video.ba(target, weight, damping, ii_all, jj_all, t0=t0, t1=t1,
-                          iters=iters, lm=lm, ep=ep, motion_only=motion_only, ba_type=ba_type)
+                          iters=iters, lm=lm, ep=ep, motion_only=motion_only, ba_type=ba_type, **kw)
             self.video.dirty[:t] = True
