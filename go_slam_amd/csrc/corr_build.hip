@@ -55,6 +55,18 @@ __global__ __launch_bounds__(256) void corr_prep_kernel(const _Float16* __restri
   const int p0 = blockIdx.x * 64;
   const int pp = (threadIdx.x & 31) * 2, cr = threadIdx.x >> 5;
   const bool pair_ok = ((hw & 1) == 0) && (p0 + pp + 1 < hw);
+  if ((hw & 1) == 0) {
+    // even maps (every map the tracker builds): a lane's pixel pair is inside the map or outside it as a whole, so all
+    // sixteen of its loads go out unconditionally from a clamped address and are zeroed afterwards (behind the `pair_ok`
+    // branch each load was waited for before the next was issued: sixteen dependent round trips per workgroup)
+    const int pq = min(p0 + pp, hw - 2);
+    const bool in_map = p0 + pp < hw;
+    half2v v[KDIM / 8];
+#pragma unroll
+    for (int k = 0; k < KDIM / 8; ++k) v[k] = *reinterpret_cast<const half2v*>(in + (size_t)(cr + 8 * k) * hw + pq);
+#pragma unroll
+    for (int k = 0; k < KDIM / 8; ++k) *reinterpret_cast<half2v*>(&t[cr + 8 * k][pp]) = in_map ? v[k] : half2v{0, 0};
+  } else
 #pragma unroll 4
   for (int c = cr; c < KDIM; c += 8) {
     const _Float16* src = in + (size_t)c * hw + p0 + pp;

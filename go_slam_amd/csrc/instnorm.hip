@@ -197,13 +197,24 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const _Float16* __restric
   const int c8n = c >> 3;
   const int cg = (int)(t % c8n);
   const int img = (int)(t / ((size_t)hw * c8n));
+  // every operand is requested before the first is used, behind no branch (an absent operand reads a valid address and is
+  // ignored): x, then the bias, then the statistics, then the skip tensor were up to four dependent round trips of a
+  // 4 us kernel that runs fifteen times per input frame
+  typedef float float4v __attribute__((ext_vector_type(4)));
   half8 v = reinterpret_cast<const half8*>(x)[t];
+  const half8 sk = reinterpret_cast<const half8*>(skip ? skip : x)[t];
+  const half8 bv = *reinterpret_cast<const half8*>(bias ? bias + cg * 8 : x);
+  float4v f0 = {0.f, 1.f, 0.f, 1.f}, f1 = f0, f2 = f0, f3 = f0;
+  if (final_) {                           // (a kernel argument: the branch is uniform and the four loads stay together)
+    const float4v* fp = reinterpret_cast<const float4v*>(final_ + ((size_t)img * c + cg * 8) * 2);
+    f0 = fp[0]; f1 = fp[1]; f2 = fp[2]; f3 = fp[3];
+  }
   if (bias) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (_Float16)((float)v[j] + (float)bias[cg * 8 + j]);
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)((float)v[j] + (float)bv[j]);
   }
   if (final_) {
-    const float* f = final_ + ((size_t)img * c + cg * 8) * 2;
+    const float f[16] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3], f2[0], f2[1], f2[2], f2[3], f3[0], f3[1], f3[2], f3[3]};
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (_Float16)(((float)v[j] - f[2 * j]) * f[2 * j + 1]);
   }
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(256) void norm_act_kernel(const _Float16* __restric
     for (int j = 0; j < 8; ++j) v[j] = v[j] > (_Float16)0.0f ? v[j] : (_Float16)0.0f;
   }
   if (skip) {
-    const half8 s = reinterpret_cast<const half8*>(skip)[t];
+    const half8 s = sk;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (_Float16)((float)s[j] + (float)v[j]);
   }
@@ -246,7 +257,7 @@ extern "C" int gs_norm_act(const void* x, const void* bias, const void* skip, vo
   GS_REQUIRE(channels == 32 || channels == 64 || channels == 128 || channels == 256 || !instance_norm,
              "norm_act: instance norm supports 32, 64, 128 or 256 channels (got %d)", channels);
   GS_REQUIRE(channels > 0 && channels % 8 == 0, "norm_act: channels must be a multiple of 8");
-  GS_REQUIRE((((size_t)x | (size_t)y | (size_t)skip) & 15) == 0, "norm_act: tensors must be 16-byte aligned");
+  GS_REQUIRE((((size_t)x | (size_t)y | (size_t)skip | (size_t)bias) & 15) == 0, "norm_act: tensors must be 16-byte aligned");
   if (n == 0) return GS_OK;
   hipStream_t st = (hipStream_t)stream;
   const float* fin = nullptr;
