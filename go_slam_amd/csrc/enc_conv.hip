@@ -201,19 +201,36 @@ __global__ __launch_bounds__(256) void enc_stem_kernel(EncArgs A) {
   const EncBias bias = load_bias16(A.bias, A.wpack, 0, lane), sbias = load_bias16(A.stat_bias, A.wpack, 0, lane);
   const half4* ximg = reinterpret_cast<const half4*>(A.x) + (size_t)img * A.h * A.w;
   const half4 zero4 = {0, 0, 0, 0};
+  // all 28 pixel loads and 14 weight fragments of the wave are requested before the first product, from addresses
+  // clamped into the image (taps outside it are zeroed by a select afterwards): as `inside ? load : 0` every k-step's
+  // loads were waited for before the next step's were issued -- 14 dependent round trips in a 12 us kernel
+  half4 px0[14], px1[14];
+  half8 wf[14];
 #pragma unroll
   for (int dy = 0; dy < 7; ++dy) {
     const int iy = 2 * oy + dy - 3;
-    const bool rowok = active && iy >= 0 && iy < A.h && ox < A.wo;
-    const half4* xrow = ximg + (size_t)(rowok ? iy : 0) * A.w;
+    const half4* xrow = ximg + (size_t)min(max(iy, 0), A.h - 1) * A.w;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int t0 = 4 * ks + 2 * kh;                // this half-wave's two taps of the k-step
       const int ix0 = 2 * ox + t0 - 3, ix1 = ix0 + 1;
-      const half4 p0 = (rowok && ix0 >= 0 && ix0 < A.w) ? xrow[ix0] : zero4;
-      const half4 p1 = (rowok && ix1 >= 0 && ix1 < A.w) ? xrow[ix1] : zero4;     // (tap 7: weights are zero)
+      px0[dy * 2 + ks] = xrow[min(max(ix0, 0), A.w - 1)];
+      px1[dy * 2 + ks] = xrow[min(max(ix1, 0), A.w - 1)];
+      wf[dy * 2 + ks] = A.wpack[(dy * 2 + ks) * 64 + lane];
+    }
+  }
+#pragma unroll
+  for (int dy = 0; dy < 7; ++dy) {
+    const int iy = 2 * oy + dy - 3;
+    const bool rowok = active && iy >= 0 && iy < A.h && ox < A.wo;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int t0 = 4 * ks + 2 * kh;
+      const int ix0 = 2 * ox + t0 - 3, ix1 = ix0 + 1;
+      const half4 p0 = (rowok && ix0 >= 0 && ix0 < A.w) ? px0[dy * 2 + ks] : zero4;
+      const half4 p1 = (rowok && ix1 >= 0 && ix1 < A.w) ? px1[dy * 2 + ks] : zero4;     // (tap 7: weights are zero)
       const half8 b = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.wpack[(dy * 2 + ks) * 64 + lane], b, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[dy * 2 + ks], b, acc, 0, 0, 0);
     }
   }
   if (active) store_tile(acc, tiles[wv], A, img, oy, ox0, 0, lane, red + wv * SLAB, bias, sbias);
