@@ -124,7 +124,36 @@ __global__ __launch_bounds__(256) void render_sample_wave_kernel(
     float* __restrict__ z_vals, float* __restrict__ dists, int n, int ns, int nsurf) {
   __shared__ float sa[4][64], sb[4][64], sz[4][128];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const float gt_max = gt_max_dev ? *gt_max_dev : gt_max_host;
+  float gt_max = gt_max_dev ? *gt_max_dev : gt_max_host;
+  if (!gt_max_dev && gt_depth && gt_max_host == -INFINITY) {
+    // the batch maximum (render.py:121,140: `gt_depth.max()`, NaN if any depth is NaN) taken HERE, by every workgroup for
+    // itself -- n floats from L2 -- instead of by a reduction launch in front of this one (5 of a render batch's 167 us)
+    __shared__ float smax[4];
+    __shared__ int snan[4];
+    float m = -INFINITY;
+    int isnan_ = 0;
+    for (int i0 = threadIdx.x * 4; i0 < n; i0 += 1024) {
+      float v[4];
+      if (i0 + 4 <= n) {
+        const float4 q = *reinterpret_cast<const float4*>(gt_depth + i0);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i0 + u < n ? gt_depth[i0 + u] : -INFINITY;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { m = fmaxf(m, v[u]); isnan_ |= (v[u] != v[u]) ? 1 : 0; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      m = fmaxf(m, __shfl_xor(m, o));
+      isnan_ |= __shfl_xor(isnan_, o);
+    }
+    if (lane == 0) { smax[wave] = m; snan[wave] = isnan_; }
+    __syncthreads();
+    m = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    gt_max = (snan[0] | snan[1] | snan[2] | snan[3]) ? NAN : m;
+  }
   const int r = blockIdx.x * 4 + wave;
   if (r >= n) return;
   float far_bb = INFINITY;
@@ -961,6 +990,8 @@ extern "C" int gs_render_sample(const float* rays_o, const float* rays_d, const 
   GS_REQUIRE(rays_o && rays_d && bound && t_samples && z_vals && dists, "render_sample: null pointer");
   GS_REQUIRE(n >= 0 && n_samples > 0 && n_surface >= 0, "render_sample: bad shape");
   GS_REQUIRE(n_surface == 0 || t_surface, "render_sample: t_surface required");
+  GS_REQUIRE(gt_max_dev || !gt_depth || gt_max != -INFINITY || (n_samples <= 64 && n_surface <= 64 && (((size_t)gt_depth) & 15) == 0),
+             "render_sample: the in-launch batch maximum needs n_samples, n_surface <= 64 and a 16-byte aligned gt_depth");
   if (n == 0) return GS_OK;
   GS_TIMING_PRE();
   if (n_samples <= 64 && n_surface <= 64)

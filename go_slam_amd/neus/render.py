@@ -58,9 +58,15 @@ class Renderer:
             return z, z.clone()
         if gt_depth is not None:
             gt_depth = gt_depth.reshape(-1).float().contiguous()
+            gt_max = 0.0
             if gt_max_dev is None:
-                gt_max_dev = gt_depth.max().reshape(1)  # stays on the device: the kernel reads it (the reference's
-            gt_max = 0.0                                # .max() at :121,:140 costs a host sync per batch)
+                # the batch maximum never leaves the device (the reference's .max() at :121,:140 costs a host sync per
+                # batch): taken inside the sampling launch where that is possible (-inf asks for it), by a reduction
+                # launch in front of it otherwise
+                if ns <= 64 and nsurf <= 64 and n <= 65536 and gt_depth.data_ptr() % 16 == 0:
+                    gt_max = float("-inf")
+                else:
+                    gt_max_dev = gt_depth.max().reshape(1)
         else:
             gt_max, gt_max_dev = 0.0, None
         if self.perturb > 0 and perturb_rand is None:

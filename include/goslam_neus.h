@@ -38,7 +38,9 @@ int gs_grid_meta_default(gs_grid_meta* meta_host);
  *   bound f32 [3,2] (device); t_samples f32 [n_samples] = torch.linspace(0,1,n_samples),
  *   t_surface f32 [n_surface] likewise; perturb f32 [n_samples] = the shared
  *   torch.rand(N_samples) vector (:159) or NULL; gt_max = gt_depth.max() as a host scalar, or -- when
- *   gt_max_dev != NULL -- read from that device scalar instead (no host round trip per batch);
+ *   gt_max_dev != NULL -- read from that device scalar instead (no host round trip per batch); or -- gt_max_dev == NULL
+ *   and gt_max == -INFINITY, n_samples / n_surface <= 64 -- taken over gt_depth inside the launch (NaN if any depth is
+ *   NaN, as torch.max): no reduction launch in front of this one;
  *   -> z_vals, dists f32 [n, n_samples + n_surface].                                          */
 int gs_render_sample(const float* rays_o, const float* rays_d, const float* gt_depth,
                      const float* bound, const float* t_samples, const float* t_surface,

@@ -1259,3 +1259,28 @@ def test_ray_bank_device_draw_equals_build_rays(N, dev, H, W, F, n_rays):
                                       _lib.stream_ptr(dev)), "ray_draw")
     depth10 = items[10][1].reshape(-1)
     assert torch.equal(z[:n_rays], depth10[keep[0]].expand(n_rays)) and torch.equal(z[n_rays:], depth10[keep[-1]].expand(n_rays))
+
+
+@pytest.mark.parametrize("n", [1, 5, 257, 4096, 4099])
+def test_render_sample_in_launch_batch_maximum_equals_the_reduction_launch(N, dev, n):
+    """Renderer.sample with the batch's depth maximum taken inside the sampling launch (gs_render_sample with gt_max = -inf)
+    against the same call fed `gt_depth.max()` as a device scalar (src/render.py:121,140): bit for bit, at sizes that end
+    inside a 16-byte piece and inside a 1024-thread stride, with depth-less rays, with all depths zero, and with a NaN
+    depth (torch.max propagates it: so must the launch)."""
+    o, d, gt = _rays(n, seed=11)
+    R = N.Renderer(N_samples=24, N_surface=48)
+    bound = torch.tensor([[-5.0, 5.0], [-4.0, 4.5], [-3.0, 6.0]], device=dev)
+    g = torch.Generator().manual_seed(2)
+    pr = torch.rand(24, generator=g).to(dev)
+    cases = [gt.clone(), torch.zeros(n)]
+    bad = gt.clone()
+    bad[n // 2] = float("nan")
+    cases.append(bad)
+    for k, depth in enumerate(cases):
+        depth = depth.to(dev)
+        z1, d1 = R.sample(o.to(dev), d.to(dev), bound, depth, pr)                                  # in-launch maximum
+        z2, d2 = R.sample(o.to(dev), d.to(dev), bound, depth, pr, gt_max_dev=depth.max().reshape(1))
+        if k == 2:      # a NaN maximum: the far bound and the depth-less rays' samples are NaN in both forms (the merge's
+            assert bool(z1.isnan().any()) and bool(z2.isnan().any())       # ranks are then undefined: no slot-wise claim)
+            continue
+        assert not bool(z1.isnan().any()) and torch.equal(z1, z2) and torch.equal(d1, d2)
