@@ -7,6 +7,7 @@ upsampling.
 """
 import os
 
+import numpy as np
 import torch
 
 from .corr import AltCorrBlock, CorrBlock, CorrPool
@@ -19,6 +20,23 @@ def coords_grid(ht, wd, device):
     y, x = torch.meshgrid(torch.arange(ht, device=device).float(), torch.arange(wd, device=device).float(),
                           indexing="ij")
     return torch.stack([x, y], dim=-1)
+
+
+def _segments_np(index):
+    """droid_net.build_segments on a host numpy index (the same five entries: uniq / ix int64, offsets / order int32, n).
+    The edge tables are a few hundred integers; as torch CPU operators every step of their construction costs 5-10 us of
+    dispatch -- 0.27 ms per edge index, 0.79 ms per loop-closure chunk index, all of it with the GPU idle behind the
+    device-to-host read that feeds it -- where numpy takes ~1 us."""
+    uniq, ix = np.unique(index, return_inverse=True)
+    ix = ix.reshape(-1).astype(np.int64)
+    order = np.argsort(ix, kind="stable").astype(np.int32)
+    offsets = np.zeros(uniq.size + 1, dtype=np.int32)
+    offsets[1:] = np.cumsum(np.bincount(ix, minlength=uniq.size))
+    return {"uniq": uniq.astype(np.int64), "ix": ix, "offsets": offsets, "order": order, "n": int(uniq.size)}
+
+
+def _as_tensors(d):
+    return {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
 
 
 def upload_tables(host, device):
@@ -92,7 +110,6 @@ class FactorGraph:
         and cached until an edge list is replaced or written to.  The reference recomputes these every
         update with torch.unique / min / max / boolean indexing on the GPU (src/factor_graph.py:213-240),
         each a sort or a host sync; here a steady-state update issues none."""
-        from .droid_net import build_segments
         tens = (self.ii, self.jj, self.ii_inac, self.jj_inac)
         key = tuple(x._version for x in tens) + (t0, t1, bool(use_inactive))
         c = getattr(self, "_eidx", None)
@@ -100,36 +117,40 @@ class FactorGraph:
             return c
         dev = self.device
         E, Ei = self.ii.numel(), self.ii_inac.numel()
-        host = torch.cat([self.ii, self.jj, self.ii_inac, self.jj_inac]).cpu()     # ONE device-to-host read per edge set
+        host = torch.cat([self.ii, self.jj, self.ii_inac, self.jj_inac]).cpu().numpy()     # ONE device-to-host read per edge set
         ii_c, jj_c = host[:E], host[E:2 * E]
         a0 = max(1, int(ii_c.min()) + 1) if t0 is None else t0
         a0 = max(1, a0)
         a1 = (max(int(ii_c.max()), int(jj_c.max())) + 1) if t1 is None else t1
-        seg_h = build_segments(ii_c)
+        seg_h = _segments_np(ii_c)                       # (numpy on the host copy: see _segments_np)
         c = {"key": key, "tens": tens, "t0": a0, "t1": a1, "seg": None, "sel": None, "ii_min": int(ii_c.min())}
-        up = {"seg." + k: v for k, v in seg_h.items() if torch.is_tensor(v)}       # everything below goes up in ONE copy per dtype
+        up = {"seg." + k: v for k, v in seg_h.items() if isinstance(v, np.ndarray)}   # everything below goes up in ONE copy per dtype
         ii_all = ii_c
         if use_inactive:
             iin, jin = host[2 * E:2 * E + Ei], host[2 * E + Ei:]
             m = (iin >= a0 - 3) & (jin >= a0 - 3)
-            up["sel"] = torch.nonzero(m).reshape(-1)
-            ii_all = torch.cat([iin[m], ii_c])
+            up["sel"] = np.nonzero(m)[0].astype(np.int64)
+            ii_all = np.concatenate([iin[m], ii_c])
             up["ii"] = ii_all
-            up["jj"] = torch.cat([jin[m], jj_c])
+            up["jj"] = np.concatenate([jin[m], jj_c])
         else:
             c["ii"], c["jj"] = self.ii.contiguous(), self.jj.contiguous()
-        dindex = torch.unique(torch.cat([torch.arange(a0, a1), ii_all]), sorted=True)
+        dindex = np.unique(np.concatenate([np.arange(a0, a1, dtype=np.int64), ii_all]))
         up["damping_index"] = dindex
         # row of the operator's eta output (one per unique source keyframe of the ACTIVE edges) for every damping row
-        uniq = torch.unique(ii_c, sorted=True)
-        pos = torch.searchsorted(uniq, dindex).clamp_(max=max(uniq.numel() - 1, 0))
-        inv = torch.where(uniq[pos] == dindex, pos, torch.full_like(pos, -1)) if uniq.numel() else torch.full_like(dindex, -1)
-        up["damping_inv"] = inv.to(torch.int32)
-        up = upload_tables(up, dev)
-        c["seg"] = {k: (up["seg." + k] if torch.is_tensor(v) else v) for k, v in seg_h.items()}
+        uniq = seg_h["uniq"]
+        if uniq.size:
+            pos = np.minimum(np.searchsorted(uniq, dindex), uniq.size - 1)
+            inv = np.where(uniq[pos] == dindex, pos, -1)
+        else:
+            inv = np.full(dindex.shape, -1)
+        up["damping_inv"] = inv.astype(np.int32)
+        up = upload_tables(_as_tensors(up), dev)
+        c["seg"] = {k: (up["seg." + k] if isinstance(v, np.ndarray) else v) for k, v in seg_h.items()}
         for k in ("sel", "ii", "jj", "damping_index", "damping_inv"):
             if k in up:
                 c[k] = up[k]
+        uniq = torch.from_numpy(uniq)
         c["uniq_host"] = uniq
         self._eidx = c
         return c
@@ -505,7 +526,6 @@ class FactorGraph:
         and torch.unique -- two to four host syncs per 13-keyframe chunk, src/factor_graph.py:266-299): the BA window,
         the damping rows, and per chunk the edge selection, the alt-corr pyramid indices (`rig`-strided, right view for
         stereo pairs), the source keyframes to upsample and the GraphAgg segments."""
-        from .droid_net import build_segments
         tens = (self.ii, self.jj)
         # (the chunks keep laid-out copies of video.inps rows: a torch write to that buffer -- a keyframe appended or
         # shifted by rm_keyframe -- rebuilds them; writers torch cannot see use DepthVideo.add_write_hook)
@@ -514,27 +534,29 @@ class FactorGraph:
         if c is not None and c["key"] == key and all(a is b for a, b in zip(c["tens"], tens)):
             return c
         dev = self.device
-        ii_c, jj_c = self.ii.cpu(), self.jj.cpu()
+        host = torch.stack([self.ii, self.jj]).cpu().numpy()       # ONE device-to-host read; the tables below in numpy
+        ii_c, jj_c = host[0], host[1]                               # (see _segments_np)
         a0 = max(1, int(ii_c.min()) + 1) if t0 is None else t0
         a0 = max(1, a0)
         a1 = (max(int(ii_c.max()), int(jj_c.max())) + 1) if t1 is None else t1
         chunks, up, segs = [], {}, []
         s = 13
         for i in range(int(ii_c.min()), int(ii_c.max()) + 1, s):
-            sel = torch.nonzero((ii_c >= i) & (ii_c < i + s)).reshape(-1)
-            if sel.numel() < 1:
+            sel = np.nonzero((ii_c >= i) & (ii_c < i + s))[0].astype(np.int64)
+            if sel.size < 1:
                 continue
             iis, jjs = ii_c[sel], jj_c[sel]
             n = len(segs)
             up.update({f"{n}.sel": sel, f"{n}.ii": iis, f"{n}.jj": jjs, f"{n}.corr_ii": rig * iis,
-                       f"{n}.corr_jj": rig * jjs + (iis == jjs).long(), f"{n}.uniq": torch.unique(iis, sorted=True)})
-            segs.append(build_segments(iis))
-            up.update({f"{n}.seg.{k}": v for k, v in segs[-1].items() if torch.is_tensor(v)})
-        up["damping_index"] = torch.unique(torch.cat([torch.arange(a0, a1), ii_c]), sorted=True)
+                       f"{n}.corr_jj": rig * jjs + (iis == jjs).astype(np.int64), f"{n}.uniq": np.unique(iis)})
+            segs.append(_segments_np(iis))
+            up.update({f"{n}.seg.{k}": v for k, v in segs[-1].items() if isinstance(v, np.ndarray)})
+        up["damping_index"] = np.unique(np.concatenate([np.arange(a0, a1, dtype=np.int64), ii_c]))
+        up = _as_tensors(up)
         up = upload_tables(up, dev)                     # every chunk's tables in ONE copy per dtype
         for n, seg_h in enumerate(segs):
             ck = {k: up[f"{n}.{k}"] for k in ("sel", "ii", "jj", "corr_ii", "corr_jj", "uniq")}
-            seg = {k: (up[f"{n}.seg.{k}"] if torch.is_tensor(v) else v) for k, v in seg_h.items()}
+            seg = {k: (up[f"{n}.seg.{k}"] if isinstance(v, np.ndarray) else v) for k, v in seg_h.items()}
             ck["seg_kw"] = {"seg": seg} if getattr(self.update_op, "_forward_fast", None) is not None else {}
             # (the chunk's context features are per-keyframe constants: gathered and laid out once per edge set -- the
             # index cache is rebuilt whenever an edge list or, through rm_keyframe, a keyframe slot changes -- instead of
