@@ -106,6 +106,44 @@ if "--copies" in sys.argv:                           # WHERE the host <-> device
     print(json.dumps([[k[0], k[1], round(v / n_kf, 2)] for k, v in tr.sites.most_common(60)], indent=0))
     sys.exit(0)
 
+if "--hostgaps" in sys.argv:                         # host time between consecutive library launches of a keyframe (> 60 us)
+    from collections import defaultdict
+    from go_slam_amd import _lib
+    L = _lib.lib()
+    log = []
+    real = {}
+
+    def wrap(name):
+        fn = getattr(L, name)
+        real[name] = fn
+
+        def call(*a, **k):
+            log.append((time.perf_counter(), name))
+            return fn(*a, **k)
+        call.restype, call.argtypes = fn.restype, fn.argtypes
+        return call
+    for name in list(_lib.SIGNATURES):
+        if name.startswith("gs_") and "workspace" not in name and "blocks" not in name and "timing" not in name:
+            try:
+                setattr(L, name, wrap(name))
+            except Exception:
+                pass
+    agg = defaultdict(lambda: [0, 0.0])
+    for _ in range(n_kf):
+        frame_stage()
+        torch.cuda.synchronize()
+        log.clear()
+        fe()
+        torch.cuda.synchronize()
+        for (t0, a), (t1, b) in zip(log, log[1:]):
+            if t1 - t0 > 60e-6:
+                e = agg[(a, b)]
+                e[0] += 1
+                e[1] += (t1 - t0) * 1e6
+    print(json.dumps([[k[0], k[1], round(v[0] / n_kf, 2), round(v[1] / v[0])] for k, v in
+                      sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]], indent=0))
+    sys.exit(0)
+
 if "--cprofile" in sys.argv:                         # where the HOST time of a keyframe goes (no device sync inside)
     import cProfile
     import io
